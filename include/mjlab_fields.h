@@ -1,0 +1,223 @@
+/* mjlab_fields.h -- field catalogue of the mjModel / mjData subset that crosses the C ABI.
+ *
+ * One X-macro list per (struct, element type).  The HIP library instantiates it with
+ * `real = float` and DEVICE pointers, the CPU oracle with `real = double` (or float) and
+ * HOST pointers; the Python host side discovers the struct layout at run time through
+ * mjlab_model_layout() / mjlab_data_layout() (a comma-separated list of
+ * "kind:name:ncol" items in struct order), so there is a single source of truth.
+ *
+ * Names, shapes and conventions follow mjModel / mjData (reference catalogue:
+ * typings/mujoco/_structs.pyi:113-867 (MjData), :916ff (MjModel)); the reference reads
+ * and writes them through `sim.model.<field>` / `sim.data.<field>`
+ * (reference: src/mjlab/sim/sim_data.py:174-229, src/mjlab/entity/data.py:69-351).
+ *
+ * X(name, ncol, count)  -- one row of `ncol` elements per item, `count` = size symbol.
+ */
+#ifndef MJLAB_FIELDS_H_
+#define MJLAB_FIELDS_H_
+
+/* ---- model: int32, shared by all worlds -------------------------------------- */
+#define MJLAB_MODEL_INT_FIELDS(X)                                               \
+  X(body_parentid, 1, nbody)                                                    \
+  X(body_rootid, 1, nbody)                                                      \
+  X(body_weldid, 1, nbody)                                                      \
+  X(body_jntnum, 1, nbody)                                                      \
+  X(body_jntadr, 1, nbody)                                                      \
+  X(body_dofnum, 1, nbody)                                                      \
+  X(body_dofadr, 1, nbody)                                                      \
+  X(body_depth, 1, nbody)                                                       \
+  X(body_dofmask, 2, nbody) /* lo, hi 32 bits of the ancestor-dof bitmask */     \
+  X(jnt_type, 1, njnt)                                                          \
+  X(jnt_qposadr, 1, njnt)                                                       \
+  X(jnt_dofadr, 1, njnt)                                                        \
+  X(jnt_bodyid, 1, njnt)                                                        \
+  X(jnt_limited, 1, njnt)                                                       \
+  X(dof_bodyid, 1, nv)                                                          \
+  X(dof_jntid, 1, nv)                                                           \
+  X(dof_parentid, 1, nv)                                                        \
+  X(geom_type, 1, ngeom)                                                        \
+  X(geom_bodyid, 1, ngeom)                                                      \
+  X(geom_condim, 1, ngeom)                                                      \
+  X(geom_priority, 1, ngeom)                                                    \
+  X(site_bodyid, 1, nsite)                                                      \
+  X(actuator_trnid, 2, nu)                                                      \
+  X(actuator_ctrllimited, 1, nu)                                                \
+  X(actuator_forcelimited, 1, nu)                                               \
+  X(sensor_objtype, 1, nsensor)                                                 \
+  X(sensor_objid, 1, nsensor)                                                   \
+  X(sensor_reftype, 1, nsensor)                                                 \
+  X(sensor_refid, 1, nsensor)                                                   \
+  X(sensor_intprm, 3, nsensor)                                                  \
+  X(sensor_dim, 1, nsensor)                                                     \
+  X(sensor_adr, 1, nsensor)                                                     \
+  X(pair_geom, 2, npair)
+
+/* ---- model: real; each carries a per-world stride (0 = shared, else elements) -- */
+#define MJLAB_MODEL_REAL_FIELDS(X)                                              \
+  X(qpos0, 1, nq)                                                               \
+  X(body_pos, 3, nbody)                                                         \
+  X(body_quat, 4, nbody)                                                        \
+  X(body_ipos, 3, nbody)                                                        \
+  X(body_iquat, 4, nbody)                                                       \
+  X(body_mass, 1, nbody)                                                        \
+  X(body_subtreemass, 1, nbody)                                                 \
+  X(body_inertia, 3, nbody)                                                     \
+  X(body_invweight0, 2, nbody)                                                  \
+  X(jnt_pos, 3, njnt)                                                           \
+  X(jnt_axis, 3, njnt)                                                          \
+  X(jnt_range, 2, njnt)                                                         \
+  X(jnt_margin, 1, njnt)                                                        \
+  X(jnt_stiffness, 1, njnt)                                                     \
+  X(jnt_solref, 2, njnt)                                                        \
+  X(jnt_solimp, 5, njnt)                                                        \
+  X(dof_armature, 1, nv)                                                        \
+  X(dof_damping, 1, nv)                                                         \
+  X(dof_frictionloss, 1, nv)                                                    \
+  X(dof_invweight0, 1, nv)                                                      \
+  X(geom_size, 3, ngeom)                                                        \
+  X(geom_pos, 3, ngeom)                                                         \
+  X(geom_quat, 4, ngeom)                                                        \
+  X(geom_friction, 3, ngeom)                                                    \
+  X(geom_solref, 2, ngeom)                                                      \
+  X(geom_solimp, 5, ngeom)                                                      \
+  X(geom_solmix, 1, ngeom)                                                      \
+  X(geom_margin, 1, ngeom)                                                      \
+  X(geom_gap, 1, ngeom)                                                         \
+  X(geom_rbound, 1, ngeom)                                                      \
+  X(site_pos, 3, nsite)                                                         \
+  X(site_quat, 4, nsite)                                                        \
+  X(actuator_gainprm, 10, nu)                                                   \
+  X(actuator_biasprm, 10, nu)                                                   \
+  X(actuator_ctrlrange, 2, nu)                                                  \
+  X(actuator_forcerange, 2, nu)                                                 \
+  X(actuator_gear, 6, nu)
+
+/* ---- data: real, leading dimension nworld ------------------------------------ */
+#define MJLAB_DATA_REAL_FIELDS(X)                                               \
+  X(time, 1, one)                                                               \
+  X(qpos, 1, nq)                                                                \
+  X(qvel, 1, nv)                                                                \
+  X(ctrl, 1, nu)                                                                \
+  X(qacc_warmstart, 1, nv)                                                      \
+  X(qfrc_applied, 1, nv)                                                        \
+  X(xfrc_applied, 6, nbody)                                                     \
+  X(qacc, 1, nv)                                                                \
+  X(xpos, 3, nbody)                                                             \
+  X(xquat, 4, nbody)                                                            \
+  X(xmat, 9, nbody)                                                             \
+  X(xipos, 3, nbody)                                                            \
+  X(ximat, 9, nbody)                                                            \
+  X(xanchor, 3, njnt)                                                           \
+  X(xaxis, 3, njnt)                                                             \
+  X(geom_xpos, 3, ngeom)                                                        \
+  X(geom_xmat, 9, ngeom)                                                        \
+  X(site_xpos, 3, nsite)                                                        \
+  X(site_xmat, 9, nsite)                                                        \
+  X(subtree_com, 3, nbody)                                                      \
+  X(cinert, 10, nbody)                                                          \
+  X(cdof, 6, nv)                                                                \
+  X(cvel, 6, nbody)                                                             \
+  X(cdof_dot, 6, nv)                                                            \
+  X(qM, 1, nvnv)  /* dense nv x nv joint-space inertia (row-major) */            \
+  X(qLD, 1, nvnv) /* dense lower Cholesky factor of qM */                        \
+  X(qfrc_bias, 1, nv)                                                           \
+  X(qfrc_passive, 1, nv)                                                        \
+  X(qfrc_actuator, 1, nv)                                                       \
+  X(actuator_force, 1, nu)                                                      \
+  X(qfrc_smooth, 1, nv)                                                         \
+  X(qacc_smooth, 1, nv)                                                         \
+  X(qfrc_constraint, 1, nv)                                                     \
+  X(sensordata, 1, nsensordata)                                                 \
+  X(contact_dist, 1, nconmax)                                                   \
+  X(contact_pos, 3, nconmax)                                                    \
+  X(contact_frame, 9, nconmax)                                                  \
+  X(contact_includemargin, 1, nconmax)                                          \
+  X(contact_friction, 5, nconmax)                                               \
+  X(contact_solref, 2, nconmax)                                                 \
+  X(contact_solimp, 5, nconmax)                                                 \
+  X(efc_J, 1, njmaxnv) /* row-major njmax x nv */                                \
+  X(efc_pos, 1, njmax)                                                          \
+  X(efc_margin, 1, njmax)                                                       \
+  X(efc_D, 1, njmax)                                                            \
+  X(efc_aref, 1, njmax)                                                         \
+  X(efc_force, 1, njmax)
+
+/* ---- data: int32, leading dimension nworld ------------------------------------ */
+#define MJLAB_DATA_INT_FIELDS(X)                                                \
+  X(ncon, 1, one)                                                               \
+  X(nefc, 1, one)                                                               \
+  X(solver_niter, 1, one)                                                       \
+  X(contact_dim, 1, nconmax)                                                    \
+  X(contact_geom, 2, nconmax)                                                   \
+  X(contact_efc_address, 1, nconmax)                                            \
+  X(efc_type, 1, njmax)                                                         \
+  X(efc_id, 1, njmax)
+
+/* mjtJoint, mjtGeom, mjtObj, mjtIntegrator subsets */
+enum { MJLAB_JNT_FREE = 0, MJLAB_JNT_BALL = 1, MJLAB_JNT_SLIDE = 2, MJLAB_JNT_HINGE = 3 };
+enum {
+  MJLAB_GEOM_PLANE = 0, MJLAB_GEOM_HFIELD = 1, MJLAB_GEOM_SPHERE = 2, MJLAB_GEOM_CAPSULE = 3,
+  MJLAB_GEOM_ELLIPSOID = 4, MJLAB_GEOM_CYLINDER = 5, MJLAB_GEOM_BOX = 6, MJLAB_GEOM_MESH = 7
+};
+enum { MJLAB_OBJ_BODY = 1, MJLAB_OBJ_XBODY = 2, MJLAB_OBJ_GEOM = 5, MJLAB_OBJ_SITE = 6 };
+enum { MJLAB_INT_EULER = 0, MJLAB_INT_IMPLICITFAST = 3 };
+enum { MJLAB_EFC_LIMIT = 3, MJLAB_EFC_CONTACT_FRICTIONLESS = 4, MJLAB_EFC_CONTACT_PYRAMIDAL = 5 };
+
+/* Sizes shared by model and data (host struct, passed by pointer). */
+typedef struct mjlab_sizes {
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nsensor, nsensordata, npair;
+  int nworld;  /* number of worlds (environments) */
+  int nconmax; /* contact capacity PER WORLD */
+  int njmax;   /* constraint-row capacity PER WORLD */
+} mjlab_sizes_t;
+
+/* mjOption subset (always double on the host side). */
+typedef struct mjlab_option {
+  double timestep;
+  double gravity[3];
+  double impratio;
+  double tolerance;
+  double ls_tolerance;
+  double meaninertia; /* mjModel.stat.meaninertia */
+  int iterations;
+  int ls_iterations;
+  int integrator;
+  int cone;
+} mjlab_option_t;
+
+#define MJLAB_DECL_INT_(name, ncol, count) const int* name;
+#define MJLAB_DECL_REAL_(name, ncol, count) \
+  const MJLAB_REAL* name;                   \
+  int name##_ws; /* per-world stride in elements, 0 = shared */
+#define MJLAB_DECL_DREAL_(name, ncol, count) MJLAB_REAL* name;
+#define MJLAB_DECL_DINT_(name, ncol, count) int* name;
+
+/* The two structs are declared by including this header after defining MJLAB_REAL and
+ * the struct names:
+ *   #define MJLAB_REAL float
+ *   #define MJLAB_MODEL_T mjlab_model_t
+ *   #define MJLAB_DATA_T  mjlab_data_t
+ */
+#ifdef MJLAB_REAL
+typedef struct MJLAB_MODEL_T {
+  mjlab_sizes_t size;
+  mjlab_option_t opt;
+  MJLAB_MODEL_INT_FIELDS(MJLAB_DECL_INT_)
+  MJLAB_MODEL_REAL_FIELDS(MJLAB_DECL_REAL_)
+} MJLAB_MODEL_T;
+
+typedef struct MJLAB_DATA_T {
+  MJLAB_DATA_REAL_FIELDS(MJLAB_DECL_DREAL_)
+  MJLAB_DATA_INT_FIELDS(MJLAB_DECL_DINT_)
+} MJLAB_DATA_T;
+#endif
+
+#define MJLAB_STR_(x) #x
+#define MJLAB_LAYOUT_INT_(name, ncol, count) "i:" #name ":" MJLAB_STR_(ncol) ":" #count ","
+#define MJLAB_LAYOUT_REAL_(name, ncol, count) "r:" #name ":" MJLAB_STR_(ncol) ":" #count ","
+#define MJLAB_MODEL_LAYOUT_STRING \
+  MJLAB_MODEL_INT_FIELDS(MJLAB_LAYOUT_INT_) MJLAB_MODEL_REAL_FIELDS(MJLAB_LAYOUT_REAL_)
+#define MJLAB_DATA_LAYOUT_STRING \
+  MJLAB_DATA_REAL_FIELDS(MJLAB_LAYOUT_REAL_) MJLAB_DATA_INT_FIELDS(MJLAB_LAYOUT_INT_)
+
+#endif /* MJLAB_FIELDS_H_ */

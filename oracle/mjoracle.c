@@ -1,0 +1,1117 @@
+/* mjoracle.c -- CPU restatement of the physics step.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product path (mjlab_amd/csrc) never links or calls it.
+ *
+ * PARITY UNPINNED: the arithmetic of the reference's hot path lives in third-party
+ * packages that are absent from /root/reference and from this image
+ * (mujoco_warp @ 486642c3fa262a989b482e0e506716d5793d61a9, mujoco 3.3.7.dev811775910;
+ * reference pyproject.toml:94-96, call sites src/mjlab/sim/sim.py:136,139,187,195).
+ * This file restates MuJoCo's published forward-dynamics pipeline (mj_step:
+ * engine_forward.c / engine_core_smooth.c / engine_core_constraint.c /
+ * engine_collision_primitive.c / engine_solver.c of the mujoco 3.3 line) from its
+ * documentation and public algorithm descriptions; it is validated against analytic
+ * cases and physical invariants (tests/test_oracle_physics.py), not against golden
+ * vectors of the reference, which has none.
+ *
+ * Stage names follow the reference's stub docstrings
+ * (typings/mujoco/_functions.pyi: mj_kinematics :803, mj_comPos :358, mj_crb :399,
+ * mj_factorM :449, mj_collision :353, mj_makeConstraint :835, mj_comVel :363,
+ * mj_passive :957, mj_rne :1070, mj_fwdActuation :493, mj_fwdAcceleration :488,
+ * mj_fwdConstraint :498, mj_sensorAcc :1104, mj_implicit :555, mj_Euler :919).
+ *
+ * Build: gcc -O2 -shared -fPIC [-DMJO_FLOAT] (see oracle/Makefile).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef MJO_FLOAT
+#define MJLAB_REAL float
+#else
+#define MJLAB_REAL double
+#endif
+#define MJLAB_MODEL_T mjo_model_t
+#define MJLAB_DATA_T mjo_data_t
+#include "../include/mjlab_fields.h"
+
+typedef MJLAB_REAL real;
+#define MINVAL ((real)1e-15)
+#define MINIMP ((real)0.0001)
+#define MAXIMP ((real)0.9999)
+
+#define MF(name, w) (m->name + (size_t)(w) * (size_t)m->name##_ws)
+
+const char* mjo_model_layout(void) { return MJLAB_MODEL_LAYOUT_STRING; }
+const char* mjo_data_layout(void) { return MJLAB_DATA_LAYOUT_STRING; }
+int mjo_sizeof_real(void) { return (int)sizeof(real); }
+int mjo_sizeof_model(void) { return (int)sizeof(mjo_model_t); }
+int mjo_sizeof_data(void) { return (int)sizeof(mjo_data_t); }
+
+/* ------------------------------------------------------------------ small math */
+static inline real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(real* r, const real* a, const real* b) {
+  real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline real normalize3(real* v) {
+  real n = sqrt(dot3(v, v));
+  if (n < MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; return 0; }
+  v[0] /= n; v[1] /= n; v[2] /= n;
+  return n;
+}
+static inline void normalize4(real* q) {
+  real n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+static inline void mul_quat(real* r, const real* a, const real* b) {
+  real w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  real x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  real y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  real z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+static inline void quat2mat(real* R, const real* q) {
+  real q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  real q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
+  real q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+  R[0] = q00 + q11 - q22 - q33; R[4] = q00 - q11 + q22 - q33; R[8] = q00 - q11 - q22 + q33;
+  R[1] = 2 * (q12 - q03); R[2] = 2 * (q13 + q02);
+  R[3] = 2 * (q12 + q03); R[5] = 2 * (q23 - q01);
+  R[6] = 2 * (q13 - q02); R[7] = 2 * (q23 + q01);
+}
+static inline void rot_vec_quat(real* r, const real* v, const real* q) {
+  real R[9];
+  quat2mat(R, q);
+  real x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  real y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  real z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void mul_mat_vec3(real* r, const real* R, const real* v) {
+  real x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  real y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  real z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void axis_angle2quat(real* q, const real* axis, real angle) {
+  real s = sin(angle * (real)0.5);
+  q[0] = cos(angle * (real)0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+static inline real clipr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* spatial helpers; motion vectors are [angular(3), linear(3)] about the com-frame origin */
+static void mul_inert_vec(real* r, const real* i, const real* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+static void cross_motion(real* r, const real* vel, const real* v) {
+  r[0] = -vel[2] * v[1] + vel[1] * v[2];
+  r[1] = vel[2] * v[0] - vel[0] * v[2];
+  r[2] = -vel[1] * v[0] + vel[0] * v[1];
+  r[3] = -vel[2] * v[4] + vel[1] * v[5] - vel[5] * v[1] + vel[4] * v[2];
+  r[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
+  r[5] = -vel[1] * v[3] + vel[0] * v[4] - vel[4] * v[0] + vel[3] * v[1];
+}
+static void cross_force(real* r, const real* vel, const real* f) {
+  r[0] = -vel[2] * f[1] + vel[1] * f[2] - vel[5] * f[4] + vel[4] * f[5];
+  r[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
+  r[2] = -vel[1] * f[0] + vel[0] * f[1] - vel[4] * f[3] + vel[3] * f[4];
+  r[3] = -vel[2] * f[4] + vel[1] * f[5];
+  r[4] = vel[2] * f[3] - vel[0] * f[5];
+  r[5] = -vel[1] * f[3] + vel[0] * f[4];
+}
+
+/* per-world views */
+#define D(name, n) (d->name + (size_t)w * (size_t)(n))
+
+/* ------------------------------------------------------------------ position stage */
+static void local2global(real* xp, real* xm, const real* bpos, const real* bquat, const real* bmat,
+                         const real* pos, const real* quat) {
+  real q[4], t[3];
+  mul_mat_vec3(t, bmat, pos);
+  xp[0] = bpos[0] + t[0]; xp[1] = bpos[1] + t[1]; xp[2] = bpos[2] + t[2];
+  mul_quat(q, bquat, quat);
+  quat2mat(xm, q);
+}
+
+static void kinematics(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  real* qpos = D(qpos, s->nq);
+  real *xpos = D(xpos, 3 * s->nbody), *xquat = D(xquat, 4 * s->nbody), *xmat = D(xmat, 9 * s->nbody);
+  real *xipos = D(xipos, 3 * s->nbody), *ximat = D(ximat, 9 * s->nbody);
+  real *xanchor = D(xanchor, 3 * s->njnt), *xaxis = D(xaxis, 3 * s->njnt);
+  const real* qpos0 = MF(qpos0, w);
+  /* world */
+  xpos[0] = xpos[1] = xpos[2] = 0;
+  xquat[0] = 1; xquat[1] = xquat[2] = xquat[3] = 0;
+  quat2mat(xmat, xquat);
+  for (int i = 1; i < s->nbody; i++) {
+    int pid = m->body_parentid[i], ja = m->body_jntadr[i], jn = m->body_jntnum[i];
+    real pos[3], quat[4];
+    if (jn == 1 && m->jnt_type[ja] == MJLAB_JNT_FREE) {
+      int qa = m->jnt_qposadr[ja];
+      memcpy(pos, qpos + qa, 3 * sizeof(real));
+      memcpy(quat, qpos + qa + 3, 4 * sizeof(real));
+      normalize4(quat);
+      memcpy(xanchor + 3 * ja, pos, 3 * sizeof(real));
+      memcpy(xaxis + 3 * ja, MF(jnt_axis, w) + 3 * ja, 3 * sizeof(real));
+    } else {
+      real t[3];
+      mul_mat_vec3(t, xmat + 9 * pid, MF(body_pos, w) + 3 * i);
+      pos[0] = xpos[3 * pid] + t[0]; pos[1] = xpos[3 * pid + 1] + t[1]; pos[2] = xpos[3 * pid + 2] + t[2];
+      mul_quat(quat, xquat + 4 * pid, MF(body_quat, w) + 4 * i);
+      for (int j = ja; j < ja + jn; j++) {
+        int qa = m->jnt_qposadr[j];
+        const real *jaxis = MF(jnt_axis, w) + 3 * j, *jpos = MF(jnt_pos, w) + 3 * j;
+        rot_vec_quat(xaxis + 3 * j, jaxis, quat);
+        rot_vec_quat(t, jpos, quat);
+        xanchor[3 * j] = t[0] + pos[0]; xanchor[3 * j + 1] = t[1] + pos[1]; xanchor[3 * j + 2] = t[2] + pos[2];
+        if (m->jnt_type[j] == MJLAB_JNT_SLIDE) {
+          real dq = qpos[qa] - qpos0[qa];
+          pos[0] += xaxis[3 * j] * dq; pos[1] += xaxis[3 * j + 1] * dq; pos[2] += xaxis[3 * j + 2] * dq;
+        } else { /* hinge */
+          real ql[4], qn[4];
+          axis_angle2quat(ql, jaxis, qpos[qa] - qpos0[qa]);
+          mul_quat(qn, quat, ql);
+          memcpy(quat, qn, sizeof(qn));
+          rot_vec_quat(t, jpos, quat);
+          pos[0] = xanchor[3 * j] - t[0]; pos[1] = xanchor[3 * j + 1] - t[1]; pos[2] = xanchor[3 * j + 2] - t[2];
+        }
+      }
+    }
+    normalize4(quat);
+    memcpy(xpos + 3 * i, pos, sizeof(pos));
+    memcpy(xquat + 4 * i, quat, sizeof(quat));
+    quat2mat(xmat + 9 * i, quat);
+  }
+  for (int i = 0; i < s->nbody; i++)
+    local2global(xipos + 3 * i, ximat + 9 * i, xpos + 3 * i, xquat + 4 * i, xmat + 9 * i,
+                 MF(body_ipos, w) + 3 * i, MF(body_iquat, w) + 4 * i);
+  real *gx = D(geom_xpos, 3 * s->ngeom), *gm = D(geom_xmat, 9 * s->ngeom);
+  for (int g = 0; g < s->ngeom; g++) {
+    int b = m->geom_bodyid[g];
+    local2global(gx + 3 * g, gm + 9 * g, xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, MF(geom_pos, w) + 3 * g,
+                 MF(geom_quat, w) + 4 * g);
+  }
+  real *sx = D(site_xpos, 3 * s->nsite), *sm = D(site_xmat, 9 * s->nsite);
+  for (int g = 0; g < s->nsite; g++) {
+    int b = m->site_bodyid[g];
+    local2global(sx + 3 * g, sm + 9 * g, xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, MF(site_pos, w) + 3 * g,
+                 MF(site_quat, w) + 4 * g);
+  }
+}
+
+static void com_pos(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int nb = s->nbody;
+  real *xipos = D(xipos, 3 * nb), *ximat = D(ximat, 9 * nb), *sub = D(subtree_com, 3 * nb);
+  real *cinert = D(cinert, 10 * nb), *cdof = D(cdof, 6 * s->nv);
+  real *xanchor = D(xanchor, 3 * s->njnt), *xaxis = D(xaxis, 3 * s->njnt), *xmat = D(xmat, 9 * nb);
+  const real *mass = MF(body_mass, w), *stm = MF(body_subtreemass, w), *inertia = MF(body_inertia, w);
+  for (int i = 0; i < nb; i++)
+    for (int k = 0; k < 3; k++) sub[3 * i + k] = mass[i] * xipos[3 * i + k];
+  for (int i = nb - 1; i > 0; i--)
+    for (int k = 0; k < 3; k++) sub[3 * m->body_parentid[i] + k] += sub[3 * i + k];
+  for (int i = 0; i < nb; i++) {
+    if (stm[i] < MINVAL) memcpy(sub + 3 * i, xipos + 3 * i, 3 * sizeof(real));
+    else for (int k = 0; k < 3; k++) sub[3 * i + k] /= stm[i];
+  }
+  memset(cinert, 0, 10 * sizeof(real));
+  for (int i = 1; i < nb; i++) {
+    const real *mat = ximat + 9 * i, *in = inertia + 3 * i;
+    real dif[3], tmp[9], *res = cinert + 10 * i, ms = mass[i];
+    for (int k = 0; k < 3; k++) dif[k] = xipos[3 * i + k] - sub[3 * m->body_rootid[i] + k];
+    tmp[0] = mat[0] * in[0]; tmp[1] = mat[3] * in[0]; tmp[2] = mat[6] * in[0];
+    tmp[3] = mat[1] * in[1]; tmp[4] = mat[4] * in[1]; tmp[5] = mat[7] * in[1];
+    tmp[6] = mat[2] * in[2]; tmp[7] = mat[5] * in[2]; tmp[8] = mat[8] * in[2];
+    res[0] = mat[0] * tmp[0] + mat[1] * tmp[3] + mat[2] * tmp[6];
+    res[1] = mat[3] * tmp[1] + mat[4] * tmp[4] + mat[5] * tmp[7];
+    res[2] = mat[6] * tmp[2] + mat[7] * tmp[5] + mat[8] * tmp[8];
+    res[3] = mat[0] * tmp[1] + mat[1] * tmp[4] + mat[2] * tmp[7];
+    res[4] = mat[0] * tmp[2] + mat[1] * tmp[5] + mat[2] * tmp[8];
+    res[5] = mat[3] * tmp[2] + mat[4] * tmp[5] + mat[5] * tmp[8];
+    res[0] += ms * (dif[1] * dif[1] + dif[2] * dif[2]);
+    res[1] += ms * (dif[0] * dif[0] + dif[2] * dif[2]);
+    res[2] += ms * (dif[0] * dif[0] + dif[1] * dif[1]);
+    res[3] -= ms * dif[0] * dif[1];
+    res[4] -= ms * dif[0] * dif[2];
+    res[5] -= ms * dif[1] * dif[2];
+    res[6] = ms * dif[0]; res[7] = ms * dif[1]; res[8] = ms * dif[2];
+    res[9] = ms;
+  }
+  for (int j = 0; j < s->njnt; j++) {
+    int b = m->jnt_bodyid[j], da = m->jnt_dofadr[j];
+    real off[3];
+    for (int k = 0; k < 3; k++) off[k] = sub[3 * m->body_rootid[b] + k] - xanchor[3 * j + k];
+    switch (m->jnt_type[j]) {
+      case MJLAB_JNT_FREE:
+        memset(cdof + 6 * da, 0, 18 * sizeof(real));
+        for (int k = 0; k < 3; k++) cdof[6 * (da + k) + 3 + k] = 1;
+        for (int k = 0; k < 3; k++) {
+          real ax[3] = {xmat[9 * b + k], xmat[9 * b + 3 + k], xmat[9 * b + 6 + k]};
+          real* c = cdof + 6 * (da + 3 + k);
+          memcpy(c, ax, sizeof(ax));
+          cross3(c + 3, ax, off);
+        }
+        break;
+      case MJLAB_JNT_SLIDE:
+        cdof[6 * da] = cdof[6 * da + 1] = cdof[6 * da + 2] = 0;
+        memcpy(cdof + 6 * da + 3, xaxis + 3 * j, 3 * sizeof(real));
+        break;
+      default: /* hinge */
+        memcpy(cdof + 6 * da, xaxis + 3 * j, 3 * sizeof(real));
+        cross3(cdof + 6 * da + 3, xaxis + 3 * j, off);
+    }
+  }
+}
+
+/* dense Cholesky A = L L^T in place (lower), returns rank deficiency count */
+static int chol_factor(real* A, int n) {
+  int bad = 0;
+  for (int j = 0; j < n; j++) {
+    real t = A[j * n + j];
+    for (int k = 0; k < j; k++) t -= A[j * n + k] * A[j * n + k];
+    if (t < MINVAL) { t = MINVAL; bad++; }
+    t = sqrt(t);
+    A[j * n + j] = t;
+    for (int i = j + 1; i < n; i++) {
+      real v = A[i * n + j];
+      for (int k = 0; k < j; k++) v -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = v / t;
+    }
+  }
+  return bad;
+}
+static void chol_solve(const real* L, int n, real* x) {
+  for (int i = 0; i < n; i++) {
+    real t = x[i];
+    for (int k = 0; k < i; k++) t -= L[i * n + k] * x[k];
+    x[i] = t / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    real t = x[i];
+    for (int k = i + 1; k < n; k++) t -= L[k * n + i] * x[k];
+    x[i] = t / L[i * n + i];
+  }
+}
+
+static void crb_factor(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int nb = s->nbody, nv = s->nv;
+  real *cinert = D(cinert, 10 * nb), *cdof = D(cdof, 6 * nv), *M = D(qM, nv * nv), *L = D(qLD, nv * nv);
+  real* crb = (real*)malloc(sizeof(real) * 10 * nb);
+  memcpy(crb, cinert, sizeof(real) * 10 * nb);
+  for (int i = nb - 1; i > 0; i--) {
+    int p = m->body_parentid[i];
+    if (p > 0) for (int k = 0; k < 10; k++) crb[10 * p + k] += crb[10 * i + k];
+  }
+  memset(M, 0, sizeof(real) * nv * nv);
+  const real* arm = MF(dof_armature, w);
+  for (int i = 0; i < nv; i++) {
+    real buf[6];
+    mul_inert_vec(buf, crb + 10 * m->dof_bodyid[i], cdof + 6 * i);
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+      real v = 0;
+      for (int k = 0; k < 6; k++) v += cdof[6 * j + k] * buf[k];
+      M[i * nv + j] = v;
+      M[j * nv + i] = v;
+    }
+    M[i * nv + i] += arm[i];
+  }
+  free(crb);
+  memcpy(L, M, sizeof(real) * nv * nv);
+  chol_factor(L, nv);
+  for (int i = 0; i < nv; i++) for (int j = i + 1; j < nv; j++) L[i * nv + j] = 0;
+}
+
+/* ------------------------------------------------------------------ collision */
+typedef struct { real dist, pos[3], frame[9]; } rawcon_t;
+
+static void make_frame(real* f) {
+  /* f[0:3] = normal (unit). Build tangents as mju_makeFrame does. */
+  real y[3] = {f[3], f[4], f[5]};
+  if (sqrt(dot3(y, y)) < (real)0.5) {
+    y[0] = y[1] = y[2] = 0;
+    if (f[1] < (real)0.5 && f[1] > (real)-0.5) y[1] = 1; else y[2] = 1;
+  }
+  real t = dot3(f, y);
+  y[0] -= t * f[0]; y[1] -= t * f[1]; y[2] -= t * f[2];
+  normalize3(y);
+  f[3] = y[0]; f[4] = y[1]; f[5] = y[2];
+  cross3(f + 6, f, y);
+}
+
+static int plane_sphere(rawcon_t* c, real margin, const real* ppos, const real* pmat, const real* spos, real r) {
+  real n[3] = {pmat[2], pmat[5], pmat[8]}, dif[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
+  real cdist = dot3(dif, n);
+  if (cdist > margin + r) return 0;
+  c->dist = cdist - r;
+  for (int k = 0; k < 3; k++) c->pos[k] = spos[k] + n[k] * (-c->dist * (real)0.5 - r);
+  memcpy(c->frame, n, sizeof(n));
+  c->frame[3] = c->frame[4] = c->frame[5] = 0;
+  return 1;
+}
+static int sphere_sphere(rawcon_t* c, real margin, const real* p1, real r1, const real* p2, real r2) {
+  real dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  real cd2 = dot3(dif, dif), mn = margin + r1 + r2;
+  if (cd2 > mn * mn) return 0;
+  real len = sqrt(cd2);
+  if (len < MINVAL) { dif[0] = 1; dif[1] = dif[2] = 0; }
+  else { dif[0] /= len; dif[1] /= len; dif[2] /= len; }
+  c->dist = len - r1 - r2;
+  for (int k = 0; k < 3; k++) c->pos[k] = p1[k] + dif[k] * (r1 + c->dist * (real)0.5);
+  memcpy(c->frame, dif, sizeof(dif));
+  c->frame[3] = c->frame[4] = c->frame[5] = 0;
+  return 1;
+}
+static int plane_capsule(rawcon_t* c, real margin, const real* ppos, const real* pmat, const real* cpos,
+                         const real* cmat, const real* size) {
+  real axis[3] = {cmat[2], cmat[5], cmat[8]}, p[3];
+  int n = 0;
+  for (int k = 0; k < 3; k++) p[k] = cpos[k] + axis[k] * size[1];
+  int n1 = plane_sphere(c + n, margin, ppos, pmat, p, size[0]);
+  if (n1) { memcpy(c[n].frame + 3, axis, sizeof(axis)); n++; }
+  for (int k = 0; k < 3; k++) p[k] = cpos[k] - axis[k] * size[1];
+  int n2 = plane_sphere(c + n, margin, ppos, pmat, p, size[0]);
+  if (n2) { memcpy(c[n].frame + 3, axis, sizeof(axis)); n++; }
+  return n;
+}
+static int plane_box(rawcon_t* c, real margin, const real* ppos, const real* pmat, const real* bpos, const real* bmat,
+                     const real* size) {
+  real n[3] = {pmat[2], pmat[5], pmat[8]}, dif[3] = {bpos[0] - ppos[0], bpos[1] - ppos[1], bpos[2] - ppos[2]};
+  real dist = dot3(dif, n);
+  int cnt = 0;
+  for (int i = 0; i < 8; i++) {
+    real vec[3] = {(i & 1) ? size[0] : -size[0], (i & 2) ? size[1] : -size[1], (i & 4) ? size[2] : -size[2]}, corner[3];
+    mul_mat_vec3(corner, bmat, vec);
+    real ldist = dot3(n, corner);
+    if (dist + ldist > margin || ldist > 0) continue;
+    c[cnt].dist = dist + ldist;
+    for (int k = 0; k < 3; k++) c[cnt].pos[k] = corner[k] + bpos[k] + n[k] * (-c[cnt].dist * (real)0.5);
+    memcpy(c[cnt].frame, n, sizeof(n));
+    c[cnt].frame[3] = c[cnt].frame[4] = c[cnt].frame[5] = 0;
+    if (++cnt >= 4) return 4;
+  }
+  return cnt;
+}
+static int sphere_capsule(rawcon_t* c, real margin, const real* spos, real r, const real* cpos, const real* cmat,
+                          const real* size) {
+  real axis[3] = {cmat[2], cmat[5], cmat[8]}, vec[3] = {spos[0] - cpos[0], spos[1] - cpos[1], spos[2] - cpos[2]};
+  real x = clipr(dot3(axis, vec), -size[1], size[1]);
+  for (int k = 0; k < 3; k++) vec[k] = cpos[k] + axis[k] * x;
+  return sphere_sphere(c, margin, spos, r, vec, size[0]);
+}
+static int capsule_capsule(rawcon_t* c, real margin, const real* pos1, const real* mat1, const real* size1,
+                           const real* pos2, const real* mat2, const real* size2) {
+  real axis1[3] = {mat1[2], mat1[5], mat1[8]}, axis2[3] = {mat2[2], mat2[5], mat2[8]};
+  real dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  real ma = dot3(axis1, axis1), mb = -dot3(axis1, axis2), mc = dot3(axis2, axis2);
+  real u = -dot3(axis1, dif), v = dot3(axis2, dif), det = ma * mc - mb * mb;
+  real vec1[3], vec2[3];
+  if (fabs(det) >= MINVAL) {
+    real x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > size1[1]) { x1 = size1[1]; x2 = (v - mb * size1[1]) / mc; }
+    else if (x1 < -size1[1]) { x1 = -size1[1]; x2 = (v + mb * size1[1]) / mc; }
+    if (x2 > size2[1]) { x2 = size2[1]; x1 = clipr((u - mb * size2[1]) / ma, -size1[1], size1[1]); }
+    else if (x2 < -size2[1]) { x2 = -size2[1]; x1 = clipr((u + mb * size2[1]) / ma, -size1[1], size1[1]); }
+    for (int k = 0; k < 3; k++) { vec1[k] = pos1[k] + axis1[k] * x1; vec2[k] = pos2[k] + axis2[k] * x2; }
+    return sphere_sphere(c, margin, vec1, size1[0], vec2, size2[0]);
+  }
+  /* parallel axes: test the segment ends, up to two contacts */
+  int n = 0;
+  real x2;
+  for (int k = 0; k < 3; k++) vec1[k] = pos1[k] + axis1[k] * size1[1];
+  x2 = clipr((v - mb * size1[1]) / mc, -size2[1], size2[1]);
+  for (int k = 0; k < 3; k++) vec2[k] = pos2[k] + axis2[k] * x2;
+  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  for (int k = 0; k < 3; k++) vec1[k] = pos1[k] - axis1[k] * size1[1];
+  x2 = clipr((v + mb * size1[1]) / mc, -size2[1], size2[1]);
+  for (int k = 0; k < 3; k++) vec2[k] = pos2[k] + axis2[k] * x2;
+  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  if (n == 2) return n;
+  real x1;
+  for (int k = 0; k < 3; k++) vec2[k] = pos2[k] + axis2[k] * size2[1];
+  x1 = clipr((u - mb * size2[1]) / ma, -size1[1], size1[1]);
+  for (int k = 0; k < 3; k++) vec1[k] = pos1[k] + axis1[k] * x1;
+  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  if (n == 2) return n;
+  for (int k = 0; k < 3; k++) vec2[k] = pos2[k] - axis2[k] * size2[1];
+  x1 = clipr((u + mb * size2[1]) / ma, -size1[1], size1[1]);
+  for (int k = 0; k < 3; k++) vec1[k] = pos1[k] + axis1[k] * x1;
+  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  return n;
+}
+
+static void collision(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int ncm = s->nconmax;
+  real *gx = D(geom_xpos, 3 * s->ngeom), *gm = D(geom_xmat, 9 * s->ngeom);
+  const real *gsize = MF(geom_size, w), *rbound = MF(geom_rbound, w), *gmargin = MF(geom_margin, w), *ggap = MF(geom_gap, w);
+  const real *gfri = MF(geom_friction, w), *gsolref = MF(geom_solref, w), *gsolimp = MF(geom_solimp, w), *gsolmix = MF(geom_solmix, w);
+  int ncon = 0;
+  for (int p = 0; p < s->npair; p++) {
+    int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
+    int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    real margin = gmargin[g1] > gmargin[g2] ? gmargin[g1] : gmargin[g2];
+    real gap = ggap[g1] > ggap[g2] ? ggap[g1] : ggap[g2];
+    const real *p1 = gx + 3 * g1, *p2 = gx + 3 * g2, *m1 = gm + 9 * g1, *m2 = gm + 9 * g2;
+    const real *s1 = gsize + 3 * g1, *s2 = gsize + 3 * g2;
+    /* bounding-sphere / plane rejection */
+    if (t1 == MJLAB_GEOM_PLANE) {
+      real n[3] = {m1[2], m1[5], m1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+      if (dot3(dif, n) > margin + rbound[g2]) continue;
+    } else {
+      real dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, bound = margin + rbound[g1] + rbound[g2];
+      if (dot3(dif, dif) > bound * bound) continue;
+    }
+    rawcon_t rc[4];
+    int n = 0;
+    if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_SPHERE) n = plane_sphere(rc, margin, p1, m1, p2, s2[0]);
+    else if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_CAPSULE) n = plane_capsule(rc, margin, p1, m1, p2, m2, s2);
+    else if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_BOX) n = plane_box(rc, margin, p1, m1, p2, m2, s2);
+    else if (t1 == MJLAB_GEOM_SPHERE && t2 == MJLAB_GEOM_SPHERE) n = sphere_sphere(rc, margin, p1, s1[0], p2, s2[0]);
+    else if (t1 == MJLAB_GEOM_SPHERE && t2 == MJLAB_GEOM_CAPSULE) n = sphere_capsule(rc, margin, p1, s1[0], p2, m2, s2);
+    else if (t1 == MJLAB_GEOM_CAPSULE && t2 == MJLAB_GEOM_CAPSULE) n = capsule_capsule(rc, margin, p1, m1, s1, p2, m2, s2);
+    else continue; /* unsupported pair types never reach here: the compiler rejects them */
+    if (!n) continue;
+    /* contact parameters (mj_contactParam) */
+    int condim;
+    real fri[3], solref[2], solimp[5];
+    int pr1 = m->geom_priority[g1], pr2 = m->geom_priority[g2];
+    if (pr1 != pr2) {
+      int gi = pr1 > pr2 ? g1 : g2;
+      condim = m->geom_condim[gi];
+      memcpy(fri, gfri + 3 * gi, sizeof(fri));
+      memcpy(solref, gsolref + 2 * gi, sizeof(solref));
+      memcpy(solimp, gsolimp + 5 * gi, sizeof(solimp));
+    } else {
+      condim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+      for (int k = 0; k < 3; k++) fri[k] = gfri[3 * g1 + k] > gfri[3 * g2 + k] ? gfri[3 * g1 + k] : gfri[3 * g2 + k];
+      real mix;
+      real sm1 = gsolmix[g1], sm2 = gsolmix[g2];
+      if (sm1 >= MINVAL && sm2 >= MINVAL) mix = sm1 / (sm1 + sm2);
+      else if (sm1 < MINVAL && sm2 < MINVAL) mix = (real)0.5;
+      else if (sm1 < MINVAL) mix = 0;
+      else mix = 1;
+      if (gsolref[2 * g1] > 0 && gsolref[2 * g2] > 0)
+        for (int k = 0; k < 2; k++) solref[k] = mix * gsolref[2 * g1 + k] + (1 - mix) * gsolref[2 * g2 + k];
+      else
+        for (int k = 0; k < 2; k++) solref[k] = gsolref[2 * g1 + k] < gsolref[2 * g2 + k] ? gsolref[2 * g1 + k] : gsolref[2 * g2 + k];
+      for (int k = 0; k < 5; k++) solimp[k] = mix * gsolimp[5 * g1 + k] + (1 - mix) * gsolimp[5 * g2 + k];
+    }
+    for (int i = 0; i < n && ncon < ncm; i++) {
+      make_frame(rc[i].frame);
+      D(contact_dist, ncm)[ncon] = rc[i].dist;
+      memcpy(D(contact_pos, 3 * ncm) + 3 * ncon, rc[i].pos, 3 * sizeof(real));
+      memcpy(D(contact_frame, 9 * ncm) + 9 * ncon, rc[i].frame, 9 * sizeof(real));
+      D(contact_includemargin, ncm)[ncon] = margin - gap;
+      real* f5 = D(contact_friction, 5 * ncm) + 5 * ncon;
+      f5[0] = f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = f5[4] = fri[2];
+      memcpy(D(contact_solref, 2 * ncm) + 2 * ncon, solref, sizeof(solref));
+      memcpy(D(contact_solimp, 5 * ncm) + 5 * ncon, solimp, sizeof(solimp));
+      (d->contact_dim + (size_t)w * ncm)[ncon] = condim;
+      (d->contact_geom + (size_t)w * 2 * ncm)[2 * ncon] = g1;
+      (d->contact_geom + (size_t)w * 2 * ncm)[2 * ncon + 1] = g2;
+      (d->contact_efc_address + (size_t)w * ncm)[ncon] = -1;
+      ncon++;
+    }
+  }
+  d->ncon[w] = ncon;
+}
+
+/* ------------------------------------------------------------------ constraints */
+static real impedance(const real* solimp, real pos, real margin) {
+  real dmin = clipr(solimp[0], MINIMP, MAXIMP), dmax = clipr(solimp[1], MINIMP, MAXIMP);
+  real width = solimp[2] > MINVAL ? solimp[2] : MINVAL;
+  real mid = clipr(solimp[3], MINIMP, MAXIMP), power = solimp[4] > 1 ? solimp[4] : 1;
+  real x = (pos - margin) / width;
+  if (x < 0) x = -x;
+  real y;
+  if (x >= 1) y = 1;
+  else if (x == 0) y = 0;
+  else if (x <= mid) y = (1 / pow(mid, power - 1)) * pow(x, power);
+  else y = 1 - (1 / pow(1 - mid, power - 1)) * pow(1 - x, power);
+  return dmin + y * (dmax - dmin);
+}
+
+/* writes row r: J given, pos/margin/solref/solimp/diagApprox; returns imp-based R */
+static void finish_row(const mjo_model_t* m, mjo_data_t* d, int w, int r, real pos, real margin, const real* solref,
+                       const real* solimp, real diag_approx, int type, int id) {
+  const mjlab_sizes_t* s = &m->size;
+  int nv = s->nv, njm = s->njmax;
+  real* J = D(efc_J, njm * nv) + (size_t)r * nv;
+  real* qvel = D(qvel, nv);
+  real vel = 0;
+  for (int i = 0; i < nv; i++) vel += J[i] * qvel[i];
+  real imp = impedance(solimp, pos, margin);
+  real dmax = clipr(solimp[1], MINIMP, MAXIMP);
+  real k, b;
+  if (solref[0] > 0) {
+    real tc = solref[0], dr = solref[1];
+    real h2 = 2 * (real)m->opt.timestep;
+    if (tc < h2) tc = h2; /* refsafe */
+    real kd = dmax * dmax * tc * tc * dr * dr, bd = dmax * tc;
+    k = 1 / (kd > MINVAL ? kd : MINVAL);
+    b = 2 / (bd > MINVAL ? bd : MINVAL);
+  } else {
+    real kd = dmax * dmax, bd = dmax;
+    k = -solref[0] / (kd > MINVAL ? kd : MINVAL);
+    b = -solref[1] / (bd > MINVAL ? bd : MINVAL);
+  }
+  real R = (1 - imp) / imp * diag_approx;
+  if (R < MINVAL) R = MINVAL;
+  D(efc_pos, njm)[r] = pos;
+  D(efc_margin, njm)[r] = margin;
+  D(efc_D, njm)[r] = 1 / R; /* pyramidal rows are rescaled by the caller */
+  D(efc_aref, njm)[r] = -b * vel - k * imp * (pos - margin);
+  (d->efc_type + (size_t)w * njm)[r] = type;
+  (d->efc_id + (size_t)w * njm)[r] = id;
+}
+
+static void make_constraint(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int nv = s->nv, njm = s->njmax, ncm = s->nconmax, nb = s->nbody;
+  real* J = D(efc_J, njm * nv);
+  real *qpos = D(qpos, s->nq), *cdof = D(cdof, 6 * nv), *sub = D(subtree_com, 3 * nb);
+  int nefc = 0;
+  /* joint limits (hinge / slide) */
+  const real *range = MF(jnt_range, w), *jmargin = MF(jnt_margin, w), *jsolref = MF(jnt_solref, w),
+             *jsolimp = MF(jnt_solimp, w), *dinv = MF(dof_invweight0, w);
+  for (int j = 0; j < s->njnt; j++) {
+    if (!m->jnt_limited[j] || m->jnt_type[j] == MJLAB_JNT_FREE) continue;
+    real value = qpos[m->jnt_qposadr[j]], mg = jmargin[j];
+    for (int side = -1; side <= 1; side += 2) {
+      real dist = side * (range[2 * j + (side + 1) / 2] - value);
+      if (dist < mg && nefc < njm) {
+        real* row = J + (size_t)nefc * nv;
+        memset(row, 0, sizeof(real) * nv);
+        row[m->jnt_dofadr[j]] = (real)(-side);
+        finish_row(m, d, w, nefc, dist, mg, jsolref + 2 * j, jsolimp + 5 * j, dinv[m->jnt_dofadr[j]], MJLAB_EFC_LIMIT, j);
+        nefc++;
+      }
+    }
+  }
+  /* contacts */
+  int ncon = d->ncon[w];
+  const real* binv = MF(body_invweight0, w);
+  for (int c = 0; c < ncon; c++) {
+    int dim = (d->contact_dim + (size_t)w * ncm)[c];
+    real dist = D(contact_dist, ncm)[c], inc = D(contact_includemargin, ncm)[c];
+    (d->contact_efc_address + (size_t)w * ncm)[c] = -1;
+    if (dist >= inc) continue;
+    int nrow = dim == 1 ? 1 : 2 * (dim - 1);
+    if (nefc + nrow > njm) continue;
+    int g1 = (d->contact_geom + (size_t)w * 2 * ncm)[2 * c], g2 = (d->contact_geom + (size_t)w * 2 * ncm)[2 * c + 1];
+    int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+    const real *pos = D(contact_pos, 3 * ncm) + 3 * c, *frame = D(contact_frame, 9 * ncm) + 9 * c;
+    const real* fri = D(contact_friction, 5 * ncm) + 5 * c;
+    /* translational Jacobian difference (body2 - body1) at the contact point, in the contact frame */
+    real jf[3][64];
+    int bodies[2] = {b1, b2};
+    for (int i = 0; i < nv; i++) jf[0][i] = jf[1][i] = jf[2][i] = 0;
+    for (int side = 0; side < 2; side++) {
+      int b = bodies[side];
+      real sgn = side ? 1 : -1;
+      unsigned lo = (unsigned)m->body_dofmask[2 * b], hi = (unsigned)m->body_dofmask[2 * b + 1];
+      real off[3];
+      for (int k = 0; k < 3; k++) off[k] = pos[k] - sub[3 * m->body_rootid[b] + k];
+      for (int i = 0; i < nv; i++) {
+        int on = i < 32 ? (lo >> i) & 1 : (hi >> (i - 32)) & 1;
+        if (!on) continue;
+        real jp[3];
+        cross3(jp, cdof + 6 * i, off);
+        for (int k = 0; k < 3; k++) jp[k] += cdof[6 * i + 3 + k];
+        for (int a = 0; a < 3; a++) jf[a][i] += sgn * dot3(frame + 3 * a, jp);
+      }
+    }
+    real tran = binv[2 * b1] + binv[2 * b2];
+    (d->contact_efc_address + (size_t)w * ncm)[c] = nefc;
+    const real *solref = D(contact_solref, 2 * ncm) + 2 * c, *solimp = D(contact_solimp, 5 * ncm) + 5 * c;
+    if (dim == 1) {
+      memcpy(J + (size_t)nefc * nv, jf[0], sizeof(real) * nv);
+      finish_row(m, d, w, nefc, dist, inc, solref, solimp, tran, MJLAB_EFC_CONTACT_FRICTIONLESS, c);
+      nefc++;
+    } else {
+      int first = nefc;
+      for (int k = 1; k < dim; k++) {
+        real mu = fri[k - 1];
+        for (int sg = 0; sg < 2; sg++) {
+          real* row = J + (size_t)nefc * nv;
+          for (int i = 0; i < nv; i++) row[i] = jf[0][i] + (sg ? -mu : mu) * jf[k][i];
+          finish_row(m, d, w, nefc, dist, inc, solref, solimp, tran + mu * mu * tran, MJLAB_EFC_CONTACT_PYRAMIDAL, c);
+          nefc++;
+        }
+      }
+      /* pyramid rows share R = 2 mu^2 R_first, mu = friction[0] / sqrt(impratio) */
+      real mu = fri[0] * sqrt(1 / (real)m->opt.impratio);
+      real Rpy = 2 * mu * mu * (1 / D(efc_D, njm)[first]);
+      if (Rpy < MINVAL) Rpy = MINVAL;
+      for (int r = first; r < nefc; r++) D(efc_D, njm)[r] = 1 / Rpy;
+    }
+  }
+  d->nefc[w] = nefc;
+}
+
+/* ------------------------------------------------------------------ velocity / forces */
+static void com_vel(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int nb = s->nbody, nv = s->nv;
+  real *cvel = D(cvel, 6 * nb), *cdof = D(cdof, 6 * nv), *cdd = D(cdof_dot, 6 * nv), *qvel = D(qvel, nv);
+  memset(cvel, 0, 6 * sizeof(real));
+  for (int i = 1; i < nb; i++) {
+    real v[6];
+    memcpy(v, cvel + 6 * m->body_parentid[i], sizeof(v));
+    int ja = m->body_jntadr[i], jn = m->body_jntnum[i];
+    for (int j = ja; j < ja + jn; j++) {
+      int da = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == MJLAB_JNT_FREE) {
+        memset(cdd + 6 * da, 0, 18 * sizeof(real));
+        for (int k = 0; k < 3; k++) for (int a = 0; a < 6; a++) v[a] += cdof[6 * (da + k) + a] * qvel[da + k];
+        for (int k = 3; k < 6; k++) cross_motion(cdd + 6 * (da + k), v, cdof + 6 * (da + k));
+        for (int k = 3; k < 6; k++) for (int a = 0; a < 6; a++) v[a] += cdof[6 * (da + k) + a] * qvel[da + k];
+      } else {
+        cross_motion(cdd + 6 * da, v, cdof + 6 * da);
+        for (int a = 0; a < 6; a++) v[a] += cdof[6 * da + a] * qvel[da];
+      }
+    }
+    memcpy(cvel + 6 * i, v, sizeof(v));
+  }
+}
+
+static void rne_bias(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int nb = s->nbody, nv = s->nv;
+  real *cvel = D(cvel, 6 * nb), *cdof = D(cdof, 6 * nv), *cdd = D(cdof_dot, 6 * nv), *qvel = D(qvel, nv);
+  real *cinert = D(cinert, 10 * nb), *bias = D(qfrc_bias, nv);
+  real* cacc = (real*)calloc(6 * nb, sizeof(real));
+  real* cfrc = (real*)calloc(6 * nb, sizeof(real));
+  for (int k = 0; k < 3; k++) cacc[3 + k] = -(real)m->opt.gravity[k];
+  for (int i = 1; i < nb; i++) {
+    real* a = cacc + 6 * i;
+    memcpy(a, cacc + 6 * m->body_parentid[i], 6 * sizeof(real));
+    int da = m->body_dofadr[i];
+    for (int k = 0; k < m->body_dofnum[i]; k++)
+      for (int c = 0; c < 6; c++) a[c] += cdd[6 * (da + k) + c] * qvel[da + k];
+    real t1[6], t2[6], t3[6];
+    mul_inert_vec(t1, cinert + 10 * i, a);
+    mul_inert_vec(t2, cinert + 10 * i, cvel + 6 * i);
+    cross_force(t3, cvel + 6 * i, t2);
+    for (int c = 0; c < 6; c++) cfrc[6 * i + c] = t1[c] + t3[c];
+  }
+  for (int i = nb - 1; i > 0; i--) {
+    int p = m->body_parentid[i];
+    if (p > 0) for (int c = 0; c < 6; c++) cfrc[6 * p + c] += cfrc[6 * i + c];
+  }
+  for (int i = 0; i < nv; i++) {
+    real v = 0;
+    for (int c = 0; c < 6; c++) v += cdof[6 * i + c] * cfrc[6 * m->dof_bodyid[i] + c];
+    bias[i] = v;
+  }
+  free(cacc);
+  free(cfrc);
+}
+
+static void smooth_forces(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int nb = s->nbody, nv = s->nv, nu = s->nu;
+  real *qpos = D(qpos, s->nq), *qvel = D(qvel, nv), *ctrl = D(ctrl, nu);
+  real *passive = D(qfrc_passive, nv), *qact = D(qfrc_actuator, nv), *aforce = D(actuator_force, nu);
+  real *smooth = D(qfrc_smooth, nv), *bias = D(qfrc_bias, nv), *applied = D(qfrc_applied, nv);
+  const real *damping = MF(dof_damping, w), *stiff = MF(jnt_stiffness, w), *qpos0 = MF(qpos0, w);
+  /* passive: joint springs (reference pose = qpos0) and dof damping */
+  for (int i = 0; i < nv; i++) passive[i] = -damping[i] * qvel[i];
+  for (int j = 0; j < s->njnt; j++) {
+    if (stiff[j] == 0 || m->jnt_type[j] == MJLAB_JNT_FREE) continue;
+    int qa = m->jnt_qposadr[j];
+    passive[m->jnt_dofadr[j]] -= stiff[j] * (qpos[qa] - qpos0[qa]);
+  }
+  /* actuation: joint transmission, fixed gain, affine bias */
+  memset(qact, 0, sizeof(real) * nv);
+  const real *gain = MF(actuator_gainprm, w), *biasprm = MF(actuator_biasprm, w), *crange = MF(actuator_ctrlrange, w),
+             *frange = MF(actuator_forcerange, w), *gear = MF(actuator_gear, w);
+  for (int a = 0; a < nu; a++) {
+    int j = m->actuator_trnid[2 * a], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    real g = gear[6 * a], c = ctrl[a];
+    if (m->actuator_ctrllimited[a]) c = clipr(c, crange[2 * a], crange[2 * a + 1]);
+    real len = g * qpos[qa], vel = g * qvel[da];
+    real f = gain[10 * a] * c + biasprm[10 * a] + biasprm[10 * a + 1] * len + biasprm[10 * a + 2] * vel;
+    if (m->actuator_forcelimited[a]) f = clipr(f, frange[2 * a], frange[2 * a + 1]);
+    aforce[a] = f;
+    qact[da] += g * f;
+  }
+  for (int i = 0; i < nv; i++) smooth[i] = passive[i] - bias[i] + applied[i] + qact[i];
+  /* Cartesian perturbations: xfrc_applied = [force, torque] at xipos, world frame */
+  real *xfrc = D(xfrc_applied, 6 * nb), *xipos = D(xipos, 3 * nb), *sub = D(subtree_com, 3 * nb), *cdof = D(cdof, 6 * nv);
+  for (int b = 1; b < nb; b++) {
+    const real* f = xfrc + 6 * b;
+    if (f[0] == 0 && f[1] == 0 && f[2] == 0 && f[3] == 0 && f[4] == 0 && f[5] == 0) continue;
+    unsigned lo = (unsigned)m->body_dofmask[2 * b], hi = (unsigned)m->body_dofmask[2 * b + 1];
+    real off[3];
+    for (int k = 0; k < 3; k++) off[k] = xipos[3 * b + k] - sub[3 * m->body_rootid[b] + k];
+    for (int i = 0; i < nv; i++) {
+      int on = i < 32 ? (lo >> i) & 1 : (hi >> (i - 32)) & 1;
+      if (!on) continue;
+      real jp[3];
+      cross3(jp, cdof + 6 * i, off);
+      for (int k = 0; k < 3; k++) jp[k] += cdof[6 * i + 3 + k];
+      smooth[i] += dot3(jp, f) + dot3(cdof + 6 * i, f + 3);
+    }
+  }
+  real* qas = D(qacc_smooth, nv);
+  memcpy(qas, smooth, sizeof(real) * nv);
+  chol_solve(D(qLD, nv * nv), nv, qas);
+}
+
+/* ------------------------------------------------------------------ Newton solver */
+typedef struct {
+  int nv, nefc, ls_iter;
+  const real *J, *Dv, *aref, *M, *qfrc_smooth, *qacc_smooth;
+  real *qacc, *Ma, *jar, *grad, *search, *Mv, *jv, *force, *qfrc_constraint, *H;
+  real quad_gauss[3], cost, gauss;
+} nctx_t;
+
+typedef struct { real alpha, cost, d0, d1; } lspnt_t;
+
+static void update_constraint(nctx_t* c) {
+  int nv = c->nv;
+  real cost = 0;
+  memset(c->qfrc_constraint, 0, sizeof(real) * nv);
+  for (int r = 0; r < c->nefc; r++) {
+    real x = c->jar[r];
+    if (x < 0) {
+      c->force[r] = -c->Dv[r] * x;
+      cost += (real)0.5 * c->Dv[r] * x * x;
+      const real* row = c->J + (size_t)r * nv;
+      for (int i = 0; i < nv; i++) c->qfrc_constraint[i] += row[i] * c->force[r];
+    } else c->force[r] = 0;
+  }
+  real gauss = 0;
+  for (int i = 0; i < nv; i++) gauss += (real)0.5 * (c->Ma[i] - c->qfrc_smooth[i]) * (c->qacc[i] - c->qacc_smooth[i]);
+  c->gauss = gauss;
+  c->cost = cost + gauss;
+}
+
+static void update_gradient(nctx_t* c) {
+  int nv = c->nv;
+  for (int i = 0; i < nv; i++) c->grad[i] = c->Ma[i] - c->qfrc_smooth[i] - c->qfrc_constraint[i];
+  memcpy(c->H, c->M, sizeof(real) * nv * nv);
+  for (int r = 0; r < c->nefc; r++) {
+    if (c->jar[r] >= 0) continue;
+    const real* row = c->J + (size_t)r * nv;
+    real Dr = c->Dv[r];
+    for (int i = 0; i < nv; i++) {
+      if (row[i] == 0) continue;
+      real t = Dr * row[i];
+      for (int j = 0; j <= i; j++) c->H[i * nv + j] += t * row[j];
+    }
+  }
+  chol_factor(c->H, nv);
+  for (int i = 0; i < nv; i++) c->search[i] = c->grad[i];
+  chol_solve(c->H, nv, c->search);
+  for (int i = 0; i < nv; i++) c->search[i] = -c->search[i];
+}
+
+static void ls_eval(nctx_t* c, lspnt_t* p, real alpha) {
+  real cost = alpha * alpha * c->quad_gauss[2] + alpha * c->quad_gauss[1] + c->quad_gauss[0];
+  real d0 = 2 * alpha * c->quad_gauss[2] + c->quad_gauss[1], d1 = 2 * c->quad_gauss[2];
+  for (int r = 0; r < c->nefc; r++) {
+    real x = c->jar[r] + alpha * c->jv[r];
+    if (x < 0) {
+      real Dr = c->Dv[r], q0 = (real)0.5 * Dr * c->jar[r] * c->jar[r], q1 = Dr * c->jar[r] * c->jv[r], q2 = (real)0.5 * Dr * c->jv[r] * c->jv[r];
+      cost += alpha * alpha * q2 + alpha * q1 + q0;
+      d0 += 2 * alpha * q2 + q1;
+      d1 += 2 * q2;
+    }
+  }
+  if (d1 <= 0) d1 = MINVAL;
+  p->alpha = alpha; p->cost = cost; p->d0 = d0; p->d1 = d1;
+  c->ls_iter++;
+}
+
+static int update_bracket(nctx_t* c, lspnt_t* p, const lspnt_t* cand, lspnt_t* pnext) {
+  int flag = 0;
+  for (int i = 0; i < 3; i++) {
+    if (p->d0 < 0 && cand[i].d0 < 0 && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
+    else if (p->d0 > 0 && cand[i].d0 > 0 && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
+  }
+  if (flag) ls_eval(c, pnext, p->alpha - p->d0 / p->d1);
+  return flag;
+}
+
+static real line_search(const mjo_model_t* m, nctx_t* c) {
+  int nv = c->nv, lsmax = m->opt.ls_iterations;
+  real snorm = 0;
+  for (int i = 0; i < nv; i++) snorm += c->search[i] * c->search[i];
+  snorm = sqrt(snorm);
+  c->ls_iter = 0;
+  if (snorm < MINVAL) return 0;
+  real scale = (real)m->opt.meaninertia * (nv > 1 ? nv : 1);
+  real gtol = (real)m->opt.tolerance * (real)m->opt.ls_tolerance * snorm * scale;
+  /* prepare: Mv, jv, Gauss quadratic */
+  for (int i = 0; i < nv; i++) {
+    real t = 0;
+    for (int j = 0; j < nv; j++) t += c->M[i * nv + j] * c->search[j];
+    c->Mv[i] = t;
+  }
+  for (int r = 0; r < c->nefc; r++) {
+    real t = 0;
+    const real* row = c->J + (size_t)r * nv;
+    for (int i = 0; i < nv; i++) t += row[i] * c->search[i];
+    c->jv[r] = t;
+  }
+  c->quad_gauss[0] = c->gauss;
+  c->quad_gauss[1] = 0;
+  c->quad_gauss[2] = 0;
+  for (int i = 0; i < nv; i++) {
+    c->quad_gauss[1] += c->search[i] * (c->Ma[i] - c->qfrc_smooth[i]);
+    c->quad_gauss[2] += (real)0.5 * c->search[i] * c->Mv[i];
+  }
+  lspnt_t p0, p1, p2, pmid, p1next, p2next;
+  ls_eval(c, &p0, 0);
+  ls_eval(c, &p1, p0.alpha - p0.d0 / p0.d1);
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabs(p1.d0) < gtol) return p1.alpha;
+  int dir = p1.d0 < 0 ? 1 : -1;
+  int p2update = 0;
+  p2 = p1;
+  while (p1.d0 * dir <= -gtol && c->ls_iter < lsmax) {
+    p2 = p1;
+    p2update = 1;
+    ls_eval(c, &p1, p1.alpha - p1.d0 / p1.d1);
+    if (fabs(p1.d0) < gtol) return p1.alpha;
+  }
+  if (c->ls_iter >= lsmax) return p1.alpha;
+  if (!p2update) return p1.alpha;
+  p2next = p1;
+  ls_eval(c, &p1next, p1.alpha - p1.d0 / p1.d1);
+  while (c->ls_iter < lsmax) {
+    ls_eval(c, &pmid, (real)0.5 * (p1.alpha + p2.alpha));
+    lspnt_t cand[3] = {p1next, p2next, pmid};
+    real bestcost = 0;
+    int best = -1;
+    for (int i = 0; i < 3; i++)
+      if (fabs(cand[i].d0) < gtol && (best == -1 || cand[i].cost < bestcost)) { bestcost = cand[i].cost; best = i; }
+    if (best >= 0) return cand[best].alpha;
+    int b1 = update_bracket(c, &p1, cand, &p1next);
+    int b2 = update_bracket(c, &p2, cand, &p2next);
+    if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : 0;
+  }
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0;
+}
+
+static real constraint_cost_at(nctx_t* c, const real* qacc, int with_gauss) {
+  int nv = c->nv;
+  real cost = 0;
+  for (int r = 0; r < c->nefc; r++) {
+    const real* row = c->J + (size_t)r * nv;
+    real x = -c->aref[r];
+    for (int i = 0; i < nv; i++) x += row[i] * qacc[i];
+    if (x < 0) cost += (real)0.5 * c->Dv[r] * x * x;
+  }
+  if (with_gauss)
+    for (int i = 0; i < nv; i++) {
+      real ma = 0;
+      for (int j = 0; j < nv; j++) ma += c->M[i * nv + j] * qacc[j];
+      cost += (real)0.5 * (ma - c->qfrc_smooth[i]) * (qacc[i] - c->qacc_smooth[i]);
+    }
+  return cost;
+}
+
+static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int nv = s->nv, njm = s->njmax, nefc = d->nefc[w];
+  real *qacc = D(qacc, nv), *ws = D(qacc_warmstart, nv), *qas = D(qacc_smooth, nv);
+  real* force = D(efc_force, njm);
+  if (nefc == 0) {
+    memcpy(qacc, qas, sizeof(real) * nv);
+    memcpy(ws, qas, sizeof(real) * nv);
+    memset(D(qfrc_constraint, nv), 0, sizeof(real) * nv);
+    d->solver_niter[w] = 0;
+    return;
+  }
+  nctx_t c;
+  c.nv = nv; c.nefc = nefc;
+  c.J = D(efc_J, njm * nv); c.Dv = D(efc_D, njm); c.aref = D(efc_aref, njm); c.M = D(qM, nv * nv);
+  c.qfrc_smooth = D(qfrc_smooth, nv); c.qacc_smooth = qas; c.qacc = qacc; c.force = force;
+  c.qfrc_constraint = D(qfrc_constraint, nv);
+  real* buf = (real*)calloc((size_t)5 * nv + 2 * nefc + (size_t)nv * nv, sizeof(real));
+  c.Ma = buf; c.grad = buf + nv; c.search = buf + 2 * nv; c.Mv = buf + 3 * nv;
+  c.jar = buf + 5 * nv; c.jv = c.jar + nefc; c.H = c.jv + nefc;
+  /* warmstart: better of qacc_warmstart and qacc_smooth */
+  real cw = constraint_cost_at(&c, ws, 1), cs = constraint_cost_at(&c, qas, 0);
+  memcpy(qacc, cw > cs ? qas : ws, sizeof(real) * nv);
+  for (int i = 0; i < nv; i++) {
+    real t = 0;
+    for (int j = 0; j < nv; j++) t += c.M[i * nv + j] * qacc[j];
+    c.Ma[i] = t;
+  }
+  for (int r = 0; r < nefc; r++) {
+    const real* row = c.J + (size_t)r * nv;
+    real x = -c.aref[r];
+    for (int i = 0; i < nv; i++) x += row[i] * qacc[i];
+    c.jar[r] = x;
+  }
+  real scale = 1 / ((real)m->opt.meaninertia * (nv > 1 ? nv : 1));
+  update_constraint(&c);
+  update_gradient(&c);
+  int iter = 0;
+  while (iter < m->opt.iterations) {
+    real alpha = line_search(m, &c);
+    if (alpha == 0) break;
+    for (int i = 0; i < nv; i++) { qacc[i] += alpha * c.search[i]; c.Ma[i] += alpha * c.Mv[i]; }
+    for (int r = 0; r < nefc; r++) c.jar[r] += alpha * c.jv[r];
+    real oldcost = c.cost;
+    update_constraint(&c);
+    update_gradient(&c);
+    real improvement = scale * (oldcost - c.cost), gn = 0;
+    for (int i = 0; i < nv; i++) gn += c.grad[i] * c.grad[i];
+    real gradient = scale * sqrt(gn);
+    iter++;
+    if (improvement < (real)m->opt.tolerance || gradient < (real)m->opt.tolerance) break;
+  }
+  d->solver_niter[w] = iter;
+  memcpy(ws, qacc, sizeof(real) * nv);
+  free(buf);
+}
+
+/* ------------------------------------------------------------------ sensors */
+static int in_subtree(const mjo_model_t* m, int body, int root) {
+  while (body > 0 && body != root) body = m->body_parentid[body];
+  return body == root;
+}
+static int sensor_match(const mjo_model_t* m, int type, int id, int geom) {
+  if (type < 0) return 1;
+  int b = m->geom_bodyid[geom];
+  if (type == MJLAB_OBJ_GEOM) return geom == id;
+  if (type == MJLAB_OBJ_BODY) return b == id;
+  if (type == MJLAB_OBJ_XBODY) return in_subtree(m, b, id);
+  return 0;
+}
+static void sensors(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int ncm = s->nconmax, ncon = d->ncon[w];
+  real* sd = D(sensordata, s->nsensordata);
+  for (int i = 0; i < s->nsensordata; i++) sd[i] = 0;
+  const int* cg = d->contact_geom + (size_t)w * 2 * ncm;
+  const int* cadr = d->contact_efc_address + (size_t)w * ncm;
+  for (int k = 0; k < s->nsensor; k++) {
+    int cnt = 0;
+    for (int c = 0; c < ncon; c++) {
+      if (cadr[c] < 0) continue;
+      int g1 = cg[2 * c], g2 = cg[2 * c + 1];
+      int ot = m->sensor_objtype[k], oi = m->sensor_objid[k], rt = m->sensor_reftype[k], ri = m->sensor_refid[k];
+      if ((sensor_match(m, ot, oi, g1) && sensor_match(m, rt, ri, g2)) ||
+          (sensor_match(m, ot, oi, g2) && sensor_match(m, rt, ri, g1)))
+        cnt++;
+    }
+    /* dataspec = found only: slot 0 holds the number of matching contacts */
+    sd[m->sensor_adr[k]] = (real)cnt;
+  }
+}
+
+/* ------------------------------------------------------------------ integration */
+static void integrate(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int nv = s->nv, nu = s->nu;
+  real h = (real)m->opt.timestep;
+  real *qpos = D(qpos, s->nq), *qvel = D(qvel, nv), *qacc = D(qacc, nv);
+  real* a = (real*)malloc(sizeof(real) * (nv + (size_t)nv * nv));
+  real* A = a + nv;
+  const real* damping = MF(dof_damping, w);
+  int need_solve = 0;
+  real* diag = (real*)calloc(nv, sizeof(real));
+  for (int i = 0; i < nv; i++) { diag[i] = damping[i]; if (damping[i] > 0) need_solve = 1; }
+  if (m->opt.integrator == MJLAB_INT_IMPLICITFAST) {
+    /* qDeriv restricted to its diagonal: joint-transmission actuator velocity gains + dof damping */
+    const real *biasprm = MF(actuator_biasprm, w), *gear = MF(actuator_gear, w), *frange = MF(actuator_forcerange, w);
+    real* aforce = D(actuator_force, nu);
+    for (int k = 0; k < nu; k++) {
+      if (m->actuator_forcelimited[k] && (aforce[k] <= frange[2 * k] || aforce[k] >= frange[2 * k + 1])) continue;
+      int da = m->jnt_dofadr[m->actuator_trnid[2 * k]];
+      diag[da] -= gear[6 * k] * gear[6 * k] * biasprm[10 * k + 2];
+    }
+    need_solve = 1;
+  }
+  if (need_solve) {
+    memcpy(A, D(qM, nv * nv), sizeof(real) * nv * nv);
+    for (int i = 0; i < nv; i++) A[i * nv + i] += h * diag[i];
+    real *smooth = D(qfrc_smooth, nv), *qc = D(qfrc_constraint, nv);
+    for (int i = 0; i < nv; i++) a[i] = smooth[i] + qc[i];
+    chol_factor(A, nv);
+    chol_solve(A, nv, a);
+  } else memcpy(a, qacc, sizeof(real) * nv);
+  for (int i = 0; i < nv; i++) qvel[i] += h * a[i];
+  for (int j = 0; j < s->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == MJLAB_JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos[qa + k] += h * qvel[da + k];
+      real ax[3] = {qvel[da + 3], qvel[da + 4], qvel[da + 5]}, q[4], qr[4], *quat = qpos + qa + 3;
+      real ang = h * normalize3(ax);
+      axis_angle2quat(qr, ax, ang);
+      normalize4(quat);
+      mul_quat(q, quat, qr);
+      memcpy(quat, q, sizeof(q));
+      normalize4(quat);
+    } else qpos[qa] += h * qvel[da];
+  }
+  d->time[w] += h;
+  free(a);
+  free(diag);
+}
+
+/* ------------------------------------------------------------------ public API */
+void mjo_forward(const mjo_model_t* m, mjo_data_t* d, int w) {
+  kinematics(m, d, w);
+  com_pos(m, d, w);
+  crb_factor(m, d, w);
+  collision(m, d, w);
+  make_constraint(m, d, w);
+  com_vel(m, d, w);
+  rne_bias(m, d, w);
+  smooth_forces(m, d, w);
+  solve(m, d, w);
+  sensors(m, d, w);
+}
+
+void mjo_step(const mjo_model_t* m, mjo_data_t* d, int w) {
+  mjo_forward(m, d, w);
+  integrate(m, d, w);
+}
+
+typedef struct { const mjo_model_t* m; mjo_data_t* d; int w0, w1, nstep, fwd_only; } job_t;
+static void* worker(void* arg) {
+  job_t* j = (job_t*)arg;
+  for (int w = j->w0; w < j->w1; w++)
+    for (int k = 0; k < j->nstep; k++) {
+      if (j->fwd_only) mjo_forward(j->m, j->d, w); else mjo_step(j->m, j->d, w);
+    }
+  return 0;
+}
+/* runs `nstep` steps (or one forward when nstep == 0) on every world with `nthread` threads */
+void mjo_run(const mjo_model_t* m, mjo_data_t* d, int nstep, int nthread) {
+  int nw = m->size.nworld;
+  if (nthread < 1) nthread = 1;
+  if (nthread > nw) nthread = nw;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthread);
+  job_t* jobs = (job_t*)malloc(sizeof(job_t) * nthread);
+  for (int t = 0; t < nthread; t++) {
+    jobs[t].m = m; jobs[t].d = d;
+    jobs[t].w0 = (int)((long long)nw * t / nthread);
+    jobs[t].w1 = (int)((long long)nw * (t + 1) / nthread);
+    jobs[t].nstep = nstep > 0 ? nstep : 1;
+    jobs[t].fwd_only = nstep == 0;
+    if (nthread == 1) worker(&jobs[t]); else pthread_create(&th[t], 0, worker, &jobs[t]);
+  }
+  if (nthread > 1) for (int t = 0; t < nthread; t++) pthread_join(th[t], 0);
+  free(th);
+  free(jobs);
+}
