@@ -1,0 +1,78 @@
+/* mjlab_amd.h -- C ABI of the MI355X-native batched physics step.
+ *
+ * Drop-in boundary for the reference's only hot path:
+ *
+ *   mjwarp.step(wp_model, wp_data)      reference src/mjlab/sim/sim.py:136,195
+ *   mjwarp.forward(wp_model, wp_data)   reference src/mjlab/sim/sim.py:139,187
+ *   repeat_array_kernel / expand_model_fields
+ *                                       reference src/mjlab/sim/randomization.py:9-55
+ *
+ * Plain pointers and sizes only (no torch types).  All array pointers inside
+ * mjlab_model_t / mjlab_data_t are DEVICE pointers owned by the caller (the Python
+ * host side allocates them as torch tensors so that `sim.data.<field>` is zero-copy,
+ * reference src/mjlab/sim/sim_data.py:15-64); the structs themselves live on the host
+ * and are passed by pointer.  Every call only ENQUEUES work on `stream` (a
+ * hipStream_t passed as void*) and returns; nothing synchronises.
+ *
+ * Return value: 0 on success, otherwise a hipError_t / negative library error;
+ * mjlab_last_error() returns a static description of the last failure of the
+ * calling thread.
+ */
+#ifndef MJLAB_AMD_H_
+#define MJLAB_AMD_H_
+
+#define MJLAB_REAL float
+#define MJLAB_MODEL_T mjlab_model_t
+#define MJLAB_DATA_T mjlab_data_t
+#include "mjlab_fields.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJLAB_ABI_VERSION 1
+
+/* stage bits for mjlab_forward_stages (testing / profiling of single stages) */
+enum {
+  MJLAB_STAGE_POSITION = 1,   /* kinematics, comPos, crb, factorM          */
+  MJLAB_STAGE_COLLISION = 2,  /* broad + narrow phase -> contacts          */
+  MJLAB_STAGE_VELOCITY = 4,   /* comVel, passive, rne, actuation, qacc_smooth */
+  MJLAB_STAGE_CONSTRAINT = 8, /* makeConstraint (limits + contacts), contact sensors */
+  MJLAB_STAGE_SOLVE = 16,     /* Newton solver -> qacc, efc_force          */
+  MJLAB_STAGE_INTEGRATE = 32, /* Euler / implicitfast position+velocity update */
+  MJLAB_STAGE_FORWARD = 31,
+  MJLAB_STAGE_STEP = 63
+};
+
+int mjlab_abi_version(void);
+const char* mjlab_last_error(void);
+
+/* Struct layouts as "kind:name:ncol:count," lists in struct order (see mjlab_fields.h). */
+const char* mjlab_model_layout(void);
+const char* mjlab_data_layout(void);
+int mjlab_sizeof_model(void);
+int mjlab_sizeof_data(void);
+
+/* Replaces mjwarp.step: advance every world by `nsubstep` physics steps
+ * (forward dynamics + integration each).  Reference: sim/sim.py:189-195; the
+ * decimation loop that calls it 4x per env step is envs/manager_based_rl_env.py:109-114. */
+int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void* stream);
+
+/* Replaces mjwarp.forward: everything of a step except the integration
+ * (reference: sim/sim.py:182-187). */
+int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream);
+
+/* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
+int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);
+
+/* Replaces repeat_array_kernel (reference sim/randomization.py:9-17):
+ * dst[w * nelem + i] = src[i] for w < nworld, elements of `elem_size` bytes (4 or 8). */
+int mjlab_tile_field(void* dst, const void* src, long long nelem, int nworld, int elem_size, void* stream);
+
+/* LDS bytes per workgroup of each stage kernel for this model (occupancy reporting). */
+int mjlab_lds_bytes(const mjlab_model_t* m, int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJLAB_AMD_H_ */

@@ -26,6 +26,9 @@
   X(body_dofnum, 1, nbody)                                                      \
   X(body_dofadr, 1, nbody)                                                      \
   X(body_depth, 1, nbody)                                                       \
+  X(body_subtreenum, 1, nbody) /* bodies in the DFS-contiguous subtree, self included */ \
+  X(level_body, 1, nbody)      /* body ids sorted by tree depth */                \
+  X(level_adr, 1, nlevelp1)    /* level L = level_body[level_adr[L] .. level_adr[L+1]) */ \
   X(body_dofmask, 2, nbody) /* lo, hi 32 bits of the ancestor-dof bitmask */     \
   X(jnt_type, 1, njnt)                                                          \
   X(jnt_qposadr, 1, njnt)                                                       \
@@ -166,6 +169,7 @@ enum { MJLAB_EFC_LIMIT = 3, MJLAB_EFC_CONTACT_FRICTIONLESS = 4, MJLAB_EFC_CONTAC
 /* Sizes shared by model and data (host struct, passed by pointer). */
 typedef struct mjlab_sizes {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nsensor, nsensordata, npair;
+  int nlevel;  /* number of tree levels (world = level 0) */
   int nworld;  /* number of worlds (environments) */
   int nconmax; /* contact capacity PER WORLD */
   int njmax;   /* constraint-row capacity PER WORLD */

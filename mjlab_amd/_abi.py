@@ -15,7 +15,7 @@ from .mjcf import Model
 
 _SIZE_FIELDS = (
   "nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata", "npair",
-  "nworld", "nconmax", "njmax",
+  "nlevel", "nworld", "nconmax", "njmax",
 )  # fmt: skip
 
 
@@ -70,6 +70,8 @@ def make_data_struct(fields: list[FieldSpec]) -> type[ctypes.Structure]:
 def count_of(sym: str, m: Model, nconmax: int, njmax: int) -> int:
   if sym == "one":
     return 1
+  if sym == "nlevelp1":
+    return m.nlevel + 1
   if sym == "nvnv":
     return m.nv * m.nv
   if sym == "njmaxnv":
@@ -83,7 +85,7 @@ def count_of(sym: str, m: Model, nconmax: int, njmax: int) -> int:
 
 def fill_sizes(m: Model, nworld: int, nconmax: int, njmax: int) -> Sizes:
   s = Sizes()
-  for n in _SIZE_FIELDS[:10]:
+  for n in _SIZE_FIELDS[:11]:
     setattr(s, n, int(getattr(m, n)))
   s.nworld, s.nconmax, s.njmax = nworld, nconmax, njmax
   return s

@@ -1,0 +1,1512 @@
+// mjlab_amd.hip -- batched MuJoCo-style physics step for MI355X (gfx950 / CDNA4).
+//
+// Replaces the reference's foreign calls mjwarp.step / mjwarp.forward
+// (reference: src/mjlab/sim/sim.py:136,139,187,195).  Stage names follow MuJoCo's
+// pipeline as catalogued by the reference's stubs (typings/mujoco/_functions.pyi:
+// mj_kinematics :803, mj_comPos :358, mj_crb :399, mj_factorM :449, mj_collision :353,
+// mj_makeConstraint :835, mj_comVel :363, mj_rne :1070, mj_fwdActuation :493,
+// mj_fwdAcceleration :488, mj_fwdConstraint :498, mj_implicit :555).
+//
+// Execution model: ONE WORLD (environment) PER WAVEFRONT.  A workgroup is a single
+// 64-lane wave, so every stage kernel launches `nworld` workgroups; with 4096 worlds that
+// is 16 waves per CU on the 256 CUs of an MI355X, all resident at once when a stage keeps
+// its LDS footprint at or below ~10 KB.  Inside a wave, lanes own tree nodes (bodies of one
+// depth level), dofs, candidate geom pairs, constraint rows or matrix rows, depending on
+// the stage.  Public mjData arrays are [nworld][n] row-major, so "lanes = elements of one
+// world's row" gives coalesced HBM traffic; intermediates that never leave a stage live in
+// LDS or registers.  The only GEMM-shaped work -- the Newton Hessian H = M + J^T D J -- is
+// streamed row-major from L2 straight into fp32 MFMA (v_mfma_f32_16x16x4_f32) operands.
+//
+// All arithmetic is fp32 (like the reference's Warp kernels); ids are int32.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/mjlab_amd.h"
+
+typedef mjlab_model_t Model;
+typedef mjlab_data_t Data;
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+
+#define MINVAL 1e-15f
+#define MINIMP 0.0001f
+#define MAXIMP 0.9999f
+#define MF(name) (m.name + (size_t)w * (size_t)m.name##_ws)
+
+// ------------------------------------------------------------------------------------
+// wave-level helpers (wave = 64 lanes)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+// Sum over the wave; the result is made explicitly wave-uniform (SGPR) so that the solver's
+// control flow compiles to scalar branches.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  *total = __shfl(incl, 63);
+  return incl - v;
+}
+__device__ __forceinline__ void lds_to_global(float* dst, const float* src, int n, int lane) {
+  for (int k = lane; k < n; k += 64) dst[k] = src[k];
+}
+__device__ __forceinline__ void global_to_lds(float* dst, const float* src, int n, int lane) {
+  for (int k = lane; k < n; k += 64) dst[k] = src[k];
+}
+
+// ------------------------------------------------------------------------------------
+// small math (quaternions w-x-y-z, row-major 3x3)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(float* r, const float* a, const float* b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ float normalize3(float* v) {
+  float n = sqrtf(dot3(v, v));
+  if (n < MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; return 0; }
+  float inv = 1.0f / n;
+  v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  return n;
+}
+__device__ __forceinline__ void normalize4(float* q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  float inv = 1.0f / n;
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+__device__ __forceinline__ void mul_quat(float* r, const float* a, const float* b) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+__device__ __forceinline__ void quat2mat(float* R, const float* q) {
+  float q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  float q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
+  float q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+  R[0] = q00 + q11 - q22 - q33; R[4] = q00 - q11 + q22 - q33; R[8] = q00 - q11 - q22 + q33;
+  R[1] = 2 * (q12 - q03); R[2] = 2 * (q13 + q02);
+  R[3] = 2 * (q12 + q03); R[5] = 2 * (q23 - q01);
+  R[6] = 2 * (q13 - q02); R[7] = 2 * (q23 + q01);
+}
+__device__ __forceinline__ void mul_mat_vec3(float* r, const float* R, const float* v) {
+  float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  float y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  float z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void rot_vec_quat(float* r, const float* v, const float* q) {
+  float R[9];
+  quat2mat(R, q);
+  mul_mat_vec3(r, R, v);
+}
+__device__ __forceinline__ void axis_angle2quat(float* q, const float* axis, float angle) {
+  float s, c;
+  sincosf(angle * 0.5f, &s, &c);
+  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+__device__ __forceinline__ float clipf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// spatial algebra; motion vectors are [angular(3), linear(3)] about subtree_com[root]
+__device__ __forceinline__ void mul_inert_vec(float* r, const float* i, const float* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+__device__ __forceinline__ void cross_motion(float* r, const float* vel, const float* v) {
+  r[0] = -vel[2] * v[1] + vel[1] * v[2];
+  r[1] = vel[2] * v[0] - vel[0] * v[2];
+  r[2] = -vel[1] * v[0] + vel[0] * v[1];
+  r[3] = -vel[2] * v[4] + vel[1] * v[5] - vel[5] * v[1] + vel[4] * v[2];
+  r[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
+  r[5] = -vel[1] * v[3] + vel[0] * v[4] - vel[4] * v[0] + vel[3] * v[1];
+}
+__device__ __forceinline__ void cross_force(float* r, const float* vel, const float* f) {
+  r[0] = -vel[2] * f[1] + vel[1] * f[2] - vel[5] * f[4] + vel[4] * f[5];
+  r[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
+  r[2] = -vel[1] * f[0] + vel[0] * f[1] - vel[4] * f[3] + vel[3] * f[4];
+  r[3] = -vel[2] * f[4] + vel[1] * f[5];
+  r[4] = vel[2] * f[3] - vel[0] * f[5];
+  r[5] = -vel[1] * f[3] + vel[0] * f[4];
+}
+
+__device__ __forceinline__ bool dof_in_chain(const Model& m, int body, int dof) {
+  unsigned lo = (unsigned)m.body_dofmask[2 * body], hi = (unsigned)m.body_dofmask[2 * body + 1];
+  return dof < 32 ? ((lo >> dof) & 1u) : ((hi >> (dof - 32)) & 1u);
+}
+
+// ------------------------------------------------------------------------------------
+// dense Cholesky in LDS, one wave, n <= 64.  A is n x n with leading dimension ld (odd, so
+// that both row and column walks are bank-conflict free for ds_read_b32); lower triangle
+// in, L out (in place); invd[k] = 1 / L[k][k].
+// ------------------------------------------------------------------------------------
+__device__ void chol_factor_lds(float* A, float* invd, int n, int ld, int lane) {
+  for (int j = 0; j < n; ++j) {
+    float t = 0.f;
+    if (lane >= j && lane < n) {
+      t = A[lane * ld + j];
+      const float* ri = A + lane * ld;
+      const float* rj = A + j * ld;
+      for (int k = 0; k < j; ++k) t -= ri[k] * rj[k];
+    }
+    float djj = lane_bcast(t, j);
+    djj = fmaxf(djj, MINVAL);
+    float dsq = sqrtf(djj), inv = 1.0f / dsq;
+    if (lane == j) { A[j * ld + j] = dsq; invd[j] = inv; }
+    else if (lane > j && lane < n) A[lane * ld + j] = t * inv;
+    __syncthreads();
+  }
+}
+// Solves L L^T x = b where lane i owns b_i (lanes >= n pass anything); returns x_i.
+__device__ float chol_solve_lds(const float* L, const float* invd, int n, int ld, float b, int lane) {
+  for (int k = 0; k < n; ++k) {
+    float xk = lane_bcast(b, k) * invd[k];
+    if (lane == k) b = xk;
+    else if (lane > k && lane < n) b -= L[lane * ld + k] * xk;
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    float xk = lane_bcast(b, k) * invd[k];
+    if (lane == k) b = xk;
+    else if (lane < k) b -= L[k * ld + lane] * xk;
+  }
+  return b;
+}
+// y_i = sum_j M[i][j] v_j with M symmetric, dense row-major in GLOBAL memory (ld = n);
+// lane i owns v_i and y_i.  Row j is read coalesced, v_j is broadcast from lane j.
+__device__ float symm_mul_global(const float* M, int n, float v, int lane) {
+  float y = 0.f;
+  for (int j = 0; j < n; ++j) {
+    float vj = lane_bcast(v, j);
+    float mij = lane < n ? M[j * n + lane] : 0.f;
+    y += mij * vj;
+  }
+  return y;
+}
+
+// ====================================================================================
+// Stage 1: position  (mj_kinematics, mj_comPos, mj_crb, mj_factorM)
+// ====================================================================================
+__device__ __forceinline__ void local2global(float* xp, float* xm, const float* bpos, const float* bquat,
+                                             const float* bmat, const float* pos, const float* quat) {
+  float q[4], t[3];
+  mul_mat_vec3(t, bmat, pos);
+  xp[0] = bpos[0] + t[0]; xp[1] = bpos[1] + t[1]; xp[2] = bpos[2] + t[2];
+  mul_quat(q, bquat, quat);
+  quat2mat(xm, q);
+}
+
+__host__ __device__ inline int position_lds_floats(const mjlab_sizes_t& s) {
+  int nb = s.nbody, nv = s.nv, nj = s.njnt, ld = nv | 1;
+  int persistent = 3 * nb + 10 * nb + 10 * nb + 6 * nv + 6 * nv;
+  int kin = s.nq + 28 * nb + 6 * nj;
+  int mat = nv * ld + nv;
+  return persistent + (kin > mat ? kin : mat);
+}
+
+__global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ng = m.size.ngeom, ns = m.size.nsite;
+  float* s_sub = smem;
+  float* s_cinert = s_sub + 3 * nb;
+  float* s_crb = s_cinert + 10 * nb;
+  float* s_cdof = s_crb + 10 * nb;
+  float* s_buf = s_cdof + 6 * nv;
+  float* regA = s_buf + 6 * nv;
+  float* s_qpos = regA;
+  float* s_xpos = s_qpos + nq;
+  float* s_xquat = s_xpos + 3 * nb;
+  float* s_xmat = s_xquat + 4 * nb;
+  float* s_xipos = s_xmat + 9 * nb;
+  float* s_ximat = s_xipos + 3 * nb;
+  float* s_xanchor = s_ximat + 9 * nb;
+  float* s_xaxis = s_xanchor + 3 * nj;
+  const int ld = nv | 1;
+  float* s_M = regA;  // aliases the kinematics region once it has been consumed
+  float* s_invd = s_M + nv * ld;
+
+  global_to_lds(s_qpos, d.qpos + (size_t)w * nq, nq, lane);
+  if (lane == 0) {
+    s_xpos[0] = s_xpos[1] = s_xpos[2] = 0.f;
+    s_xquat[0] = 1.f; s_xquat[1] = s_xquat[2] = s_xquat[3] = 0.f;
+  }
+  if (lane < 9) s_xmat[lane] = (lane % 4 == 0) ? 1.f : 0.f;
+  __syncthreads();
+
+  const float* qpos0 = MF(qpos0);
+  const float *body_pos = MF(body_pos), *body_quat = MF(body_quat), *jnt_axis = MF(jnt_axis), *jnt_pos = MF(jnt_pos);
+  // ---- kinematics: one tree level at a time, lanes = bodies of the level
+  for (int L = 1; L < m.size.nlevel; ++L) {
+    const int a0 = m.level_adr[L], a1 = m.level_adr[L + 1];
+    for (int idx = a0 + lane; idx < a1; idx += 64) {
+      const int i = m.level_body[idx];
+      const int pid = m.body_parentid[i], ja = m.body_jntadr[i], jn = m.body_jntnum[i];
+      float pos[3], quat[4];
+      if (jn == 1 && m.jnt_type[ja] == MJLAB_JNT_FREE) {
+        const int qa = m.jnt_qposadr[ja];
+        for (int k = 0; k < 3; ++k) pos[k] = s_qpos[qa + k];
+        for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
+        normalize4(quat);
+        for (int k = 0; k < 3; ++k) { s_xanchor[3 * ja + k] = pos[k]; s_xaxis[3 * ja + k] = jnt_axis[3 * ja + k]; }
+      } else {
+        float t[3], bp[3], bq[4], pq[4], pm[9];
+        for (int k = 0; k < 3; ++k) bp[k] = body_pos[3 * i + k];
+        for (int k = 0; k < 4; ++k) { bq[k] = body_quat[4 * i + k]; pq[k] = s_xquat[4 * pid + k]; }
+        for (int k = 0; k < 9; ++k) pm[k] = s_xmat[9 * pid + k];
+        mul_mat_vec3(t, pm, bp);
+        for (int k = 0; k < 3; ++k) pos[k] = s_xpos[3 * pid + k] + t[k];
+        mul_quat(quat, pq, bq);
+        for (int j = ja; j < ja + jn; ++j) {
+          const int qa = m.jnt_qposadr[j];
+          float jax[3], jp[3], xax[3], anc[3];
+          for (int k = 0; k < 3; ++k) { jax[k] = jnt_axis[3 * j + k]; jp[k] = jnt_pos[3 * j + k]; }
+          rot_vec_quat(xax, jax, quat);
+          rot_vec_quat(t, jp, quat);
+          for (int k = 0; k < 3; ++k) anc[k] = t[k] + pos[k];
+          if (m.jnt_type[j] == MJLAB_JNT_SLIDE) {
+            const float dq = s_qpos[qa] - qpos0[qa];
+            for (int k = 0; k < 3; ++k) pos[k] += xax[k] * dq;
+          } else {
+            float ql[4], qn[4];
+            axis_angle2quat(ql, jax, s_qpos[qa] - qpos0[qa]);
+            mul_quat(qn, quat, ql);
+            for (int k = 0; k < 4; ++k) quat[k] = qn[k];
+            rot_vec_quat(t, jp, quat);
+            for (int k = 0; k < 3; ++k) pos[k] = anc[k] - t[k];
+          }
+          for (int k = 0; k < 3; ++k) { s_xanchor[3 * j + k] = anc[k]; s_xaxis[3 * j + k] = xax[k]; }
+        }
+      }
+      normalize4(quat);
+      float R[9];
+      quat2mat(R, quat);
+      for (int k = 0; k < 3; ++k) s_xpos[3 * i + k] = pos[k];
+      for (int k = 0; k < 4; ++k) s_xquat[4 * i + k] = quat[k];
+      for (int k = 0; k < 9; ++k) s_xmat[9 * i + k] = R[k];
+    }
+    __syncthreads();
+  }
+  // ---- inertial frames, geoms, sites
+  const float *body_ipos = MF(body_ipos), *body_iquat = MF(body_iquat);
+  for (int i = lane; i < nb; i += 64) {
+    float bp[3], bq[4], bm[9], ip[3], iq[4], xp[3], xm[9];
+    for (int k = 0; k < 3; ++k) { bp[k] = s_xpos[3 * i + k]; ip[k] = body_ipos[3 * i + k]; }
+    for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * i + k]; iq[k] = body_iquat[4 * i + k]; }
+    for (int k = 0; k < 9; ++k) bm[k] = s_xmat[9 * i + k];
+    local2global(xp, xm, bp, bq, bm, ip, iq);
+    for (int k = 0; k < 3; ++k) s_xipos[3 * i + k] = xp[k];
+    for (int k = 0; k < 9; ++k) s_ximat[9 * i + k] = xm[k];
+  }
+  {
+    const float *gpos = MF(geom_pos), *gquat = MF(geom_quat);
+    float* gx = d.geom_xpos + (size_t)w * 3 * ng;
+    float* gm = d.geom_xmat + (size_t)w * 9 * ng;
+    for (int g = lane; g < ng; g += 64) {
+      const int b = m.geom_bodyid[g];
+      float bp[3], bq[4], bm[9], ip[3], iq[4], xp[3], xm[9];
+      for (int k = 0; k < 3; ++k) { bp[k] = s_xpos[3 * b + k]; ip[k] = gpos[3 * g + k]; }
+      for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; iq[k] = gquat[4 * g + k]; }
+      for (int k = 0; k < 9; ++k) bm[k] = s_xmat[9 * b + k];
+      local2global(xp, xm, bp, bq, bm, ip, iq);
+      for (int k = 0; k < 3; ++k) gx[3 * g + k] = xp[k];
+      for (int k = 0; k < 9; ++k) gm[9 * g + k] = xm[k];
+    }
+    const float *spos = MF(site_pos), *squat = MF(site_quat);
+    float* sx = d.site_xpos + (size_t)w * 3 * ns;
+    float* sm = d.site_xmat + (size_t)w * 9 * ns;
+    for (int g = lane; g < ns; g += 64) {
+      const int b = m.site_bodyid[g];
+      float bp[3], bq[4], bm[9], ip[3], iq[4], xp[3], xm[9];
+      for (int k = 0; k < 3; ++k) { bp[k] = s_xpos[3 * b + k]; ip[k] = spos[3 * g + k]; }
+      for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; iq[k] = squat[4 * g + k]; }
+      for (int k = 0; k < 9; ++k) bm[k] = s_xmat[9 * b + k];
+      local2global(xp, xm, bp, bq, bm, ip, iq);
+      for (int k = 0; k < 3; ++k) sx[3 * g + k] = xp[k];
+      for (int k = 0; k < 9; ++k) sm[9 * g + k] = xm[k];
+    }
+  }
+  __syncthreads();
+  lds_to_global(d.xpos + (size_t)w * 3 * nb, s_xpos, 3 * nb, lane);
+  lds_to_global(d.xquat + (size_t)w * 4 * nb, s_xquat, 4 * nb, lane);
+  lds_to_global(d.xmat + (size_t)w * 9 * nb, s_xmat, 9 * nb, lane);
+  lds_to_global(d.xipos + (size_t)w * 3 * nb, s_xipos, 3 * nb, lane);
+  lds_to_global(d.ximat + (size_t)w * 9 * nb, s_ximat, 9 * nb, lane);
+  lds_to_global(d.xanchor + (size_t)w * 3 * nj, s_xanchor, 3 * nj, lane);
+  lds_to_global(d.xaxis + (size_t)w * 3 * nj, s_xaxis, 3 * nj, lane);
+
+  // ---- comPos: subtree_com (a subtree is a contiguous body-id range), cinert, cdof
+  const float *mass = MF(body_mass), *stm = MF(body_subtreemass), *inertia = MF(body_inertia);
+  for (int it = lane; it < 3 * nb; it += 64) {
+    const int b = it / 3, c = it - 3 * b, e = b + m.body_subtreenum[b];
+    float acc = 0.f;
+    for (int j = b; j < e; ++j) acc += mass[j] * s_xipos[3 * j + c];
+    const float sm_ = stm[b];
+    s_sub[it] = sm_ < MINVAL ? s_xipos[it] : acc / sm_;
+  }
+  __syncthreads();
+  for (int i = lane; i < nb; i += 64) {
+    float res[10];
+    if (i == 0) {
+      for (int k = 0; k < 10; ++k) res[k] = 0.f;
+    } else {
+      float mat[9], in[3], dif[3], tmp[9];
+      const float ms = mass[i];
+      const int root = m.body_rootid[i];
+      for (int k = 0; k < 9; ++k) mat[k] = s_ximat[9 * i + k];
+      for (int k = 0; k < 3; ++k) { in[k] = inertia[3 * i + k]; dif[k] = s_xipos[3 * i + k] - s_sub[3 * root + k]; }
+      tmp[0] = mat[0] * in[0]; tmp[1] = mat[3] * in[0]; tmp[2] = mat[6] * in[0];
+      tmp[3] = mat[1] * in[1]; tmp[4] = mat[4] * in[1]; tmp[5] = mat[7] * in[1];
+      tmp[6] = mat[2] * in[2]; tmp[7] = mat[5] * in[2]; tmp[8] = mat[8] * in[2];
+      res[0] = mat[0] * tmp[0] + mat[1] * tmp[3] + mat[2] * tmp[6];
+      res[1] = mat[3] * tmp[1] + mat[4] * tmp[4] + mat[5] * tmp[7];
+      res[2] = mat[6] * tmp[2] + mat[7] * tmp[5] + mat[8] * tmp[8];
+      res[3] = mat[0] * tmp[1] + mat[1] * tmp[4] + mat[2] * tmp[7];
+      res[4] = mat[0] * tmp[2] + mat[1] * tmp[5] + mat[2] * tmp[8];
+      res[5] = mat[3] * tmp[2] + mat[4] * tmp[5] + mat[5] * tmp[8];
+      res[0] += ms * (dif[1] * dif[1] + dif[2] * dif[2]);
+      res[1] += ms * (dif[0] * dif[0] + dif[2] * dif[2]);
+      res[2] += ms * (dif[0] * dif[0] + dif[1] * dif[1]);
+      res[3] -= ms * dif[0] * dif[1];
+      res[4] -= ms * dif[0] * dif[2];
+      res[5] -= ms * dif[1] * dif[2];
+      res[6] = ms * dif[0]; res[7] = ms * dif[1]; res[8] = ms * dif[2];
+      res[9] = ms;
+    }
+    for (int k = 0; k < 10; ++k) s_cinert[10 * i + k] = res[k];
+  }
+  for (int i = lane; i < nv; i += 64) {
+    const int j = m.dof_jntid[i], b = m.jnt_bodyid[j], k = i - m.jnt_dofadr[j], type = m.jnt_type[j];
+    const int root = m.body_rootid[b];
+    float off[3], c6[6];
+    for (int a = 0; a < 3; ++a) off[a] = s_sub[3 * root + a] - s_xanchor[3 * j + a];
+    if (type == MJLAB_JNT_FREE && k < 3) {
+      for (int a = 0; a < 6; ++a) c6[a] = (a == 3 + k) ? 1.f : 0.f;
+    } else if (type == MJLAB_JNT_FREE) {
+      float ax[3] = {s_xmat[9 * b + (k - 3)], s_xmat[9 * b + 3 + (k - 3)], s_xmat[9 * b + 6 + (k - 3)]};
+      for (int a = 0; a < 3; ++a) c6[a] = ax[a];
+      cross3(c6 + 3, ax, off);
+    } else if (type == MJLAB_JNT_SLIDE) {
+      for (int a = 0; a < 3; ++a) { c6[a] = 0.f; c6[3 + a] = s_xaxis[3 * j + a]; }
+    } else {
+      float ax[3] = {s_xaxis[3 * j], s_xaxis[3 * j + 1], s_xaxis[3 * j + 2]};
+      for (int a = 0; a < 3; ++a) c6[a] = ax[a];
+      cross3(c6 + 3, ax, off);
+    }
+    for (int a = 0; a < 6; ++a) s_cdof[6 * i + a] = c6[a];
+  }
+  __syncthreads();
+  lds_to_global(d.subtree_com + (size_t)w * 3 * nb, s_sub, 3 * nb, lane);
+  lds_to_global(d.cinert + (size_t)w * 10 * nb, s_cinert, 10 * nb, lane);
+  lds_to_global(d.cdof + (size_t)w * 6 * nv, s_cdof, 6 * nv, lane);
+
+  // ---- crb: composite inertia = sum of cinert over the subtree range
+  for (int it = lane; it < 10 * nb; it += 64) {
+    const int b = it / 10, c = it - 10 * b, e = b + m.body_subtreenum[b];
+    float acc = 0.f;
+    for (int j = b; j < e; ++j) acc += s_cinert[10 * j + c];
+    s_crb[it] = acc;
+  }
+  __syncthreads();
+  for (int i = lane; i < nv; i += 64) {
+    float in[10], v[6], r[6];
+    const int b = m.dof_bodyid[i];
+    for (int k = 0; k < 10; ++k) in[k] = s_crb[10 * b + k];
+    for (int k = 0; k < 6; ++k) v[k] = s_cdof[6 * i + k];
+    mul_inert_vec(r, in, v);
+    for (int k = 0; k < 6; ++k) s_buf[6 * i + k] = r[k];
+  }
+  __syncthreads();
+  // M[i][j] = cdof_j . (crb_i cdof_i) for j an ancestor dof of i (or i itself), else 0
+  const float* arm = MF(dof_armature);
+  for (int i = 0; i < nv; ++i) {
+    const int bi = m.dof_bodyid[i];
+    if (lane <= i) {
+      float v = 0.f;
+      if (dof_in_chain(m, bi, lane)) {
+        for (int k = 0; k < 6; ++k) v += s_cdof[6 * lane + k] * s_buf[6 * i + k];
+      }
+      if (lane == i) v += arm[i];
+      s_M[i * ld + lane] = v;
+      s_M[lane * ld + i] = v;
+    }
+  }
+  __syncthreads();
+  {
+    float* qM = d.qM + (size_t)w * nv * nv;
+    for (int k = lane; k < nv * nv; k += 64) { int i = k / nv, j = k - i * nv; qM[k] = s_M[i * ld + j]; }
+  }
+  __syncthreads();
+  chol_factor_lds(s_M, s_invd, nv, ld, lane);
+  {
+    float* qLD = d.qLD + (size_t)w * nv * nv;
+    for (int k = lane; k < nv * nv; k += 64) { int i = k / nv, j = k - i * nv; qLD[k] = j <= i ? s_M[i * ld + j] : 0.f; }
+  }
+}
+
+// ====================================================================================
+// Stage 2: collision (static candidate pair list; plane/sphere/capsule/box primitives)
+// ====================================================================================
+struct RawCon { float dist, pos[3], frame[6]; };
+
+__device__ __forceinline__ int plane_sphere(RawCon* c, float margin, const float* ppos, const float* pn, const float* spos, float r) {
+  float dif[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
+  float cdist = dot3(dif, pn);
+  if (cdist > margin + r) return 0;
+  c->dist = cdist - r;
+  for (int k = 0; k < 3; ++k) { c->pos[k] = spos[k] + pn[k] * (-c->dist * 0.5f - r); c->frame[k] = pn[k]; c->frame[3 + k] = 0.f; }
+  return 1;
+}
+__device__ __forceinline__ int sphere_sphere(RawCon* c, float margin, const float* p1, float r1, const float* p2, float r2) {
+  float dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  float cd2 = dot3(dif, dif), mn = margin + r1 + r2;
+  if (cd2 > mn * mn) return 0;
+  float len = sqrtf(cd2);
+  if (len < MINVAL) { dif[0] = 1.f; dif[1] = dif[2] = 0.f; }
+  else { float inv = 1.0f / len; dif[0] *= inv; dif[1] *= inv; dif[2] *= inv; }
+  c->dist = len - r1 - r2;
+  for (int k = 0; k < 3; ++k) { c->pos[k] = p1[k] + dif[k] * (r1 + c->dist * 0.5f); c->frame[k] = dif[k]; c->frame[3 + k] = 0.f; }
+  return 1;
+}
+__device__ int capsule_capsule(RawCon* c, float margin, const float* pos1, const float* axis1, const float* size1,
+                               const float* pos2, const float* axis2, const float* size2) {
+  float dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  float ma = dot3(axis1, axis1), mb = -dot3(axis1, axis2), mc = dot3(axis2, axis2);
+  float u = -dot3(axis1, dif), v = dot3(axis2, dif), det = ma * mc - mb * mb;
+  float vec1[3], vec2[3];
+  if (fabsf(det) >= MINVAL) {
+    float x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > size1[1]) { x1 = size1[1]; x2 = (v - mb * size1[1]) / mc; }
+    else if (x1 < -size1[1]) { x1 = -size1[1]; x2 = (v + mb * size1[1]) / mc; }
+    if (x2 > size2[1]) { x2 = size2[1]; x1 = clipf((u - mb * size2[1]) / ma, -size1[1], size1[1]); }
+    else if (x2 < -size2[1]) { x2 = -size2[1]; x1 = clipf((u + mb * size2[1]) / ma, -size1[1], size1[1]); }
+    for (int k = 0; k < 3; ++k) { vec1[k] = pos1[k] + axis1[k] * x1; vec2[k] = pos2[k] + axis2[k] * x2; }
+    return sphere_sphere(c, margin, vec1, size1[0], vec2, size2[0]);
+  }
+  int n = 0;
+  float x2;
+  for (int k = 0; k < 3; ++k) vec1[k] = pos1[k] + axis1[k] * size1[1];
+  x2 = clipf((v - mb * size1[1]) / mc, -size2[1], size2[1]);
+  for (int k = 0; k < 3; ++k) vec2[k] = pos2[k] + axis2[k] * x2;
+  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  for (int k = 0; k < 3; ++k) vec1[k] = pos1[k] - axis1[k] * size1[1];
+  x2 = clipf((v + mb * size1[1]) / mc, -size2[1], size2[1]);
+  for (int k = 0; k < 3; ++k) vec2[k] = pos2[k] + axis2[k] * x2;
+  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  if (n == 2) return n;
+  float x1;
+  for (int k = 0; k < 3; ++k) vec2[k] = pos2[k] + axis2[k] * size2[1];
+  x1 = clipf((u - mb * size2[1]) / ma, -size1[1], size1[1]);
+  for (int k = 0; k < 3; ++k) vec1[k] = pos1[k] + axis1[k] * x1;
+  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  if (n == 2) return n;
+  for (int k = 0; k < 3; ++k) vec2[k] = pos2[k] - axis2[k] * size2[1];
+  x1 = clipf((u + mb * size2[1]) / ma, -size1[1], size1[1]);
+  for (int k = 0; k < 3; ++k) vec1[k] = pos1[k] + axis1[k] * x1;
+  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  return n;
+}
+
+__device__ __forceinline__ void make_frame(float* f9, const float* f6) {
+  float x[3] = {f6[0], f6[1], f6[2]}, y[3] = {f6[3], f6[4], f6[5]};
+  if (sqrtf(dot3(y, y)) < 0.5f) {
+    y[0] = y[1] = y[2] = 0.f;
+    if (x[1] < 0.5f && x[1] > -0.5f) y[1] = 1.f; else y[2] = 1.f;
+  }
+  float t = dot3(x, y);
+  y[0] -= t * x[0]; y[1] -= t * x[1]; y[2] -= t * x[2];
+  normalize3(y);
+  float z[3];
+  cross3(z, x, y);
+  for (int k = 0; k < 3; ++k) { f9[k] = x[k]; f9[3 + k] = y[k]; f9[6 + k] = z[k]; }
+}
+
+__host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) { return 12 * s.ngeom; }
+
+__global__ __launch_bounds__(64) void k_collision(const Model m, const Data d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int ng = m.size.ngeom, ncm = m.size.nconmax, npair = m.size.npair;
+  float* s_gx = smem;
+  float* s_gm = s_gx + 3 * ng;
+  global_to_lds(s_gx, d.geom_xpos + (size_t)w * 3 * ng, 3 * ng, lane);
+  global_to_lds(s_gm, d.geom_xmat + (size_t)w * 9 * ng, 9 * ng, lane);
+  __syncthreads();
+  const float *gsize = MF(geom_size), *rbound = MF(geom_rbound), *gmargin = MF(geom_margin), *ggap = MF(geom_gap);
+  const float *gfri = MF(geom_friction), *gsolref = MF(geom_solref), *gsolimp = MF(geom_solimp), *gsolmix = MF(geom_solmix);
+  int base = 0;  // contacts emitted so far (wave-uniform)
+  for (int p0 = 0; p0 < npair; p0 += 64) {
+    const int p = p0 + lane;
+    RawCon rc[4];
+    int n = 0, g1 = 0, g2 = 0;
+    float margin = 0.f, gap = 0.f;
+    if (p < npair) {
+      g1 = m.pair_geom[2 * p]; g2 = m.pair_geom[2 * p + 1];
+      const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+      margin = fmaxf(gmargin[g1], gmargin[g2]);
+      gap = fmaxf(ggap[g1], ggap[g2]);
+      float p1[3], p2[3], z1[3], z2[3], s1[3], s2[3];
+      for (int k = 0; k < 3; ++k) {
+        p1[k] = s_gx[3 * g1 + k]; p2[k] = s_gx[3 * g2 + k];
+        z1[k] = s_gm[9 * g1 + 3 * k + 2]; z2[k] = s_gm[9 * g2 + 3 * k + 2];
+        s1[k] = gsize[3 * g1 + k]; s2[k] = gsize[3 * g2 + k];
+      }
+      bool near;
+      float dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+      if (t1 == MJLAB_GEOM_PLANE) near = dot3(dif, z1) <= margin + rbound[g2];
+      else { float bound = margin + rbound[g1] + rbound[g2]; near = dot3(dif, dif) <= bound * bound; }
+      if (near) {
+        if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_SPHERE) {
+          n = plane_sphere(rc, margin, p1, z1, p2, s2[0]);
+        } else if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_CAPSULE) {
+          float q[3];
+          for (int k = 0; k < 3; ++k) q[k] = p2[k] + z2[k] * s2[1];
+          if (plane_sphere(rc + n, margin, p1, z1, q, s2[0])) { for (int k = 0; k < 3; ++k) rc[n].frame[3 + k] = z2[k]; n++; }
+          for (int k = 0; k < 3; ++k) q[k] = p2[k] - z2[k] * s2[1];
+          if (plane_sphere(rc + n, margin, p1, z1, q, s2[0])) { for (int k = 0; k < 3; ++k) rc[n].frame[3 + k] = z2[k]; n++; }
+        } else if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_BOX) {
+          const float dist = dot3(dif, z1);
+          float bm[9];
+          for (int k = 0; k < 9; ++k) bm[k] = s_gm[9 * g2 + k];
+          for (int i = 0; i < 8 && n < 4; ++i) {
+            float vec[3] = {(i & 1) ? s2[0] : -s2[0], (i & 2) ? s2[1] : -s2[1], (i & 4) ? s2[2] : -s2[2]}, corner[3];
+            mul_mat_vec3(corner, bm, vec);
+            const float ldist = dot3(z1, corner);
+            if (dist + ldist > margin || ldist > 0.f) continue;
+            rc[n].dist = dist + ldist;
+            for (int k = 0; k < 3; ++k) {
+              rc[n].pos[k] = corner[k] + p2[k] + z1[k] * (-rc[n].dist * 0.5f);
+              rc[n].frame[k] = z1[k]; rc[n].frame[3 + k] = 0.f;
+            }
+            n++;
+          }
+        } else if (t1 == MJLAB_GEOM_SPHERE && t2 == MJLAB_GEOM_SPHERE) {
+          n = sphere_sphere(rc, margin, p1, s1[0], p2, s2[0]);
+        } else if (t1 == MJLAB_GEOM_SPHERE && t2 == MJLAB_GEOM_CAPSULE) {
+          float vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+          const float x = clipf(dot3(z2, vec), -s2[1], s2[1]);
+          for (int k = 0; k < 3; ++k) vec[k] = p2[k] + z2[k] * x;
+          n = sphere_sphere(rc, margin, p1, s1[0], vec, s2[0]);
+        } else if (t1 == MJLAB_GEOM_CAPSULE && t2 == MJLAB_GEOM_CAPSULE) {
+          n = capsule_capsule(rc, margin, p1, z1, s1, p2, z2, s2);
+        }
+      }
+    }
+    int total;
+    const int off = wave_excl_scan(n, lane, &total);
+    if (n > 0) {
+      // contact parameters (mj_contactParam)
+      int condim;
+      float fri[3], solref[2], solimp[5];
+      const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+      if (pr1 != pr2) {
+        const int gi = pr1 > pr2 ? g1 : g2;
+        condim = m.geom_condim[gi];
+        for (int k = 0; k < 3; ++k) fri[k] = gfri[3 * gi + k];
+        for (int k = 0; k < 2; ++k) solref[k] = gsolref[2 * gi + k];
+        for (int k = 0; k < 5; ++k) solimp[k] = gsolimp[5 * gi + k];
+      } else {
+        condim = max(m.geom_condim[g1], m.geom_condim[g2]);
+        for (int k = 0; k < 3; ++k) fri[k] = fmaxf(gfri[3 * g1 + k], gfri[3 * g2 + k]);
+        const float sm1 = gsolmix[g1], sm2 = gsolmix[g2];
+        float mix;
+        if (sm1 >= MINVAL && sm2 >= MINVAL) mix = sm1 / (sm1 + sm2);
+        else if (sm1 < MINVAL && sm2 < MINVAL) mix = 0.5f;
+        else if (sm1 < MINVAL) mix = 0.f;
+        else mix = 1.f;
+        if (gsolref[2 * g1] > 0.f && gsolref[2 * g2] > 0.f)
+          for (int k = 0; k < 2; ++k) solref[k] = mix * gsolref[2 * g1 + k] + (1.f - mix) * gsolref[2 * g2 + k];
+        else
+          for (int k = 0; k < 2; ++k) solref[k] = fminf(gsolref[2 * g1 + k], gsolref[2 * g2 + k]);
+        for (int k = 0; k < 5; ++k) solimp[k] = mix * gsolimp[5 * g1 + k] + (1.f - mix) * gsolimp[5 * g2 + k];
+      }
+      for (int i = 0; i < n; ++i) {
+        const int c = base + off + i;
+        if (c >= ncm) break;
+        float f9[9];
+        make_frame(f9, rc[i].frame);
+        const size_t wc = (size_t)w * ncm + c;
+        d.contact_dist[wc] = rc[i].dist;
+        for (int k = 0; k < 3; ++k) d.contact_pos[3 * wc + k] = rc[i].pos[k];
+        for (int k = 0; k < 9; ++k) d.contact_frame[9 * wc + k] = f9[k];
+        d.contact_includemargin[wc] = margin - gap;
+        float* f5 = d.contact_friction + 5 * wc;
+        f5[0] = f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = f5[4] = fri[2];
+        for (int k = 0; k < 2; ++k) d.contact_solref[2 * wc + k] = solref[k];
+        for (int k = 0; k < 5; ++k) d.contact_solimp[5 * wc + k] = solimp[k];
+        d.contact_dim[wc] = condim;
+        d.contact_geom[2 * wc] = g1;
+        d.contact_geom[2 * wc + 1] = g2;
+        d.contact_efc_address[wc] = -1;
+      }
+    }
+    base += total;
+  }
+  if (lane == 0) d.ncon[w] = base < ncm ? base : ncm;
+}
+
+// ====================================================================================
+// Stage 3: velocity + smooth forces (mj_comVel, mj_passive, mj_rne, mj_fwdActuation)
+// ====================================================================================
+__host__ __device__ inline int velocity_lds_floats(const mjlab_sizes_t& s) {
+  return 2 * s.nv + 12 * s.nv + 10 * s.nbody + 24 * s.nbody;
+}
+
+__global__ __launch_bounds__(64) void k_velocity(const Model m, const Data d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt;
+  float* s_qvel = smem;
+  float* s_qact = s_qvel + nv;
+  float* s_cdof = s_qact + nv;
+  float* s_cdd = s_cdof + 6 * nv;
+  float* s_cinert = s_cdd + 6 * nv;
+  float* s_cvel = s_cinert + 10 * nb;
+  float* s_cacc = s_cvel + 6 * nb;
+  float* s_cfrc = s_cacc + 6 * nb;
+  float* s_cfs = s_cfrc + 6 * nb;
+  global_to_lds(s_qvel, d.qvel + (size_t)w * nv, nv, lane);
+  global_to_lds(s_cdof, d.cdof + (size_t)w * 6 * nv, 6 * nv, lane);
+  global_to_lds(s_cinert, d.cinert + (size_t)w * 10 * nb, 10 * nb, lane);
+  if (lane < 6) {
+    s_cvel[lane] = 0.f;
+    s_cacc[lane] = lane < 3 ? 0.f : -(float)m.opt.gravity[lane - 3];
+    s_cfrc[lane] = 0.f;
+  }
+  for (int i = lane; i < nv; i += 64) s_qact[i] = 0.f;
+  __syncthreads();
+  // ---- down-sweep by level: cvel, cdof_dot, cacc, cfrc_body
+  for (int L = 1; L < m.size.nlevel; ++L) {
+    const int a0 = m.level_adr[L], a1 = m.level_adr[L + 1];
+    for (int idx = a0 + lane; idx < a1; idx += 64) {
+      const int i = m.level_body[idx];
+      const int pid = m.body_parentid[i], ja = m.body_jntadr[i], jn = m.body_jntnum[i];
+      float v[6], a[6];
+      for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * pid + k]; a[k] = s_cacc[6 * pid + k]; }
+      for (int j = ja; j < ja + jn; ++j) {
+        const int da = m.jnt_dofadr[j];
+        if (m.jnt_type[j] == MJLAB_JNT_FREE) {
+          for (int k = 0; k < 3; ++k) {
+            const float qv = s_qvel[da + k];
+            for (int c = 0; c < 6; ++c) { v[c] += s_cdof[6 * (da + k) + c] * qv; s_cdd[6 * (da + k) + c] = 0.f; }
+          }
+          float cd[3][6];
+          for (int k = 0; k < 3; ++k) {
+            float c6[6];
+            for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * (da + 3 + k) + c];
+            cross_motion(cd[k], v, c6);
+          }
+          for (int k = 0; k < 3; ++k) {
+            const float qv = s_qvel[da + 3 + k];
+            for (int c = 0; c < 6; ++c) {
+              v[c] += s_cdof[6 * (da + 3 + k) + c] * qv;
+              a[c] += cd[k][c] * qv;
+              s_cdd[6 * (da + 3 + k) + c] = cd[k][c];
+            }
+          }
+        } else {
+          float c6[6], cd[6];
+          const float qv = s_qvel[da];
+          for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * da + c];
+          cross_motion(cd, v, c6);
+          for (int c = 0; c < 6; ++c) { v[c] += c6[c] * qv; a[c] += cd[c] * qv; s_cdd[6 * da + c] = cd[c]; }
+        }
+      }
+      float in[10], t1[6], t2[6], t3[6];
+      for (int k = 0; k < 10; ++k) in[k] = s_cinert[10 * i + k];
+      mul_inert_vec(t1, in, a);
+      mul_inert_vec(t2, in, v);
+      cross_force(t3, v, t2);
+      for (int k = 0; k < 6; ++k) { s_cvel[6 * i + k] = v[k]; s_cacc[6 * i + k] = a[k]; s_cfrc[6 * i + k] = t1[k] + t3[k]; }
+    }
+    __syncthreads();
+  }
+  lds_to_global(d.cvel + (size_t)w * 6 * nb, s_cvel, 6 * nb, lane);
+  lds_to_global(d.cdof_dot + (size_t)w * 6 * nv, s_cdd, 6 * nv, lane);
+  // ---- up-sweep as subtree range sums
+  for (int it = lane; it < 6 * nb; it += 64) {
+    const int b = it / 6, c = it - 6 * b, e = b + m.body_subtreenum[b];
+    float acc = 0.f;
+    for (int j = b; j < e; ++j) acc += s_cfrc[6 * j + c];
+    s_cfs[it] = acc;
+  }
+  __syncthreads();
+  // ---- actuation (joint transmission, fixed gain, affine bias)
+  {
+    const float *gain = MF(actuator_gainprm), *biasprm = MF(actuator_biasprm), *crange = MF(actuator_ctrlrange),
+                *frange = MF(actuator_forcerange), *gear = MF(actuator_gear);
+    const float* qpos = d.qpos + (size_t)w * nq;
+    const float* ctrl = d.ctrl + (size_t)w * nu;
+    for (int a = lane; a < nu; a += 64) {
+      const int j = m.actuator_trnid[2 * a], qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+      const float g = gear[6 * a];
+      float c = ctrl[a];
+      if (m.actuator_ctrllimited[a]) c = clipf(c, crange[2 * a], crange[2 * a + 1]);
+      const float len = g * qpos[qa], vel = g * s_qvel[da];
+      float f = gain[10 * a] * c + biasprm[10 * a] + biasprm[10 * a + 1] * len + biasprm[10 * a + 2] * vel;
+      if (m.actuator_forcelimited[a]) f = clipf(f, frange[2 * a], frange[2 * a + 1]);
+      d.actuator_force[(size_t)w * nu + a] = f;
+      atomicAdd(&s_qact[da], g * f);
+    }
+  }
+  __syncthreads();
+  // ---- bias, passive, smooth force; lanes = dofs
+  const float *damping = MF(dof_damping), *stiff = MF(jnt_stiffness), *qpos0 = MF(qpos0);
+  const float* xfrc = d.xfrc_applied + (size_t)w * 6 * nb;
+  // bodies with a nonzero Cartesian perturbation (usually none)
+  unsigned long long xmask_total = 0ull;
+  for (int b0 = 0; b0 < nb; b0 += 64) {
+    const int b = b0 + lane;
+    bool nz = false;
+    if (b > 0 && b < nb) for (int k = 0; k < 6; ++k) nz |= xfrc[6 * b + k] != 0.f;
+    const unsigned long long mk = __ballot(nz);
+    if (mk) {
+      xmask_total |= mk;
+    }
+  }
+  for (int i0 = 0; i0 < nv; i0 += 64) {
+    const int i = i0 + lane;
+    if (i >= nv) break;
+    const int bi = m.dof_bodyid[i], j = m.dof_jntid[i];
+    float c6[6];
+    for (int k = 0; k < 6; ++k) c6[k] = s_cdof[6 * i + k];
+    float bias = 0.f;
+    for (int k = 0; k < 6; ++k) bias += c6[k] * s_cfs[6 * bi + k];
+    float passive = -damping[i] * s_qvel[i];
+    if (m.jnt_type[j] != MJLAB_JNT_FREE && stiff[j] != 0.f) {
+      const int qa = m.jnt_qposadr[j];
+      passive -= stiff[j] * (d.qpos[(size_t)w * nq + qa] - qpos0[qa]);
+    }
+    float smooth = passive - bias + d.qfrc_applied[(size_t)w * nv + i] + s_qact[i];
+    if (xmask_total) {
+      const float* xipos = d.xipos + (size_t)w * 3 * nb;
+      const float* sub = d.subtree_com + (size_t)w * 3 * nb;
+      for (int b = 1; b < nb; ++b) {
+        float f[6];
+        bool nz = false;
+        for (int k = 0; k < 6; ++k) { f[k] = xfrc[6 * b + k]; nz |= f[k] != 0.f; }
+        if (!nz || !dof_in_chain(m, b, i)) continue;
+        const int root = m.body_rootid[b];
+        float off[3], jp[3];
+        for (int k = 0; k < 3; ++k) off[k] = xipos[3 * b + k] - sub[3 * root + k];
+        cross3(jp, c6, off);
+        for (int k = 0; k < 3; ++k) jp[k] += c6[3 + k];
+        smooth += dot3(jp, f) + dot3(c6, f + 3);
+      }
+    }
+    d.qfrc_bias[(size_t)w * nv + i] = bias;
+    d.qfrc_passive[(size_t)w * nv + i] = passive;
+    d.qfrc_actuator[(size_t)w * nv + i] = s_qact[i];
+    d.qfrc_smooth[(size_t)w * nv + i] = smooth;
+  }
+  (void)nj;
+}
+
+// ====================================================================================
+// Stage 4: constraints (mj_makeConstraint: joint limits + contacts; contact sensors)
+// ====================================================================================
+__device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
+  const float dmin = clipf(solimp[0], MINIMP, MAXIMP), dmax = clipf(solimp[1], MINIMP, MAXIMP);
+  const float width = fmaxf(solimp[2], MINVAL);
+  const float mid = clipf(solimp[3], MINIMP, MAXIMP), power = fmaxf(solimp[4], 1.f);
+  float x = fabsf((pos - margin) / width);
+  float y;
+  if (x >= 1.f) y = 1.f;
+  else if (x == 0.f) y = 0.f;
+  else if (x <= mid) y = (power == 2.f) ? x * x / mid : powf(x, power) / powf(mid, power - 1.f);
+  else {
+    const float omx = 1.f - x, omm = 1.f - mid;
+    y = 1.f - ((power == 2.f) ? omx * omx / omm : powf(omx, power) / powf(omm, power - 1.f));
+  }
+  return dmin + y * (dmax - dmin);
+}
+// reference acceleration and regulariser of one row
+__device__ __forceinline__ void row_params(float timestep, const float* solref, const float* solimp, float pos, float margin,
+                                           float vel, float diag_approx, float* aref, float* R) {
+  const float imp = impedance(solimp, pos, margin);
+  const float dmax = clipf(solimp[1], MINIMP, MAXIMP);
+  float k, b;
+  if (solref[0] > 0.f) {
+    const float tc = fmaxf(solref[0], 2.f * timestep), dr = solref[1];
+    k = 1.f / fmaxf(dmax * dmax * tc * tc * dr * dr, MINVAL);
+    b = 2.f / fmaxf(dmax * tc, MINVAL);
+  } else {
+    k = -solref[0] / fmaxf(dmax * dmax, MINVAL);
+    b = -solref[1] / fmaxf(dmax, MINVAL);
+  }
+  *R = fmaxf((1.f - imp) / imp * diag_approx, MINVAL);
+  *aref = -b * vel - k * imp * (pos - margin);
+}
+
+__host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) { return s.nconmax + 2 * s.njmax; }
+
+__global__ __launch_bounds__(64) void k_constraint(const Model m, const Data d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ncm = m.size.nconmax, njm = m.size.njmax;
+  int* s_cadr = (int*)smem;            // contact -> first efc row (or -1)
+  int* s_ldof = s_cadr + ncm;          // limit row -> dof
+  float* s_lsign = (float*)(s_ldof + njm);  // limit row -> Jacobian entry (+-1)
+  const float timestep = (float)m.opt.timestep;
+  float* J = d.efc_J + (size_t)w * njm * nv;
+  const size_t wr = (size_t)w * njm;
+  int nefc = 0;
+  // ---- joint limits: lanes = joints, rows assigned in (joint, side) order
+  {
+    const float *range = MF(jnt_range), *jmargin = MF(jnt_margin), *jsolref = MF(jnt_solref), *jsolimp = MF(jnt_solimp),
+                *dinv = MF(dof_invweight0);
+    const float* qpos = d.qpos + (size_t)w * nq;
+    const float* qvel = d.qvel + (size_t)w * nv;
+    for (int j0 = 0; j0 < nj; j0 += 64) {
+      const int j = j0 + lane;
+      float dist[2] = {0.f, 0.f};
+      int act[2] = {0, 0};
+      float mg = 0.f;
+      int da = 0;
+      if (j < nj && m.jnt_limited[j] && m.jnt_type[j] != MJLAB_JNT_FREE) {
+        const float value = qpos[m.jnt_qposadr[j]];
+        mg = jmargin[j];
+        da = m.jnt_dofadr[j];
+        dist[0] = value - range[2 * j];
+        dist[1] = range[2 * j + 1] - value;
+        act[0] = dist[0] < mg;
+        act[1] = dist[1] < mg;
+      }
+      int total;
+      int off = nefc + wave_excl_scan(act[0] + act[1], lane, &total);
+      for (int side = 0; side < 2; ++side) {
+        if (!act[side]) continue;
+        const int r = off++;
+        if (r >= njm) continue;
+        const float sgn = side == 0 ? 1.f : -1.f;
+        float aref, R;
+        row_params(timestep, jsolref + 2 * j, jsolimp + 5 * j, dist[side], mg, sgn * qvel[da], dinv[da], &aref, &R);
+        s_ldof[r] = da;
+        s_lsign[r] = sgn;
+        d.efc_pos[wr + r] = dist[side];
+        d.efc_margin[wr + r] = mg;
+        d.efc_D[wr + r] = 1.f / R;
+        d.efc_aref[wr + r] = aref;
+        d.efc_type[wr + r] = MJLAB_EFC_LIMIT;
+        d.efc_id[wr + r] = j;
+      }
+      nefc = min(nefc + total, njm);
+    }
+    __syncthreads();
+    for (int r = 0; r < nefc; ++r) {
+      const int dof = s_ldof[r];
+      const float sg = s_lsign[r];
+      for (int i = lane; i < nv; i += 64) J[(size_t)r * nv + i] = (i == dof) ? sg : 0.f;
+    }
+  }
+  // ---- contacts: one contact at a time, lanes = dofs
+  const int ncon = d.ncon[w];
+  const float* binv = MF(body_invweight0);
+  const float* sub = d.subtree_com + (size_t)w * 3 * nb;
+  const float impratio_rs = sqrtf(1.f / (float)m.opt.impratio);
+  float c6[6], qv = 0.f;  // this lane's dof (nv <= 64)
+  for (int k = 0; k < 6; ++k) c6[k] = lane < nv ? d.cdof[((size_t)w * nv + lane) * 6 + k] : 0.f;
+  if (lane < nv) qv = d.qvel[(size_t)w * nv + lane];
+  for (int c = 0; c < ncon; ++c) {
+    const size_t wc = (size_t)w * ncm + c;
+    const int dim = d.contact_dim[wc];
+    const float dist = d.contact_dist[wc], inc = d.contact_includemargin[wc];
+    const int nrow = dim == 1 ? 1 : 2 * (dim - 1);
+    if (dist >= inc || nefc + nrow > njm) {
+      if (lane == 0) { s_cadr[c] = -1; d.contact_efc_address[wc] = -1; }
+      continue;
+    }
+    const int g1 = d.contact_geom[2 * wc], g2 = d.contact_geom[2 * wc + 1];
+    const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+    float pos[3], frame[9], fri[5], solref[2], solimp[5];
+    for (int k = 0; k < 3; ++k) pos[k] = d.contact_pos[3 * wc + k];
+    for (int k = 0; k < 9; ++k) frame[k] = d.contact_frame[9 * wc + k];
+    for (int k = 0; k < 5; ++k) { fri[k] = d.contact_friction[5 * wc + k]; solimp[k] = d.contact_solimp[5 * wc + k]; }
+    for (int k = 0; k < 2; ++k) solref[k] = d.contact_solref[2 * wc + k];
+    float jf[3] = {0.f, 0.f, 0.f};
+    if (lane < nv) {
+      const int bodies[2] = {b1, b2};
+      for (int side = 0; side < 2; ++side) {
+        const int b = bodies[side];
+        if (!dof_in_chain(m, b, lane)) continue;
+        const int root = m.body_rootid[b];
+        float off[3], jp[3];
+        for (int k = 0; k < 3; ++k) off[k] = pos[k] - sub[3 * root + k];
+        cross3(jp, c6, off);
+        for (int k = 0; k < 3; ++k) jp[k] += c6[3 + k];
+        const float sgn = side ? 1.f : -1.f;
+        for (int a = 0; a < 3; ++a) jf[a] += sgn * dot3(frame + 3 * a, jp);
+      }
+    }
+    const float v0 = wave_sum(jf[0] * qv);
+    const float tran = binv[2 * b1] + binv[2 * b2];
+    if (lane == 0) { s_cadr[c] = nefc; d.contact_efc_address[wc] = nefc; }
+    if (dim == 1) {
+      float aref, R;
+      row_params(timestep, solref, solimp, dist, inc, v0, tran, &aref, &R);
+      if (lane < nv) J[(size_t)nefc * nv + lane] = jf[0];
+      if (lane == 0) {
+        d.efc_pos[wr + nefc] = dist; d.efc_margin[wr + nefc] = inc; d.efc_D[wr + nefc] = 1.f / R; d.efc_aref[wr + nefc] = aref;
+        d.efc_type[wr + nefc] = MJLAB_EFC_CONTACT_FRICTIONLESS; d.efc_id[wr + nefc] = c;
+      }
+      nefc += 1;
+    } else {
+      const float v1 = wave_sum(jf[1] * qv), v2 = wave_sum(jf[2] * qv);
+      float Rfirst = 0.f;
+      for (int r = 0; r < nrow; ++r) {
+        const int kk = 1 + (r >> 1);
+        const float mu = fri[kk - 1], sg = (r & 1) ? -mu : mu;
+        const float vel = v0 + sg * (kk == 1 ? v1 : v2);
+        float aref, R;
+        row_params(timestep, solref, solimp, dist, inc, vel, tran + mu * mu * tran, &aref, &R);
+        if (r == 0) Rfirst = R;
+        if (lane < nv) J[(size_t)(nefc + r) * nv + lane] = jf[0] + sg * (kk == 1 ? jf[1] : jf[2]);
+        if (lane == 0) {
+          const float mu0 = fri[0] * impratio_rs;
+          const float Rpy = fmaxf(2.f * mu0 * mu0 * Rfirst, MINVAL);
+          d.efc_pos[wr + nefc + r] = dist; d.efc_margin[wr + nefc + r] = inc; d.efc_D[wr + nefc + r] = 1.f / Rpy;
+          d.efc_aref[wr + nefc + r] = aref;
+          d.efc_type[wr + nefc + r] = MJLAB_EFC_CONTACT_PYRAMIDAL; d.efc_id[wr + nefc + r] = c;
+        }
+      }
+      nefc += nrow;
+    }
+  }
+  if (lane == 0) d.nefc[w] = nefc;
+  __syncthreads();
+  // ---- contact sensors ("found" data spec): count of matching contacts that are in efc
+  const int nsens = m.size.nsensor;
+  for (int k = 0; k < nsens; ++k) {
+    const int ot = m.sensor_objtype[k], oi = m.sensor_objid[k], rt = m.sensor_reftype[k], ri = m.sensor_refid[k];
+    int cnt = 0;
+    for (int c0 = 0; c0 < ncon; c0 += 64) {
+      const int c = c0 + lane;
+      bool hit = false;
+      if (c < ncon && s_cadr[c] >= 0) {
+        const size_t wc = (size_t)w * ncm + c;
+        const int g[2] = {d.contact_geom[2 * wc], d.contact_geom[2 * wc + 1]};
+        bool mo[2], mr[2];
+        for (int s = 0; s < 2; ++s) {
+          const int b = m.geom_bodyid[g[s]];
+          mo[s] = ot == MJLAB_OBJ_GEOM ? g[s] == oi : ot == MJLAB_OBJ_BODY ? b == oi : (b >= oi && b < oi + m.body_subtreenum[oi]);
+          mr[s] = rt < 0 ? true : rt == MJLAB_OBJ_GEOM ? g[s] == ri : rt == MJLAB_OBJ_BODY ? b == ri : (b >= ri && b < ri + m.body_subtreenum[ri]);
+        }
+        hit = (mo[0] && mr[1]) || (mo[1] && mr[0]);
+      }
+      cnt += __popcll(__ballot(hit));
+    }
+    const int adr = m.sensor_adr[k], dim = m.sensor_dim[k];
+    float* sd = d.sensordata + (size_t)w * m.size.nsensordata;
+    for (int i = lane; i < dim; i += 64) sd[adr + i] = i == 0 ? (float)cnt : 0.f;
+  }
+}
+
+// ====================================================================================
+// Stage 5+6: Newton solver (mj_fwdConstraint) and integration (mj_Euler / mj_implicit)
+// ====================================================================================
+struct LsPnt { float alpha, cost, d0, d1; };
+
+__host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
+  int ld = s.nv | 1;
+  return s.nv * ld + s.nv + 3 * s.njmax + s.nv;
+}
+
+template <int NB>
+struct SolveCtx {
+  const float* J;  // global, row-major nefc x nv
+  const float* M;  // global, dense nv x nv
+  float *s_H, *s_invd, *s_jar, *s_jv, *s_D;
+  int nv, ld, nefc, lane;
+  float quad_gauss[3];
+  int ls_iter;
+};
+
+// x16[cb] = x[16 cb + (lane & 15)], gathered from the lane-owned layout
+template <int NB>
+__device__ __forceinline__ void gather16(float x, float (&x16)[NB], int lane) {
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) x16[cb] = __shfl(x, 16 * cb + (lane & 15));
+}
+template <int NB>
+__device__ __forceinline__ float pick16(const float (&v)[NB], int lane) {
+  float r = v[0];
+#pragma unroll
+  for (int cb = 1; cb < NB; ++cb) r = ((lane >> 4) == cb) ? v[cb] : r;
+  return r;
+}
+
+// out[r] = sum_i J[r][i] x_i (+ out2 for a second vector); lanes form 4 row groups x 16 columns
+template <int NB, bool TWO>
+__device__ __forceinline__ void jac_mul(const SolveCtx<NB>& c, const float (&x16)[NB], const float (&y16)[NB], float* out, float* out2) {
+  const int sub = c.lane >> 4, col = c.lane & 15;
+  for (int r0 = 0; r0 < c.nefc; r0 += 4) {
+    const int r = r0 + sub;
+    float acc = 0.f, acc2 = 0.f;
+    if (r < c.nefc) {
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        const int cc = 16 * cb + col;
+        const float jv = cc < c.nv ? c.J[(size_t)r * c.nv + cc] : 0.f;
+        acc += jv * x16[cb];
+        if (TWO) acc2 += jv * y16[cb];
+      }
+    }
+    acc = group16_sum(acc);
+    if (TWO) acc2 = group16_sum(acc2);
+    if (col == 0 && r < c.nefc) { out[r] = acc; if (TWO) out2[r] = acc2; }
+  }
+}
+
+// One pass over J: H = M + J^T diag(D*active) J into LDS (lower triangle) via fp32 MFMA and
+// the lane-owned constraint force qfrc_constraint_i = sum_r J[r][i] f_r.
+template <int NB>
+__device__ __forceinline__ float hessian_pass(const SolveCtx<NB>& c) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  f32x4 acc[NT];
+  float jtf[NB];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) jtf[cb] = 0.f;
+  const int sub = c.lane >> 4, col = c.lane & 15;
+  for (int r0 = 0; r0 < c.nefc; r0 += 4) {
+    const int r = r0 + sub;
+    float dact = 0.f, f = 0.f;
+    if (r < c.nefc) {
+      const float jar = c.s_jar[r], Dr = c.s_D[r];
+      if (jar < 0.f) { dact = Dr; f = -Dr * jar; }
+    }
+    float x[NB], a[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const int cc = 16 * cb + col;
+      x[cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
+      jtf[cb] += x[cb] * f;
+      a[cb] = dact * x[cb];
+    }
+    int t = 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int Jb = 0; Jb <= I; ++Jb) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[Jb], acc[t], 0, 0, 0);
+        ++t;
+      }
+  }
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) { jtf[cb] += __shfl_xor(jtf[cb], 16); jtf[cb] += __shfl_xor(jtf[cb], 32); }
+  // store tiles (+ M) to LDS, lower triangle only
+  int t = 0;
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int Jb = 0; Jb <= I; ++Jb) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
+        if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.M[row * c.nv + cc];
+      }
+      ++t;
+    }
+  return pick16<NB>(jtf, c.lane);
+}
+
+template <int NB>
+__device__ __forceinline__ void ls_eval(SolveCtx<NB>& c, LsPnt* p, float alpha) {
+  float cost = 0.f, d0 = 0.f, d1 = 0.f;
+  for (int r = c.lane; r < c.nefc; r += 64) {
+    const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r];
+    const float x = j0 + alpha * jv;
+    if (x < 0.f) {
+      const float q0 = 0.5f * Dr * j0 * j0, q1 = Dr * j0 * jv, q2 = 0.5f * Dr * jv * jv;
+      cost += alpha * alpha * q2 + alpha * q1 + q0;
+      d0 += 2.f * alpha * q2 + q1;
+      d1 += 2.f * q2;
+    }
+  }
+  cost = wave_sum(cost); d0 = wave_sum(d0); d1 = wave_sum(d1);
+  cost += alpha * alpha * c.quad_gauss[2] + alpha * c.quad_gauss[1] + c.quad_gauss[0];
+  d0 += 2.f * alpha * c.quad_gauss[2] + c.quad_gauss[1];
+  d1 += 2.f * c.quad_gauss[2];
+  if (d1 <= 0.f) d1 = MINVAL;
+  p->alpha = alpha; p->cost = cost; p->d0 = d0; p->d1 = d1;
+  c.ls_iter++;
+}
+template <int NB>
+__device__ __forceinline__ int update_bracket(SolveCtx<NB>& c, LsPnt* p, const LsPnt* cand, LsPnt* pnext) {
+  int flag = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (p->d0 < 0.f && cand[i].d0 < 0.f && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
+    else if (p->d0 > 0.f && cand[i].d0 > 0.f && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
+  }
+  if (flag) ls_eval(c, pnext, p->alpha - p->d0 / p->d1);
+  return flag;
+}
+// exact 1-D line search on the piecewise-quadratic cost (safeguarded Newton + bracketing)
+template <int NB>
+__device__ float line_search(SolveCtx<NB>& c, float gtol, int lsmax) {
+  LsPnt p0, p1, p2, pmid, p1next, p2next;
+  c.ls_iter = 0;
+  ls_eval(c, &p0, 0.f);
+  ls_eval(c, &p1, p0.alpha - p0.d0 / p0.d1);
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabsf(p1.d0) < gtol) return p1.alpha;
+  const float dir = p1.d0 < 0.f ? 1.f : -1.f;
+  bool p2update = false;
+  p2 = p1;
+  while (p1.d0 * dir <= -gtol && c.ls_iter < lsmax) {
+    p2 = p1;
+    p2update = true;
+    ls_eval(c, &p1, p1.alpha - p1.d0 / p1.d1);
+    if (fabsf(p1.d0) < gtol) return p1.alpha;
+  }
+  if (c.ls_iter >= lsmax) return p1.alpha;
+  if (!p2update) return p1.alpha;
+  p2next = p1;
+  ls_eval(c, &p1next, p1.alpha - p1.d0 / p1.d1);
+  while (c.ls_iter < lsmax) {
+    ls_eval(c, &pmid, 0.5f * (p1.alpha + p2.alpha));
+    LsPnt cand[3] = {p1next, p2next, pmid};
+    float bestcost = 0.f;
+    int best = -1;
+    for (int i = 0; i < 3; ++i)
+      if (fabsf(cand[i].d0) < gtol && (best == -1 || cand[i].cost < bestcost)) { bestcost = cand[i].cost; best = i; }
+    if (best >= 0) return cand[best].alpha;
+    const int b1 = update_bracket(c, &p1, cand, &p1next);
+    const int b2 = update_bracket(c, &p2, cand, &p2next);
+    if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : 0.f;
+  }
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0.f;
+}
+
+// constraint cost sum_r s(jar_r) over rows held in LDS
+__device__ __forceinline__ float constraint_cost(const float* s_jar, const float* s_D, int nefc, int lane) {
+  float cost = 0.f;
+  for (int r = lane; r < nefc; r += 64) {
+    const float x = s_jar[r];
+    if (x < 0.f) cost += 0.5f * s_D[r] * x * x;
+  }
+  return wave_sum(cost);
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
+  const int ld = nv | 1;
+  SolveCtx<NB> c;
+  c.s_H = smem;
+  c.s_invd = c.s_H + nv * ld;
+  c.s_jar = c.s_invd + nv;
+  c.s_jv = c.s_jar + njm;
+  c.s_D = c.s_jv + njm;
+  float* s_vec = c.s_D + njm;  // nv scratch (new qvel for the position update)
+  c.J = d.efc_J + (size_t)w * njm * nv;
+  c.M = d.qM + (size_t)w * nv * nv;
+  c.nv = nv; c.ld = ld; c.lane = lane;
+  const size_t wv = (size_t)w * nv + lane;
+  const bool own = lane < nv;
+  const float qs = own ? d.qfrc_smooth[wv] : 0.f;
+  float qacc = 0.f, fc = 0.f;
+
+  if (do_solve) {
+    const int nefc = d.nefc[w];
+    c.nefc = nefc;
+    // qacc_smooth = M^-1 qfrc_smooth using the factor from the position stage
+    {
+      const float* qLD = d.qLD + (size_t)w * nv * nv;
+      for (int k = lane; k < nv * nv; k += 64) { int i = k / nv, j = k - i * nv; c.s_H[i * ld + j] = qLD[k]; }
+      __syncthreads();
+      if (own) c.s_invd[lane] = 1.0f / c.s_H[lane * ld + lane];
+      __syncthreads();
+    }
+    const float qas = chol_solve_lds(c.s_H, c.s_invd, nv, ld, qs, lane);
+    __syncthreads();
+    if (own) d.qacc_smooth[wv] = qas;
+    if (nefc == 0) {
+      qacc = qas;
+      if (lane == 0) d.solver_niter[w] = 0;
+    } else {
+      const size_t wr = (size_t)w * njm;
+      for (int r = lane; r < nefc; r += 64) c.s_D[r] = d.efc_D[wr + r];
+      // ---- warmstart: better of qacc_warmstart and qacc_smooth
+      const float ws = own ? d.qacc_warmstart[wv] : 0.f;
+      float x16[NB], y16[NB];
+      gather16<NB>(ws, x16, lane);
+      gather16<NB>(qas, y16, lane);
+      jac_mul<NB, true>(c, x16, y16, c.s_jar, c.s_jv);
+      __syncthreads();
+      for (int r = lane; r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
+      __syncthreads();
+      const float Ma_ws = symm_mul_global(c.M, nv, ws, lane);
+      float cost_ws = constraint_cost(c.s_jar, c.s_D, nefc, lane) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
+      const float cost_s = constraint_cost(c.s_jv, c.s_D, nefc, lane);
+      float Ma;
+      if (cost_ws > cost_s) {
+        qacc = qas;
+        Ma = symm_mul_global(c.M, nv, qas, lane);
+        for (int r = lane; r < nefc; r += 64) c.s_jar[r] = c.s_jv[r];
+        __syncthreads();
+      } else {
+        qacc = ws;
+        Ma = Ma_ws;
+      }
+      const float nvf = (float)(nv > 1 ? nv : 1), mi = (float)m.opt.meaninertia;
+      const float scale = 1.f / (mi * nvf), tol = (float)m.opt.tolerance, lstol = (float)m.opt.ls_tolerance;
+      // ---- initial constraint state, gradient, Hessian, search direction
+      float cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
+      float gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
+      cost += gauss;
+      fc = hessian_pass<NB>(c);
+      float grad = own ? Ma - qs - fc : 0.f;
+      __syncthreads();
+      chol_factor_lds(c.s_H, c.s_invd, nv, ld, lane);
+      float search = -chol_solve_lds(c.s_H, c.s_invd, nv, ld, grad, lane);
+      if (!own) search = 0.f;
+      int iter = 0;
+      const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
+      while (iter < maxiter) {
+        // ---- line search
+        const float snorm = sqrtf(wave_sum(search * search));
+        if (snorm < MINVAL) break;
+        const float gtol = tol * lstol * snorm * mi * nvf;
+        const float Mv = symm_mul_global(c.M, nv, search, lane);
+        gather16<NB>(search, x16, lane);
+        __syncthreads();
+        jac_mul<NB, false>(c, x16, x16, c.s_jv, c.s_jv);
+        __syncthreads();
+        c.quad_gauss[0] = gauss;
+        c.quad_gauss[1] = wave_sum(own ? search * (Ma - qs) : 0.f);
+        c.quad_gauss[2] = wave_sum(own ? 0.5f * search * Mv : 0.f);
+        const float alpha = line_search<NB>(c, gtol, lsmax);
+        if (alpha == 0.f) break;
+        qacc += alpha * search;
+        Ma += alpha * Mv;
+        for (int r = lane; r < nefc; r += 64) c.s_jar[r] += alpha * c.s_jv[r];
+        __syncthreads();
+        const float oldcost = cost;
+        cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
+        gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
+        cost += gauss;
+        fc = hessian_pass<NB>(c);
+        grad = own ? Ma - qs - fc : 0.f;
+        __syncthreads();
+        chol_factor_lds(c.s_H, c.s_invd, nv, ld, lane);
+        search = -chol_solve_lds(c.s_H, c.s_invd, nv, ld, grad, lane);
+        if (!own) search = 0.f;
+        const float improvement = scale * (oldcost - cost);
+        const float gradient = scale * sqrtf(wave_sum(grad * grad));
+        iter++;
+        if (improvement < tol || gradient < tol) break;
+      }
+      if (lane == 0) d.solver_niter[w] = iter;
+      for (int r = lane; r < nefc; r += 64) {
+        const float x = c.s_jar[r];
+        d.efc_force[wr + r] = x < 0.f ? -c.s_D[r] * x : 0.f;
+      }
+    }
+    if (own) {
+      d.qacc[wv] = qacc;
+      d.qacc_warmstart[wv] = qacc;
+      d.qfrc_constraint[wv] = fc;
+    }
+  } else if (own) {
+    qacc = d.qacc[wv];
+    fc = d.qfrc_constraint[wv];
+  }
+
+  if (do_integrate) {
+    const float h = (float)m.opt.timestep;
+    float a = qacc;
+    // diagonal of -d(qfrc_smooth)/d(qvel): dof damping (+ actuator velocity gains for implicitfast)
+    float diag = own ? MF(dof_damping)[lane] : 0.f;
+    bool need = diag > 0.f;
+    if (m.opt.integrator == MJLAB_INT_IMPLICITFAST) {
+      need = true;
+      const float *biasprm = MF(actuator_biasprm), *gear = MF(actuator_gear), *frange = MF(actuator_forcerange);
+      for (int k = 0; k < nu; ++k) {  // wave-uniform loop; the owning lane takes the term
+        const int da = m.jnt_dofadr[m.actuator_trnid[2 * k]];
+        if (da != lane) continue;
+        const float f = d.actuator_force[(size_t)w * nu + k];
+        if (m.actuator_forcelimited[k] && (f <= frange[2 * k] || f >= frange[2 * k + 1])) continue;
+        diag -= gear[6 * k] * gear[6 * k] * biasprm[10 * k + 2];
+      }
+    }
+    if (__ballot(need)) {
+      __syncthreads();
+      for (int k = lane; k < nv * nv; k += 64) {
+        int i = k / nv, j = k - i * nv;
+        if (j <= i) c.s_H[i * ld + j] = c.M[k];
+      }
+      __syncthreads();
+      if (own) c.s_H[lane * ld + lane] += h * diag;
+      __syncthreads();
+      chol_factor_lds(c.s_H, c.s_invd, nv, ld, lane);
+      a = chol_solve_lds(c.s_H, c.s_invd, nv, ld, qs + fc, lane);
+    }
+    float qv = 0.f;
+    if (own) {
+      qv = d.qvel[wv] + h * a;
+      d.qvel[wv] = qv;
+      s_vec[lane] = qv;
+    }
+    __syncthreads();
+    float* qpos = d.qpos + (size_t)w * nq;
+    for (int j = lane; j < nj; j += 64) {
+      const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+      if (m.jnt_type[j] == MJLAB_JNT_FREE) {
+        for (int k = 0; k < 3; ++k) qpos[qa + k] += h * s_vec[da + k];
+        float ax[3] = {s_vec[da + 3], s_vec[da + 4], s_vec[da + 5]}, q[4], qr[4], qn[4];
+        for (int k = 0; k < 4; ++k) q[k] = qpos[qa + 3 + k];
+        const float ang = h * normalize3(ax);
+        axis_angle2quat(qr, ax, ang);
+        normalize4(q);
+        mul_quat(qn, q, qr);
+        normalize4(qn);
+        for (int k = 0; k < 4; ++k) qpos[qa + 3 + k] = qn[k];
+      } else {
+        qpos[qa] += h * s_vec[da];
+      }
+    }
+    if (lane == 0) d.time[w] += h;
+  }
+}
+
+// ====================================================================================
+// repeat_array_kernel replacement (reference src/mjlab/sim/randomization.py:9-17)
+// ====================================================================================
+template <typename T>
+__global__ void k_tile(T* dst, const T* src, long long nelem, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = src[i % nelem];
+}
+
+// ====================================================================================
+// C ABI
+// ====================================================================================
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s (code %d%s%s)", what, code, code > 0 ? ": " : "", code > 0 ? hipGetErrorString((hipError_t)code) : "");
+  return code;
+}
+
+extern "C" {
+
+int mjlab_abi_version(void) { return MJLAB_ABI_VERSION; }
+const char* mjlab_last_error(void) { return g_err; }
+const char* mjlab_model_layout(void) { return MJLAB_MODEL_LAYOUT_STRING; }
+const char* mjlab_data_layout(void) { return MJLAB_DATA_LAYOUT_STRING; }
+int mjlab_sizeof_model(void) { return (int)sizeof(mjlab_model_t); }
+int mjlab_sizeof_data(void) { return (int)sizeof(mjlab_data_t); }
+
+int mjlab_lds_bytes(const mjlab_model_t* m, int stage) {
+  switch (stage) {
+    case MJLAB_STAGE_POSITION: return 4 * position_lds_floats(m->size);
+    case MJLAB_STAGE_COLLISION: return 4 * collision_lds_floats(m->size);
+    case MJLAB_STAGE_VELOCITY: return 4 * velocity_lds_floats(m->size);
+    case MJLAB_STAGE_CONSTRAINT: return 4 * constraint_lds_floats(m->size);
+    case MJLAB_STAGE_SOLVE:
+    case MJLAB_STAGE_INTEGRATE: return 4 * solve_lds_floats(m->size);
+  }
+  return -1;
+}
+
+static int check_model(const mjlab_model_t* m) {
+  const mjlab_sizes_t& s = m->size;
+  if (s.nworld < 1) return fail(-2, "nworld must be >= 1");
+  if (s.nv < 1 || s.nv > 64) return fail(-3, "nv must be in [1, 64] (one dof per lane)");
+  if (s.njmax < 1 || s.nconmax < 1) return fail(-4, "njmax and nconmax must be >= 1");
+  if (m->opt.cone != 0) return fail(-5, "only the pyramidal friction cone is implemented");
+  if (m->opt.integrator != MJLAB_INT_EULER && m->opt.integrator != MJLAB_INT_IMPLICITFAST)
+    return fail(-6, "integrator must be Euler or implicitfast");
+  for (int st = 1; st <= 16; st <<= 1)
+    if (mjlab_lds_bytes(m, st) > 160 * 1024) return fail(-7, "model too large for the LDS-resident stage kernels");
+  return 0;
+}
+
+#define LAUNCH(kernel, ldsfloats, ...)                                                                      \
+  do {                                                                                                      \
+    hipLaunchKernelGGL(kernel, dim3(m->size.nworld), dim3(64), (size_t)4 * (ldsfloats), st, __VA_ARGS__);  \
+    hipError_t e_ = hipGetLastError();                                                                      \
+    if (e_ != hipSuccess) return fail((int)e_, #kernel " launch failed");                                   \
+  } while (0)
+
+static int launch_solve(const mjlab_model_t* m, const mjlab_data_t* d, int do_solve, int do_integrate, hipStream_t st) {
+  const int nblk = (m->size.nv + 15) / 16;
+  const int lds = solve_lds_floats(m->size);
+  switch (nblk) {
+    case 1: LAUNCH(k_solve_integrate<1>, lds, *m, *d, do_solve, do_integrate); break;
+    case 2: LAUNCH(k_solve_integrate<2>, lds, *m, *d, do_solve, do_integrate); break;
+    case 3: LAUNCH(k_solve_integrate<3>, lds, *m, *d, do_solve, do_integrate); break;
+    default: LAUNCH(k_solve_integrate<4>, lds, *m, *d, do_solve, do_integrate); break;
+  }
+  return 0;
+}
+
+int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (stages & MJLAB_STAGE_POSITION) LAUNCH(k_position, position_lds_floats(m->size), *m, *d);
+  if (stages & MJLAB_STAGE_COLLISION) LAUNCH(k_collision, collision_lds_floats(m->size), *m, *d);
+  if (stages & MJLAB_STAGE_VELOCITY) LAUNCH(k_velocity, velocity_lds_floats(m->size), *m, *d);
+  if (stages & MJLAB_STAGE_CONSTRAINT) LAUNCH(k_constraint, constraint_lds_floats(m->size), *m, *d);
+  if (stages & (MJLAB_STAGE_SOLVE | MJLAB_STAGE_INTEGRATE)) {
+    rc = launch_solve(m, d, (stages & MJLAB_STAGE_SOLVE) != 0, (stages & MJLAB_STAGE_INTEGRATE) != 0, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream) {
+  return mjlab_forward_stages(m, d, MJLAB_STAGE_FORWARD, stream);
+}
+
+int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void* stream) {
+  if (nsubstep < 1) return fail(-8, "nsubstep must be >= 1");
+  for (int k = 0; k < nsubstep; ++k) {
+    int rc = mjlab_forward_stages(m, d, MJLAB_STAGE_STEP, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int mjlab_tile_field(void* dst, const void* src, long long nelem, int nworld, int elem_size, void* stream) {
+  if (nelem <= 0 || nworld <= 0) return fail(-9, "tile: empty field");
+  const long long total = nelem * nworld;
+  const int block = 256;
+  long long grid = (total + block - 1) / block;
+  if (grid > 2048) grid = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (elem_size == 4) hipLaunchKernelGGL(k_tile<unsigned>, dim3((unsigned)grid), dim3(block), 0, st, (unsigned*)dst, (const unsigned*)src, nelem, total);
+  else if (elem_size == 8) hipLaunchKernelGGL(k_tile<unsigned long long>, dim3((unsigned)grid), dim3(block), 0, st, (unsigned long long*)dst, (const unsigned long long*)src, nelem, total);
+  else return fail(-10, "tile: elem_size must be 4 or 8");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "k_tile launch failed");
+  return 0;
+}
+
+}  // extern "C"

@@ -807,6 +807,15 @@ def _compile(spec: Spec) -> Model:
   for i in range(1, nbody):
     m.body_depth[i] = m.body_depth[m.body_parentid[i]] + 1
 
+  m.nlevel = int(m.body_depth.max()) + 1
+  order = np.argsort(m.body_depth, kind="stable").astype(np.int32)
+  m.level_body = order
+  m.level_adr = np.searchsorted(m.body_depth[order], np.arange(m.nlevel + 1)).astype(np.int32)
+  # bodies are in depth-first order, so a subtree is the contiguous id range [b, b + subtreenum[b])
+  m.body_subtreenum = np.ones(nbody, np.int32)
+  for i in range(nbody - 1, 0, -1):
+    m.body_subtreenum[m.body_parentid[i]] += m.body_subtreenum[i]
+
   # ---- joints / dofs -------------------------------------------------------
   m.jnt_type = np.array(jnt_type, np.int32).reshape(njnt)
   m.jnt_qposadr = np.array(jnt_qposadr, np.int32).reshape(njnt)

@@ -1,0 +1,296 @@
+"""``Simulation``: the drop-in boundary of the reference's physics hot path.
+
+Mirrors reference ``src/mjlab/sim/sim.py:43-198`` (``MujocoCfg``, ``SimulationCfg``,
+``Simulation`` with ``step / forward / create_graph / expand_model_fields / reset / close``
+and the ``model`` / ``data`` bridges), with the two foreign calls replaced:
+
+  ``mjwarp.step(wp_model, wp_data)``     -> ``mjlab_step``     (include/mjlab_amd.h)
+  ``mjwarp.forward(wp_model, wp_data)``  -> ``mjlab_forward``
+  ``repeat_array_kernel``                -> ``mjlab_tile_field``
+  ``wp.ScopedCapture`` / ``wp.capture_launch`` (CUDA graph) -> hipGraph capture/replay on
+  PyTorch-ROCm's current stream (``torch.cuda.CUDAGraph`` is a hipGraph on ROCm).
+
+Device arrays are allocated here as torch tensors and handed to the C ABI as raw device
+pointers; everything is enqueued on torch's current stream, so writes made through
+``sim.data.<field>[...] = v`` are ordered before the next ``step()`` without extra fences
+(the reference needs ``torch.cuda.ExternalStream`` for that: sim_data.py:33-44,58-64).
+
+There is no CPU path: constructing a ``Simulation`` on a device without a GPU raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass, field
+from typing import Literal
+
+import numpy as np
+import torch
+
+from . import _abi, native
+from .mjcf import CONE_ELLIPTIC, CONE_PYRAMIDAL, INT_EULER, INT_IMPLICITFAST, SOL_CG, SOL_NEWTON, SOL_PGS, Model, Spec
+from .sim_data import Bridge
+
+_CONE_MAP = {"pyramidal": CONE_PYRAMIDAL, "elliptic": CONE_ELLIPTIC}
+_INTEGRATOR_MAP = {"euler": INT_EULER, "implicitfast": INT_IMPLICITFAST}
+_SOLVER_MAP = {"newton": SOL_NEWTON, "cg": SOL_CG, "pgs": SOL_PGS}
+
+
+@dataclass
+class MujocoCfg:
+  """Solver / integrator options (reference sim/sim.py:43-82; same names and defaults)."""
+
+  timestep: float = 0.002
+  integrator: Literal["euler", "implicitfast"] = "implicitfast"
+  impratio: float = 1.0
+  cone: Literal["pyramidal", "elliptic"] = "pyramidal"
+  jacobian: Literal["auto", "dense", "sparse"] = "auto"
+  solver: Literal["newton", "cg", "pgs"] = "newton"
+  iterations: int = 100
+  tolerance: float = 1e-8
+  ls_iterations: int = 50
+  ls_tolerance: float = 0.01
+  gravity: tuple[float, float, float] = (0, 0, -9.81)
+
+  def edit_spec(self, spec: Spec) -> None:
+    o = spec.option
+    o.cone = _CONE_MAP[self.cone]
+    o.integrator = _INTEGRATOR_MAP[self.integrator]
+    o.solver = _SOLVER_MAP[self.solver]
+    o.timestep = self.timestep
+    o.impratio = self.impratio
+    o.gravity = tuple(float(g) for g in self.gravity)
+    o.iterations = self.iterations
+    o.tolerance = self.tolerance
+    o.ls_iterations = self.ls_iterations
+    o.ls_tolerance = self.ls_tolerance
+
+
+@dataclass(kw_only=True)
+class SimulationCfg:
+  """Reference sim/sim.py:85-91.  ``nconmax`` is accepted for signature parity; contact
+  capacity is per world here and derived from ``njmax`` (see _abi.default_capacities)."""
+
+  nconmax: int | None = None
+  njmax: int | None = None
+  ls_parallel: bool = True  # accepted for parity; the line search here is the exact (iterative) one
+  mujoco: MujocoCfg = field(default_factory=MujocoCfg)
+  use_graph: bool = True
+
+
+class HostData:
+  """Host-side ``mjData`` stand-in (qpos0 state) kept for viewers/exporters
+  (reference sim/sim.py:106-107,145-150)."""
+
+  def __init__(self, model: Model) -> None:
+    self.qpos = model.qpos0.copy()
+    self.qvel = np.zeros(model.nv)
+    self.ctrl = np.zeros(model.nu)
+    self.time = 0.0
+
+
+_EXTRA_MODEL_FIELDS = ("geom_rgba",)  # DR-able host fields not consumed by the kernels
+
+
+class Simulation:
+  """Batched physics on one MI355X; one world per wavefront (see csrc/mjlab_amd.hip)."""
+
+  def __init__(self, num_envs: int, cfg: SimulationCfg, model: Model, device: str) -> None:
+    dev = torch.device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+      raise RuntimeError(
+        f"mjlab_amd.Simulation needs a ROCm GPU device (got '{device}', "
+        f"torch.cuda.is_available()={torch.cuda.is_available()}); there is no CPU fallback"
+      )
+    if model.opt.solver != SOL_NEWTON:
+      raise NotImplementedError("only the Newton solver is implemented")
+    if model.opt.cone != CONE_PYRAMIDAL:
+      raise NotImplementedError("only the pyramidal cone is implemented")
+    self.cfg = cfg
+    self.device = device
+    self._dev = dev
+    self.num_envs = num_envs
+    self._mj_model = model
+    self._mj_data = HostData(model)
+    self._lib = native.lib()
+    mf, df, MS, DS = native.layouts()
+    self._mfields = {f.name: f for f in mf}
+    self._dfields = {f.name: f for f in df}
+    self.nconmax, self.njmax = _abi.default_capacities(model, cfg.nconmax, cfg.njmax)
+
+    with torch.cuda.device(dev):
+      # ---- model
+      self._m = MS()
+      self._m.size = _abi.fill_sizes(model, num_envs, self.nconmax, self.njmax)
+      self._m.opt = _abi.fill_option(model)
+      self._model_base: dict[str, torch.Tensor] = {}
+      self._model_view: dict[str, torch.Tensor] = {}
+      for f in mf:
+        if f.kind == "i":
+          t = torch.from_numpy(_abi.model_int_array(model, f.name)).to(dev)
+          self._model_base[f.name] = t
+          self._model_view[f.name] = t
+          setattr(self._m, f.name, t.data_ptr())
+        else:
+          host = np.ascontiguousarray(getattr(model, f.name), dtype=np.float32)
+          t = torch.from_numpy(host).to(dev).unsqueeze(0).contiguous()
+          self._model_base[f.name] = t
+          self._model_view[f.name] = t.expand(num_envs, *t.shape[1:])
+          setattr(self._m, f.name, t.data_ptr())
+          setattr(self._m, f.name + "_ws", 0)
+      for name in _EXTRA_MODEL_FIELDS:
+        host = np.ascontiguousarray(getattr(model, name), dtype=np.float32)
+        t = torch.from_numpy(host).to(dev).unsqueeze(0).contiguous()
+        self._model_base[name] = t
+        self._model_view[name] = t.expand(num_envs, *t.shape[1:])
+      # ---- data
+      self._d = DS()
+      self._data: dict[str, torch.Tensor] = {}
+      for f in df:
+        n = _abi.count_of(f.count, model, self.nconmax, self.njmax)
+        dtype = torch.int32 if f.kind == "i" else torch.float32
+        flat = torch.zeros((num_envs, n * f.ncol), dtype=dtype, device=dev)
+        setattr(self._d, f.name, flat.data_ptr())
+        self._data[f.name] = self._shape_view(f, flat, n)
+      self._data["qpos"][:] = torch.from_numpy(model.qpos0.astype(np.float32)).to(dev)
+
+    scalars = {k: int(getattr(model, k)) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata")}
+    self._model_bridge = Bridge("sim.model", self._model_view, {**scalars, "opt": model.opt, "nworld": num_envs})
+    self._data_bridge = Bridge("sim.data", self._data, {"nworld": num_envs, "njmax": self.njmax, "nconmax": self.nconmax})
+
+    self.use_graph = bool(cfg.use_graph) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
+    self.step_graph: torch.cuda.CUDAGraph | None = None
+    self.forward_graph: torch.cuda.CUDAGraph | None = None
+    self.forward()  # populate derived fields like mjwarp.put_data does from mj_forward
+    self.create_graph()
+
+  # ------------------------------------------------------------------ helpers
+  @staticmethod
+  def _shape_view(f: _abi.FieldSpec, flat: torch.Tensor, n: int) -> torch.Tensor:
+    nw = flat.shape[0]
+    if f.count == "one":
+      return flat.view(nw) if f.ncol == 1 else flat.view(nw, f.ncol)
+    if f.count == "nvnv":
+      nv = int(round(n**0.5))
+      return flat.view(nw, nv, nv)
+    if f.count == "njmaxnv":
+      return flat  # (nworld, njmax * nv), reshaped by users that need it
+    if f.ncol == 1:
+      return flat.view(nw, n)
+    if f.ncol == 9 and f.name.endswith("xmat") or f.name in ("ximat",):
+      return flat.view(nw, n, 3, 3)
+    return flat.view(nw, n, f.ncol)
+
+  def _stream(self) -> int:
+    return torch.cuda.current_stream(self._dev).cuda_stream
+
+  def _launch_step(self, nsubstep: int = 1) -> None:
+    native.check(self._lib.mjlab_step(ctypes.byref(self._m), ctypes.byref(self._d), nsubstep, self._stream()), "mjlab_step")
+
+  def _launch_forward(self) -> None:
+    native.check(self._lib.mjlab_forward(ctypes.byref(self._m), ctypes.byref(self._d), self._stream()), "mjlab_forward")
+
+  def forward_stages(self, stages: int) -> None:
+    """Run selected pipeline stages once (testing / profiling)."""
+    with torch.cuda.device(self._dev):
+      native.check(
+        self._lib.mjlab_forward_stages(ctypes.byref(self._m), ctypes.byref(self._d), stages, self._stream()),
+        "mjlab_forward_stages",
+      )
+
+  # ------------------------------------------------------------------ reference surface
+  def create_graph(self) -> None:
+    """(Re-)capture the step / forward launch sequences into hipGraphs
+    (reference sim/sim.py:131-140)."""
+    self.step_graph = None
+    self.forward_graph = None
+    if not self.use_graph:
+      return
+    with torch.cuda.device(self._dev):
+      torch.cuda.synchronize(self._dev)
+      # Graph capture re-runs nothing: the captured launches only execute on replay, but
+      # capture itself must not mutate state, which holds because launches are recorded.
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g):
+        self._launch_step(1)
+      self.step_graph = g
+      g2 = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g2):
+        self._launch_forward()
+      self.forward_graph = g2
+
+  @property
+  def mj_model(self) -> Model:
+    return self._mj_model
+
+  @property
+  def mj_data(self) -> HostData:
+    return self._mj_data
+
+  @property
+  def data(self) -> Bridge:
+    return self._data_bridge
+
+  @property
+  def model(self) -> Bridge:
+    return self._model_bridge
+
+  def expand_model_fields(self, fields: list[str]) -> None:
+    """Give each listed model field a per-world copy (reference sim/sim.py:170-176,
+    sim/randomization.py:20-55).  Raises ValueError for unknown fields."""
+    invalid = [f for f in fields if not hasattr(self._mj_model, f)]
+    if invalid:
+      raise ValueError(f"Fields not found in model: {invalid}")
+    if self.num_envs == 1:
+      return
+    with torch.cuda.device(self._dev):
+      for name in fields:
+        if name not in self._model_base:
+          host = np.ascontiguousarray(getattr(self._mj_model, name), dtype=np.float32)
+          self._model_base[name] = torch.from_numpy(host).to(self._dev).unsqueeze(0).contiguous()
+        base = self._model_base[name]
+        if base.dtype != torch.float32:
+          raise ValueError(f"Field '{name}' is an integer topology field and cannot be per-world")
+        if base.shape[0] == self.num_envs:
+          continue  # already expanded
+        nelem = base[0].numel()
+        dst = torch.empty((self.num_envs, *base.shape[1:]), dtype=base.dtype, device=self._dev)
+        native.check(
+          self._lib.mjlab_tile_field(dst.data_ptr(), base.data_ptr(), nelem, self.num_envs, 4, self._stream()),
+          "mjlab_tile_field",
+        )
+        self._model_base[name] = dst
+        self._model_view[name] = dst
+        if name in self._mfields:
+          setattr(self._m, name, dst.data_ptr())
+          setattr(self._m, name + "_ws", int(nelem))
+      # pointers changed: captured graphs are stale (the reference re-captures too:
+      # envs/manager_based_rl_env.py:102-104)
+      self.step_graph = None
+      self.forward_graph = None
+
+  def reset(self) -> None:
+    pass  # reference sim/sim.py:178-180
+
+  def forward(self) -> None:
+    with torch.cuda.device(self._dev):
+      if self.use_graph and self.forward_graph is not None:
+        self.forward_graph.replay()
+      else:
+        self._launch_forward()
+
+  def step(self) -> None:
+    with torch.cuda.device(self._dev):
+      if self.use_graph and self.step_graph is not None:
+        self.step_graph.replay()
+      else:
+        self._launch_step(1)
+
+  def close(self) -> None:
+    pass
+
+  # ------------------------------------------------------------------ extras
+  def lds_bytes(self) -> dict[str, int]:
+    names = {"position": 1, "collision": 2, "velocity": 4, "constraint": 8, "solve": 16}
+    return {k: int(self._lib.mjlab_lds_bytes(ctypes.byref(self._m), v)) for k, v in names.items()}
