@@ -1,0 +1,207 @@
+"""Benchmark of the physics hot path: env-steps/s, Unitree G1 velocity-flat, 4096 envs per GPU.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one env (control) step of the reference's hot loop
+(src/mjlab/envs/manager_based_rl_env.py:106-147) restricted to its physics: random action
+-> 4 x [write ctrl, Simulation.step()] -> termination check + masked reset ->
+Simulation.forward().  Inputs are resident in HBM before the timed region.  One process per
+GPU; worlds are sharded across ranks (weak scaling, 4096 per GPU); for N > 1 the per-step
+observation rows are all-gathered over RCCL like the north_star's obs/reward gather.
+
+Prints ONE JSON line on rank 0 (contract in the task statement); extra objects:
+  roofline     -- dominant kernel (Newton solve + integrate) vs the HBM roofline, using
+                  SURVEY.md section 8(d)'s algorithmic bytes per world per physics step;
+  cpu_baseline -- the CPU oracle (a port, NOT upstream mj_step) timed on this host's cores
+                  on a bounded sample of the same workload.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from mjlab_amd import dist as mdist  # noqa: E402
+from mjlab_amd import native, robots  # noqa: E402
+from mjlab_amd.rollout import PhysicsRollout, g1_action_scale  # noqa: E402
+from mjlab_amd.sim import Simulation, SimulationCfg  # noqa: E402
+
+# compulsory HBM traffic of the public mjData contract, fp32
+ALGO_BYTES_PER_WORLD_STEP = {"g1_velocity_flat": 10156, "g1_tracking_flat": 10716, "go1_velocity_flat": 5672}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(scene: str, seed: int) -> dict:
+  """Time the CPU oracle (test infrastructure, used here only as the reported baseline)."""
+  from oracle.oracle import OracleSim
+
+  model = robots.load_model(scene)
+  cores = os.cpu_count() or 1
+  nworld, env_steps = 64 * cores, 10
+  ora = OracleSim(model, nworld, njmax=300, precision="f64")
+  rng = np.random.default_rng(seed)
+  ora.reset(key=0)
+  jn = model.actuator_trnid[:, 0]
+  default = model.key_qpos[0][model.jnt_qposadr[jn]]
+  scale = g1_action_scale(model) if scene.startswith("g1") else 0.25
+  ora.forward(nthread=cores)
+  t0 = time.perf_counter()
+  for _ in range(env_steps):
+    ora.ctrl[:] = default + scale * rng.uniform(-1, 1, size=(nworld, model.nu))
+    ora.step(4, nthread=cores)
+    ora.forward(nthread=cores)
+  dt = time.perf_counter() - t0
+  return {
+    "value": nworld * env_steps / dt,
+    "unit": "env-steps/s",
+    "cores": cores,
+    "kind": "port",
+    "sample": f"{nworld} worlds x {env_steps} env-steps (4 substeps + 1 forward each), fp64 C oracle, {cores} pthreads; "
+    "CPU restatement, not upstream mj_step",
+  }
+
+
+def main() -> None:
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=200)
+  ap.add_argument("--warmup", type=int, default=30)
+  ap.add_argument("--envs-per-gpu", type=int, default=4096)
+  ap.add_argument("--scene", default="g1_velocity_flat")
+  ap.add_argument("--no-gather", action="store_true")
+  ap.add_argument("--no-graph", action="store_true")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--seed", type=int, default=42)
+  args = ap.parse_args()
+
+  info = mdist.init_from_env(args.envs_per_gpu)
+  if info.world_size != args.gpus:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={info.world_size}; launch with torch.distributed.run")
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+  native.lib()  # fail loudly if the HIP extension is missing
+  dev = f"cuda:{info.local_rank}"
+  torch.cuda.set_device(info.local_rank)
+
+  model = robots.load_model(args.scene)
+  sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph), model, dev)
+  scale = g1_action_scale(model) if args.scene.startswith("g1") else 0.25
+  roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info))
+  gather = info.world_size > 1 and not args.no_gather
+
+  def env_step() -> None:
+    roll.step(roll.random_action())
+    if gather:
+      mdist.gather_rollout(info, roll.observation_rows())
+
+  for _ in range(args.warmup):
+    env_step()
+  mdist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    env_step()
+  torch.cuda.synchronize()
+  mdist.barrier()
+  elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+
+  # ---- dominant-kernel timing with HIP events on the launch stream (instrumented pass:
+  # same workload, stages launched one by one so the solve kernel can be bracketed)
+  solve_ms, stage_ms = None, {}
+  if info.rank == 0:
+    stages = [("position", 1), ("collision", 2), ("velocity", 4), ("constraint", 8), ("solve_integrate", 48)]
+    acc = {k: 0.0 for k, _ in stages}
+    nlaunch = 0
+    reps = max(5, min(args.steps, 25))
+    for _ in range(reps):
+      sim.data.ctrl[:] = roll.default_joint + roll.random_action() * roll.action_scale
+      for _ in range(roll.decimation):
+        evs = []
+        for name, bits in stages:
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record()
+          sim.forward_stages(bits)
+          e1.record()
+          evs.append((name, e0, e1))
+        torch.cuda.synchronize()
+        for name, e0, e1 in evs:
+          acc[name] += e0.elapsed_time(e1)
+        nlaunch += 1
+    stage_ms = {k: v / nlaunch for k, v in acc.items()}
+    solve_ms = stage_ms["solve_integrate"]
+
+  if info.rank == 0:
+    n_env = args.envs_per_gpu * info.world_size
+    value = n_env * args.steps / elapsed
+    algo = ALGO_BYTES_PER_WORLD_STEP.get(args.scene)
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+      try:
+        traffic = json.loads(tfile.read_text()).get(args.scene, {}).get("solve_integrate_bytes_per_launch")
+      except Exception:  # noqa: BLE001
+        traffic = None
+    roof = None
+    if algo and solve_ms:
+      achieved = algo * args.envs_per_gpu / (solve_ms * 1e-3) / 1e9
+      roof = {
+        "bound": "hbm",
+        "kernel": "k_solve_integrate",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": algo * args.envs_per_gpu,
+        "kernel_ms": solve_ms,
+        "stage_ms": stage_ms,
+        "note": "latency/LDS-bound by construction (SURVEY.md 8d): lower HBM traffic is better",
+      }
+    cpu = None
+    if not args.no_cpu_baseline:
+      try:
+        cpu = cpu_baseline(args.scene, args.seed)
+      except Exception as e:  # noqa: BLE001
+        cpu = {"error": str(e)}
+    out = {
+      "metric": "env-steps/sec at num_envs=4096 per GPU, Unitree-G1 flat (physics hot path: 4 substeps + 1 forward per env-step)",
+      "value": value,
+      "unit": "env-steps/s",
+      "n_gpus": info.world_size,
+      "steps": args.steps,
+      "warmup": args.warmup,
+      "ms_per_step": elapsed / args.steps * 1e3,
+      "higher_is_better": True,
+      "scaling": "weak",
+      "vs_baseline": None,
+      "dtype": "f32",
+      "data": "synthetic (random actions, keyframe resets; compiled model from the reference MJCF)",
+      "config": {
+        "workload": f"{args.scene}: {args.envs_per_gpu} envs/GPU, timestep 0.005, decimation 4, Newton 10 it / 20 ls, implicitfast, pyramidal, njmax 300",
+        "global_envs": n_env,
+        "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL obs all-gather" if gather else ""),
+        "graph": sim.use_graph,
+      },
+      "world_physics_steps_per_s": value * roll.decimation,
+      "roofline": roof,
+      "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+  if torch.distributed.is_initialized():
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,100 @@
+"""Env-sharded multi-GPU execution: one process per GPU, worlds partitioned across ranks.
+
+The physics step has no cross-world term, so ranks never exchange data inside
+``Simulation.step()``.  The only exchange the path has is the one BASELINE.json's
+north_star names: per control step the per-env observation / reward / done rows are
+all-gathered to the learner and the actions travel back.  The
+reference itself is single-process (``scripts/train.py:29`` hard-codes ``cuda:0``), so
+this module is new functionality, not a port.
+
+Backend "nccl" is RCCL on ROCm; "gloo" runs the same logic on CPU tensors for tests.
+"""
+
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class ShardInfo:
+  rank: int
+  world_size: int
+  local_rank: int
+  envs_per_rank: int
+
+  @property
+  def global_envs(self) -> int:
+    return self.envs_per_rank * self.world_size
+
+  @property
+  def env_slice(self) -> slice:
+    return slice(self.rank * self.envs_per_rank, (self.rank + 1) * self.envs_per_rank)
+
+
+def init_from_env(envs_per_rank: int, backend: str | None = None) -> ShardInfo:
+  """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+  world_size = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world_size > 1 and not dist.is_initialized():
+    if backend is None:
+      backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+      torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
+  return ShardInfo(rank, world_size, local_rank, envs_per_rank)
+
+
+def seed_for_rank(seed: int, info: ShardInfo) -> int:
+  """Rank r uses seed + r."""
+  return seed + info.rank
+
+
+def gather_rollout(info: ShardInfo, rows: torch.Tensor) -> torch.Tensor:
+  """All-gather per-env rows ``(envs_per_rank, k)`` into ``(global_envs, k)`` in rank order.
+
+  One fused buffer per control step ([obs | reward | done] columns) instead of one
+  collective per tensor: xGMI is point-to-point, few larger transfers beat many small ones.
+  """
+  if info.world_size == 1:
+    return rows
+  out = torch.empty((info.global_envs, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+  dist.all_gather_into_tensor(out, rows.contiguous())
+  return out
+
+
+def scatter_actions(info: ShardInfo, actions_global: torch.Tensor | None, action_dim: int, device, src: int = 0) -> torch.Tensor:
+  """Learner (rank ``src``) -> each rank's ``(envs_per_rank, action_dim)`` slice."""
+  if info.world_size == 1:
+    assert actions_global is not None
+    return actions_global
+  out = torch.empty((info.envs_per_rank, action_dim), dtype=torch.float32, device=device)
+  if dist.get_backend() == "nccl":
+    # RCCL has no scatter from a list on every version: broadcast + slice keeps it to one
+    # collective of N x action_dim floats (475 KB at 4096 x 29), far below link bandwidth.
+    buf = actions_global if info.rank == src else torch.empty((info.global_envs, action_dim), dtype=torch.float32, device=device)
+    dist.broadcast(buf, src=src)
+    out.copy_(buf[info.env_slice])
+  else:
+    chunks = list(actions_global.chunk(info.world_size)) if info.rank == src else None
+    dist.scatter(out, chunks, src=src)
+  return out
+
+
+def max_over_ranks(value: float, device) -> float:
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return value
+  t = torch.tensor([value], dtype=torch.float64, device=device)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return float(t.item())
+
+
+def barrier() -> None:
+  if dist.is_initialized() and dist.get_world_size() > 1:
+    dist.barrier()

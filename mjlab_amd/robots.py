@@ -457,23 +457,33 @@ MIXED_XML = """
   <option timestep="0.004"/>
   <worldbody>
     <geom name="floor" type="plane" size="0 0 0.01"/>
-    <body name="cap" pos="0 0 0.25" quat="0.92388 0 0.382683 0">
+    <body name="cap" pos="0 0 0.055" quat="0.707107 0 0.707107 0">
       <inertial pos="0 0 0" mass="1.5" diaginertia="0.02 0.02 0.004"/>
       <freejoint name="cap_root"/>
       <geom name="cap_geom" type="capsule" size="0.06 0.2"/>
     </body>
-    <body name="ball" pos="0.05 0.02 0.62">
+    <body name="ball" pos="0.05 0.0 0.205">
       <inertial pos="0 0 0" mass="0.7" diaginertia="0.003 0.003 0.003"/>
       <freejoint name="ball_root"/>
       <geom name="ball_geom" type="sphere" size="0.1" condim="1"/>
     </body>
-    <body name="slider" pos="0.8 0 0.5">
+    <body name="cap2" pos="-0.1 0 0.16" quat="0.707107 0.707107 0 0">
+      <inertial pos="0 0 0" mass="0.8" diaginertia="0.01 0.01 0.002"/>
+      <freejoint name="cap2_root"/>
+      <geom name="cap2_geom" type="capsule" size="0.05 0.15" friction="0.7 0.005 0.0001"/>
+    </body>
+    <body name="ball2" pos="0.22 0.02 0.205">
+      <inertial pos="0 0 0" mass="0.3" diaginertia="0.001 0.001 0.001"/>
+      <freejoint name="ball2_root"/>
+      <geom name="ball2_geom" type="sphere" size="0.08" priority="1" solimp="0.9 0.95 0.01"/>
+    </body>
+    <body name="slider" pos="0.8 0 0.07">
       <inertial pos="0 0 0" mass="1" diaginertia="0.01 0.01 0.01"/>
       <joint name="slide" type="slide" axis="0 0 1" range="-0.3 0.3"/>
       <geom name="slider_geom" type="sphere" size="0.08"/>
       <body name="arm" pos="0 0 0">
         <inertial pos="0.2 0 0" mass="0.5" diaginertia="0.001 0.01 0.01"/>
-        <joint name="elbow" type="hinge" axis="0 1 0" range="-0.5 0.5" pos="0 0 0"/>
+        <joint name="elbow" type="hinge" axis="0 1 0" range="-0.05 0.05" pos="0 0 0"/>
         <geom name="arm_geom" type="capsule" size="0.04" fromto="0.1 0 0 0.4 0 0"/>
       </body>
     </body>

@@ -1,0 +1,113 @@
+"""Minimal control-step driver around ``Simulation`` for benchmarks and tests.
+
+Restates the physics-facing part of ``ManagerBasedRlEnv.step`` (reference
+src/mjlab/envs/manager_based_rl_env.py:106-147): process action -> ``decimation`` x
+[write ctrl, ``sim.step()``] -> termination check -> masked reset of terminated envs ->
+``sim.forward()``.  The MDP managers (rewards, observations, commands) are outside the
+physics hot path and are not reproduced; resets are mask-based (no ``nonzero()`` host sync).
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .mjcf import JNT_FREE, Model
+from .sim import Simulation
+
+
+class PhysicsRollout:
+  def __init__(self, sim: Simulation, action_scale: np.ndarray | float = 0.25, decimation: int = 4,
+               episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0) -> None:
+    m: Model = sim.mj_model
+    dev = sim.data.qpos.device
+    self.sim, self.m, self.decimation = sim, m, decimation
+    self.gen = torch.Generator(device=dev)
+    self.gen.manual_seed(seed)
+    self.key_qpos = torch.tensor(m.key_qpos[key] if m.nkey else m.qpos0, dtype=torch.float32, device=dev)
+    jn = m.actuator_trnid[:, 0]
+    self.act_qadr = torch.tensor(m.jnt_qposadr[jn], dtype=torch.long, device=dev)
+    self.default_joint = self.key_qpos[self.act_qadr]
+    scale = np.broadcast_to(np.asarray(action_scale, dtype=np.float32), (m.nu,)).copy()
+    self.action_scale = torch.tensor(scale, device=dev)
+    self.has_free = m.njnt > 0 and m.jnt_type[0] == JNT_FREE
+    self.max_len = int(round(episode_length_s / (m.opt.timestep * decimation)))
+    self.min_height = min_height
+    n = sim.num_envs
+    # start at random episode phase like the reference (train.py:109-111 init_at_random_ep_len)
+    self.episode_length = torch.randint(0, self.max_len, (n,), device=dev, generator=self.gen)
+    self.reset_all()
+
+  def _sample_reset_qpos(self, n: int) -> torch.Tensor:
+    """Keyframe pose with x, y in U(-0.5, 0.5) and yaw in U(-3.14, 3.14)
+    (reference src/mjlab/tasks/velocity/velocity_env_cfg.py:136-144)."""
+    q = self.key_qpos.unsqueeze(0).repeat(n, 1)
+    if self.has_free:
+      dev = q.device
+      xy = torch.rand((n, 2), device=dev, generator=self.gen) - 0.5
+      yaw = (torch.rand((n,), device=dev, generator=self.gen) * 2 - 1) * 3.14
+      q[:, 0:2] += xy
+      q[:, 3] = torch.cos(yaw * 0.5)
+      q[:, 4:6] = 0.0
+      q[:, 6] = torch.sin(yaw * 0.5)
+    return q
+
+  def reset_all(self) -> None:
+    d = self.sim.data
+    n = self.sim.num_envs
+    d.qpos[:] = self._sample_reset_qpos(n)
+    d.qvel[:] = 0.0
+    d.ctrl[:] = self.default_joint
+    d.qacc_warmstart[:] = 0.0
+    self.sim.forward()
+
+  def step(self, action: torch.Tensor) -> torch.Tensor:
+    """One control step; returns the boolean reset mask."""
+    d = self.sim.data
+    target = self.default_joint + action * self.action_scale
+    for _ in range(self.decimation):
+      d.ctrl[:] = target
+      self.sim.step()
+    self.episode_length += 1
+    fell = d.qpos[:, 2] < self.min_height if self.has_free else torch.zeros_like(self.episode_length, dtype=torch.bool)
+    bad = ~torch.isfinite(d.qpos).all(dim=1)
+    reset = fell | bad | (self.episode_length >= self.max_len)
+    fresh = self._sample_reset_qpos(self.sim.num_envs)
+    rm = reset.unsqueeze(1)
+    d.qpos[:] = torch.where(rm, fresh, torch.nan_to_num(d.qpos))
+    d.qvel[:] = torch.where(rm, torch.zeros_like(d.qvel), torch.nan_to_num(d.qvel))
+    d.qacc_warmstart[:] = torch.where(rm, torch.zeros_like(d.qacc_warmstart), torch.nan_to_num(d.qacc_warmstart))
+    self.episode_length = torch.where(reset, torch.zeros_like(self.episode_length), self.episode_length)
+    self.sim.forward()
+    return reset
+
+  def random_action(self) -> torch.Tensor:
+    """``2 U(0,1) - 1`` per actuator (reference scripts/play.py:159-172 "random" agent)."""
+    return torch.rand((self.sim.num_envs, self.m.nu), device=self.key_qpos.device, generator=self.gen) * 2 - 1
+
+  def observation_rows(self) -> torch.Tensor:
+    """A policy-observation-sized row per env (99 floats for G1) for the gather path."""
+    d = self.sim.data
+    parts = [d.qvel, d.qpos[:, 7:] if self.has_free else d.qpos, d.ctrl, d.sensordata]
+    if self.has_free:
+      parts.append(d.qpos[:, 3:7])
+    return torch.cat(parts, dim=1)
+
+
+def g1_action_scale(model: Model) -> np.ndarray:
+  from . import robots
+
+  names = [model.names["joint"][j].split("/")[-1] for j in model.actuator_trnid[:, 0]]
+  return robots.action_scale(robots.g1_actuators(), names).astype(np.float32)
+
+
+def go1_action_scale(model: Model) -> np.ndarray:
+  from . import robots
+
+  names = [model.names["joint"][j].split("/")[-1] for j in model.actuator_trnid[:, 0]]
+  return robots.action_scale(robots.go1_actuators(), names).astype(np.float32)
+
+
+_ = math

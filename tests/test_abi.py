@@ -1,0 +1,63 @@
+"""C-ABI library: loads, exports every symbol include/mjlab_amd.h declares, layouts agree."""
+
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from mjlab_amd import _abi, native, robots
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_exports_every_declared_symbol():
+  L = native.lib()
+  header = (ROOT / "include" / "mjlab_amd.h").read_text()
+  declared = set(re.findall(r"\b(mjlab_[a-z_]+)\s*\(", header))
+  assert declared == set(native.EXPORTED_SYMBOLS)
+  for sym in declared:
+    assert hasattr(L, sym), sym
+  assert L.mjlab_abi_version() == 1
+
+
+def test_layout_matches_struct_sizes():
+  mf, df, MS, DS = native.layouts()
+  L = native.lib()
+  assert ctypes.sizeof(MS) == L.mjlab_sizeof_model()
+  assert ctypes.sizeof(DS) == L.mjlab_sizeof_data()
+  assert {"qpos", "qvel", "ctrl", "xpos", "xquat", "cvel", "subtree_com", "sensordata", "actuator_force"} <= {f.name for f in df}
+  m = robots.load_model("g1_velocity_flat")
+  for f in mf:  # every model field the kernels need exists on the host model
+    assert hasattr(m, f.name), f.name
+
+
+def test_oracle_and_product_share_layout():
+  from oracle.oracle import _load
+
+  o = _load("f64")
+  L = native.lib()
+  assert o.mjo_model_layout() == L.mjlab_model_layout()
+  assert o.mjo_data_layout() == L.mjlab_data_layout()
+
+
+def test_no_cpu_fallback():
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  with pytest.raises(RuntimeError, match="no CPU fallback"):
+    Simulation(2, SimulationCfg(), robots.pendulum_model(), "cpu")
+
+
+def test_product_does_not_import_oracle():
+  for p in (ROOT / "mjlab_amd").rglob("*.py"):
+    txt = p.read_text()
+    assert "import oracle" not in txt and "from oracle" not in txt, p
+  for p in (ROOT / "mjlab_amd" / "csrc").glob("*"):
+    if p.suffix in (".hip", ".h", ".cpp"):
+      assert "oracle" not in p.read_text().lower(), p
+
+
+def test_default_capacities():
+  m = robots.load_model("g1_velocity_flat")
+  ncon, njmax = _abi.default_capacities(m, 140_000, 300)
+  assert njmax == 300 and ncon == 300

@@ -1,0 +1,242 @@
+"""HIP path vs the CPU oracle on seeded inputs, through the Simulation boundary / C ABI.
+
+Tolerances: the device computes in fp32, the oracle in fp64.  State-like outputs
+(qpos, qvel, kinematics) must agree to 1e-5 relative (north_star); quantities that pass
+through the iterative constraint solver (qacc, constraint forces) to 1e-3, because the
+fp32 termination test stops at a slightly different Newton iterate.
+"""
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tools"))
+
+pytestmark = pytest.mark.gpu
+
+from make_golden import golden_inputs, models  # noqa: E402
+
+from oracle.oracle import OracleSim  # noqa: E402
+
+KIN = ("xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat", "site_xpos", "site_xmat",
+       "subtree_com", "cinert", "cdof", "qM", "qLD")  # fmt: skip
+VEL = ("cvel", "cdof_dot", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "actuator_force", "qfrc_smooth")
+
+
+def _rel(a, b):
+  a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+  return np.abs(a - b).max() / max(1e-6, np.abs(b).max()) if b.size else 0.0
+
+
+def _pair(name, nworld=8, seed=11, graph=False, njmax=300):
+  import torch
+
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = models()[name]
+  qpos, qvel, ctrl = golden_inputs(model, nworld, seed)
+  sim = Simulation(nworld, SimulationCfg(njmax=njmax, use_graph=graph), model, "cuda:0")
+  ora = OracleSim(model, nworld, njmax=njmax, precision="f64")
+  for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+    getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+    getattr(ora, f)[:] = v
+  return sim, ora, model
+
+
+def _np(t):
+  import torch
+
+  torch.cuda.synchronize()
+  return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["box", "mixed", "go1_velocity_flat", "g1_velocity_flat", "g1_tracking_flat"])
+def test_forward_all_fields(name):
+  sim, ora, model = _pair(name)
+  sim.forward()
+  ora.forward()
+  assert np.array_equal(_np(sim.data.ncon).ravel(), ora.ncon.ravel())
+  assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
+  for f in KIN:
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 2e-6, f
+  for f in VEL:
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-5, f
+  # constraint rows: same order by construction (pair order, limits first)
+  nv = model.nv
+  for w in range(sim.num_envs):
+    n = int(ora.nefc[w, 0])
+    Jg = _np(sim.data.efc_J)[w].reshape(-1, nv)[:n]
+    assert _rel(Jg, ora.efc_J[w].reshape(-1, nv)[:n]) < 1e-5
+    for f in ("efc_D", "efc_aref", "efc_pos"):
+      assert _rel(_np(getattr(sim.data, f))[w, :n], getattr(ora, f)[w, :n]) < 1e-4, f
+  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 1e-4
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
+  assert _rel(_np(sim.data.qfrc_constraint), ora.qfrc_constraint) < 1e-3
+  assert np.array_equal(_np(sim.data.sensordata), ora.sensordata.astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["pendulum", "box", "mixed", "go1_velocity_flat", "g1_velocity_flat"])
+def test_rollout_state(name):
+  if name == "pendulum":
+    import torch
+
+    from mjlab_amd import robots
+    from mjlab_amd.sim import Simulation, SimulationCfg
+
+    model = robots.pendulum_model()
+    sim = Simulation(3, SimulationCfg(), model, "cuda:0")
+    ora = OracleSim(model, 3)
+    q0 = np.array([[0.5], [-1.0], [2.5]])
+    sim.data.qpos[:] = torch.from_numpy(q0.astype(np.float32)).cuda()
+    ora.qpos[:] = q0
+    nstep, tq, tv = 200, 1e-4, 1e-3
+  else:
+    sim, ora, model = _pair(name)
+    nstep, tq, tv = 10, 2e-5, 1e-3
+  for _ in range(nstep):
+    sim.step()
+  ora.step(nstep)
+  assert _rel(_np(sim.data.qpos), ora.qpos) < tq
+  assert _rel(_np(sim.data.qvel), ora.qvel) < tv
+  assert _np(sim.data.time) == pytest.approx(ora.time.ravel(), rel=1e-5)
+
+
+def test_graph_replay_equals_eager():
+  a, _, _ = _pair("g1_velocity_flat", graph=False)
+  b, _, _ = _pair("g1_velocity_flat", graph=True)
+  assert b.step_graph is not None
+  for _ in range(5):
+    a.step()
+    b.step()
+  a.forward()
+  b.forward()
+  for f in ("qpos", "qvel", "qacc", "xpos", "sensordata"):
+    assert np.array_equal(_np(getattr(a.data, f)), _np(getattr(b.data, f))), f
+
+
+def test_single_world_and_odd_world_counts():
+  for nworld in (1, 3, 67):
+    sim, ora, _ = _pair("go1_velocity_flat", nworld=nworld)
+    sim.step()
+    ora.step()
+    assert _rel(_np(sim.data.qpos), ora.qpos) < 1e-5
+
+
+def test_row_capacity_overflow_is_consistent():
+  # njmax smaller than the rows the state wants: both sides must drop the same contacts
+  sim, ora, _ = _pair("g1_velocity_flat", njmax=24)
+  sim.forward()
+  ora.forward()
+  assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
+  assert _np(sim.data.nefc).max() <= 24
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
+
+
+def test_no_contact_state_and_zero_ctrl():
+  import torch
+
+  sim, ora, model = _pair("g1_velocity_flat")
+  sim.data.qpos[:, 2] += 2.0
+  ora.qpos[:, 2] += 2.0
+  sim.data.ctrl[:] = 0
+  ora.ctrl[:] = 0
+  sim.step()
+  ora.step()
+  assert int(_np(sim.data.ncon).max()) == 0
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 1e-5
+  torch.cuda.synchronize()
+
+
+def test_xfrc_and_qfrc_applied():
+  import torch
+
+  sim, ora, model = _pair("go1_velocity_flat")
+  rng = np.random.default_rng(5)
+  xf = np.zeros((sim.num_envs, model.nbody, 6))
+  xf[:, 2] = rng.normal(0, 20, (sim.num_envs, 6))
+  xf[::2, 7, :3] = rng.normal(0, 10, (sim.num_envs // 2, 3))
+  qf = rng.normal(0, 2, (sim.num_envs, model.nv))
+  sim.data.xfrc_applied[:] = torch.from_numpy(xf.astype(np.float32)).cuda()
+  sim.data.qfrc_applied[:] = torch.from_numpy(qf.astype(np.float32)).cuda()
+  ora.xfrc_applied[:] = xf
+  ora.qfrc_applied[:] = qf
+  sim.forward()
+  ora.forward()
+  assert _rel(_np(sim.data.qfrc_smooth), ora.qfrc_smooth) < 1e-5
+  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 1e-4
+
+
+def test_expand_model_fields_per_world_friction():
+  import torch
+
+  sim, ora, model = _pair("g1_velocity_flat")
+  with pytest.raises(ValueError, match="Fields not found"):
+    sim.expand_model_fields(["not_a_field"])
+  before = sim.model.geom_friction
+  assert before.shape == (sim.num_envs, model.ngeom, 3) and before.stride(0) == 0
+  sim.expand_model_fields(["geom_friction", "body_ipos", "qpos0"])
+  fr = sim.model.geom_friction
+  assert fr.stride(0) == model.ngeom * 3
+  assert torch.equal(fr[5], torch.from_numpy(model.geom_friction.astype(np.float32)).cuda())
+  rng = np.random.default_rng(9)
+  feet = [i for i, n in enumerate(model.names["geom"]) if "foot" in n and n.endswith("collision")]
+  vals = rng.uniform(0.3, 1.2, (sim.num_envs, len(feet)))
+  ptr = fr.data_ptr()
+  env_grid = torch.arange(sim.num_envs).cuda()[:, None]
+  fr[env_grid, torch.tensor(feet).cuda()[None, :], 0] = torch.from_numpy(vals.astype(np.float32)).cuda()
+  assert sim.model.geom_friction.data_ptr() == ptr
+  ofr = ora.expand_model_field("geom_friction")
+  ofr[:, feet, 0] = vals
+  sim.create_graph()
+  for _ in range(3):
+    sim.step()
+  ora.step(3)
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 1e-3
+  assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-5
+  # and friction really matters: a world with different friction diverges from world-shared friction
+  sim2, _, _ = _pair("g1_velocity_flat")
+  for _ in range(3):
+    sim2.step()
+  assert _rel(_np(sim2.data.qvel), _np(sim.data.qvel)) > 1e-4
+
+
+def test_bridge_contract():
+  import torch
+
+  sim, _, model = _pair("go1_velocity_flat", nworld=4)
+  assert sim.data.nworld == 4
+  assert sim.data.qpos.shape == (4, model.nq) and sim.data.xpos.shape == (4, model.nbody, 3)
+  assert sim.data.xmat.shape == (4, model.nbody, 3, 3) and sim.data.geom_xmat.shape == (4, model.ngeom, 3, 3)
+  assert sim.data.cvel.shape == (4, model.nbody, 6) and sim.data.time.shape == (4,)
+  assert sim.model.geom_bodyid.shape == (model.ngeom,) and sim.model.jnt_range.shape == (4, model.njnt, 2)
+  with pytest.raises(AttributeError, match="read-only"):
+    sim.data.qpos = torch.zeros(1)
+  with pytest.raises(AttributeError):
+    sim.model.body_mass = torch.zeros(1)
+  ptr = sim.data.qpos.data_ptr()
+  sim.data.qpos[1:3, 0] = 0.5
+  assert sim.data.qpos.data_ptr() == ptr and float(sim.data.qpos[2, 0]) == 0.5
+  assert float((sim.data.qpos * 2.0)[1, 0]) == 1.0  # plain torch ops work
+
+
+def test_rollout_driver_runs_and_resets():
+  import torch
+
+  from mjlab_amd import robots
+  from mjlab_amd.rollout import PhysicsRollout, g1_action_scale
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = robots.load_model("g1_velocity_flat")
+  sim = Simulation(256, SimulationCfg(njmax=300), model, "cuda:0")
+  roll = PhysicsRollout(sim, action_scale=g1_action_scale(model), seed=1)
+  nreset = 0
+  for _ in range(60):
+    nreset += int(roll.step(roll.random_action()).sum())
+  torch.cuda.synchronize()
+  assert torch.isfinite(sim.data.qpos).all()
+  assert float(sim.data.qpos[:, 2].min()) > 0.2  # fallen robots were reset
+  assert roll.observation_rows().shape == (256, 99)
+  assert nreset > 0

@@ -1,0 +1,193 @@
+"""The CPU oracle against analytic cases and physical invariants.
+
+The reference holds no numeric golden vectors for the step ("parity
+unpinned"), so the restatement is pinned to physics instead: pendulum period and energy,
+free fall, resting contact force = m g, momentum conservation in free flight, M SPD,
+M qacc + bias = tau + J^T f, and the KKT conditions of the constraint solver.
+"""
+
+import math
+
+import numpy as np
+import pytest
+
+from mjlab_amd import mjcf, robots
+from oracle.oracle import OracleSim
+
+
+def test_pendulum_period_and_energy():
+  m = robots.pendulum_model()
+  s = OracleSim(m)
+  s.qpos[0, 0] = 0.05
+  th, en = [], []
+  inertia = 0.0841667 + 1.0 * 0.25
+  for _ in range(5000):
+    s.step()
+    th.append(s.qpos[0, 0])
+    en.append(0.5 * inertia * s.qvel[0, 0] ** 2 + 9.81 * 0.5 * (1 - math.cos(s.qpos[0, 0])))
+  th = np.array(th)
+  zc = np.where((th[:-1] > 0) & (th[1:] <= 0))[0]
+  period = (zc[-1] - zc[0]) / (len(zc) - 1) * m.opt.timestep
+  assert period == pytest.approx(2 * math.pi * math.sqrt(inertia / (9.81 * 0.5)), rel=2e-3)
+  assert max(en) / min(en) < 1.02  # semi-implicit Euler: bounded energy drift
+
+
+def test_pendulum_implicitfast_matches_euler_without_damping():
+  a, b = OracleSim(robots.pendulum_model(mjcf.INT_EULER)), OracleSim(robots.pendulum_model(mjcf.INT_IMPLICITFAST))
+  for s in (a, b):
+    s.qpos[0, 0] = 0.5
+    s.step(200)
+  assert a.qpos[0, 0] == pytest.approx(b.qpos[0, 0], abs=1e-12)
+
+
+def test_free_fall():
+  m = robots.box_model()
+  s = OracleSim(m)
+  s.qpos[0, 2] = 5.0
+  s.step(100)
+  t = 100 * m.opt.timestep
+  assert s.qvel[0, 2] == pytest.approx(-9.81 * t, rel=1e-9)
+  assert s.ncon[0, 0] == 0 and s.time[0, 0] == pytest.approx(t)
+
+
+def test_box_resting_force_is_mg():
+  s = OracleSim(robots.box_model())
+  s.step(600)
+  n = s.nefc[0, 0]
+  assert s.ncon[0, 0] == 4 and n == 16
+  # pyramidal rows: the normal force of a contact is the sum of its 4 row forces
+  assert s.efc_force[0, :n].sum() == pytest.approx(2 * 9.81, rel=1e-6)
+  assert np.abs(s.qvel[0]).max() < 1e-6
+  assert s.qpos[0, 2] == pytest.approx(0.1, abs=2e-3)
+
+
+def test_momentum_conserved_in_free_flight():
+  m = robots.load_model("g1_velocity_flat")
+  s = OracleSim(m)
+  s.reset(key=0)
+  s.qpos[0, 2] = 3.0
+  rng = np.random.default_rng(0)
+  s.qvel[0] = rng.normal(0, 1.0, m.nv)
+  s.mfield["actuator_gainprm"][:] = 0
+  s.mfield["actuator_biasprm"][:] = 0
+  g = np.array(m.opt.gravity)
+
+  def momentum():
+    s.forward()
+    mass = m.body_mass
+    # linear momentum from body com velocities: v_com = cvel_lin + w x (xipos - subtree_com[root])
+    p = np.zeros(3)
+    for b in range(1, m.nbody):
+      w, v = s.cvel[0, b, :3], s.cvel[0, b, 3:]
+      off = s.xipos[0, b] - s.subtree_com[0, m.body_rootid[b]]
+      p += mass[b] * (v + np.cross(w, off))
+    return p
+
+  total = m.body_mass.sum()
+  errs = []
+  q0, v0 = s.qpos.copy(), s.qvel.copy()
+  for h, n in ((0.005, 40), (0.00125, 160)):  # discretisation error must shrink with the timestep
+    s.qpos[:], s.qvel[:] = q0, v0
+    s._m.opt.timestep = h
+    p0 = momentum()
+    s.step(n)
+    p1 = momentum()
+    assert s.ncon[0, 0] == 0
+    errs.append(np.abs(p1 - p0 - total * g * n * h).max())
+  assert errs[0] < 0.1 and errs[1] < 0.4 * errs[0]
+
+
+def test_mass_matrix_matches_jacobian_form_and_is_spd():
+  m = robots.load_model("go1_velocity_flat")
+  s = OracleSim(m)
+  rng = np.random.default_rng(1)
+  s.reset(key=0)
+  s.qpos[0, 7:] += rng.normal(0, 0.3, m.nq - 7)
+  q = rng.normal(size=4)
+  s.qpos[0, 3:7] = q / np.linalg.norm(q)
+  s.forward()
+  M = s.qM[0].reshape(m.nv, m.nv)
+  kin = mjcf.kinematics_np(m, s.qpos[0])
+  assert np.allclose(M, mjcf.mass_matrix_np(m, kin), atol=1e-10)
+  assert np.allclose(M, M.T) and np.linalg.eigvalsh(M).min() > 0
+  L = s.qLD[0].reshape(m.nv, m.nv)
+  assert np.allclose(L @ L.T, M, atol=1e-10)
+  assert np.allclose(s.xpos[0], kin["xpos"], atol=1e-12)
+
+
+def test_equation_of_motion_and_kkt():
+  m = robots.load_model("g1_velocity_flat")
+  s = OracleSim(m, njmax=300)
+  s.reset(key=0)
+  s.qpos[0, 2] -= 0.03
+  rng = np.random.default_rng(2)
+  s.qvel[0] = rng.normal(0, 0.3, m.nv)
+  s.ctrl[0] += rng.normal(0, 0.2, m.nu)
+  old_it = m.opt.iterations
+  s._m.opt.iterations = 100
+  s.forward()
+  s._m.opt.iterations = old_it
+  nv, n = m.nv, s.nefc[0, 0]
+  assert n > 0
+  M = s.qM[0].reshape(nv, nv)
+  J = s.efc_J[0].reshape(-1, nv)[:n]
+  f = s.efc_force[0, :n]
+  # M qacc = qfrc_smooth + J^T f
+  assert M @ s.qacc[0] == pytest.approx(s.qfrc_smooth[0] + J.T @ f, rel=1e-6, abs=1e-6)
+  assert s.qfrc_constraint[0] == pytest.approx(J.T @ f, rel=1e-9, abs=1e-9)
+  # KKT of the unilateral rows: f >= 0, f = -D min(0, J a - aref)
+  jar = J @ s.qacc[0] - s.efc_aref[0, :n]
+  assert np.all(f >= 0)
+  assert f == pytest.approx(-s.efc_D[0, :n] * np.minimum(0, jar), rel=1e-6, abs=1e-7)
+  # smooth dynamics: M qacc_smooth = qfrc_smooth
+  assert M @ s.qacc_smooth[0] == pytest.approx(s.qfrc_smooth[0], rel=1e-8, abs=1e-8)
+
+
+def test_joint_limit_pushes_back():
+  m = robots.mixed_model()
+  s = OracleSim(m)
+  ja = m.names["joint"].index("elbow")
+  qa, da = m.jnt_qposadr[ja], m.jnt_dofadr[ja]
+  s.qpos[0, qa] = 0.15  # beyond the upper limit 0.05
+  s.ctrl[0] = [0.0, 0.5] if m.actuator_trnid[0, 0] != ja else [0.5, 0.0]
+  s.forward()
+  n = s.nefc[0, 0]
+  rows = [r for r in range(n) if s.efc_type[0, r] == 3]
+  assert len(rows) == 1 and s.efc_pos[0, rows[0]] == pytest.approx(-0.1)
+  assert s.efc_J[0].reshape(-1, m.nv)[rows[0], da] == -1.0
+  assert s.qfrc_constraint[0, da] < 0
+
+
+def test_contact_primitives_and_sensor():
+  m = robots.mixed_model()
+  s = OracleSim(m)
+  s.forward()
+  g = s.contact_geom[0, : s.ncon[0, 0]]
+  types = {(m.geom_type[a], m.geom_type[b]) for a, b in g}
+  # every primitive pair of the path appears in the initial configuration
+  assert {(0, 2), (0, 3), (2, 2), (2, 3), (3, 3)} <= types
+  assert s.sensordata[0, 0] == 2  # cap-floor contact sensor "found": both capsule ends
+  s.step(400)
+  assert np.all(np.isfinite(s.qpos)) and np.abs(s.qvel).max() < 50
+
+
+def test_f32_build_tracks_f64():
+  m = robots.load_model("go1_velocity_flat")
+  a, b = OracleSim(m, 2, precision="f64"), OracleSim(m, 2, precision="f32")
+  for s in (a, b):
+    s.reset(key=0)
+    s.step(20)
+  assert b.qpos == pytest.approx(a.qpos, rel=1e-4, abs=1e-4)
+
+
+def test_threads_give_identical_results():
+  m = robots.load_model("go1_velocity_flat")
+  a, b = OracleSim(m, 16), OracleSim(m, 16)
+  rng = np.random.default_rng(3)
+  q = rng.normal(0, 0.05, (16, m.nq - 7))
+  for s in (a, b):
+    s.reset(key=0)
+    s.qpos[:, 7:] += q
+  a.step(10, nthread=1)
+  b.step(10, nthread=4)
+  assert np.array_equal(a.qpos, b.qpos)

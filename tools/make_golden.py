@@ -1,0 +1,71 @@
+"""Generate tests/golden/*.npz: seeded inputs and fp64-oracle outputs for each scene.
+
+The reference holds no numeric golden vectors for the step and cannot be run here (its
+engine, mujoco_warp/mujoco, is not installed) -- SURVEY.md section 8c.  These fixtures are
+therefore REGRESSION vectors produced by this repository's own fp64 oracle; they pin the
+oracle (CPU test) and the HIP path (GPU test) to each other over time, not to upstream.
+"""
+
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from mjlab_amd import robots  # noqa: E402
+from oracle.oracle import OracleSim  # noqa: E402
+
+OUT_FIELDS = ("qpos", "qvel", "qacc", "xpos", "xquat", "cvel", "subtree_com", "sensordata", "actuator_force", "qfrc_bias")
+
+
+def golden_inputs(model, nworld, seed):
+  rng = np.random.default_rng(seed)
+  base = model.key_qpos[0] if model.nkey else model.qpos0
+  qpos = np.tile(base, (nworld, 1))
+  qvel = rng.normal(0, 0.3, size=(nworld, model.nv))
+  for j in range(model.njnt):
+    qa = model.jnt_qposadr[j]
+    if model.jnt_type[j] == 0:
+      qpos[:, qa + 2] += rng.uniform(-0.04, 0.02, size=nworld)
+      q = qpos[:, qa + 3 : qa + 7] + rng.normal(0, 0.05, size=(nworld, 4))
+      qpos[:, qa + 3 : qa + 7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    else:
+      qpos[:, qa] += rng.normal(0, 0.1, size=nworld)
+  ctrl = np.zeros((nworld, model.nu))
+  if model.nu:
+    jn = model.actuator_trnid[:, 0]
+    ctrl = qpos[:, model.jnt_qposadr[jn]] + rng.normal(0, 0.2, size=(nworld, model.nu))
+  return qpos, qvel, ctrl
+
+
+def models():
+  out = {n: robots.load_model(n) for n in robots.SCENES}
+  out["mixed"] = robots.mixed_model()
+  out["box"] = robots.box_model()
+  return out
+
+
+def main():
+  gold = ROOT / "tests" / "golden"
+  gold.mkdir(exist_ok=True)
+  for name, model in models().items():
+    nworld, nstep = 4, 5
+    qpos, qvel, ctrl = golden_inputs(model, nworld, seed=7)
+    s = OracleSim(model, nworld, njmax=300, precision="f64")
+    s.qpos[:], s.qvel[:], s.ctrl[:] = qpos, qvel, ctrl
+    s.forward()
+    blob = {"in_qpos": qpos, "in_qvel": qvel, "in_ctrl": ctrl, "nstep": np.array(nstep)}
+    for f in OUT_FIELDS + ("nefc", "ncon"):
+      blob["fwd_" + f] = getattr(s, f).copy()
+    s.step(nstep)
+    s.forward()
+    for f in OUT_FIELDS + ("nefc", "ncon"):
+      blob["step_" + f] = getattr(s, f).copy()
+    np.savez_compressed(gold / f"{name}.npz", **blob)
+    print(name, "nefc after forward", s.nefc.ravel())
+
+
+if __name__ == "__main__":
+  main()
