@@ -69,6 +69,9 @@ int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stag
  * dst[w * nelem + i] = src[i] for w < nworld, elements of `elem_size` bytes (4 or 8). */
 int mjlab_tile_field(void* dst, const void* src, long long nelem, int nworld, int elem_size, void* stream);
 
+/* Device self-test of the wave-level primitives (DPP reductions); synchronises `stream`. */
+int mjlab_selftest(void* stream);
+
 /* LDS bytes per workgroup of each stage kernel for this model (occupancy reporting). */
 int mjlab_lds_bytes(const mjlab_model_t* m, int stage);
 

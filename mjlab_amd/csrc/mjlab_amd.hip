@@ -41,14 +41,37 @@ typedef float __attribute__((ext_vector_type(4))) f32x4;
 __device__ __forceinline__ float lane_bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
+// DPP cross-lane moves (no LDS traffic): dpp_ctrl encodings of the GFX9 family --
+// quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141, row_bcast:15 0x142,
+// row_bcast:31 0x143.  Lanes disabled by row_mask receive `old` (= 0 here).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+// Sum over each row of 16 lanes (xor-butterfly 1,2 | half-mirror | mirror); every lane of the
+// row ends with the row total.
+__device__ __forceinline__ float group16_sum(float v) {
+  v += dpp_mov<0xB1, 0xF, true>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xF, true>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xF, true>(v);  // row_half_mirror
+  v += dpp_mov<0x140, 0xF, true>(v);  // row_mirror
+  return v;
+}
 // Sum over the wave; the result is made explicitly wave-uniform (SGPR) so that the solver's
 // control flow compiles to scalar branches.
 __device__ __forceinline__ float wave_sum(float v) {
+  v = group16_sum(v);
+  v += dpp_mov<0x142, 0xA, false>(v);  // rows 1,3 += lane 15 of rows 0,2
+  v += dpp_mov<0x143, 0xC, false>(v);  // rows 2,3 += lane 31
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// reference implementations through the LDS crossbar (used by the self-test only)
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+  return v;
 }
-__device__ __forceinline__ float group16_sum(float v) {
+__device__ __forceinline__ float group16_sum_shfl(float v) {
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
@@ -157,18 +180,36 @@ __device__ __forceinline__ bool dof_in_chain(const Model& m, int body, int dof) 
 }
 
 // ------------------------------------------------------------------------------------
-// dense Cholesky in LDS, one wave, n <= 64.  A is n x n with leading dimension ld (odd, so
-// that both row and column walks are bank-conflict free for ds_read_b32); lower triangle
-// in, L out (in place); invd[k] = 1 / L[k][k].
+// dense Cholesky in LDS, one wave, n <= 64.  A is n x n with leading dimension
+// ld = chol_ld(n) (a multiple of 4 with ld/4 odd: rows are 16-byte aligned and a
+// ds_read_b128 of the same column chunk from 16 different rows is bank-conflict free);
+// lower triangle in, L out (in place); invd[k] = 1 / L[k][k].  Left-looking by column,
+// lane i owns row i: the dot products stream two rows with 128-bit LDS reads into four
+// independent accumulators.
 // ------------------------------------------------------------------------------------
+__host__ __device__ inline int chol_ld(int n) {
+  int ld = (n + 3) & ~3;
+  if ((ld & 7) == 0) ld += 4;
+  return ld;
+}
 __device__ void chol_factor_lds(float* A, float* invd, int n, int ld, int lane) {
   for (int j = 0; j < n; ++j) {
     float t = 0.f;
     if (lane >= j && lane < n) {
-      t = A[lane * ld + j];
-      const float* ri = A + lane * ld;
-      const float* rj = A + j * ld;
-      for (int k = 0; k < j; ++k) t -= ri[k] * rj[k];
+      const float4* ri = reinterpret_cast<const float4*>(A + lane * ld);
+      const float4* rj = reinterpret_cast<const float4*>(A + j * ld);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      const int j4 = j >> 2, rem = j & 3;
+      for (int k = 0; k < j4; ++k) {
+        const float4 a = ri[k], b = rj[k];
+        s0 += a.x * b.x; s1 += a.y * b.y; s2 += a.z * b.z; s3 += a.w * b.w;
+      }
+      const float4 a = ri[j4], b = rj[j4];
+      if (rem > 0) s0 += a.x * b.x;
+      if (rem > 1) s1 += a.y * b.y;
+      if (rem > 2) s2 += a.z * b.z;
+      const float aij = rem == 0 ? a.x : rem == 1 ? a.y : rem == 2 ? a.z : a.w;
+      t = aij - ((s0 + s1) + (s2 + s3));
     }
     float djj = lane_bcast(t, j);
     djj = fmaxf(djj, MINVAL);
@@ -196,10 +237,13 @@ __device__ float chol_solve_lds(const float* L, const float* invd, int n, int ld
 // lane i owns v_i and y_i.  Row j is read coalesced, v_j is broadcast from lane j.
 __device__ float symm_mul_global(const float* M, int n, float v, int lane) {
   float y = 0.f;
-  for (int j = 0; j < n; ++j) {
-    float vj = lane_bcast(v, j);
-    float mij = lane < n ? M[j * n + lane] : 0.f;
-    y += mij * vj;
+  for (int j0 = 0; j0 < n; j0 += 8) {
+    float mv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mv[u] = (lane < n && j0 + u < n) ? M[(j0 + u) * n + lane] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + u < n) y += mv[u] * lane_bcast(v, j0 + u);
   }
   return y;
 }
@@ -217,8 +261,8 @@ __device__ __forceinline__ void local2global(float* xp, float* xm, const float* 
 }
 
 __host__ __device__ inline int position_lds_floats(const mjlab_sizes_t& s) {
-  int nb = s.nbody, nv = s.nv, nj = s.njnt, ld = nv | 1;
-  int persistent = 3 * nb + 10 * nb + 10 * nb + 6 * nv + 6 * nv;
+  int nb = s.nbody, nv = s.nv, nj = s.njnt, ld = chol_ld(nv);
+  int persistent = (3 * nb + 10 * nb + 10 * nb + 6 * nv + 6 * nv + 3) & ~3;
   int kin = s.nq + 28 * nb + 6 * nj;
   int mat = nv * ld + nv;
   return persistent + (kin > mat ? kin : mat);
@@ -233,7 +277,7 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
   float* s_crb = s_cinert + 10 * nb;
   float* s_cdof = s_crb + 10 * nb;
   float* s_buf = s_cdof + 6 * nv;
-  float* regA = s_buf + 6 * nv;
+  float* regA = smem + ((23 * nb + 12 * nv + 3) & ~3);  // 16-byte aligned for the Cholesky row reads
   float* s_qpos = regA;
   float* s_xpos = s_qpos + nq;
   float* s_xquat = s_xpos + 3 * nb;
@@ -242,7 +286,7 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
   float* s_ximat = s_xipos + 3 * nb;
   float* s_xanchor = s_ximat + 9 * nb;
   float* s_xaxis = s_xanchor + 3 * nj;
-  const int ld = nv | 1;
+  const int ld = chol_ld(nv);
   float* s_M = regA;  // aliases the kinematics region once it has been consumed
   float* s_invd = s_M + nv * ld;
 
@@ -1027,7 +1071,7 @@ __global__ __launch_bounds__(64) void k_constraint(const Model m, const Data d) 
 struct LsPnt { float alpha, cost, d0, d1; };
 
 __host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
-  int ld = s.nv | 1;
+  int ld = chol_ld(s.nv);
   return s.nv * ld + s.nv + 3 * s.njmax + s.nv;
 }
 
@@ -1155,6 +1199,7 @@ __device__ __forceinline__ void ls_eval(SolveCtx<NB>& c, LsPnt* p, float alpha) 
 template <int NB>
 __device__ __forceinline__ int update_bracket(SolveCtx<NB>& c, LsPnt* p, const LsPnt* cand, LsPnt* pnext) {
   int flag = 0;
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
     if (p->d0 < 0.f && cand[i].d0 < 0.f && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
     else if (p->d0 > 0.f && cand[i].d0 > 0.f && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
@@ -1187,11 +1232,12 @@ __device__ float line_search(SolveCtx<NB>& c, float gtol, int lsmax) {
   while (c.ls_iter < lsmax) {
     ls_eval(c, &pmid, 0.5f * (p1.alpha + p2.alpha));
     LsPnt cand[3] = {p1next, p2next, pmid};
-    float bestcost = 0.f;
-    int best = -1;
+    float bestcost = 0.f, bestalpha = 0.f;
+    bool found = false;
+#pragma unroll
     for (int i = 0; i < 3; ++i)
-      if (fabsf(cand[i].d0) < gtol && (best == -1 || cand[i].cost < bestcost)) { bestcost = cand[i].cost; best = i; }
-    if (best >= 0) return cand[best].alpha;
+      if (fabsf(cand[i].d0) < gtol && (!found || cand[i].cost < bestcost)) { bestcost = cand[i].cost; bestalpha = cand[i].alpha; found = true; }
+    if (found) return bestalpha;
     const int b1 = update_bracket(c, &p1, cand, &p1next);
     const int b2 = update_bracket(c, &p2, cand, &p2next);
     if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : 0.f;
@@ -1216,7 +1262,7 @@ __global__ __launch_bounds__(64) void k_solve_integrate(const Model m, const Dat
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
-  const int ld = nv | 1;
+  const int ld = chol_ld(nv);
   SolveCtx<NB> c;
   c.s_H = smem;
   c.s_invd = c.s_H + nv * ld;
@@ -1404,6 +1450,15 @@ __global__ void k_tile(T* dst, const T* src, long long nelem, long long total) {
     dst[i] = src[i % nelem];
 }
 
+// self-test of the DPP reductions against the ds_bpermute versions
+__global__ void k_selftest(const float* in, int* nerr) {
+  const float v = in[blockIdx.x * 64 + threadIdx.x];
+  const float a = wave_sum(v), b = wave_sum_shfl(v);
+  const float c = group16_sum(v), e = group16_sum_shfl(v);
+  const float tol = 1e-4f * (1.f + fabsf(b));
+  if (fabsf(a - b) > tol || fabsf(c - e) > 1e-4f * (1.f + fabsf(e))) atomicAdd(nerr, 1);
+}
+
 // ====================================================================================
 // C ABI
 // ====================================================================================
@@ -1491,6 +1546,28 @@ int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void
     int rc = mjlab_forward_stages(m, d, MJLAB_STAGE_STEP, stream);
     if (rc) return rc;
   }
+  return 0;
+}
+
+int mjlab_selftest(void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = 16, n = nblk * 64;
+  float h[16 * 64];
+  unsigned x = 12345u;
+  for (int i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = (float)(int)(x >> 8) / 8388608.f - 1.f; }
+  float* din = nullptr;
+  int* derr = nullptr;
+  int herr = -1;
+  if (hipMalloc(&din, sizeof(h)) != hipSuccess || hipMalloc(&derr, sizeof(int)) != hipSuccess) return fail(-11, "selftest: hipMalloc");
+  hipMemcpyAsync(din, h, sizeof(h), hipMemcpyHostToDevice, st);
+  hipMemsetAsync(derr, 0, sizeof(int), st);
+  hipLaunchKernelGGL(k_selftest, dim3(nblk), dim3(64), 0, st, din, derr);
+  hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, st);
+  hipError_t e = hipStreamSynchronize(st);
+  hipFree(din);
+  hipFree(derr);
+  if (e != hipSuccess) return fail((int)e, "selftest failed to run");
+  if (herr != 0) return fail(-12, "selftest: DPP wave reductions disagree with the shuffle reference");
   return 0;
 }
 

@@ -240,3 +240,11 @@ def test_rollout_driver_runs_and_resets():
   assert float(sim.data.qpos[:, 2].min()) > 0.2  # fallen robots were reset
   assert roll.observation_rows().shape == (256, 99)
   assert nreset > 0
+
+
+def test_device_selftest_wave_primitives():
+  import torch
+
+  from mjlab_amd import native
+
+  native.check(native.lib().mjlab_selftest(torch.cuda.current_stream().cuda_stream), "mjlab_selftest")
