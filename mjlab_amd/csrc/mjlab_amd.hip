@@ -93,6 +93,28 @@ __device__ __forceinline__ void global_to_lds(float* dst, const float* src, int 
   for (int k = lane; k < n; k += 64) dst[k] = src[k];
 }
 
+// Dense n x n matrix copies between row-major global memory (leading dimension n) and LDS
+// (leading dimension ld); lanes walk consecutive global elements, (i, j) tracked without
+// integer division.
+__device__ __forceinline__ void dense_global_to_lds(float* dst, const float* src, int n, int ld, int lane, bool lower_only) {
+  int i = 0, j = lane;
+  while (j >= n) { j -= n; ++i; }
+  for (int k = lane; k < n * n; k += 64) {
+    if (!lower_only || j <= i) dst[i * ld + j] = src[k];
+    j += 64;
+    while (j >= n) { j -= n; ++i; }
+  }
+}
+__device__ __forceinline__ void dense_lds_to_global(float* dst, const float* src, int n, int ld, int lane, bool zero_upper) {
+  int i = 0, j = lane;
+  while (j >= n) { j -= n; ++i; }
+  for (int k = lane; k < n * n; k += 64) {
+    dst[k] = (zero_upper && j > i) ? 0.f : src[i * ld + j];
+    j += 64;
+    while (j >= n) { j -= n; ++i; }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // small math (quaternions w-x-y-z, row-major 3x3)
 // ------------------------------------------------------------------------------------
@@ -213,7 +235,10 @@ __device__ void chol_factor_lds(float* A, float* invd, int n, int ld, int lane) 
     }
     float djj = lane_bcast(t, j);
     djj = fmaxf(djj, MINVAL);
-    float dsq = sqrtf(djj), inv = 1.0f / dsq;
+    // v_rsq_f32 (1 ulp) + one Newton step instead of IEEE sqrt and divide
+    float inv = __builtin_amdgcn_rsqf(djj);
+    inv = inv * (1.5f - 0.5f * djj * inv * inv);
+    const float dsq = djj * inv;
     if (lane == j) { A[j * ld + j] = dsq; invd[j] = inv; }
     else if (lane > j && lane < n) A[lane * ld + j] = t * inv;
     __syncthreads();
@@ -496,16 +521,10 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
     }
   }
   __syncthreads();
-  {
-    float* qM = d.qM + (size_t)w * nv * nv;
-    for (int k = lane; k < nv * nv; k += 64) { int i = k / nv, j = k - i * nv; qM[k] = s_M[i * ld + j]; }
-  }
+  dense_lds_to_global(d.qM + (size_t)w * nv * nv, s_M, nv, ld, lane, false);
   __syncthreads();
   chol_factor_lds(s_M, s_invd, nv, ld, lane);
-  {
-    float* qLD = d.qLD + (size_t)w * nv * nv;
-    for (int k = lane; k < nv * nv; k += 64) { int i = k / nv, j = k - i * nv; qLD[k] = j <= i ? s_M[i * ld + j] : 0.f; }
-  }
+  dense_lds_to_global(d.qLD + (size_t)w * nv * nv, s_M, nv, ld, lane, true);
 }
 
 // ====================================================================================
@@ -1123,7 +1142,7 @@ __device__ __forceinline__ void jac_mul(const SolveCtx<NB>& c, const float (&x16
 
 // One pass over J: H = M + J^T diag(D*active) J into LDS (lower triangle) via fp32 MFMA and
 // the lane-owned constraint force qfrc_constraint_i = sum_r J[r][i] f_r.
-template <int NB>
+template <int NB, bool WITH_H>
 __device__ __forceinline__ float hessian_pass(const SolveCtx<NB>& c) {
   constexpr int NT = NB * (NB + 1) / 2;
   f32x4 acc[NT];
@@ -1148,30 +1167,34 @@ __device__ __forceinline__ float hessian_pass(const SolveCtx<NB>& c) {
       jtf[cb] += x[cb] * f;
       a[cb] = dact * x[cb];
     }
+    if (WITH_H) {
+      int t = 0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int Jb = 0; Jb <= I; ++Jb) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[Jb], acc[t], 0, 0, 0);
+          ++t;
+        }
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) { jtf[cb] += __shfl_xor(jtf[cb], 16); jtf[cb] += __shfl_xor(jtf[cb], 32); }
+  // store tiles (+ M) to LDS, lower triangle only
+  if (WITH_H) {
     int t = 0;
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
       for (int Jb = 0; Jb <= I; ++Jb) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[Jb], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
+          if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.M[row * c.nv + cc];
+        }
         ++t;
       }
   }
-#pragma unroll
-  for (int cb = 0; cb < NB; ++cb) { jtf[cb] += __shfl_xor(jtf[cb], 16); jtf[cb] += __shfl_xor(jtf[cb], 32); }
-  // store tiles (+ M) to LDS, lower triangle only
-  int t = 0;
-#pragma unroll
-  for (int I = 0; I < NB; ++I)
-#pragma unroll
-    for (int Jb = 0; Jb <= I; ++Jb) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
-        if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.M[row * c.nv + cc];
-      }
-      ++t;
-    }
   return pick16<NB>(jtf, c.lane);
 }
 
@@ -1258,7 +1281,7 @@ __device__ __forceinline__ float constraint_cost(const float* s_jar, const float
 }
 
 template <int NB>
-__global__ __launch_bounds__(64) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate) {
+__global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
@@ -1283,8 +1306,7 @@ __global__ __launch_bounds__(64) void k_solve_integrate(const Model m, const Dat
     c.nefc = nefc;
     // qacc_smooth = M^-1 qfrc_smooth using the factor from the position stage
     {
-      const float* qLD = d.qLD + (size_t)w * nv * nv;
-      for (int k = lane; k < nv * nv; k += 64) { int i = k / nv, j = k - i * nv; c.s_H[i * ld + j] = qLD[k]; }
+      dense_global_to_lds(c.s_H, d.qLD + (size_t)w * nv * nv, nv, ld, lane, true);
       __syncthreads();
       if (own) c.s_invd[lane] = 1.0f / c.s_H[lane * ld + lane];
       __syncthreads();
@@ -1313,7 +1335,7 @@ __global__ __launch_bounds__(64) void k_solve_integrate(const Model m, const Dat
       float Ma;
       if (cost_ws > cost_s) {
         qacc = qas;
-        Ma = symm_mul_global(c.M, nv, qas, lane);
+        Ma = qs;  // M qacc_smooth = qfrc_smooth
         for (int r = lane; r < nefc; r += 64) c.s_jar[r] = c.s_jv[r];
         __syncthreads();
       } else {
@@ -1326,7 +1348,7 @@ __global__ __launch_bounds__(64) void k_solve_integrate(const Model m, const Dat
       float cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
       float gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
       cost += gauss;
-      fc = hessian_pass<NB>(c);
+      fc = hessian_pass<NB, true>(c);
       float grad = own ? Ma - qs - fc : 0.f;
       __syncthreads();
       chol_factor_lds(c.s_H, c.s_invd, nv, ld, lane);
@@ -1351,22 +1373,35 @@ __global__ __launch_bounds__(64) void k_solve_integrate(const Model m, const Dat
         if (alpha == 0.f) break;
         qacc += alpha * search;
         Ma += alpha * Mv;
-        for (int r = lane; r < nefc; r += 64) c.s_jar[r] += alpha * c.s_jv[r];
+        bool changed = false;  // did any row switch between active and satisfied?
+        for (int r = lane; r < nefc; r += 64) {
+          const float o = c.s_jar[r], nw = o + alpha * c.s_jv[r];
+          changed |= (o < 0.f) != (nw < 0.f);
+          c.s_jar[r] = nw;
+        }
+        const bool any_changed = __ballot(changed) != 0ull;
         __syncthreads();
         const float oldcost = cost;
         cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
         gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
         cost += gauss;
-        fc = hessian_pass<NB>(c);
+        // Gradient first: the convergence test only needs J^T f, so the Hessian, its Cholesky
+        // factor and the next search direction are computed only when another iteration
+        // follows (identical results: a direction computed before a break is never used).
+        fc = hessian_pass<NB, false>(c);
         grad = own ? Ma - qs - fc : 0.f;
-        __syncthreads();
-        chol_factor_lds(c.s_H, c.s_invd, nv, ld, lane);
-        search = -chol_solve_lds(c.s_H, c.s_invd, nv, ld, grad, lane);
-        if (!own) search = 0.f;
         const float improvement = scale * (oldcost - cost);
         const float gradient = scale * sqrtf(wave_sum(grad * grad));
         iter++;
-        if (improvement < tol || gradient < tol) break;
+        if (improvement < tol || gradient < tol || iter >= maxiter) break;
+        if (any_changed) {  // same active set -> same H -> the factor in LDS is still valid
+          __syncthreads();
+          hessian_pass<NB, true>(c);
+          __syncthreads();
+          chol_factor_lds(c.s_H, c.s_invd, nv, ld, lane);
+        }
+        search = -chol_solve_lds(c.s_H, c.s_invd, nv, ld, grad, lane);
+        if (!own) search = 0.f;
       }
       if (lane == 0) d.solver_niter[w] = iter;
       for (int r = lane; r < nefc; r += 64) {
@@ -1403,10 +1438,7 @@ __global__ __launch_bounds__(64) void k_solve_integrate(const Model m, const Dat
     }
     if (__ballot(need)) {
       __syncthreads();
-      for (int k = lane; k < nv * nv; k += 64) {
-        int i = k / nv, j = k - i * nv;
-        if (j <= i) c.s_H[i * ld + j] = c.M[k];
-      }
+      dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
       __syncthreads();
       if (own) c.s_H[lane * ld + lane] += h * diag;
       __syncthreads();
