@@ -202,75 +202,141 @@ __device__ __forceinline__ bool dof_in_chain(const Model& m, int body, int dof) 
 }
 
 // ------------------------------------------------------------------------------------
-// dense Cholesky in LDS, one wave, n <= 64.  A is n x n with leading dimension
-// ld = chol_ld(n) (a multiple of 4 with ld/4 odd: rows are 16-byte aligned and a
-// ds_read_b128 of the same column chunk from 16 different rows is bank-conflict free);
-// lower triangle in, L out (in place); invd[k] = 1 / L[k][k].  Left-looking by column,
-// lane i owns row i: the dot products stream two rows with 128-bit LDS reads into four
-// independent accumulators.
+// Dense Cholesky A = L L^T for one world, n <= 64, REGISTER-RESIDENT: lane i owns row i of
+// the lower triangle in NVP VGPRs (NVP = nv padded to a compile-time size; rows >= nv are
+// identity).  The left-looking column sweep is fully unrolled, so L[j][k] is a
+// v_readlane of lane j's k-th register feeding an FMA with an SGPR operand: no LDS traffic
+// and no barriers inside the factorization (about 2 instructions per multiply-add instead
+// of the ~12 an LDS-resident sweep needs).  The matrix travels through LDS only to move
+// between layouts: MFMA tiles -> rows (before), rows -> columns of L for the backward
+// substitution (after).  LDS leading dimension LD is a multiple of 4 with LD/4 odd, so the
+// per-lane 128-bit row accesses are bank-conflict free.
 // ------------------------------------------------------------------------------------
-__host__ __device__ inline int chol_ld(int n) {
-  int ld = (n + 3) & ~3;
-  if ((ld & 7) == 0) ld += 4;
-  return ld;
+template <int NVP>
+struct CholCfg {
+  static constexpr int LD = (NVP % 8 == 4) ? NVP : NVP + 4;
+  static constexpr int NB = (NVP + 15) / 16;  // 16-column blocks for the MFMA Hessian
+};
+
+// row `lane` of the LDS matrix into registers; rows >= n become identity rows
+template <int NVP>
+__device__ __forceinline__ void chol_load_row(const float* A, int n, int lane, float (&a)[NVP]) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  const int row = lane < NVP ? lane : NVP - 1;
+  const float4* r = reinterpret_cast<const float4*>(A + row * LD);
+#pragma unroll
+  for (int c = 0; c < NVP / 4; ++c) {
+    const float4 v = r[c];
+    a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+  }
+#pragma unroll
+  for (int j = 0; j < NVP; ++j) a[j] = lane >= n ? (j == lane ? 1.f : 0.f) : a[j];
 }
-__device__ void chol_factor_lds(float* A, float* invd, int n, int ld, int lane) {
-  for (int j = 0; j < n; ++j) {
-    float t = 0.f;
-    if (lane >= j && lane < n) {
-      const float4* ri = reinterpret_cast<const float4*>(A + lane * ld);
-      const float4* rj = reinterpret_cast<const float4*>(A + j * ld);
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      const int j4 = j >> 2, rem = j & 3;
-      for (int k = 0; k < j4; ++k) {
-        const float4 a = ri[k], b = rj[k];
-        s0 += a.x * b.x; s1 += a.y * b.y; s2 += a.z * b.z; s3 += a.w * b.w;
-      }
-      const float4 a = ri[j4], b = rj[j4];
-      if (rem > 0) s0 += a.x * b.x;
-      if (rem > 1) s1 += a.y * b.y;
-      if (rem > 2) s2 += a.z * b.z;
-      const float aij = rem == 0 ? a.x : rem == 1 ? a.y : rem == 2 ? a.z : a.w;
-      t = aij - ((s0 + s1) + (s2 + s3));
+// in-register factorization; on return a[j] = L[lane][j] (zero above the diagonal) and the
+// function value is 1 / L[lane][lane]
+template <int NVP>
+__device__ __forceinline__ float chol_factor_regs(float (&a)[NVP], int lane) {
+  float invd = 1.f;
+#pragma unroll
+  for (int j = 0; j < NVP; ++j) {
+    float t0 = a[j], t1 = 0.f;
+#pragma unroll
+    for (int k = 0; k + 1 < j; k += 2) {
+      t0 -= a[k] * lane_bcast(a[k], j);
+      t1 -= a[k + 1] * lane_bcast(a[k + 1], j);
     }
-    float djj = lane_bcast(t, j);
-    djj = fmaxf(djj, MINVAL);
-    // v_rsq_f32 (1 ulp) + one Newton step instead of IEEE sqrt and divide
-    float inv = __builtin_amdgcn_rsqf(djj);
+    if (j & 1) t0 -= a[j - 1] * lane_bcast(a[j - 1], j);
+    const float t = t0 + t1;
+    const float djj = fmaxf(lane_bcast(t, j), MINVAL);
+    float inv = __builtin_amdgcn_rsqf(djj);  // v_rsq_f32 (1 ulp) + one Newton step
     inv = inv * (1.5f - 0.5f * djj * inv * inv);
-    const float dsq = djj * inv;
-    if (lane == j) { A[j * ld + j] = dsq; invd[j] = inv; }
-    else if (lane > j && lane < n) A[lane * ld + j] = t * inv;
-    __syncthreads();
+    a[j] = lane > j ? t * inv : (lane == j ? djj * inv : 0.f);
+    invd = lane == j ? inv : invd;
+    // keep the scheduler from hoisting later columns' v_readlane results (SGPRs) across
+    // this point: hundreds of live broadcasts would spill SGPRs into VGPRs
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return invd;
+}
+// A (LDS, lower triangle valid for rows < n) -> L (LDS, full rows incl. zero upper part),
+// s_invd[i] = 1 / L[i][i].  Caller synchronises before (A complete) and after (L visible).
+template <int NVP>
+__device__ __forceinline__ void chol_factor(float* A, float* s_invd, int n, int lane) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  float a[NVP];
+  chol_load_row<NVP>(A, n, lane, a);
+  const float invd = chol_factor_regs<NVP>(a, lane);
+  if (lane < NVP) {
+    float4* r = reinterpret_cast<float4*>(A + lane * LD);
+#pragma unroll
+    for (int c = 0; c < NVP / 4; ++c) r[c] = make_float4(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+    s_invd[lane] = invd;
   }
 }
-// Solves L L^T x = b where lane i owns b_i (lanes >= n pass anything); returns x_i.
-__device__ float chol_solve_lds(const float* L, const float* invd, int n, int ld, float b, int lane) {
-  for (int k = 0; k < n; ++k) {
-    float xk = lane_bcast(b, k) * invd[k];
-    if (lane == k) b = xk;
-    else if (lane > k && lane < n) b -= L[lane * ld + k] * xk;
+// Solves L L^T x = b with L in LDS (as left by chol_factor); lane i owns b_i / x_i
+// (lanes >= n must pass 0).  Forward substitution uses row i of L, backward substitution
+// row i of L^T (= column i of L, read with unit stride across lanes).
+template <int NVP>
+__device__ __forceinline__ float chol_solve(const float* L, const float* s_invd, int lane, float b) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  const int li = lane < NVP ? lane : NVP - 1;
+  const float invd = s_invd[li];
+  {
+    float a[NVP];
+    const float4* r = reinterpret_cast<const float4*>(L + li * LD);
+#pragma unroll
+    for (int c = 0; c < NVP / 4; ++c) {
+      const float4 v = r[c];
+      a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+      const float xk = lane_bcast(b * invd, k);
+      b = lane == k ? xk : fmaf(-a[k], xk, b);  // a[k] = 0 for lanes < k
+    }
   }
-  for (int k = n - 1; k >= 0; --k) {
-    float xk = lane_bcast(b, k) * invd[k];
-    if (lane == k) b = xk;
-    else if (lane < k) b -= L[k * ld + lane] * xk;
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float at[NVP];
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) at[k] = L[k * LD + li];  // L[k][i]: zero for k < i
+#pragma unroll
+    for (int k = NVP - 1; k >= 0; --k) {
+      const float xk = lane_bcast(b * invd, k);
+      b = lane == k ? xk : fmaf(-at[k], xk, b);
+    }
   }
   return b;
 }
 // y_i = sum_j M[i][j] v_j with M symmetric, dense row-major in GLOBAL memory (ld = n);
-// lane i owns v_i and y_i.  Row j is read coalesced, v_j is broadcast from lane j.
-__device__ float symm_mul_global(const float* M, int n, float v, int lane) {
-  float y = 0.f;
-  for (int j0 = 0; j0 < n; j0 += 8) {
-    float mv[8];
+// lane i owns v_i and y_i.  Row j is read coalesced (M[j][i] = M[i][j]), v_j comes from
+// lane j by v_readlane; fully unrolled so all loads are in flight together.
+template <int NVP>
+__device__ __forceinline__ float symm_mul_global(const float* M, int n, float v, int lane) {
+  // The element offset is made opaque to the optimiser: otherwise the NVP row addresses are
+  // loop-invariant 64-bit VGPR pairs that get hoisted out of the Newton loop and spilled.
+  int off = lane < n ? lane : 0;
+  asm volatile("" : "+v"(off));
+  constexpr int CH = 12;  // loads in flight per chunk
+  float y0 = 0.f, y1 = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) mv[u] = (lane < n && j0 + u < n) ? M[(j0 + u) * n + lane] : 0.f;
+  for (int j0 = 0; j0 < NVP; j0 += CH) {
+    float mv[CH];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (j0 + u < n) y += mv[u] * lane_bcast(v, j0 + u);
+    for (int u = 0; u < CH; ++u) {
+      const int j = j0 + u;
+      mv[u] = (j < NVP && j < n) ? M[j * n + off] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int j = j0 + u;
+      if (j < NVP) {
+        if (u & 1) y1 = fmaf(mv[u], lane_bcast(v, j), y1);
+        else y0 = fmaf(mv[u], lane_bcast(v, j), y0);
+      }
+    }
   }
-  return y;
+  return lane < n ? y0 + y1 : 0.f;
 }
 
 // ====================================================================================
@@ -286,10 +352,10 @@ __device__ __forceinline__ void local2global(float* xp, float* xm, const float* 
 }
 
 __host__ __device__ inline int position_lds_floats(const mjlab_sizes_t& s) {
-  int nb = s.nbody, nv = s.nv, nj = s.njnt, ld = chol_ld(nv);
+  int nb = s.nbody, nv = s.nv, nj = s.njnt, ld = nv | 1;
   int persistent = (3 * nb + 10 * nb + 10 * nb + 6 * nv + 6 * nv + 3) & ~3;
   int kin = s.nq + 28 * nb + 6 * nj;
-  int mat = nv * ld + nv;
+  int mat = nv * ld;
   return persistent + (kin > mat ? kin : mat);
 }
 
@@ -311,9 +377,8 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
   float* s_ximat = s_xipos + 3 * nb;
   float* s_xanchor = s_ximat + 9 * nb;
   float* s_xaxis = s_xanchor + 3 * nj;
-  const int ld = chol_ld(nv);
-  float* s_M = regA;  // aliases the kinematics region once it has been consumed
-  float* s_invd = s_M + nv * ld;
+  const int ld = nv | 1;  // odd: conflict-free row and column walks
+  float* s_M = regA;      // aliases the kinematics region once it has been consumed
 
   global_to_lds(s_qpos, d.qpos + (size_t)w * nq, nq, lane);
   if (lane == 0) {
@@ -521,10 +586,8 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
     }
   }
   __syncthreads();
+  // the Cholesky factor of M (mj_factorM) is produced by the solve stage, where it is used
   dense_lds_to_global(d.qM + (size_t)w * nv * nv, s_M, nv, ld, lane, false);
-  __syncthreads();
-  chol_factor_lds(s_M, s_invd, nv, ld, lane);
-  dense_lds_to_global(d.qLD + (size_t)w * nv * nv, s_M, nv, ld, lane, true);
 }
 
 // ====================================================================================
@@ -1089,17 +1152,25 @@ __global__ __launch_bounds__(64) void k_constraint(const Model m, const Data d) 
 // ====================================================================================
 struct LsPnt { float alpha, cost, d0, d1; };
 
+// compile-time padded sizes the solve kernel is instantiated for
+__host__ __device__ inline int solve_nvp(int nv) {
+  const int sizes[] = {8, 16, 20, 24, 32, 36, 40, 48, 64};
+  for (int i = 0; i < 9; ++i) if (nv <= sizes[i]) return sizes[i];
+  return -1;
+}
 __host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
-  int ld = chol_ld(s.nv);
-  return s.nv * ld + s.nv + 3 * s.njmax + s.nv;
+  const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
+  return nvp * ld + nvp + 3 * s.njmax + 64;
 }
 
-template <int NB>
+template <int NVP>
 struct SolveCtx {
+  static constexpr int NB = CholCfg<NVP>::NB;
+  static constexpr int ld = CholCfg<NVP>::LD;
   const float* J;  // global, row-major nefc x nv
   const float* M;  // global, dense nv x nv
   float *s_H, *s_invd, *s_jar, *s_jv, *s_D;
-  int nv, ld, nefc, lane;
+  int nv, nefc, lane;
   float quad_gauss[3];
   int ls_iter;
 };
@@ -1119,8 +1190,9 @@ __device__ __forceinline__ float pick16(const float (&v)[NB], int lane) {
 }
 
 // out[r] = sum_i J[r][i] x_i (+ out2 for a second vector); lanes form 4 row groups x 16 columns
-template <int NB, bool TWO>
-__device__ __forceinline__ void jac_mul(const SolveCtx<NB>& c, const float (&x16)[NB], const float (&y16)[NB], float* out, float* out2) {
+template <int NVP, bool TWO>
+__device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x16)[CholCfg<NVP>::NB], const float (&y16)[CholCfg<NVP>::NB], float* out, float* out2) {
+  constexpr int NB = CholCfg<NVP>::NB;
   const int sub = c.lane >> 4, col = c.lane & 15;
   for (int r0 = 0; r0 < c.nefc; r0 += 4) {
     const int r = r0 + sub;
@@ -1142,8 +1214,9 @@ __device__ __forceinline__ void jac_mul(const SolveCtx<NB>& c, const float (&x16
 
 // One pass over J: H = M + J^T diag(D*active) J into LDS (lower triangle) via fp32 MFMA and
 // the lane-owned constraint force qfrc_constraint_i = sum_r J[r][i] f_r.
-template <int NB, bool WITH_H>
-__device__ __forceinline__ float hessian_pass(const SolveCtx<NB>& c) {
+template <int NVP, bool WITH_H>
+__device__ __forceinline__ float hessian_pass(const SolveCtx<NVP>& c) {
+  constexpr int NB = CholCfg<NVP>::NB;
   constexpr int NT = NB * (NB + 1) / 2;
   f32x4 acc[NT];
   float jtf[NB];
@@ -1182,6 +1255,10 @@ __device__ __forceinline__ float hessian_pass(const SolveCtx<NB>& c) {
   for (int cb = 0; cb < NB; ++cb) { jtf[cb] += __shfl_xor(jtf[cb], 16); jtf[cb] += __shfl_xor(jtf[cb], 32); }
   // store tiles (+ M) to LDS, lower triangle only
   if (WITH_H) {
+    // per-lane part of the M offset, opaque so that the 4 NT addresses are not hoisted out of
+    // the Newton loop as 64-bit VGPR pairs (and then spilled)
+    int moff = sub * 4 * c.nv + col;
+    asm volatile("" : "+v"(moff));
     int t = 0;
 #pragma unroll
     for (int I = 0; I < NB; ++I)
@@ -1190,7 +1267,7 @@ __device__ __forceinline__ float hessian_pass(const SolveCtx<NB>& c) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
-          if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.M[row * c.nv + cc];
+          if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.M[(16 * I + k) * c.nv + 16 * Jb + moff];
         }
         ++t;
       }
@@ -1198,8 +1275,8 @@ __device__ __forceinline__ float hessian_pass(const SolveCtx<NB>& c) {
   return pick16<NB>(jtf, c.lane);
 }
 
-template <int NB>
-__device__ __forceinline__ void ls_eval(SolveCtx<NB>& c, LsPnt* p, float alpha) {
+template <int NVP>
+__device__ __forceinline__ void ls_eval(SolveCtx<NVP>& c, LsPnt* p, float alpha) {
   float cost = 0.f, d0 = 0.f, d1 = 0.f;
   for (int r = c.lane; r < c.nefc; r += 64) {
     const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r];
@@ -1219,8 +1296,8 @@ __device__ __forceinline__ void ls_eval(SolveCtx<NB>& c, LsPnt* p, float alpha) 
   p->alpha = alpha; p->cost = cost; p->d0 = d0; p->d1 = d1;
   c.ls_iter++;
 }
-template <int NB>
-__device__ __forceinline__ int update_bracket(SolveCtx<NB>& c, LsPnt* p, const LsPnt* cand, LsPnt* pnext) {
+template <int NVP>
+__device__ __forceinline__ int update_bracket(SolveCtx<NVP>& c, LsPnt* p, const LsPnt* cand, LsPnt* pnext) {
   int flag = 0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -1231,8 +1308,8 @@ __device__ __forceinline__ int update_bracket(SolveCtx<NB>& c, LsPnt* p, const L
   return flag;
 }
 // exact 1-D line search on the piecewise-quadratic cost (safeguarded Newton + bracketing)
-template <int NB>
-__device__ float line_search(SolveCtx<NB>& c, float gtol, int lsmax) {
+template <int NVP>
+__device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
   LsPnt p0, p1, p2, pmid, p1next, p2next;
   c.ls_iter = 0;
   ls_eval(c, &p0, 0.f);
@@ -1280,22 +1357,22 @@ __device__ __forceinline__ float constraint_cost(const float* s_jar, const float
   return wave_sum(cost);
 }
 
-template <int NB>
+template <int NVP>
 __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NB = CholCfg<NVP>::NB, ld = CholCfg<NVP>::LD;
   const int w = blockIdx.x, lane = threadIdx.x;
   const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
-  const int ld = chol_ld(nv);
-  SolveCtx<NB> c;
+  SolveCtx<NVP> c;
   c.s_H = smem;
-  c.s_invd = c.s_H + nv * ld;
-  c.s_jar = c.s_invd + nv;
+  c.s_invd = c.s_H + NVP * ld;
+  c.s_jar = c.s_invd + NVP;
   c.s_jv = c.s_jar + njm;
   c.s_D = c.s_jv + njm;
-  float* s_vec = c.s_D + njm;  // nv scratch (new qvel for the position update)
+  float* s_vec = c.s_D + njm;  // 64 floats of scratch (new qvel for the position update)
   c.J = d.efc_J + (size_t)w * njm * nv;
   c.M = d.qM + (size_t)w * nv * nv;
-  c.nv = nv; c.ld = ld; c.lane = lane;
+  c.nv = nv; c.lane = lane;
   const size_t wv = (size_t)w * nv + lane;
   const bool own = lane < nv;
   const float qs = own ? d.qfrc_smooth[wv] : 0.f;
@@ -1304,14 +1381,13 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
   if (do_solve) {
     const int nefc = d.nefc[w];
     c.nefc = nefc;
-    // qacc_smooth = M^-1 qfrc_smooth using the factor from the position stage
-    {
-      dense_global_to_lds(c.s_H, d.qLD + (size_t)w * nv * nv, nv, ld, lane, true);
-      __syncthreads();
-      if (own) c.s_invd[lane] = 1.0f / c.s_H[lane * ld + lane];
-      __syncthreads();
-    }
-    const float qas = chol_solve_lds(c.s_H, c.s_invd, nv, ld, qs, lane);
+    // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
+    dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
+    __syncthreads();
+    chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+    __syncthreads();
+    dense_lds_to_global(d.qLD + (size_t)w * nv * nv, c.s_H, nv, ld, lane, true);
+    const float qas = chol_solve<NVP>(c.s_H, c.s_invd, lane, qs);
     __syncthreads();
     if (own) d.qacc_smooth[wv] = qas;
     if (nefc == 0) {
@@ -1325,11 +1401,11 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
       float x16[NB], y16[NB];
       gather16<NB>(ws, x16, lane);
       gather16<NB>(qas, y16, lane);
-      jac_mul<NB, true>(c, x16, y16, c.s_jar, c.s_jv);
+      jac_mul<NVP, true>(c, x16, y16, c.s_jar, c.s_jv);
       __syncthreads();
       for (int r = lane; r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
       __syncthreads();
-      const float Ma_ws = symm_mul_global(c.M, nv, ws, lane);
+      const float Ma_ws = symm_mul_global<NVP>(c.M, nv, ws, lane);
       float cost_ws = constraint_cost(c.s_jar, c.s_D, nefc, lane) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
       const float cost_s = constraint_cost(c.s_jv, c.s_D, nefc, lane);
       float Ma;
@@ -1348,11 +1424,12 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
       float cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
       float gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
       cost += gauss;
-      fc = hessian_pass<NB, true>(c);
+      fc = hessian_pass<NVP, true>(c);
       float grad = own ? Ma - qs - fc : 0.f;
       __syncthreads();
-      chol_factor_lds(c.s_H, c.s_invd, nv, ld, lane);
-      float search = -chol_solve_lds(c.s_H, c.s_invd, nv, ld, grad, lane);
+      chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+      __syncthreads();
+      float search = -chol_solve<NVP>(c.s_H, c.s_invd, lane, grad);
       if (!own) search = 0.f;
       int iter = 0;
       const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
@@ -1361,15 +1438,15 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         const float snorm = sqrtf(wave_sum(search * search));
         if (snorm < MINVAL) break;
         const float gtol = tol * lstol * snorm * mi * nvf;
-        const float Mv = symm_mul_global(c.M, nv, search, lane);
+        const float Mv = symm_mul_global<NVP>(c.M, nv, search, lane);
         gather16<NB>(search, x16, lane);
         __syncthreads();
-        jac_mul<NB, false>(c, x16, x16, c.s_jv, c.s_jv);
+        jac_mul<NVP, false>(c, x16, x16, c.s_jv, c.s_jv);
         __syncthreads();
         c.quad_gauss[0] = gauss;
         c.quad_gauss[1] = wave_sum(own ? search * (Ma - qs) : 0.f);
         c.quad_gauss[2] = wave_sum(own ? 0.5f * search * Mv : 0.f);
-        const float alpha = line_search<NB>(c, gtol, lsmax);
+        const float alpha = line_search<NVP>(c, gtol, lsmax);
         if (alpha == 0.f) break;
         qacc += alpha * search;
         Ma += alpha * Mv;
@@ -1388,7 +1465,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         // Gradient first: the convergence test only needs J^T f, so the Hessian, its Cholesky
         // factor and the next search direction are computed only when another iteration
         // follows (identical results: a direction computed before a break is never used).
-        fc = hessian_pass<NB, false>(c);
+        fc = hessian_pass<NVP, false>(c);
         grad = own ? Ma - qs - fc : 0.f;
         const float improvement = scale * (oldcost - cost);
         const float gradient = scale * sqrtf(wave_sum(grad * grad));
@@ -1396,11 +1473,12 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         if (improvement < tol || gradient < tol || iter >= maxiter) break;
         if (any_changed) {  // same active set -> same H -> the factor in LDS is still valid
           __syncthreads();
-          hessian_pass<NB, true>(c);
+          hessian_pass<NVP, true>(c);
           __syncthreads();
-          chol_factor_lds(c.s_H, c.s_invd, nv, ld, lane);
+          chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+          __syncthreads();
         }
-        search = -chol_solve_lds(c.s_H, c.s_invd, nv, ld, grad, lane);
+        search = -chol_solve<NVP>(c.s_H, c.s_invd, lane, grad);
         if (!own) search = 0.f;
       }
       if (lane == 0) d.solver_niter[w] = iter;
@@ -1442,8 +1520,9 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
       __syncthreads();
       if (own) c.s_H[lane * ld + lane] += h * diag;
       __syncthreads();
-      chol_factor_lds(c.s_H, c.s_invd, nv, ld, lane);
-      a = chol_solve_lds(c.s_H, c.s_invd, nv, ld, qs + fc, lane);
+      chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+      __syncthreads();
+      a = chol_solve<NVP>(c.s_H, c.s_invd, lane, own ? qs + fc : 0.f);
     }
     float qv = 0.f;
     if (own) {
@@ -1542,13 +1621,18 @@ static int check_model(const mjlab_model_t* m) {
   } while (0)
 
 static int launch_solve(const mjlab_model_t* m, const mjlab_data_t* d, int do_solve, int do_integrate, hipStream_t st) {
-  const int nblk = (m->size.nv + 15) / 16;
   const int lds = solve_lds_floats(m->size);
-  switch (nblk) {
-    case 1: LAUNCH(k_solve_integrate<1>, lds, *m, *d, do_solve, do_integrate); break;
-    case 2: LAUNCH(k_solve_integrate<2>, lds, *m, *d, do_solve, do_integrate); break;
-    case 3: LAUNCH(k_solve_integrate<3>, lds, *m, *d, do_solve, do_integrate); break;
-    default: LAUNCH(k_solve_integrate<4>, lds, *m, *d, do_solve, do_integrate); break;
+  switch (solve_nvp(m->size.nv)) {
+    case 8: LAUNCH(k_solve_integrate<8>, lds, *m, *d, do_solve, do_integrate); break;
+    case 16: LAUNCH(k_solve_integrate<16>, lds, *m, *d, do_solve, do_integrate); break;
+    case 20: LAUNCH(k_solve_integrate<20>, lds, *m, *d, do_solve, do_integrate); break;
+    case 24: LAUNCH(k_solve_integrate<24>, lds, *m, *d, do_solve, do_integrate); break;
+    case 32: LAUNCH(k_solve_integrate<32>, lds, *m, *d, do_solve, do_integrate); break;
+    case 36: LAUNCH(k_solve_integrate<36>, lds, *m, *d, do_solve, do_integrate); break;
+    case 40: LAUNCH(k_solve_integrate<40>, lds, *m, *d, do_solve, do_integrate); break;
+    case 48: LAUNCH(k_solve_integrate<48>, lds, *m, *d, do_solve, do_integrate); break;
+    case 64: LAUNCH(k_solve_integrate<64>, lds, *m, *d, do_solve, do_integrate); break;
+    default: return fail(-3, "nv must be in [1, 64]");
   }
   return 0;
 }
