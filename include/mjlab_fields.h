@@ -122,7 +122,7 @@
   X(cvel, 6, nbody)                                                             \
   X(cdof_dot, 6, nv)                                                            \
   X(qM, 1, nvnv)  /* dense nv x nv joint-space inertia (row-major) */            \
-  X(qLD, 1, nvnv) /* dense lower Cholesky factor of qM */                        \
+  X(qLD, 1, nvnv) /* dense lower Cholesky factor of qM (oracle only; the HIP factor stays in LDS) */                      \
   X(qfrc_bias, 1, nv)                                                           \
   X(qfrc_passive, 1, nv)                                                        \
   X(qfrc_actuator, 1, nv)                                                       \
@@ -143,7 +143,8 @@
   X(efc_margin, 1, njmax)                                                       \
   X(efc_D, 1, njmax)                                                            \
   X(efc_aref, 1, njmax)                                                         \
-  X(efc_force, 1, njmax)
+  X(efc_force, 1, njmax)                                                        \
+  X(profile, 16, one) /* per-world per-phase cycle counts; written only by -DMJLAB_PROFILE builds */
 
 /* ---- data: int32, leading dimension nworld ------------------------------------ */
 #define MJLAB_DATA_INT_FIELDS(X)                                                \

@@ -29,6 +29,21 @@
 typedef mjlab_model_t Model;
 typedef mjlab_data_t Data;
 typedef float __attribute__((ext_vector_type(4))) f32x4;
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+
+// Opt-in phase profiling (tools/profile_phases.py builds a second library with
+// -DMJLAB_PROFILE): accumulates shader-clock deltas per phase into data.profile[world][16].
+#ifdef MJLAB_PROFILE
+#define PROF_INIT() long long prof_last_ = clock64(); float prof_acc_[16] = {0}
+#define PROF_MARK(id) do { long long n_ = clock64(); prof_acc_[id] += (float)(n_ - prof_last_); prof_last_ = n_; } while (0)
+#define PROF_COUNT(id) prof_acc_[id] += 1.f
+#define PROF_FLUSH(ptr) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) (ptr)[i_] += prof_acc_[i_]; } while (0)
+#else
+#define PROF_INIT() do {} while (0)
+#define PROF_MARK(id) do {} while (0)
+#define PROF_COUNT(id) do {} while (0)
+#define PROF_FLUSH(ptr) do {} while (0)
+#endif
 
 #define MINVAL 1e-15f
 #define MINIMP 0.0001f
@@ -232,50 +247,45 @@ __device__ __forceinline__ void chol_load_row(const float* A, int n, int lane, f
 #pragma unroll
   for (int j = 0; j < NVP; ++j) a[j] = lane >= n ? (j == lane ? 1.f : 0.f) : a[j];
 }
-// in-register factorization; on return a[j] = L[lane][j] (zero above the diagonal) and the
-// function value is 1 / L[lane][lane]
-template <int NVP>
-__device__ __forceinline__ float chol_factor_regs(float (&a)[NVP], int lane) {
-  float invd = 1.f;
-#pragma unroll
-  for (int j = 0; j < NVP; ++j) {
-    float t0 = a[j], t1 = 0.f;
-#pragma unroll
-    for (int k = 0; k + 1 < j; k += 2) {
-      t0 -= a[k] * lane_bcast(a[k], j);
-      t1 -= a[k + 1] * lane_bcast(a[k + 1], j);
-    }
-    if (j & 1) t0 -= a[j - 1] * lane_bcast(a[j - 1], j);
-    const float t = t0 + t1;
-    const float djj = fmaxf(lane_bcast(t, j), MINVAL);
-    float inv = __builtin_amdgcn_rsqf(djj);  // v_rsq_f32 (1 ulp) + one Newton step
-    inv = inv * (1.5f - 0.5f * djj * inv * inv);
-    a[j] = lane > j ? t * inv : (lane == j ? djj * inv : 0.f);
-    invd = lane == j ? inv : invd;
-    // keep the scheduler from hoisting later columns' v_readlane results (SGPRs) across
-    // this point: hundreds of live broadcasts would spill SGPRs into VGPRs
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return invd;
-}
-// A (LDS, lower triangle valid for rows < n) -> L (LDS, full rows incl. zero upper part),
-// s_invd[i] = 1 / L[i][i].  Caller synchronises before (A complete) and after (L visible).
+// A (LDS, lower triangle valid for rows < n) -> unit-lower factor of A = Lu D Lu^T in LDS:
+// Lu[i][j] (i > j) in place, ZERO on and above the diagonal, s_invd[i] = 1 / D_i.  With the
+// zero diagonal the substitutions below are a bare v_readlane + v_fma per step (no select,
+// no per-step scaling).  The column sweep works on the Cholesky factor L (a[k] = L[i][k])
+// in registers and converts on the way out: Lu[i][j] = L[i][j] / L[j][j], D_j = L[j][j]^2.
+// Caller synchronises before (A complete) and after (factor visible).
 template <int NVP>
 __device__ __forceinline__ void chol_factor(float* A, float* s_invd, int n, int lane) {
   constexpr int LD = CholCfg<NVP>::LD;
   float a[NVP];
   chol_load_row<NVP>(A, n, lane, a);
-  const float invd = chol_factor_regs<NVP>(a, lane);
-  if (lane < NVP) {
-    float4* r = reinterpret_cast<float4*>(A + lane * LD);
+  float* out = A + (lane < NVP ? lane : NVP - 1) * LD;
 #pragma unroll
-    for (int c = 0; c < NVP / 4; ++c) r[c] = make_float4(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
-    s_invd[lane] = invd;
+  for (int j = 0; j < NVP; ++j) {
+    // t_i = A[i][j] - sum_{k<j} L[i][k] L[j][k]; two accumulators, products issued in pairs so
+    // that they map onto v_pk_fma_f32 and the v_readlane -> VALU hazard slots are filled
+    f32x2 acc = {a[j], 0.f};
+#pragma unroll
+    for (int k = 0; k + 1 < j; k += 2) {
+      const f32x2 av = {a[k], a[k + 1]};
+      const f32x2 sv = {lane_bcast(a[k], j), lane_bcast(a[k + 1], j)};
+      acc -= av * sv;
+    }
+    float t = acc.x + acc.y;
+    if (j & 1) t -= a[j - 1] * lane_bcast(a[j - 1], j);
+    const float djj = fmaxf(lane_bcast(t, j), MINVAL);
+    float inv = __builtin_amdgcn_rsqf(djj);  // v_rsq_f32 (1 ulp) + one Newton step
+    inv = inv * (1.5f - 0.5f * djj * inv * inv);
+    const float inv2 = inv * inv;            // 1 / D_j
+    a[j] = lane > j ? t * inv : 0.f;         // L[i][j] for the remaining columns
+    if (lane < NVP) out[j] = lane > j ? t * inv2 : 0.f;
+    if (lane == j) s_invd[j] = inv2;
+    // keep later columns' broadcasts (SGPRs) from being hoisted across this point
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
-// Solves L L^T x = b with L in LDS (as left by chol_factor); lane i owns b_i / x_i
-// (lanes >= n must pass 0).  Forward substitution uses row i of L, backward substitution
-// row i of L^T (= column i of L, read with unit stride across lanes).
+// Solves Lu D Lu^T x = b with the factor in LDS (as left by chol_factor); lane i owns
+// b_i / x_i (lanes >= n must pass 0).  Forward substitution uses row i of Lu, backward
+// substitution row i of Lu^T (= column i of Lu, read with unit stride across lanes).
 template <int NVP>
 __device__ __forceinline__ float chol_solve(const float* L, const float* s_invd, int lane, float b) {
   constexpr int LD = CholCfg<NVP>::LD;
@@ -290,21 +300,16 @@ __device__ __forceinline__ float chol_solve(const float* L, const float* s_invd,
       a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
     }
 #pragma unroll
-    for (int k = 0; k < NVP; ++k) {
-      const float xk = lane_bcast(b * invd, k);
-      b = lane == k ? xk : fmaf(-a[k], xk, b);  // a[k] = 0 for lanes < k
-    }
+    for (int k = 0; k < NVP; ++k) b = fmaf(-a[k], lane_bcast(b, k), b);  // a[k] = 0 for lanes <= k
   }
+  b *= invd;
   __builtin_amdgcn_sched_barrier(0);
   {
     float at[NVP];
 #pragma unroll
-    for (int k = 0; k < NVP; ++k) at[k] = L[k * LD + li];  // L[k][i]: zero for k < i
+    for (int k = 0; k < NVP; ++k) at[k] = L[k * LD + li];  // Lu[k][i]: zero for k <= i
 #pragma unroll
-    for (int k = NVP - 1; k >= 0; --k) {
-      const float xk = lane_bcast(b * invd, k);
-      b = lane == k ? xk : fmaf(-at[k], xk, b);
-    }
+    for (int k = NVP - 1; k >= 0; --k) b = fmaf(-at[k], lane_bcast(b, k), b);
   }
   return b;
 }
@@ -1377,6 +1382,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
   const bool own = lane < nv;
   const float qs = own ? d.qfrc_smooth[wv] : 0.f;
   float qacc = 0.f, fc = 0.f;
+  PROF_INIT();
 
   if (do_solve) {
     const int nefc = d.nefc[w];
@@ -1386,9 +1392,10 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     __syncthreads();
     chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
     __syncthreads();
-    dense_lds_to_global(d.qLD + (size_t)w * nv * nv, c.s_H, nv, ld, lane, true);
+    PROF_MARK(0);
     const float qas = chol_solve<NVP>(c.s_H, c.s_invd, lane, qs);
     __syncthreads();
+    PROF_MARK(1);
     if (own) d.qacc_smooth[wv] = qas;
     if (nefc == 0) {
       qacc = qas;
@@ -1420,6 +1427,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
       }
       const float nvf = (float)(nv > 1 ? nv : 1), mi = (float)m.opt.meaninertia;
       const float scale = 1.f / (mi * nvf), tol = (float)m.opt.tolerance, lstol = (float)m.opt.ls_tolerance;
+      PROF_MARK(2);
       // ---- initial constraint state, gradient, Hessian, search direction
       float cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
       float gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
@@ -1427,10 +1435,12 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
       fc = hessian_pass<NVP, true>(c);
       float grad = own ? Ma - qs - fc : 0.f;
       __syncthreads();
+      PROF_MARK(3);
       chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
       __syncthreads();
       float search = -chol_solve<NVP>(c.s_H, c.s_invd, lane, grad);
       if (!own) search = 0.f;
+      PROF_MARK(4);
       int iter = 0;
       const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
       while (iter < maxiter) {
@@ -1446,7 +1456,13 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         c.quad_gauss[0] = gauss;
         c.quad_gauss[1] = wave_sum(own ? search * (Ma - qs) : 0.f);
         c.quad_gauss[2] = wave_sum(own ? 0.5f * search * Mv : 0.f);
+        PROF_MARK(5);
         const float alpha = line_search<NVP>(c, gtol, lsmax);
+        PROF_MARK(6);
+#ifdef MJLAB_PROFILE
+        prof_acc_[10] += (float)c.ls_iter;
+        prof_acc_[11] += 1.f;
+#endif
         if (alpha == 0.f) break;
         qacc += alpha * search;
         Ma += alpha * Mv;
@@ -1470,6 +1486,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         const float improvement = scale * (oldcost - cost);
         const float gradient = scale * sqrtf(wave_sum(grad * grad));
         iter++;
+        PROF_MARK(7);
         if (improvement < tol || gradient < tol || iter >= maxiter) break;
         if (any_changed) {  // same active set -> same H -> the factor in LDS is still valid
           __syncthreads();
@@ -1480,6 +1497,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         }
         search = -chol_solve<NVP>(c.s_H, c.s_invd, lane, grad);
         if (!own) search = 0.f;
+        PROF_MARK(4);
       }
       if (lane == 0) d.solver_niter[w] = iter;
       for (int r = lane; r < nefc; r += 64) {
@@ -1497,6 +1515,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     fc = d.qfrc_constraint[wv];
   }
 
+  PROF_MARK(8);
   if (do_integrate) {
     const float h = (float)m.opt.timestep;
     float a = qacc;
@@ -1550,6 +1569,8 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     }
     if (lane == 0) d.time[w] += h;
   }
+  PROF_MARK(9);
+  PROF_FLUSH(d.profile + (size_t)w * 16);
 }
 
 // ====================================================================================

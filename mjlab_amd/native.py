@@ -15,7 +15,7 @@ from pathlib import Path
 from . import _abi
 
 CSRC = Path(__file__).parent / "csrc"
-LIB_PATH = CSRC / "libmjlab_amd.so"
+LIB_PATH = Path(os.environ.get("MJLAB_AMD_LIB", CSRC / "libmjlab_amd.so"))
 SOURCES = [CSRC / "mjlab_amd.hip"]
 HEADERS = [Path(__file__).parents[1] / "include" / "mjlab_amd.h", Path(__file__).parents[1] / "include" / "mjlab_fields.h"]
 

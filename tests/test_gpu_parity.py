@@ -22,7 +22,7 @@ from make_golden import golden_inputs, models  # noqa: E402
 from oracle.oracle import OracleSim  # noqa: E402
 
 KIN = ("xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat", "site_xpos", "site_xmat",
-       "subtree_com", "cinert", "cdof", "qM", "qLD")  # fmt: skip
+       "subtree_com", "cinert", "cdof", "qM")  # fmt: skip  (qLD: the factor never leaves the solve kernel's LDS)
 VEL = ("cvel", "cdof_dot", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "actuator_force", "qfrc_smooth")
 
 

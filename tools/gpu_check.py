@@ -15,7 +15,7 @@ from oracle.oracle import OracleSim  # noqa: E402
 
 FIELDS = [
   "xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat", "site_xpos", "subtree_com",
-  "cinert", "cdof", "qM", "qLD", "cvel", "cdof_dot", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "actuator_force",
+  "cinert", "cdof", "qM", "cvel", "cdof_dot", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "actuator_force",
   "qfrc_smooth", "qacc_smooth", "qfrc_constraint", "qacc", "qacc_warmstart", "sensordata", "qpos", "qvel", "time",
 ]  # fmt: skip
 

@@ -1,0 +1,39 @@
+"""Per-phase shader-clock breakdown of the solve kernel (GPU box).
+
+Build first (in the dev container):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMJLAB_PROFILE \
+    -shared -fPIC -o gpurun_prof/libmjlab_amd_prof.so mjlab_amd/csrc/mjlab_amd.hip
+Run: MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so python tools/profile_phases.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from mjlab_amd import robots  # noqa: E402
+from mjlab_amd.rollout import PhysicsRollout, g1_action_scale  # noqa: E402
+from mjlab_amd.sim import Simulation, SimulationCfg  # noqa: E402
+
+NAMES = ["M load+factor+qLD", "qacc_smooth solve", "warmstart", "init hessian pass", "H factor+solve", "LS prep (Mv, Jv)",
+         "LS evals", "post-LS update + J^T f", "solve tail", "integrate", "ls evals (count)", "line searches (count)"]
+
+model = robots.load_model("g1_velocity_flat")
+sim = Simulation(4096, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
+roll = PhysicsRollout(sim, action_scale=g1_action_scale(model), seed=42)
+for _ in range(40):
+  roll.step(roll.random_action())
+sim.data.profile[:] = 0
+nstep = 20
+for _ in range(nstep):
+  sim.step()
+torch.cuda.synchronize()
+p = sim.data.profile.cpu().numpy().astype(np.float64) / nstep
+tot = p[:, :10].sum(axis=1)
+print(f"mean cycles per world-step in k_solve_integrate: {tot.mean():.0f}  (p50 {np.percentile(tot,50):.0f}, p90 {np.percentile(tot,90):.0f}, max {tot.max():.0f})")
+for i, n in enumerate(NAMES):
+  if i < 10:
+    print(f"  {n:28s} {p[:, i].mean():10.0f} cycles  {100*p[:, i].mean()/tot.mean():5.1f}%")
+  else:
+    print(f"  {n:28s} {p[:, i].mean():10.2f}")
+print("nefc mean", sim.data.nefc.float().mean().item(), "niter mean", sim.data.solver_niter.float().mean().item())
