@@ -45,6 +45,15 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #define PROF_FLUSH(ptr) do {} while (0)
 #endif
 
+// The dense factor / substitution routines are large fully-unrolled bodies used at several
+// points of the solve kernel; keeping ONE out-of-line copy keeps the kernel inside the
+// instruction cache (define MJLAB_CHOL_FORCEINLINE to compare).
+#ifdef MJLAB_CHOL_FORCEINLINE
+#define CHOL_INLINE __forceinline__
+#else
+#define CHOL_INLINE __attribute__((noinline))
+#endif
+
 #define MINVAL 1e-15f
 #define MINIMP 0.0001f
 #define MAXIMP 0.9999f
@@ -254,7 +263,7 @@ __device__ __forceinline__ void chol_load_row(const float* A, int n, int lane, f
 // in registers and converts on the way out: Lu[i][j] = L[i][j] / L[j][j], D_j = L[j][j]^2.
 // Caller synchronises before (A complete) and after (factor visible).
 template <int NVP>
-__device__ __forceinline__ void chol_factor(float* A, float* s_invd, int n, int lane) {
+__device__ CHOL_INLINE void chol_factor(float* A, float* s_invd, int n, int lane) {
   constexpr int LD = CholCfg<NVP>::LD;
   float a[NVP];
   chol_load_row<NVP>(A, n, lane, a);
@@ -287,7 +296,7 @@ __device__ __forceinline__ void chol_factor(float* A, float* s_invd, int n, int 
 // b_i / x_i (lanes >= n must pass 0).  Forward substitution uses row i of Lu, backward
 // substitution row i of Lu^T (= column i of Lu, read with unit stride across lanes).
 template <int NVP>
-__device__ __forceinline__ float chol_solve(const float* L, const float* s_invd, int lane, float b) {
+__device__ CHOL_INLINE float chol_solve(const float* L, const float* s_invd, int lane, float b) {
   constexpr int LD = CholCfg<NVP>::LD;
   const int li = lane < NVP ? lane : NVP - 1;
   const float invd = s_invd[li];
@@ -1523,15 +1532,20 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     float diag = own ? MF(dof_damping)[lane] : 0.f;
     bool need = diag > 0.f;
     if (m.opt.integrator == MJLAB_INT_IMPLICITFAST) {
+      // d(qfrc_actuator)/d(qvel) of the affine-bias actuators: lanes = actuators, scattered to
+      // the owning dof through LDS (clamped actuators have zero derivative)
       need = true;
       const float *biasprm = MF(actuator_biasprm), *gear = MF(actuator_gear), *frange = MF(actuator_forcerange);
-      for (int k = 0; k < nu; ++k) {  // wave-uniform loop; the owning lane takes the term
+      s_vec[lane] = 0.f;
+      __syncthreads();
+      for (int k = lane; k < nu; k += 64) {
         const int da = m.jnt_dofadr[m.actuator_trnid[2 * k]];
-        if (da != lane) continue;
         const float f = d.actuator_force[(size_t)w * nu + k];
         if (m.actuator_forcelimited[k] && (f <= frange[2 * k] || f >= frange[2 * k + 1])) continue;
-        diag -= gear[6 * k] * gear[6 * k] * biasprm[10 * k + 2];
+        atomicAdd(&s_vec[da], -gear[6 * k] * gear[6 * k] * biasprm[10 * k + 2]);
       }
+      __syncthreads();
+      diag += s_vec[lane];
     }
     if (__ballot(need)) {
       __syncthreads();

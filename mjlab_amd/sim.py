@@ -23,7 +23,7 @@ from __future__ import annotations
 import ctypes
 import os
 from dataclasses import dataclass, field
-from typing import Literal
+from typing import Any, Literal
 
 import numpy as np
 import torch
@@ -79,6 +79,62 @@ class SimulationCfg:
   use_graph: bool = True
 
 
+def check_supported(model: Model) -> None:
+  """Reject, loudly, every model feature the HIP kernels do not implement (instead of
+  silently simulating something else).  The supported set is what BASELINE.json's
+  configurations use."""
+  if model.opt.solver != SOL_NEWTON:
+    raise NotImplementedError("only the Newton solver is implemented")
+  if model.opt.cone != CONE_PYRAMIDAL:
+    raise NotImplementedError("only the pyramidal cone is implemented")
+  if model.opt.integrator not in (INT_EULER, INT_IMPLICITFAST):
+    raise NotImplementedError("integrator must be 'euler' or 'implicitfast'")
+  if model.nv > 64:
+    raise NotImplementedError(f"nv = {model.nv} > 64: one dof per lane of a 64-wide wavefront")
+  if (np.asarray(model.jnt_type) == 1).any():
+    raise NotImplementedError("ball joints are not implemented")
+  if np.any(np.asarray(model.dof_frictionloss) != 0):
+    raise NotImplementedError("dof_frictionloss != 0 (friction-loss constraint rows) is not implemented")
+  for name in ("neq", "ntendon", "nmocap", "nflex"):
+    if int(getattr(model, name, 0)) != 0:
+      raise NotImplementedError(f"{name} != 0 is not implemented")
+  dims = np.asarray(model.geom_condim)[np.asarray(model.pair_geom).reshape(-1)] if model.npair else np.zeros(0, int)
+  if dims.size and not np.isin(dims, (1, 3)).all():
+    raise NotImplementedError("only condim 1 and 3 contacts are implemented")
+  if model.nsensor:
+    spec = np.asarray(model.sensor_intprm)[:, 0]
+    if (spec != 1).any():
+      raise NotImplementedError("contact sensors support only the 'found' data spec")
+
+
+class _NumpyView:
+  """``wp.array``-like handle: ``.numpy()`` copies the field to the host
+  (reference use: src/mjlab/viewer/viser.py:557,620-632)."""
+
+  def __init__(self, t: torch.Tensor) -> None:
+    self._t = t
+
+  def numpy(self) -> np.ndarray:
+    return self._t.detach().cpu().numpy()
+
+  @property
+  def shape(self):
+    return tuple(self._t.shape)
+
+
+class _RawStruct:
+  """Stand-in for ``sim.wp_model`` / ``sim.wp_data`` (reference sim/sim.py:152-158)."""
+
+  def __init__(self, bridge: "Bridge", opt: Any | None = None) -> None:
+    object.__setattr__(self, "_bridge", bridge)
+    if opt is not None:
+      object.__setattr__(self, "opt", opt)
+
+  def __getattr__(self, name: str) -> Any:
+    v = getattr(object.__getattribute__(self, "_bridge"), name)
+    return _NumpyView(v) if isinstance(v, torch.Tensor) else v
+
+
 class HostData:
   """Host-side ``mjData`` stand-in (qpos0 state) kept for viewers/exporters
   (reference sim/sim.py:106-107,145-150)."""
@@ -103,10 +159,7 @@ class Simulation:
         f"mjlab_amd.Simulation needs a ROCm GPU device (got '{device}', "
         f"torch.cuda.is_available()={torch.cuda.is_available()}); there is no CPU fallback"
       )
-    if model.opt.solver != SOL_NEWTON:
-      raise NotImplementedError("only the Newton solver is implemented")
-    if model.opt.cone != CONE_PYRAMIDAL:
-      raise NotImplementedError("only the pyramidal cone is implemented")
+    check_supported(model)
     self.cfg = cfg
     self.device = device
     self._dev = dev
@@ -227,6 +280,14 @@ class Simulation:
   @property
   def mj_data(self) -> HostData:
     return self._mj_data
+
+  @property
+  def wp_model(self) -> _RawStruct:
+    return _RawStruct(self._model_bridge, self._mj_model.opt)
+
+  @property
+  def wp_data(self) -> _RawStruct:
+    return _RawStruct(self._data_bridge)
 
   @property
   def data(self) -> Bridge:

@@ -1,0 +1,62 @@
+"""Host-side logic of the Simulation boundary that needs no GPU."""
+
+import copy
+
+import numpy as np
+import pytest
+
+from mjlab_amd import robots
+from mjlab_amd.sim import Simulation, SimulationCfg, check_supported
+from mjlab_amd.sim_data import Bridge
+
+
+def test_supported_models_pass():
+  for name in robots.SCENES:
+    check_supported(robots.load_model(name))
+  for m in (robots.box_model(), robots.mixed_model(), robots.pendulum_model()):
+    check_supported(m)
+
+
+@pytest.mark.parametrize(
+  "mutate, match",
+  [
+    (lambda m: setattr(m.opt, "solver", 1), "Newton"),
+    (lambda m: setattr(m.opt, "cone", 1), "pyramidal"),
+    (lambda m: m.dof_frictionloss.__setitem__(3, 0.1), "frictionloss"),
+    (lambda m: m.jnt_type.__setitem__(2, 1), "ball"),
+    (lambda m: m.geom_condim.__setitem__(slice(None), 4), "condim"),
+    (lambda m: m.sensor_intprm.__setitem__((0, 0), 3), "found"),
+  ],
+)
+def test_unsupported_features_are_rejected(mutate, match):
+  m = copy.deepcopy(robots.load_model("g1_velocity_flat"))
+  mutate(m)
+  with pytest.raises(NotImplementedError, match=match):
+    check_supported(m)
+
+
+def test_no_cpu_fallback():
+  """The product path must fail loudly without a GPU (reference: device is always cuda, scripts/train.py:29)."""
+  import torch
+
+  if torch.cuda.is_available():
+    pytest.skip("GPU present")
+  with pytest.raises(RuntimeError, match="no CPU fallback"):
+    Simulation(2, SimulationCfg(), robots.pendulum_model(), "cpu")
+
+
+def test_bridge_is_read_only_and_views_are_stable():
+  """reference tests/test_sim_data.py:62-81 semantics on the bridge class itself."""
+  import torch
+
+  t = torch.zeros(4, 3)
+  b = Bridge("sim.data", {"qpos": t}, {"nworld": 4})
+  with pytest.raises(AttributeError, match="read-only"):
+    b.qpos = torch.ones(4, 3)
+  ptr = b.qpos.data_ptr()
+  b.qpos[1:3] = 5.0
+  assert b.qpos.data_ptr() == ptr and float(t[1, 0]) == 5.0
+  assert b.nworld == 4
+  with pytest.raises(AttributeError):
+    _ = b.nope
+  assert np.array_equal(b.qpos.numpy()[0], np.zeros(3))
