@@ -144,7 +144,7 @@
   X(efc_D, 1, njmax)                                                            \
   X(efc_aref, 1, njmax)                                                         \
   X(efc_force, 1, njmax)                                                        \
-  X(profile, 16, one) /* per-world per-phase cycle counts; written only by -DMJLAB_PROFILE builds */
+  X(profile, 64, one) /* per-world per-phase cycle counts; written only by -DMJLAB_PROFILE builds */
 
 /* ---- data: int32, leading dimension nworld ------------------------------------ */
 #define MJLAB_DATA_INT_FIELDS(X)                                                \

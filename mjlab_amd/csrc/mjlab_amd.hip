@@ -367,7 +367,7 @@ __device__ __forceinline__ void local2global(float* xp, float* xm, const float* 
 
 __host__ __device__ inline int position_lds_floats(const mjlab_sizes_t& s) {
   int nb = s.nbody, nv = s.nv, nj = s.njnt, ld = nv | 1;
-  int persistent = (3 * nb + 10 * nb + 10 * nb + 6 * nv + 6 * nv + 3) & ~3;
+  int persistent = (3 * nb + 10 * nb + 10 * nb + 6 * nv + 6 * nv + nb + 3) & ~3;
   int kin = s.nq + 28 * nb + 6 * nj;
   int mat = nv * ld;
   return persistent + (kin > mat ? kin : mat);
@@ -382,7 +382,8 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
   float* s_crb = s_cinert + 10 * nb;
   float* s_cdof = s_crb + 10 * nb;
   float* s_buf = s_cdof + 6 * nv;
-  float* regA = smem + ((23 * nb + 12 * nv + 3) & ~3);  // 16-byte aligned for the Cholesky row reads
+  float* s_mass = s_buf + 6 * nv;
+  float* regA = smem + ((24 * nb + 12 * nv + 3) & ~3);  // 16-byte aligned
   float* s_qpos = regA;
   float* s_xpos = s_qpos + nq;
   float* s_xquat = s_xpos + 3 * nb;
@@ -402,59 +403,81 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
   if (lane < 9) s_xmat[lane] = (lane % 4 == 0) ? 1.f : 0.f;
   __syncthreads();
 
+  PROF_INIT();
   const float* qpos0 = MF(qpos0);
   const float *body_pos = MF(body_pos), *body_quat = MF(body_quat), *jnt_axis = MF(jnt_axis), *jnt_pos = MF(jnt_pos);
-  // ---- kinematics: one tree level at a time, lanes = bodies of the level
-  for (int L = 1; L < m.size.nlevel; ++L) {
-    const int a0 = m.level_adr[L], a1 = m.level_adr[L + 1];
-    for (int idx = a0 + lane; idx < a1; idx += 64) {
-      const int i = m.level_body[idx];
-      const int pid = m.body_parentid[i], ja = m.body_jntadr[i], jn = m.body_jntnum[i];
-      float pos[3], quat[4];
-      if (jn == 1 && m.jnt_type[ja] == MJLAB_JNT_FREE) {
-        const int qa = m.jnt_qposadr[ja];
-        for (int k = 0; k < 3; ++k) pos[k] = s_qpos[qa + k];
-        for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
-        normalize4(quat);
-        for (int k = 0; k < 3; ++k) { s_xanchor[3 * ja + k] = pos[k]; s_xaxis[3 * ja + k] = jnt_axis[3 * ja + k]; }
-      } else {
-        float t[3], bp[3], bq[4], pq[4], pm[9];
-        for (int k = 0; k < 3; ++k) bp[k] = body_pos[3 * i + k];
-        for (int k = 0; k < 4; ++k) { bq[k] = body_quat[4 * i + k]; pq[k] = s_xquat[4 * pid + k]; }
-        for (int k = 0; k < 9; ++k) pm[k] = s_xmat[9 * pid + k];
-        mul_mat_vec3(t, pm, bp);
-        for (int k = 0; k < 3; ++k) pos[k] = s_xpos[3 * pid + k] + t[k];
-        mul_quat(quat, pq, bq);
-        for (int j = ja; j < ja + jn; ++j) {
-          const int qa = m.jnt_qposadr[j];
-          float jax[3], jp[3], xax[3], anc[3];
-          for (int k = 0; k < 3; ++k) { jax[k] = jnt_axis[3 * j + k]; jp[k] = jnt_pos[3 * j + k]; }
-          rot_vec_quat(xax, jax, quat);
-          rot_vec_quat(t, jp, quat);
-          for (int k = 0; k < 3; ++k) anc[k] = t[k] + pos[k];
-          if (m.jnt_type[j] == MJLAB_JNT_SLIDE) {
-            const float dq = s_qpos[qa] - qpos0[qa];
-            for (int k = 0; k < 3; ++k) pos[k] += xax[k] * dq;
-          } else {
-            float ql[4], qn[4];
-            axis_angle2quat(ql, jax, s_qpos[qa] - qpos0[qa]);
-            mul_quat(qn, quat, ql);
-            for (int k = 0; k < 4; ++k) quat[k] = qn[k];
-            rot_vec_quat(t, jp, quat);
-            for (int k = 0; k < 3; ++k) pos[k] = anc[k] - t[k];
-          }
-          for (int k = 0; k < 3; ++k) { s_xanchor[3 * j + k] = anc[k]; s_xaxis[3 * j + k] = xax[k]; }
-        }
-      }
-      normalize4(quat);
-      float R[9];
-      quat2mat(R, quat);
-      for (int k = 0; k < 3; ++k) s_xpos[3 * i + k] = pos[k];
-      for (int k = 0; k < 4; ++k) s_xquat[4 * i + k] = quat[k];
-      for (int k = 0; k < 9; ++k) s_xmat[9 * i + k] = R[k];
+  // ---- kinematics: lane = body (nbody <= 64, enforced by check_model).  Everything that does
+  // not depend on the parent is fetched BEFORE the level sweep, so a level costs one LDS
+  // round trip (parent pose) plus arithmetic; bodies with more than one joint take the
+  // remaining joints from global memory inside the sweep.
+  {
+    const int b = lane < nb ? lane : 0;
+    const int depth = lane < nb ? m.body_depth[b] : -1;
+    const int pid = m.body_parentid[b], ja = m.body_jntadr[b], jn = m.body_jntnum[b];
+    float bp[3], bq[4], jax[3] = {0.f, 0.f, 1.f}, jp[3] = {0.f, 0.f, 0.f}, q0 = 0.f;
+    int jtype = -1, qa = 0;
+    for (int k = 0; k < 3; ++k) bp[k] = body_pos[3 * b + k];
+    for (int k = 0; k < 4; ++k) bq[k] = body_quat[4 * b + k];
+    if (jn > 0) {
+      jtype = m.jnt_type[ja];
+      qa = m.jnt_qposadr[ja];
+      for (int k = 0; k < 3; ++k) { jax[k] = jnt_axis[3 * ja + k]; jp[k] = jnt_pos[3 * ja + k]; }
+      q0 = qpos0[qa];
     }
-    __syncthreads();
+    for (int L = 1; L < m.size.nlevel; ++L) {
+      if (depth == L) {
+        float pos[3], quat[4];
+        if (jn == 1 && jtype == MJLAB_JNT_FREE) {
+          for (int k = 0; k < 3; ++k) pos[k] = s_qpos[qa + k];
+          for (int k = 0; k < 4; ++k) quat[k] = s_qpos[qa + 3 + k];
+          normalize4(quat);
+          for (int k = 0; k < 3; ++k) { s_xanchor[3 * ja + k] = pos[k]; s_xaxis[3 * ja + k] = jax[k]; }
+        } else {
+          float t[3], pq[4], pm[9];
+          for (int k = 0; k < 4; ++k) pq[k] = s_xquat[4 * pid + k];
+          for (int k = 0; k < 9; ++k) pm[k] = s_xmat[9 * pid + k];
+          mul_mat_vec3(t, pm, bp);
+          for (int k = 0; k < 3; ++k) pos[k] = s_xpos[3 * pid + k] + t[k];
+          mul_quat(quat, pq, bq);
+          for (int j = ja; j < ja + jn; ++j) {
+            float ax[3], jpos[3], xax[3], anc[3];
+            int type, qadr;
+            float qref;
+            if (j == ja) {
+              type = jtype; qadr = qa; qref = q0;
+              for (int k = 0; k < 3; ++k) { ax[k] = jax[k]; jpos[k] = jp[k]; }
+            } else {
+              type = m.jnt_type[j]; qadr = m.jnt_qposadr[j]; qref = qpos0[qadr];
+              for (int k = 0; k < 3; ++k) { ax[k] = jnt_axis[3 * j + k]; jpos[k] = jnt_pos[3 * j + k]; }
+            }
+            rot_vec_quat(xax, ax, quat);
+            rot_vec_quat(t, jpos, quat);
+            for (int k = 0; k < 3; ++k) anc[k] = t[k] + pos[k];
+            if (type == MJLAB_JNT_SLIDE) {
+              const float dq = s_qpos[qadr] - qref;
+              for (int k = 0; k < 3; ++k) pos[k] += xax[k] * dq;
+            } else {
+              float ql[4], qn[4];
+              axis_angle2quat(ql, ax, s_qpos[qadr] - qref);
+              mul_quat(qn, quat, ql);
+              for (int k = 0; k < 4; ++k) quat[k] = qn[k];
+              rot_vec_quat(t, jpos, quat);
+              for (int k = 0; k < 3; ++k) pos[k] = anc[k] - t[k];
+            }
+            for (int k = 0; k < 3; ++k) { s_xanchor[3 * j + k] = anc[k]; s_xaxis[3 * j + k] = xax[k]; }
+          }
+        }
+        normalize4(quat);
+        float R[9];
+        quat2mat(R, quat);
+        for (int k = 0; k < 3; ++k) s_xpos[3 * b + k] = pos[k];
+        for (int k = 0; k < 4; ++k) s_xquat[4 * b + k] = quat[k];
+        for (int k = 0; k < 9; ++k) s_xmat[9 * b + k] = R[k];
+      }
+      __syncthreads();
+    }
   }
+  PROF_MARK(0);
   // ---- inertial frames, geoms, sites
   const float *body_ipos = MF(body_ipos), *body_iquat = MF(body_iquat);
   for (int i = lane; i < nb; i += 64) {
@@ -495,6 +518,7 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
     }
   }
   __syncthreads();
+  PROF_MARK(1);
   lds_to_global(d.xpos + (size_t)w * 3 * nb, s_xpos, 3 * nb, lane);
   lds_to_global(d.xquat + (size_t)w * 4 * nb, s_xquat, 4 * nb, lane);
   lds_to_global(d.xmat + (size_t)w * 9 * nb, s_xmat, 9 * nb, lane);
@@ -503,13 +527,26 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
   lds_to_global(d.xanchor + (size_t)w * 3 * nj, s_xanchor, 3 * nj, lane);
   lds_to_global(d.xaxis + (size_t)w * 3 * nj, s_xaxis, 3 * nj, lane);
 
+  PROF_MARK(2);
   // ---- comPos: subtree_com (a subtree is a contiguous body-id range), cinert, cdof
   const float *mass = MF(body_mass), *stm = MF(body_subtreemass), *inertia = MF(body_inertia);
+  // body masses staged in LDS for the range sums
+  for (int i = lane; i < nb; i += 64) s_mass[i] = mass[i];
+  __syncthreads();
   for (int it = lane; it < 3 * nb; it += 64) {
     const int b = it / 3, c = it - 3 * b, e = b + m.body_subtreenum[b];
-    float acc = 0.f;
-    for (int j = b; j < e; ++j) acc += mass[j] * s_xipos[3 * j + c];
     const float sm_ = stm[b];
+    // four independent partial sums: the LDS reads of a group are in flight together
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = b;
+    for (; j + 3 < e; j += 4) {
+      a0 += s_mass[j] * s_xipos[3 * j + c];
+      a1 += s_mass[j + 1] * s_xipos[3 * j + 3 + c];
+      a2 += s_mass[j + 2] * s_xipos[3 * j + 6 + c];
+      a3 += s_mass[j + 3] * s_xipos[3 * j + 9 + c];
+    }
+    for (; j < e; ++j) a0 += s_mass[j] * s_xipos[3 * j + c];
+    const float acc = (a0 + a1) + (a2 + a3);
     s_sub[it] = sm_ < MINVAL ? s_xipos[it] : acc / sm_;
   }
   __syncthreads();
@@ -564,16 +601,25 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
     for (int a = 0; a < 6; ++a) s_cdof[6 * i + a] = c6[a];
   }
   __syncthreads();
+  PROF_MARK(3);
   lds_to_global(d.subtree_com + (size_t)w * 3 * nb, s_sub, 3 * nb, lane);
   lds_to_global(d.cinert + (size_t)w * 10 * nb, s_cinert, 10 * nb, lane);
   lds_to_global(d.cdof + (size_t)w * 6 * nv, s_cdof, 6 * nv, lane);
 
+  PROF_MARK(4);
   // ---- crb: composite inertia = sum of cinert over the subtree range
   for (int it = lane; it < 10 * nb; it += 64) {
     const int b = it / 10, c = it - 10 * b, e = b + m.body_subtreenum[b];
-    float acc = 0.f;
-    for (int j = b; j < e; ++j) acc += s_cinert[10 * j + c];
-    s_crb[it] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = b;
+    for (; j + 3 < e; j += 4) {
+      a0 += s_cinert[10 * j + c];
+      a1 += s_cinert[10 * j + 10 + c];
+      a2 += s_cinert[10 * j + 20 + c];
+      a3 += s_cinert[10 * j + 30 + c];
+    }
+    for (; j < e; ++j) a0 += s_cinert[10 * j + c];
+    s_crb[it] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
   for (int i = lane; i < nv; i += 64) {
@@ -585,23 +631,31 @@ __global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
     for (int k = 0; k < 6; ++k) s_buf[6 * i + k] = r[k];
   }
   __syncthreads();
-  // M[i][j] = cdof_j . (crb_i cdof_i) for j an ancestor dof of i (or i itself), else 0
+  PROF_MARK(5);
+  // M[i][j] = cdof_j . (crb_i cdof_i) for j an ancestor dof of i (or i itself), else 0:
+  // lane i clears row i, then walks its ancestor chain (dof_parentid) and fills both triangles
   const float* arm = MF(dof_armature);
-  for (int i = 0; i < nv; ++i) {
-    const int bi = m.dof_bodyid[i];
-    if (lane <= i) {
+  for (int k = lane; k < nv * ld; k += 64) s_M[k] = 0.f;
+  __syncthreads();
+  if (lane < nv) {
+    float f6[6];
+    for (int k = 0; k < 6; ++k) f6[k] = s_buf[6 * lane + k];
+    int j = lane;
+    while (j >= 0) {
       float v = 0.f;
-      if (dof_in_chain(m, bi, lane)) {
-        for (int k = 0; k < 6; ++k) v += s_cdof[6 * lane + k] * s_buf[6 * i + k];
-      }
-      if (lane == i) v += arm[i];
-      s_M[i * ld + lane] = v;
-      s_M[lane * ld + i] = v;
+      for (int k = 0; k < 6; ++k) v += s_cdof[6 * j + k] * f6[k];
+      if (j == lane) v += arm[lane];
+      s_M[lane * ld + j] = v;
+      s_M[j * ld + lane] = v;
+      j = m.dof_parentid[j];
     }
   }
   __syncthreads();
+  PROF_MARK(6);
   // the Cholesky factor of M (mj_factorM) is produced by the solve stage, where it is used
   dense_lds_to_global(d.qM + (size_t)w * nv * nv, s_M, nv, ld, lane, false);
+  PROF_MARK(7);
+  PROF_FLUSH(d.profile + (size_t)w * 64 + 16);
 }
 
 // ====================================================================================
@@ -998,15 +1052,37 @@ __device__ __forceinline__ void row_params(float timestep, const float* solref, 
   *aref = -b * vel - k * imp * (pos - margin);
 }
 
-__host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) { return s.nconmax + 2 * s.njmax; }
+// LDS: contact -> efc address (all contacts, for the sensors), limit rows, and one chunk of 64
+// staged contacts as structure-of-arrays (CC_* rows of 64).
+enum {
+  CC_OFF1 = 0,    // 3: contact point relative to subtree_com[root of body 1]
+  CC_OFF2 = 3,    // 3: same for body 2
+  CC_FRAME = 6,   // 9: contact frame (rows: normal, tangent 1, tangent 2)
+  CC_MASK = 15,   // 4: ancestor-dof bitmasks (lo1, hi1, lo2, hi2), int bits
+  CC_MU = 19,     // 2: friction[0], friction[1]
+  CC_B = 21,      // damping coefficient of the reference acceleration
+  CC_KIP = 22,    // stiffness * impedance * (dist - margin)
+  CC_D = 23,      // efc_D of every row of the contact
+  CC_DIST = 24,
+  CC_INC = 25,
+  CC_ADR = 26,    // first efc row (int bits) or -1
+  CC_DIM = 27,    // condim (int bits)
+  CC_NROWS = 28
+};
+__host__ __device__ inline int constraint_nlim(const mjlab_sizes_t& s) { return 2 * s.njnt < s.njmax ? 2 * s.njnt : s.njmax; }
+__host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) {
+  return s.nconmax + 2 * constraint_nlim(s) + CC_NROWS * 64;
+}
 
 __global__ __launch_bounds__(64) void k_constraint(const Model m, const Data d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ncm = m.size.nconmax, njm = m.size.njmax;
-  int* s_cadr = (int*)smem;            // contact -> first efc row (or -1)
-  int* s_ldof = s_cadr + ncm;          // limit row -> dof
-  float* s_lsign = (float*)(s_ldof + njm);  // limit row -> Jacobian entry (+-1)
+  const int nlim = constraint_nlim(m.size);
+  int* s_cadr = (int*)smem;                  // contact -> first efc row (or -1)
+  int* s_ldof = s_cadr + ncm;                // limit row -> dof
+  float* s_lsign = (float*)(s_ldof + nlim);  // limit row -> Jacobian entry (+-1)
+  float* s_cc = s_lsign + nlim;              // staged contact chunk, [CC_NROWS][64]
   const float timestep = (float)m.opt.timestep;
   float* J = d.efc_J + (size_t)w * njm * nv;
   const size_t wr = (size_t)w * njm;
@@ -1059,7 +1135,10 @@ __global__ __launch_bounds__(64) void k_constraint(const Model m, const Data d) 
       for (int i = lane; i < nv; i += 64) J[(size_t)r * nv + i] = (i == dof) ? sg : 0.f;
     }
   }
-  // ---- contacts: one contact at a time, lanes = dofs
+  // ---- contacts.  Phase A (lanes = contacts of a chunk): fetch the contact, its bodies'
+  // chain masks and offsets, and evaluate everything that is per contact (impedance,
+  // regulariser, reference stiffness/damping) once, into LDS.  Phase B (lanes = dofs): one
+  // contact at a time, Jacobian rows from LDS operands only.
   const int ncon = d.ncon[w];
   const float* binv = MF(body_invweight0);
   const float* sub = d.subtree_com + (size_t)w * 3 * nb;
@@ -1067,70 +1146,138 @@ __global__ __launch_bounds__(64) void k_constraint(const Model m, const Data d) 
   float c6[6], qv = 0.f;  // this lane's dof (nv <= 64)
   for (int k = 0; k < 6; ++k) c6[k] = lane < nv ? d.cdof[((size_t)w * nv + lane) * 6 + k] : 0.f;
   if (lane < nv) qv = d.qvel[(size_t)w * nv + lane];
-  for (int c = 0; c < ncon; ++c) {
-    const size_t wc = (size_t)w * ncm + c;
-    const int dim = d.contact_dim[wc];
-    const float dist = d.contact_dist[wc], inc = d.contact_includemargin[wc];
-    const int nrow = dim == 1 ? 1 : 2 * (dim - 1);
-    if (dist >= inc || nefc + nrow > njm) {
-      if (lane == 0) { s_cadr[c] = -1; d.contact_efc_address[wc] = -1; }
-      continue;
-    }
-    const int g1 = d.contact_geom[2 * wc], g2 = d.contact_geom[2 * wc + 1];
-    const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
-    float pos[3], frame[9], fri[5], solref[2], solimp[5];
-    for (int k = 0; k < 3; ++k) pos[k] = d.contact_pos[3 * wc + k];
-    for (int k = 0; k < 9; ++k) frame[k] = d.contact_frame[9 * wc + k];
-    for (int k = 0; k < 5; ++k) { fri[k] = d.contact_friction[5 * wc + k]; solimp[k] = d.contact_solimp[5 * wc + k]; }
-    for (int k = 0; k < 2; ++k) solref[k] = d.contact_solref[2 * wc + k];
-    float jf[3] = {0.f, 0.f, 0.f};
-    if (lane < nv) {
-      const int bodies[2] = {b1, b2};
-      for (int side = 0; side < 2; ++side) {
-        const int b = bodies[side];
-        if (!dof_in_chain(m, b, lane)) continue;
-        const int root = m.body_rootid[b];
-        float off[3], jp[3];
-        for (int k = 0; k < 3; ++k) off[k] = pos[k] - sub[3 * root + k];
-        cross3(jp, c6, off);
-        for (int k = 0; k < 3; ++k) jp[k] += c6[3 + k];
-        const float sgn = side ? 1.f : -1.f;
-        for (int a = 0; a < 3; ++a) jf[a] += sgn * dot3(frame + 3 * a, jp);
+  for (int c0 = 0; c0 < ncon; c0 += 64) {
+    const int c = c0 + lane;
+    int nrow = 0, dim = 0;
+    if (c < ncon) {
+      const size_t wc = (size_t)w * ncm + c;
+      dim = d.contact_dim[wc];
+      const float dist = d.contact_dist[wc], inc = d.contact_includemargin[wc];
+      const int g1 = d.contact_geom[2 * wc], g2 = d.contact_geom[2 * wc + 1];
+      float pos[3], solref[2], solimp[5];
+      for (int k = 0; k < 3; ++k) pos[k] = d.contact_pos[3 * wc + k];
+      for (int k = 0; k < 9; ++k) s_cc[(CC_FRAME + k) * 64 + lane] = d.contact_frame[9 * wc + k];
+      const float mu0 = d.contact_friction[5 * wc], mu1 = d.contact_friction[5 * wc + 1];
+      for (int k = 0; k < 2; ++k) solref[k] = d.contact_solref[2 * wc + k];
+      for (int k = 0; k < 5; ++k) solimp[k] = d.contact_solimp[5 * wc + k];
+      const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+      const int r1 = m.body_rootid[b1], r2 = m.body_rootid[b2];
+      for (int k = 0; k < 3; ++k) {
+        s_cc[(CC_OFF1 + k) * 64 + lane] = pos[k] - sub[3 * r1 + k];
+        s_cc[(CC_OFF2 + k) * 64 + lane] = pos[k] - sub[3 * r2 + k];
       }
-    }
-    const float v0 = wave_sum(jf[0] * qv);
-    const float tran = binv[2 * b1] + binv[2 * b2];
-    if (lane == 0) { s_cadr[c] = nefc; d.contact_efc_address[wc] = nefc; }
-    if (dim == 1) {
-      float aref, R;
-      row_params(timestep, solref, solimp, dist, inc, v0, tran, &aref, &R);
-      if (lane < nv) J[(size_t)nefc * nv + lane] = jf[0];
-      if (lane == 0) {
-        d.efc_pos[wr + nefc] = dist; d.efc_margin[wr + nefc] = inc; d.efc_D[wr + nefc] = 1.f / R; d.efc_aref[wr + nefc] = aref;
-        d.efc_type[wr + nefc] = MJLAB_EFC_CONTACT_FRICTIONLESS; d.efc_id[wr + nefc] = c;
+      int* mk = (int*)s_cc + CC_MASK * 64 + lane;
+      mk[0] = m.body_dofmask[2 * b1]; mk[64] = m.body_dofmask[2 * b1 + 1];
+      mk[128] = m.body_dofmask[2 * b2]; mk[192] = m.body_dofmask[2 * b2 + 1];
+      const float tran = binv[2 * b1] + binv[2 * b2];
+      // reference acceleration and regulariser (same expressions as row_params)
+      const float imp = impedance(solimp, dist, inc);
+      const float dmax = clipf(solimp[1], MINIMP, MAXIMP);
+      float kk, bb;
+      if (solref[0] > 0.f) {
+        const float tc = fmaxf(solref[0], 2.f * timestep), dr = solref[1];
+        kk = 1.f / fmaxf(dmax * dmax * tc * tc * dr * dr, MINVAL);
+        bb = 2.f / fmaxf(dmax * tc, MINVAL);
+      } else {
+        kk = -solref[0] / fmaxf(dmax * dmax, MINVAL);
+        bb = -solref[1] / fmaxf(dmax, MINVAL);
       }
-      nefc += 1;
-    } else {
-      const float v1 = wave_sum(jf[1] * qv), v2 = wave_sum(jf[2] * qv);
-      float Rfirst = 0.f;
-      for (int r = 0; r < nrow; ++r) {
-        const int kk = 1 + (r >> 1);
-        const float mu = fri[kk - 1], sg = (r & 1) ? -mu : mu;
-        const float vel = v0 + sg * (kk == 1 ? v1 : v2);
-        float aref, R;
-        row_params(timestep, solref, solimp, dist, inc, vel, tran + mu * mu * tran, &aref, &R);
-        if (r == 0) Rfirst = R;
-        if (lane < nv) J[(size_t)(nefc + r) * nv + lane] = jf[0] + sg * (kk == 1 ? jf[1] : jf[2]);
-        if (lane == 0) {
-          const float mu0 = fri[0] * impratio_rs;
-          const float Rpy = fmaxf(2.f * mu0 * mu0 * Rfirst, MINVAL);
-          d.efc_pos[wr + nefc + r] = dist; d.efc_margin[wr + nefc + r] = inc; d.efc_D[wr + nefc + r] = 1.f / Rpy;
-          d.efc_aref[wr + nefc + r] = aref;
-          d.efc_type[wr + nefc + r] = MJLAB_EFC_CONTACT_PYRAMIDAL; d.efc_id[wr + nefc + r] = c;
+      float Dc;
+      if (dim == 1) {
+        Dc = 1.f / fmaxf((1.f - imp) / imp * tran, MINVAL);
+      } else {
+        const float Rfirst = fmaxf((1.f - imp) / imp * (tran + mu0 * mu0 * tran), MINVAL);
+        const float mu0i = mu0 * impratio_rs;
+        Dc = 1.f / fmaxf(2.f * mu0i * mu0i * Rfirst, MINVAL);
+      }
+      s_cc[CC_MU * 64 + lane] = mu0; s_cc[(CC_MU + 1) * 64 + lane] = mu1;
+      s_cc[CC_B * 64 + lane] = bb;
+      s_cc[CC_KIP * 64 + lane] = kk * imp * (dist - inc);
+      s_cc[CC_D * 64 + lane] = Dc;
+      s_cc[CC_DIST * 64 + lane] = dist;
+      s_cc[CC_INC * 64 + lane] = inc;
+      ((int*)s_cc)[CC_DIM * 64 + lane] = dim;
+      if (dist < inc) nrow = dim == 1 ? 1 : 2 * (dim - 1);
+    }
+    // efc addresses: contacts take rows in order; one that does not fit is dropped
+    int total;
+    int adr = nefc + wave_excl_scan(nrow, lane, &total);
+    if (nefc + total > njm) {  // rare: replay the sequential rule
+      int run = nefc;
+      for (int l = 0; l < 64; ++l) {
+        const int nr = __shfl(nrow, l);
+        const bool fits = nr > 0 && run + nr <= njm;
+        if (lane == l) adr = fits ? run : -1;
+        if (fits) run += nr;
+      }
+      total = run - nefc;
+    } else if (nrow == 0) {
+      adr = -1;
+    }
+    if (c < ncon) {
+      s_cadr[c] = adr;
+      d.contact_efc_address[(size_t)w * ncm + c] = adr;
+      ((int*)s_cc)[CC_ADR * 64 + lane] = adr;
+    }
+    unsigned long long todo = __ballot(adr >= 0 && c < ncon);
+    __syncthreads();
+    while (todo) {
+      const int i = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int* icc = (const int*)s_cc;
+      const int adr_i = icc[CC_ADR * 64 + i], dim_i = icc[CC_DIM * 64 + i];
+      const unsigned lo1 = (unsigned)icc[CC_MASK * 64 + i], hi1 = (unsigned)icc[(CC_MASK + 1) * 64 + i];
+      const unsigned lo2 = (unsigned)icc[(CC_MASK + 2) * 64 + i], hi2 = (unsigned)icc[(CC_MASK + 3) * 64 + i];
+      const bool in1 = lane < 32 ? ((lo1 >> lane) & 1u) : ((hi1 >> (lane - 32)) & 1u);
+      const bool in2 = lane < 32 ? ((lo2 >> lane) & 1u) : ((hi2 >> (lane - 32)) & 1u);
+      float frame[9], off1[3], off2[3];
+      for (int k = 0; k < 9; ++k) frame[k] = s_cc[(CC_FRAME + k) * 64 + i];
+      for (int k = 0; k < 3; ++k) { off1[k] = s_cc[(CC_OFF1 + k) * 64 + i]; off2[k] = s_cc[(CC_OFF2 + k) * 64 + i]; }
+      float jf[3] = {0.f, 0.f, 0.f};
+      if (lane < nv) {
+        float jp[3];
+        if (in1) {
+          cross3(jp, c6, off1);
+          for (int k = 0; k < 3; ++k) jp[k] += c6[3 + k];
+          for (int a = 0; a < 3; ++a) jf[a] -= dot3(frame + 3 * a, jp);
+        }
+        if (in2) {
+          cross3(jp, c6, off2);
+          for (int k = 0; k < 3; ++k) jp[k] += c6[3 + k];
+          for (int a = 0; a < 3; ++a) jf[a] += dot3(frame + 3 * a, jp);
         }
       }
-      nefc += nrow;
+      const float bb = s_cc[CC_B * 64 + i], kip = s_cc[CC_KIP * 64 + i], Dc = s_cc[CC_D * 64 + i];
+      const float dist = s_cc[CC_DIST * 64 + i], inc = s_cc[CC_INC * 64 + i];
+      const float v0 = wave_sum(jf[0] * qv);
+      const int cid = c0 + i;
+      if (dim_i == 1) {
+        if (lane < nv) J[(size_t)adr_i * nv + lane] = jf[0];
+        if (lane == 0) {
+          d.efc_pos[wr + adr_i] = dist; d.efc_margin[wr + adr_i] = inc; d.efc_D[wr + adr_i] = Dc;
+          d.efc_aref[wr + adr_i] = -bb * v0 - kip;
+          d.efc_type[wr + adr_i] = MJLAB_EFC_CONTACT_FRICTIONLESS; d.efc_id[wr + adr_i] = cid;
+        }
+      } else {
+        const float v1 = wave_sum(jf[1] * qv), v2 = wave_sum(jf[2] * qv);
+        const float mu0 = s_cc[CC_MU * 64 + i], mu1 = s_cc[(CC_MU + 1) * 64 + i];
+        const int nrow_i = 2 * (dim_i - 1);
+        for (int r = 0; r < nrow_i; ++r) {
+          const float mu = (r >> 1) ? mu1 : mu0, sg = (r & 1) ? -mu : mu;
+          if (lane < nv) J[(size_t)(adr_i + r) * nv + lane] = jf[0] + sg * ((r >> 1) ? jf[2] : jf[1]);
+        }
+        if (lane < nrow_i) {  // lanes = rows of this contact for the scalar row fields
+          const float mu = (lane >> 1) ? mu1 : mu0, sg = (lane & 1) ? -mu : mu;
+          const float vel = v0 + sg * ((lane >> 1) ? v2 : v1);
+          const size_t rr = wr + adr_i + lane;
+          d.efc_pos[rr] = dist; d.efc_margin[rr] = inc; d.efc_D[rr] = Dc;
+          d.efc_aref[rr] = -bb * vel - kip;
+          d.efc_type[rr] = MJLAB_EFC_CONTACT_PYRAMIDAL; d.efc_id[rr] = cid;
+        }
+      }
     }
+    nefc += total;
+    __syncthreads();
   }
   if (lane == 0) d.nefc[w] = nefc;
   __syncthreads();
@@ -1203,90 +1350,123 @@ __device__ __forceinline__ float pick16(const float (&v)[NB], int lane) {
   return r;
 }
 
+// Rows are walked 16 at a time (4 MFMA-shaped groups of 4 rows x 16 columns): the loads of a
+// 16-row block are issued together, so a pass over J exposes one memory round trip per 16 rows.
+#ifndef MJLAB_JU
+#define MJLAB_JU 4
+#endif
+constexpr int JU = MJLAB_JU;  // 4-row groups per unrolled block
+
 // out[r] = sum_i J[r][i] x_i (+ out2 for a second vector); lanes form 4 row groups x 16 columns
 template <int NVP, bool TWO>
 __device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x16)[CholCfg<NVP>::NB], const float (&y16)[CholCfg<NVP>::NB], float* out, float* out2) {
   constexpr int NB = CholCfg<NVP>::NB;
   const int sub = c.lane >> 4, col = c.lane & 15;
-  for (int r0 = 0; r0 < c.nefc; r0 += 4) {
-    const int r = r0 + sub;
-    float acc = 0.f, acc2 = 0.f;
-    if (r < c.nefc) {
+  for (int r0 = 0; r0 < c.nefc; r0 += 4 * JU) {
+    float jv[JU][NB];
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      const int r = r0 + 4 * u + sub;
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
         const int cc = 16 * cb + col;
-        const float jv = cc < c.nv ? c.J[(size_t)r * c.nv + cc] : 0.f;
-        acc += jv * x16[cb];
-        if (TWO) acc2 += jv * y16[cb];
+        jv[u][cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
       }
     }
-    acc = group16_sum(acc);
-    if (TWO) acc2 = group16_sum(acc2);
-    if (col == 0 && r < c.nefc) { out[r] = acc; if (TWO) out2[r] = acc2; }
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      const int r = r0 + 4 * u + sub;
+      float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        acc += jv[u][cb] * x16[cb];
+        if (TWO) acc2 += jv[u][cb] * y16[cb];
+      }
+      acc = group16_sum(acc);
+      if (TWO) acc2 = group16_sum(acc2);
+      if (col == 0 && r < c.nefc) { out[r] = acc; if (TWO) out2[r] = acc2; }
+    }
   }
 }
 
-// One pass over J: H = M + J^T diag(D*active) J into LDS (lower triangle) via fp32 MFMA and
-// the lane-owned constraint force qfrc_constraint_i = sum_r J[r][i] f_r.
+// One pass over J: the lane-owned constraint force qfrc_constraint_i = sum_r J[r][i] f_r and,
+// if WITH_H, the tiles of J^T diag(D*active) J (lower-triangular 16x16 blocks) in `acc` via
+// fp32 MFMA.  The tiles stay in registers: hessian_store() adds M and lays them out in LDS
+// only when the Newton iteration actually needs a new factorization.
 template <int NVP, bool WITH_H>
-__device__ __forceinline__ float hessian_pass(const SolveCtx<NVP>& c) {
+__device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2]) {
   constexpr int NB = CholCfg<NVP>::NB;
   constexpr int NT = NB * (NB + 1) / 2;
-  f32x4 acc[NT];
   float jtf[NB];
+  if (WITH_H) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) jtf[cb] = 0.f;
   const int sub = c.lane >> 4, col = c.lane & 15;
-  for (int r0 = 0; r0 < c.nefc; r0 += 4) {
-    const int r = r0 + sub;
-    float dact = 0.f, f = 0.f;
-    if (r < c.nefc) {
-      const float jar = c.s_jar[r], Dr = c.s_D[r];
-      if (jar < 0.f) { dact = Dr; f = -Dr * jar; }
+  for (int r0 = 0; r0 < c.nefc; r0 += 4 * JU) {
+    float x[JU][NB], dact[JU], f[JU];
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      const int r = r0 + 4 * u + sub;
+      dact[u] = 0.f; f[u] = 0.f;
+      if (r < c.nefc) {
+        const float jar = c.s_jar[r], Dr = c.s_D[r];
+        if (jar < 0.f) { dact[u] = Dr; f[u] = -Dr * jar; }
+      }
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        const int cc = 16 * cb + col;
+        x[u][cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
+      }
     }
-    float x[NB], a[NB];
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      const int cc = 16 * cb + col;
-      x[cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
-      jtf[cb] += x[cb] * f;
-      a[cb] = dact * x[cb];
-    }
-    if (WITH_H) {
-      int t = 0;
+    for (int u = 0; u < JU; ++u) {
+      float a[NB];
 #pragma unroll
-      for (int I = 0; I < NB; ++I)
+      for (int cb = 0; cb < NB; ++cb) {
+        jtf[cb] += x[u][cb] * f[u];
+        a[cb] = dact[u] * x[u][cb];
+      }
+      if (WITH_H) {
+        int t = 0;
 #pragma unroll
-        for (int Jb = 0; Jb <= I; ++Jb) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[Jb], acc[t], 0, 0, 0);
-          ++t;
-        }
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int Jb = 0; Jb <= I; ++Jb) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[u][Jb], acc[t], 0, 0, 0);
+            ++t;
+          }
+      }
     }
   }
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) { jtf[cb] += __shfl_xor(jtf[cb], 16); jtf[cb] += __shfl_xor(jtf[cb], 32); }
-  // store tiles (+ M) to LDS, lower triangle only
-  if (WITH_H) {
-    // per-lane part of the M offset, opaque so that the 4 NT addresses are not hoisted out of
-    // the Newton loop as 64-bit VGPR pairs (and then spilled)
-    int moff = sub * 4 * c.nv + col;
-    asm volatile("" : "+v"(moff));
-    int t = 0;
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int Jb = 0; Jb <= I; ++Jb) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
-          if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.M[(16 * I + k) * c.nv + 16 * Jb + moff];
-        }
-        ++t;
-      }
-  }
   return pick16<NB>(jtf, c.lane);
+}
+
+// H = M + tiles -> LDS (lower triangle only)
+template <int NVP>
+__device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2]) {
+  constexpr int NB = CholCfg<NVP>::NB;
+  const int sub = c.lane >> 4, col = c.lane & 15;
+  // per-lane part of the M offset, opaque so that the 4 NT addresses are not hoisted out of
+  // the Newton loop as 64-bit VGPR pairs (and then spilled)
+  int moff = sub * 4 * c.nv + col;
+  asm volatile("" : "+v"(moff));
+  int t = 0;
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int Jb = 0; Jb <= I; ++Jb) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
+        if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.M[(16 * I + k) * c.nv + 16 * Jb + moff];
+      }
+      ++t;
+    }
 }
 
 template <int NVP>
@@ -1441,8 +1621,13 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
       float cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
       float gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
       cost += gauss;
-      fc = hessian_pass<NVP, true>(c);
-      float grad = own ? Ma - qs - fc : 0.f;
+      float grad;
+      {
+        f32x4 htile[NB * (NB + 1) / 2];
+        fc = hessian_accum<NVP, true>(c, htile);
+        grad = own ? Ma - qs - fc : 0.f;
+        hessian_store<NVP>(c, htile);
+      }
       __syncthreads();
       PROF_MARK(3);
       chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
@@ -1487,23 +1672,40 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
         gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
         cost += gauss;
-        // Gradient first: the convergence test only needs J^T f, so the Hessian, its Cholesky
-        // factor and the next search direction are computed only when another iteration
-        // follows (identical results: a direction computed before a break is never used).
-        fc = hessian_pass<NVP, false>(c);
-        grad = own ? Ma - qs - fc : 0.f;
-        const float improvement = scale * (oldcost - cost);
-        const float gradient = scale * sqrtf(wave_sum(grad * grad));
+        // One pass over J gives J^T f for the convergence test and, if the active set changed,
+        // the new Hessian tiles (kept in registers).  Laying H out in LDS, its factorization
+        // and the next search direction happen only when another iteration follows
+        // (identical results: a direction computed before a break is never used); with an
+        // unchanged active set H is unchanged and the factor in LDS is reused.
+        // (The two branches are spelled out so that the 24 tile registers are live only inside
+        // the branch that needs them, not across the line search and the factorization calls.)
+        bool done;
         iter++;
-        PROF_MARK(7);
-        if (improvement < tol || gradient < tol || iter >= maxiter) break;
-        if (any_changed) {  // same active set -> same H -> the factor in LDS is still valid
-          __syncthreads();
-          hessian_pass<NVP, true>(c);
-          __syncthreads();
-          chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
-          __syncthreads();
+        if (any_changed) {
+          f32x4 htile[NB * (NB + 1) / 2];
+          fc = hessian_accum<NVP, true>(c, htile);
+          grad = own ? Ma - qs - fc : 0.f;
+          const float improvement = scale * (oldcost - cost);
+          const float gradient = scale * sqrtf(wave_sum(grad * grad));
+          done = improvement < tol || gradient < tol || iter >= maxiter;
+          PROF_MARK(7);
+          if (!done) {
+            __syncthreads();
+            hessian_store<NVP>(c, htile);
+            __syncthreads();
+            chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+            __syncthreads();
+          }
+        } else {  // same active set -> same H -> the factor in LDS is still valid
+          f32x4 unused[NB * (NB + 1) / 2];
+          fc = hessian_accum<NVP, false>(c, unused);
+          grad = own ? Ma - qs - fc : 0.f;
+          const float improvement = scale * (oldcost - cost);
+          const float gradient = scale * sqrtf(wave_sum(grad * grad));
+          done = improvement < tol || gradient < tol || iter >= maxiter;
+          PROF_MARK(7);
         }
+        if (done) break;
         search = -chol_solve<NVP>(c.s_H, c.s_invd, lane, grad);
         if (!own) search = 0.f;
         PROF_MARK(4);
@@ -1584,7 +1786,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     if (lane == 0) d.time[w] += h;
   }
   PROF_MARK(9);
-  PROF_FLUSH(d.profile + (size_t)w * 16);
+  PROF_FLUSH(d.profile + (size_t)w * 64);
 }
 
 // ====================================================================================
@@ -1639,6 +1841,7 @@ static int check_model(const mjlab_model_t* m) {
   const mjlab_sizes_t& s = m->size;
   if (s.nworld < 1) return fail(-2, "nworld must be >= 1");
   if (s.nv < 1 || s.nv > 64) return fail(-3, "nv must be in [1, 64] (one dof per lane)");
+  if (s.nbody < 1 || s.nbody > 64) return fail(-13, "nbody must be in [1, 64] (one body per lane in the kinematics sweep)");
   if (s.njmax < 1 || s.nconmax < 1) return fail(-4, "njmax and nconmax must be >= 1");
   if (m->opt.cone != 0) return fail(-5, "only the pyramidal friction cone is implemented");
   if (m->opt.integrator != MJLAB_INT_EULER && m->opt.integrator != MJLAB_INT_IMPLICITFAST)

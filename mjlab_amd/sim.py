@@ -91,6 +91,8 @@ def check_supported(model: Model) -> None:
     raise NotImplementedError("integrator must be 'euler' or 'implicitfast'")
   if model.nv > 64:
     raise NotImplementedError(f"nv = {model.nv} > 64: one dof per lane of a 64-wide wavefront")
+  if model.nbody > 64:
+    raise NotImplementedError(f"nbody = {model.nbody} > 64: one body per lane in the kinematics sweep")
   if (np.asarray(model.jnt_type) == 1).any():
     raise NotImplementedError("ball joints are not implemented")
   if np.any(np.asarray(model.dof_frictionloss) != 0):
