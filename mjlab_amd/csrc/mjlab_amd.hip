@@ -54,6 +54,9 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #define CHOL_INLINE __attribute__((noinline))
 #endif
 
+#ifndef MJLAB_CB
+#define MJLAB_CB 16
+#endif
 #define MINVAL 1e-15f
 #define MINIMP 0.0001f
 #define MAXIMP 0.9999f
@@ -242,70 +245,107 @@ struct CholCfg {
   static constexpr int NB = (NVP + 15) / 16;  // 16-column blocks for the MFMA Hessian
 };
 
-// row `lane` of the LDS matrix into registers; rows >= n become identity rows
+// LDS-qualified views: the factor routines are out-of-line functions, and a generic `float*`
+// argument would make every access pay for an address-space check.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
 template <int NVP>
-__device__ __forceinline__ void chol_load_row(const float* A, int n, int lane, float (&a)[NVP]) {
+__device__ __forceinline__ void chol_pad_rows(float* A, int n, int lane) {
   constexpr int LD = CholCfg<NVP>::LD;
-  const int row = lane < NVP ? lane : NVP - 1;
-  const float4* r = reinterpret_cast<const float4*>(A + row * LD);
+  for (int k = n * LD + lane; k < NVP * LD; k += 64) A[k] = 0.f;
+}
+template <int NVP>
+__device__ __forceinline__ void chol_pad_diag(float* A, int n, int lane) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  if (lane >= n && lane < NVP) A[lane * LD + lane] = 1.f;
+}
+// A (LDS, lower triangle valid for rows < n) -> unit-lower factor of A = Lu D Lu^T in place:
+// Lu[i][j] (i > j), ZERO on and above the diagonal, s_invd[i] = 1 / D_i.  With the zero
+// diagonal the substitutions below are a bare v_readlane + v_fma per step.
+//
+// Lane i owns row i in NVP registers.  Left-looking column sweep, fully unrolled:
+//   t_i = A[i][j] - sum_{k<j} W[i][k] * Lu[j][k],   W[i][k] = t_i of step k (kept in a[k]),
+//   D_j = t_j,  Lu[i][j] = t_i / D_j  -> written to LDS column j by every lane.
+// Row j of Lu, which every lane needs in step j, is read back from LDS as 128-bit
+// *broadcast* reads (all lanes, same address: conflict-free), ceil(j/4) instructions instead
+// of j cross-lane v_readlane's; the wave's DS queue is in order, so the column written in
+// step j-1 is visible without a barrier.  No square roots (LDL^T).
+// Lanes >= NVP mirror lane NVP-1 (same row, same arithmetic, same values stored), which keeps
+// the sweep free of exec-mask branches.  Rows n <= i < NVP must hold identity rows on entry:
+// producers call chol_pad_rows() once per kernel (zero fill; the factor keeps those rows'
+// off-diagonals at zero) and chol_pad_diag() after every (re)write of the matrix.
+// Caller synchronises before and after.
+template <int NVP>
+__device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int lane) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  lds_f32* A = (lds_f32*)A_;
+  lds_f32* s_invd = (lds_f32*)s_invd_;
+  const int rowid = lane < NVP ? lane : NVP - 1;
+  lds_f32* row = A + rowid * LD;
+  float a[NVP];
 #pragma unroll
   for (int c = 0; c < NVP / 4; ++c) {
-    const float4 v = r[c];
+    const f32x4 v = *(lds_f32x4*)(row + 4 * c);
     a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
   }
-#pragma unroll
-  for (int j = 0; j < NVP; ++j) a[j] = lane >= n ? (j == lane ? 1.f : 0.f) : a[j];
-}
-// A (LDS, lower triangle valid for rows < n) -> unit-lower factor of A = Lu D Lu^T in LDS:
-// Lu[i][j] (i > j) in place, ZERO on and above the diagonal, s_invd[i] = 1 / D_i.  With the
-// zero diagonal the substitutions below are a bare v_readlane + v_fma per step (no select,
-// no per-step scaling).  The column sweep works on the Cholesky factor L (a[k] = L[i][k])
-// in registers and converts on the way out: Lu[i][j] = L[i][j] / L[j][j], D_j = L[j][j]^2.
-// Caller synchronises before (A complete) and after (factor visible).
-template <int NVP>
-__device__ CHOL_INLINE void chol_factor(float* A, float* s_invd, int n, int lane) {
-  constexpr int LD = CholCfg<NVP>::LD;
-  float a[NVP];
-  chol_load_row<NVP>(A, n, lane, a);
-  float* out = A + (lane < NVP ? lane : NVP - 1) * LD;
+  (void)n;  // rows >= n are identity rows already (chol_pad_rows / chol_pad_diag by the producer)
+  float myinvd = 1.f;
 #pragma unroll
   for (int j = 0; j < NVP; ++j) {
-    // t_i = A[i][j] - sum_{k<j} L[i][k] L[j][k]; two accumulators, products issued in pairs so
-    // that they map onto v_pk_fma_f32 and the v_readlane -> VALU hazard slots are filled
+    // row j of Lu in batches of CB columns (bounds the registers the reads occupy); two
+    // accumulators, products in pairs (v_pk_fma_f32)
+    constexpr int CB = MJLAB_CB;
     f32x2 acc = {a[j], 0.f};
 #pragma unroll
-    for (int k = 0; k + 1 < j; k += 2) {
-      const f32x2 av = {a[k], a[k + 1]};
-      const f32x2 sv = {lane_bcast(a[k], j), lane_bcast(a[k + 1], j)};
-      acc -= av * sv;
+    for (int k0 = 0; k0 < j; k0 += CB) {
+      float rj[CB];
+#pragma unroll
+      for (int q = 0; q < CB / 4; ++q) {
+        if (k0 + 4 * q < j) {
+          const f32x4 v = *(lds_f32x4*)(A + j * LD + k0 + 4 * q);
+          rj[4 * q] = v.x; rj[4 * q + 1] = v.y; rj[4 * q + 2] = v.z; rj[4 * q + 3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < CB; k += 2) {
+        if (k0 + k + 1 < j) {
+          const f32x2 av = {a[k0 + k], a[k0 + k + 1]};
+          const f32x2 sv = {rj[k], rj[k + 1]};
+          acc -= av * sv;
+        } else if (k0 + k < j) {
+          acc.x -= a[k0 + k] * rj[k];
+        }
+      }
+      if (k0 + CB < j) __builtin_amdgcn_sched_barrier(0);
     }
-    float t = acc.x + acc.y;
-    if (j & 1) t -= a[j - 1] * lane_bcast(a[j - 1], j);
+    const float t = acc.x + acc.y;
     const float djj = fmaxf(lane_bcast(t, j), MINVAL);
-    float inv = __builtin_amdgcn_rsqf(djj);  // v_rsq_f32 (1 ulp) + one Newton step
-    inv = inv * (1.5f - 0.5f * djj * inv * inv);
-    const float inv2 = inv * inv;            // 1 / D_j
-    a[j] = lane > j ? t * inv : 0.f;         // L[i][j] for the remaining columns
-    if (lane < NVP) out[j] = lane > j ? t * inv2 : 0.f;
-    if (lane == j) s_invd[j] = inv2;
-    // keep later columns' broadcasts (SGPRs) from being hoisted across this point
+    float invd = __builtin_amdgcn_rcpf(djj);  // v_rcp_f32 (1 ulp) + one Newton step
+    invd = invd * (2.f - djj * invd);
+    a[j] = t;
+    row[j] = rowid > j ? t * invd : 0.f;
+    myinvd = rowid == j ? invd : myinvd;
+    // keep the scheduler from hoisting later rows' reads across this point (register pressure)
     __builtin_amdgcn_sched_barrier(0);
   }
+  s_invd[rowid] = myinvd;
 }
 // Solves Lu D Lu^T x = b with the factor in LDS (as left by chol_factor); lane i owns
 // b_i / x_i (lanes >= n must pass 0).  Forward substitution uses row i of Lu, backward
 // substitution row i of Lu^T (= column i of Lu, read with unit stride across lanes).
 template <int NVP>
-__device__ CHOL_INLINE float chol_solve(const float* L, const float* s_invd, int lane, float b) {
+__device__ CHOL_INLINE float chol_solve(const float* L_, const float* s_invd_, int lane, float b) {
   constexpr int LD = CholCfg<NVP>::LD;
+  const lds_f32* L = (const lds_f32*)L_;
+  const lds_f32* s_invd = (const lds_f32*)s_invd_;
   const int li = lane < NVP ? lane : NVP - 1;
   const float invd = s_invd[li];
   {
     float a[NVP];
-    const float4* r = reinterpret_cast<const float4*>(L + li * LD);
 #pragma unroll
     for (int c = 0; c < NVP / 4; ++c) {
-      const float4 v = r[c];
+      const f32x4 v = *(const lds_f32x4*)(L + li * LD + 4 * c);
       a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
     }
 #pragma unroll
@@ -1566,6 +1606,12 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
   float* s_vec = c.s_D + njm;  // 64 floats of scratch (new qvel for the position update)
   c.J = d.efc_J + (size_t)w * njm * nv;
   c.M = d.qM + (size_t)w * nv * nv;
+#ifdef MJLAB_EXP_J0  // timing experiment only (wrong results): every world reads world 0's J
+  c.J = d.efc_J;
+#endif
+#ifdef MJLAB_EXP_M0  // timing experiment only (wrong results): every world reads world 0's M
+  c.M = d.qM;
+#endif
   c.nv = nv; c.lane = lane;
   const size_t wv = (size_t)w * nv + lane;
   const bool own = lane < nv;
@@ -1578,11 +1624,19 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     c.nefc = nefc;
     // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
     dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
-    __syncthreads();
-    chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+    chol_pad_rows<NVP>(c.s_H, nv, lane);
+    chol_pad_diag<NVP>(c.s_H, nv, lane);
     __syncthreads();
     PROF_MARK(0);
+    chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+    PROF_MARK(12);
+    PROF_COUNT(14);
+    __syncthreads();
+    PROF_MARK(0);
+    PROF_MARK(1);
     const float qas = chol_solve<NVP>(c.s_H, c.s_invd, lane, qs);
+    PROF_MARK(13);
+    PROF_COUNT(15);
     __syncthreads();
     PROF_MARK(1);
     if (own) d.qacc_smooth[wv] = qas;
@@ -1627,12 +1681,19 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         fc = hessian_accum<NVP, true>(c, htile);
         grad = own ? Ma - qs - fc : 0.f;
         hessian_store<NVP>(c, htile);
+        chol_pad_diag<NVP>(c.s_H, nv, lane);
       }
       __syncthreads();
       PROF_MARK(3);
+      PROF_MARK(4);
       chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+      PROF_MARK(12);
+      PROF_COUNT(14);
       __syncthreads();
+      PROF_MARK(4);
       float search = -chol_solve<NVP>(c.s_H, c.s_invd, lane, grad);
+      PROF_MARK(13);
+      PROF_COUNT(15);
       if (!own) search = 0.f;
       PROF_MARK(4);
       int iter = 0;
@@ -1692,8 +1753,12 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
           if (!done) {
             __syncthreads();
             hessian_store<NVP>(c, htile);
+            chol_pad_diag<NVP>(c.s_H, nv, lane);
             __syncthreads();
+            PROF_MARK(7);
             chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+            PROF_MARK(12);
+            PROF_COUNT(14);
             __syncthreads();
           }
         } else {  // same active set -> same H -> the factor in LDS is still valid
@@ -1706,7 +1771,10 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
           PROF_MARK(7);
         }
         if (done) break;
+        PROF_MARK(4);
         search = -chol_solve<NVP>(c.s_H, c.s_invd, lane, grad);
+        PROF_MARK(13);
+        PROF_COUNT(15);
         if (!own) search = 0.f;
         PROF_MARK(4);
       }
@@ -1752,12 +1820,20 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     if (__ballot(need)) {
       __syncthreads();
       dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
+      chol_pad_rows<NVP>(c.s_H, nv, lane);
+      chol_pad_diag<NVP>(c.s_H, nv, lane);
       __syncthreads();
       if (own) c.s_H[lane * ld + lane] += h * diag;
       __syncthreads();
+      PROF_MARK(9);
       chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+      PROF_MARK(12);
+      PROF_COUNT(14);
       __syncthreads();
+      PROF_MARK(9);
       a = chol_solve<NVP>(c.s_H, c.s_invd, lane, own ? qs + fc : 0.f);
+      PROF_MARK(13);
+      PROF_COUNT(15);
     }
     float qv = 0.f;
     if (own) {

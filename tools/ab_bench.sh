@@ -3,7 +3,7 @@
 # smoke and a short bench; prints env-steps/s and per-stage ms.
 for L in gpurun_prof/ab_*.so; do
   echo "== $L"
-  MJLAB_AMD_LIB=$L timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+  [ -z "$NOSMOKE" ] && MJLAB_AMD_LIB=$L timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
   MJLAB_AMD_LIB=$L timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
