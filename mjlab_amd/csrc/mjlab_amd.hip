@@ -51,7 +51,7 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #ifdef MJLAB_CHOL_FORCEINLINE
 #define CHOL_INLINE __forceinline__
 #else
-#define CHOL_INLINE __attribute__((noinline))
+#define CHOL_INLINE __forceinline__
 #endif
 
 #ifndef MJLAB_CB
@@ -1591,6 +1591,15 @@ __device__ __forceinline__ float constraint_cost(const float* s_jar, const float
   return wave_sum(cost);
 }
 
+// The kernel is written as a small state machine around ONE factor + substitution site:
+//   ST_SMOOTH     s_H = M,            rhs = qfrc_smooth          -> qacc_smooth
+//   ST_NEWTON     s_H = H (if new),   rhs = gradient             -> search direction, line
+//                 search, update, convergence test (repeats)
+//   ST_INTEGRATE  s_H = M + h*diag,   rhs = qfrc_smooth + J^T f  -> implicit acceleration
+// so the fully unrolled factorization is inlined exactly once: no call ABI, no callee-saved
+// registers through scratch memory, and the register allocator sees the whole kernel.
+enum { ST_SMOOTH = 0, ST_NEWTON = 1, ST_PREP_INTEGRATE = 2, ST_INTEGRATE = 3 };
+
 template <int NVP>
 __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1606,119 +1615,197 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
   float* s_vec = c.s_D + njm;  // 64 floats of scratch (new qvel for the position update)
   c.J = d.efc_J + (size_t)w * njm * nv;
   c.M = d.qM + (size_t)w * nv * nv;
-#ifdef MJLAB_EXP_J0  // timing experiment only (wrong results): every world reads world 0's J
-  c.J = d.efc_J;
-#endif
-#ifdef MJLAB_EXP_M0  // timing experiment only (wrong results): every world reads world 0's M
-  c.M = d.qM;
-#endif
   c.nv = nv; c.lane = lane;
   const size_t wv = (size_t)w * nv + lane;
+  const size_t wr = (size_t)w * njm;
   const bool own = lane < nv;
   const float qs = own ? d.qfrc_smooth[wv] : 0.f;
-  float qacc = 0.f, fc = 0.f;
+  const float h = (float)m.opt.timestep;
+  const float nvf = (float)(nv > 1 ? nv : 1), mi = (float)m.opt.meaninertia;
+  const float scale = 1.f / (mi * nvf), tol = (float)m.opt.tolerance, lstol = (float)m.opt.ls_tolerance;
+  const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
+  const int nefc = do_solve ? d.nefc[w] : 0;
+  c.nefc = nefc;
+  float qacc = 0.f, fc = 0.f, qas = 0.f, Ma = 0.f, cost = 0.f, gauss = 0.f, rhs = 0.f;
+  int iter = 0, state;
+  bool need_factor = true;
   PROF_INIT();
 
   if (do_solve) {
-    const int nefc = d.nefc[w];
-    c.nefc = nefc;
     // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
     dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
     chol_pad_rows<NVP>(c.s_H, nv, lane);
     chol_pad_diag<NVP>(c.s_H, nv, lane);
-    __syncthreads();
+    rhs = qs;
+    state = ST_SMOOTH;
     PROF_MARK(0);
-    chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
-    PROF_MARK(12);
-    PROF_COUNT(14);
-    __syncthreads();
-    PROF_MARK(0);
-    PROF_MARK(1);
-    const float qas = chol_solve<NVP>(c.s_H, c.s_invd, lane, qs);
-    PROF_MARK(13);
-    PROF_COUNT(15);
-    __syncthreads();
-    PROF_MARK(1);
-    if (own) d.qacc_smooth[wv] = qas;
-    if (nefc == 0) {
-      qacc = qas;
-      if (lane == 0) d.solver_niter[w] = 0;
-    } else {
-      const size_t wr = (size_t)w * njm;
-      for (int r = lane; r < nefc; r += 64) c.s_D[r] = d.efc_D[wr + r];
-      // ---- warmstart: better of qacc_warmstart and qacc_smooth
-      const float ws = own ? d.qacc_warmstart[wv] : 0.f;
-      float x16[NB], y16[NB];
-      gather16<NB>(ws, x16, lane);
-      gather16<NB>(qas, y16, lane);
-      jac_mul<NVP, true>(c, x16, y16, c.s_jar, c.s_jv);
-      __syncthreads();
-      for (int r = lane; r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
-      __syncthreads();
-      const float Ma_ws = symm_mul_global<NVP>(c.M, nv, ws, lane);
-      float cost_ws = constraint_cost(c.s_jar, c.s_D, nefc, lane) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
-      const float cost_s = constraint_cost(c.s_jv, c.s_D, nefc, lane);
-      float Ma;
-      if (cost_ws > cost_s) {
-        qacc = qas;
-        Ma = qs;  // M qacc_smooth = qfrc_smooth
-        for (int r = lane; r < nefc; r += 64) c.s_jar[r] = c.s_jv[r];
+  } else {
+    if (own) { qacc = d.qacc[wv]; fc = d.qfrc_constraint[wv]; }
+    state = ST_PREP_INTEGRATE;
+  }
+
+  for (;;) {
+    bool skip_solve = false;
+    if (state == ST_PREP_INTEGRATE) {
+      // s_H = M + h * diag(-d qfrc_smooth / d qvel), rhs = qfrc_smooth + J^T f
+      if (!do_integrate) break;
+      // diagonal of -d(qfrc_smooth)/d(qvel): dof damping (+ actuator velocity gains for implicitfast)
+      float diag = own ? MF(dof_damping)[lane] : 0.f;
+      bool need = diag > 0.f;
+      if (m.opt.integrator == MJLAB_INT_IMPLICITFAST) {
+        // d(qfrc_actuator)/d(qvel) of the affine-bias actuators: lanes = actuators, scattered
+        // to the owning dof through LDS (clamped actuators have zero derivative)
+        need = true;
+        const float *biasprm = MF(actuator_biasprm), *gear = MF(actuator_gear), *frange = MF(actuator_forcerange);
         __syncthreads();
-      } else {
-        qacc = ws;
-        Ma = Ma_ws;
+        s_vec[lane] = 0.f;
+        __syncthreads();
+        for (int k = lane; k < nu; k += 64) {
+          const int da = m.jnt_dofadr[m.actuator_trnid[2 * k]];
+          const float f = d.actuator_force[(size_t)w * nu + k];
+          if (m.actuator_forcelimited[k] && (f <= frange[2 * k] || f >= frange[2 * k + 1])) continue;
+          atomicAdd(&s_vec[da], -gear[6 * k] * gear[6 * k] * biasprm[10 * k + 2]);
+        }
+        __syncthreads();
+        diag += s_vec[lane];
       }
-      const float nvf = (float)(nv > 1 ? nv : 1), mi = (float)m.opt.meaninertia;
-      const float scale = 1.f / (mi * nvf), tol = (float)m.opt.tolerance, lstol = (float)m.opt.ls_tolerance;
-      PROF_MARK(2);
-      // ---- initial constraint state, gradient, Hessian, search direction
-      float cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
-      float gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
-      cost += gauss;
-      float grad;
-      {
-        f32x4 htile[NB * (NB + 1) / 2];
-        fc = hessian_accum<NVP, true>(c, htile);
-        grad = own ? Ma - qs - fc : 0.f;
-        hessian_store<NVP>(c, htile);
+      state = ST_INTEGRATE;
+      if (__ballot(need)) {
+        __syncthreads();
+        dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
+        chol_pad_rows<NVP>(c.s_H, nv, lane);
         chol_pad_diag<NVP>(c.s_H, nv, lane);
+        __syncthreads();
+        if (own) c.s_H[lane * ld + lane] += h * diag;
+        rhs = own ? qs + fc : 0.f;
+        need_factor = true;
+      } else {
+        skip_solve = true;  // explicit Euler without damping: a = qacc
       }
-      __syncthreads();
-      PROF_MARK(3);
-      PROF_MARK(4);
-      chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
-      PROF_MARK(12);
-      PROF_COUNT(14);
-      __syncthreads();
-      PROF_MARK(4);
-      float search = -chol_solve<NVP>(c.s_H, c.s_invd, lane, grad);
+    }
+
+    float x = qacc;
+    if (!skip_solve) {
+      if (need_factor) {
+        __syncthreads();
+        chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+        __syncthreads();
+        PROF_MARK(12);
+        PROF_COUNT(14);
+      }
+      x = chol_solve<NVP>(c.s_H, c.s_invd, lane, rhs);
       PROF_MARK(13);
       PROF_COUNT(15);
-      if (!own) search = 0.f;
-      PROF_MARK(4);
-      int iter = 0;
-      const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
-      while (iter < maxiter) {
-        // ---- line search
-        const float snorm = sqrtf(wave_sum(search * search));
-        if (snorm < MINVAL) break;
-        const float gtol = tol * lstol * snorm * mi * nvf;
-        const float Mv = symm_mul_global<NVP>(c.M, nv, search, lane);
-        gather16<NB>(search, x16, lane);
+    }
+
+    if (state == ST_INTEGRATE) {
+      // velocity / position update with acceleration x (mj_Euler / mj_implicit tail)
+      if (own) {
+        const float qv = d.qvel[wv] + h * x;
+        d.qvel[wv] = qv;
+        s_vec[lane] = qv;
+      }
+      __syncthreads();
+      float* qpos = d.qpos + (size_t)w * nq;
+      for (int j = lane; j < nj; j += 64) {
+        const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+        if (m.jnt_type[j] == MJLAB_JNT_FREE) {
+          for (int k = 0; k < 3; ++k) qpos[qa + k] += h * s_vec[da + k];
+          float ax[3] = {s_vec[da + 3], s_vec[da + 4], s_vec[da + 5]}, q[4], qr[4], qn[4];
+          for (int k = 0; k < 4; ++k) q[k] = qpos[qa + 3 + k];
+          const float ang = h * normalize3(ax);
+          axis_angle2quat(qr, ax, ang);
+          normalize4(q);
+          mul_quat(qn, q, qr);
+          normalize4(qn);
+          for (int k = 0; k < 4; ++k) qpos[qa + 3 + k] = qn[k];
+        } else {
+          qpos[qa] += h * s_vec[da];
+        }
+      }
+      if (lane == 0) d.time[w] += h;
+      PROF_MARK(9);
+      break;
+    }
+
+    bool finished = false;  // constraint solve finished in this pass
+    if (state == ST_SMOOTH) {
+      qas = x;
+      __syncthreads();
+      if (own) d.qacc_smooth[wv] = qas;
+      if (nefc == 0) {
+        qacc = qas;
+        finished = true;
+      } else {
+        for (int r = lane; r < nefc; r += 64) c.s_D[r] = d.efc_D[wr + r];
+        // ---- warmstart: better of qacc_warmstart and qacc_smooth
+        const float ws = own ? d.qacc_warmstart[wv] : 0.f;
+        {
+          float x16[NB], y16[NB];
+          gather16<NB>(ws, x16, lane);
+          gather16<NB>(qas, y16, lane);
+          jac_mul<NVP, true>(c, x16, y16, c.s_jar, c.s_jv);
+        }
         __syncthreads();
-        jac_mul<NVP, false>(c, x16, x16, c.s_jv, c.s_jv);
+        for (int r = lane; r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
+        __syncthreads();
+        const float Ma_ws = symm_mul_global<NVP>(c.M, nv, ws, lane);
+        const float cost_ws = constraint_cost(c.s_jar, c.s_D, nefc, lane) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
+        const float cost_s = constraint_cost(c.s_jv, c.s_D, nefc, lane);
+        if (cost_ws > cost_s) {
+          qacc = qas;
+          Ma = qs;  // M qacc_smooth = qfrc_smooth
+          for (int r = lane; r < nefc; r += 64) c.s_jar[r] = c.s_jv[r];
+          __syncthreads();
+        } else {
+          qacc = ws;
+          Ma = Ma_ws;
+        }
+        PROF_MARK(2);
+        // ---- initial constraint state, gradient, Hessian
+        cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
+        gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
+        cost += gauss;
+        {
+          f32x4 htile[NB * (NB + 1) / 2];
+          fc = hessian_accum<NVP, true>(c, htile);
+          rhs = own ? Ma - qs - fc : 0.f;
+          hessian_store<NVP>(c, htile);
+          chol_pad_diag<NVP>(c.s_H, nv, lane);
+        }
+        PROF_MARK(3);
+        need_factor = true;
+        state = ST_NEWTON;
+      }
+    } else {
+      // ---- ST_NEWTON: x = H^-1 grad -> line search along -x, update, convergence test
+      const float search = own ? -x : 0.f;
+      const float snorm = sqrtf(wave_sum(search * search));
+      float alpha = 0.f, Mv = 0.f;
+      if (snorm >= MINVAL) {
+        const float gtol = tol * lstol * snorm * mi * nvf;
+        Mv = symm_mul_global<NVP>(c.M, nv, search, lane);
+        {
+          float x16[NB];
+          gather16<NB>(search, x16, lane);
+          __syncthreads();
+          jac_mul<NVP, false>(c, x16, x16, c.s_jv, c.s_jv);
+        }
         __syncthreads();
         c.quad_gauss[0] = gauss;
         c.quad_gauss[1] = wave_sum(own ? search * (Ma - qs) : 0.f);
         c.quad_gauss[2] = wave_sum(own ? 0.5f * search * Mv : 0.f);
         PROF_MARK(5);
-        const float alpha = line_search<NVP>(c, gtol, lsmax);
+        alpha = line_search<NVP>(c, gtol, lsmax);
         PROF_MARK(6);
 #ifdef MJLAB_PROFILE
         prof_acc_[10] += (float)c.ls_iter;
         prof_acc_[11] += 1.f;
 #endif
-        if (alpha == 0.f) break;
+      }
+      if (alpha == 0.f) {
+        finished = true;  // no direction or no progress: keep the current iterate
+      } else {
         qacc += alpha * search;
         Ma += alpha * Mv;
         bool changed = false;  // did any row switch between active and satisfied?
@@ -1733,135 +1820,52 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
         gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
         cost += gauss;
-        // One pass over J gives J^T f for the convergence test and, if the active set changed,
-        // the new Hessian tiles (kept in registers).  Laying H out in LDS, its factorization
-        // and the next search direction happen only when another iteration follows
-        // (identical results: a direction computed before a break is never used); with an
-        // unchanged active set H is unchanged and the factor in LDS is reused.
-        // (The two branches are spelled out so that the 24 tile registers are live only inside
-        // the branch that needs them, not across the line search and the factorization calls.)
-        bool done;
+        // One pass over J gives J^T f for the convergence test and, if the active set
+        // changed, the new Hessian tiles (kept in registers).  Laying H out in LDS and its
+        // factorization happen only when another iteration follows; with an unchanged active
+        // set H is unchanged and the factor in LDS is reused.  (The two branches are spelled
+        // out so that the 24 tile registers are live only inside the branch that needs them.)
         iter++;
         if (any_changed) {
           f32x4 htile[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, true>(c, htile);
-          grad = own ? Ma - qs - fc : 0.f;
+          rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
-          const float gradient = scale * sqrtf(wave_sum(grad * grad));
-          done = improvement < tol || gradient < tol || iter >= maxiter;
-          PROF_MARK(7);
-          if (!done) {
+          const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
+          finished = improvement < tol || gradient < tol || iter >= maxiter;
+          if (!finished) {
             __syncthreads();
             hessian_store<NVP>(c, htile);
             chol_pad_diag<NVP>(c.s_H, nv, lane);
-            __syncthreads();
-            PROF_MARK(7);
-            chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
-            PROF_MARK(12);
-            PROF_COUNT(14);
-            __syncthreads();
           }
+          need_factor = true;
         } else {  // same active set -> same H -> the factor in LDS is still valid
           f32x4 unused[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, false>(c, unused);
-          grad = own ? Ma - qs - fc : 0.f;
+          rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
-          const float gradient = scale * sqrtf(wave_sum(grad * grad));
-          done = improvement < tol || gradient < tol || iter >= maxiter;
-          PROF_MARK(7);
+          const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
+          finished = improvement < tol || gradient < tol || iter >= maxiter;
+          need_factor = false;
         }
-        if (done) break;
-        PROF_MARK(4);
-        search = -chol_solve<NVP>(c.s_H, c.s_invd, lane, grad);
-        PROF_MARK(13);
-        PROF_COUNT(15);
-        if (!own) search = 0.f;
-        PROF_MARK(4);
+        PROF_MARK(7);
       }
+    }
+    if (finished) {  // publish the solve, then hand over to the integrator
       if (lane == 0) d.solver_niter[w] = iter;
       for (int r = lane; r < nefc; r += 64) {
-        const float x = c.s_jar[r];
-        d.efc_force[wr + r] = x < 0.f ? -c.s_D[r] * x : 0.f;
+        const float xr = c.s_jar[r];
+        d.efc_force[wr + r] = xr < 0.f ? -c.s_D[r] * xr : 0.f;
       }
+      if (own) {
+        d.qacc[wv] = qacc;
+        d.qacc_warmstart[wv] = qacc;
+        d.qfrc_constraint[wv] = fc;
+      }
+      PROF_MARK(8);
+      state = ST_PREP_INTEGRATE;
     }
-    if (own) {
-      d.qacc[wv] = qacc;
-      d.qacc_warmstart[wv] = qacc;
-      d.qfrc_constraint[wv] = fc;
-    }
-  } else if (own) {
-    qacc = d.qacc[wv];
-    fc = d.qfrc_constraint[wv];
   }
-
-  PROF_MARK(8);
-  if (do_integrate) {
-    const float h = (float)m.opt.timestep;
-    float a = qacc;
-    // diagonal of -d(qfrc_smooth)/d(qvel): dof damping (+ actuator velocity gains for implicitfast)
-    float diag = own ? MF(dof_damping)[lane] : 0.f;
-    bool need = diag > 0.f;
-    if (m.opt.integrator == MJLAB_INT_IMPLICITFAST) {
-      // d(qfrc_actuator)/d(qvel) of the affine-bias actuators: lanes = actuators, scattered to
-      // the owning dof through LDS (clamped actuators have zero derivative)
-      need = true;
-      const float *biasprm = MF(actuator_biasprm), *gear = MF(actuator_gear), *frange = MF(actuator_forcerange);
-      s_vec[lane] = 0.f;
-      __syncthreads();
-      for (int k = lane; k < nu; k += 64) {
-        const int da = m.jnt_dofadr[m.actuator_trnid[2 * k]];
-        const float f = d.actuator_force[(size_t)w * nu + k];
-        if (m.actuator_forcelimited[k] && (f <= frange[2 * k] || f >= frange[2 * k + 1])) continue;
-        atomicAdd(&s_vec[da], -gear[6 * k] * gear[6 * k] * biasprm[10 * k + 2]);
-      }
-      __syncthreads();
-      diag += s_vec[lane];
-    }
-    if (__ballot(need)) {
-      __syncthreads();
-      dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
-      chol_pad_rows<NVP>(c.s_H, nv, lane);
-      chol_pad_diag<NVP>(c.s_H, nv, lane);
-      __syncthreads();
-      if (own) c.s_H[lane * ld + lane] += h * diag;
-      __syncthreads();
-      PROF_MARK(9);
-      chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
-      PROF_MARK(12);
-      PROF_COUNT(14);
-      __syncthreads();
-      PROF_MARK(9);
-      a = chol_solve<NVP>(c.s_H, c.s_invd, lane, own ? qs + fc : 0.f);
-      PROF_MARK(13);
-      PROF_COUNT(15);
-    }
-    float qv = 0.f;
-    if (own) {
-      qv = d.qvel[wv] + h * a;
-      d.qvel[wv] = qv;
-      s_vec[lane] = qv;
-    }
-    __syncthreads();
-    float* qpos = d.qpos + (size_t)w * nq;
-    for (int j = lane; j < nj; j += 64) {
-      const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-      if (m.jnt_type[j] == MJLAB_JNT_FREE) {
-        for (int k = 0; k < 3; ++k) qpos[qa + k] += h * s_vec[da + k];
-        float ax[3] = {s_vec[da + 3], s_vec[da + 4], s_vec[da + 5]}, q[4], qr[4], qn[4];
-        for (int k = 0; k < 4; ++k) q[k] = qpos[qa + 3 + k];
-        const float ang = h * normalize3(ax);
-        axis_angle2quat(qr, ax, ang);
-        normalize4(q);
-        mul_quat(qn, q, qr);
-        normalize4(qn);
-        for (int k = 0; k < 4; ++k) qpos[qa + 3 + k] = qn[k];
-      } else {
-        qpos[qa] += h * s_vec[da];
-      }
-    }
-    if (lane == 0) d.time[w] += h;
-  }
-  PROF_MARK(9);
   PROF_FLUSH(d.profile + (size_t)w * 64);
 }
 
