@@ -81,7 +81,12 @@ def main() -> None:
   ap.add_argument("--envs-per-gpu", type=int, default=4096)
   ap.add_argument("--scene", default="g1_velocity_flat")
   ap.add_argument("--no-gather", action="store_true")
-  ap.add_argument("--no-graph", action="store_true")
+  ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly (no hipGraph at all)")
+  ap.add_argument("--no-step-graph", action="store_true",
+                  help="replay Simulation's per-call step/forward graphs like the reference (sim/sim.py:185,193) "
+                  "instead of one hipGraph per control step")
+  ap.add_argument("--masked-forward", action="store_true",
+                  help="extension: forward() only on reset worlds (default: all worlds, like the reference)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--seed", type=int, default=42)
   args = ap.parse_args()
@@ -98,7 +103,11 @@ def main() -> None:
   model = robots.load_model(args.scene)
   sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else 0.25
-  roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info))
+  roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info),
+                        masked_forward=args.masked_forward)
+  step_graph = not args.no_graph and not args.no_step_graph
+  if step_graph:
+    roll.capture_graph()
   gather = info.world_size > 1 and not args.no_gather
 
   def env_step() -> None:
@@ -192,7 +201,8 @@ def main() -> None:
         "workload": f"{args.scene}: {args.envs_per_gpu} envs/GPU, timestep 0.005, decimation 4, Newton 10 it / 20 ls, implicitfast, pyramidal, njmax 300",
         "global_envs": n_env,
         "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL obs all-gather" if gather else ""),
-        "graph": sim.use_graph,
+        "graph": "one hipGraph per control step" if step_graph else ("per-call step/forward hipGraphs" if sim.use_graph else "none"),
+        "forward_after_reset": "reset worlds only (extension)" if args.masked_forward else "all worlds (reference behaviour)",
       },
       "world_physics_steps_per_s": value * roll.decimation,
       "roofline": roof,

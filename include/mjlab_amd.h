@@ -62,6 +62,12 @@ int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void
  * (reference: sim/sim.py:182-187). */
 int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream);
 
+/* Extension (not in the reference API): mjlab_forward restricted to
+ * the worlds whose d->world_mask entry is non-zero; the other worlds' arrays are left untouched.
+ * The reference runs forward() on ALL worlds whenever any env resets
+ * (envs/manager_based_rl_env.py:128-132). */
+int mjlab_forward_masked(const mjlab_model_t* m, const mjlab_data_t* d, void* stream);
+
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);
 

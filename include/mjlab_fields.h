@@ -151,6 +151,7 @@
   X(ncon, 1, one)                                                               \
   X(nefc, 1, one)                                                               \
   X(solver_niter, 1, one)                                                       \
+  X(world_mask, 1, one) /* mjlab_forward_masked: worlds with 0 are skipped */     \
   X(contact_dim, 1, nconmax)                                                    \
   X(contact_geom, 2, nconmax)                                                   \
   X(contact_efc_address, 1, nconmax)                                            \

@@ -413,9 +413,10 @@ __host__ __device__ inline int position_lds_floats(const mjlab_sizes_t& s) {
   return persistent + (kin > mat ? kin : mat);
 }
 
-__global__ __launch_bounds__(64) void k_position(const Model m, const Data d) {
+__global__ __launch_bounds__(64) void k_position(const Model m, const Data d, const int use_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
+  if (use_mask && !d.world_mask[w]) return;
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ng = m.size.ngeom, ns = m.size.nsite;
   float* s_sub = smem;
   float* s_cinert = s_sub + 3 * nb;
@@ -777,9 +778,10 @@ __device__ __forceinline__ void make_frame(float* f9, const float* f6) {
 
 __host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) { return 12 * s.ngeom; }
 
-__global__ __launch_bounds__(64) void k_collision(const Model m, const Data d) {
+__global__ __launch_bounds__(64) void k_collision(const Model m, const Data d, const int use_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
+  if (use_mask && !d.world_mask[w]) return;
   const int ng = m.size.ngeom, ncm = m.size.nconmax, npair = m.size.npair;
   float* s_gx = smem;
   float* s_gm = s_gx + 3 * ng;
@@ -906,9 +908,10 @@ __host__ __device__ inline int velocity_lds_floats(const mjlab_sizes_t& s) {
   return 2 * s.nv + 12 * s.nv + 10 * s.nbody + 24 * s.nbody;
 }
 
-__global__ __launch_bounds__(64) void k_velocity(const Model m, const Data d) {
+__global__ __launch_bounds__(64) void k_velocity(const Model m, const Data d, const int use_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
+  if (use_mask && !d.world_mask[w]) return;
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt;
   float* s_qvel = smem;
   float* s_qact = s_qvel + nv;
@@ -1114,9 +1117,10 @@ __host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) {
   return s.nconmax + 2 * constraint_nlim(s) + CC_NROWS * 64;
 }
 
-__global__ __launch_bounds__(64) void k_constraint(const Model m, const Data d) {
+__global__ __launch_bounds__(64) void k_constraint(const Model m, const Data d, const int use_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
+  if (use_mask && !d.world_mask[w]) return;
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ncm = m.size.nconmax, njm = m.size.njmax;
   const int nlim = constraint_nlim(m.size);
   int* s_cadr = (int*)smem;                  // contact -> first efc row (or -1)
@@ -1601,10 +1605,11 @@ __device__ __forceinline__ float constraint_cost(const float* s_jar, const float
 enum { ST_SMOOTH = 0, ST_NEWTON = 1, ST_PREP_INTEGRATE = 2, ST_INTEGRATE = 3 };
 
 template <int NVP>
-__global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate) {
+__global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate, const int use_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = CholCfg<NVP>::NB, ld = CholCfg<NVP>::LD;
   const int w = blockIdx.x, lane = threadIdx.x;
+  if (use_mask && !d.world_mask[w]) return;
   const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
   SolveCtx<NVP> c;
   c.s_H = smem;
@@ -1938,36 +1943,44 @@ static int check_model(const mjlab_model_t* m) {
     if (e_ != hipSuccess) return fail((int)e_, #kernel " launch failed");                                   \
   } while (0)
 
-static int launch_solve(const mjlab_model_t* m, const mjlab_data_t* d, int do_solve, int do_integrate, hipStream_t st) {
+static int launch_solve(const mjlab_model_t* m, const mjlab_data_t* d, int do_solve, int do_integrate, int use_mask, hipStream_t st) {
   const int lds = solve_lds_floats(m->size);
   switch (solve_nvp(m->size.nv)) {
-    case 8: LAUNCH(k_solve_integrate<8>, lds, *m, *d, do_solve, do_integrate); break;
-    case 16: LAUNCH(k_solve_integrate<16>, lds, *m, *d, do_solve, do_integrate); break;
-    case 20: LAUNCH(k_solve_integrate<20>, lds, *m, *d, do_solve, do_integrate); break;
-    case 24: LAUNCH(k_solve_integrate<24>, lds, *m, *d, do_solve, do_integrate); break;
-    case 32: LAUNCH(k_solve_integrate<32>, lds, *m, *d, do_solve, do_integrate); break;
-    case 36: LAUNCH(k_solve_integrate<36>, lds, *m, *d, do_solve, do_integrate); break;
-    case 40: LAUNCH(k_solve_integrate<40>, lds, *m, *d, do_solve, do_integrate); break;
-    case 48: LAUNCH(k_solve_integrate<48>, lds, *m, *d, do_solve, do_integrate); break;
-    case 64: LAUNCH(k_solve_integrate<64>, lds, *m, *d, do_solve, do_integrate); break;
+    case 8: LAUNCH(k_solve_integrate<8>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
+    case 16: LAUNCH(k_solve_integrate<16>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
+    case 20: LAUNCH(k_solve_integrate<20>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
+    case 24: LAUNCH(k_solve_integrate<24>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
+    case 32: LAUNCH(k_solve_integrate<32>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
+    case 36: LAUNCH(k_solve_integrate<36>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
+    case 40: LAUNCH(k_solve_integrate<40>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
+    case 48: LAUNCH(k_solve_integrate<48>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
+    case 64: LAUNCH(k_solve_integrate<64>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
     default: return fail(-3, "nv must be in [1, 64]");
   }
   return 0;
 }
 
-int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream) {
+static int forward_stages_impl(const mjlab_model_t* m, const mjlab_data_t* d, int stages, int use_mask, void* stream) {
   int rc = check_model(m);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (stages & MJLAB_STAGE_POSITION) LAUNCH(k_position, position_lds_floats(m->size), *m, *d);
-  if (stages & MJLAB_STAGE_COLLISION) LAUNCH(k_collision, collision_lds_floats(m->size), *m, *d);
-  if (stages & MJLAB_STAGE_VELOCITY) LAUNCH(k_velocity, velocity_lds_floats(m->size), *m, *d);
-  if (stages & MJLAB_STAGE_CONSTRAINT) LAUNCH(k_constraint, constraint_lds_floats(m->size), *m, *d);
+  if (stages & MJLAB_STAGE_POSITION) LAUNCH(k_position, position_lds_floats(m->size), *m, *d, use_mask);
+  if (stages & MJLAB_STAGE_COLLISION) LAUNCH(k_collision, collision_lds_floats(m->size), *m, *d, use_mask);
+  if (stages & MJLAB_STAGE_VELOCITY) LAUNCH(k_velocity, velocity_lds_floats(m->size), *m, *d, use_mask);
+  if (stages & MJLAB_STAGE_CONSTRAINT) LAUNCH(k_constraint, constraint_lds_floats(m->size), *m, *d, use_mask);
   if (stages & (MJLAB_STAGE_SOLVE | MJLAB_STAGE_INTEGRATE)) {
-    rc = launch_solve(m, d, (stages & MJLAB_STAGE_SOLVE) != 0, (stages & MJLAB_STAGE_INTEGRATE) != 0, st);
+    rc = launch_solve(m, d, (stages & MJLAB_STAGE_SOLVE) != 0, (stages & MJLAB_STAGE_INTEGRATE) != 0, use_mask, st);
     if (rc) return rc;
   }
   return 0;
+}
+
+int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream) {
+  return forward_stages_impl(m, d, stages, 0, stream);
+}
+
+int mjlab_forward_masked(const mjlab_model_t* m, const mjlab_data_t* d, void* stream) {
+  return forward_stages_impl(m, d, MJLAB_STAGE_FORWARD, 1, stream);
 }
 
 int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream) {

@@ -20,7 +20,8 @@ from .sim import Simulation
 
 class PhysicsRollout:
   def __init__(self, sim: Simulation, action_scale: np.ndarray | float = 0.25, decimation: int = 4,
-               episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0) -> None:
+               episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0,
+               masked_forward: bool = False) -> None:
     m: Model = sim.mj_model
     dev = sim.data.qpos.device
     self.sim, self.m, self.decimation = sim, m, decimation
@@ -35,7 +36,11 @@ class PhysicsRollout:
     self.has_free = m.njnt > 0 and m.jnt_type[0] == JNT_FREE
     self.max_len = int(round(episode_length_s / (m.opt.timestep * decimation)))
     self.min_height = min_height
+    # False = the reference's behaviour (forward on ALL worlds after a reset,
+    # envs/manager_based_rl_env.py:128-132); True = only the reset worlds (extension)
+    self.masked_forward = masked_forward
     n = sim.num_envs
+    self._graph: torch.cuda.CUDAGraph | None = None
     # start at random episode phase like the reference (train.py:109-111 init_at_random_ep_len)
     self.episode_length = torch.randint(0, self.max_len, (n,), device=dev, generator=self.gen)
     self.reset_all()
@@ -64,13 +69,49 @@ class PhysicsRollout:
     self.sim.forward()
 
   def step(self, action: torch.Tensor) -> torch.Tensor:
-    """One control step; returns the boolean reset mask."""
+    """One control step; returns the boolean reset mask.
+
+    With ``capture_graph()`` done, the whole control step -- action processing, the
+    ``decimation`` physics steps, termination test, masked reset and the forward pass -- is
+    ONE hipGraph replay (resets are mask based, so there is no
+    ``nonzero()`` host sync and nothing data dependent on the host side)."""
+    if self._graph is not None:
+      self._action_buf.copy_(action)
+      self._graph.replay()
+      return self._reset_buf
+    return self._step_eager(action)
+
+  def capture_graph(self) -> None:
+    """Capture one control step into a hipGraph (the physics kernels are launched directly
+    inside the capture, not through the Simulation's own step/forward graphs)."""
+    n = self.sim.num_envs
+    dev = self.key_qpos.device
+    self._action_buf = torch.zeros((n, self.m.nu), device=dev)
+    self._reset_buf = torch.zeros((n,), dtype=torch.bool, device=dev)
+    sim_graph = self.sim.use_graph
+    self.sim.use_graph = False  # nested replays cannot be captured; record the raw launches
+    try:
+      # warm-up on a side stream (allocator, lazy init), then capture
+      st = torch.cuda.Stream(device=dev)
+      st.wait_stream(torch.cuda.current_stream(dev))
+      with torch.cuda.stream(st):
+        self._reset_buf.copy_(self._step_eager(self._action_buf))
+      torch.cuda.current_stream(dev).wait_stream(st)
+      g = torch.cuda.CUDAGraph()
+      g.register_generator_state(self.gen)
+      with torch.cuda.graph(g):
+        self._reset_buf.copy_(self._step_eager(self._action_buf))
+      self._graph = g
+    finally:
+      self.sim.use_graph = sim_graph
+
+  def _step_eager(self, action: torch.Tensor) -> torch.Tensor:
     d = self.sim.data
     target = self.default_joint + action * self.action_scale
     for _ in range(self.decimation):
       d.ctrl[:] = target
       self.sim.step()
-    self.episode_length += 1
+    self.episode_length.add_(1)
     fell = d.qpos[:, 2] < self.min_height if self.has_free else torch.zeros_like(self.episode_length, dtype=torch.bool)
     bad = ~torch.isfinite(d.qpos).all(dim=1)
     reset = fell | bad | (self.episode_length >= self.max_len)
@@ -79,8 +120,8 @@ class PhysicsRollout:
     d.qpos[:] = torch.where(rm, fresh, torch.nan_to_num(d.qpos))
     d.qvel[:] = torch.where(rm, torch.zeros_like(d.qvel), torch.nan_to_num(d.qvel))
     d.qacc_warmstart[:] = torch.where(rm, torch.zeros_like(d.qacc_warmstart), torch.nan_to_num(d.qacc_warmstart))
-    self.episode_length = torch.where(reset, torch.zeros_like(self.episode_length), self.episode_length)
-    self.sim.forward()
+    self.episode_length.copy_(torch.where(reset, torch.zeros_like(self.episode_length), self.episode_length))
+    self.sim.forward(reset if self.masked_forward else None)
     return reset
 
   def random_action(self) -> torch.Tensor:

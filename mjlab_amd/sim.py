@@ -336,8 +336,15 @@ class Simulation:
   def reset(self) -> None:
     pass  # reference sim/sim.py:178-180
 
-  def forward(self) -> None:
+  def forward(self, env_mask: torch.Tensor | None = None) -> None:
+    """``forward()`` is the reference call (all worlds, sim/sim.py:182-187).  ``env_mask`` (bool
+    or int tensor of shape ``(num_envs,)``) is an extension: only the marked worlds are
+    recomputed; it is enqueued without any host sync."""
     with torch.cuda.device(self._dev):
+      if env_mask is not None:
+        self._data["world_mask"].copy_(env_mask.to(torch.int32).view(-1))
+        native.check(self._lib.mjlab_forward_masked(ctypes.byref(self._m), ctypes.byref(self._d), self._stream()), "mjlab_forward_masked")
+        return
       if self.use_graph and self.forward_graph is not None:
         self.forward_graph.replay()
       else:
