@@ -1378,6 +1378,9 @@ struct SolveCtx {
   int nv, nefc, lane;
   float quad_gauss[3];
   int ls_iter;
+  // line search: quadratic coefficients of this lane's row (rows 0..63) for the current search
+  // direction, so that an evaluation touches LDS only for rows >= 64
+  float lj0, ljv, lq0, lq1, lq2;
 };
 
 // x16[cb] = x[16 cb + (lane & 15)], gathered from the lane-owned layout
@@ -1513,10 +1516,27 @@ __device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x
     }
 }
 
+// cost of row r along the search direction: D/2 (j0 + alpha jv)^2 where that is negative
+template <int NVP>
+__device__ __forceinline__ void ls_prepare(SolveCtx<NVP>& c) {
+  const int r = c.lane;
+  float j0 = 1.f, jv = 0.f, Dr = 0.f;  // lanes beyond nefc: never active
+  if (r < c.nefc) { j0 = c.s_jar[r]; jv = c.s_jv[r]; Dr = c.s_D[r]; }
+  c.lj0 = j0; c.ljv = jv;
+  c.lq0 = 0.5f * Dr * j0 * j0; c.lq1 = Dr * j0 * jv; c.lq2 = 0.5f * Dr * jv * jv;
+}
+__device__ __forceinline__ float ls_newton_step(float alpha, float d0, float d1) {
+  return alpha - d0 * __builtin_amdgcn_rcpf(d1);  // 1 ulp reciprocal: alpha only has to meet ls_tolerance
+}
 template <int NVP>
 __device__ __forceinline__ void ls_eval(SolveCtx<NVP>& c, LsPnt* p, float alpha) {
   float cost = 0.f, d0 = 0.f, d1 = 0.f;
-  for (int r = c.lane; r < c.nefc; r += 64) {
+  if (c.lj0 + alpha * c.ljv < 0.f) {
+    cost = alpha * alpha * c.lq2 + alpha * c.lq1 + c.lq0;
+    d0 = 2.f * alpha * c.lq2 + c.lq1;
+    d1 = 2.f * c.lq2;
+  }
+  for (int r = c.lane + 64; r < c.nefc; r += 64) {
     const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r];
     const float x = j0 + alpha * jv;
     if (x < 0.f) {
@@ -1542,7 +1562,7 @@ __device__ __forceinline__ int update_bracket(SolveCtx<NVP>& c, LsPnt* p, const 
     if (p->d0 < 0.f && cand[i].d0 < 0.f && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
     else if (p->d0 > 0.f && cand[i].d0 > 0.f && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
   }
-  if (flag) ls_eval(c, pnext, p->alpha - p->d0 / p->d1);
+  if (flag) ls_eval(c, pnext, ls_newton_step(p->alpha, p->d0, p->d1));
   return flag;
 }
 // exact 1-D line search on the piecewise-quadratic cost (safeguarded Newton + bracketing)
@@ -1550,8 +1570,9 @@ template <int NVP>
 __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
   LsPnt p0, p1, p2, pmid, p1next, p2next;
   c.ls_iter = 0;
+  ls_prepare(c);
   ls_eval(c, &p0, 0.f);
-  ls_eval(c, &p1, p0.alpha - p0.d0 / p0.d1);
+  ls_eval(c, &p1, ls_newton_step(p0.alpha, p0.d0, p0.d1));
   if (p0.cost < p1.cost) p1 = p0;
   if (fabsf(p1.d0) < gtol) return p1.alpha;
   const float dir = p1.d0 < 0.f ? 1.f : -1.f;
@@ -1560,13 +1581,13 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
   while (p1.d0 * dir <= -gtol && c.ls_iter < lsmax) {
     p2 = p1;
     p2update = true;
-    ls_eval(c, &p1, p1.alpha - p1.d0 / p1.d1);
+    ls_eval(c, &p1, ls_newton_step(p1.alpha, p1.d0, p1.d1));
     if (fabsf(p1.d0) < gtol) return p1.alpha;
   }
   if (c.ls_iter >= lsmax) return p1.alpha;
   if (!p2update) return p1.alpha;
   p2next = p1;
-  ls_eval(c, &p1next, p1.alpha - p1.d0 / p1.d1);
+  ls_eval(c, &p1next, ls_newton_step(p1.alpha, p1.d0, p1.d1));
   while (c.ls_iter < lsmax) {
     ls_eval(c, &pmid, 0.5f * (p1.alpha + p2.alpha));
     LsPnt cand[3] = {p1next, p2next, pmid};
