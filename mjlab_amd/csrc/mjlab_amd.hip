@@ -55,7 +55,7 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #endif
 
 #ifndef MJLAB_CB
-#define MJLAB_CB 16
+#define MJLAB_CB 12
 #endif
 #define MINVAL 1e-15f
 #define MINIMP 0.0001f
@@ -260,6 +260,73 @@ __device__ __forceinline__ void chol_pad_diag(float* A, int n, int lane) {
   constexpr int LD = CholCfg<NVP>::LD;
   if (lane >= n && lane < NVP) A[lane * LD + lane] = 1.f;
 }
+// Column sweep of the factorization below, written as compile-time recursion over the column J
+// and the batch BI so that every register-array index and the choice of ping-pong buffer is a
+// constant (the arrays must live in VGPRs, never in scratch).
+template <int NVP, int CB>
+struct CholSweep {
+  static constexpr int LD = CholCfg<NVP>::LD;
+  template <int R, int K0>
+  static __device__ __forceinline__ void load_batch(lds_f32* A, float (&dst)[CB]) {
+#pragma unroll
+    for (int q = 0; q < CB / 4; ++q) {
+      if (K0 + 4 * q < R) {
+        const f32x4 v = *(lds_f32x4*)(A + R * LD + K0 + 4 * q);
+        dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+      }
+    }
+  }
+  // batch BI of column J: request the next batch (same row, or first batch of row J+1) into
+  // `nxt`, feed `cur` to the FMAs, recurse with the buffers swapped
+  template <int J, int BI>
+  static __device__ __forceinline__ void batches(const float (&a)[NVP], f32x2& acc, float (&cur)[CB], float (&nxt)[CB], lds_f32* A) {
+    constexpr int NBJ = (J + CB - 1) / CB, K0 = BI * CB;
+    if constexpr (BI < NBJ) {
+      if constexpr (BI + 1 < NBJ) load_batch<J, K0 + CB>(A, nxt);
+      else if constexpr (J + 1 < NVP) load_batch<J + 1, 0>(A, nxt);
+#pragma unroll
+      for (int k = 0; k < CB; k += 2) {
+        if (K0 + k + 1 < J) {
+          const f32x2 av = {a[K0 + k], a[K0 + k + 1]};
+          const f32x2 sv = {cur[k], cur[k + 1]};
+          acc -= av * sv;
+        } else if (K0 + k < J) {
+          acc.x -= a[K0 + k] * cur[k];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      batches<J, BI + 1>(a, acc, nxt, cur, A);
+    }
+  }
+  // column J; `cur` holds (or is about to receive) the first batch of row J
+  template <int J>
+  static __device__ __forceinline__ void col(float (&a)[NVP], float (&cur)[CB], float (&oth)[CB], lds_f32* A, lds_f32* row, int rowid, float& myinvd) {
+    constexpr int NBJ = (J + CB - 1) / CB;
+    f32x2 acc = {a[J], 0.f};  // two accumulators, products in pairs (v_pk_fma_f32)
+    batches<J, 0>(a, acc, cur, oth, A);
+    const float t = acc.x + acc.y;
+    const float djj = fmaxf(lane_bcast(t, J), MINVAL);
+    float invd = __builtin_amdgcn_rcpf(djj);  // v_rcp_f32 (1 ulp) + one Newton step
+    invd = invd * (2.f - djj * invd);
+    a[J] = t;
+    const float lu = rowid > J ? t * invd : 0.f;
+    row[J] = lu;
+    myinvd = rowid == J ? invd : myinvd;
+    if constexpr (J + 1 < NVP) {
+      // after NBJ swaps the first batch of row J+1 sits in `cur` (NBJ even) or `oth` (NBJ odd)
+      if constexpr (NBJ == 0) {
+        load_batch<J + 1, 0>(A, cur);  // J == 0: nothing was in flight
+      } else if constexpr (J < CB) {   // entry written after the request: patch from lane J+1
+        const float e = lane_bcast(lu, J + 1);
+        if constexpr (NBJ % 2 == 0) cur[J] = e; else oth[J] = e;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NBJ % 2 == 0) col<J + 1>(a, cur, oth, A, row, rowid, myinvd);
+      else col<J + 1>(a, oth, cur, A, row, rowid, myinvd);
+    }
+  }
+};
+
 // A (LDS, lower triangle valid for rows < n) -> unit-lower factor of A = Lu D Lu^T in place:
 // Lu[i][j] (i > j), ZERO on and above the diagonal, s_invd[i] = 1 / D_i.  With the zero
 // diagonal the substitutions below are a bare v_readlane + v_fma per step.
@@ -291,44 +358,14 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
   }
   (void)n;  // rows >= n are identity rows already (chol_pad_rows / chol_pad_diag by the producer)
   float myinvd = 1.f;
-#pragma unroll
-  for (int j = 0; j < NVP; ++j) {
-    // row j of Lu in batches of CB columns (bounds the registers the reads occupy); two
-    // accumulators, products in pairs (v_pk_fma_f32)
-    constexpr int CB = MJLAB_CB;
-    f32x2 acc = {a[j], 0.f};
-#pragma unroll
-    for (int k0 = 0; k0 < j; k0 += CB) {
-      float rj[CB];
-#pragma unroll
-      for (int q = 0; q < CB / 4; ++q) {
-        if (k0 + 4 * q < j) {
-          const f32x4 v = *(lds_f32x4*)(A + j * LD + k0 + 4 * q);
-          rj[4 * q] = v.x; rj[4 * q + 1] = v.y; rj[4 * q + 2] = v.z; rj[4 * q + 3] = v.w;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < CB; k += 2) {
-        if (k0 + k + 1 < j) {
-          const f32x2 av = {a[k0 + k], a[k0 + k + 1]};
-          const f32x2 sv = {rj[k], rj[k + 1]};
-          acc -= av * sv;
-        } else if (k0 + k < j) {
-          acc.x -= a[k0 + k] * rj[k];
-        }
-      }
-      if (k0 + CB < j) __builtin_amdgcn_sched_barrier(0);
-    }
-    const float t = acc.x + acc.y;
-    const float djj = fmaxf(lane_bcast(t, j), MINVAL);
-    float invd = __builtin_amdgcn_rcpf(djj);  // v_rcp_f32 (1 ulp) + one Newton step
-    invd = invd * (2.f - djj * invd);
-    a[j] = t;
-    row[j] = rowid > j ? t * invd : 0.f;
-    myinvd = rowid == j ? invd : myinvd;
-    // keep the scheduler from hoisting later rows' reads across this point (register pressure)
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  // Row j of Lu is consumed in batches of CB columns.  The batches are software pipelined
+  // through two register buffers: while batch i feeds the FMAs, the reads of batch i+1 --
+  // the next batch of the same row, or the first batch of the next row -- are already in
+  // flight, so the sweep does not stall on an LDS round trip per column.  The first batch of
+  // row j+1 is requested before column j is written; its one missing entry Lu[j+1][j] is
+  // patched in from lane j+1's register.
+  float bufA[MJLAB_CB], bufB[MJLAB_CB];
+  CholSweep<NVP, MJLAB_CB>::template col<0>(a, bufA, bufB, A, row, rowid, myinvd);
   s_invd[rowid] = myinvd;
 }
 // Solves Lu D Lu^T x = b with the factor in LDS (as left by chol_factor); lane i owns
