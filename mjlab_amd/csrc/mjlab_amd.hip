@@ -348,7 +348,10 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
   constexpr int LD = CholCfg<NVP>::LD;
   lds_f32* A = (lds_f32*)A_;
   lds_f32* s_invd = (lds_f32*)s_invd_;
-  const int rowid = lane < NVP ? lane : NVP - 1;
+  int rowid = lane < NVP ? lane : NVP - 1;
+  // opaque: otherwise the 2 NVP lane-mask compares below are loop invariant for the caller's
+  // solver loop, get hoisted out of it and live (spilled) in ~150 SGPRs
+  asm volatile("" : "+v"(rowid));
   lds_f32* row = A + rowid * LD;
   float a[NVP];
 #pragma unroll
