@@ -179,7 +179,7 @@ def main() -> None:
         "note": "latency/LDS-bound by construction (SURVEY.md 8d): lower HBM traffic is better",
       }
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and info.world_size == 1:  # reported at N = 1 only
       try:
         cpu = cpu_baseline(args.scene, args.seed)
       except Exception as e:  # noqa: BLE001
