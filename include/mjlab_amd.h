@@ -68,6 +68,34 @@ int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream);
  * (envs/manager_based_rl_env.py:128-132). */
 int mjlab_forward_masked(const mjlab_model_t* m, const mjlab_data_t* d, void* stream);
 
+/* Extension: fused post-step read-back of the quantities the
+ * reference's EntityData derives with 3-6 small torch kernels each
+ * (src/mjlab/entity/data.py:20-31 compute_velocity_from_cvel, :190-261 root_* / body_* pose
+ * and velocity, :315-328 joint_pos/vel/acc, :487-516 projected_gravity_b, heading_w,
+ * root_*_vel_b).  One launch, one wave per world; every pointer is a device pointer with a
+ * leading dimension nworld; outputs may be NULL to skip them. */
+typedef struct mjlab_entity_view {
+  int nbody;        /* entity bodies */
+  int njoint;       /* entity joints that are not the free joint */
+  int root_body_id; /* global body id of the entity's root link */
+  int pad_;
+  const int* body_ids;    /* [nbody] global body ids */
+  const int* joint_q_adr; /* [njoint] qpos addresses */
+  const int* joint_v_adr; /* [njoint] dof addresses */
+  float gravity_vec_w[3]; /* (0, 0, -1) in the reference, entity/entity.py:418 */
+  float forward_vec_b[3]; /* (1, 0, 0), entity/entity.py:419 */
+  float* body_link_pose_w; /* (nworld, nbody, 7): xpos, xquat */
+  float* body_link_vel_w;  /* (nworld, nbody, 6): linear, angular (world frame, at the link origin) */
+  float* body_com_pose_w;  /* (nworld, nbody, 7): xipos, xquat * body_iquat */
+  float* body_com_vel_w;   /* (nworld, nbody, 6): at the body centre of mass */
+  float* root_derived;     /* (nworld, 16): projected_gravity_b 0:3, heading_w 3, root_link_lin_vel_b 4:7,
+                              root_link_ang_vel_b 7:10, root_com_lin_vel_b 10:13, root_com_ang_vel_b 13:16 */
+  float* joint_pos;        /* (nworld, njoint) */
+  float* joint_vel;        /* (nworld, njoint) */
+  float* joint_acc;        /* (nworld, njoint) */
+} mjlab_entity_view_t;
+int mjlab_entity_readback(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_entity_view_t* v, void* stream);
+
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);
 

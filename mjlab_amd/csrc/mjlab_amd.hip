@@ -1936,6 +1936,85 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
 }
 
 // ====================================================================================
+// Fused read-back of EntityData's derived quantities (extension, see include/mjlab_amd.h)
+// ====================================================================================
+__device__ __forceinline__ void quat_apply_dev(float* r, const float* q, const float* v, float sign) {
+  // reference third_party/isaaclab/.../math.py:623-662: t = 2 xyz x v;  v +- w t + xyz x t
+  float t[3], u[3];
+  cross3(t, q + 1, v);
+  for (int k = 0; k < 3; ++k) t[k] *= 2.f;
+  cross3(u, q + 1, t);
+  for (int k = 0; k < 3; ++k) r[k] = v[k] + sign * q[0] * t[k] + u[k];
+}
+// world-frame velocity at point `pos` from the c-frame spatial velocity (entity/data.py:20-31)
+__device__ __forceinline__ void vel_from_cvel(float* out6, const float* pos, const float* sub, const float* cv) {
+  float off[3] = {sub[0] - pos[0], sub[1] - pos[1], sub[2] - pos[2]}, c[3];
+  cross3(c, cv, off);
+  for (int k = 0; k < 3; ++k) { out6[k] = cv[3 + k] - c[k]; out6[3 + k] = cv[k]; }
+}
+
+__global__ __launch_bounds__(64) void k_entity_readback(const Model m, const Data d, const mjlab_entity_view_t v) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int nb = m.size.nbody, nq = m.size.nq, nv = m.size.nv;
+  const float* sub = d.subtree_com + ((size_t)w * nb + v.root_body_id) * 3;
+  const float sc[3] = {sub[0], sub[1], sub[2]};
+  const float* biq = MF(body_iquat);
+  for (int i = lane; i < v.nbody; i += 64) {
+    const int b = v.body_ids[i];
+    const size_t wb = (size_t)w * nb + b, wi = (size_t)w * v.nbody + i;
+    float pos[3], ipos[3], q[4], iq[4], cv[6], qc[4], o6[6];
+    for (int k = 0; k < 3; ++k) { pos[k] = d.xpos[3 * wb + k]; ipos[k] = d.xipos[3 * wb + k]; }
+    for (int k = 0; k < 4; ++k) { q[k] = d.xquat[4 * wb + k]; iq[k] = biq[4 * b + k]; }
+    for (int k = 0; k < 6; ++k) cv[k] = d.cvel[6 * wb + k];
+    if (v.body_link_pose_w) {
+      for (int k = 0; k < 3; ++k) v.body_link_pose_w[7 * wi + k] = pos[k];
+      for (int k = 0; k < 4; ++k) v.body_link_pose_w[7 * wi + 3 + k] = q[k];
+    }
+    if (v.body_link_vel_w) {
+      vel_from_cvel(o6, pos, sc, cv);
+      for (int k = 0; k < 6; ++k) v.body_link_vel_w[6 * wi + k] = o6[k];
+    }
+    if (v.body_com_pose_w) {
+      mul_quat(qc, q, iq);
+      for (int k = 0; k < 3; ++k) v.body_com_pose_w[7 * wi + k] = ipos[k];
+      for (int k = 0; k < 4; ++k) v.body_com_pose_w[7 * wi + 3 + k] = qc[k];
+    }
+    if (v.body_com_vel_w) {
+      vel_from_cvel(o6, ipos, sc, cv);
+      for (int k = 0; k < 6; ++k) v.body_com_vel_w[6 * wi + k] = o6[k];
+    }
+  }
+  if (v.root_derived && lane == 0) {
+    const size_t wb = (size_t)w * nb + v.root_body_id;
+    float pos[3], ipos[3], q[4], cv[6], lv[6], cvl[6], r[3];
+    for (int k = 0; k < 3; ++k) { pos[k] = d.xpos[3 * wb + k]; ipos[k] = d.xipos[3 * wb + k]; }
+    for (int k = 0; k < 4; ++k) q[k] = d.xquat[4 * wb + k];
+    for (int k = 0; k < 6; ++k) cv[k] = d.cvel[6 * wb + k];
+    vel_from_cvel(lv, pos, sc, cv);
+    vel_from_cvel(cvl, ipos, sc, cv);
+    float* o = v.root_derived + (size_t)w * 16;
+    quat_apply_dev(r, q, v.gravity_vec_w, -1.f);
+    for (int k = 0; k < 3; ++k) o[k] = r[k];
+    quat_apply_dev(r, q, v.forward_vec_b, 1.f);
+    o[3] = atan2f(r[1], r[0]);
+    quat_apply_dev(r, q, lv, -1.f);
+    for (int k = 0; k < 3; ++k) o[4 + k] = r[k];
+    quat_apply_dev(r, q, lv + 3, -1.f);
+    for (int k = 0; k < 3; ++k) o[7 + k] = r[k];
+    quat_apply_dev(r, q, cvl, -1.f);
+    for (int k = 0; k < 3; ++k) o[10 + k] = r[k];
+    quat_apply_dev(r, q, cvl + 3, -1.f);
+    for (int k = 0; k < 3; ++k) o[13 + k] = r[k];
+  }
+  for (int j = lane; j < v.njoint; j += 64) {
+    const size_t wj = (size_t)w * v.njoint + j;
+    if (v.joint_pos) v.joint_pos[wj] = d.qpos[(size_t)w * nq + v.joint_q_adr[j]];
+    if (v.joint_vel) v.joint_vel[wj] = d.qvel[(size_t)w * nv + v.joint_v_adr[j]];
+    if (v.joint_acc) v.joint_acc[wj] = d.qacc[(size_t)w * nv + v.joint_v_adr[j]];
+  }
+}
+
+// ====================================================================================
 // repeat_array_kernel replacement (reference src/mjlab/sim/randomization.py:9-17)
 // ====================================================================================
 template <typename T>
@@ -2054,6 +2133,18 @@ int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void
     int rc = mjlab_forward_stages(m, d, MJLAB_STAGE_STEP, stream);
     if (rc) return rc;
   }
+  return 0;
+}
+
+int mjlab_entity_readback(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_entity_view_t* v, void* stream) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!v || v->nbody < 0 || v->njoint < 0 || v->root_body_id < 0 || v->root_body_id >= m->size.nbody)
+    return fail(-14, "entity_readback: bad view");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_entity_readback, dim3(m->size.nworld), dim3(64), 0, st, *m, *d, *v);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "k_entity_readback launch failed");
   return 0;
 }
 
