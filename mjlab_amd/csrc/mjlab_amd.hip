@@ -1480,8 +1480,25 @@ __device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x1
 // if WITH_H, the tiles of J^T diag(D*active) J (lower-triangular 16x16 blocks) in `acc` via
 // fp32 MFMA.  The tiles stay in registers: hessian_store() adds M and lays them out in LDS
 // only when the Newton iteration actually needs a new factorization.
+// Only ACTIVE rows (jar < 0) contribute to J^T f and to J^T D J, and at a typical state they are
+// about a third of the rows, so the pass runs over a compacted list of active row indices
+// (built with wave ballots into the LDS area of s_jv, which is dead between two line searches).
+// Returns the number of active rows; the list is in increasing row order.
+template <int NVP>
+__device__ __forceinline__ int build_active_list(const SolveCtx<NVP>& c, int* s_act) {
+  int nact = 0;
+  for (int r0 = 0; r0 < c.nefc; r0 += 64) {
+    const int r = r0 + c.lane;
+    const bool act = r < c.nefc && c.s_jar[r] < 0.f;
+    const unsigned long long mask = __ballot(act);
+    if (act) s_act[nact + __popcll(mask & ((1ull << c.lane) - 1ull))] = r;
+    nact += __popcll(mask);
+  }
+  return nact;
+}
+
 template <int NVP, bool WITH_H>
-__device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2]) {
+__device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2], const int* s_act, int nact) {
   constexpr int NB = CholCfg<NVP>::NB;
   constexpr int NT = NB * (NB + 1) / 2;
   float jtf[NB];
@@ -1492,20 +1509,19 @@ __device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&a
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) jtf[cb] = 0.f;
   const int sub = c.lane >> 4, col = c.lane & 15;
-  for (int r0 = 0; r0 < c.nefc; r0 += 4 * JU) {
+  for (int k0 = 0; k0 < nact; k0 += 4 * JU) {
     float x[JU][NB], dact[JU], f[JU];
 #pragma unroll
     for (int u = 0; u < JU; ++u) {
-      const int r = r0 + 4 * u + sub;
+      const int k = k0 + 4 * u + sub;
+      const bool valid = k < nact;
+      const int r = valid ? s_act[k] : 0;
       dact[u] = 0.f; f[u] = 0.f;
-      if (r < c.nefc) {
-        const float jar = c.s_jar[r], Dr = c.s_D[r];
-        if (jar < 0.f) { dact[u] = Dr; f[u] = -Dr * jar; }
-      }
+      if (valid) { dact[u] = c.s_D[r]; f[u] = -dact[u] * c.s_jar[r]; }
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
         const int cc = 16 * cb + col;
-        x[u][cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
+        x[u][cb] = (valid && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
       }
     }
 #pragma unroll
@@ -1833,8 +1849,12 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
         cost += gauss;
         {
+          __syncthreads();
+          int* s_act = (int*)c.s_jv;
+          const int nact = build_active_list<NVP>(c, s_act);
+          __syncthreads();
           f32x4 htile[NB * (NB + 1) / 2];
-          fc = hessian_accum<NVP, true>(c, htile);
+          fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
           rhs = own ? Ma - qs - fc : 0.f;
           hessian_store<NVP>(c, htile);
           chol_pad_diag<NVP>(c.s_H, nv, lane);
@@ -1892,9 +1912,12 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         // set H is unchanged and the factor in LDS is reused.  (The two branches are spelled
         // out so that the 24 tile registers are live only inside the branch that needs them.)
         iter++;
+        int* s_act = (int*)c.s_jv;  // J search is dead until the next line search
+        const int nact = build_active_list<NVP>(c, s_act);
+        __syncthreads();
         if (any_changed) {
           f32x4 htile[NB * (NB + 1) / 2];
-          fc = hessian_accum<NVP, true>(c, htile);
+          fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
@@ -1907,7 +1930,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
           need_factor = true;
         } else {  // same active set -> same H -> the factor in LDS is still valid
           f32x4 unused[NB * (NB + 1) / 2];
-          fc = hessian_accum<NVP, false>(c, unused);
+          fc = hessian_accum<NVP, false>(c, unused, s_act, nact);
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
