@@ -763,7 +763,7 @@ __device__ __forceinline__ int sphere_sphere(RawCon* c, float margin, const floa
   for (int k = 0; k < 3; ++k) { c->pos[k] = p1[k] + dif[k] * (r1 + c->dist * 0.5f); c->frame[k] = dif[k]; c->frame[3 + k] = 0.f; }
   return 1;
 }
-__device__ int capsule_capsule(RawCon* c, float margin, const float* pos1, const float* axis1, const float* size1,
+__device__ __forceinline__ int capsule_capsule(RawCon* c, float margin, const float* pos1, const float* axis1, const float* size1,
                                const float* pos2, const float* axis2, const float* size2) {
   float dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
   float ma = dot3(axis1, axis1), mb = -dot3(axis1, axis2), mc = dot3(axis2, axis2);
@@ -778,28 +778,37 @@ __device__ int capsule_capsule(RawCon* c, float margin, const float* pos1, const
     for (int k = 0; k < 3; ++k) { vec1[k] = pos1[k] + axis1[k] * x1; vec2[k] = pos2[k] + axis2[k] * x2; }
     return sphere_sphere(c, margin, vec1, size1[0], vec2, size2[0]);
   }
+  // parallel axes: up to two contacts out of four end-point candidates, taken in order.  The
+  // output slots are written with compile-time indices (a run-time `c + n` would push the
+  // whole contact array into scratch memory).
   int n = 0;
-  float x2;
+  RawCon t;
+  auto push = [&](bool ok) {
+    if (ok) {
+      if (n == 0) c[0] = t; else if (n == 1) c[1] = t;
+      ++n;
+    }
+  };
+  float x1, x2;
   for (int k = 0; k < 3; ++k) vec1[k] = pos1[k] + axis1[k] * size1[1];
   x2 = clipf((v - mb * size1[1]) / mc, -size2[1], size2[1]);
   for (int k = 0; k < 3; ++k) vec2[k] = pos2[k] + axis2[k] * x2;
-  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  push(sphere_sphere(&t, margin, vec1, size1[0], vec2, size2[0]) != 0);
   for (int k = 0; k < 3; ++k) vec1[k] = pos1[k] - axis1[k] * size1[1];
   x2 = clipf((v + mb * size1[1]) / mc, -size2[1], size2[1]);
   for (int k = 0; k < 3; ++k) vec2[k] = pos2[k] + axis2[k] * x2;
-  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  push(sphere_sphere(&t, margin, vec1, size1[0], vec2, size2[0]) != 0);
   if (n == 2) return n;
-  float x1;
   for (int k = 0; k < 3; ++k) vec2[k] = pos2[k] + axis2[k] * size2[1];
   x1 = clipf((u - mb * size2[1]) / ma, -size1[1], size1[1]);
   for (int k = 0; k < 3; ++k) vec1[k] = pos1[k] + axis1[k] * x1;
-  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
+  push(sphere_sphere(&t, margin, vec1, size1[0], vec2, size2[0]) != 0);
   if (n == 2) return n;
   for (int k = 0; k < 3; ++k) vec2[k] = pos2[k] - axis2[k] * size2[1];
   x1 = clipf((u + mb * size2[1]) / ma, -size1[1], size1[1]);
   for (int k = 0; k < 3; ++k) vec1[k] = pos1[k] + axis1[k] * x1;
-  n += sphere_sphere(c + n, margin, vec1, size1[0], vec2, size2[0]);
-  return n;
+  push(sphere_sphere(&t, margin, vec1, size1[0], vec2, size2[0]) != 0);
+  return n < 2 ? n : 2;
 }
 
 __device__ __forceinline__ void make_frame(float* f9, const float* f6) {
@@ -856,10 +865,15 @@ __global__ __launch_bounds__(64) void k_collision(const Model m, const Data d, c
           n = plane_sphere(rc, margin, p1, z1, p2, s2[0]);
         } else if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_CAPSULE) {
           float q[3];
+          RawCon t;
           for (int k = 0; k < 3; ++k) q[k] = p2[k] + z2[k] * s2[1];
-          if (plane_sphere(rc + n, margin, p1, z1, q, s2[0])) { for (int k = 0; k < 3; ++k) rc[n].frame[3 + k] = z2[k]; n++; }
+          if (plane_sphere(&t, margin, p1, z1, q, s2[0])) { for (int k = 0; k < 3; ++k) t.frame[3 + k] = z2[k]; rc[0] = t; n = 1; }
           for (int k = 0; k < 3; ++k) q[k] = p2[k] - z2[k] * s2[1];
-          if (plane_sphere(rc + n, margin, p1, z1, q, s2[0])) { for (int k = 0; k < 3; ++k) rc[n].frame[3 + k] = z2[k]; n++; }
+          if (plane_sphere(&t, margin, p1, z1, q, s2[0])) {
+            for (int k = 0; k < 3; ++k) t.frame[3 + k] = z2[k];
+            if (n == 0) rc[0] = t; else rc[1] = t;
+            n++;
+          }
         } else if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_BOX) {
           const float dist = dot3(dif, z1);
           float bm[9];
@@ -869,11 +883,13 @@ __global__ __launch_bounds__(64) void k_collision(const Model m, const Data d, c
             mul_mat_vec3(corner, bm, vec);
             const float ldist = dot3(z1, corner);
             if (dist + ldist > margin || ldist > 0.f) continue;
-            rc[n].dist = dist + ldist;
+            RawCon t;
+            t.dist = dist + ldist;
             for (int k = 0; k < 3; ++k) {
-              rc[n].pos[k] = corner[k] + p2[k] + z1[k] * (-rc[n].dist * 0.5f);
-              rc[n].frame[k] = z1[k]; rc[n].frame[3 + k] = 0.f;
+              t.pos[k] = corner[k] + p2[k] + z1[k] * (-t.dist * 0.5f);
+              t.frame[k] = z1[k]; t.frame[3 + k] = 0.f;
             }
+            if (n == 0) rc[0] = t; else if (n == 1) rc[1] = t; else if (n == 2) rc[2] = t; else rc[3] = t;
             n++;
           }
         } else if (t1 == MJLAB_GEOM_SPHERE && t2 == MJLAB_GEOM_SPHERE) {
@@ -916,7 +932,9 @@ __global__ __launch_bounds__(64) void k_collision(const Model m, const Data d, c
           for (int k = 0; k < 2; ++k) solref[k] = fminf(gsolref[2 * g1 + k], gsolref[2 * g2 + k]);
         for (int k = 0; k < 5; ++k) solimp[k] = mix * gsolimp[5 * g1 + k] + (1.f - mix) * gsolimp[5 * g2 + k];
       }
-      for (int i = 0; i < n; ++i) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i >= n) break;
         const int c = base + off + i;
         if (c >= ncm) break;
         float f9[9];
@@ -948,7 +966,7 @@ __host__ __device__ inline int velocity_lds_floats(const mjlab_sizes_t& s) {
   return 2 * s.nv + 12 * s.nv + 10 * s.nbody + 24 * s.nbody;
 }
 
-__global__ __launch_bounds__(64) void k_velocity(const Model m, const Data d, const int use_mask) {
+__global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d, const int use_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if (use_mask && !d.world_mask[w]) return;
@@ -972,51 +990,65 @@ __global__ __launch_bounds__(64) void k_velocity(const Model m, const Data d, co
   }
   for (int i = lane; i < nv; i += 64) s_qact[i] = 0.f;
   __syncthreads();
-  // ---- down-sweep by level: cvel, cdof_dot, cacc, cfrc_body
-  for (int L = 1; L < m.size.nlevel; ++L) {
-    const int a0 = m.level_adr[L], a1 = m.level_adr[L + 1];
-    for (int idx = a0 + lane; idx < a1; idx += 64) {
-      const int i = m.level_body[idx];
-      const int pid = m.body_parentid[i], ja = m.body_jntadr[i], jn = m.body_jntnum[i];
-      float v[6], a[6];
-      for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * pid + k]; a[k] = s_cacc[6 * pid + k]; }
-      for (int j = ja; j < ja + jn; ++j) {
-        const int da = m.jnt_dofadr[j];
-        if (m.jnt_type[j] == MJLAB_JNT_FREE) {
-          for (int k = 0; k < 3; ++k) {
-            const float qv = s_qvel[da + k];
-            for (int c = 0; c < 6; ++c) { v[c] += s_cdof[6 * (da + k) + c] * qv; s_cdd[6 * (da + k) + c] = 0.f; }
-          }
-          float cd[3][6];
-          for (int k = 0; k < 3; ++k) {
-            float c6[6];
-            for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * (da + 3 + k) + c];
-            cross_motion(cd[k], v, c6);
-          }
-          for (int k = 0; k < 3; ++k) {
-            const float qv = s_qvel[da + 3 + k];
-            for (int c = 0; c < 6; ++c) {
-              v[c] += s_cdof[6 * (da + 3 + k) + c] * qv;
-              a[c] += cd[k][c] * qv;
-              s_cdd[6 * (da + 3 + k) + c] = cd[k][c];
+  // ---- down-sweep by level: cvel, cdof_dot, cacc, cfrc_body.  lane = body (nbody <= 64): the
+  // body's topology, inertia and first joint's motion axis are fetched before the sweep, so a
+  // level costs one LDS round trip (parent velocity / acceleration) plus arithmetic.
+  {
+    const int i = lane < nb ? lane : 0;
+    const int depth = lane < nb ? m.body_depth[i] : -1;
+    const int pid = m.body_parentid[i], ja = m.body_jntadr[i], jn = m.body_jntnum[i];
+    int da0 = 0, jtype0 = -1;
+    if (jn > 0) { da0 = m.jnt_dofadr[ja]; jtype0 = m.jnt_type[ja]; }
+    float in[10], c60[6], qv0 = 0.f;
+    for (int k = 0; k < 10; ++k) in[k] = s_cinert[10 * i + k];
+    for (int k = 0; k < 6; ++k) c60[k] = s_cdof[6 * da0 + k];
+    if (jn > 0) qv0 = s_qvel[da0];
+    for (int L = 1; L < m.size.nlevel; ++L) {
+      if (depth == L) {
+        float v[6], a[6];
+        for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * pid + k]; a[k] = s_cacc[6 * pid + k]; }
+        for (int j = ja; j < ja + jn; ++j) {
+          const int da = j == ja ? da0 : m.jnt_dofadr[j];
+          const int jtype = j == ja ? jtype0 : m.jnt_type[j];
+          if (jtype == MJLAB_JNT_FREE) {
+            for (int k = 0; k < 3; ++k) {
+              const float qv = s_qvel[da + k];
+              for (int c = 0; c < 6; ++c) { v[c] += s_cdof[6 * (da + k) + c] * qv; s_cdd[6 * (da + k) + c] = 0.f; }
             }
+            float cd[3][6];
+            for (int k = 0; k < 3; ++k) {
+              float c6[6];
+              for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * (da + 3 + k) + c];
+              cross_motion(cd[k], v, c6);
+            }
+            for (int k = 0; k < 3; ++k) {
+              const float qv = s_qvel[da + 3 + k];
+              for (int c = 0; c < 6; ++c) {
+                v[c] += s_cdof[6 * (da + 3 + k) + c] * qv;
+                a[c] += cd[k][c] * qv;
+                s_cdd[6 * (da + 3 + k) + c] = cd[k][c];
+              }
+            }
+          } else {
+            float c6[6], cd[6];
+            float qv = qv0;
+            for (int c = 0; c < 6; ++c) c6[c] = c60[c];
+            if (j != ja) {
+              qv = s_qvel[da];
+              for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * da + c];
+            }
+            cross_motion(cd, v, c6);
+            for (int c = 0; c < 6; ++c) { v[c] += c6[c] * qv; a[c] += cd[c] * qv; s_cdd[6 * da + c] = cd[c]; }
           }
-        } else {
-          float c6[6], cd[6];
-          const float qv = s_qvel[da];
-          for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * da + c];
-          cross_motion(cd, v, c6);
-          for (int c = 0; c < 6; ++c) { v[c] += c6[c] * qv; a[c] += cd[c] * qv; s_cdd[6 * da + c] = cd[c]; }
         }
+        float t1[6], t2[6], t3[6];
+        mul_inert_vec(t1, in, a);
+        mul_inert_vec(t2, in, v);
+        cross_force(t3, v, t2);
+        for (int k = 0; k < 6; ++k) { s_cvel[6 * i + k] = v[k]; s_cacc[6 * i + k] = a[k]; s_cfrc[6 * i + k] = t1[k] + t3[k]; }
       }
-      float in[10], t1[6], t2[6], t3[6];
-      for (int k = 0; k < 10; ++k) in[k] = s_cinert[10 * i + k];
-      mul_inert_vec(t1, in, a);
-      mul_inert_vec(t2, in, v);
-      cross_force(t3, v, t2);
-      for (int k = 0; k < 6; ++k) { s_cvel[6 * i + k] = v[k]; s_cacc[6 * i + k] = a[k]; s_cfrc[6 * i + k] = t1[k] + t3[k]; }
+      __syncthreads();
     }
-    __syncthreads();
   }
   lds_to_global(d.cvel + (size_t)w * 6 * nb, s_cvel, 6 * nb, lane);
   lds_to_global(d.cdof_dot + (size_t)w * 6 * nv, s_cdd, 6 * nv, lane);
