@@ -45,14 +45,9 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #define PROF_FLUSH(ptr) do {} while (0)
 #endif
 
-// The dense factor / substitution routines are large fully-unrolled bodies used at several
-// points of the solve kernel; keeping ONE out-of-line copy keeps the kernel inside the
-// instruction cache (define MJLAB_CHOL_FORCEINLINE to compare).
-#ifdef MJLAB_CHOL_FORCEINLINE
+// The dense factor / substitution routines are large fully-unrolled bodies; the solve kernel is
+// organised so that each is instantiated exactly once (see k_solve_integrate).
 #define CHOL_INLINE __forceinline__
-#else
-#define CHOL_INLINE __forceinline__
-#endif
 
 #ifndef MJLAB_CB
 #define MJLAB_CB 12
