@@ -191,3 +191,162 @@ def test_threads_give_identical_results():
   a.step(10, nthread=1)
   b.step(10, nthread=4)
   assert np.array_equal(a.qpos, b.qpos)
+
+
+def _perturb(model, qpos, dof, eps):
+  """qpos (+) eps * e_dof on the configuration manifold (free joint: world translation for dofs
+  0-2, body-frame rotation for dofs 3-5, like mj_integratePos)."""
+  q = qpos.copy()
+  j = int(model.dof_jntid[dof])
+  k = dof - int(model.jnt_dofadr[j])
+  qa = int(model.jnt_qposadr[j])
+  if model.jnt_type[j] == mjcf.JNT_FREE:
+    if k < 3:
+      q[qa + k] += eps
+    else:
+      ax = np.zeros(3)
+      ax[k - 3] = 1.0
+      dq = np.concatenate([[math.cos(eps / 2)], math.sin(eps / 2) * ax])
+      q[qa + 3 : qa + 7] = mjcf.quat_mul(q[qa + 3 : qa + 7], dq)
+  else:
+    q[qa] += eps
+  return q
+
+
+def _mass_and_potential(s, model, qpos):
+  s.qpos[0] = qpos
+  s.qvel[0] = 0
+  s.forward()
+  M = s.qM[0].reshape(model.nv, model.nv).copy()
+  U = -float(np.sum(model.body_mass[:, None] * s.xipos[0] * np.asarray(model.opt.gravity)[None, :]))
+  return M, U
+
+
+@pytest.mark.parametrize("name", ["go1_velocity_flat", "g1_velocity_flat"])
+def test_bias_forces_satisfy_lagranges_equations(name):
+  """Independent check of kinematics + CRB + RNE: for every hinge dof i (a true coordinate, so
+  Lagrange's equation holds without quasi-velocity terms)
+      qfrc_bias_i = sum_j dM_ij/dt v_j - 1/2 d(v^T M v)/dq_i + dU/dq_i
+  with the derivatives of the oracle's OWN mass matrix and potential energy taken by central
+  differences on the configuration manifold."""
+  model = robots.load_model(name)
+  s = OracleSim(model, 1)
+  rng = np.random.default_rng(3)
+  q0 = model.key_qpos[0].copy()
+  q0[2] += 1.0  # off the ground: no contacts, though bias does not depend on them anyway
+  q0[7:] += rng.normal(0, 0.2, model.nq - 7)
+  quat = q0[3:7] + rng.normal(0, 0.3, 4)
+  q0[3:7] = quat / np.linalg.norm(quat)
+  v = rng.normal(0, 1.0, model.nv)
+  s.qpos[0], s.qvel[0] = q0, v
+  s.forward()
+  bias = s.qfrc_bias[0].copy()
+  eps = 1e-5
+  # dM/dt along the motion: M(q (+) eps v) by composing per-dof perturbations of size eps v_k
+  def moved(sign):
+    q = q0.copy()
+    for k in range(model.nv):
+      q = _perturb(model, q, k, sign * eps * v[k])
+    return _mass_and_potential(s, model, q)[0]
+  Mdot = (moved(+1) - moved(-1)) / (2 * eps)
+  hinge = [i for i in range(model.nv) if model.jnt_type[model.dof_jntid[i]] != mjcf.JNT_FREE]
+  expect = np.zeros(model.nv)
+  for i in hinge:
+    Mp, Up = _mass_and_potential(s, model, _perturb(model, q0, i, +eps))
+    Mm, Um = _mass_and_potential(s, model, _perturb(model, q0, i, -eps))
+    dT = 0.5 * v @ ((Mp - Mm) / (2 * eps)) @ v
+    dU = (Up - Um) / (2 * eps)
+    expect[i] = Mdot[i] @ v - dT + dU
+  err = np.abs(bias[hinge] - expect[hinge]).max() / max(1.0, np.abs(expect[hinge]).max())
+  assert err < 2e-5, err
+
+
+def test_contact_jacobian_matches_finite_difference_kinematics():
+  """Row 0 of a contact's Jacobian block times qvel must equal the normal component of the
+  relative velocity of the two bodies' material points at the contact, obtained here by moving
+  the configuration along qvel and re-running the oracle's kinematics (no Jacobian code)."""
+  model = robots.load_model("g1_velocity_flat")
+  s = OracleSim(model, 1)
+  rng = np.random.default_rng(8)
+  q0 = model.key_qpos[0].copy()
+  q0[2] -= 0.01
+  q0[7:] += rng.normal(0, 0.05, model.nq - 7)
+  v = rng.normal(0, 0.5, model.nv)
+  s.qpos[0], s.qvel[0] = q0, v
+  s.forward()
+  ncon, nefc = int(s.ncon[0, 0]), int(s.nefc[0, 0])
+  assert ncon >= 4
+  J = s.efc_J[0].reshape(-1, model.nv)[:nefc].copy()
+  adr = s.contact_efc_address[0, :ncon].astype(int).copy()
+  pos, frame = s.contact_pos[0, :ncon].copy(), s.contact_frame[0, :ncon].reshape(ncon, 3, 3).copy()
+  geoms = s.contact_geom[0, :ncon].reshape(ncon, 2).astype(int).copy()
+  dims = s.contact_dim[0, :ncon].astype(int).copy()
+  fri = s.contact_friction[0, :ncon].reshape(ncon, 5).copy()
+  xpos0, xmat0 = s.xpos[0].copy(), s.xmat[0].reshape(-1, 3, 3).copy()
+
+  def body_frames(sign, eps=1e-6):
+    q = q0.copy()
+    for k in range(model.nv):
+      q = _perturb(model, q, k, sign * eps * v[k])
+    s.qpos[0] = q
+    s.forward()
+    return s.xpos[0].copy(), s.xmat[0].reshape(-1, 3, 3).copy()
+
+  eps = 1e-6
+  xp, Rp = body_frames(+1, eps)
+  xm, Rm = body_frames(-1, eps)
+  checked = 0
+  for c in range(ncon):
+    if adr[c] < 0:
+      continue
+    vel = []
+    for g in geoms[c]:
+      b = int(model.geom_bodyid[g])
+      local = xmat0[b].T @ (pos[c] - xpos0[b])  # material point in the body frame
+      vel.append(((xp[b] + Rp[b] @ local) - (xm[b] + Rm[b] @ local)) / (2 * eps))
+    rel = vel[1] - vel[0]
+    n, t1 = frame[c, 0], frame[c, 1]
+    if dims[c] == 1:
+      got = J[adr[c]] @ v
+      want = n @ rel
+    else:  # first pyramid row: normal + mu * tangent 1
+      got = J[adr[c]] @ v
+      want = n @ rel + fri[c, 0] * (t1 @ rel)
+    assert got == pytest.approx(want, abs=2e-6 * max(1.0, abs(want))), c
+    checked += 1
+  assert checked >= 4
+
+
+def test_newton_solution_matches_independent_minimiser():
+  """qacc from the oracle's Newton solver minimises
+      1/2 (a - a0)^T M (a - a0) + sum_r D_r/2 min(0, J_r a - aref_r)^2 ;
+  an independent quasi-Newton minimiser (scipy, analytic gradient restated here) must land on
+  the same point."""
+  from scipy.optimize import minimize
+
+  model = robots.load_model("g1_velocity_flat")
+  model.opt.iterations, model.opt.ls_iterations, model.opt.tolerance = 100, 50, 1e-12
+  s = OracleSim(model, 1)
+  rng = np.random.default_rng(2)
+  q0 = model.key_qpos[0].copy()
+  q0[2] -= 0.005
+  q0[7:] += rng.normal(0, 0.05, model.nq - 7)
+  s.qpos[0], s.qvel[0] = q0, rng.normal(0, 0.2, model.nv)
+  s.ctrl[0] = q0[7:] + rng.normal(0, 0.1, model.nu)
+  s.forward()
+  nv, nefc = model.nv, int(s.nefc[0, 0])
+  assert nefc >= 16
+  M = s.qM[0].reshape(nv, nv)
+  J = s.efc_J[0].reshape(-1, nv)[:nefc]
+  D, aref, a0 = s.efc_D[0, :nefc], s.efc_aref[0, :nefc], s.qacc_smooth[0]
+
+  def cost(a):
+    jar = np.minimum(J @ a - aref, 0.0)
+    da = a - a0
+    return 0.5 * da @ M @ da + 0.5 * np.sum(D * jar * jar), M @ da + J.T @ (D * jar)
+
+  res = minimize(cost, a0, jac=True, method="BFGS", options={"gtol": 1e-9, "maxiter": 5000})
+  ref = res.x
+  got = s.qacc[0]
+  assert cost(got)[0] <= cost(ref)[0] * (1 + 1e-9) + 1e-9  # at least as good as the reference minimiser
+  assert np.abs(got - ref).max() / max(1.0, np.abs(ref).max()) < 1e-5
