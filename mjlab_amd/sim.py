@@ -209,6 +209,9 @@ class Simulation:
         setattr(self._d, f.name, flat.data_ptr())
         self._data[f.name] = self._shape_view(f, flat, n)
       self._data["qpos"][:] = torch.from_numpy(model.qpos0.astype(np.float32)).to(dev)
+      # activation state: na = 0 for every supported actuator (no dynamics), kept for API parity
+      # (reference entity/data.py reads data.act)
+      self._data["act"] = torch.zeros((num_envs, int(getattr(model, "na", 0))), dtype=torch.float32, device=dev)
 
     scalars = {k: int(getattr(model, k)) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata")}
     self._model_bridge = Bridge("sim.model", self._model_view, {**scalars, "opt": model.opt, "nworld": num_envs})

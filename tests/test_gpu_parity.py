@@ -248,3 +248,68 @@ def test_device_selftest_wave_primitives():
   from mjlab_amd import native
 
   native.check(native.lib().mjlab_selftest(torch.cuda.current_stream().cuda_stream), "mjlab_selftest")
+
+
+def test_every_domain_randomization_field_is_honoured_per_world():
+  """All fields the reference can randomise per world (FIELD_SPECS, envs/mdp/events.py:184-209):
+  expand, perturb each world differently, and compare with the oracle given the same per-world
+  values -- i.e. the kernels really read `field + w * stride` for every one of them."""
+  import torch
+
+  sim, ora, model = _pair("g1_velocity_flat", nworld=6)
+  fields = ["dof_armature", "dof_frictionloss", "dof_damping", "jnt_range", "jnt_stiffness", "body_mass", "body_ipos",
+            "body_iquat", "body_inertia", "body_pos", "body_quat", "geom_friction", "geom_pos", "geom_quat", "geom_rgba",
+            "site_pos", "site_quat", "qpos0"]  # fmt: skip
+  sim.expand_model_fields(fields)
+  rng = np.random.default_rng(17)
+  n = sim.num_envs
+
+  def unit(q):
+    return q / np.linalg.norm(q, axis=-1, keepdims=True)
+
+  for f in fields:
+    base = np.asarray(getattr(model, f), dtype=np.float64)
+    t = getattr(sim.model, f)
+    assert t.shape == (n, *base.shape) and t.stride(0) == base.size, f
+    if f in ("geom_rgba", "dof_frictionloss"):
+      continue  # not consumed by the physics (frictionloss != 0 is rejected at construction)
+    b = np.broadcast_to(base, (n, *base.shape)).copy()
+    if f in ("body_iquat", "body_quat", "geom_quat", "site_quat"):
+      new = unit(b + rng.normal(0, 0.02, b.shape))
+      if f == "body_quat":
+        new[:, :3] = b[:, :3]  # leave world / terrain / floating root frames alone
+    elif f in ("body_mass", "body_inertia", "dof_armature"):
+      new = b * rng.uniform(0.85, 1.15, b.shape)
+    elif f in ("dof_damping", "jnt_stiffness"):
+      new = b + rng.uniform(0.0, 0.5, b.shape)
+      if f == "dof_damping":
+        new[:, :6] = 0.0
+      else:
+        new[:, 0] = 0.0  # free joint
+    elif f == "jnt_range":
+      new = b + rng.uniform(-0.05, 0.05, b.shape)
+    elif f == "geom_friction":
+      new = b * rng.uniform(0.5, 1.5, b.shape)
+    elif f == "qpos0":
+      new = b.copy()
+      new[:, 7:] += rng.normal(0, 0.02, (n, base.size - 7))
+    else:  # positions
+      new = b + rng.normal(0, 0.005, b.shape)
+      if f == "body_pos":
+        new[:, :3] = b[:, :3]
+    t[:] = torch.from_numpy(new.astype(np.float32)).cuda()
+    ora.expand_model_field(f)[:] = new
+  sim.create_graph()
+  sim.forward()
+  ora.forward()
+  assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
+  for f in ("xpos", "xipos", "geom_xpos", "site_xpos", "subtree_com", "qM", "qfrc_bias", "qfrc_passive", "qfrc_smooth"):
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 2e-5, f
+  # different worlds really got different models
+  assert float(sim.data.qM[0].sub(sim.data.qM[1]).abs().max()) > 1e-3
+  for _ in range(2):
+    sim.step()
+  ora.step(2)
+  assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-5
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 2e-3
+  assert sim.data.act.shape == (n, 0)
