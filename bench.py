@@ -85,6 +85,9 @@ def main() -> None:
   ap.add_argument("--no-step-graph", action="store_true",
                   help="replay Simulation's per-call step/forward graphs like the reference (sim/sim.py:185,193) "
                   "instead of one hipGraph per control step")
+  ap.add_argument("--torch-reset", action="store_true",
+                  help="termination test + reset as a chain of torch ops (the reference's style) instead of the "
+                  "fused mjlab_masked_reset launch")
   ap.add_argument("--masked-forward", action="store_true",
                   help="extension: forward() only on reset worlds (default: all worlds, like the reference)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,7 +107,7 @@ def main() -> None:
   sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else 0.25
   roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info),
-                        masked_forward=args.masked_forward)
+                        masked_forward=args.masked_forward, fused_reset=not args.torch_reset)
   step_graph = not args.no_graph and not args.no_step_graph
   if step_graph:
     roll.capture_graph()
@@ -203,6 +206,7 @@ def main() -> None:
         "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL obs all-gather" if gather else ""),
         "graph": "one hipGraph per control step" if step_graph else ("per-call step/forward hipGraphs" if sim.use_graph else "none"),
         "forward_after_reset": "reset worlds only (extension)" if args.masked_forward else "all worlds (reference behaviour)",
+        "termination_and_reset": "torch ops" if args.torch_reset else "one fused launch (mjlab_masked_reset), mask based, no host sync",
       },
       "world_physics_steps_per_s": value * roll.decimation,
       "roofline": roof,

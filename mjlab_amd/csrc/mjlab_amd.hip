@@ -2065,6 +2065,53 @@ __global__ __launch_bounds__(64) void k_entity_readback(const Model m, const Dat
 }
 
 // ====================================================================================
+// Masked termination + reset (extension, see include/mjlab_amd.h)
+// ====================================================================================
+__device__ __forceinline__ float nan_to_num_dev(float x) {
+  if (x != x) return 0.f;
+  if (x > 3.402823466e+38f) return 3.402823466e+38f;
+  if (x < -3.402823466e+38f) return -3.402823466e+38f;
+  return x;
+}
+__global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d, const float* key_qpos, const float* rnd3,
+                                                      int* episode_length, const int max_len, const float min_height, int* reset_mask) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int nq = m.size.nq, nv = m.size.nv;
+  const bool has_free = m.size.njnt > 0 && m.jnt_type[0] == MJLAB_JNT_FREE;
+  float* qpos = d.qpos + (size_t)w * nq;
+  float* qvel = d.qvel + (size_t)w * nv;
+  float* ws = d.qacc_warmstart + (size_t)w * nv;
+  bool bad = false;
+  for (int i = lane; i < nq; i += 64) {
+    const float x = qpos[i];
+    bad |= !(fabsf(x) <= 3.402823466e+38f);  // NaN or inf
+  }
+  const int elen = episode_length[w] + 1;
+  const bool fell = has_free && qpos[2] < min_height;
+  const bool reset = __ballot(bad) != 0ull || fell || elen >= max_len;
+  if (reset) {
+    for (int i = lane; i < nq; i += 64) {
+      float x = key_qpos[i];
+      if (has_free) {
+        const float yaw = (rnd3[3 * w + 2] * 2.f - 1.f) * 3.14f;
+        if (i < 2) x += rnd3[3 * w + i] - 0.5f;
+        else if (i == 3) x = cosf(yaw * 0.5f);
+        else if (i == 4 || i == 5) x = 0.f;
+        else if (i == 6) x = sinf(yaw * 0.5f);
+      }
+      qpos[i] = x;
+    }
+    for (int i = lane; i < nv; i += 64) { qvel[i] = 0.f; ws[i] = 0.f; }
+  } else {
+    for (int i = lane; i < nv; i += 64) { qvel[i] = nan_to_num_dev(qvel[i]); ws[i] = nan_to_num_dev(ws[i]); }
+  }
+  if (lane == 0) {
+    episode_length[w] = reset ? 0 : elen;
+    reset_mask[w] = reset ? 1 : 0;
+  }
+}
+
+// ====================================================================================
 // repeat_array_kernel replacement (reference src/mjlab/sim/randomization.py:9-17)
 // ====================================================================================
 template <typename T>
@@ -2195,6 +2242,19 @@ int mjlab_entity_readback(const mjlab_model_t* m, const mjlab_data_t* d, const m
   hipLaunchKernelGGL(k_entity_readback, dim3(m->size.nworld), dim3(64), 0, st, *m, *d, *v);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, "k_entity_readback launch failed");
+  return 0;
+}
+
+int mjlab_masked_reset(const mjlab_model_t* m, const mjlab_data_t* d, const float* key_qpos, const float* rnd3,
+                       int* episode_length, int max_len, float min_height, int* reset_mask, void* stream) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!key_qpos || !rnd3 || !episode_length || !reset_mask) return fail(-15, "masked_reset: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_masked_reset, dim3(m->size.nworld), dim3(64), 0, st, *m, *d, key_qpos, rnd3, episode_length, max_len,
+                     min_height, reset_mask);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "k_masked_reset launch failed");
   return 0;
 }
 

@@ -21,7 +21,7 @@ from .sim import Simulation
 class PhysicsRollout:
   def __init__(self, sim: Simulation, action_scale: np.ndarray | float = 0.25, decimation: int = 4,
                episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0,
-               masked_forward: bool = False) -> None:
+               masked_forward: bool = False, fused_reset: bool = True) -> None:
     m: Model = sim.mj_model
     dev = sim.data.qpos.device
     self.sim, self.m, self.decimation = sim, m, decimation
@@ -39,10 +39,14 @@ class PhysicsRollout:
     # False = the reference's behaviour (forward on ALL worlds after a reset,
     # envs/manager_based_rl_env.py:128-132); True = only the reset worlds (extension)
     self.masked_forward = masked_forward
+    # True: termination test + reset in one library launch (mjlab_masked_reset); False: the same
+    # logic as a chain of torch ops (the reference's style)
+    self.fused_reset = fused_reset
     n = sim.num_envs
     self._graph: torch.cuda.CUDAGraph | None = None
     # start at random episode phase like the reference (train.py:109-111 init_at_random_ep_len)
-    self.episode_length = torch.randint(0, self.max_len, (n,), device=dev, generator=self.gen)
+    self.episode_length = torch.randint(0, self.max_len, (n,), device=dev, generator=self.gen).to(torch.int32)
+    self._reset_mask = torch.zeros((n,), dtype=torch.int32, device=dev)
     self.reset_all()
 
   def _sample_reset_qpos(self, n: int) -> torch.Tensor:
@@ -111,16 +115,31 @@ class PhysicsRollout:
     for _ in range(self.decimation):
       d.ctrl[:] = target
       self.sim.step()
-    self.episode_length.add_(1)
-    fell = d.qpos[:, 2] < self.min_height if self.has_free else torch.zeros_like(self.episode_length, dtype=torch.bool)
-    bad = ~torch.isfinite(d.qpos).all(dim=1)
-    reset = fell | bad | (self.episode_length >= self.max_len)
-    fresh = self._sample_reset_qpos(self.sim.num_envs)
-    rm = reset.unsqueeze(1)
-    d.qpos[:] = torch.where(rm, fresh, torch.nan_to_num(d.qpos))
-    d.qvel[:] = torch.where(rm, torch.zeros_like(d.qvel), torch.nan_to_num(d.qvel))
-    d.qacc_warmstart[:] = torch.where(rm, torch.zeros_like(d.qacc_warmstart), torch.nan_to_num(d.qacc_warmstart))
-    self.episode_length.copy_(torch.where(reset, torch.zeros_like(self.episode_length), self.episode_length))
+    if self.fused_reset:
+      import ctypes
+
+      from . import native
+
+      rnd = torch.rand((self.sim.num_envs, 3), device=self.key_qpos.device, generator=self.gen)
+      s = self.sim
+      native.check(
+        s._lib.mjlab_masked_reset(ctypes.byref(s._m), ctypes.byref(s._d), self.key_qpos.data_ptr(), rnd.data_ptr(),
+                                  self.episode_length.data_ptr(), self.max_len, float(self.min_height),
+                                  self._reset_mask.data_ptr(), s._stream()),
+        "mjlab_masked_reset",
+      )
+      reset = self._reset_mask.bool()
+    else:
+      self.episode_length.add_(1)
+      fell = d.qpos[:, 2] < self.min_height if self.has_free else torch.zeros_like(self.episode_length, dtype=torch.bool)
+      bad = ~torch.isfinite(d.qpos).all(dim=1)
+      reset = fell | bad | (self.episode_length >= self.max_len)
+      fresh = self._sample_reset_qpos(self.sim.num_envs)
+      rm = reset.unsqueeze(1)
+      d.qpos[:] = torch.where(rm, fresh, torch.nan_to_num(d.qpos))
+      d.qvel[:] = torch.where(rm, torch.zeros_like(d.qvel), torch.nan_to_num(d.qvel))
+      d.qacc_warmstart[:] = torch.where(rm, torch.zeros_like(d.qacc_warmstart), torch.nan_to_num(d.qacc_warmstart))
+      self.episode_length.copy_(torch.where(reset, torch.zeros_like(self.episode_length), self.episode_length))
     self.sim.forward(reset if self.masked_forward else None)
     return reset
 

@@ -341,3 +341,50 @@ def test_whole_step_graph_equals_eager_rollout():
   assert rolls[1]._graph is not None
   for f in ("qpos", "qvel", "qacc", "xpos", "sensordata"):
     assert torch.equal(getattr(rolls[0].sim.data, f), getattr(rolls[1].sim.data, f)), f
+
+
+def test_fused_masked_reset_equals_torch_chain():
+  """mjlab_masked_reset vs the same termination + reset logic as torch ops (the reference's
+  style): identical reset decisions and untouched worlds; reset worlds carry a valid sample of
+  the reset distribution (velocity_env_cfg.py:136-144)."""
+  import torch
+
+  from mjlab_amd import robots
+  from mjlab_amd.rollout import PhysicsRollout, g1_action_scale
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = robots.load_model("g1_velocity_flat")
+  rolls = []
+  for fused in (False, True):
+    sim = Simulation(1024, SimulationCfg(njmax=300), model, "cuda:0")
+    rolls.append(PhysicsRollout(sim, action_scale=g1_action_scale(model), seed=11, fused_reset=fused, episode_length_s=0.6))
+  a, b = rolls
+  b.sim.data.qpos[:] = a.sim.data.qpos
+  b.episode_length.copy_(a.episode_length)
+  gen = torch.Generator(device="cuda").manual_seed(5)
+  key = torch.tensor(model.key_qpos[0], dtype=torch.float32, device="cuda")
+  total = 0
+  for k in range(12):
+    act = torch.rand((1024, model.nu), device="cuda", generator=gen) * 2 - 1
+    if k == 5:  # a diverged world and a fallen one
+      for r in (a, b):
+        r.sim.data.qpos[3, 10] = float("nan")
+        r.sim.data.qpos[9, 2] = 0.1
+    ra, rb = a.step(act), b.step(act)
+    assert torch.equal(ra, rb), k
+    keep = ~ra
+    for f in ("qpos", "qvel", "qacc_warmstart"):
+      assert torch.equal(getattr(a.sim.data, f)[keep], getattr(b.sim.data, f)[keep]), (k, f)
+    assert torch.equal(a.episode_length, b.episode_length)
+    if bool(rb.any()):
+      q = b.sim.data.qpos[rb]
+      assert torch.equal(q[:, 7:], key[7:].expand_as(q[:, 7:])) and torch.equal(q[:, 2], key[2].expand_as(q[:, 2]))
+      assert float((q[:, :2] - key[:2]).abs().max()) <= 0.5
+      assert float(q[:, 4:6].abs().max()) == 0.0 and float((q[:, 3:7].norm(dim=1) - 1).abs().max()) < 1e-6
+      assert float(b.sim.data.qvel[rb].abs().max()) == 0.0
+      # the reset worlds are brought back in sync so that the two rollouts stay comparable
+      a.sim.data.qpos[ra] = b.sim.data.qpos[rb]
+      a.sim.forward()
+      b.sim.forward()
+    total += int(rb.sum())
+  assert total >= 2 + 1024 // 30  # the two forced resets plus time-outs of the 0.6 s episodes
