@@ -388,3 +388,42 @@ def test_fused_masked_reset_equals_torch_chain():
       b.sim.forward()
     total += int(rb.sum())
   assert total >= 2 + 1024 // 30  # the two forced resets plus time-outs of the 0.6 s episodes
+
+
+@pytest.mark.parametrize("name,stand_steps,min_z", [("g1_velocity_flat", 160, 0.55), ("go1_velocity_flat", 2000, 0.2)])
+def test_long_horizon_stability(name, stand_steps, min_z):
+  """Physical plausibility over a long horizon, 4096 worlds from slightly different poses with the
+  position actuators commanded to the keyframe pose.  The quadruped is statically stable and must
+  settle and stay up for the whole 10 s; the humanoid has no balance controller, so it must stay
+  up for the first 0.8 s and then -- wherever it ends -- come to rest on the ground without
+  anything diverging (2000 physics steps)."""
+  import torch
+
+  from mjlab_amd import robots
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = robots.load_model(name)
+  sim = Simulation(NWORLD, SimulationCfg(njmax=300), model, "cuda:0")
+  g = torch.Generator(device="cuda").manual_seed(1)
+  key = torch.tensor(model.key_qpos[0], dtype=torch.float32, device="cuda")
+  q = key.repeat(NWORLD, 1)
+  q[:, 7:] += 0.03 * torch.randn((NWORLD, model.nq - 7), device="cuda", generator=g)
+  q[:, :2] += torch.rand((NWORLD, 2), device="cuda", generator=g) - 0.5
+  sim.data.qpos[:] = q
+  sim.data.ctrl[:] = key[7:]
+  root = int(np.nonzero(model.body_parentid == 0)[0][-1])
+  z = {}
+  for k in range(1, 2001):
+    sim.step()
+    if k in (stand_steps, 1500, 2000):
+      z[k] = sim.data.qpos[:, 2].clone()
+      if k == stand_steps:
+        up = sim.data.xmat[:, root, 2, 2].clone()
+  torch.cuda.synchronize()
+  assert torch.isfinite(sim.data.qpos).all() and torch.isfinite(sim.data.qvel).all()
+  assert float(z[stand_steps].min()) > min_z, float(z[stand_steps].min())
+  assert float(up.median()) > 0.97 and float(up.min()) > 0.8  # torso upright while standing
+  assert float(z[2000].min()) > 0.03  # nothing sinks through the floor
+  assert float((z[2000] - z[1500]).abs().median()) < 5e-3  # at rest at the end (standing or lying)
+  assert float(sim.data.qvel.abs().median()) < 0.05
+  assert float(sim.data.time[0]) == pytest.approx(2000 * model.opt.timestep, rel=1e-4)
