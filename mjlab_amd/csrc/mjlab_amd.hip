@@ -448,7 +448,7 @@ __host__ __device__ inline int position_lds_floats(const mjlab_sizes_t& s) {
   return persistent + (kin > mat ? kin : mat);
 }
 
-__global__ __launch_bounds__(64) void k_position(const Model m, const Data d, const int use_mask) {
+__global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d, const int use_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if (use_mask && !d.world_mask[w]) return;
@@ -822,7 +822,7 @@ __device__ __forceinline__ void make_frame(float* f9, const float* f6) {
 
 __host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) { return 12 * s.ngeom; }
 
-__global__ __launch_bounds__(64) void k_collision(const Model m, const Data d, const int use_mask) {
+__global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d, const int use_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if (use_mask && !d.world_mask[w]) return;
@@ -1184,7 +1184,7 @@ __host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) {
   return s.nconmax + 2 * constraint_nlim(s) + CC_NROWS * 64;
 }
 
-__global__ __launch_bounds__(64) void k_constraint(const Model m, const Data d, const int use_mask) {
+__global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data d, const int use_mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if (use_mask && !d.world_mask[w]) return;
