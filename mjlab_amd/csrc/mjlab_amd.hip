@@ -1448,6 +1448,7 @@ struct SolveCtx {
   // line search: quadratic coefficients of this lane's row (rows 0..63) for the current search
   // direction, so that an evaluation touches LDS only for rows >= 64
   float lj0, ljv, lq0, lq1, lq2;
+  float mj0, mjv, mq0, mq1, mq2;  // same for row 64 + lane (worlds with more than 64 rows set the kernel's tail)
 };
 
 // x16[cb] = x[16 cb + (lane & 15)], gathered from the lane-owned layout
@@ -1607,6 +1608,10 @@ __device__ __forceinline__ void ls_prepare(SolveCtx<NVP>& c) {
   if (r < c.nefc) { j0 = c.s_jar[r]; jv = c.s_jv[r]; Dr = c.s_D[r]; }
   c.lj0 = j0; c.ljv = jv;
   c.lq0 = 0.5f * Dr * j0 * j0; c.lq1 = Dr * j0 * jv; c.lq2 = 0.5f * Dr * jv * jv;
+  j0 = 1.f; jv = 0.f; Dr = 0.f;
+  if (r + 64 < c.nefc) { j0 = c.s_jar[r + 64]; jv = c.s_jv[r + 64]; Dr = c.s_D[r + 64]; }
+  c.mj0 = j0; c.mjv = jv;
+  c.mq0 = 0.5f * Dr * j0 * j0; c.mq1 = Dr * j0 * jv; c.mq2 = 0.5f * Dr * jv * jv;
 }
 __device__ __forceinline__ float ls_newton_step(float alpha, float d0, float d1) {
   return alpha - d0 * __builtin_amdgcn_rcpf(d1);  // 1 ulp reciprocal: alpha only has to meet ls_tolerance
@@ -1619,7 +1624,12 @@ __device__ __forceinline__ void ls_eval(SolveCtx<NVP>& c, LsPnt* p, float alpha)
     d0 = 2.f * alpha * c.lq2 + c.lq1;
     d1 = 2.f * c.lq2;
   }
-  for (int r = c.lane + 64; r < c.nefc; r += 64) {
+  if (c.nefc > 64 && c.mj0 + alpha * c.mjv < 0.f) {
+    cost += alpha * alpha * c.mq2 + alpha * c.mq1 + c.mq0;
+    d0 += 2.f * alpha * c.mq2 + c.mq1;
+    d1 += 2.f * c.mq2;
+  }
+  for (int r = c.lane + 128; r < c.nefc; r += 64) {
     const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r];
     const float x = j0 + alpha * jv;
     if (x < 0.f) {
