@@ -313,3 +313,61 @@ def test_every_domain_randomization_field_is_honoured_per_world():
   assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-5
   assert _rel(_np(sim.data.qvel), ora.qvel) < 2e-3
   assert sim.data.act.shape == (n, 0)
+
+
+@pytest.mark.parametrize("njmax", [300, 100])
+def test_capacity_paths_with_hundreds_of_contacts(njmax):
+  """A large geom margin turns most of the 502 candidate pairs into contacts: several 64-contact
+  chunks in the constraint build, the sequential replay of the row-capacity rule, contact and
+  row capacities reached, line-search rows beyond the register-cached ones."""
+  import copy
+
+  import torch
+
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = copy.deepcopy(models()["g1_velocity_flat"])
+  model.geom_margin = np.full_like(model.geom_margin, 0.25)
+  nworld = 4
+  qpos, qvel, ctrl = golden_inputs(model, nworld, 13)
+  sim = Simulation(nworld, SimulationCfg(njmax=njmax, use_graph=False), model, "cuda:0")
+  ora = OracleSim(model, nworld, njmax=njmax, precision="f64")
+  for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+    getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+    getattr(ora, f)[:] = v
+  sim.forward()
+  ora.forward()
+  ncon, nefc = ora.ncon.ravel(), ora.nefc.ravel()
+  assert ncon.max() >= min(129, sim.nconmax) and nefc.max() > min(njmax, 200) - 8, (ncon, nefc)  # the scenario does what it says
+  assert np.array_equal(_np(sim.data.ncon).ravel(), ncon)
+  assert np.array_equal(_np(sim.data.nefc).ravel(), nefc)
+  assert _np(sim.data.nefc).max() <= njmax
+  nv = model.nv
+  for w in range(nworld):
+    nc, n = int(ncon[w]), int(nefc[w])
+    assert np.array_equal(_np(sim.data.contact_efc_address)[w, :nc], ora.contact_efc_address[w, :nc])
+    assert np.array_equal(_np(sim.data.efc_type)[w, :n], ora.efc_type[w, :n])
+    Jg = _np(sim.data.efc_J)[w].reshape(-1, nv)[:n]
+    assert _rel(Jg, ora.efc_J[w].reshape(-1, nv)[:n]) < 1e-5
+    for f in ("efc_D", "efc_aref", "efc_pos", "efc_margin"):
+      assert _rel(_np(getattr(sim.data, f))[w, :n], getattr(ora, f)[w, :n]) < 2e-4, f
+  assert np.array_equal(_np(sim.data.sensordata), ora.sensordata.astype(np.float32))
+  # the solve itself: both sides stop at the 10-iteration cap on a 300-row problem, so only the
+  # quality of the iterate is compared, not the iterate
+  assert torch.isfinite(sim.data.qacc).all()
+  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 1e-4
+  d = sim.data
+  M, qa, qs = d.qM.double(), d.qacc.double(), d.qfrc_smooth.double()
+  J = d.efc_J.view(nworld, njmax, nv).double()
+  rows = torch.arange(njmax, device="cuda")[None, :] < d.nefc.view(-1, 1)
+  jar = torch.where(rows, torch.einsum("wrv,wv->wr", J, qa) - d.efc_aref.double(), torch.zeros_like(d.efc_aref.double()))
+  cost_gpu = 0.5 * torch.einsum("wi,wij,wj->w", qa - d.qacc_smooth.double(), M, qa - d.qacc_smooth.double()) + 0.5 * (
+    torch.where(rows, d.efc_D.double(), torch.zeros_like(jar)) * jar.clamp_max(0) ** 2).sum(dim=1)
+  # oracle's cost at its own iterate, same formula in numpy
+  for w in range(nworld):
+    n = int(nefc[w])
+    Mo = ora.qM[w].reshape(nv, nv)
+    da = ora.qacc[w] - ora.qacc_smooth[w]
+    jo = np.minimum(ora.efc_J[w].reshape(-1, nv)[:n] @ ora.qacc[w] - ora.efc_aref[w, :n], 0)
+    cost_o = 0.5 * da @ Mo @ da + 0.5 * np.sum(ora.efc_D[w, :n] * jo * jo)
+    assert float(cost_gpu[w]) <= cost_o * 1.05 + 1e-6, (w, float(cost_gpu[w]), cost_o)
