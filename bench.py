@@ -107,7 +107,8 @@ def main() -> None:
   sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else 0.25
   roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info),
-                        masked_forward=args.masked_forward, fused_reset=not args.torch_reset)
+                        masked_forward=args.masked_forward, fused_reset=not args.torch_reset,
+                        min_height=0.3 if args.scene.startswith("g1") else 0.15)
   step_graph = not args.no_graph and not args.no_step_graph
   if step_graph:
     roll.capture_graph()
@@ -188,7 +189,8 @@ def main() -> None:
       except Exception as e:  # noqa: BLE001
         cpu = {"error": str(e)}
     out = {
-      "metric": "env-steps/sec at num_envs=4096 per GPU, Unitree-G1 flat (physics hot path: 4 substeps + 1 forward per env-step)",
+      "metric": f"env-steps/sec at num_envs={args.envs_per_gpu} per GPU, {'Unitree-G1' if args.scene.startswith('g1') else 'Unitree-Go1'} flat "
+      "(physics hot path: 4 substeps + 1 forward per env-step)",
       "value": value,
       "unit": "env-steps/s",
       "n_gpus": info.world_size,

@@ -30,7 +30,7 @@ def _rollout_state(name, nworld=NWORLD, seed=3, steps=12):
   model = robots.load_model(name)
   sim = Simulation(nworld, SimulationCfg(njmax=300 if "velocity" in name else 250), model, "cuda:0")
   scale = g1_action_scale(model) if name.startswith("g1") else go1_action_scale(model)
-  roll = PhysicsRollout(sim, action_scale=scale, seed=seed)
+  roll = PhysicsRollout(sim, action_scale=scale, seed=seed, min_height=0.3 if name.startswith("g1") else 0.15)
   for _ in range(steps):
     roll.step(roll.random_action())
   torch.cuda.synchronize()

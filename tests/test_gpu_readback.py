@@ -46,7 +46,7 @@ def test_readback_matches_reference_formulas(name):
 
   model = robots.load_model(name)
   sim = Simulation(512, SimulationCfg(njmax=300), model, "cuda:0")
-  roll = PhysicsRollout(sim, action_scale=0.25, seed=4)
+  roll = PhysicsRollout(sim, action_scale=0.25, seed=4, min_height=0.3 if name.startswith("g1") else 0.15)
   for _ in range(10):
     roll.step(roll.random_action())
   ent = EntityReadback(sim)

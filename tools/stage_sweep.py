@@ -14,7 +14,7 @@ model = robots.load_model(scene)
 stages = [("position", 1), ("collision", 2), ("velocity", 4), ("constraint", 8), ("solve_integrate", 48)]
 for nworld in (256, 1024, 2048, 4096, 8192, 16384):
   sim = Simulation(nworld, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
-  roll = PhysicsRollout(sim, action_scale=g1_action_scale(model) if scene.startswith("g1") else 0.25, seed=42)
+  roll = PhysicsRollout(sim, action_scale=g1_action_scale(model) if scene.startswith("g1") else 0.25, seed=42, min_height=0.3 if scene.startswith("g1") else 0.15)
   for _ in range(30):
     roll.step(roll.random_action())
   acc = {k: 0.0 for k, _ in stages}
