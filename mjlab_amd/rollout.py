@@ -9,11 +9,12 @@ physics hot path and are not reproduced; resets are mask-based (no ``nonzero()``
 
 from __future__ import annotations
 
-import math
+import ctypes
 
 import numpy as np
 import torch
 
+from . import native
 from .mjcf import JNT_FREE, Model
 from .sim import Simulation
 
@@ -116,10 +117,6 @@ class PhysicsRollout:
       d.ctrl[:] = target
       self.sim.step()
     if self.fused_reset:
-      import ctypes
-
-      from . import native
-
       rnd = torch.rand((self.sim.num_envs, 3), device=self.key_qpos.device, generator=self.gen)
       s = self.sim
       native.check(
@@ -169,5 +166,3 @@ def go1_action_scale(model: Model) -> np.ndarray:
   names = [model.names["joint"][j].split("/")[-1] for j in model.actuator_trnid[:, 0]]
   return robots.action_scale(robots.go1_actuators(), names).astype(np.float32)
 
-
-_ = math
