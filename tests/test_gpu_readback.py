@@ -87,3 +87,37 @@ def test_readback_matches_reference_formulas(name):
   # the root link's world velocity equals the free joint's qvel convention (linear world, angular body)
   close(ent.root_link_lin_vel_w if hasattr(ent, "root_link_lin_vel_w") else ent.root_link_vel_w[:, :3], d.qvel[:, :3], 2e-5)
   close(ent.root_link_ang_vel_b, d.qvel[:, 3:6], 2e-5)
+
+
+def test_readback_matches_vectors_from_the_reference_code():
+  """tests/golden/readback_reference.npz was computed by the reference's own torch functions
+  (tools/make_readback_golden.py); the same mjData-shaped inputs are written into sim.data and
+  the fused kernel must reproduce the outputs."""
+  from pathlib import Path
+
+  import torch
+
+  from mjlab_amd import robots
+  from mjlab_amd.entity_data import EntityReadback
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  z = np.load(Path(__file__).parent / "golden" / "readback_reference.npz")
+  model = robots.load_model("g1_velocity_flat")
+  n = z["in_xpos"].shape[0]
+  sim = Simulation(n, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
+  for f in ("xpos", "xipos", "xquat", "cvel", "subtree_com"):
+    getattr(sim.data, f)[:] = torch.from_numpy(z["in_" + f]).cuda()
+  ent = EntityReadback(sim)
+  ent.update()
+  torch.cuda.synchronize()
+
+  def close(a, name, tol=2e-6):
+    b = torch.from_numpy(z[name]).cuda()
+    assert float((a - b).abs().max()) / max(1.0, float(b.abs().max())) < tol, name
+
+  close(ent.body_link_vel_w, "body_link_vel_w")
+  close(ent.body_com_vel_w, "body_com_vel_w")
+  close(ent.body_com_pose_w[..., 3:], "body_com_quat_w")
+  for name in ("projected_gravity_b", "root_link_lin_vel_b", "root_link_ang_vel_b", "root_com_lin_vel_b", "root_com_ang_vel_b"):
+    close(getattr(ent, name), name)
+  close(ent.heading_w, "heading_w", 1e-5)
