@@ -88,6 +88,9 @@ def main() -> None:
   ap.add_argument("--torch-reset", action="store_true",
                   help="termination test + reset as a chain of torch ops (the reference's style) instead of the "
                   "fused mjlab_masked_reset launch")
+  ap.add_argument("--no-fold", action="store_true",
+                  help="recompute the position / collision / constraint stages in the step() that follows a "
+                  "forward() even where qpos and qvel did not change (the reference's behaviour; results are bit-identical)")
   ap.add_argument("--masked-forward", action="store_true",
                   help="extension: forward() only on reset worlds (default: all worlds, like the reference)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,7 +107,7 @@ def main() -> None:
   torch.cuda.set_device(info.local_rank)
 
   model = robots.load_model(args.scene)
-  sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph), model, dev)
+  sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph, fold_forward=not args.no_fold), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else 0.25
   roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info),
                         masked_forward=args.masked_forward, fused_reset=not args.torch_reset,
@@ -208,6 +211,7 @@ def main() -> None:
         "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL obs all-gather" if gather else ""),
         "graph": "one hipGraph per control step" if step_graph else ("per-call step/forward hipGraphs" if sim.use_graph else "none"),
         "forward_after_reset": "reset worlds only (extension)" if args.masked_forward else "all worlds (reference behaviour)",
+        "forward_fold": "off" if args.no_fold else "step() after forward() skips the stages that depend on qpos/qvel only where both are unchanged (bit-exact)",
         "termination_and_reset": "torch ops" if args.torch_reset else "one fused launch (mjlab_masked_reset), mask based, no host sync",
       },
       "world_physics_steps_per_s": value * roll.decimation,

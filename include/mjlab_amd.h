@@ -59,8 +59,20 @@ int mjlab_sizeof_data(void);
 int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void* stream);
 
 /* Replaces mjwarp.forward: everything of a step except the integration
- * (reference: sim/sim.py:182-187). */
+ * (reference: sim/sim.py:182-187).
+ *
+ * "Forward folded into the next step" (SURVEY.md section 8f row 2): the reference calls forward() on
+ * all worlds whenever an env was reset, writes the next action to ctrl and calls step(), whose
+ * position, collision and constraint-build stages -- functions of qpos, qvel and the model only
+ * -- recompute exactly what forward() just produced (envs/manager_based_rl_env.py:106-132).
+ * mjlab_forward snapshots qpos / qvel per world (data.sh_qpos, sh_qvel, fold_valid); the first
+ * sub-step of the next mjlab_step compares them bit by bit and skips those three stages where
+ * nothing changed.  Velocity / actuation and the constraint solve always run, so the results are
+ * bit-identical to a full recomputation.  Callers that modify per-world MODEL fields between
+ * forward() and step() must zero data.fold_valid (mjlab_amd.sim.Simulation does);
+ * mjlab_set_fold(0) disables the mechanism process-wide and returns the previous setting. */
 int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream);
+int mjlab_set_fold(int enable);
 
 /* Extension (not in the reference API): mjlab_forward restricted to
  * the worlds whose d->world_mask entry is non-zero; the other worlds' arrays are left untouched.

@@ -144,6 +144,8 @@
   X(efc_D, 1, njmax)                                                            \
   X(efc_aref, 1, njmax)                                                         \
   X(efc_force, 1, njmax)                                                        \
+  X(sh_qpos, 1, nq) /* qpos / qvel as they were at the last forward(): see fold_valid */ \
+  X(sh_qvel, 1, nv)                                                             \
   X(profile, 64, one) /* per-world per-phase cycle counts; written only by -DMJLAB_PROFILE builds */
 
 /* ---- data: int32, leading dimension nworld ------------------------------------ */
@@ -152,6 +154,8 @@
   X(nefc, 1, one)                                                               \
   X(solver_niter, 1, one)                                                       \
   X(world_mask, 1, one) /* mjlab_forward_masked: worlds with 0 are skipped */     \
+  X(fold_valid, 1, one) /* 1: position / collision / constraint arrays are those of (sh_qpos, sh_qvel) */ \
+  X(fold_reuse, 1, one) /* scratch of the current step: 1 = this world skips those three stages */ \
   X(contact_dim, 1, nconmax)                                                    \
   X(contact_geom, 2, nconmax)                                                   \
   X(contact_efc_address, 1, nconmax)                                            \

@@ -428,6 +428,14 @@ __device__ __forceinline__ float symm_mul_global(const float* M, int n, float v,
   return lane < n ? y0 + y1 : 0.f;
 }
 
+// launch flags shared by the stage kernels
+enum {
+  FLAG_MASK = 1,      // skip worlds whose world_mask entry is 0 (mjlab_forward_masked)
+  FLAG_FOLD = 2,      // step(): reuse the position / collision / constraint stages of the last forward()
+                      // in worlds whose qpos and qvel are still bit-identical (fold_reuse, set by k_position)
+  FLAG_SNAPSHOT = 4   // forward(): record qpos / qvel next to the derived arrays (fold_valid = 1)
+};
+
 // ====================================================================================
 // Stage 1: position  (mj_kinematics, mj_comPos, mj_crb, mj_factorM)
 // ====================================================================================
@@ -448,11 +456,28 @@ __host__ __device__ inline int position_lds_floats(const mjlab_sizes_t& s) {
   return persistent + (kin > mat ? kin : mat);
 }
 
-__global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d, const int use_mask) {
+__global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
-  if (use_mask && !d.world_mask[w]) return;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ng = m.size.ngeom, ns = m.size.nsite;
+  if (flags & FLAG_FOLD) {
+    // The reference calls forward() on all worlds after resets and then, with a new action in
+    // ctrl, step() -- whose position, collision and constraint-build stages depend on qpos, qvel
+    // and the model only and would reproduce the forward pass bit for bit.  Where qpos and qvel
+    // still equal the snapshot taken by forward(), those three stages are skipped
+    // ("forward folded into the next step"); velocity / actuation and the
+    // solve always run.
+    int reuse = 0;
+    if (d.fold_valid[w]) {
+      bool diff = false;
+      for (int i = lane; i < nq; i += 64) diff |= __float_as_int(d.qpos[(size_t)w * nq + i]) != __float_as_int(d.sh_qpos[(size_t)w * nq + i]);
+      for (int i = lane; i < nv; i += 64) diff |= __float_as_int(d.qvel[(size_t)w * nv + i]) != __float_as_int(d.sh_qvel[(size_t)w * nv + i]);
+      reuse = __ballot(diff) == 0ull;
+    }
+    if (lane == 0) d.fold_reuse[w] = reuse;
+    if (reuse) return;
+  }
   float* s_sub = smem;
   float* s_cinert = s_sub + 3 * nb;
   float* s_crb = s_cinert + 10 * nb;
@@ -822,10 +847,11 @@ __device__ __forceinline__ void make_frame(float* f9, const float* f6) {
 
 __host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) { return 12 * s.ngeom; }
 
-__global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d, const int use_mask) {
+__global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
-  if (use_mask && !d.world_mask[w]) return;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
   const int ng = m.size.ngeom, ncm = m.size.nconmax, npair = m.size.npair;
   float* s_gx = smem;
   float* s_gm = s_gx + 3 * ng;
@@ -961,10 +987,10 @@ __host__ __device__ inline int velocity_lds_floats(const mjlab_sizes_t& s) {
   return 2 * s.nv + 12 * s.nv + 10 * s.nbody + 24 * s.nbody;
 }
 
-__global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d, const int use_mask) {
+__global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
-  if (use_mask && !d.world_mask[w]) return;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt;
   float* s_qvel = smem;
   float* s_qact = s_qvel + nv;
@@ -1184,10 +1210,11 @@ __host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) {
   return s.nconmax + 2 * constraint_nlim(s) + CC_NROWS * 64;
 }
 
-__global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data d, const int use_mask) {
+__global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
-  if (use_mask && !d.world_mask[w]) return;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ncm = m.size.nconmax, njm = m.size.njmax;
   const int nlim = constraint_nlim(m.size);
   int* s_cadr = (int*)smem;                  // contact -> first efc row (or -1)
@@ -1719,11 +1746,11 @@ __device__ __forceinline__ float constraint_cost(const float* s_jar, const float
 enum { ST_SMOOTH = 0, ST_NEWTON = 1, ST_PREP_INTEGRATE = 2, ST_INTEGRATE = 3 };
 
 template <int NVP>
-__global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate, const int use_mask) {
+__global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = CholCfg<NVP>::NB, ld = CholCfg<NVP>::LD;
   const int w = blockIdx.x, lane = threadIdx.x;
-  if (use_mask && !d.world_mask[w]) return;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
   const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
   SolveCtx<NVP> c;
   c.s_H = smem;
@@ -1992,7 +2019,18 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
       state = ST_PREP_INTEGRATE;
     }
   }
+  if (do_integrate && lane == 0) d.fold_valid[w] = 0;  // the state moved on
   PROF_FLUSH(d.profile + (size_t)w * 64);
+}
+
+// forward(): remember the qpos / qvel the pass was computed from (see FLAG_FOLD in k_position)
+__global__ __launch_bounds__(64) void k_fold_snapshot(const Model m, const Data d, const int flags) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  const int nq = m.size.nq, nv = m.size.nv;
+  for (int i = lane; i < nq; i += 64) d.sh_qpos[(size_t)w * nq + i] = d.qpos[(size_t)w * nq + i];
+  for (int i = lane; i < nv; i += 64) d.sh_qvel[(size_t)w * nv + i] = d.qvel[(size_t)w * nv + i];
+  if (lane == 0) d.fold_valid[w] = 1;
 }
 
 // ====================================================================================
@@ -2190,54 +2228,67 @@ static int check_model(const mjlab_model_t* m) {
     if (e_ != hipSuccess) return fail((int)e_, #kernel " launch failed");                                   \
   } while (0)
 
-static int launch_solve(const mjlab_model_t* m, const mjlab_data_t* d, int do_solve, int do_integrate, int use_mask, hipStream_t st) {
+static int launch_solve(const mjlab_model_t* m, const mjlab_data_t* d, int do_solve, int do_integrate, int flags, hipStream_t st) {
   const int lds = solve_lds_floats(m->size);
   switch (solve_nvp(m->size.nv)) {
-    case 8: LAUNCH(k_solve_integrate<8>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
-    case 16: LAUNCH(k_solve_integrate<16>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
-    case 20: LAUNCH(k_solve_integrate<20>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
-    case 24: LAUNCH(k_solve_integrate<24>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
-    case 32: LAUNCH(k_solve_integrate<32>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
-    case 36: LAUNCH(k_solve_integrate<36>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
-    case 40: LAUNCH(k_solve_integrate<40>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
-    case 48: LAUNCH(k_solve_integrate<48>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
-    case 64: LAUNCH(k_solve_integrate<64>, lds, *m, *d, do_solve, do_integrate, use_mask); break;
+    case 8: LAUNCH(k_solve_integrate<8>, lds, *m, *d, do_solve, do_integrate, flags); break;
+    case 16: LAUNCH(k_solve_integrate<16>, lds, *m, *d, do_solve, do_integrate, flags); break;
+    case 20: LAUNCH(k_solve_integrate<20>, lds, *m, *d, do_solve, do_integrate, flags); break;
+    case 24: LAUNCH(k_solve_integrate<24>, lds, *m, *d, do_solve, do_integrate, flags); break;
+    case 32: LAUNCH(k_solve_integrate<32>, lds, *m, *d, do_solve, do_integrate, flags); break;
+    case 36: LAUNCH(k_solve_integrate<36>, lds, *m, *d, do_solve, do_integrate, flags); break;
+    case 40: LAUNCH(k_solve_integrate<40>, lds, *m, *d, do_solve, do_integrate, flags); break;
+    case 48: LAUNCH(k_solve_integrate<48>, lds, *m, *d, do_solve, do_integrate, flags); break;
+    case 64: LAUNCH(k_solve_integrate<64>, lds, *m, *d, do_solve, do_integrate, flags); break;
     default: return fail(-3, "nv must be in [1, 64]");
   }
   return 0;
 }
 
-static int forward_stages_impl(const mjlab_model_t* m, const mjlab_data_t* d, int stages, int use_mask, void* stream) {
+static int forward_stages_impl(const mjlab_model_t* m, const mjlab_data_t* d, int stages, int flags, void* stream) {
   int rc = check_model(m);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (stages & MJLAB_STAGE_POSITION) LAUNCH(k_position, position_lds_floats(m->size), *m, *d, use_mask);
-  if (stages & MJLAB_STAGE_COLLISION) LAUNCH(k_collision, collision_lds_floats(m->size), *m, *d, use_mask);
-  if (stages & MJLAB_STAGE_VELOCITY) LAUNCH(k_velocity, velocity_lds_floats(m->size), *m, *d, use_mask);
-  if (stages & MJLAB_STAGE_CONSTRAINT) LAUNCH(k_constraint, constraint_lds_floats(m->size), *m, *d, use_mask);
+  if (stages & MJLAB_STAGE_POSITION) LAUNCH(k_position, position_lds_floats(m->size), *m, *d, flags);
+  if (stages & MJLAB_STAGE_COLLISION) LAUNCH(k_collision, collision_lds_floats(m->size), *m, *d, flags);
+  if (stages & MJLAB_STAGE_VELOCITY) LAUNCH(k_velocity, velocity_lds_floats(m->size), *m, *d, flags);
+  if (stages & MJLAB_STAGE_CONSTRAINT) LAUNCH(k_constraint, constraint_lds_floats(m->size), *m, *d, flags);
   if (stages & (MJLAB_STAGE_SOLVE | MJLAB_STAGE_INTEGRATE)) {
-    rc = launch_solve(m, d, (stages & MJLAB_STAGE_SOLVE) != 0, (stages & MJLAB_STAGE_INTEGRATE) != 0, use_mask, st);
+    rc = launch_solve(m, d, (stages & MJLAB_STAGE_SOLVE) != 0, (stages & MJLAB_STAGE_INTEGRATE) != 0, flags, st);
     if (rc) return rc;
   }
+  if (flags & FLAG_SNAPSHOT) LAUNCH(k_fold_snapshot, 0, *m, *d, flags);
   return 0;
 }
 
+// process-wide switch for "forward folded into the next step" (default on)
+static int g_fold = 1;
+int mjlab_set_fold(int enable) {
+  const int old = g_fold;
+  g_fold = enable != 0;
+  return old;
+}
+
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream) {
+  // stage-by-stage execution (testing / profiling) leaves the derived arrays in a state the fold
+  // bookkeeping does not describe: drop it
+  if (hipMemsetAsync(d->fold_valid, 0, sizeof(int) * (size_t)m->size.nworld, (hipStream_t)stream) != hipSuccess)
+    return fail(-18, "forward_stages: memset failed");
   return forward_stages_impl(m, d, stages, 0, stream);
 }
 
 int mjlab_forward_masked(const mjlab_model_t* m, const mjlab_data_t* d, void* stream) {
-  return forward_stages_impl(m, d, MJLAB_STAGE_FORWARD, 1, stream);
+  return forward_stages_impl(m, d, MJLAB_STAGE_FORWARD, FLAG_MASK | FLAG_SNAPSHOT, stream);
 }
 
 int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream) {
-  return mjlab_forward_stages(m, d, MJLAB_STAGE_FORWARD, stream);
+  return forward_stages_impl(m, d, MJLAB_STAGE_FORWARD, FLAG_SNAPSHOT, stream);
 }
 
 int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void* stream) {
   if (nsubstep < 1) return fail(-8, "nsubstep must be >= 1");
   for (int k = 0; k < nsubstep; ++k) {
-    int rc = mjlab_forward_stages(m, d, MJLAB_STAGE_STEP, stream);
+    int rc = forward_stages_impl(m, d, MJLAB_STAGE_STEP, (k == 0 && g_fold) ? FLAG_FOLD : 0, stream);
     if (rc) return rc;
   }
   return 0;

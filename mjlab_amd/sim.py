@@ -77,6 +77,9 @@ class SimulationCfg:
   ls_parallel: bool = True  # accepted for parity; the line search here is the exact (iterative) one
   mujoco: MujocoCfg = field(default_factory=MujocoCfg)
   use_graph: bool = True
+  # step() right after forward() skips the stages that would reproduce that pass bit for bit
+  # (include/mjlab_amd.h, mjlab_forward); False recomputes them like the reference does
+  fold_forward: bool = True
 
 
 def check_supported(model: Model) -> None:
@@ -169,6 +172,7 @@ class Simulation:
     self._mj_model = model
     self._mj_data = HostData(model)
     self._lib = native.lib()
+    self._lib.mjlab_set_fold(1 if cfg.fold_forward else 0)
     mf, df, MS, DS = native.layouts()
     self._mfields = {f.name: f for f in mf}
     self._dfields = {f.name: f for f in df}
@@ -214,7 +218,9 @@ class Simulation:
       self._data["act"] = torch.zeros((num_envs, int(getattr(model, "na", 0))), dtype=torch.float32, device=dev)
 
     scalars = {k: int(getattr(model, k)) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata")}
-    self._model_bridge = Bridge("sim.model", self._model_view, {**scalars, "opt": model.opt, "nworld": num_envs})
+    self._expanded: set[str] = set()
+    self._model_bridge = Bridge("sim.model", self._model_view, {**scalars, "opt": model.opt, "nworld": num_envs},
+                                on_access=self._on_model_access)
     self._data_bridge = Bridge("sim.data", self._data, {"nworld": num_envs, "njmax": self.njmax, "nconmax": self.nconmax})
 
     self.use_graph = bool(cfg.use_graph) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
@@ -224,6 +230,13 @@ class Simulation:
     self.create_graph()
 
   # ------------------------------------------------------------------ helpers
+  def _on_model_access(self, name: str) -> None:
+    """A per-world (expanded) model field handed out may be written through (domain
+    randomisation): the last forward pass no longer describes the model, so the next step must
+    not reuse it.  Shared fields are read-only broadcasts and do not matter."""
+    if name in self._expanded:
+      self._data["fold_valid"].zero_()
+
   @staticmethod
   def _shape_view(f: _abi.FieldSpec, flat: torch.Tensor, n: int) -> torch.Tensor:
     nw = flat.shape[0]
@@ -328,9 +341,11 @@ class Simulation:
         )
         self._model_base[name] = dst
         self._model_view[name] = dst
+        self._expanded.add(name)
         if name in self._mfields:
           setattr(self._m, name, dst.data_ptr())
           setattr(self._m, name + "_ws", int(nelem))
+      self._data["fold_valid"].zero_()
       # pointers changed: captured graphs are stale (the reference re-captures too:
       # envs/manager_based_rl_env.py:102-104)
       self.step_graph = None

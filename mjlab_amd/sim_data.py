@@ -18,14 +18,18 @@ import torch
 
 
 class Bridge:
-  def __init__(self, kind: str, tensors: dict[str, torch.Tensor], scalars: dict[str, Any] | None = None) -> None:
+  def __init__(self, kind: str, tensors: dict[str, torch.Tensor], scalars: dict[str, Any] | None = None,
+               on_access: Any = None) -> None:
     object.__setattr__(self, "_kind", kind)
     object.__setattr__(self, "_tensors", tensors)
     object.__setattr__(self, "_scalars", scalars or {})
+    object.__setattr__(self, "_on_access", on_access)
 
   def __getattr__(self, name: str) -> Any:
     t = self._tensors.get(name)
     if t is not None:
+      if self._on_access is not None:
+        self._on_access(name)  # the caller may be about to write through the returned tensor
       return t
     if name in self._scalars:
       return self._scalars[name]

@@ -427,3 +427,53 @@ def test_long_horizon_stability(name, stand_steps, min_z):
   assert float((z[2000] - z[1500]).abs().median()) < 5e-3  # at rest at the end (standing or lying)
   assert float(sim.data.qvel.abs().median()) < 0.05
   assert float(sim.data.time[0]) == pytest.approx(2000 * model.opt.timestep, rel=1e-4)
+
+
+def test_forward_folded_into_next_step_is_bit_exact():
+  """step() right after forward() skips the position / collision / constraint-build stages of every
+  world whose qpos and qvel are bit-identical to what forward() saw (include/mjlab_amd.h);
+  results equal a full recomputation bit for bit; a changed state or a touched per-world model
+  field makes the world recompute."""
+  import torch
+
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  src, _, model = _rollout_state("g1_velocity_flat", nworld=512, steps=6)
+  out = {}
+  for fold in (True, False):
+    s = Simulation(512, SimulationCfg(njmax=300, use_graph=fold, fold_forward=fold), model, "cuda:0")
+    s.expand_model_fields(["geom_friction"])
+    s.create_graph()
+    _clone_into(s, src)
+    s.forward()
+    assert int(s.data.fold_valid.sum()) == 512
+    s.data.ctrl[:] += 0.02          # a new action, like the env writes before stepping
+    s.data.qvel[:100, 7] += 0.01    # worlds 0..99: the state itself changed after forward()
+    s.step()
+    s.step()
+    torch.cuda.synchronize()
+    assert int(s.data.fold_valid.sum()) == 0
+    out[fold] = {f: getattr(s.data, f).clone() for f in OUT + ("efc_J", "efc_aref", "nefc", "ncon")}
+    if fold:
+      _clone_into(s, src)
+      s.forward()
+      s.step()
+      torch.cuda.synchronize()
+      reuse = s.data.fold_reuse.clone()
+      assert int(reuse.sum()) == 512  # nothing but ctrl could have changed: all worlds reuse
+      _clone_into(s, src)
+      s.forward()
+      s.data.qvel[:100, 7] += 0.01
+      s.step()
+      torch.cuda.synchronize()
+      assert int(s.data.fold_reuse[:100].sum()) == 0 and int(s.data.fold_reuse[100:].sum()) == 412
+      _clone_into(s, src)
+      s.forward()
+      s.model.geom_friction[100:150, :, 0] *= 1.0  # touching an expanded field is enough
+      assert int(s.data.fold_valid.sum()) == 0
+      s.step()
+      torch.cuda.synchronize()
+      assert int(s.data.fold_reuse.sum()) == 0
+  for f in out[True]:
+    assert torch.equal(out[True][f], out[False][f]), f
+  Simulation(1, SimulationCfg(), model, "cuda:0")  # restore the process-wide default (fold on)
