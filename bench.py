@@ -107,8 +107,8 @@ def main() -> None:
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
   native.lib()  # fail loudly if the HIP extension is missing
-  dev = f"cuda:{info.local_rank}"
-  torch.cuda.set_device(info.local_rank)
+  dev = f"cuda:{mdist.device_index(info)}"
+  torch.cuda.set_device(mdist.device_index(info))
 
   model = robots.load_model(args.scene)
   sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph, fold_forward=not args.no_fold), model, dev)

@@ -42,11 +42,15 @@ def init_from_env(envs_per_rank: int, backend: str | None = None) -> ShardInfo:
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if world_size > 1 and not dist.is_initialized():
     if backend is None:
-      backend = "nccl" if torch.cuda.is_available() else "gloo"
+      # MJLAB_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
+      # ranks (several ranks share a device; RCCL refuses that)
+      backend = os.environ.get("MJLAB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend == "nccl":
       torch.cuda.set_device(local_rank)
+    elif torch.cuda.is_available():
+      torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
   return ShardInfo(rank, world_size, local_rank, envs_per_rank)
 
@@ -54,6 +58,12 @@ def init_from_env(envs_per_rank: int, backend: str | None = None) -> ShardInfo:
 def seed_for_rank(seed: int, info: ShardInfo) -> int:
   """Rank r uses seed + r."""
   return seed + info.rank
+
+
+def device_index(info: ShardInfo) -> int:
+  """CUDA device of this rank: local_rank, wrapped when ranks outnumber devices (gloo testing)."""
+  n = torch.cuda.device_count()
+  return info.local_rank % n if n else 0
 
 
 def gather_rollout(info: ShardInfo, rows: torch.Tensor) -> torch.Tensor:
