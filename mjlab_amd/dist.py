@@ -66,6 +66,9 @@ def device_index(info: ShardInfo) -> int:
   return info.local_rank % n if n else 0
 
 
+_GATHER_BUF: dict = {}  # receive buffers, reused across control steps (the result is valid until the next call)
+
+
 def gather_rollout(info: ShardInfo, rows: torch.Tensor) -> torch.Tensor:
   """All-gather per-env rows ``(envs_per_rank, k)`` into ``(global_envs, k)`` in rank order.
 
@@ -74,7 +77,10 @@ def gather_rollout(info: ShardInfo, rows: torch.Tensor) -> torch.Tensor:
   """
   if info.world_size == 1:
     return rows
-  out = torch.empty((info.global_envs, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+  key = (rows.shape[1], rows.dtype, rows.device)
+  out = _GATHER_BUF.get(key)
+  if out is None or out.shape[0] != info.global_envs:
+    out = _GATHER_BUF[key] = torch.empty((info.global_envs, rows.shape[1]), dtype=rows.dtype, device=rows.device)
   dist.all_gather_into_tensor(out, rows.contiguous())
   return out
 

@@ -45,6 +45,7 @@ class PhysicsRollout:
     self.fused_reset = fused_reset
     n = sim.num_envs
     self._graph: torch.cuda.CUDAGraph | None = None
+    self._obs_buf: torch.Tensor | None = None
     # start at random episode phase like the reference (train.py:109-111 init_at_random_ep_len)
     self.episode_length = torch.randint(0, self.max_len, (n,), device=dev, generator=self.gen).to(torch.int32)
     self._reset_mask = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -150,7 +151,11 @@ class PhysicsRollout:
     parts = [d.qvel, d.qpos[:, 7:] if self.has_free else d.qpos, d.ctrl, d.sensordata]
     if self.has_free:
       parts.append(d.qpos[:, 3:7])
-    return torch.cat(parts, dim=1)
+    if self._obs_buf is None:
+      self._obs_buf = torch.cat(parts, dim=1)
+    else:
+      torch.cat(parts, dim=1, out=self._obs_buf)  # no allocation in the steady state
+    return self._obs_buf
 
 
 def g1_action_scale(model: Model) -> np.ndarray:
