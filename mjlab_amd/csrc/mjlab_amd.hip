@@ -9,13 +9,24 @@
 //
 // Execution model: ONE WORLD (environment) PER WAVEFRONT.  A workgroup is a single
 // 64-lane wave, so every stage kernel launches `nworld` workgroups; with 4096 worlds that
-// is 16 waves per CU on the 256 CUs of an MI355X, all resident at once when a stage keeps
-// its LDS footprint at or below ~10 KB.  Inside a wave, lanes own tree nodes (bodies of one
-// depth level), dofs, candidate geom pairs, constraint rows or matrix rows, depending on
-// the stage.  Public mjData arrays are [nworld][n] row-major, so "lanes = elements of one
-// world's row" gives coalesced HBM traffic; intermediates that never leave a stage live in
-// LDS or registers.  The only GEMM-shaped work -- the Newton Hessian H = M + J^T D J -- is
-// streamed row-major from L2 straight into fp32 MFMA (v_mfma_f32_16x16x4_f32) operands.
+// is 16 waves per CU on the 256 CUs of an MI355X, all resident at once: every stage keeps
+// its LDS footprint at or below 10 KB and its registers at or below 128 (4 waves per SIMD).
+// Inside a wave, lanes own bodies (one per lane in the tree sweeps), dofs, candidate geom
+// pairs, contacts, constraint rows or matrix rows, depending on the stage.  Public mjData
+// arrays are [nworld][n] row-major, so "lanes = elements of one world's row" gives coalesced
+// HBM traffic; intermediates that never leave a stage live in LDS or registers.  The only
+// GEMM-shaped work -- the Newton Hessian H = M + J^T D J over the ACTIVE constraint rows --
+// is streamed row-major from L2 straight into fp32 MFMA (v_mfma_f32_16x16x4_f32) operands.
+//
+// Five stage kernels per physics step:
+//   k_position    kinematics, comPos, crb, dense M           (skipped after an unchanged forward())
+//   k_collision   static pair list, analytic primitives       (   "   )
+//   k_velocity    comVel, rne, actuation, qfrc_smooth
+//   k_constraint  limits + contacts -> efc rows, sensors      (   "   )
+//   k_solve_integrate<NVP>  Newton solver (LDL^T in registers/LDS, exact line search),
+//                 implicitfast / Euler integration; a state machine around one factor site
+// plus helpers: k_tile (expand_model_fields), k_fold_snapshot, k_masked_reset,
+// k_entity_readback.
 //
 // All arithmetic is fp32 (like the reference's Warp kernels); ids are int32.
 
