@@ -371,3 +371,52 @@ def test_capacity_paths_with_hundreds_of_contacts(njmax):
     jo = np.minimum(ora.efc_J[w].reshape(-1, nv)[:n] @ ora.qacc[w] - ora.efc_aref[w, :n], 0)
     cost_o = 0.5 * da @ Mo @ da + 0.5 * np.sum(ora.efc_D[w, :n] * jo * jo)
     assert float(cost_gpu[w]) <= cost_o * 1.05 + 1e-6, (w, float(cost_gpu[w]), cost_o)
+
+
+@pytest.mark.parametrize("variant", ["impratio", "direct_solref", "margin_gap", "solimp_power", "euler_damped"])
+def test_parameter_branches_match_oracle(variant):
+  """Less-travelled branches of the constraint parameter code (impratio scaling of the pyramid
+  regulariser, negative solref = direct stiffness/damping, geom margin/gap, solimp power != 2,
+  Euler with implicit joint damping) on the model that has every primitive and joint type."""
+  import copy
+
+  import torch
+
+  from mjlab_amd import mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = copy.deepcopy(models()["mixed"])
+  if variant == "impratio":
+    model.opt.impratio = 4.0
+  elif variant == "direct_solref":
+    model.geom_solref = np.tile(np.array([-800.0, -40.0]), (model.ngeom, 1))
+    model.jnt_solref = np.tile(np.array([-500.0, -30.0]), (model.njnt, 1))
+  elif variant == "margin_gap":
+    model.geom_margin = np.full_like(model.geom_margin, 0.02)
+    model.geom_gap = np.full_like(model.geom_gap, 0.005)
+  elif variant == "solimp_power":
+    model.geom_solimp = np.tile(np.array([0.8, 0.97, 0.01, 0.3, 3.0]), (model.ngeom, 1))
+  elif variant == "euler_damped":
+    model.opt.integrator = mjcf.INT_EULER
+    model.dof_damping = np.where(np.arange(model.nv) >= model.nv - 2, 0.8, 0.0)
+  nworld = 8
+  qpos, qvel, ctrl = golden_inputs(model, nworld, 23)
+  sim = Simulation(nworld, SimulationCfg(njmax=64, use_graph=False), model, "cuda:0")
+  ora = OracleSim(model, nworld, njmax=64, precision="f64")
+  for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+    getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+    getattr(ora, f)[:] = v
+  sim.forward()
+  ora.forward()
+  assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
+  assert ora.nefc.max() >= 3
+  for w in range(nworld):
+    n = int(ora.nefc[w, 0])
+    for f in ("efc_D", "efc_aref", "efc_pos", "efc_margin"):
+      assert _rel(_np(getattr(sim.data, f))[w, :n], getattr(ora, f)[w, :n]) < 2e-4, (variant, f)
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
+  for _ in range(5):
+    sim.step()
+  ora.step(5)
+  assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-5
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 2e-3
