@@ -71,6 +71,13 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 // ------------------------------------------------------------------------------------
 // wave-level helpers (wave = 64 lanes)
 // ------------------------------------------------------------------------------------
+// Hides a per-lane index from the optimiser at the point of use: global addresses derived from it
+// are then formed where they are needed instead of being hoisted to the top of a long kernel and
+// kept alive (spilled) across all of it.
+__device__ __forceinline__ int launder(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 __device__ __forceinline__ float lane_bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
@@ -130,6 +137,7 @@ __device__ __forceinline__ void global_to_lds(float* dst, const float* src, int 
 // (leading dimension ld); lanes walk consecutive global elements, (i, j) tracked without
 // integer division.
 __device__ __forceinline__ void dense_global_to_lds(float* dst, const float* src, int n, int ld, int lane, bool lower_only) {
+  lane = launder(lane);
   int i = 0, j = lane;
   while (j >= n) { j -= n; ++i; }
   for (int k = lane; k < n * n; k += 64) {
@@ -1497,9 +1505,12 @@ __device__ __forceinline__ void gather16(float x, float (&x16)[NB], int lane) {
 }
 template <int NB>
 __device__ __forceinline__ float pick16(const float (&v)[NB], int lane) {
+  // a chain of v_cndmask; the index is re-laundered per step because the optimiser otherwise turns
+  // the chain into a per-lane indexed load from a scratch copy of v[] (a memory round trip in
+  // the middle of every Newton iteration)
   float r = v[0];
 #pragma unroll
-  for (int cb = 1; cb < NB; ++cb) r = ((lane >> 4) == cb) ? v[cb] : r;
+  for (int cb = 1; cb < NB; ++cb) r = (launder(lane >> 4) == cb) ? v[cb] : r;
   return r;
 }
 
@@ -1514,7 +1525,7 @@ constexpr int JU = MJLAB_JU;  // 4-row groups per unrolled block
 template <int NVP, bool TWO>
 __device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x16)[CholCfg<NVP>::NB], const float (&y16)[CholCfg<NVP>::NB], float* out, float* out2) {
   constexpr int NB = CholCfg<NVP>::NB;
-  const int sub = c.lane >> 4, col = c.lane & 15;
+  const int sub = c.lane >> 4, col = launder(c.lane & 15);
   for (int r0 = 0; r0 < c.nefc; r0 += 4 * JU) {
     float jv[JU][NB];
 #pragma unroll
@@ -1574,7 +1585,7 @@ __device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&a
   }
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) jtf[cb] = 0.f;
-  const int sub = c.lane >> 4, col = c.lane & 15;
+  const int sub = c.lane >> 4, col = launder(c.lane & 15);
   for (int k0 = 0; k0 < nact; k0 += 4 * JU) {
     float x[JU][NB], dact[JU], f[JU];
 #pragma unroll
@@ -1797,7 +1808,11 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     state = ST_SMOOTH;
     PROF_MARK(0);
   } else {
-    if (own) { qacc = d.qacc[wv]; fc = d.qfrc_constraint[wv]; }
+    if (own) {
+      const size_t wve = (size_t)w * nv + launder(lane);
+      qacc = d.qacc[wve];
+      fc = d.qfrc_constraint[wve];
+    }
     state = ST_PREP_INTEGRATE;
   }
 
@@ -1807,7 +1822,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
       // s_H = M + h * diag(-d qfrc_smooth / d qvel), rhs = qfrc_smooth + J^T f
       if (!do_integrate) break;
       // diagonal of -d(qfrc_smooth)/d(qvel): dof damping (+ actuator velocity gains for implicitfast)
-      float diag = own ? MF(dof_damping)[lane] : 0.f;
+      float diag = own ? MF(dof_damping)[launder(lane)] : 0.f;
       bool need = diag > 0.f;
       if (m.opt.integrator == MJLAB_INT_IMPLICITFAST) {
         // d(qfrc_actuator)/d(qvel) of the affine-bias actuators: lanes = actuators, scattered
@@ -1858,8 +1873,9 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     if (state == ST_INTEGRATE) {
       // velocity / position update with acceleration x (mj_Euler / mj_implicit tail)
       if (own) {
-        const float qv = d.qvel[wv] + h * x;
-        d.qvel[wv] = qv;
+        const size_t wvi = (size_t)w * nv + launder(lane);
+        const float qv = d.qvel[wvi] + h * x;
+        d.qvel[wvi] = qv;
         s_vec[lane] = qv;
       }
       __syncthreads();
@@ -1889,14 +1905,15 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     if (state == ST_SMOOTH) {
       qas = x;
       __syncthreads();
-      if (own) d.qacc_smooth[wv] = qas;
+      const size_t wvs = (size_t)w * nv + launder(lane);
+      if (own) d.qacc_smooth[wvs] = qas;
       if (nefc == 0) {
         qacc = qas;
         finished = true;
       } else {
-        for (int r = lane; r < nefc; r += 64) c.s_D[r] = d.efc_D[wr + r];
+        for (int r = launder(lane); r < nefc; r += 64) c.s_D[r] = d.efc_D[wr + r];
         // ---- warmstart: better of qacc_warmstart and qacc_smooth
-        const float ws = own ? d.qacc_warmstart[wv] : 0.f;
+        const float ws = own ? d.qacc_warmstart[wvs] : 0.f;
         {
           float x16[NB], y16[NB];
           gather16<NB>(ws, x16, lane);
@@ -1904,7 +1921,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
           jac_mul<NVP, true>(c, x16, y16, c.s_jar, c.s_jv);
         }
         __syncthreads();
-        for (int r = lane; r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
+        for (int r = launder(lane); r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
         __syncthreads();
         const float Ma_ws = symm_mul_global<NVP>(c.M, nv, ws, lane);
         const float cost_ws = constraint_cost(c.s_jar, c.s_D, nefc, lane) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
@@ -2017,14 +2034,15 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
     }
     if (finished) {  // publish the solve, then hand over to the integrator
       if (lane == 0) d.solver_niter[w] = iter;
-      for (int r = lane; r < nefc; r += 64) {
+      for (int r = launder(lane); r < nefc; r += 64) {
         const float xr = c.s_jar[r];
         d.efc_force[wr + r] = xr < 0.f ? -c.s_D[r] * xr : 0.f;
       }
       if (own) {
-        d.qacc[wv] = qacc;
-        d.qacc_warmstart[wv] = qacc;
-        d.qfrc_constraint[wv] = fc;
+        const size_t wvp = (size_t)w * nv + launder(lane);
+        d.qacc[wvp] = qacc;
+        d.qacc_warmstart[wvp] = qacc;
+        d.qfrc_constraint[wvp] = fc;
       }
       PROF_MARK(8);
       state = ST_PREP_INTEGRATE;
