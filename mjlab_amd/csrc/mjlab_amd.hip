@@ -782,6 +782,16 @@ __global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d,
 // Stage 2: collision (static candidate pair list; plane/sphere/capsule/box primitives)
 // ====================================================================================
 struct RawCon { float dist, pos[3], frame[6]; };
+// dst = take ? src : dst, field by field (v_cndmask).  Contact slots are filled through VALUE
+// selects with compile-time slot indices: a conditional store to `slot[n]` makes the compiler keep
+// the whole slot array in scratch memory.
+__device__ __forceinline__ void rc_take(RawCon& dst, const RawCon& src, bool take) {
+  dst.dist = take ? src.dist : dst.dist;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dst.pos[k] = take ? src.pos[k] : dst.pos[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dst.frame[k] = take ? src.frame[k] : dst.frame[k];
+}
 
 __device__ __forceinline__ int plane_sphere(RawCon* c, float margin, const float* ppos, const float* pn, const float* spos, float r) {
   float dif[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
@@ -823,10 +833,9 @@ __device__ __forceinline__ int capsule_capsule(RawCon* c, float margin, const fl
   int n = 0;
   RawCon t;
   auto push = [&](bool ok) {
-    if (ok) {
-      if (n == 0) c[0] = t; else if (n == 1) c[1] = t;
-      ++n;
-    }
+    rc_take(c[0], t, ok && n == 0);
+    rc_take(c[1], t, ok && n == 1);
+    n += ok ? 1 : 0;
   };
   float x1, x2;
   for (int k = 0; k < 3; ++k) vec1[k] = pos1[k] + axis1[k] * size1[1];
@@ -907,13 +916,16 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
           float q[3];
           RawCon t;
           for (int k = 0; k < 3; ++k) q[k] = p2[k] + z2[k] * s2[1];
-          if (plane_sphere(&t, margin, p1, z1, q, s2[0])) { for (int k = 0; k < 3; ++k) t.frame[3 + k] = z2[k]; rc[0] = t; n = 1; }
+          bool hit = plane_sphere(&t, margin, p1, z1, q, s2[0]) != 0;
+          for (int k = 0; k < 3; ++k) t.frame[3 + k] = z2[k];
+          rc_take(rc[0], t, hit);
+          n = hit ? 1 : 0;
           for (int k = 0; k < 3; ++k) q[k] = p2[k] - z2[k] * s2[1];
-          if (plane_sphere(&t, margin, p1, z1, q, s2[0])) {
-            for (int k = 0; k < 3; ++k) t.frame[3 + k] = z2[k];
-            if (n == 0) rc[0] = t; else rc[1] = t;
-            n++;
-          }
+          hit = plane_sphere(&t, margin, p1, z1, q, s2[0]) != 0;
+          for (int k = 0; k < 3; ++k) t.frame[3 + k] = z2[k];
+          rc_take(rc[0], t, hit && n == 0);
+          rc_take(rc[1], t, hit && n == 1);
+          n += hit ? 1 : 0;
         } else if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_BOX) {
           const float dist = dot3(dif, z1);
           float bm[9];
@@ -929,7 +941,7 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
               t.pos[k] = corner[k] + p2[k] + z1[k] * (-t.dist * 0.5f);
               t.frame[k] = z1[k]; t.frame[3 + k] = 0.f;
             }
-            if (n == 0) rc[0] = t; else if (n == 1) rc[1] = t; else if (n == 2) rc[2] = t; else rc[3] = t;
+            rc_take(rc[0], t, n == 0); rc_take(rc[1], t, n == 1); rc_take(rc[2], t, n == 2); rc_take(rc[3], t, n == 3);
             n++;
           }
         } else if (t1 == MJLAB_GEOM_SPHERE && t2 == MJLAB_GEOM_SPHERE) {
@@ -973,10 +985,9 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
         for (int k = 0; k < 5; ++k) solimp[k] = mix * gsolimp[5 * g1 + k] + (1.f - mix) * gsolimp[5 * g2 + k];
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i >= n) break;
+      for (int i = 0; i < 4; ++i) {  // no early exit: rc[i] must stay a compile-time index (registers, not scratch)
         const int c = base + off + i;
-        if (c >= ncm) break;
+        if (i >= n || c >= ncm) continue;
         float f9[9];
         make_frame(f9, rc[i].frame);
         const size_t wc = (size_t)w * ncm + c;
