@@ -1,0 +1,67 @@
+"""Box-terrain generator vs the boxes recorded from the reference's own generator code
+(tests/golden/terrain_reference.npz, made by tools/make_terrain_golden.py)."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from mjlab_amd import terrains
+
+GOLD = Path(__file__).parent / "golden" / "terrain_reference.npz"
+
+
+@pytest.fixture(scope="module")
+def gold():
+  with np.load(GOLD) as z:
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("case", ["curriculum_10x20_seed0", "random_3x5_seed7", "curriculum_2x3_seed1"])
+def test_boxes_and_origins_match_reference_generator(gold, case):
+  seed, curriculum, rows, cols = (int(v) for v in gold[case + "/cfg"])
+  cfg = terrains.rough_terrains_cfg(seed=seed, curriculum=bool(curriculum), num_rows=rows, num_cols=cols)
+  t = terrains.TerrainGenerator(cfg).generate()
+  ref = gold[case + "/boxes"]
+  assert t.boxes.shape == ref.shape
+  np.testing.assert_allclose(t.boxes, ref, rtol=0, atol=1e-12)
+  np.testing.assert_allclose(t.origins, gold[case + "/origins"], rtol=0, atol=1e-12)
+
+
+def test_rough_cfg_counts():
+  t = terrains.TerrainGenerator(terrains.rough_terrains_cfg(seed=0)).generate()
+  # 8 flat columns x 10 rows (1 slab each) + 12 stair columns x 10 rows x (4 border + 6 rings x 4 + 1) + 4 outer border
+  assert len(t.boxes) == 80 + 120 * 29 + 4
+  assert (t.boxes[:, 3:] > 0).all()
+  # the outer border encloses the grid: 80 x 160 m of sub-terrains + 20 m on every side
+  lo = (t.boxes[:, :3] - t.boxes[:, 3:]).min(axis=0)
+  hi = (t.boxes[:, :3] + t.boxes[:, 3:]).max(axis=0)
+  np.testing.assert_allclose(lo[:2], [-60.0, -100.0])
+  np.testing.assert_allclose(hi[:2], [60.0, 100.0])
+
+
+def test_spawn_origin_sits_on_top_of_a_box():
+  t = terrains.TerrainGenerator(terrains.rough_terrains_cfg(seed=3, num_rows=4, num_cols=6)).generate()
+  for o in t.origins.reshape(-1, 3):
+    inside = np.all(np.abs(t.boxes[:, :2] - o[:2]) <= t.boxes[:, 3:5], axis=1)
+    top = (t.boxes[inside, 2] + t.boxes[inside, 5]).max()
+    assert abs(top - o[2]) < 1e-9
+
+
+def test_env_origins():
+  rng = np.random.default_rng(0)
+  origins = np.arange(10 * 20 * 3, dtype=np.float64).reshape(10, 20, 3)
+  eo, levels, types = terrains.env_origins_curriculum(4096, origins, 5, rng)
+  assert eo.shape == (4096, 3) and levels.max() <= 5 and levels.min() == 0
+  # types are spread evenly over the columns in env order (terrain_importer.py:222-226)
+  assert np.array_equal(types, np.arange(4096) * 20 // 4096)
+  np.testing.assert_array_equal(eo, origins[levels, types])
+  g = terrains.env_origins_grid(16, 2.0)
+  assert g.shape == (16, 3) and np.allclose(g.mean(axis=0), 0) and np.isclose(np.ptp(g[:, 0]), 6.0)
+
+
+def test_seed_required():
+  cfg = terrains.rough_terrains_cfg(seed=0)
+  cfg.seed = None
+  with pytest.raises(ValueError):
+    terrains.TerrainGenerator(cfg)
