@@ -39,7 +39,9 @@ from mjlab_amd.rollout import PhysicsRollout, g1_action_scale, go1_action_scale 
 from mjlab_amd.sim import Simulation, SimulationCfg  # noqa: E402
 
 # compulsory HBM traffic of the public mjData contract, fp32
-ALGO_BYTES_PER_WORLD_STEP = {"g1_velocity_flat": 10156, "g1_tracking_flat": 10716, "go1_velocity_flat": 5672}
+# (rough: the G1 contract without the plane geom's pose -- terrain geoms are static, their poses are
+# written once at construction and are not per-step traffic)
+ALGO_BYTES_PER_WORLD_STEP = {"g1_velocity_flat": 10156, "g1_tracking_flat": 10716, "go1_velocity_flat": 5672, "g1_velocity_rough": 10108}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -58,6 +60,9 @@ def cpu_baseline(scene: str, seed: int) -> dict:
   best = None
   for nthread in sorted({cores, max(1, cores // 2)}, reverse=True):  # SMT siblings do not always help
     ora.reset(key=0)
+    if hasattr(model, "terrain_origins"):  # spread the worlds over the terrain tiles
+      o = np.asarray(model.terrain_origins)
+      ora.qpos[:, :3] += o[rng.integers(0, min(6, o.shape[0]), nworld), np.arange(nworld) * o.shape[1] // nworld]
     ora.forward(nthread=nthread)
     t0 = time.perf_counter()
     for _ in range(env_steps):
@@ -196,7 +201,7 @@ def main() -> None:
       except Exception as e:  # noqa: BLE001
         cpu = {"error": str(e)}
     out = {
-      "metric": f"env-steps/sec at num_envs={args.envs_per_gpu} per GPU, {'Unitree-G1' if args.scene.startswith('g1') else 'Unitree-Go1'} flat "
+      "metric": f"env-steps/sec at num_envs={args.envs_per_gpu} per GPU, {'Unitree-G1' if args.scene.startswith('g1') else 'Unitree-Go1'} {'rough (box terrain)' if args.scene.endswith('rough') else 'flat'} "
       "(physics hot path: 4 substeps + 1 forward per env-step)",
       "value": value,
       "unit": "env-steps/s",

@@ -112,13 +112,17 @@ int mjlab_entity_readback(const mjlab_model_t* m, const mjlab_data_t* d, const m
  * the state reset the reference performs with a chain of small torch kernels and a nonzero()
  * host sync (envs/manager_based_rl_env.py:121-132, envs/mdp/events.py:27-124,
  * tasks/velocity/velocity_env_cfg.py:136-144), as one launch without host involvement.
- * Per world: episode_length += 1; reset = non-finite qpos | root height < min_height (free
- * root only) | episode_length >= max_len.  Reset worlds get qpos = key_qpos with x, y +=
- * U(-0.5, 0.5) and yaw = U(-3.14, 3.14) from rnd3[w] in [0,1)^3, qvel = qacc_warmstart = 0,
- * episode_length = 0; the others keep their state with NaN -> 0 and +-inf -> +-FLT_MAX in qvel
- * and qacc_warmstart.  reset_mask[w] = 1 / 0 (it may alias d->world_mask). */
+ * Per world: episode_length += 1; reset = non-finite qpos | root height above the world's
+ * origin < min_height | world z of the root's up axis < min_up_z (free root only; pass -2 to
+ * switch the orientation test off) | episode_length >= max_len.  Reset worlds get qpos =
+ * key_qpos + env_origins[w] (NULL = no offset; the terrain spawn points of
+ * terrains/terrain_importer.py:196-229) with x, y += U(-0.5, 0.5) and yaw = U(-3.14, 3.14)
+ * from rnd3[w] in [0,1)^3, qvel = qacc_warmstart = 0, episode_length = 0; the others keep
+ * their state with NaN -> 0 and +-inf -> +-FLT_MAX in qvel and qacc_warmstart.
+ * reset_mask[w] = 1 / 0 (it may alias d->world_mask). */
 int mjlab_masked_reset(const mjlab_model_t* m, const mjlab_data_t* d, const float* key_qpos, const float* rnd3,
-                       int* episode_length, int max_len, float min_height, int* reset_mask, void* stream);
+                       int* episode_length, int max_len, float min_height, int* reset_mask, const float* env_origins,
+                       float min_up_z, void* stream);
 
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);

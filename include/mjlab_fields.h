@@ -53,7 +53,12 @@
   X(sensor_intprm, 3, nsensor)                                                  \
   X(sensor_dim, 1, nsensor)                                                     \
   X(sensor_adr, 1, nsensor)                                                     \
-  X(pair_geom, 2, npair)
+  X(pair_geom, 2, npair)                                                        \
+  X(tgeom, 1, ntgeom)         /* moving geoms that can touch the terrain, ascending */ \
+  X(tbox_geom, 1, nterrain)   /* geom id of terrain box i */                      \
+  X(tbox_cell0, 2, nterrain)  /* lowest grid cell (ix, iy) of the box footprint */ \
+  X(tgrid_start, 1, ntcellp1) /* cell c = ix * ny + iy lists tgrid_item[start[c] .. start[c+1]) */ \
+  X(tgrid_item, 1, ntitem)    /* terrain box indices, ascending inside a cell */
 
 /* ---- model: real; each carries a per-world stride (0 = shared, else elements) -- */
 #define MJLAB_MODEL_REAL_FIELDS(X)                                              \
@@ -93,7 +98,10 @@
   X(actuator_biasprm, 10, nu)                                                   \
   X(actuator_ctrlrange, 2, nu)                                                  \
   X(actuator_forcerange, 2, nu)                                                 \
-  X(actuator_gear, 6, nu)
+  X(actuator_gear, 6, nu)                                                       \
+  X(tbox_pos, 3, nterrain)  /* terrain boxes in the WORLD frame (static, never per world) */ \
+  X(tbox_mat, 9, nterrain)                                                      \
+  X(tbox_size, 3, nterrain)
 
 /* ---- data: real, leading dimension nworld ------------------------------------ */
 #define MJLAB_DATA_REAL_FIELDS(X)                                               \
@@ -179,7 +187,15 @@ typedef struct mjlab_sizes {
   int nworld;  /* number of worlds (environments) */
   int nconmax; /* contact capacity PER WORLD */
   int njmax;   /* constraint-row capacity PER WORLD */
+  /* static geometry: geoms [0, nstaticgeom) hang off the world (poses written once, at
+   * construction); the collision stage stages geoms [geom_lds0, ngeom) on chip */
+  int nstaticgeom, geom_lds0;
+  /* box terrain (static colliding boxes) and its uniform xy broadphase grid */
+  int nterrain, ntgeom, ntcellp1, ntitem, tgrid_nx, tgrid_ny;
 } mjlab_sizes_t;
+
+/* terrain boxes kept per moving geom and step: the MJLAB_TCAND_MAX with the smallest ids */
+#define MJLAB_TCAND_MAX 12
 
 /* mjOption subset (always double on the host side). */
 typedef struct mjlab_option {
@@ -189,6 +205,7 @@ typedef struct mjlab_option {
   double tolerance;
   double ls_tolerance;
   double meaninertia; /* mjModel.stat.meaninertia */
+  double tgrid_x0, tgrid_y0, tgrid_cell; /* terrain grid: origin (lowest corner) and cell edge */
   int iterations;
   int ls_iterations;
   int integrator;

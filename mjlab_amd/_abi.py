@@ -11,11 +11,12 @@ from __future__ import annotations
 import ctypes
 from dataclasses import dataclass
 
-from .mjcf import Model
+from .mjcf import TCAND_MAX, Model
 
 _SIZE_FIELDS = (
   "nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata", "npair",
   "nlevel", "nworld", "nconmax", "njmax",
+  "nstaticgeom", "geom_lds0", "nterrain", "ntgeom", "ntcellp1", "ntitem", "tgrid_nx", "tgrid_ny",
 )  # fmt: skip
 
 
@@ -31,6 +32,9 @@ class Option(ctypes.Structure):
     ("tolerance", ctypes.c_double),
     ("ls_tolerance", ctypes.c_double),
     ("meaninertia", ctypes.c_double),
+    ("tgrid_x0", ctypes.c_double),
+    ("tgrid_y0", ctypes.c_double),
+    ("tgrid_cell", ctypes.c_double),
     ("iterations", ctypes.c_int),
     ("ls_iterations", ctypes.c_int),
     ("integrator", ctypes.c_int),
@@ -88,6 +92,8 @@ def fill_sizes(m: Model, nworld: int, nconmax: int, njmax: int) -> Sizes:
   for n in _SIZE_FIELDS[:11]:
     setattr(s, n, int(getattr(m, n)))
   s.nworld, s.nconmax, s.njmax = nworld, nconmax, njmax
+  for n in _SIZE_FIELDS[14:]:
+    setattr(s, n, int(getattr(m, n)))
   return s
 
 
@@ -99,6 +105,7 @@ def fill_option(m: Model) -> Option:
   o.tolerance = m.opt.tolerance
   o.ls_tolerance = m.opt.ls_tolerance
   o.meaninertia = m.meaninertia
+  o.tgrid_x0, o.tgrid_y0, o.tgrid_cell = m.tgrid_x0, m.tgrid_y0, m.tgrid_cell
   o.iterations = m.opt.iterations
   o.ls_iterations = m.opt.ls_iterations
   o.integrator = m.opt.integrator
@@ -126,9 +133,9 @@ def default_capacities(m: Model, nconmax: int | None, njmax: int | None) -> tupl
   capacities are per world: ``njmax`` rows and ``njmax`` contacts (a contact yields at
   least one row), bounded by what the model can ever produce.
   """
-  max_rows = 2 * int((m.jnt_limited != 0).sum()) + 4 * 4 * m.npair
+  max_rows = 2 * int((m.jnt_limited != 0).sum()) + 4 * 4 * (m.npair + m.ntgeom * TCAND_MAX)
   if njmax is None:
     njmax = max(1, min(max_rows, 512))
   njmax = max(1, min(int(njmax), max(max_rows, 1)))
-  ncon = max(1, min(njmax, 4 * max(m.npair, 1)))
+  ncon = max(1, min(njmax, 4 * max(m.npair + m.ntgeom * TCAND_MAX, 1)))
   return ncon, njmax

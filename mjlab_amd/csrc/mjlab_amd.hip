@@ -613,7 +613,8 @@ __global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d,
     const float *gpos = MF(geom_pos), *gquat = MF(geom_quat);
     float* gx = d.geom_xpos + (size_t)w * 3 * ng;
     float* gm = d.geom_xmat + (size_t)w * 9 * ng;
-    for (int g = lane; g < ng; g += 64) {
+    // geoms of static bodies keep the poses written at construction (sizes.nstaticgeom)
+    for (int g = m.size.nstaticgeom + lane; g < ng; g += 64) {
       const int b = m.geom_bodyid[g];
       float bp[3], bq[4], bm[9], ip[3], iq[4], xp[3], xm[9];
       for (int k = 0; k < 3; ++k) { bp[k] = s_xpos[3 * b + k]; ip[k] = gpos[3 * g + k]; }
@@ -859,6 +860,143 @@ __device__ __forceinline__ int capsule_capsule(RawCon* c, float margin, const fl
   return n < 2 ? n : 2;
 }
 
+
+// Sphere vs (static) box: centre into the box frame, clamp; outside the normal runs along
+// clamped point -> centre, inside through the nearest face.  Normal points from the sphere
+// (geom1) into the box (geom2), pos midway between the surfaces.  bmat is row major (world =
+// bmat * local).
+__device__ __forceinline__ int sphere_box(RawCon* c, float margin, const float* spos, float r, const float* bpos, const float* bmat, const float* bsize) {
+  const float dif[3] = {spos[0] - bpos[0], spos[1] - bpos[1], spos[2] - bpos[2]};
+  float loc[3], dv[3], nl[3], pl[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) loc[i] = bmat[i] * dif[0] + bmat[3 + i] * dif[1] + bmat[6 + i] * dif[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dv[i] = loc[i] - clipf(loc[i], -bsize[i], bsize[i]);
+  const float d2 = dot3(dv, dv), mn = margin + r;
+  if (d2 > mn * mn) return 0;
+  if (d2 > 0.f) {
+    const float len = sqrtf(d2);
+    c->dist = len - r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { nl[i] = dv[i] / len; pl[i] = (loc[i] - dv[i]) + nl[i] * (c->dist * 0.5f); }
+  } else {
+    // centre inside the box: leave through the nearest face (first one on ties)
+    int k = 0;
+    float depth = bsize[0] - fabsf(loc[0]);
+#pragma unroll
+    for (int i = 1; i < 3; ++i) { const float di = bsize[i] - fabsf(loc[i]); if (di < depth) { depth = di; k = i; } }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nl[i] = (i == k) ? (loc[i] >= 0.f ? 1.f : -1.f) : 0.f;
+    c->dist = -depth - r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pl[i] = loc[i] + nl[i] * ((depth - r) * 0.5f);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    c->pos[i] = bpos[i] + bmat[3 * i] * pl[0] + bmat[3 * i + 1] * pl[1] + bmat[3 * i + 2] * pl[2];
+    c->frame[i] = -(bmat[3 * i] * nl[0] + bmat[3 * i + 1] * nl[1] + bmat[3 * i + 2] * nl[2]);
+    c->frame[3 + i] = 0.f;
+  }
+  return 1;
+}
+// d/dt of half the squared distance between pc + t h (box frame) and the box, and the squared distance
+__device__ __forceinline__ float seg_box_slope(const float* pc, const float* h, const float* bsize, float t) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const float p = pc[i] + t * h[i]; s += (p - clipf(p, -bsize[i], bsize[i])) * h[i]; }
+  return s;
+}
+__device__ __forceinline__ float seg_box_dist2(const float* pc, const float* h, const float* bsize, float t) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const float p = pc[i] + t * h[i], e = p - clipf(p, -bsize[i], bsize[i]); s += e * e; }
+  return s;
+}
+// Capsule vs box: up to 4 sphere_box() contacts of spheres of the capsule's radius on its axis
+// (point cpos + axis * halflen * t): the two ends, plus the ends ta <= tb of the interval where
+// the axis is closest to the box when they are interior points outside the box.  The distance
+// along the axis is convex, so its slope is monotone: ta / tb come from two bisections.
+#define MJLAB_CAPBOX_ITERS 24
+__device__ __forceinline__ int capsule_box(RawCon* c, float margin, const float* cpos, const float* axis, const float* csize, const float* bpos,
+                                           const float* bmat, const float* bsize) {
+  const float dif[3] = {cpos[0] - bpos[0], cpos[1] - bpos[1], cpos[2] - bpos[2]};
+  float pc[3], h[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    pc[i] = bmat[i] * dif[0] + bmat[3 + i] * dif[1] + bmat[6 + i] * dif[2];
+    h[i] = (bmat[i] * axis[0] + bmat[3 + i] * axis[1] + bmat[6 + i] * axis[2]) * csize[1];
+  }
+  const float sm = seg_box_slope(pc, h, bsize, -1.f), sp = seg_box_slope(pc, h, bsize, 1.f);
+  // ta = smallest t with slope >= 0, tb = largest t with slope <= 0; both searches run in one loop
+  float alo = -1.f, ahi = 1.f, blo = -1.f, bhi = 1.f;
+  for (int it = 0; it < MJLAB_CAPBOX_ITERS; ++it) {
+    const float am = 0.5f * (alo + ahi), bm = 0.5f * (blo + bhi);
+    const bool ag = seg_box_slope(pc, h, bsize, am) >= 0.f, bl = seg_box_slope(pc, h, bsize, bm) <= 0.f;
+    ahi = ag ? am : ahi; alo = ag ? alo : am;
+    blo = bl ? bm : blo; bhi = bl ? bhi : bm;
+  }
+  const float ta = sm >= 0.f ? -1.f : (sp < 0.f ? 1.f : ahi);
+  const float tb = sp <= 0.f ? 1.f : (sm > 0.f ? -1.f : blo);
+  const float eps = 1e-6f;
+  const bool use_a = ta > -1.f + eps && ta < 1.f - eps && seg_box_dist2(pc, h, bsize, ta) > 0.f;
+  const bool use_b = tb > -1.f + eps && tb < 1.f - eps && tb - ta > eps && seg_box_dist2(pc, h, bsize, tb) > 0.f;
+  int n = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float t = q == 0 ? 1.f : (q == 1 ? -1.f : (q == 2 ? ta : tb));
+    const bool use = q < 2 ? true : (q == 2 ? use_a : use_b);
+    float p[3];
+    RawCon tc;
+    for (int k = 0; k < 3; ++k) p[k] = cpos[k] + axis[k] * (csize[1] * t);
+    const bool hit = use && sphere_box(&tc, margin, p, csize[0], bpos, bmat, bsize) != 0;
+    for (int k = 0; k < 3; ++k) tc.frame[3 + k] = axis[k];
+    rc_take(c[0], tc, hit && n == 0); rc_take(c[1], tc, hit && n == 1); rc_take(c[2], tc, hit && n == 2); rc_take(c[3], tc, hit && n == 3);
+    n += hit ? 1 : 0;
+  }
+  return n;
+}
+
+// Terrain broadphase of one moving geom: walk the grid cells under its bounding sphere and keep
+// the (at most MJLAB_TCAND_MAX, smallest ids first) boxes within reach in ascending order in
+// `cand` (this lane's LDS slots).  A box listed in several cells is looked at once, in the lowest
+// cell the two footprints share.
+__device__ __forceinline__ int terrain_walk(const Model& m, const float* centre, float reach, int* cand) {
+  const int nx = m.size.tgrid_nx, ny = m.size.tgrid_ny;
+  const float x0 = (float)m.opt.tgrid_x0, y0 = (float)m.opt.tgrid_y0, inv = 1.0f / (float)m.opt.tgrid_cell;
+  int ix0 = (int)floorf((centre[0] - reach - x0) * inv), ix1 = (int)floorf((centre[0] + reach - x0) * inv);
+  int iy0 = (int)floorf((centre[1] - reach - y0) * inv), iy1 = (int)floorf((centre[1] + reach - y0) * inv);
+  ix0 = min(max(ix0, 0), nx - 1); ix1 = min(max(ix1, 0), nx - 1);
+  iy0 = min(max(iy0, 0), ny - 1); iy1 = min(max(iy1, 0), ny - 1);
+  int n = 0;
+  for (int ix = ix0; ix <= ix1; ++ix)
+    for (int iy = iy0; iy <= iy1; ++iy) {
+      const int c = ix * ny + iy;
+      const int kend = m.tgrid_start[c + 1];
+      for (int k = m.tgrid_start[c]; k < kend; ++k) {
+        const int b = m.tgrid_item[k];
+        const int bx = m.tbox_cell0[2 * b], by = m.tbox_cell0[2 * b + 1];
+        if (ix != max(ix0, bx) || iy != max(iy0, by)) continue;
+        const float *bpos = m.tbox_pos + 3 * b, *bmat = m.tbox_mat + 9 * b, *bsize = m.tbox_size + 3 * b;
+        const float dif[3] = {centre[0] - bpos[0], centre[1] - bpos[1], centre[2] - bpos[2]};
+        float d2 = 0.f;
+        for (int i = 0; i < 3; ++i) {
+          const float loc = bmat[i] * dif[0] + bmat[3 + i] * dif[1] + bmat[6 + i] * dif[2];
+          const float dv = loc - clipf(loc, -bsize[i], bsize[i]);
+          d2 += dv * dv;
+        }
+        if (d2 > reach * reach) continue;
+        // sorted insert, bounded: the largest id falls off the end
+        int pos = n;
+        while (pos > 0 && cand[pos - 1] > b) --pos;
+        if (pos >= MJLAB_TCAND_MAX) continue;
+        for (int q = n < MJLAB_TCAND_MAX ? n : MJLAB_TCAND_MAX - 1; q > pos; --q) cand[q] = cand[q - 1];
+        cand[pos] = b;
+        n = n < MJLAB_TCAND_MAX ? n + 1 : n;
+      }
+    }
+  return n;
+}
+
 __device__ __forceinline__ void make_frame(float* f9, const float* f6) {
   float x[3] = {f6[0], f6[1], f6[2]}, y[3] = {f6[3], f6[4], f6[5]};
   if (sqrtf(dot3(y, y)) < 0.5f) {
@@ -873,18 +1011,73 @@ __device__ __forceinline__ void make_frame(float* f9, const float* f6) {
   for (int k = 0; k < 3; ++k) { f9[k] = x[k]; f9[3 + k] = y[k]; f9[6 + k] = z[k]; }
 }
 
-__host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) { return 12 * s.ngeom; }
+// LDS: poses of geoms [geom_lds0, ngeom) | per moving geom TCAND_MAX candidate boxes | flat pair list
+__host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) {
+  return 12 * (s.ngeom - s.geom_lds0) + 2 * s.ntgeom * MJLAB_TCAND_MAX;
+}
+
+// Contact parameters (mj_contactParam) of the pair (g1, g2) + ordered append of this lane's n
+// raw contacts at slots base + off ..
+__device__ __forceinline__ void emit_contacts(const Model& m, const Data& d, int w, int g1, int g2, float margin, float gap, const RawCon (&rc)[4],
+                                              int n, int first, const float* gfri, const float* gsolref, const float* gsolimp, const float* gsolmix) {
+  const int ncm = m.size.nconmax;
+  int condim;
+  float fri[3], solref[2], solimp[5];
+  const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+  if (pr1 != pr2) {
+    const int gi = pr1 > pr2 ? g1 : g2;
+    condim = m.geom_condim[gi];
+    for (int k = 0; k < 3; ++k) fri[k] = gfri[3 * gi + k];
+    for (int k = 0; k < 2; ++k) solref[k] = gsolref[2 * gi + k];
+    for (int k = 0; k < 5; ++k) solimp[k] = gsolimp[5 * gi + k];
+  } else {
+    condim = max(m.geom_condim[g1], m.geom_condim[g2]);
+    for (int k = 0; k < 3; ++k) fri[k] = fmaxf(gfri[3 * g1 + k], gfri[3 * g2 + k]);
+    const float sm1 = gsolmix[g1], sm2 = gsolmix[g2];
+    float mix;
+    if (sm1 >= MINVAL && sm2 >= MINVAL) mix = sm1 / (sm1 + sm2);
+    else if (sm1 < MINVAL && sm2 < MINVAL) mix = 0.5f;
+    else if (sm1 < MINVAL) mix = 0.f;
+    else mix = 1.f;
+    if (gsolref[2 * g1] > 0.f && gsolref[2 * g2] > 0.f)
+      for (int k = 0; k < 2; ++k) solref[k] = mix * gsolref[2 * g1 + k] + (1.f - mix) * gsolref[2 * g2 + k];
+    else
+      for (int k = 0; k < 2; ++k) solref[k] = fminf(gsolref[2 * g1 + k], gsolref[2 * g2 + k]);
+    for (int k = 0; k < 5; ++k) solimp[k] = mix * gsolimp[5 * g1 + k] + (1.f - mix) * gsolimp[5 * g2 + k];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // no early exit: rc[i] must stay a compile-time index (registers, not scratch)
+    const int c = first + i;
+    if (i >= n || c >= ncm) continue;
+    float f9[9];
+    make_frame(f9, rc[i].frame);
+    const size_t wc = (size_t)w * ncm + c;
+    d.contact_dist[wc] = rc[i].dist;
+    for (int k = 0; k < 3; ++k) d.contact_pos[3 * wc + k] = rc[i].pos[k];
+    for (int k = 0; k < 9; ++k) d.contact_frame[9 * wc + k] = f9[k];
+    d.contact_includemargin[wc] = margin - gap;
+    float* f5 = d.contact_friction + 5 * wc;
+    f5[0] = f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = f5[4] = fri[2];
+    for (int k = 0; k < 2; ++k) d.contact_solref[2 * wc + k] = solref[k];
+    for (int k = 0; k < 5; ++k) d.contact_solimp[5 * wc + k] = solimp[k];
+    d.contact_dim[wc] = condim;
+    d.contact_geom[2 * wc] = g1;
+    d.contact_geom[2 * wc + 1] = g2;
+    d.contact_efc_address[wc] = -1;
+  }
+}
 
 __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
   if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
-  const int ng = m.size.ngeom, ncm = m.size.nconmax, npair = m.size.npair;
+  const int ng = m.size.ngeom, npair = m.size.npair;
+  const int g0 = m.size.geom_lds0, nl = ng - g0;  // geoms [g0, ng) are staged; s_gx / s_gm are indexed by g - g0
   float* s_gx = smem;
-  float* s_gm = s_gx + 3 * ng;
-  global_to_lds(s_gx, d.geom_xpos + (size_t)w * 3 * ng, 3 * ng, lane);
-  global_to_lds(s_gm, d.geom_xmat + (size_t)w * 9 * ng, 9 * ng, lane);
+  float* s_gm = s_gx + 3 * nl;
+  global_to_lds(s_gx, d.geom_xpos + ((size_t)w * ng + g0) * 3, 3 * nl, lane);
+  global_to_lds(s_gm, d.geom_xmat + ((size_t)w * ng + g0) * 9, 9 * nl, lane);
   __syncthreads();
   const float *gsize = MF(geom_size), *rbound = MF(geom_rbound), *gmargin = MF(geom_margin), *ggap = MF(geom_gap);
   const float *gfri = MF(geom_friction), *gsolref = MF(geom_solref), *gsolimp = MF(geom_solimp), *gsolmix = MF(geom_solmix);
@@ -899,10 +1092,11 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
       const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
       margin = fmaxf(gmargin[g1], gmargin[g2]);
       gap = fmaxf(ggap[g1], ggap[g2]);
+      const int l1 = g1 - g0, l2 = g2 - g0;
       float p1[3], p2[3], z1[3], z2[3], s1[3], s2[3];
       for (int k = 0; k < 3; ++k) {
-        p1[k] = s_gx[3 * g1 + k]; p2[k] = s_gx[3 * g2 + k];
-        z1[k] = s_gm[9 * g1 + 3 * k + 2]; z2[k] = s_gm[9 * g2 + 3 * k + 2];
+        p1[k] = s_gx[3 * l1 + k]; p2[k] = s_gx[3 * l2 + k];
+        z1[k] = s_gm[9 * l1 + 3 * k + 2]; z2[k] = s_gm[9 * l2 + 3 * k + 2];
         s1[k] = gsize[3 * g1 + k]; s2[k] = gsize[3 * g2 + k];
       }
       bool near;
@@ -929,7 +1123,7 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
         } else if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_BOX) {
           const float dist = dot3(dif, z1);
           float bm[9];
-          for (int k = 0; k < 9; ++k) bm[k] = s_gm[9 * g2 + k];
+          for (int k = 0; k < 9; ++k) bm[k] = s_gm[9 * l2 + k];
           for (int i = 0; i < 8 && n < 4; ++i) {
             float vec[3] = {(i & 1) ? s2[0] : -s2[0], (i & 2) ? s2[1] : -s2[1], (i & 4) ? s2[2] : -s2[2]}, corner[3];
             mul_mat_vec3(corner, bm, vec);
@@ -958,55 +1152,57 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
     }
     int total;
     const int off = wave_excl_scan(n, lane, &total);
-    if (n > 0) {
-      // contact parameters (mj_contactParam)
-      int condim;
-      float fri[3], solref[2], solimp[5];
-      const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
-      if (pr1 != pr2) {
-        const int gi = pr1 > pr2 ? g1 : g2;
-        condim = m.geom_condim[gi];
-        for (int k = 0; k < 3; ++k) fri[k] = gfri[3 * gi + k];
-        for (int k = 0; k < 2; ++k) solref[k] = gsolref[2 * gi + k];
-        for (int k = 0; k < 5; ++k) solimp[k] = gsolimp[5 * gi + k];
-      } else {
-        condim = max(m.geom_condim[g1], m.geom_condim[g2]);
-        for (int k = 0; k < 3; ++k) fri[k] = fmaxf(gfri[3 * g1 + k], gfri[3 * g2 + k]);
-        const float sm1 = gsolmix[g1], sm2 = gsolmix[g2];
-        float mix;
-        if (sm1 >= MINVAL && sm2 >= MINVAL) mix = sm1 / (sm1 + sm2);
-        else if (sm1 < MINVAL && sm2 < MINVAL) mix = 0.5f;
-        else if (sm1 < MINVAL) mix = 0.f;
-        else mix = 1.f;
-        if (gsolref[2 * g1] > 0.f && gsolref[2 * g2] > 0.f)
-          for (int k = 0; k < 2; ++k) solref[k] = mix * gsolref[2 * g1 + k] + (1.f - mix) * gsolref[2 * g2 + k];
-        else
-          for (int k = 0; k < 2; ++k) solref[k] = fminf(gsolref[2 * g1 + k], gsolref[2 * g2 + k]);
-        for (int k = 0; k < 5; ++k) solimp[k] = mix * gsolimp[5 * g1 + k] + (1.f - mix) * gsolimp[5 * g2 + k];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {  // no early exit: rc[i] must stay a compile-time index (registers, not scratch)
-        const int c = base + off + i;
-        if (i >= n || c >= ncm) continue;
-        float f9[9];
-        make_frame(f9, rc[i].frame);
-        const size_t wc = (size_t)w * ncm + c;
-        d.contact_dist[wc] = rc[i].dist;
-        for (int k = 0; k < 3; ++k) d.contact_pos[3 * wc + k] = rc[i].pos[k];
-        for (int k = 0; k < 9; ++k) d.contact_frame[9 * wc + k] = f9[k];
-        d.contact_includemargin[wc] = margin - gap;
-        float* f5 = d.contact_friction + 5 * wc;
-        f5[0] = f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = f5[4] = fri[2];
-        for (int k = 0; k < 2; ++k) d.contact_solref[2 * wc + k] = solref[k];
-        for (int k = 0; k < 5; ++k) d.contact_solimp[5 * wc + k] = solimp[k];
-        d.contact_dim[wc] = condim;
-        d.contact_geom[2 * wc] = g1;
-        d.contact_geom[2 * wc + 1] = g2;
-        d.contact_efc_address[wc] = -1;
-      }
-    }
+    if (n > 0) emit_contacts(m, d, w, g1, g2, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix);
     base += total;
   }
+  // ---- box terrain: moving spheres / capsules vs static boxes found through the xy grid ----
+  const int ntg = m.size.ntgeom;
+  if (ntg > 0) {
+    int* s_cand = (int*)(s_gm + 9 * nl);            // [ntg][TCAND_MAX] box ids, ascending per geom
+    int* s_pair = s_cand + ntg * MJLAB_TCAND_MAX;   // flat, ordered candidate list: (ti << 24) | slot
+    int pbase = 0;
+    for (int t0 = 0; t0 < ntg; t0 += 64) {          // lanes = moving geoms
+      const int ti = t0 + lane;
+      int nc = 0;
+      if (ti < ntg) {
+        const int g = m.tgeom[ti];
+        nc = terrain_walk(m, s_gx + 3 * (g - g0), rbound[g] + gmargin[g], s_cand + ti * MJLAB_TCAND_MAX);
+      }
+      int total;
+      const int off = wave_excl_scan(nc, lane, &total);
+      for (int q = 0; q < nc; ++q) s_pair[pbase + off + q] = (ti << 24) | q;
+      pbase += total;
+    }
+    __syncthreads();
+    for (int p0 = 0; p0 < pbase; p0 += 64) {        // lanes = candidate (geom, box) pairs
+      const int p = p0 + lane;
+      RawCon rc[4];
+      int n = 0, g = 0, gb = 0;
+      float margin = 0.f, gap = 0.f;
+      if (p < pbase) {
+        const int code = s_pair[p], ti = code >> 24;
+        const int b = s_cand[ti * MJLAB_TCAND_MAX + (code & 0xffffff)];
+        g = m.tgeom[ti];
+        gb = m.tbox_geom[b];
+        margin = gmargin[g];  // terrain boxes carry no margin / gap (checked when the model is compiled)
+        gap = ggap[g];
+        const int l = g - g0;
+        float cp[3], cz[3], cs[3], bpos[3], bmat[9], bsize[3];
+        for (int k = 0; k < 3; ++k) {
+          cp[k] = s_gx[3 * l + k]; cz[k] = s_gm[9 * l + 3 * k + 2]; cs[k] = gsize[3 * g + k];
+          bpos[k] = m.tbox_pos[3 * b + k]; bsize[k] = m.tbox_size[3 * b + k];
+        }
+        for (int k = 0; k < 9; ++k) bmat[k] = m.tbox_mat[9 * b + k];
+        if (m.geom_type[g] == MJLAB_GEOM_SPHERE) n = sphere_box(rc, margin, cp, cs[0], bpos, bmat, bsize);
+        else n = capsule_box(rc, margin, cp, cz, cs, bpos, bmat, bsize);
+      }
+      int total;
+      const int off = wave_excl_scan(n, lane, &total);
+      if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix);
+      base += total;
+    }
+  }
+  const int ncm = m.size.nconmax;
   if (lane == 0) d.ncon[w] = base < ncm ? base : ncm;
 }
 
@@ -2162,7 +2358,8 @@ __device__ __forceinline__ float nan_to_num_dev(float x) {
   return x;
 }
 __global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d, const float* key_qpos, const float* rnd3,
-                                                      int* episode_length, const int max_len, const float min_height, int* reset_mask) {
+                                                      int* episode_length, const int max_len, const float min_height, int* reset_mask,
+                                                      const float* env_origins, const float min_up_z) {
   const int w = blockIdx.x, lane = threadIdx.x;
   const int nq = m.size.nq, nv = m.size.nv;
   const bool has_free = m.size.njnt > 0 && m.jnt_type[0] == MJLAB_JNT_FREE;
@@ -2175,14 +2372,20 @@ __global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d
     bad |= !(fabsf(x) <= 3.402823466e+38f);  // NaN or inf
   }
   const int elen = episode_length[w] + 1;
-  const bool fell = has_free && qpos[2] < min_height;
+  float org[3] = {0.f, 0.f, 0.f};
+  if (env_origins)
+    for (int k = 0; k < 3; ++k) org[k] = env_origins[3 * w + k];
+  // world z of the root's up axis = 1 - 2 (qx^2 + qy^2): the bad-orientation test of the
+  // reference (envs/mdp/terminations.py bad_orientation: projected gravity vs a limit angle)
+  const bool fell = has_free && (qpos[2] - org[2] < min_height || 1.f - 2.f * (qpos[4] * qpos[4] + qpos[5] * qpos[5]) < min_up_z);
   const bool reset = __ballot(bad) != 0ull || fell || elen >= max_len;
   if (reset) {
     for (int i = lane; i < nq; i += 64) {
       float x = key_qpos[i];
       if (has_free) {
         const float yaw = (rnd3[3 * w + 2] * 2.f - 1.f) * 3.14f;
-        if (i < 2) x += rnd3[3 * w + i] - 0.5f;
+        if (i < 2) x += rnd3[3 * w + i] - 0.5f + org[i];
+        else if (i == 2) x += org[2];
         else if (i == 3) x = cosf(yaw * 0.5f);
         else if (i == 4 || i == 5) x = 0.f;
         else if (i == 6) x = sinf(yaw * 0.5f);
@@ -2347,13 +2550,14 @@ int mjlab_entity_readback(const mjlab_model_t* m, const mjlab_data_t* d, const m
 }
 
 int mjlab_masked_reset(const mjlab_model_t* m, const mjlab_data_t* d, const float* key_qpos, const float* rnd3,
-                       int* episode_length, int max_len, float min_height, int* reset_mask, void* stream) {
+                       int* episode_length, int max_len, float min_height, int* reset_mask, const float* env_origins,
+                       float min_up_z, void* stream) {
   int rc = check_model(m);
   if (rc) return rc;
   if (!key_qpos || !rnd3 || !episode_length || !reset_mask) return fail(-15, "masked_reset: null argument");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_masked_reset, dim3(m->size.nworld), dim3(64), 0, st, *m, *d, key_qpos, rnd3, episode_length, max_len,
-                     min_height, reset_mask);
+                     min_height, reset_mask, env_origins, min_up_z);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, "k_masked_reset launch failed");
   return 0;

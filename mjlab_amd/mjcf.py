@@ -710,7 +710,100 @@ class Model:
           setattr(m.opt, name, tuple(val) if isinstance(val, list) else val)
         elif kind == "n":
           m.names[name] = [str(s) for s in v.tolist()]
+    if not hasattr(m, "nterrain"):  # saved before the static-geometry / terrain fields existed
+      static = m.body_weldid[m.geom_bodyid] == 0
+      m.nstaticgeom = int(np.argmin(static)) if not static.all() else m.ngeom
+      m.geom_lds0 = int(min(m.nstaticgeom, m.pair_geom.min())) if m.npair else m.nstaticgeom
+      _compile_terrain(m, np.zeros(0, np.int64), [])
     return m
+
+
+# geom-type pairs (type1 <= type2) the collision stage has a function for; a moving sphere or
+# capsule additionally collides with static boxes through the terrain path
+_PAIR_FUNCS = {
+  (GEOM_PLANE, GEOM_SPHERE), (GEOM_PLANE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_BOX),
+  (GEOM_SPHERE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_CAPSULE),
+}  # fmt: skip
+TERRAIN_CELL = 0.5  # m, edge of a broadphase grid cell
+TCAND_MAX = 12  # terrain boxes kept per moving geom and step (the ones with the smallest ids)
+
+
+def _static_body_poses(m: "Model") -> tuple[np.ndarray, np.ndarray]:
+  """World pose of every static body (weldid 0); rows of moving bodies are left at identity."""
+  xpos = np.zeros((m.nbody, 3))
+  xquat = np.tile([1.0, 0, 0, 0], (m.nbody, 1))
+  for b in range(1, m.nbody):
+    if m.body_weldid[b] == 0:
+      p = m.body_parentid[b]
+      xpos[b] = xpos[p] + quat_to_mat(xquat[p]) @ m.body_pos[b]
+      xquat[b] = quat_normalize(quat_mul(xquat[p], m.body_quat[b]))
+  return xpos, xquat
+
+
+def _compile_terrain(m: "Model", tids: np.ndarray, moving: list[int]) -> None:
+  """Terrain boxes in the world frame + the uniform xy grid the collision stage walks.
+
+  ``tgrid_item[tgrid_start[c] : tgrid_start[c + 1]]`` lists (ascending) the boxes whose
+  footprint touches cell ``c = ix * ny + iy``; ``tbox_cell0`` is the lowest cell of a box, which
+  lets a walker visit a (geom, box) pair exactly once: in the cell
+  ``(max(ix0_geom, ix0_box), max(iy0_geom, iy0_box))``."""
+  nt = len(tids)
+  m.nterrain = nt
+  m.tbox_geom = tids.astype(np.int32)
+  m.tbox_pos = np.zeros((nt, 3))
+  m.tbox_mat = np.zeros((nt, 9))
+  m.tbox_size = m.geom_size[tids].copy().reshape(nt, 3)
+  m.tbox_cell0 = np.zeros((nt, 2), np.int32)
+  m.tgeom = np.zeros(0, np.int32)
+  m.tgrid_start = np.zeros(1, np.int32)
+  m.tgrid_item = np.zeros(0, np.int32)
+  m.tgrid_nx = m.tgrid_ny = 0
+  m.tgrid_x0 = m.tgrid_y0 = 0.0
+  m.tgrid_cell = TERRAIN_CELL
+  if nt == 0:
+    m.ntgeom, m.ntcellp1, m.ntitem = 0, 1, 0
+    return
+  if np.any(m.geom_margin[tids] != 0) or np.any(m.geom_gap[tids] != 0):
+    raise NotImplementedError("terrain boxes must have margin = gap = 0")
+  ct, ca = m.geom_contype[tids], m.geom_conaffinity[tids]
+  if (ct != ct[0]).any() or (ca != ca[0]).any():
+    raise NotImplementedError("terrain boxes must share one contype / conaffinity")
+  tg = [g for g in moving if (m.geom_contype[g] & ca[0]) or (ct[0] & m.geom_conaffinity[g])]
+  for g in tg:
+    if m.geom_type[g] not in (GEOM_SPHERE, GEOM_CAPSULE):
+      raise NotImplementedError(f"geom '{m.names['geom'][g]}' (type {m.geom_type[g]}) vs box terrain: only spheres and capsules collide with static boxes")
+  m.tgeom = np.array(tg, np.int32)
+  m.ntgeom = len(tg)
+  xpos, xquat = _static_body_poses(m)
+  half = np.zeros((nt, 3))
+  for i, g in enumerate(tids):
+    b = m.geom_bodyid[g]
+    rb = quat_to_mat(xquat[b])
+    r = rb @ quat_to_mat(m.geom_quat[g])
+    m.tbox_pos[i] = xpos[b] + rb @ m.geom_pos[g]
+    m.tbox_mat[i] = r.reshape(9)
+    half[i] = np.abs(r) @ m.geom_size[g]
+  lo, hi = m.tbox_pos - half, m.tbox_pos + half
+  cell = TERRAIN_CELL
+  x0, y0 = float(lo[:, 0].min()), float(lo[:, 1].min())
+  nx = max(1, int(np.ceil((hi[:, 0].max() - x0) / cell)))
+  ny = max(1, int(np.ceil((hi[:, 1].max() - y0) / cell)))
+  ix0 = np.clip(np.floor((lo[:, 0] - x0) / cell).astype(np.int64), 0, nx - 1)
+  ix1 = np.clip(np.floor((hi[:, 0] - x0) / cell).astype(np.int64), 0, nx - 1)
+  iy0 = np.clip(np.floor((lo[:, 1] - y0) / cell).astype(np.int64), 0, ny - 1)
+  iy1 = np.clip(np.floor((hi[:, 1] - y0) / cell).astype(np.int64), 0, ny - 1)
+  cells, items = [], []
+  for i in range(nt):
+    c = np.add.outer(np.arange(ix0[i], ix1[i] + 1) * ny, np.arange(iy0[i], iy1[i] + 1)).ravel()
+    cells.append(c)
+    items.append(np.full(c.size, i, np.int64))
+  cells, items = np.concatenate(cells), np.concatenate(items)
+  order = np.argsort(cells, kind="stable")  # boxes stay in ascending order inside a cell
+  m.tgrid_item = items[order].astype(np.int32)
+  m.tgrid_start = np.searchsorted(cells[order], np.arange(nx * ny + 1)).astype(np.int32)
+  m.tbox_cell0 = np.stack([ix0, iy0], axis=1).astype(np.int32)
+  m.tgrid_nx, m.tgrid_ny, m.tgrid_x0, m.tgrid_y0 = nx, ny, x0, y0
+  m.ntcellp1, m.ntitem = nx * ny + 1, int(m.tgrid_item.size)
 
 
 def _compile(spec: Spec) -> Model:
@@ -982,9 +1075,18 @@ def _compile(spec: Spec) -> Model:
     ia, ib = m.names["body"].index(a), m.names["body"].index(b)
     excl.add((min(ia, ib), max(ia, ib)))
   m.nexclude = len(excl)
+  # Static geoms (world body or welded to it) never move: their poses are computed once.  Static
+  # colliding BOXES are the terrain (reference src/mjlab/terrains/primitive_terrains.py: every
+  # terrain piece is a box under the static ``terrain`` body); there can be thousands, so they
+  # never enter the static pair list -- moving geoms find them through a uniform xy grid.
+  static = m.body_weldid[m.geom_bodyid] == 0
+  collides = (m.geom_contype != 0) | (m.geom_conaffinity != 0)
+  terrain = static & (m.geom_type == GEOM_BOX) & collides
+  m.nstaticgeom = int(np.argmin(static)) if not static.all() else ngeom  # leading run of static geoms
   pairs = []
-  for g1 in range(ngeom):
-    for g2 in range(g1 + 1, ngeom):
+  cand = [g for g in range(ngeom) if collides[g] and not terrain[g]]
+  for i1, g1 in enumerate(cand):
+    for g2 in cand[i1 + 1 :]:
       ct1, ca1 = m.geom_contype[g1], m.geom_conaffinity[g1]
       ct2, ca2 = m.geom_contype[g2], m.geom_conaffinity[g2]
       if not ((ct1 & ca2) or (ct2 & ca1)):
@@ -1002,9 +1104,15 @@ def _compile(spec: Spec) -> Model:
         continue
       # collision functions are defined for type1 <= type2
       a_, b_ = (g1, g2) if m.geom_type[g1] <= m.geom_type[g2] else (g2, g1)
+      t1, t2 = m.geom_type[a_], m.geom_type[b_]
+      if (t1, t2) not in _PAIR_FUNCS:
+        raise NotImplementedError(f"no collision function for geom types ({t1}, {t2}): '{m.names['geom'][a_]}' vs '{m.names['geom'][b_]}'")
       pairs.append((a_, b_))
   m.pair_geom = np.array(pairs, np.int32).reshape(len(pairs), 2)
   m.npair = len(pairs)
+  _compile_terrain(m, np.flatnonzero(terrain), [g for g in cand if not static[g]])
+  # geoms [geom_lds0, ngeom) are the ones the collision stage keeps on chip
+  m.geom_lds0 = int(min(m.nstaticgeom, m.pair_geom.min())) if m.npair else m.nstaticgeom
 
   # ---- keyframes ----------------------------------------------------------------
   nkey = len(spec.keys)

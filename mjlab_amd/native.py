@@ -70,7 +70,7 @@ def lib() -> ctypes.CDLL:
   L.mjlab_forward_masked.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
   L.mjlab_entity_readback.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
   L.mjlab_masked_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                   ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+                                   ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
   L.mjlab_forward_stages.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
   L.mjlab_tile_field.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
   L.mjlab_selftest.argtypes = [ctypes.c_void_p]

@@ -333,11 +333,19 @@ def _task_options(spec: Spec) -> None:
   o.gravity = (0.0, 0.0, -9.81)
 
 
-def build_scene(robot: Spec, key: InitialState | None) -> Spec:
-  """World + ``terrain`` plane + robot attached with prefix ``robot/``."""
+def build_scene(robot: Spec, key: InitialState | None, terrain_cfg=None) -> Spec:
+  """World + ``terrain`` body + robot attached with prefix ``robot/``.  The terrain is the ground
+  plane (reference terrain_importer.py:183-194) or, with ``terrain_cfg`` (a
+  ``terrains.TerrainGeneratorCfg``), the generated boxes (terrain_importer.py:82-90); the
+  sub-terrain origins are kept on the spec as ``terrain_origins``."""
   scene = Spec()
-  terrain = scene.add_body("terrain")
-  scene.add_geom(terrain, "terrain", GEOM_PLANE, (0, 0, 0.01))
+  if terrain_cfg is None:
+    terrain = scene.add_body("terrain")
+    scene.add_geom(terrain, "terrain", GEOM_PLANE, (0, 0, 0.01))
+  else:
+    from . import terrains
+
+    scene.terrain_origins = terrains.TerrainGenerator(terrain_cfg).compile(scene).origins
   if key is not None:
     add_init_keyframe(robot, key)
   keys = robot.keys
@@ -398,14 +406,32 @@ def compile_scene(name: str) -> Model:
     for s in spec.sensors:
       if s.refname == "robot/terrain":
         s.refname = "terrain"
+  elif name == "g1_velocity_rough":
+    # Mjlab-Velocity-Rough-Unitree-G1: same robot and sensors as the flat task on the generated
+    # box terrain (reference tasks/velocity/config/g1/rough_env_cfg.py:13-34,
+    # velocity_env_cfg.py:30-37,275-278: ROUGH_TERRAINS_CFG with the curriculum switched on).
+    # The reference leaves the generator unseeded; a product build needs a fixed seed.
+    from . import terrains
+
+    sensors = tuple(
+      ContactSensorCfg(name=f"{s}_foot_ground_contact", body1=f"{s}_ankle_roll_link", body2="terrain", num=1, data=("found",), reduce="netforce")
+      for s in ("left", "right")
+    )
+    spec = build_scene(g1_spec(sensors), G1_KNEES_BENT, terrains.rough_terrains_cfg(seed=ROUGH_TERRAIN_SEED))
+    for s in spec.sensors:
+      if s.refname == "robot/terrain":
+        s.refname = "terrain"
   else:
     raise KeyError(name)
   _task_options(spec)
   model = spec.compile()
+  if hasattr(spec, "terrain_origins"):
+    model.terrain_origins = np.asarray(spec.terrain_origins, dtype=np.float64)
   return model
 
 
-SCENES = ("g1_velocity_flat", "g1_tracking_flat", "go1_velocity_flat")
+ROUGH_TERRAIN_SEED = 0
+SCENES = ("g1_velocity_flat", "g1_tracking_flat", "go1_velocity_flat", "g1_velocity_rough")
 
 
 def load_model(name: str) -> Model:

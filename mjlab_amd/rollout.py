@@ -10,6 +10,7 @@ physics hot path and are not reproduced; resets are mask-based (no ``nonzero()``
 from __future__ import annotations
 
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -22,7 +23,8 @@ from .sim import Simulation
 class PhysicsRollout:
   def __init__(self, sim: Simulation, action_scale: np.ndarray | float = 0.25, decimation: int = 4,
                episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0,
-               masked_forward: bool = False, fused_reset: bool = True) -> None:
+               masked_forward: bool = False, fused_reset: bool = True, min_up_z: float | None = None,
+               max_init_terrain_level: int | None = 5) -> None:
     m: Model = sim.mj_model
     dev = sim.data.qpos.device
     self.sim, self.m, self.decimation = sim, m, decimation
@@ -44,6 +46,23 @@ class PhysicsRollout:
     # logic as a chain of torch ops (the reference's style)
     self.fused_reset = fused_reset
     n = sim.num_envs
+    # Environment origins.  On a generated terrain every env spawns on its sub-terrain's origin
+    # (reference terrains/terrain_importer.py:196-229, max_init_terrain_level = 5 in
+    # tasks/velocity/velocity_env_cfg.py:35) and the termination is the reference's orientation
+    # test (bad_orientation, limit 70 degrees: velocity_env_cfg.py TerminationCfg.fell_over)
+    # instead of an absolute height; on the plane all envs share the origin.
+    self.env_origins: torch.Tensor | None = None
+    origins = getattr(m, "terrain_origins", None)
+    if origins is not None and self.has_free:
+      from . import terrains
+
+      eo, self.terrain_levels, self.terrain_types = terrains.env_origins_curriculum(
+        n, np.asarray(origins), max_init_terrain_level, np.random.default_rng(seed)
+      )
+      self.env_origins = torch.tensor(eo, dtype=torch.float32, device=dev)
+      if min_up_z is None:
+        min_up_z, self.min_height = math.cos(math.radians(70.0)), -1.0e9
+    self.min_up_z = -2.0 if min_up_z is None else float(min_up_z)
     self._graph: torch.cuda.CUDAGraph | None = None
     self._obs_buf: torch.Tensor | None = None
     # start at random episode phase like the reference (train.py:109-111 init_at_random_ep_len)
@@ -60,6 +79,8 @@ class PhysicsRollout:
       xy = torch.rand((n, 2), device=dev, generator=self.gen) - 0.5
       yaw = (torch.rand((n,), device=dev, generator=self.gen) * 2 - 1) * 3.14
       q[:, 0:2] += xy
+      if self.env_origins is not None:
+        q[:, 0:3] += self.env_origins
       q[:, 3] = torch.cos(yaw * 0.5)
       q[:, 4:6] = 0.0
       q[:, 6] = torch.sin(yaw * 0.5)
@@ -123,13 +144,19 @@ class PhysicsRollout:
       native.check(
         s._lib.mjlab_masked_reset(ctypes.byref(s._m), ctypes.byref(s._d), self.key_qpos.data_ptr(), rnd.data_ptr(),
                                   self.episode_length.data_ptr(), self.max_len, float(self.min_height),
-                                  self._reset_mask.data_ptr(), s._stream()),
+                                  self._reset_mask.data_ptr(), 0 if self.env_origins is None else self.env_origins.data_ptr(),
+                                  self.min_up_z, s._stream()),
         "mjlab_masked_reset",
       )
       reset = self._reset_mask.bool()
     else:
       self.episode_length.add_(1)
-      fell = d.qpos[:, 2] < self.min_height if self.has_free else torch.zeros_like(self.episode_length, dtype=torch.bool)
+      if self.has_free:
+        z0 = self.env_origins[:, 2] if self.env_origins is not None else 0.0
+        up_z = 1.0 - 2.0 * (d.qpos[:, 4] ** 2 + d.qpos[:, 5] ** 2)
+        fell = (d.qpos[:, 2] - z0 < self.min_height) | (up_z < self.min_up_z)
+      else:
+        fell = torch.zeros_like(self.episode_length, dtype=torch.bool)
       bad = ~torch.isfinite(d.qpos).all(dim=1)
       reset = fell | bad | (self.episode_length >= self.max_len)
       fresh = self._sample_reset_qpos(self.sim.num_envs)

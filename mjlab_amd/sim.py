@@ -226,7 +226,11 @@ class Simulation:
     self.use_graph = bool(cfg.use_graph) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
     self.step_graph: torch.cuda.CUDAGraph | None = None
     self.forward_graph: torch.cuda.CUDAGraph | None = None
-    self.forward()  # populate derived fields like mjwarp.put_data does from mj_forward
+    # populate derived fields like mjwarp.put_data does from mj_forward; this first pass also
+    # writes the poses of the static geoms (world / terrain bodies), which later passes skip
+    self._m.size.nstaticgeom = 0
+    self.forward()
+    self._m.size.nstaticgeom = int(model.nstaticgeom)
     self.create_graph()
 
   # ------------------------------------------------------------------ helpers
@@ -323,6 +327,11 @@ class Simulation:
       raise ValueError(f"Fields not found in model: {invalid}")
     if self.num_envs == 1:
       return
+    moves_static = [f for f in fields if f in ("geom_pos", "geom_quat", "body_pos", "body_quat")]
+    if moves_static:
+      if self._mj_model.nterrain:
+        raise NotImplementedError(f"per-world {moves_static} with a box terrain: terrain boxes are static and shared by all worlds")
+      self._m.size.nstaticgeom = 0  # static geoms may now differ per world: recompute them every pass
     with torch.cuda.device(self._dev):
       for name in fields:
         if name not in self._model_base:

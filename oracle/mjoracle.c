@@ -449,12 +449,197 @@ static int capsule_capsule(rawcon_t* c, real margin, const real* pos1, const rea
   return n;
 }
 
+/* Sphere vs box (MuJoCo's mjc_SphereBox semantics: engine_collision_box.c).  The sphere centre is
+ * taken into the box frame and clamped to the box; outside, the normal runs along the
+ * clamped-point -> centre direction, inside, through the nearest face.  The contact normal points
+ * from the sphere (geom1) into the box (geom2); pos is midway between the two surfaces. */
+static int sphere_box(rawcon_t* c, real margin, const real* spos, real r, const real* bpos, const real* bmat, const real* bsize) {
+  real dif[3] = {spos[0] - bpos[0], spos[1] - bpos[1], spos[2] - bpos[2]}, loc[3], dv[3], nl[3], pl[3];
+  for (int i = 0; i < 3; i++) loc[i] = bmat[i] * dif[0] + bmat[3 + i] * dif[1] + bmat[6 + i] * dif[2];
+  for (int i = 0; i < 3; i++) dv[i] = loc[i] - clipr(loc[i], -bsize[i], bsize[i]);
+  real d2 = dot3(dv, dv), mn = margin + r;
+  if (d2 > mn * mn) return 0;
+  if (d2 > 0) {
+    real len = sqrt(d2);
+    c->dist = len - r;
+    for (int i = 0; i < 3; i++) { nl[i] = dv[i] / len; pl[i] = (loc[i] - dv[i]) + nl[i] * (c->dist * (real)0.5); }
+  } else {
+    /* centre inside the box: leave through the nearest face (first one on ties) */
+    int k = 0;
+    real depth = bsize[0] - fabs(loc[0]);
+    for (int i = 1; i < 3; i++) { real di = bsize[i] - fabs(loc[i]); if (di < depth) { depth = di; k = i; } }
+    nl[0] = nl[1] = nl[2] = 0;
+    nl[k] = loc[k] >= 0 ? 1 : -1;
+    c->dist = -depth - r;
+    for (int i = 0; i < 3; i++) pl[i] = loc[i] + nl[i] * ((depth - r) * (real)0.5);
+  }
+  for (int i = 0; i < 3; i++) {
+    c->pos[i] = bpos[i] + bmat[3 * i] * pl[0] + bmat[3 * i + 1] * pl[1] + bmat[3 * i + 2] * pl[2];
+    c->frame[i] = -(bmat[3 * i] * nl[0] + bmat[3 * i + 1] * nl[1] + bmat[3 * i + 2] * nl[2]);
+  }
+  c->frame[3] = c->frame[4] = c->frame[5] = 0;
+  return 1;
+}
+
+/* d/dt of half the squared distance between the point pc + t h (box frame) and the box */
+static inline real seg_box_slope(const real* pc, const real* h, const real* bsize, real t) {
+  real s = 0;
+  for (int i = 0; i < 3; i++) { real p = pc[i] + t * h[i]; s += (p - clipr(p, -bsize[i], bsize[i])) * h[i]; }
+  return s;
+}
+static inline real seg_box_dist2(const real* pc, const real* h, const real* bsize, real t) {
+  real s = 0;
+  for (int i = 0; i < 3; i++) { real p = pc[i] + t * h[i], e = p - clipr(p, -bsize[i], bsize[i]); s += e * e; }
+  return s;
+}
+/* Capsule vs box, up to 4 contacts, all of them sphere_box() contacts of spheres of the capsule's
+ * radius centred on its axis at t in [-1, 1] (the construction mjc_CapsuleBox uses, with its own
+ * choice of points -- upstream's feature-case analysis is not reproducible from its documentation,
+ * so the points are defined here): the two end points (exactly plane_capsule's contacts when the
+ * capsule lies over a face), plus the ends ta <= tb of the interval where the axis is closest to
+ * the box -- the distance along the axis is convex, so its slope is monotone and ta / tb are found by
+ * bisection -- when they are interior points OUTSIDE the box (a capsule crossing an edge or a
+ * corner; where the axis itself pierces the box the end points carry the contact). */
+#define MJO_CAPBOX_ITERS 24
+static int capsule_box(rawcon_t* c, real margin, const real* cpos, const real* cmat, const real* csize, const real* bpos,
+                       const real* bmat, const real* bsize) {
+  real axis[3] = {cmat[2], cmat[5], cmat[8]}, dif[3] = {cpos[0] - bpos[0], cpos[1] - bpos[1], cpos[2] - bpos[2]};
+  real pc[3], h[3];
+  for (int i = 0; i < 3; i++) {
+    pc[i] = bmat[i] * dif[0] + bmat[3 + i] * dif[1] + bmat[6 + i] * dif[2];
+    h[i] = (bmat[i] * axis[0] + bmat[3 + i] * axis[1] + bmat[6 + i] * axis[2]) * csize[1];
+  }
+  real sm = seg_box_slope(pc, h, bsize, -1), sp = seg_box_slope(pc, h, bsize, 1);
+  real ta, tb;
+  /* ta = smallest t with slope >= 0 */
+  if (sm >= 0) ta = -1;
+  else if (sp < 0) ta = 1;
+  else {
+    real lo = -1, hi = 1;
+    for (int it = 0; it < MJO_CAPBOX_ITERS; it++) {
+      real mid = (real)0.5 * (lo + hi);
+      if (seg_box_slope(pc, h, bsize, mid) >= 0) hi = mid; else lo = mid;
+    }
+    ta = hi;
+  }
+  /* tb = largest t with slope <= 0 */
+  if (sp <= 0) tb = 1;
+  else if (sm > 0) tb = -1;
+  else {
+    real lo = -1, hi = 1;
+    for (int it = 0; it < MJO_CAPBOX_ITERS; it++) {
+      real mid = (real)0.5 * (lo + hi);
+      if (seg_box_slope(pc, h, bsize, mid) <= 0) lo = mid; else hi = mid;
+    }
+    tb = lo;
+  }
+  const real eps = (real)1e-6;
+  real ts[4] = {1, -1, ta, tb};
+  int use[4] = {1, 1, ta > -1 + eps && ta < 1 - eps && seg_box_dist2(pc, h, bsize, ta) > 0,
+                tb > -1 + eps && tb < 1 - eps && tb - ta > eps && seg_box_dist2(pc, h, bsize, tb) > 0};
+  int n = 0;
+  for (int q = 0; q < 4; q++) {
+    if (!use[q]) continue;
+    real p[3];
+    for (int k = 0; k < 3; k++) p[k] = cpos[k] + axis[k] * (csize[1] * ts[q]);
+    if (sphere_box(c + n, margin, p, csize[0], bpos, bmat, bsize)) { memcpy(c[n].frame + 3, axis, sizeof(axis)); n++; }
+  }
+  return n;
+}
+
+/* contact parameters (mj_contactParam) + append n raw contacts of the pair (g1, g2) */
+static void emit_contacts(const mjo_model_t* m, mjo_data_t* d, int w, int g1, int g2, real margin, real gap, rawcon_t* rc, int n,
+                          int* pncon) {
+  const int ncm = m->size.nconmax;
+  const real *gfri = MF(geom_friction, w), *gsolref = MF(geom_solref, w), *gsolimp = MF(geom_solimp, w), *gsolmix = MF(geom_solmix, w);
+  int ncon = *pncon;
+  int condim;
+  real fri[3], solref[2], solimp[5];
+  int pr1 = m->geom_priority[g1], pr2 = m->geom_priority[g2];
+  if (pr1 != pr2) {
+    int gi = pr1 > pr2 ? g1 : g2;
+    condim = m->geom_condim[gi];
+    memcpy(fri, gfri + 3 * gi, sizeof(fri));
+    memcpy(solref, gsolref + 2 * gi, sizeof(solref));
+    memcpy(solimp, gsolimp + 5 * gi, sizeof(solimp));
+  } else {
+    condim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+    for (int k = 0; k < 3; k++) fri[k] = gfri[3 * g1 + k] > gfri[3 * g2 + k] ? gfri[3 * g1 + k] : gfri[3 * g2 + k];
+    real mix;
+    real sm1 = gsolmix[g1], sm2 = gsolmix[g2];
+    if (sm1 >= MINVAL && sm2 >= MINVAL) mix = sm1 / (sm1 + sm2);
+    else if (sm1 < MINVAL && sm2 < MINVAL) mix = (real)0.5;
+    else if (sm1 < MINVAL) mix = 0;
+    else mix = 1;
+    if (gsolref[2 * g1] > 0 && gsolref[2 * g2] > 0)
+      for (int k = 0; k < 2; k++) solref[k] = mix * gsolref[2 * g1 + k] + (1 - mix) * gsolref[2 * g2 + k];
+    else
+      for (int k = 0; k < 2; k++) solref[k] = gsolref[2 * g1 + k] < gsolref[2 * g2 + k] ? gsolref[2 * g1 + k] : gsolref[2 * g2 + k];
+    for (int k = 0; k < 5; k++) solimp[k] = mix * gsolimp[5 * g1 + k] + (1 - mix) * gsolimp[5 * g2 + k];
+  }
+  for (int i = 0; i < n && ncon < ncm; i++) {
+    make_frame(rc[i].frame);
+    D(contact_dist, ncm)[ncon] = rc[i].dist;
+    memcpy(D(contact_pos, 3 * ncm) + 3 * ncon, rc[i].pos, 3 * sizeof(real));
+    memcpy(D(contact_frame, 9 * ncm) + 9 * ncon, rc[i].frame, 9 * sizeof(real));
+    D(contact_includemargin, ncm)[ncon] = margin - gap;
+    real* f5 = D(contact_friction, 5 * ncm) + 5 * ncon;
+    f5[0] = f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = f5[4] = fri[2];
+    memcpy(D(contact_solref, 2 * ncm) + 2 * ncon, solref, sizeof(solref));
+    memcpy(D(contact_solimp, 5 * ncm) + 5 * ncon, solimp, sizeof(solimp));
+    (d->contact_dim + (size_t)w * ncm)[ncon] = condim;
+    (d->contact_geom + (size_t)w * 2 * ncm)[2 * ncon] = g1;
+    (d->contact_geom + (size_t)w * 2 * ncm)[2 * ncon + 1] = g2;
+    (d->contact_efc_address + (size_t)w * ncm)[ncon] = -1;
+    ncon++;
+  }
+  *pncon = ncon;
+}
+
+/* Terrain broadphase for one moving geom: walk the grid cells under its bounding sphere and keep
+ * the (at most MJLAB_TCAND_MAX, smallest ids first) boxes within reach, in ascending order.  A box
+ * listed in several cells is looked at once, in the lowest cell the two footprints share. */
+static int terrain_candidates(const mjo_model_t* m, const real* centre, real reach, int* cand) {
+  const mjlab_sizes_t* s = &m->size;
+  const int nx = s->tgrid_nx, ny = s->tgrid_ny;
+  const real x0 = (real)m->opt.tgrid_x0, y0 = (real)m->opt.tgrid_y0, inv = (real)1 / (real)m->opt.tgrid_cell;
+  int ix0 = (int)floor((centre[0] - reach - x0) * inv), ix1 = (int)floor((centre[0] + reach - x0) * inv);
+  int iy0 = (int)floor((centre[1] - reach - y0) * inv), iy1 = (int)floor((centre[1] + reach - y0) * inv);
+  ix0 = ix0 < 0 ? 0 : (ix0 > nx - 1 ? nx - 1 : ix0); ix1 = ix1 < 0 ? 0 : (ix1 > nx - 1 ? nx - 1 : ix1);
+  iy0 = iy0 < 0 ? 0 : (iy0 > ny - 1 ? ny - 1 : iy0); iy1 = iy1 < 0 ? 0 : (iy1 > ny - 1 ? ny - 1 : iy1);
+  int n = 0;
+  for (int ix = ix0; ix <= ix1; ix++)
+    for (int iy = iy0; iy <= iy1; iy++) {
+      const int c = ix * ny + iy;
+      for (int k = m->tgrid_start[c]; k < m->tgrid_start[c + 1]; k++) {
+        const int b = m->tgrid_item[k];
+        const int bx = m->tbox_cell0[2 * b], by = m->tbox_cell0[2 * b + 1];
+        if (ix != (ix0 > bx ? ix0 : bx) || iy != (iy0 > by ? iy0 : by)) continue;
+        const real *bpos = m->tbox_pos + 3 * b, *bmat = m->tbox_mat + 9 * b, *bsize = m->tbox_size + 3 * b;
+        real dif[3] = {centre[0] - bpos[0], centre[1] - bpos[1], centre[2] - bpos[2]}, d2 = 0;
+        for (int i = 0; i < 3; i++) {
+          real loc = bmat[i] * dif[0] + bmat[3 + i] * dif[1] + bmat[6 + i] * dif[2];
+          real dv = loc - clipr(loc, -bsize[i], bsize[i]);
+          d2 += dv * dv;
+        }
+        if (d2 > reach * reach) continue;
+        /* sorted insert, bounded: the largest id falls off the end */
+        int pos = n < MJLAB_TCAND_MAX ? n : MJLAB_TCAND_MAX;
+        while (pos > 0 && cand[pos - 1] > b) pos--;
+        if (pos >= MJLAB_TCAND_MAX) continue;
+        int last = n < MJLAB_TCAND_MAX ? n : MJLAB_TCAND_MAX - 1;
+        for (int q = last; q > pos; q--) cand[q] = cand[q - 1];
+        cand[pos] = b;
+        if (n < MJLAB_TCAND_MAX) n++;
+      }
+    }
+  return n;
+}
+
 static void collision(const mjo_model_t* m, mjo_data_t* d, int w) {
   const mjlab_sizes_t* s = &m->size;
-  int ncm = s->nconmax;
   real *gx = D(geom_xpos, 3 * s->ngeom), *gm = D(geom_xmat, 9 * s->ngeom);
   const real *gsize = MF(geom_size, w), *rbound = MF(geom_rbound, w), *gmargin = MF(geom_margin, w), *ggap = MF(geom_gap, w);
-  const real *gfri = MF(geom_friction, w), *gsolref = MF(geom_solref, w), *gsolimp = MF(geom_solimp, w), *gsolmix = MF(geom_solmix, w);
   int ncon = 0;
   for (int p = 0; p < s->npair; p++) {
     int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
@@ -481,46 +666,23 @@ static void collision(const mjo_model_t* m, mjo_data_t* d, int w) {
     else if (t1 == MJLAB_GEOM_CAPSULE && t2 == MJLAB_GEOM_CAPSULE) n = capsule_capsule(rc, margin, p1, m1, s1, p2, m2, s2);
     else continue; /* unsupported pair types never reach here: the compiler rejects them */
     if (!n) continue;
-    /* contact parameters (mj_contactParam) */
-    int condim;
-    real fri[3], solref[2], solimp[5];
-    int pr1 = m->geom_priority[g1], pr2 = m->geom_priority[g2];
-    if (pr1 != pr2) {
-      int gi = pr1 > pr2 ? g1 : g2;
-      condim = m->geom_condim[gi];
-      memcpy(fri, gfri + 3 * gi, sizeof(fri));
-      memcpy(solref, gsolref + 2 * gi, sizeof(solref));
-      memcpy(solimp, gsolimp + 5 * gi, sizeof(solimp));
-    } else {
-      condim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
-      for (int k = 0; k < 3; k++) fri[k] = gfri[3 * g1 + k] > gfri[3 * g2 + k] ? gfri[3 * g1 + k] : gfri[3 * g2 + k];
-      real mix;
-      real sm1 = gsolmix[g1], sm2 = gsolmix[g2];
-      if (sm1 >= MINVAL && sm2 >= MINVAL) mix = sm1 / (sm1 + sm2);
-      else if (sm1 < MINVAL && sm2 < MINVAL) mix = (real)0.5;
-      else if (sm1 < MINVAL) mix = 0;
-      else mix = 1;
-      if (gsolref[2 * g1] > 0 && gsolref[2 * g2] > 0)
-        for (int k = 0; k < 2; k++) solref[k] = mix * gsolref[2 * g1 + k] + (1 - mix) * gsolref[2 * g2 + k];
-      else
-        for (int k = 0; k < 2; k++) solref[k] = gsolref[2 * g1 + k] < gsolref[2 * g2 + k] ? gsolref[2 * g1 + k] : gsolref[2 * g2 + k];
-      for (int k = 0; k < 5; k++) solimp[k] = mix * gsolimp[5 * g1 + k] + (1 - mix) * gsolimp[5 * g2 + k];
-    }
-    for (int i = 0; i < n && ncon < ncm; i++) {
-      make_frame(rc[i].frame);
-      D(contact_dist, ncm)[ncon] = rc[i].dist;
-      memcpy(D(contact_pos, 3 * ncm) + 3 * ncon, rc[i].pos, 3 * sizeof(real));
-      memcpy(D(contact_frame, 9 * ncm) + 9 * ncon, rc[i].frame, 9 * sizeof(real));
-      D(contact_includemargin, ncm)[ncon] = margin - gap;
-      real* f5 = D(contact_friction, 5 * ncm) + 5 * ncon;
-      f5[0] = f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = f5[4] = fri[2];
-      memcpy(D(contact_solref, 2 * ncm) + 2 * ncon, solref, sizeof(solref));
-      memcpy(D(contact_solimp, 5 * ncm) + 5 * ncon, solimp, sizeof(solimp));
-      (d->contact_dim + (size_t)w * ncm)[ncon] = condim;
-      (d->contact_geom + (size_t)w * 2 * ncm)[2 * ncon] = g1;
-      (d->contact_geom + (size_t)w * 2 * ncm)[2 * ncon + 1] = g2;
-      (d->contact_efc_address + (size_t)w * ncm)[ncon] = -1;
-      ncon++;
+    emit_contacts(m, d, w, g1, g2, margin, gap, rc, n, &ncon);
+  }
+  /* moving spheres / capsules vs the box terrain; terrain boxes carry no margin (checked at
+   * model compile time), so the pair margin is the moving geom's */
+  for (int ti = 0; ti < s->ntgeom; ti++) {
+    int g = m->tgeom[ti], cand[MJLAB_TCAND_MAX];
+    real margin = gmargin[g], gap = ggap[g];
+    int nc = terrain_candidates(m, gx + 3 * g, rbound[g] + margin, cand);
+    for (int q = 0; q < nc; q++) {
+      int b = cand[q];
+      rawcon_t rc[4];
+      int n = 0;
+      if (m->geom_type[g] == MJLAB_GEOM_SPHERE)
+        n = sphere_box(rc, margin, gx + 3 * g, gsize[3 * g], m->tbox_pos + 3 * b, m->tbox_mat + 9 * b, m->tbox_size + 3 * b);
+      else if (m->geom_type[g] == MJLAB_GEOM_CAPSULE)
+        n = capsule_box(rc, margin, gx + 3 * g, gm + 9 * g, gsize + 3 * g, m->tbox_pos + 3 * b, m->tbox_mat + 9 * b, m->tbox_size + 3 * b);
+      if (n) emit_contacts(m, d, w, g, m->tbox_geom[b], margin, gap, rc, n, &ncon);
     }
   }
   d->ncon[w] = ncon;

@@ -1,0 +1,199 @@
+"""Box-terrain collision on the GPU vs the CPU oracle: sphere /
+capsule vs static boxes through the grid broadphase, through the Simulation boundary / C ABI."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_parity import KIN, VEL, _np, _rel  # noqa: E402
+from test_terrain_collision import probes_on  # noqa: E402
+
+from mjlab_amd import robots, terrains  # noqa: E402
+from oracle.oracle import OracleSim  # noqa: E402
+
+
+def _sims(model, nworld, njmax=300, graph=False):
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  return Simulation(nworld, SimulationCfg(njmax=njmax, use_graph=graph), model, "cuda:0"), OracleSim(model, nworld, njmax=njmax)
+
+
+def _set(sim, ora, **fields):
+  import torch
+
+  for f, v in fields.items():
+    getattr(sim.data, f)[:] = torch.from_numpy(np.asarray(v, dtype=np.float32)).cuda()
+    getattr(ora, f)[:] = v
+
+
+def _contacts_match(sim, ora, tol=2e-5, ftol=1e-4):
+  ncon = _np(sim.data.ncon).ravel()
+  assert np.array_equal(ncon, ora.ncon.ravel())
+  assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
+  gd, gp, gf, gg = (_np(getattr(sim.data, f)) for f in ("contact_dist", "contact_pos", "contact_frame", "contact_geom"))
+  for w in range(sim.num_envs):
+    n = int(ncon[w])
+    assert np.array_equal(gg[w, :n], ora.contact_geom[w, :n])  # same pairs in the same order
+    assert np.abs(gd[w, :n] - ora.contact_dist[w, :n]).max(initial=0) < tol
+    assert np.abs(gp[w, :n] - ora.contact_pos[w, :n]).max(initial=0) < tol * max(1.0, np.abs(ora.contact_pos[w, :n]).max(initial=0))
+    assert np.abs(gf[w, :n].reshape(n, 9) - ora.contact_frame[w, :n].reshape(n, 9)).max(initial=0) < ftol
+
+
+def _probe_states(t, nw, seed):
+  r = np.random.default_rng(seed)
+  b = t.boxes[r.integers(0, len(t.boxes), size=(nw, 2))]
+  p = b[..., :3] + r.uniform(-1.05, 1.05, size=(nw, 2, 3)) * b[..., 3:]
+  p[..., 2] = b[..., 2] + b[..., 5] + r.uniform(-0.02, 0.12, size=(nw, 2))
+  qpos = np.zeros((nw, 14))
+  qpos[:, 0:3], qpos[:, 7:10] = p[:, 0], p[:, 1]
+  q = r.normal(size=(nw, 4))
+  qpos[:, 3] = 1
+  qpos[:, 10:14] = q / np.linalg.norm(q, axis=1, keepdims=True)
+  return qpos
+
+
+def test_probes_on_random_terrain_forward_and_rollout():
+  cfg = terrains.rough_terrains_cfg(seed=5, num_rows=3, num_cols=5)
+  cfg.border_width = 2.0
+  t = terrains.TerrainGenerator(cfg).generate()
+  model = probes_on(t.boxes)
+  nw = 256
+  sim, ora = _sims(model, nw)
+  _set(sim, ora, qpos=_probe_states(t, nw, 2), qvel=np.random.default_rng(3).normal(scale=0.2, size=(nw, 12)))
+  sim.forward()
+  ora.forward()
+  assert ora.ncon.sum() > 150
+  _contacts_match(sim, ora)
+  # exact corner / edge configurations sit on decision boundaries of the Newton iteration count;
+  # compare accelerations in the bulk and require every world to be close
+  assert np.quantile(np.abs(_np(sim.data.qacc) - ora.qacc).max(axis=1) / np.maximum(1.0, np.abs(ora.qacc).max(axis=1)), 0.95) < 1e-3
+  for _ in range(20):
+    sim.step()
+  ora.step(20)
+  err = np.abs(_np(sim.data.qpos) - ora.qpos).max(axis=1)
+  assert np.quantile(err, 0.95) < 1e-4 and np.isfinite(_np(sim.data.qpos)).all()
+
+
+def _rough_states(model, nw, seed, spread=1.8):
+  rng = np.random.default_rng(seed)
+  qpos = np.tile(model.key_qpos[0], (nw, 1))
+  rows, cols = rng.integers(0, 10, nw), np.arange(nw) * 20 // nw
+  qpos[:, :3] += model.terrain_origins[rows, cols]
+  qpos[:, 0:2] += rng.uniform(-spread, spread, (nw, 2))
+  qpos[:, 2] -= rng.uniform(0.0, 0.04, nw)
+  qpos[:, 7:] += rng.normal(scale=0.1, size=(nw, model.nq - 7))
+  yaw = rng.uniform(-3.14, 3.14, nw)
+  qpos[:, 3], qpos[:, 4:6], qpos[:, 6] = np.cos(yaw / 2), 0.0, np.sin(yaw / 2)
+  return qpos, rng.normal(scale=0.3, size=(nw, model.nv))
+
+
+def test_g1_rough_forward_all_fields():
+  model = robots.load_model("g1_velocity_rough")
+  nw = 64
+  sim, ora = _sims(model, nw)
+  qpos, qvel = _rough_states(model, nw, 0)
+  _set(sim, ora, qpos=qpos, qvel=qvel, ctrl=np.tile(model.key_ctrl[0], (nw, 1)))
+  sim.forward()
+  ora.forward()
+  assert (ora.ncon > 0).mean() > 0.8
+  # frames: the foot capsules are 1 cm thin and up to ~100 m from the world origin, where fp32
+  # coordinates resolve 7.6 um: the direction of a ~1 cm clamped-point -> centre vector at an edge
+  # is good to ~1e-3 (same for any fp32 engine working in world coordinates)
+  _contacts_match(sim, ora, tol=5e-5, ftol=3e-3)
+  # quantities built from DIFFERENCES of world positions (offsets from the subtree CoM) inherit the
+  # 7.6 um resolution of fp32 coordinates ~100 m from the origin: ~1e-5 relative instead of 1e-6
+  far = ("cinert", "cdof", "qM")
+  for f in KIN:
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < (5e-5 if f in far else 2e-6), f
+  for f in VEL:
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-4, f
+  nv = model.nv
+  for w in range(nw):
+    n = int(ora.nefc[w, 0])
+    assert _rel(_np(sim.data.efc_J)[w].reshape(-1, nv)[:n], ora.efc_J[w].reshape(-1, nv)[:n]) < 3e-3  # rows inherit the edge-normal resolution (ftol above)
+  qa, qo = _np(sim.data.qacc), ora.qacc
+  assert np.quantile(np.abs(qa - qo).max(axis=1) / np.abs(qo).max(axis=1), 0.9) < 1e-3
+  assert np.array_equal(_np(sim.data.sensordata), ora.sensordata.astype(np.float32))
+  # terrain geoms keep the poses written at construction
+  gx = _np(sim.data.geom_xpos)
+  np.testing.assert_allclose(gx[:, : model.nterrain], np.broadcast_to(model.tbox_pos, (nw, model.nterrain, 3)), atol=1e-5)
+
+
+def test_g1_rough_rollout_tracks_oracle():
+  model = robots.load_model("g1_velocity_rough")
+  nw = 32
+  sim, ora = _sims(model, nw, graph=True)
+  qpos, qvel = _rough_states(model, nw, 1, spread=0.3)
+  _set(sim, ora, qpos=qpos, qvel=qvel * 0.2, ctrl=np.tile(model.key_ctrl[0], (nw, 1)))
+  for _ in range(10):
+    sim.step()
+  ora.step(10)
+  err = np.abs(_np(sim.data.qpos) - ora.qpos).max(axis=1)
+  assert np.quantile(err, 0.9) < 5e-5, err
+  assert np.isfinite(_np(sim.data.qvel)).all()
+
+
+def test_g1_on_a_flat_slab_equals_g1_on_the_plane_gpu():
+  """Flat sub-terrain vs ground plane on the device: same accelerations, same roll-out."""
+  rough, flat = robots.load_model("g1_velocity_rough"), robots.load_model("g1_velocity_flat")
+  nw = 32
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  # columns 0..7 of the curriculum grid are flat slabs (top at z = 0)
+  rng = np.random.default_rng(4)
+  qpos = np.tile(flat.key_qpos[0], (nw, 1))
+  qpos[:, 2] -= rng.uniform(0.0, 0.03, nw)
+  qpos[:, 7:] += rng.normal(scale=0.1, size=(nw, flat.nq - 7))
+  qvel = rng.normal(scale=0.3, size=(nw, flat.nv))
+  origin = rough.terrain_origins[rng.integers(0, 10, nw), rng.integers(0, 8, nw)]
+  assert np.all(origin[:, 2] == 0)
+  import torch
+
+  res = []
+  for model, shift in ((rough, origin), (flat, 0 * origin)):
+    sim = Simulation(nw, SimulationCfg(njmax=300), model, "cuda:0")
+    q = qpos.copy()
+    q[:, :3] += shift
+    sim.data.qpos[:] = torch.from_numpy(q.astype(np.float32)).cuda()
+    sim.data.qvel[:] = torch.from_numpy(qvel.astype(np.float32)).cuda()
+    sim.data.ctrl[:] = torch.from_numpy(np.tile(flat.key_ctrl[0], (nw, 1)).astype(np.float32)).cuda()
+    sim.forward()
+    qacc = _np(sim.data.qacc).copy()
+    ncon = _np(sim.data.ncon).copy()
+    for _ in range(40):
+      sim.step()
+    q1 = _np(sim.data.qpos).copy()
+    q1[:, :3] -= shift
+    res.append((ncon, qacc, q1))
+  (nb, ab, qb), (npl, ap, qp) = res
+  assert np.array_equal(nb.ravel(), npl.ravel()) and (nb > 4).mean() > 0.7
+  assert np.quantile(np.abs(ab - ap).max(axis=1) / np.abs(ap).max(axis=1), 0.9) < 2e-3
+  # positions are offset by up to ~100 m on the rough map: fp32 resolution there is ~1e-5
+  assert np.quantile(np.abs(qb - qp).max(axis=1), 0.9) < 2e-3
+
+
+def test_rough_fullsize_rollout_is_stable():
+  """4096 G1s over the whole 200-tile map, random actions, resets on: finite, above the terrain,
+  contact capacity respected."""
+  import torch
+
+  from mjlab_amd.rollout import PhysicsRollout, g1_action_scale
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = robots.load_model("g1_velocity_rough")
+  sim = Simulation(4096, SimulationCfg(njmax=300), model, "cuda:0")
+  ro = PhysicsRollout(sim, g1_action_scale(model), seed=3)
+  assert ro.env_origins is not None and ro.env_origins.shape == (4096, 3)
+  nreset = 0
+  for _ in range(60):
+    nreset += int(ro.step(ro.random_action()).sum())
+  torch.cuda.synchronize()
+  qpos = _np(sim.data.qpos)
+  assert np.isfinite(qpos).all() and np.isfinite(_np(sim.data.qvel)).all()
+  assert (_np(sim.data.ncon) <= sim.nconmax).all() and (_np(sim.data.nefc) <= sim.njmax).all()
+  assert (_np(sim.data.ncon) > 0).mean() > 0.6  # freshly reset robots start a few cm above the ground
+  # heights above the own tile's spawn origin stay in a sane band (nobody fell through or flew off)
+  rel_z = qpos[:, 2] - ro.env_origins[:, 2].cpu().numpy()
+  assert (rel_z > -1.2).all() and (rel_z < 1.5).all()
+  assert nreset < 4096  # not everybody falls within 1.2 s

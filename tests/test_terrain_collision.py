@@ -1,0 +1,279 @@
+"""Box-terrain collision of the CPU oracle: sphere / capsule vs static boxes through the grid
+broadphase.  Analytic cases, equivalence with the ground plane on a flat slab, broadphase vs
+exhaustive search, and the rough-terrain G1 scene."""
+
+import numpy as np
+import pytest
+
+from mjlab_amd import mjcf, robots, terrains
+from mjlab_amd.mjcf import GEOM_BOX, Spec
+from oracle.oracle import OracleSim
+
+BODIES_XML = """
+<mujoco model="probes">
+  <compiler angle="radian"/>
+  <option timestep="0.002"/>
+  <worldbody>
+    <body name="ball" pos="0 0 1">
+      <inertial pos="0 0 0" mass="1" diaginertia="0.004 0.004 0.004"/>
+      <freejoint name="ball_root"/>
+      <geom name="ball_geom" type="sphere" size="0.1"/>
+    </body>
+    <body name="cap" pos="2 0 1" quat="0.707107 0 0.707107 0">
+      <inertial pos="0 0 0" mass="1" diaginertia="0.02 0.02 0.002"/>
+      <freejoint name="cap_root"/>
+      <geom name="cap_geom" type="capsule" size="0.05 0.2"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def probes_on(boxes, plane=False) -> mjcf.Model:
+  """Free sphere (r 0.1) + free capsule (r 0.05, half length 0.2, axis along x) over static boxes."""
+  spec = Spec.from_string(BODIES_XML)
+  spec.option.integrator = mjcf.INT_IMPLICITFAST
+  scene = Spec()
+  scene.option = spec.option
+  t = scene.add_body("terrain")
+  if plane:
+    scene.add_geom(t, "terrain", mjcf.GEOM_PLANE, (0, 0, 0.01))
+  else:
+    terrains.add_boxes(scene, t, np.asarray(boxes, dtype=np.float64))
+  scene.attach(spec)
+  return scene.compile()
+
+
+SLAB = [[0, 0, -0.5, 20, 20, 0.5]]  # top face at z = 0
+
+
+def contacts(o, w=0):
+  n = int(o.ncon[w, 0])
+  return dict(n=n, dist=o.contact_dist[w, :n], pos=o.contact_pos[w, :n], frame=o.contact_frame[w, :n], geom=o.contact_geom[w, :n])
+
+
+def test_sphere_on_face_edge_corner_and_inside():
+  m = probes_on([[0, 0, -0.5, 1, 1, 0.5]])
+  o = OracleSim(m, nworld=5)
+  o.qpos[:, 7:10] = [50, 0, 5]  # capsule out of the way
+  o.qpos[:, 3] = o.qpos[:, 10] = 1
+  r = 0.1
+  o.qpos[0, :3] = [0.2, -0.3, 0.08]  # over the top face, 2 cm deep
+  o.qpos[1, :3] = [1.05, 0.0, 0.05]  # beyond the +x edge, diagonal normal
+  o.qpos[2, :3] = [1.04, 1.04, 0.04]  # beyond the (+x, +y, +z) corner
+  o.qpos[3, :3] = [0.3, 0.2, -0.01]  # centre inside the box, nearest face = top
+  o.qpos[4, :3] = [0.0, 0.0, 0.2]  # clear of the box
+  o.forward()
+  c = contacts(o, 0)
+  assert c["n"] == 1 and np.isclose(c["dist"][0], -0.02)
+  np.testing.assert_allclose(c["frame"][0, :3], [0, 0, -1], atol=1e-12)  # from the sphere into the box
+  np.testing.assert_allclose(c["pos"][0], [0.2, -0.3, -0.01], atol=1e-12)  # midway between the surfaces
+  assert tuple(c["geom"][0]) == (m.names["geom"].index("ball_geom"), m.names["geom"].index("terrain_0"))
+  c = contacts(o, 1)
+  d = np.array([0.05, 0.0, 0.05])
+  assert c["n"] == 1 and np.isclose(c["dist"][0], np.linalg.norm(d) - r)
+  np.testing.assert_allclose(c["frame"][0, :3], -d / np.linalg.norm(d), atol=1e-12)
+  c = contacts(o, 2)
+  d = np.array([0.04, 0.04, 0.04])
+  assert c["n"] == 1 and np.isclose(c["dist"][0], np.linalg.norm(d) - r)
+  np.testing.assert_allclose(c["frame"][0, :3], -d / np.linalg.norm(d), atol=1e-12)
+  c = contacts(o, 3)
+  assert c["n"] == 1 and np.isclose(c["dist"][0], -0.01 - r)
+  np.testing.assert_allclose(c["frame"][0, :3], [0, 0, -1], atol=1e-12)
+  assert contacts(o, 4)["n"] == 0
+
+
+def test_capsule_on_face_matches_plane_capsule():
+  """Over a face the capsule's contacts are plane_capsule's two end-point contacts."""
+  mb, mp = probes_on(SLAB), probes_on(None, plane=True)
+  rng = np.random.default_rng(0)
+  for _ in range(20):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    z = rng.uniform(0.0, 0.3)
+    res = []
+    for m in (mb, mp):
+      o = OracleSim(m, nworld=1)
+      o.qpos[0, :3] = [50, 0, 5]
+      o.qpos[0, 3] = 1
+      o.qpos[0, 7:10] = [rng.uniform(-1, 1) * 0, 0, z]
+      o.qpos[0, 10:14] = q
+      o.forward()
+      res.append(contacts(o))
+    b, p = res
+    assert b["n"] == p["n"]
+    if b["n"]:
+      np.testing.assert_allclose(b["dist"], p["dist"], atol=1e-12)
+      np.testing.assert_allclose(b["pos"], p["pos"], atol=1e-12)
+      np.testing.assert_allclose(b["frame"][:, :3], -p["frame"][:, :3], atol=1e-12)  # geom1 -> geom2 flips
+
+
+def test_capsule_across_an_edge_and_a_ridge():
+  # capsule along x, centred on the +x edge of a 1 m box: one end over the top face, one in the air
+  m = probes_on([[0, 0, -0.5, 1, 1, 0.5]])
+  o = OracleSim(m, nworld=2)
+  o.qpos[:, :3] = [50, 0, 5]
+  o.qpos[:, 3] = 1
+  o.qpos[0, 7:10] = [1.0, 0.0, 0.04]  # axis spans x in [0.8, 1.2], 1 cm deep
+  o.qpos[0, 10:14] = [0.707107, 0, 0.707107, 0]
+  o.forward()
+  c = contacts(o, 0)
+  # the end over the face and the point where the axis leaves the face (x = 1), both 1 cm deep
+  assert c["n"] == 2
+  np.testing.assert_allclose(np.sort(c["pos"][:, 0]), [0.8, 1.0], atol=1e-5)
+  np.testing.assert_allclose(c["dist"], -0.01, atol=1e-6)
+  np.testing.assert_allclose(c["frame"][:, :3], [[0, 0, -1]] * 2, atol=1e-5)
+  # thin ridge (2 cm wide) crossed at right angles by the capsule: one contact in the middle
+  m = probes_on([[0, 0, -0.5, 0.01, 1, 0.5]])
+  o = OracleSim(m, nworld=1)
+  o.qpos[0, :3] = [50, 0, 5]
+  o.qpos[0, 3] = 1
+  o.qpos[0, 7:10] = [0.0, 0.0, 0.045]
+  o.qpos[0, 10:14] = [0.707107, 0, 0.707107, 0]
+  o.forward()
+  c = contacts(o)
+  assert c["n"] == 2  # both ends of the 2 cm support interval
+  np.testing.assert_allclose(np.sort(c["pos"][:, 0]), [-0.01, 0.01], atol=1e-5)
+  np.testing.assert_allclose(c["dist"], -0.005, atol=1e-6)
+
+
+def test_sphere_and_capsule_come_to_rest_on_a_box():
+  m = probes_on([[0, 0, -0.5, 5, 5, 0.5]])
+  o = OracleSim(m, nworld=1)
+  o.qpos[0, :3] = [0.3, 0.2, 0.15]
+  o.qpos[0, 3] = 1
+  o.qpos[0, 7:10] = [2.0, 0.1, 0.1]
+  o.qpos[0, 10:14] = [0.707107, 0, 0.707107, 0]
+  o.step(1500)
+  assert abs(o.qpos[0, 2] - 0.1) < 2e-3 and abs(o.qpos[0, 9] - 0.05) < 2e-3
+  assert np.abs(o.qvel).max() < 1e-3
+  # contact forces carry the weight: total normal force = (m1 + m2) g
+  o.forward()
+  assert np.isclose(o.qfrc_constraint[0, 2] + o.qfrc_constraint[0, 8], 2 * 9.81, rtol=1e-3)
+
+
+def test_grid_broadphase_equals_exhaustive_search(monkeypatch):
+  """Same terrain compiled with 0.5 m cells and with one huge cell (every box a candidate of
+  every geom) gives identical contacts."""
+  cfg = terrains.rough_terrains_cfg(seed=5, num_rows=3, num_cols=5)
+  cfg.border_width = 2.0
+  t = terrains.TerrainGenerator(cfg).generate()
+  m_grid = probes_on(t.boxes)
+  monkeypatch.setattr(mjcf, "TERRAIN_CELL", 1000.0)
+  m_all = probes_on(t.boxes)
+  assert m_grid.tgrid_nx > 10 and m_all.tgrid_nx == 1 and m_all.tgrid_ny == 1
+  rng = np.random.default_rng(1)
+  nw = 64
+  og, oa = OracleSim(m_grid, nworld=nw), OracleSim(m_all, nworld=nw)
+  for o in (og, oa):
+    r = np.random.default_rng(2)
+    # probes near the surface of randomly chosen boxes (on top, beside, across edges)
+    b = t.boxes[r.integers(0, len(t.boxes), size=(nw, 2))]
+    p = b[..., :3] + r.uniform(-1.05, 1.05, size=(nw, 2, 3)) * b[..., 3:]
+    p[..., 2] = b[..., 2] + b[..., 5] + r.uniform(-0.02, 0.12, size=(nw, 2))
+    o.qpos[:, 0:3], o.qpos[:, 7:10] = p[:, 0], p[:, 1]
+    q = r.normal(size=(nw, 4))
+    o.qpos[:, 3] = 1
+    o.qpos[:, 10:14] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    o.forward()
+  assert og.ncon.sum() > 40 and (og.ncon > 0).mean() > 0.5
+  np.testing.assert_array_equal(og.ncon, oa.ncon)
+  for f in ("contact_dist", "contact_pos", "contact_frame", "contact_geom", "efc_J", "qacc"):
+    np.testing.assert_array_equal(getattr(og, f), getattr(oa, f))
+  del rng
+
+
+def g1_on_slab() -> mjcf.Model:
+  sensors = tuple(
+    robots.ContactSensorCfg(name=f"{s}_foot_ground_contact", body1=f"{s}_ankle_roll_link", body2="terrain", num=1, data=("found",), reduce="netforce")
+    for s in ("left", "right")
+  )
+  cfg = terrains.TerrainGeneratorCfg(size=(8.0, 8.0), seed=0, sub_terrains={"flat": terrains.BoxFlatTerrainCfg()})
+  spec = robots.build_scene(robots.g1_spec(sensors), robots.G1_KNEES_BENT, cfg)
+  for s in spec.sensors:
+    if s.refname == "robot/terrain":
+      s.refname = "terrain"
+  robots._task_options(spec)
+  return spec.compile()
+
+
+@pytest.mark.skipif(not robots.REFERENCE_ROOT.exists(), reason="needs the reference robot MJCF")
+def test_g1_on_a_flat_slab_equals_g1_on_the_plane():
+  """The flat sub-terrain (a 1 m slab whose top is z = 0) must give the physics of the ground
+  plane: same contact count, depths and points, same accelerations and sensor readings."""
+  mb = g1_on_slab()
+  mp = robots.load_model("g1_velocity_flat")
+  assert mb.nterrain == 1 and mb.ntgeom == 33 and mb.npair == mp.npair - 33
+  rng = np.random.default_rng(3)
+  nw = 16
+  qpos = np.tile(mp.key_qpos[0], (nw, 1))
+  qpos[:, 2] -= rng.uniform(0.0, 0.03, nw)
+  qpos[:, 7:] += rng.normal(scale=0.1, size=(nw, mp.nq - 7))
+  qpos[:, 0:2] += rng.uniform(-2, 2, (nw, 2))  # the slab spans [-4, 4] x [-4, 4]
+  qvel = rng.normal(scale=0.3, size=(nw, mp.nv))
+  res = []
+  for m in (mb, mp):
+    o = OracleSim(m, nworld=nw, njmax=300)
+    o.qpos[:], o.qvel[:], o.ctrl[:] = qpos, qvel, m.key_ctrl[0]
+    o.forward()
+    res.append(o)
+  b, p = res
+  np.testing.assert_array_equal(b.ncon, p.ncon)
+  assert b.ncon.min() > 4
+  np.testing.assert_array_equal(b.nefc, p.nefc)
+  # the plane pairs come first in the flat scene, the terrain contacts last in the slab scene:
+  # compare as sets of (depth, point)
+  for w in range(nw):
+    n = int(b.ncon[w, 0])
+    kb = np.concatenate([b.contact_dist[w, :n, None], b.contact_pos[w, :n]], axis=1)
+    kp = np.concatenate([p.contact_dist[w, :n, None], p.contact_pos[w, :n]], axis=1)
+    np.testing.assert_allclose(kb[np.lexsort(kb.T)], kp[np.lexsort(kp.T)], atol=1e-10)
+  np.testing.assert_allclose(b.qacc, p.qacc, rtol=1e-6, atol=1e-6)
+  np.testing.assert_allclose(b.sensordata, p.sensordata, atol=1e-9)
+  # ... and over a roll-out
+  for o in res:
+    for _ in range(100):
+      o.step(1)
+  np.testing.assert_allclose(b.qpos, p.qpos, atol=1e-5)
+
+
+def test_g1_rough_scene_model():
+  m = robots.load_model("g1_velocity_rough")
+  assert m.nterrain == 3564 and m.ngeom == 3564 + 68 and m.nstaticgeom == 3564 and m.geom_lds0 == 3564
+  assert m.ntgeom == 33 and m.npair == 469  # robot self pairs only: the terrain is reached through the grid
+  assert m.terrain_origins.shape == (10, 20, 3)
+  # grid covers every box footprint; items ascending inside a cell; cell0 is the lowest cell
+  assert m.tgrid_start[-1] == m.ntitem == len(m.tgrid_item)
+  for c in np.random.default_rng(0).integers(0, m.ntcellp1 - 1, 200):
+    it = m.tgrid_item[m.tgrid_start[c] : m.tgrid_start[c + 1]]
+    assert (np.diff(it) > 0).all()
+    ix, iy = divmod(int(c), m.tgrid_ny)
+    assert (m.tbox_cell0[it, 0] <= ix).all() and (m.tbox_cell0[it, 1] <= iy).all()
+  np.testing.assert_array_equal(m.geom_type[m.tbox_geom], GEOM_BOX)
+
+
+def test_g1_stands_and_walks_off_steps_on_rough_terrain():
+  m = robots.load_model("g1_velocity_rough")
+  nw = 12
+  o = OracleSim(m, nworld=nw, njmax=300)
+  o.reset(key=0)
+  rng = np.random.default_rng(0)
+  rows, cols = rng.integers(0, 10, nw), np.arange(nw) * 20 // nw
+  o.qpos[:, :3] += m.terrain_origins[rows, cols]
+  o.qpos[:, 0:2] += rng.uniform(-1.8, 1.8, (nw, 2))  # also off the central platform, onto the steps
+  for _ in range(160):
+    o.ctrl[:] = m.key_ctrl[0]
+    o.step(1)
+  assert np.isfinite(o.qpos).all() and np.isfinite(o.qvel).all()
+  assert (o.ncon[:, 0] > 0).all()
+  assert (o.nefc[:, 0] <= 300).all()
+  # nobody fell through the terrain: pelvis above the local surface
+  top = []
+  for w in range(nw):
+    p = o.qpos[w, :2]
+    inside = np.all(np.abs(m.tbox_pos[:, :2] - p) <= m.tbox_size[:, :2], axis=1)
+    top.append((m.tbox_pos[inside, 2] + m.tbox_size[inside, 2]).max())
+  height = o.qpos[:, 2] - np.array(top)
+  assert (height > 0.05).all() and (height > 0.5).mean() > 0.7  # a PD-only robot may sit down on a step edge
+  # the foot sensors see the terrain body
+  assert (o.sensordata.sum(axis=1) >= 1).mean() > 0.7
