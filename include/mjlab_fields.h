@@ -101,7 +101,8 @@
   X(actuator_gear, 6, nu)                                                       \
   X(tbox_pos, 3, nterrain)  /* terrain boxes in the WORLD frame (static, never per world) */ \
   X(tbox_mat, 9, nterrain)                                                      \
-  X(tbox_size, 3, nterrain)
+  X(tbox_size, 3, nterrain)                                                     \
+  X(tgrid_ztop, 1, ntcell) /* highest box top in the cell: geoms wholly above it skip the cell */
 
 /* ---- data: real, leading dimension nworld ------------------------------------ */
 #define MJLAB_DATA_REAL_FIELDS(X)                                               \
@@ -191,7 +192,7 @@ typedef struct mjlab_sizes {
    * construction); the collision stage stages geoms [geom_lds0, ngeom) on chip */
   int nstaticgeom, geom_lds0;
   /* box terrain (static colliding boxes) and its uniform xy broadphase grid */
-  int nterrain, ntgeom, ntcellp1, ntitem, tgrid_nx, tgrid_ny;
+  int nterrain, ntgeom, ntcell, ntcellp1, ntitem, tgrid_nx, tgrid_ny;
 } mjlab_sizes_t;
 
 /* terrain boxes kept per moving geom and step: the MJLAB_TCAND_MAX with the smallest ids */

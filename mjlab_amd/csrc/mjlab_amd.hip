@@ -971,6 +971,7 @@ __device__ __forceinline__ int terrain_walk(const Model& m, const float* centre,
   for (int ix = ix0; ix <= ix1; ++ix)
     for (int iy = iy0; iy <= iy1; ++iy) {
       const int c = ix * ny + iy;
+      if (centre[2] - reach > m.tgrid_ztop[c]) continue;  // wholly above everything in this cell
       const int kend = m.tgrid_start[c + 1];
       for (int k = m.tgrid_start[c]; k < kend; ++k) {
         const int b = m.tgrid_item[k];

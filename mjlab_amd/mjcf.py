@@ -710,7 +710,7 @@ class Model:
           setattr(m.opt, name, tuple(val) if isinstance(val, list) else val)
         elif kind == "n":
           m.names[name] = [str(s) for s in v.tolist()]
-    if not hasattr(m, "nterrain"):  # saved before the static-geometry / terrain fields existed
+    if not hasattr(m, "tgrid_ztop"):  # saved before the static-geometry / terrain fields existed
       static = m.body_weldid[m.geom_bodyid] == 0
       m.nstaticgeom = int(np.argmin(static)) if not static.all() else m.ngeom
       m.geom_lds0 = int(min(m.nstaticgeom, m.pair_geom.min())) if m.npair else m.nstaticgeom
@@ -760,8 +760,9 @@ def _compile_terrain(m: "Model", tids: np.ndarray, moving: list[int]) -> None:
   m.tgrid_nx = m.tgrid_ny = 0
   m.tgrid_x0 = m.tgrid_y0 = 0.0
   m.tgrid_cell = TERRAIN_CELL
+  m.tgrid_ztop = np.zeros(0)
   if nt == 0:
-    m.ntgeom, m.ntcellp1, m.ntitem = 0, 1, 0
+    m.ntgeom, m.ntcell, m.ntcellp1, m.ntitem = 0, 0, 1, 0
     return
   if np.any(m.geom_margin[tids] != 0) or np.any(m.geom_gap[tids] != 0):
     raise NotImplementedError("terrain boxes must have margin = gap = 0")
@@ -803,7 +804,11 @@ def _compile_terrain(m: "Model", tids: np.ndarray, moving: list[int]) -> None:
   m.tgrid_start = np.searchsorted(cells[order], np.arange(nx * ny + 1)).astype(np.int32)
   m.tbox_cell0 = np.stack([ix0, iy0], axis=1).astype(np.int32)
   m.tgrid_nx, m.tgrid_ny, m.tgrid_x0, m.tgrid_y0 = nx, ny, x0, y0
-  m.ntcellp1, m.ntitem = nx * ny + 1, int(m.tgrid_item.size)
+  m.ntcell, m.ntcellp1, m.ntitem = nx * ny, nx * ny + 1, int(m.tgrid_item.size)
+  # highest box top per cell (-inf-like for empty cells): a geom whose bounding sphere is wholly
+  # above it cannot reach any box of the cell
+  m.tgrid_ztop = np.full(nx * ny, -1.0e30)
+  np.maximum.at(m.tgrid_ztop, cells, hi[items, 2])
 
 
 def _compile(spec: Spec) -> Model:

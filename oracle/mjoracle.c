@@ -194,8 +194,9 @@ static void kinematics(const mjo_model_t* m, mjo_data_t* d, int w) {
   for (int i = 0; i < s->nbody; i++)
     local2global(xipos + 3 * i, ximat + 9 * i, xpos + 3 * i, xquat + 4 * i, xmat + 9 * i,
                  MF(body_ipos, w) + 3 * i, MF(body_iquat, w) + 4 * i);
+  /* geoms of static bodies (the first nstaticgeom) are posed once, by mjo_static_geoms() */
   real *gx = D(geom_xpos, 3 * s->ngeom), *gm = D(geom_xmat, 9 * s->ngeom);
-  for (int g = 0; g < s->ngeom; g++) {
+  for (int g = s->nstaticgeom; g < s->ngeom; g++) {
     int b = m->geom_bodyid[g];
     local2global(gx + 3 * g, gm + 9 * g, xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, MF(geom_pos, w) + 3 * g,
                  MF(geom_quat, w) + 4 * g);
@@ -611,6 +612,7 @@ static int terrain_candidates(const mjo_model_t* m, const real* centre, real rea
   for (int ix = ix0; ix <= ix1; ix++)
     for (int iy = iy0; iy <= iy1; iy++) {
       const int c = ix * ny + iy;
+      if (centre[2] - reach > m->tgrid_ztop[c]) continue; /* wholly above everything in this cell */
       for (int k = m->tgrid_start[c]; k < m->tgrid_start[c + 1]; k++) {
         const int b = m->tgrid_item[k];
         const int bx = m->tbox_cell0[2 * b], by = m->tbox_cell0[2 * b + 1];
@@ -1258,6 +1260,31 @@ static void* worker(void* arg) {
     }
   return 0;
 }
+/* Poses of the static geoms (world / terrain bodies) of every world; to be called once after the
+ * data arrays are (re)initialised -- the per-step kinematics skips them, like the HIP path. */
+void mjo_static_geoms(const mjo_model_t* m, mjo_data_t* d) {
+  const mjlab_sizes_t* s = &m->size;
+  for (int w = 0; w < s->nworld; w++) {
+    real *gx = D(geom_xpos, 3 * s->ngeom), *gm = D(geom_xmat, 9 * s->ngeom);
+    for (int g = 0; g < s->nstaticgeom; g++) {
+      /* static bodies: compose the (constant) chain up to the world */
+      real pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0}, mat[9];
+      int chain[64], n = 0;
+      for (int b = m->geom_bodyid[g]; b > 0 && n < 64; b = m->body_parentid[b]) chain[n++] = b;
+      for (int k = n - 1; k >= 0; k--) {
+        real p[3], q[4];
+        rot_vec_quat(p, MF(body_pos, w) + 3 * chain[k], quat);
+        for (int i = 0; i < 3; i++) pos[i] += p[i];
+        mul_quat(q, quat, MF(body_quat, w) + 4 * chain[k]);
+        normalize4(q);
+        memcpy(quat, q, sizeof(q));
+      }
+      quat2mat(mat, quat);
+      local2global(gx + 3 * g, gm + 9 * g, pos, quat, mat, MF(geom_pos, w) + 3 * g, MF(geom_quat, w) + 4 * g);
+    }
+  }
+}
+
 /* runs `nstep` steps (or one forward when nstep == 0) on every world with `nthread` threads */
 void mjo_run(const mjo_model_t* m, mjo_data_t* d, int nstep, int nthread) {
   int nw = m->size.nworld;

@@ -95,6 +95,7 @@ class OracleSim:
     if key is not None:
       self.qvel[:] = m.key_qvel[key]
       self.ctrl[:] = m.key_ctrl[key]
+    self.lib.mjo_static_geoms(ctypes.byref(self._m), ctypes.byref(self._d))
 
   def forward(self, nthread: int = 1) -> None:
     self.lib.mjo_run(ctypes.byref(self._m), ctypes.byref(self._d), 0, nthread)
