@@ -1,7 +1,7 @@
 """Procedural box terrains and environment origins (host side, numpy only).
 
 Restates what the rough-terrain tasks of the reference put under the ``terrain`` body
-(reference src/mjlab/terrains/terrain_generator.py:62-250, primitive_terrains.py:52-377,
+(reference src/mjlab/terrains/terrain_generator.py:62-250, primitive_terrains.py:52-639,
 utils.py:11-108, config.py:7-57) and how environments are placed on it
 (terrain_importer.py:196-240).  Every terrain piece is an axis-aligned static box; the
 physics step collides robot geoms against them through a uniform-grid broadphase
@@ -127,6 +127,70 @@ class BoxInvertedPyramidStairsTerrainCfg(BoxPyramidStairsTerrainCfg):
     w = self.step_width
     boxes.append(_box(sx / 2.0, sy / 2.0, -total - h / 2.0, inner[0] - 2 * nsteps * w, inner[1] - 2 * nsteps * w, h))
     return np.array(boxes), np.array([sx / 2.0, sy / 2.0, -(nsteps + 1) * h])
+
+
+@dataclass(kw_only=True)
+class BoxRandomGridTerrainCfg(SubTerrainCfg):
+  """Grid of columns with random heights around a central platform
+  (primitive_terrains.py:379-639): four border strips, then the columns -- individually, or
+  greedily merged into rectangles of equal quantised height -- then the platform."""
+
+  grid_width: float
+  grid_height_range: tuple[float, float]
+  platform_width: float = 1.0
+  holes: bool = False
+  merge_similar_heights: bool = False
+  height_merge_threshold: float = 0.05
+  max_merge_distance: int = 3
+
+  def function(self, difficulty, rng):
+    sx, sy = self.size
+    if sx != sy:
+      raise ValueError(f"The terrain must be square. Received size: {self.size}.")
+    gh = self.grid_height_range[0] + difficulty * (self.grid_height_range[1] - self.grid_height_range[0])
+    nx, ny = int(sx / self.grid_width), int(sy / self.grid_width)
+    depth = 1.0  # the columns reach 1 m below z = 0
+    border = sx - min(nx, ny) * self.grid_width
+    if border <= 0:
+      raise RuntimeError("Border width must be greater than 0! Adjust the parameter 'self.grid_width'.")
+    bt = border / 2
+    zc = -depth / 2
+    inner_y = sy - 2 * bt
+    boxes = [
+      _box(sx / 2, sy - bt / 2, zc, sx, bt, depth),
+      _box(sx / 2, bt / 2, zc, sx, bt, depth),
+      _box(bt / 2, sx / 2, zc, bt, inner_y, depth),
+      _box(sx - bt / 2, sx / 2, zc, bt, inner_y, depth),
+    ]
+    hmap = rng.uniform(-gh, gh, (nx, ny))
+    gw = self.grid_width
+    if self.merge_similar_heights and not self.holes:
+      q = np.round(hmap / self.height_merge_threshold) * self.height_merge_threshold
+      done = np.zeros((nx, ny), dtype=bool)
+      for i in range(nx):
+        for j in range(ny):
+          if done[i, j]:
+            continue
+          h = q[i, j]
+          i1 = i + 1  # grow along x first, then along y over the whole x run
+          while i1 < min(i + self.max_merge_distance, nx) and not done[i1, j] and abs(q[i1, j] - h) < 1e-6:
+            i1 += 1
+          j1 = j + 1
+          while j1 < min(j + self.max_merge_distance, ny) and not done[i:i1, j1].any() and (np.abs(q[i:i1, j1] - h) <= 1e-6).all():
+            j1 += 1
+          done[i:i1, j:j1] = True
+          boxes.append(_box(bt + (i + (i1 - i) / 2) * gw, bt + (j + (j1 - j) / 2) * gw, zc + h / 2, (i1 - i) * gw, (j1 - j) * gw, depth + h))
+    else:
+      lo, hi = sx / 2 - self.platform_width / 2, sx / 2 + self.platform_width / 2
+      for i in range(nx):
+        cx = bt + (i + 0.5) * gw
+        for j in range(ny):
+          cy = bt + (j + 0.5) * gw
+          if self.holes and not (lo <= cx <= hi or lo <= cy <= hi):
+            continue  # holes: only the cross through the platform is filled
+          boxes.append(_box(cx, cy, zc + hmap[i, j] / 2, gw, gw, depth + hmap[i, j]))
+    boxes.append(_box(sx / 2, sy / 2, zc + gh / 2, self.platform_width, self.platform_width, depth + gh))
+    return np.array(boxes), np.array([sx / 2, sy / 2, gh])
 
 
 @dataclass(kw_only=True)

@@ -53,8 +53,13 @@ def _probe_states(t, nw, seed):
   return qpos
 
 
-def test_probes_on_random_terrain_forward_and_rollout():
-  cfg = terrains.rough_terrains_cfg(seed=5, num_rows=3, num_cols=5)
+@pytest.mark.parametrize("kind", ["stairs", "random_grid"])
+def test_probes_on_random_terrain_forward_and_rollout(kind):
+  if kind == "stairs":
+    cfg = terrains.rough_terrains_cfg(seed=5, num_rows=3, num_cols=5)
+  else:  # 0.45 m columns of random height: many small boxes per cell, contacts on column edges
+    sub = terrains.BoxRandomGridTerrainCfg(grid_width=0.45, grid_height_range=(0.05, 0.2), platform_width=2.0)
+    cfg = terrains.TerrainGeneratorCfg(size=(8.0, 8.0), seed=11, num_rows=2, num_cols=2, sub_terrains={"grid": sub})
   cfg.border_width = 2.0
   t = terrains.TerrainGenerator(cfg).generate()
   model = probes_on(t.boxes)
@@ -118,6 +123,37 @@ def test_g1_rough_forward_all_fields():
   # terrain geoms keep the poses written at construction
   gx = _np(sim.data.geom_xpos)
   np.testing.assert_allclose(gx[:, : model.nterrain], np.broadcast_to(model.tbox_pos, (nw, model.nterrain, 3)), atol=1e-5)
+
+
+def test_g1_rough_per_world_friction_and_small_capacity():
+  """Domain randomisation of the foot friction on the terrain scene (reference
+  tasks/velocity/velocity_env_cfg.py:162-172 through expand_model_fields), and the capacity
+  path: with room for only 16 contacts / 60 rows both sides keep the same first ones."""
+  import torch
+
+  model = robots.load_model("g1_velocity_rough")
+  nw = 32
+  feet = [i for i, n in enumerate(model.names["geom"]) if "foot" in n and n.endswith("_collision")]
+  assert len(feet) == 14
+  fr = np.random.default_rng(5).uniform(0.3, 1.2, (nw, len(feet)))
+  for njmax in (300, 60):
+    sim, ora = _sims(model, nw, njmax=njmax)
+    qpos, qvel = _rough_states(model, nw, 6)
+    _set(sim, ora, qpos=qpos, qvel=qvel, ctrl=np.tile(model.key_ctrl[0], (nw, 1)))
+    sim.expand_model_fields(["geom_friction"])
+    sim.model.geom_friction[:, feet, 0] = torch.from_numpy(fr.astype(np.float32)).cuda()
+    ora.expand_model_field("geom_friction")[:, feet, 0] = fr
+    sim.forward()
+    ora.forward()
+    _contacts_match(sim, ora, tol=5e-5, ftol=3e-3)
+    gf = _np(sim.data.contact_friction)
+    for w in range(nw):
+      n = int(ora.ncon[w, 0])
+      assert np.abs(gf[w, :n] - ora.contact_friction[w, :n]).max(initial=0) < 1e-6
+    if njmax == 60:
+      assert (ora.nefc[:, 0] <= 60).all() and (ora.nefc[:, 0] >= 56).mean() > 0.3  # capacity actually binds
+    sim.step()
+    assert np.isfinite(_np(sim.data.qpos)).all()
 
 
 def test_g1_rough_rollout_tracks_oracle():

@@ -28,6 +28,17 @@ def test_boxes_and_origins_match_reference_generator(gold, case):
   np.testing.assert_allclose(t.origins, gold[case + "/origins"], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("mode,kw", [("plain", {}), ("merged", {"merge_similar_heights": True}), ("holes", {"holes": True})])
+def test_random_grid_matches_reference_generator(gold, mode, kw):
+  sub = terrains.BoxRandomGridTerrainCfg(grid_width=0.45, grid_height_range=(0.05, 0.2), platform_width=2.0, **kw)
+  cfg = terrains.TerrainGeneratorCfg(size=(8.0, 8.0), seed=11, num_rows=2, num_cols=2, border_width=1.0, sub_terrains={"grid": sub})
+  t = terrains.TerrainGenerator(cfg).generate()
+  ref = gold[f"grid_{mode}/boxes"]
+  assert t.boxes.shape == ref.shape
+  np.testing.assert_allclose(t.boxes, ref, rtol=0, atol=1e-12)
+  np.testing.assert_allclose(t.origins, gold[f"grid_{mode}/origins"], rtol=0, atol=1e-12)
+
+
 def test_rough_cfg_counts():
   t = terrains.TerrainGenerator(terrains.rough_terrains_cfg(seed=0)).generate()
   # 8 flat columns x 10 rows (1 slab each) + 12 stair columns x 10 rows x (4 border + 6 rings x 4 + 1) + 4 outer border

@@ -37,6 +37,11 @@ def golden_inputs(model, nworld, seed):
   if model.nu:
     jn = model.actuator_trnid[:, 0]
     ctrl = qpos[:, model.jnt_qposadr[jn]] + rng.normal(0, 0.2, size=(nworld, model.nu))
+  origins = getattr(model, "terrain_origins", None)
+  if origins is not None:  # terrain scenes: spread the worlds over the sub-terrains (drawn last: other scenes keep their inputs)
+    r, c = rng.integers(0, origins.shape[0], nworld), rng.integers(0, origins.shape[1], nworld)
+    qpos[:, :3] += origins[r, c]
+    qpos[:, :2] += rng.uniform(-1.5, 1.5, size=(nworld, 2))
   return qpos, qvel, ctrl
 
 

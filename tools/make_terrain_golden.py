@@ -88,6 +88,24 @@ def main() -> None:
     out[name + "/origins"] = np.array(gen.terrain_origins)
     out[name + "/cfg"] = np.array([kw["seed"], int(kw["curriculum"]), kw["num_rows"], kw["num_cols"]])
     print(name, len(geoms), "boxes")
+  # the fourth box terrain of the reference (not part of ROUGH_TERRAINS_CFG): random grid, in its
+  # three modes, through the same generator
+  import mjlab.terrains as tg
+  from mjlab.terrains.terrain_generator import TerrainGeneratorCfg
+
+  grid_modes = {"plain": {}, "merged": {"merge_similar_heights": True}, "holes": {"holes": True}}
+  for mode, kw in grid_modes.items():
+    cfg = TerrainGeneratorCfg(
+      size=(8.0, 8.0), seed=11, num_rows=2, num_cols=2, border_width=1.0,
+      sub_terrains={"grid": tg.BoxRandomGridTerrainCfg(grid_width=0.45, grid_height_range=(0.05, 0.2), platform_width=2.0, **kw)},
+    )
+    gen = TerrainGenerator(cfg, device="cpu")
+    spec = _Spec()
+    gen.compile(spec)
+    geoms = spec.body("terrain").geoms
+    out[f"grid_{mode}/boxes"] = np.array([np.concatenate([g.pos, g.size]) for g in geoms])
+    out[f"grid_{mode}/origins"] = np.array(gen.terrain_origins)
+    print("grid", mode, len(geoms), "boxes")
   path = ROOT / "tests" / "golden" / "terrain_reference.npz"
   np.savez_compressed(path, **out)
   print("wrote", path)
