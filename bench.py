@@ -41,7 +41,8 @@ from mjlab_amd.sim import Simulation, SimulationCfg  # noqa: E402
 # compulsory HBM traffic of the public mjData contract, fp32
 # (rough: the G1 contract without the plane geom's pose -- terrain geoms are static, their poses are
 # written once at construction and are not per-step traffic)
-ALGO_BYTES_PER_WORLD_STEP = {"g1_velocity_flat": 10156, "g1_tracking_flat": 10716, "go1_velocity_flat": 5672, "g1_velocity_rough": 10108}
+ALGO_BYTES_PER_WORLD_STEP = {"g1_velocity_flat": 10156, "g1_tracking_flat": 10716, "go1_velocity_flat": 5672, "g1_velocity_rough": 10108,
+                             "go1_velocity_rough": 5624}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 

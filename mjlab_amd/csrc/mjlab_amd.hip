@@ -1012,9 +1012,9 @@ __device__ __forceinline__ void make_frame(float* f9, const float* f6) {
   for (int k = 0; k < 3; ++k) { f9[k] = x[k]; f9[3 + k] = y[k]; f9[6 + k] = z[k]; }
 }
 
-// LDS: poses of geoms [geom_lds0, ngeom) | per moving geom TCAND_MAX candidate boxes | flat pair list
+// LDS: poses of geoms [geom_lds0, ngeom) | per moving geom TCAND_MAX candidate boxes | flat pair lists (non-box, box)
 __host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) {
-  return 12 * (s.ngeom - s.geom_lds0) + 2 * s.ntgeom * MJLAB_TCAND_MAX;
+  return 12 * (s.ngeom - s.geom_lds0) + 3 * s.ntgeom * MJLAB_TCAND_MAX;
 }
 
 // Contact parameters (mj_contactParam) of the pair (g1, g2) + ordered append of this lane's n
@@ -1161,18 +1161,24 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
   if (ntg > 0) {
     int* s_cand = (int*)(s_gm + 9 * nl);            // [ntg][TCAND_MAX] box ids, ascending per geom
     int* s_pair = s_cand + ntg * MJLAB_TCAND_MAX;   // flat, ordered candidate list: (ti << 24) | slot
-    int pbase = 0;
+    int* s_pairb = s_pair + ntg * MJLAB_TCAND_MAX;  // the same for moving BOX geoms (own sweep below)
+    int pbase = 0, bbase = 0;
     for (int t0 = 0; t0 < ntg; t0 += 64) {          // lanes = moving geoms
       const int ti = t0 + lane;
       int nc = 0;
+      bool isbox = false;
       if (ti < ntg) {
         const int g = m.tgeom[ti];
+        isbox = m.geom_type[g] == MJLAB_GEOM_BOX;
         nc = terrain_walk(m, s_gx + 3 * (g - g0), rbound[g] + gmargin[g], s_cand + ti * MJLAB_TCAND_MAX);
       }
-      int total;
-      const int off = wave_excl_scan(nc, lane, &total);
-      for (int q = 0; q < nc; ++q) s_pair[pbase + off + q] = (ti << 24) | q;
+      int total, totalb;
+      const int off = wave_excl_scan(isbox ? 0 : nc, lane, &total);
+      const int offb = wave_excl_scan(isbox ? nc : 0, lane, &totalb);
+      int* dst = isbox ? s_pairb + bbase + offb : s_pair + pbase + off;
+      for (int q = 0; q < nc; ++q) dst[q] = (ti << 24) | q;
       pbase += total;
+      bbase += totalb;
     }
     __syncthreads();
     for (int p0 = 0; p0 < pbase; p0 += 64) {        // lanes = candidate (geom, box) pairs
@@ -1197,6 +1203,43 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
         if (m.geom_type[g] == MJLAB_GEOM_SPHERE) n = sphere_box(rc, margin, cp, cs[0], bpos, bmat, bsize);
         else n = capsule_box(rc, margin, cp, cz, cs, bpos, bmat, bsize);
       }
+      int total;
+      const int off = wave_excl_scan(n, lane, &total);
+      if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix);
+      base += total;
+    }
+    // Moving boxes: the 8 corners of the box as points (sphere_box with radius 0), lanes = (pair,
+    // corner), 8 pairs per sweep; the first 4 hits of a pair in corner order are kept -- on a face
+    // exactly the plane-box contacts.  Not a full box-box test: see DESIGN.md section 7 (row 4).
+    for (int p0 = 0; p0 < 8 * bbase; p0 += 64) {
+      const int p = p0 + lane, corner_id = lane & 7;
+      RawCon rc[4];
+      int g = 0, gb = 0;
+      float margin = 0.f, gap = 0.f;
+      bool hit = false;
+      if (p < 8 * bbase) {
+        const int code = s_pairb[p >> 3], ti = code >> 24;
+        const int b = s_cand[ti * MJLAB_TCAND_MAX + (code & 0xffffff)];
+        g = m.tgeom[ti];
+        gb = m.tbox_geom[b];
+        margin = gmargin[g];
+        gap = ggap[g];
+        const int l = g - g0;
+        float cp[3], vec[3], corner[3], bpos[3], bmat[9], bsize[3];
+        for (int k = 0; k < 3; ++k) {
+          const float sz = gsize[3 * g + k];
+          cp[k] = s_gx[3 * l + k]; vec[k] = ((corner_id >> k) & 1) ? sz : -sz;
+          bpos[k] = m.tbox_pos[3 * b + k]; bsize[k] = m.tbox_size[3 * b + k];
+        }
+        mul_mat_vec3(corner, s_gm + 9 * l, vec);
+        for (int k = 0; k < 3; ++k) corner[k] += cp[k];
+        for (int k = 0; k < 9; ++k) bmat[k] = m.tbox_mat[9 * b + k];
+        hit = sphere_box(rc, margin, corner, 0.f, bpos, bmat, bsize) != 0;
+      }
+      // rank of this hit among the hits of the same pair (8 consecutive lanes)
+      const unsigned long long hits = __ballot(hit);
+      const int rank = __popcll(hits & (0xffull << (lane & 56)) & ((1ull << lane) - 1ull));
+      const int n = hit && rank < 4 ? 1 : 0;
       int total;
       const int off = wave_excl_scan(n, lane, &total);
       if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix);

@@ -718,8 +718,8 @@ class Model:
     return m
 
 
-# geom-type pairs (type1 <= type2) the collision stage has a function for; a moving sphere or
-# capsule additionally collides with static boxes through the terrain path
+# geom-type pairs (type1 <= type2) the collision stage has a function for; moving spheres, capsules
+# and (by their corners) boxes additionally collide with static boxes through the terrain path
 _PAIR_FUNCS = {
   (GEOM_PLANE, GEOM_SPHERE), (GEOM_PLANE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_BOX),
   (GEOM_SPHERE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_CAPSULE),
@@ -771,8 +771,8 @@ def _compile_terrain(m: "Model", tids: np.ndarray, moving: list[int]) -> None:
     raise NotImplementedError("terrain boxes must share one contype / conaffinity")
   tg = [g for g in moving if (m.geom_contype[g] & ca[0]) or (ct[0] & m.geom_conaffinity[g])]
   for g in tg:
-    if m.geom_type[g] not in (GEOM_SPHERE, GEOM_CAPSULE):
-      raise NotImplementedError(f"geom '{m.names['geom'][g]}' (type {m.geom_type[g]}) vs box terrain: only spheres and capsules collide with static boxes")
+    if m.geom_type[g] not in (GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX):
+      raise NotImplementedError(f"geom '{m.names['geom'][g]}' (type {m.geom_type[g]}) vs box terrain: only spheres, capsules and boxes (corner contacts) collide with static boxes")
   m.tgeom = np.array(tg, np.int32)
   m.ntgeom = len(tg)
   xpos, xquat = _static_body_poses(m)

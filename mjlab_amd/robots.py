@@ -421,6 +421,18 @@ def compile_scene(name: str) -> Model:
     for s in spec.sensors:
       if s.refname == "robot/terrain":
         s.refname = "terrain"
+  elif name == "go1_velocity_rough":
+    # Mjlab-Velocity-Rough-Unitree-Go1 (reference tasks/velocity/config/go1/rough_env_cfg.py:13-47)
+    from . import terrains
+
+    sensors = tuple(
+      ContactSensorCfg(name=f"{leg}_foot_ground_contact", geom1=f"{leg}_foot_collision", body2="terrain", num=1, data=("found",), reduce="netforce")
+      for leg in ("FR", "FL", "RR", "RL")
+    )
+    spec = build_scene(go1_spec(sensors), GO1_INIT, terrains.rough_terrains_cfg(seed=ROUGH_TERRAIN_SEED))
+    for s in spec.sensors:
+      if s.refname == "robot/terrain":
+        s.refname = "terrain"
   else:
     raise KeyError(name)
   _task_options(spec)
@@ -431,7 +443,7 @@ def compile_scene(name: str) -> Model:
 
 
 ROUGH_TERRAIN_SEED = 0
-SCENES = ("g1_velocity_flat", "g1_tracking_flat", "go1_velocity_flat", "g1_velocity_rough")
+SCENES = ("g1_velocity_flat", "g1_tracking_flat", "go1_velocity_flat", "g1_velocity_rough", "go1_velocity_rough")
 
 
 def load_model(name: str) -> Model:

@@ -548,6 +548,23 @@ static int capsule_box(rawcon_t* c, real margin, const real* cpos, const real* c
   return n;
 }
 
+/* Moving box vs static box: the moving box's corners as points against the static box (sphere_box
+ * with radius 0), first 4 hits in corner order -- on a face exactly plane_box's contacts.  This is
+ * NOT mjc_BoxBox: contacts where an edge or corner of the static box pokes into a FACE of the
+ * moving box are not generated (in the reference's scenes the only moving box is Go1's trunk, which
+ * meets the ground when the robot has already fallen).  geom1 = moving box, normal into the terrain. */
+static int box_corners_box(rawcon_t* c, real margin, const real* pos, const real* mat, const real* size, const real* bpos,
+                           const real* bmat, const real* bsize) {
+  int n = 0;
+  for (int i = 0; i < 8 && n < 4; i++) {
+    real vec[3] = {(i & 1) ? size[0] : -size[0], (i & 2) ? size[1] : -size[1], (i & 4) ? size[2] : -size[2]}, corner[3];
+    mul_mat_vec3(corner, mat, vec);
+    for (int k = 0; k < 3; k++) corner[k] += pos[k];
+    n += sphere_box(c + n, margin, corner, 0, bpos, bmat, bsize);
+  }
+  return n;
+}
+
 /* contact parameters (mj_contactParam) + append n raw contacts of the pair (g1, g2) */
 static void emit_contacts(const mjo_model_t* m, mjo_data_t* d, int w, int g1, int g2, real margin, real gap, rawcon_t* rc, int n,
                           int* pncon) {
@@ -672,8 +689,12 @@ static void collision(const mjo_model_t* m, mjo_data_t* d, int w) {
   }
   /* moving spheres / capsules vs the box terrain; terrain boxes carry no margin (checked at
    * model compile time), so the pair margin is the moving geom's */
+  /* two passes: spheres and capsules first, then moving boxes (the HIP path runs them as separate
+   * sweeps; contact order is part of the parity contract) */
+  for (int pass = 0; pass < 2; pass++)
   for (int ti = 0; ti < s->ntgeom; ti++) {
     int g = m->tgeom[ti], cand[MJLAB_TCAND_MAX];
+    if ((m->geom_type[g] == MJLAB_GEOM_BOX) != (pass == 1)) continue;
     real margin = gmargin[g], gap = ggap[g];
     int nc = terrain_candidates(m, gx + 3 * g, rbound[g] + margin, cand);
     for (int q = 0; q < nc; q++) {
@@ -684,6 +705,8 @@ static void collision(const mjo_model_t* m, mjo_data_t* d, int w) {
         n = sphere_box(rc, margin, gx + 3 * g, gsize[3 * g], m->tbox_pos + 3 * b, m->tbox_mat + 9 * b, m->tbox_size + 3 * b);
       else if (m->geom_type[g] == MJLAB_GEOM_CAPSULE)
         n = capsule_box(rc, margin, gx + 3 * g, gm + 9 * g, gsize + 3 * g, m->tbox_pos + 3 * b, m->tbox_mat + 9 * b, m->tbox_size + 3 * b);
+      else if (m->geom_type[g] == MJLAB_GEOM_BOX)
+        n = box_corners_box(rc, margin, gx + 3 * g, gm + 9 * g, gsize + 3 * g, m->tbox_pos + 3 * b, m->tbox_mat + 9 * b, m->tbox_size + 3 * b);
       if (n) emit_contacts(m, d, w, g, m->tbox_geom[b], margin, gap, rc, n, &ncon);
     }
   }

@@ -85,6 +85,8 @@ class OracleSim:
     self.mfield[name] = arr
     setattr(self._m, name, arr.ctypes.data)
     setattr(self._m, name + "_ws", int(base.size))
+    if name in ("geom_pos", "geom_quat", "body_pos", "body_quat"):
+      self._m.size.nstaticgeom = 0  # static geoms may now differ per world: pose them every pass (as Simulation does)
     return arr
 
   def reset(self, key: int | None = None) -> None:

@@ -125,6 +125,60 @@ def test_g1_rough_forward_all_fields():
   np.testing.assert_allclose(gx[:, : model.nterrain], np.broadcast_to(model.tbox_pos, (nw, model.nterrain, 3)), atol=1e-5)
 
 
+def test_go1_rough_and_moving_box_match_oracle():
+  """Go1 on the rough map (sphere feet, capsule legs, the trunk BOX by its corners) and a free box
+  tumbling over stairs: same contacts in the same order as the oracle."""
+  model = robots.load_model("go1_velocity_rough")
+  nw = 64
+  sim, ora = _sims(model, nw)
+  rng = np.random.default_rng(8)
+  qpos = np.tile(model.key_qpos[0], (nw, 1))
+  rows, cols = rng.integers(0, 10, nw), np.arange(nw) * 20 // nw
+  qpos[:, :3] += model.terrain_origins[rows, cols]
+  qpos[:, 0:2] += rng.uniform(-1.8, 1.8, (nw, 2))
+  qpos[:, 2] -= rng.uniform(0.0, 0.25, nw)  # down to the belly: trunk corners touch
+  q = np.array([1.0, 0, 0, 0]) + rng.normal(scale=0.2, size=(nw, 4))
+  qpos[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+  qpos[:, 7:] += rng.normal(scale=0.1, size=(nw, model.nq - 7))
+  _set(sim, ora, qpos=qpos, qvel=rng.normal(scale=0.3, size=(nw, model.nv)), ctrl=np.tile(model.key_ctrl[0], (nw, 1)))
+  sim.forward()
+  ora.forward()
+  trunk = model.names["geom"].index("robot/trunk_collision")
+  assert sum((ora.contact_geom[w, : int(ora.ncon[w, 0]), 0] == trunk).any() for w in range(nw)) > 10
+  _contacts_match(sim, ora, tol=5e-5, ftol=3e-3)
+  assert np.array_equal(_np(sim.data.sensordata), ora.sensordata.astype(np.float32))
+  qa, qo = _np(sim.data.qacc), ora.qacc
+  assert np.quantile(np.abs(qa - qo).max(axis=1) / np.maximum(1.0, np.abs(qo).max(axis=1)), 0.9) < 1e-3
+  for _ in range(5):
+    sim.step()
+  assert np.isfinite(_np(sim.data.qpos)).all()
+
+  # free box over a small stairs map
+  from mjlab_amd import mjcf
+
+  spec = mjcf.Spec.from_string(robots.BOX_XML)
+  spec.option.integrator = mjcf.INT_IMPLICITFAST
+  spec.world.geoms.clear()
+  cfg = terrains.rough_terrains_cfg(seed=5, num_rows=2, num_cols=5)
+  cfg.border_width = 2.0
+  t = terrains.TerrainGenerator(cfg).generate()
+  terrains.add_boxes(spec, spec.add_body("terrain"), t.boxes)
+  model = spec.compile()
+  nw = 128
+  sim, ora = _sims(model, nw)
+  b = t.boxes[rng.integers(0, len(t.boxes), nw)]
+  qpos = np.zeros((nw, 7))
+  qpos[:, :3] = b[:, :3] + rng.uniform(-1.0, 1.0, (nw, 3)) * b[:, 3:]
+  qpos[:, 2] = b[:, 2] + b[:, 5] + rng.uniform(0.05, 0.16, nw)
+  q = rng.normal(size=(nw, 4))
+  qpos[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+  _set(sim, ora, qpos=qpos, qvel=rng.normal(scale=0.2, size=(nw, 6)))
+  sim.forward()
+  ora.forward()
+  assert (ora.ncon > 0).mean() > 0.5
+  _contacts_match(sim, ora)
+
+
 def test_g1_rough_per_world_friction_and_small_capacity():
   """Domain randomisation of the foot friction on the terrain scene (reference
   tasks/velocity/velocity_env_cfg.py:162-172 through expand_model_fields), and the capacity

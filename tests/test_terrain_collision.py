@@ -237,6 +237,72 @@ def test_g1_on_a_flat_slab_equals_g1_on_the_plane():
   np.testing.assert_allclose(b.qpos, p.qpos, atol=1e-5)
 
 
+def test_moving_box_on_a_slab_equals_box_on_the_plane():
+  """Corner contacts of a moving box on a terrain face are plane_box's contacts."""
+  plane = robots.box_model()
+  spec = Spec.from_string(robots.BOX_XML)
+  spec.option.integrator = mjcf.INT_IMPLICITFAST
+  spec.world.geoms.clear()  # drop the floor plane, stand the box on a slab instead
+  terrains.add_boxes(spec, spec.add_body("terrain"), np.array([[0, 0, -0.5, 5, 5, 0.5]]))
+  slab = spec.compile()
+  assert slab.nterrain == 1 and slab.ntgeom == 1 and slab.npair == 0 and plane.npair == 1
+  rng = np.random.default_rng(0)
+  nw = 16
+  qpos = np.tile(plane.qpos0, (nw, 1))
+  qpos[:, 2] = rng.uniform(0.06, 0.16, nw)
+  q = np.array([1.0, 0, 0, 0]) + rng.normal(scale=0.15, size=(nw, 4))
+  qpos[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+  qvel = rng.normal(scale=0.3, size=(nw, 6))
+  res = []
+  for m in (slab, plane):
+    o = OracleSim(m, nworld=nw)
+    o.qpos[:], o.qvel[:] = qpos, qvel
+    o.forward()
+    res.append(o)
+  b, p = res
+  np.testing.assert_array_equal(b.ncon, p.ncon)
+  assert b.ncon.max() == 4 and (b.ncon > 0).mean() > 0.6
+  for w in range(nw):
+    n = int(b.ncon[w, 0])
+    np.testing.assert_allclose(b.contact_dist[w, :n], p.contact_dist[w, :n], atol=1e-12)
+    np.testing.assert_allclose(b.contact_pos[w, :n], p.contact_pos[w, :n], atol=1e-12)
+    np.testing.assert_allclose(b.contact_frame[w, :n, :3], -p.contact_frame[w, :n, :3], atol=1e-12)
+  np.testing.assert_allclose(b.qacc, p.qacc, rtol=1e-7, atol=1e-7)
+  for o in res:
+    o.step(300)
+  np.testing.assert_allclose(b.qpos, p.qpos, atol=1e-6)
+
+
+def test_go1_rough_scene_stands():
+  m = robots.load_model("go1_velocity_rough")
+  assert m.nterrain == 3564 and m.npair == 0 and m.ntgeom == 30  # Go1 geoms only collide with the ground
+  assert (m.geom_type[m.tgeom] == GEOM_BOX).sum() == 1  # the trunk
+  nw = 10
+  o = OracleSim(m, nworld=nw, njmax=300)
+  o.reset(key=0)
+  rng = np.random.default_rng(1)
+  rows, cols = rng.integers(0, 10, nw), np.arange(nw) * 20 // nw
+  o.qpos[:, :3] += m.terrain_origins[rows, cols]
+  for _ in range(200):
+    o.ctrl[:] = m.key_ctrl[0]
+    o.step(1)
+  assert np.isfinite(o.qpos).all()
+  # four feet on the ground, trunk at standing height above the platform
+  assert (o.sensordata.sum(axis=1) == 4).mean() > 0.8
+  h = o.qpos[:, 2] - m.terrain_origins[rows, cols][:, 2]
+  assert (h > 0.2).all() and (h < 0.4).all()
+  # a robot dropped on its back rests on trunk corners / head, not inside the terrain
+  o.reset(key=0)
+  o.qpos[:, :3] += m.terrain_origins[rows, cols]
+  o.qpos[:, 3:7] = [0, 1, 0, 0]
+  o.step(300)
+  h = o.qpos[:, 2] - m.terrain_origins[rows, cols][:, 2]
+  assert np.isfinite(o.qpos).all() and (h > 0.03).all()
+  tg = m.names["geom"].index("robot/trunk_collision")
+  touching = [(o.contact_geom[w, : int(o.ncon[w, 0]), 0] == tg).any() for w in range(nw)]
+  assert np.mean(touching) > 0.5
+
+
 def test_g1_rough_scene_model():
   m = robots.load_model("g1_velocity_rough")
   assert m.nterrain == 3564 and m.ngeom == 3564 + 68 and m.nstaticgeom == 3564 and m.geom_lds0 == 3564
