@@ -53,10 +53,14 @@ def _probe_states(t, nw, seed):
   return qpos
 
 
-@pytest.mark.parametrize("kind", ["stairs", "random_grid"])
+@pytest.mark.parametrize("kind", ["stairs", "random_grid", "dense_columns"])
 def test_probes_on_random_terrain_forward_and_rollout(kind):
   if kind == "stairs":
     cfg = terrains.rough_terrains_cfg(seed=5, num_rows=3, num_cols=5)
+  elif kind == "dense_columns":  # more boxes within reach than the candidate list holds
+    from test_terrain_collision import dense_columns_cfg
+
+    cfg = dense_columns_cfg()
   else:  # 0.45 m columns of random height: many small boxes per cell, contacts on column edges
     sub = terrains.BoxRandomGridTerrainCfg(grid_width=0.45, grid_height_range=(0.05, 0.2), platform_width=2.0)
     cfg = terrains.TerrainGeneratorCfg(size=(8.0, 8.0), seed=11, num_rows=2, num_cols=2, sub_terrains={"grid": sub})

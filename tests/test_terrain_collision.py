@@ -152,10 +152,18 @@ def test_sphere_and_capsule_come_to_rest_on_a_box():
   assert np.isclose(o.qfrc_constraint[0, 2] + o.qfrc_constraint[0, 8], 2 * 9.81, rtol=1e-3)
 
 
-def test_grid_broadphase_equals_exhaustive_search(monkeypatch):
+def dense_columns_cfg() -> terrains.TerrainGeneratorCfg:
+  """12 cm columns: the capsule probe's bounding sphere (25 cm) reaches more than MJLAB_TCAND_MAX = 12 of them."""
+  sub = terrains.BoxRandomGridTerrainCfg(grid_width=0.12, grid_height_range=(0.01, 0.03), platform_width=0.5)
+  return terrains.TerrainGeneratorCfg(size=(4.0, 4.0), seed=3, num_rows=1, num_cols=2, sub_terrains={"grid": sub})
+
+
+@pytest.mark.parametrize("kind", ["stairs", "dense_columns"])
+def test_grid_broadphase_equals_exhaustive_search(monkeypatch, kind):
   """Same terrain compiled with 0.5 m cells and with one huge cell (every box a candidate of
-  every geom) gives identical contacts."""
-  cfg = terrains.rough_terrains_cfg(seed=5, num_rows=3, num_cols=5)
+  every geom) gives identical contacts -- also when a geom reaches more boxes than the candidate
+  list holds (both keep the MJLAB_TCAND_MAX smallest ids, whatever the walk order)."""
+  cfg = terrains.rough_terrains_cfg(seed=5, num_rows=3, num_cols=5) if kind == "stairs" else dense_columns_cfg()
   cfg.border_width = 2.0
   t = terrains.TerrainGenerator(cfg).generate()
   m_grid = probes_on(t.boxes)
@@ -177,6 +185,11 @@ def test_grid_broadphase_equals_exhaustive_search(monkeypatch):
     o.qpos[:, 10:14] = q / np.linalg.norm(q, axis=1, keepdims=True)
     o.forward()
   assert og.ncon.sum() > 40 and (og.ncon > 0).mean() > 0.5
+  if kind == "dense_columns":
+    # the candidate list really overflows: count the columns within reach of the capsule probes
+    reach = 0.25  # bounding sphere: radius 0.05 + half length 0.2
+    d = np.maximum(np.abs(og.qpos[:, None, 7:10] - t.boxes[None, :, :3]) - t.boxes[None, :, 3:], 0.0)
+    assert ((d**2).sum(axis=2) <= reach**2).sum(axis=1).max() > 12
   np.testing.assert_array_equal(og.ncon, oa.ncon)
   for f in ("contact_dist", "contact_pos", "contact_frame", "contact_geom", "efc_J", "qacc"):
     np.testing.assert_array_equal(getattr(og, f), getattr(oa, f))

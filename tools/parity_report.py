@@ -31,7 +31,8 @@ def per_world_rel(a, b):
   return np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-6)
 
 
-for scene in ("g1_velocity_flat", "g1_tracking_flat", "go1_velocity_flat"):
+SCENES = sys.argv[2].split(",") if len(sys.argv) > 2 else ["g1_velocity_flat", "g1_tracking_flat", "go1_velocity_flat", "g1_velocity_rough", "go1_velocity_rough"]
+for scene in SCENES:
   model = robots.load_model(scene)
   njmax = 300 if "velocity" in scene else 250
   sim = Simulation(N, SimulationCfg(njmax=njmax, use_graph=False), model, "cuda:0")
