@@ -73,7 +73,7 @@ def test_probes_on_random_terrain_forward_and_rollout(kind):
   sim.forward()
   ora.forward()
   assert ora.ncon.sum() > 150
-  _contacts_match(sim, ora)
+  _contacts_match(sim, ora, ftol=5e-4)  # edge / corner normals of cm-sized offsets: ~1e-4 in fp32
   # exact corner / edge configurations sit on decision boundaries of the Newton iteration count;
   # compare accelerations in the bulk and require every world to be close
   assert np.quantile(np.abs(_np(sim.data.qacc) - ora.qacc).max(axis=1) / np.maximum(1.0, np.abs(ora.qacc).max(axis=1)), 0.95) < 1e-3
