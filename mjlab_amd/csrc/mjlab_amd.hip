@@ -1378,155 +1378,167 @@ __host__ __device__ inline int velocity_lds_floats(const mjlab_sizes_t& s) {
   return 2 * s.nv + 12 * s.nv + 10 * s.nbody + 24 * s.nbody;
 }
 
+// One actuator: joint transmission, fixed gain, affine bias (reference utils/spec_config.py:441-453).
+struct ActuatorConst { int trn, ctrllimited, forcelimited; float gear, ctrl, crange[2], frange[2], gain, bias[3]; };
+__device__ __forceinline__ void load_actuator(ActuatorConst& c, const Model& m, const float* ctrl, const float* gain, const float* biasprm,
+                                              const float* crange, const float* frange, const float* gear, int a) {
+  c.trn = m.actuator_trnid[2 * a];
+  c.ctrllimited = m.actuator_ctrllimited[a];
+  c.forcelimited = m.actuator_forcelimited[a];
+  c.gear = gear[6 * a];
+  c.ctrl = ctrl[a];
+  c.gain = gain[10 * a];
+  for (int k = 0; k < 2; ++k) { c.crange[k] = crange[2 * a + k]; c.frange[k] = frange[2 * a + k]; }
+  for (int k = 0; k < 3; ++k) c.bias[k] = biasprm[10 * a + k];
+}
+
+// Lowest set bit of a 64-bit mask held as two words; clears it.  Returns -1 when empty.
+__device__ __forceinline__ int pop_lowest(unsigned& lo, unsigned& hi) {
+  if (lo) { const int k = __ffs(lo) - 1; lo &= lo - 1u; return k; }
+  if (hi) { const int k = __ffs(hi) - 1; hi &= hi - 1u; return 32 + k; }
+  return -1;
+}
+
 __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
-  const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt;
+  const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nu = m.size.nu;
   float* s_qvel = smem;
   float* s_qact = s_qvel + nv;
   float* s_cdof = s_qact + nv;
   float* s_cdd = s_cdof + 6 * nv;
-  float* s_cinert = s_cdd + 6 * nv;
-  float* s_cvel = s_cinert + 10 * nb;
-  float* s_cacc = s_cvel + 6 * nb;
-  float* s_cfrc = s_cacc + 6 * nb;
+  float* s_cvel = s_cdd + 6 * nv;
+  float* s_cfrc = s_cvel + 6 * nb;
   float* s_cfs = s_cfrc + 6 * nb;
+  // ---- prologue: everything this lane needs from memory in any of its roles (body / dof /
+  // actuator `lane`), as one batch of independent loads plus a short second one for values reached
+  // through an index; the rest of the kernel only stores (see k_position)
+  const float* qpos = d.qpos + (size_t)w * nq;
+  const int rb = lane < nb ? lane : 0;  // body role
+  const int b_snum = m.body_subtreenum[rb];
+  unsigned b_mlo = (unsigned)m.body_dofmask[2 * rb], b_mhi = (unsigned)m.body_dofmask[2 * rb + 1];
+  float b_in[10], b_xf[6];
+  for (int k = 0; k < 10; ++k) b_in[k] = d.cinert[((size_t)w * nb + rb) * 10 + k];
+  for (int k = 0; k < 6; ++k) b_xf[k] = d.xfrc_applied[((size_t)w * nb + rb) * 6 + k];
+  const int rv = lane < nv ? lane : 0;  // dof role
+  const int v_body = m.dof_bodyid[rv], v_jnt = m.dof_jntid[rv];
+  const float v_damp = MF(dof_damping)[rv], v_applied = d.qfrc_applied[(size_t)w * nv + rv];
+  const float *gain = MF(actuator_gainprm), *biasprm = MF(actuator_biasprm), *crange = MF(actuator_ctrlrange),
+              *frange = MF(actuator_forcerange), *gear = MF(actuator_gear);
+  const float* ctrl = d.ctrl + (size_t)w * nu;
+  ActuatorConst act;
+  if (lane < nu) load_actuator(act, m, ctrl, gain, biasprm, crange, frange, gear, lane);
   global_to_lds(s_qvel, d.qvel + (size_t)w * nv, nv, lane);
   global_to_lds(s_cdof, d.cdof + (size_t)w * 6 * nv, 6 * nv, lane);
-  global_to_lds(s_cinert, d.cinert + (size_t)w * 10 * nb, 10 * nb, lane);
-  if (lane < 6) {
-    s_cvel[lane] = 0.f;
-    s_cacc[lane] = lane < 3 ? 0.f : -(float)m.opt.gravity[lane - 3];
-    s_cfrc[lane] = 0.f;
+  // second level
+  const int v_type = m.jnt_type[v_jnt], v_dofadr = m.jnt_dofadr[v_jnt], v_qadr = m.jnt_qposadr[v_jnt];
+  const float v_stiff = MF(jnt_stiffness)[v_jnt];
+  unsigned v_mlo = (unsigned)m.body_dofmask[2 * v_body], v_mhi = (unsigned)m.body_dofmask[2 * v_body + 1];
+  int a_qadr = 0, a_dadr = 0;
+  float a_qpos = 0.f;
+  if (lane < nu) {
+    a_qadr = m.jnt_qposadr[act.trn];
+    a_dadr = m.jnt_dofadr[act.trn];
+    a_qpos = qpos[a_qadr];
   }
   for (int i = lane; i < nv; i += 64) s_qact[i] = 0.f;
   __syncthreads();
-  // ---- down-sweep by level: cvel, cdof_dot, cacc, cfrc_body.  lane = body (nbody <= 64): the
-  // body's topology, inertia and first joint's motion axis are fetched before the sweep, so a
-  // level costs one LDS round trip (parent velocity / acceleration) plus arithmetic.
-  {
-    const int i = lane < nb ? lane : 0;
-    const int depth = lane < nb ? m.body_depth[i] : -1;
-    const int pid = m.body_parentid[i], ja = m.body_jntadr[i], jn = m.body_jntnum[i];
-    int da0 = 0, jtype0 = -1;
-    if (jn > 0) { da0 = m.jnt_dofadr[ja]; jtype0 = m.jnt_type[ja]; }
-    float in[10], c60[6], qv0 = 0.f;
-    for (int k = 0; k < 10; ++k) in[k] = s_cinert[10 * i + k];
-    for (int k = 0; k < 6; ++k) c60[k] = s_cdof[6 * da0 + k];
-    if (jn > 0) qv0 = s_qvel[da0];
-    for (int L = 1; L < m.size.nlevel; ++L) {
-      if (depth == L) {
-        float v[6], a[6];
-        for (int k = 0; k < 6; ++k) { v[k] = s_cvel[6 * pid + k]; a[k] = s_cacc[6 * pid + k]; }
-        for (int j = ja; j < ja + jn; ++j) {
-          const int da = j == ja ? da0 : m.jnt_dofadr[j];
-          const int jtype = j == ja ? jtype0 : m.jnt_type[j];
-          if (jtype == MJLAB_JNT_FREE) {
-            for (int k = 0; k < 3; ++k) {
-              const float qv = s_qvel[da + k];
-              for (int c = 0; c < 6; ++c) { v[c] += s_cdof[6 * (da + k) + c] * qv; s_cdd[6 * (da + k) + c] = 0.f; }
-            }
-            float cd[3][6];
-            for (int k = 0; k < 3; ++k) {
-              float c6[6];
-              for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * (da + 3 + k) + c];
-              cross_motion(cd[k], v, c6);
-            }
-            for (int k = 0; k < 3; ++k) {
-              const float qv = s_qvel[da + 3 + k];
-              for (int c = 0; c < 6; ++c) {
-                v[c] += s_cdof[6 * (da + 3 + k) + c] * qv;
-                a[c] += cd[k][c] * qv;
-                s_cdd[6 * (da + 3 + k) + c] = cd[k][c];
-              }
-            }
-          } else {
-            float c6[6], cd[6];
-            float qv = qv0;
-            for (int c = 0; c < 6; ++c) c6[c] = c60[c];
-            if (j != ja) {
-              qv = s_qvel[da];
-              for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * da + c];
-            }
-            cross_motion(cd, v, c6);
-            for (int c = 0; c < 6; ++c) { v[c] += c6[c] * qv; a[c] += cd[c] * qv; s_cdd[6 * da + c] = cd[c]; }
-          }
-        }
-        float t1[6], t2[6], t3[6];
-        mul_inert_vec(t1, in, a);
-        mul_inert_vec(t2, in, v);
-        cross_force(t3, v, t2);
-        for (int k = 0; k < 6; ++k) { s_cvel[6 * i + k] = v[k]; s_cacc[6 * i + k] = a[k]; s_cfrc[6 * i + k] = t1[k] + t3[k]; }
-      }
-      __syncthreads();
+
+  // ---- mj_comVel / mj_rne without a level sweep.  cvel of a body is the sum of cdof_k qvel_k over
+  // the dofs k of its ancestor chain (body_dofmask, ascending = root first, the order the
+  // sequential sweep adds them in), and cdof_dot_j = cvel-just-before-dof-j x cdof_j: every dof
+  // and every body sums its own chain (<= depth + 5 terms from LDS), nobody waits for a parent.
+  if (lane < nv) {
+    // dofs strictly before j; the three rotational dofs of a free joint all use the velocity after
+    // its translations (mj_comVel), i.e. the prefix before the rotational block
+    const int lim = (v_type == MJLAB_JNT_FREE && lane >= v_dofadr + 3) ? v_dofadr + 3 : lane;
+    unsigned lo = lim >= 32 ? v_mlo : (v_mlo & ((1u << lim) - 1u));
+    unsigned hi = lim >= 32 ? (v_mhi & ((1u << (lim - 32)) - 1u)) : 0u;
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c6[6], cd[6];
+    for (int k = pop_lowest(lo, hi); k >= 0; k = pop_lowest(lo, hi)) {
+      const float qv = s_qvel[k];
+      for (int c = 0; c < 6; ++c) v[c] += s_cdof[6 * k + c] * qv;
     }
-  }
-  lds_to_global(d.cvel + (size_t)w * 6 * nb, s_cvel, 6 * nb, lane);
-  lds_to_global(d.cdof_dot + (size_t)w * 6 * nv, s_cdd, 6 * nv, lane);
-  // ---- up-sweep as subtree range sums
-  for (int it = lane; it < 6 * nb; it += 64) {
-    const int b = it / 6, c = it - 6 * b, e = b + m.body_subtreenum[b];
-    float acc = 0.f;
-    for (int j = b; j < e; ++j) acc += s_cfrc[6 * j + c];
-    s_cfs[it] = acc;
+    for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * lane + c];
+    cross_motion(cd, v, c6);
+    const bool zero = v_type == MJLAB_JNT_FREE && lane < v_dofadr + 3;  // translations of a free joint
+    for (int c = 0; c < 6; ++c) s_cdd[6 * lane + c] = zero ? 0.f : cd[c];
   }
   __syncthreads();
-  // ---- actuation (joint transmission, fixed gain, affine bias)
-  {
-    const float *gain = MF(actuator_gainprm), *biasprm = MF(actuator_biasprm), *crange = MF(actuator_ctrlrange),
-                *frange = MF(actuator_forcerange), *gear = MF(actuator_gear);
-    const float* qpos = d.qpos + (size_t)w * nq;
-    const float* ctrl = d.ctrl + (size_t)w * nu;
-    for (int a = lane; a < nu; a += 64) {
-      const int j = m.actuator_trnid[2 * a], qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-      const float g = gear[6 * a];
-      float c = ctrl[a];
-      if (m.actuator_ctrllimited[a]) c = clipf(c, crange[2 * a], crange[2 * a + 1]);
-      const float len = g * qpos[qa], vel = g * s_qvel[da];
-      float f = gain[10 * a] * c + biasprm[10 * a] + biasprm[10 * a + 1] * len + biasprm[10 * a + 2] * vel;
-      if (m.actuator_forcelimited[a]) f = clipf(f, frange[2 * a], frange[2 * a + 1]);
-      d.actuator_force[(size_t)w * nu + a] = f;
-      atomicAdd(&s_qact[da], g * f);
+  if (lane < nb) {
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a[6];
+    for (int c = 0; c < 6; ++c) a[c] = c < 3 ? 0.f : -(float)m.opt.gravity[c - 3];
+    if (lane == 0) {
+      for (int c = 0; c < 6; ++c) { s_cvel[c] = 0.f; s_cfrc[c] = 0.f; }
+    } else {
+      for (int k = pop_lowest(b_mlo, b_mhi); k >= 0; k = pop_lowest(b_mlo, b_mhi)) {
+        const float qv = s_qvel[k];
+        for (int c = 0; c < 6; ++c) { v[c] += s_cdof[6 * k + c] * qv; a[c] += s_cdd[6 * k + c] * qv; }
+      }
+      float t1[6], t2[6], t3[6];
+      mul_inert_vec(t1, b_in, a);
+      mul_inert_vec(t2, b_in, v);
+      cross_force(t3, v, t2);
+      for (int k = 0; k < 6; ++k) { s_cvel[6 * lane + k] = v[k]; s_cfrc[6 * lane + k] = t1[k] + t3[k]; }
     }
+  }
+  __syncthreads();
+  lds_to_global(d.cvel + (size_t)w * 6 * nb, s_cvel, 6 * nb, lane);
+  lds_to_global(d.cdof_dot + (size_t)w * 6 * nv, s_cdd, 6 * nv, lane);
+  // ---- up-sweep as subtree range sums (a subtree is a contiguous body-id range)
+  for (int it0 = 0; it0 < 6 * nb; it0 += 64) {
+    const int it = it0 + lane, bq = it < 6 * nb ? it / 6 : 0;
+    const int snum = __shfl(b_snum, bq);
+    if (it >= 6 * nb) continue;
+    const int c = it - 6 * bq, e = bq + snum;
+    float a0 = 0.f, a1 = 0.f;
+    int j = bq;
+    for (; j + 1 < e; j += 2) { a0 += s_cfrc[6 * j + c]; a1 += s_cfrc[6 * j + 6 + c]; }
+    if (j < e) a0 += s_cfrc[6 * j + c];
+    s_cfs[it] = a0 + a1;
+  }
+  // ---- actuation
+  for (int a0 = 0; a0 < nu; a0 += 64) {
+    const int a = a0 + lane;
+    if (a >= nu) break;
+    if (a0 > 0) {  // models with more than 64 actuators: later rounds load in place
+      load_actuator(act, m, ctrl, gain, biasprm, crange, frange, gear, a);
+      a_qadr = m.jnt_qposadr[act.trn];
+      a_dadr = m.jnt_dofadr[act.trn];
+      a_qpos = qpos[a_qadr];
+    }
+    float c = act.ctrl;
+    if (act.ctrllimited) c = clipf(c, act.crange[0], act.crange[1]);
+    const float len = act.gear * a_qpos, vel = act.gear * s_qvel[a_dadr];
+    float f = act.gain * c + act.bias[0] + act.bias[1] * len + act.bias[2] * vel;
+    if (act.forcelimited) f = clipf(f, act.frange[0], act.frange[1]);
+    d.actuator_force[(size_t)w * nu + a] = f;
+    atomicAdd(&s_qact[a_dadr], act.gear * f);
   }
   __syncthreads();
   // ---- bias, passive, smooth force; lanes = dofs
-  const float *damping = MF(dof_damping), *stiff = MF(jnt_stiffness), *qpos0 = MF(qpos0);
-  const float* xfrc = d.xfrc_applied + (size_t)w * 6 * nb;
   // bodies with a nonzero Cartesian perturbation (usually none)
-  unsigned long long xmask_total = 0ull;
-  for (int b0 = 0; b0 < nb; b0 += 64) {
-    const int b = b0 + lane;
-    bool nz = false;
-    if (b > 0 && b < nb) for (int k = 0; k < 6; ++k) nz |= xfrc[6 * b + k] != 0.f;
-    const unsigned long long mk = __ballot(nz);
-    if (mk) {
-      xmask_total |= mk;
-    }
-  }
-  for (int i0 = 0; i0 < nv; i0 += 64) {
-    const int i = i0 + lane;
-    if (i >= nv) break;
-    const int bi = m.dof_bodyid[i], j = m.dof_jntid[i];
+  bool xnz = false;
+  if (lane > 0 && lane < nb) for (int k = 0; k < 6; ++k) xnz |= b_xf[k] != 0.f;
+  const unsigned long long xmask = __ballot(xnz);
+  if (lane < nv) {
+    const int i = lane;
     float c6[6];
     for (int k = 0; k < 6; ++k) c6[k] = s_cdof[6 * i + k];
     float bias = 0.f;
-    for (int k = 0; k < 6; ++k) bias += c6[k] * s_cfs[6 * bi + k];
-    float passive = -damping[i] * s_qvel[i];
-    if (m.jnt_type[j] != MJLAB_JNT_FREE && stiff[j] != 0.f) {
-      const int qa = m.jnt_qposadr[j];
-      passive -= stiff[j] * (d.qpos[(size_t)w * nq + qa] - qpos0[qa]);
-    }
-    float smooth = passive - bias + d.qfrc_applied[(size_t)w * nv + i] + s_qact[i];
-    if (xmask_total) {
+    for (int k = 0; k < 6; ++k) bias += c6[k] * s_cfs[6 * v_body + k];
+    float passive = -v_damp * s_qvel[i];
+    if (v_type != MJLAB_JNT_FREE && v_stiff != 0.f) passive -= v_stiff * (qpos[v_qadr] - MF(qpos0)[v_qadr]);
+    float smooth = passive - bias + v_applied + s_qact[i];
+    if (xmask) {
+      const float* xfrc = d.xfrc_applied + (size_t)w * 6 * nb;
       const float* xipos = d.xipos + (size_t)w * 3 * nb;
       const float* sub = d.subtree_com + (size_t)w * 3 * nb;
       for (int b = 1; b < nb; ++b) {
+        if (!((xmask >> b) & 1ull) || !dof_in_chain(m, b, i)) continue;
         float f[6];
-        bool nz = false;
-        for (int k = 0; k < 6; ++k) { f[k] = xfrc[6 * b + k]; nz |= f[k] != 0.f; }
-        if (!nz || !dof_in_chain(m, b, i)) continue;
+        for (int k = 0; k < 6; ++k) f[k] = xfrc[6 * b + k];
         const int root = m.body_rootid[b];
         float off[3], jp[3];
         for (int k = 0; k < 3; ++k) off[k] = xipos[3 * b + k] - sub[3 * root + k];
@@ -1540,7 +1552,6 @@ __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d,
     d.qfrc_actuator[(size_t)w * nv + i] = s_qact[i];
     d.qfrc_smooth[(size_t)w * nv + i] = smooth;
   }
-  (void)nj;
 }
 
 // ====================================================================================
