@@ -1133,9 +1133,10 @@ __device__ __forceinline__ void make_frame(float* f9, const float* f6) {
   for (int k = 0; k < 3; ++k) { f9[k] = x[k]; f9[3 + k] = y[k]; f9[6 + k] = z[k]; }
 }
 
-// LDS: poses of geoms [geom_lds0, ngeom) | per moving geom TCAND_MAX candidate boxes | flat pair lists (non-box, box)
+// LDS: poses (12) and constants (8: type, size, rbound, margin, gap) of geoms [geom_lds0, ngeom) | per moving geom TCAND_MAX
+// candidate boxes | flat pair lists (non-box, box)
 __host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) {
-  return 12 * (s.ngeom - s.geom_lds0) + 3 * s.ntgeom * MJLAB_TCAND_MAX;
+  return 20 * (s.ngeom - s.geom_lds0) + 3 * s.ntgeom * MJLAB_TCAND_MAX;
 }
 
 // Contact parameters (mj_contactParam) of the pair (g1, g2) + ordered append of this lane's n
@@ -1198,33 +1199,48 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
   const int g0 = m.size.geom_lds0, nl = ng - g0;  // geoms [g0, ng) are staged; s_gx / s_gm are indexed by g - g0
   float* s_gx = smem;
   float* s_gm = s_gx + 3 * nl;
-  global_to_lds(s_gx, d.geom_xpos + ((size_t)w * ng + g0) * 3, 3 * nl, lane);
-  global_to_lds(s_gm, d.geom_xmat + ((size_t)w * ng + g0) * 9, 9 * nl, lane);
-  __syncthreads();
+  float* s_gc = s_gm + 9 * nl;  // per staged geom: type (as int bits), size[3], rbound, margin, gap, -
   const float *gsize = MF(geom_size), *rbound = MF(geom_rbound), *gmargin = MF(geom_margin), *ggap = MF(geom_gap);
   const float *gfri = MF(geom_friction), *gsolref = MF(geom_solref), *gsolimp = MF(geom_solimp), *gsolmix = MF(geom_solmix);
+  // The stage is bound by dependent global round trips: every per-geom constant the narrow phase
+  // needs goes to LDS in this one batch, and the pair list is fetched one sweep ahead, so a sweep
+  // finds all of its operands on chip.
+  int ng1 = 0, ng2 = 0;  // geoms of pair (sweep 0, this lane)
+  if (lane < npair) { ng1 = m.pair_geom[2 * lane]; ng2 = m.pair_geom[2 * lane + 1]; }
+  global_to_lds(s_gx, d.geom_xpos + ((size_t)w * ng + g0) * 3, 3 * nl, lane);
+  global_to_lds(s_gm, d.geom_xmat + ((size_t)w * ng + g0) * 9, 9 * nl, lane);
+  for (int l = lane; l < nl; l += 64) {
+    const int g = g0 + l;
+    ((int*)s_gc)[8 * l] = m.geom_type[g];
+    for (int k = 0; k < 3; ++k) s_gc[8 * l + 1 + k] = gsize[3 * g + k];
+    s_gc[8 * l + 4] = rbound[g];
+    s_gc[8 * l + 5] = gmargin[g];
+    s_gc[8 * l + 6] = ggap[g];
+  }
+  __syncthreads();
   int base = 0;  // contacts emitted so far (wave-uniform)
   for (int p0 = 0; p0 < npair; p0 += 64) {
     const int p = p0 + lane;
     RawCon rc[4];
-    int n = 0, g1 = 0, g2 = 0;
+    int n = 0;
+    const int g1 = ng1, g2 = ng2;
+    if (p + 64 < npair) { ng1 = m.pair_geom[2 * (p + 64)]; ng2 = m.pair_geom[2 * (p + 64) + 1]; }  // next sweep
     float margin = 0.f, gap = 0.f;
     if (p < npair) {
-      g1 = m.pair_geom[2 * p]; g2 = m.pair_geom[2 * p + 1];
-      const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-      margin = fmaxf(gmargin[g1], gmargin[g2]);
-      gap = fmaxf(ggap[g1], ggap[g2]);
       const int l1 = g1 - g0, l2 = g2 - g0;
+      const int t1 = ((const int*)s_gc)[8 * l1], t2 = ((const int*)s_gc)[8 * l2];
+      margin = fmaxf(s_gc[8 * l1 + 5], s_gc[8 * l2 + 5]);
+      gap = fmaxf(s_gc[8 * l1 + 6], s_gc[8 * l2 + 6]);
       float p1[3], p2[3], z1[3], z2[3], s1[3], s2[3];
       for (int k = 0; k < 3; ++k) {
         p1[k] = s_gx[3 * l1 + k]; p2[k] = s_gx[3 * l2 + k];
         z1[k] = s_gm[9 * l1 + 3 * k + 2]; z2[k] = s_gm[9 * l2 + 3 * k + 2];
-        s1[k] = gsize[3 * g1 + k]; s2[k] = gsize[3 * g2 + k];
+        s1[k] = s_gc[8 * l1 + 1 + k]; s2[k] = s_gc[8 * l2 + 1 + k];
       }
       bool near;
       float dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-      if (t1 == MJLAB_GEOM_PLANE) near = dot3(dif, z1) <= margin + rbound[g2];
-      else { float bound = margin + rbound[g1] + rbound[g2]; near = dot3(dif, dif) <= bound * bound; }
+      if (t1 == MJLAB_GEOM_PLANE) near = dot3(dif, z1) <= margin + s_gc[8 * l2 + 4];
+      else { float bound = margin + s_gc[8 * l1 + 4] + s_gc[8 * l2 + 4]; near = dot3(dif, dif) <= bound * bound; }
       if (near) {
         if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_SPHERE) {
           n = plane_sphere(rc, margin, p1, z1, p2, s2[0]);
@@ -1280,7 +1296,7 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
   // ---- box terrain: moving spheres / capsules vs static boxes found through the xy grid ----
   const int ntg = m.size.ntgeom;
   if (ntg > 0) {
-    int* s_cand = (int*)(s_gm + 9 * nl);            // [ntg][TCAND_MAX] box ids, ascending per geom
+    int* s_cand = (int*)(s_gc + 8 * nl);            // [ntg][TCAND_MAX] box ids, ascending per geom
     int* s_pair = s_cand + ntg * MJLAB_TCAND_MAX;   // flat, ordered candidate list: (ti << 24) | slot
     int* s_pairb = s_pair + ntg * MJLAB_TCAND_MAX;  // the same for moving BOX geoms (own sweep below)
     int pbase = 0, bbase = 0;
@@ -1290,8 +1306,8 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
       bool isbox = false;
       if (ti < ntg) {
         const int g = m.tgeom[ti];
-        isbox = m.geom_type[g] == MJLAB_GEOM_BOX;
-        nc = terrain_walk(m, s_gx + 3 * (g - g0), rbound[g] + gmargin[g], s_cand + ti * MJLAB_TCAND_MAX);
+        isbox = ((const int*)s_gc)[8 * (g - g0)] == MJLAB_GEOM_BOX;
+        nc = terrain_walk(m, s_gx + 3 * (g - g0), s_gc[8 * (g - g0) + 4] + s_gc[8 * (g - g0) + 5], s_cand + ti * MJLAB_TCAND_MAX);
       }
       int total, totalb;
       const int off = wave_excl_scan(isbox ? 0 : nc, lane, &total);
@@ -1312,16 +1328,16 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
         const int b = s_cand[ti * MJLAB_TCAND_MAX + (code & 0xffffff)];
         g = m.tgeom[ti];
         gb = m.tbox_geom[b];
-        margin = gmargin[g];  // terrain boxes carry no margin / gap (checked when the model is compiled)
-        gap = ggap[g];
         const int l = g - g0;
+        margin = s_gc[8 * l + 5];  // terrain boxes carry no margin / gap (checked when the model is compiled)
+        gap = s_gc[8 * l + 6];
         float cp[3], cz[3], cs[3], bpos[3], bmat[9], bsize[3];
         for (int k = 0; k < 3; ++k) {
-          cp[k] = s_gx[3 * l + k]; cz[k] = s_gm[9 * l + 3 * k + 2]; cs[k] = gsize[3 * g + k];
+          cp[k] = s_gx[3 * l + k]; cz[k] = s_gm[9 * l + 3 * k + 2]; cs[k] = s_gc[8 * l + 1 + k];
           bpos[k] = m.tbox_pos[3 * b + k]; bsize[k] = m.tbox_size[3 * b + k];
         }
         for (int k = 0; k < 9; ++k) bmat[k] = m.tbox_mat[9 * b + k];
-        if (m.geom_type[g] == MJLAB_GEOM_SPHERE) n = sphere_box(rc, margin, cp, cs[0], bpos, bmat, bsize);
+        if (((const int*)s_gc)[8 * l] == MJLAB_GEOM_SPHERE) n = sphere_box(rc, margin, cp, cs[0], bpos, bmat, bsize);
         else n = capsule_box(rc, margin, cp, cz, cs, bpos, bmat, bsize);
       }
       int total;
@@ -1343,12 +1359,12 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
         const int b = s_cand[ti * MJLAB_TCAND_MAX + (code & 0xffffff)];
         g = m.tgeom[ti];
         gb = m.tbox_geom[b];
-        margin = gmargin[g];
-        gap = ggap[g];
         const int l = g - g0;
+        margin = s_gc[8 * l + 5];
+        gap = s_gc[8 * l + 6];
         float cp[3], vec[3], corner[3], bpos[3], bmat[9], bsize[3];
         for (int k = 0; k < 3; ++k) {
-          const float sz = gsize[3 * g + k];
+          const float sz = s_gc[8 * l + 1 + k];
           cp[k] = s_gx[3 * l + k]; vec[k] = ((corner_id >> k) & 1) ? sz : -sz;
           bpos[k] = m.tbox_pos[3 * b + k]; bsize[k] = m.tbox_size[3 * b + k];
         }
