@@ -1136,7 +1136,8 @@ __device__ __forceinline__ void make_frame(float* f9, const float* f6) {
 // LDS: poses (12) and constants (8: type, size, rbound, margin, gap) of geoms [geom_lds0, ngeom) | per moving geom TCAND_MAX
 // candidate boxes | flat pair lists (non-box, box)
 __host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) {
-  return 20 * (s.ngeom - s.geom_lds0) + 3 * s.ntgeom * MJLAB_TCAND_MAX;
+  const int lists = 3 * s.ntgeom * MJLAB_TCAND_MAX;  // terrain lists; the close-pair list (npair) aliases them
+  return 20 * (s.ngeom - s.geom_lds0) + (lists > s.npair ? lists : s.npair);
 }
 
 // Contact parameters (mj_contactParam) of the pair (g1, g2) + ordered append of this lane's n
@@ -1199,6 +1200,7 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
   const int g0 = m.size.geom_lds0, nl = ng - g0;  // geoms [g0, ng) are staged; s_gx / s_gm are indexed by g - g0
   float* s_gx = smem;
   float* s_gm = s_gx + 3 * nl;
+  PROF_INIT();
   float* s_gc = s_gm + 9 * nl;  // per staged geom: type (as int bits), size[3], rbound, margin, gap, -
   const float *gsize = MF(geom_size), *rbound = MF(geom_rbound), *gmargin = MF(geom_margin), *ggap = MF(geom_gap);
   const float *gfri = MF(geom_friction), *gsolref = MF(geom_solref), *gsolimp = MF(geom_solimp), *gsolmix = MF(geom_solmix);
@@ -1218,15 +1220,45 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
     s_gc[8 * l + 6] = ggap[g];
   }
   __syncthreads();
-  int base = 0;  // contacts emitted so far (wave-uniform)
+  PROF_MARK(0);
+  // ---- static pairs, pass 1: the cheap bounding test for every pair, survivors compacted IN PAIR
+  // ORDER into an LDS list.  Few of the 502 G1 pairs are ever close, so the divergent narrow
+  // phase below runs over one or two sweeps instead of eight.
+  int* s_near = (int*)(s_gc + 8 * nl);  // (g1 << 16) | g2; aliases the terrain lists (built later)
+  int nnear = 0;
   for (int p0 = 0; p0 < npair; p0 += 64) {
     const int p = p0 + lane;
-    RawCon rc[4];
-    int n = 0;
     const int g1 = ng1, g2 = ng2;
     if (p + 64 < npair) { ng1 = m.pair_geom[2 * (p + 64)]; ng2 = m.pair_geom[2 * (p + 64) + 1]; }  // next sweep
-    float margin = 0.f, gap = 0.f;
+    bool near = false;
     if (p < npair) {
+      const int l1 = g1 - g0, l2 = g2 - g0;
+      const float margin = fmaxf(s_gc[8 * l1 + 5], s_gc[8 * l2 + 5]);
+      float dif[3];
+      for (int k = 0; k < 3; ++k) dif[k] = s_gx[3 * l2 + k] - s_gx[3 * l1 + k];
+      if (((const int*)s_gc)[8 * l1] == MJLAB_GEOM_PLANE) {
+        const float z1[3] = {s_gm[9 * l1 + 2], s_gm[9 * l1 + 5], s_gm[9 * l1 + 8]};
+        near = dot3(dif, z1) <= margin + s_gc[8 * l2 + 4];
+      } else {
+        const float bound = margin + s_gc[8 * l1 + 4] + s_gc[8 * l2 + 4];
+        near = dot3(dif, dif) <= bound * bound;
+      }
+    }
+    const unsigned long long nm = __ballot(near);
+    if (near) s_near[nnear + __popcll(nm & ((1ull << lane) - 1ull))] = (g1 << 16) | g2;
+    nnear += __popcll(nm);
+  }
+  __syncthreads();
+  int base = 0;  // contacts emitted so far (wave-uniform)
+  // ---- pass 2: narrow phase over the close pairs
+  for (int p0 = 0; p0 < nnear; p0 += 64) {
+    const int p = p0 + lane;
+    RawCon rc[4];
+    int n = 0, g1 = 0, g2 = 0;
+    float margin = 0.f, gap = 0.f;
+    if (p < nnear) {
+      const int code = s_near[p];
+      g1 = code >> 16; g2 = code & 0xffff;
       const int l1 = g1 - g0, l2 = g2 - g0;
       const int t1 = ((const int*)s_gc)[8 * l1], t2 = ((const int*)s_gc)[8 * l2];
       margin = fmaxf(s_gc[8 * l1 + 5], s_gc[8 * l2 + 5]);
@@ -1237,11 +1269,8 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
         z1[k] = s_gm[9 * l1 + 3 * k + 2]; z2[k] = s_gm[9 * l2 + 3 * k + 2];
         s1[k] = s_gc[8 * l1 + 1 + k]; s2[k] = s_gc[8 * l2 + 1 + k];
       }
-      bool near;
       float dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-      if (t1 == MJLAB_GEOM_PLANE) near = dot3(dif, z1) <= margin + s_gc[8 * l2 + 4];
-      else { float bound = margin + s_gc[8 * l1 + 4] + s_gc[8 * l2 + 4]; near = dot3(dif, dif) <= bound * bound; }
-      if (near) {
+      {
         if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_SPHERE) {
           n = plane_sphere(rc, margin, p1, z1, p2, s2[0]);
         } else if (t1 == MJLAB_GEOM_PLANE && t2 == MJLAB_GEOM_CAPSULE) {
@@ -1293,9 +1322,11 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
     if (n > 0) emit_contacts(m, d, w, g1, g2, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix);
     base += total;
   }
+  PROF_MARK(1);
   // ---- box terrain: moving spheres / capsules vs static boxes found through the xy grid ----
   const int ntg = m.size.ntgeom;
   if (ntg > 0) {
+    __syncthreads();  // the close-pair list shares its LDS with the lists built below
     int* s_cand = (int*)(s_gc + 8 * nl);            // [ntg][TCAND_MAX] box ids, ascending per geom
     int* s_pair = s_cand + ntg * MJLAB_TCAND_MAX;   // flat, ordered candidate list: (ti << 24) | slot
     int* s_pairb = s_pair + ntg * MJLAB_TCAND_MAX;  // the same for moving BOX geoms (own sweep below)
@@ -1385,6 +1416,8 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
   }
   const int ncm = m.size.nconmax;
   if (lane == 0) d.ncon[w] = base < ncm ? base : ncm;
+  PROF_MARK(2);
+  PROF_FLUSH(d.profile + (size_t)w * 64 + 32);
 }
 
 // ====================================================================================
@@ -1408,11 +1441,30 @@ __device__ __forceinline__ void load_actuator(ActuatorConst& c, const Model& m, 
   for (int k = 0; k < 3; ++k) c.bias[k] = biasprm[10 * a + k];
 }
 
-// Lowest set bit of a 64-bit mask held as two words; clears it.  Returns -1 when empty.
-__device__ __forceinline__ int pop_lowest(unsigned& lo, unsigned& hi) {
-  if (lo) { const int k = __ffs(lo) - 1; lo &= lo - 1u; return k; }
-  if (hi) { const int k = __ffs(hi) - 1; hi &= hi - 1u; return 32 + k; }
-  return -1;
+// v += sum_k cdof_k qvel_k (and a += sum_k cdd_k qvel_k) over the set bits k of (lo, hi), ascending.
+// Four terms per round: their LDS reads are issued together (a rolled loop would wait for each
+// term's operands in turn); slots past the end of the mask contribute c * 0.
+template <bool WITH_A>
+__device__ __forceinline__ void chain_accum(unsigned long long mk, const float* s_qvel, const float* s_cdof, const float* s_cdd,
+                                            float (&v)[6], float (&a)[6]) {
+  while (mk) {
+    int k[4];
+    float qv[4], c[4][6], cd[4][6];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // lowest set bit, cleared; -1 once the mask is empty (all by value: registers)
+      k[u] = mk ? __ffsll((long long)mk) - 1 : -1;
+      mk &= mk - 1ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k[u] >= 0 ? k[u] : 0;
+      qv[u] = k[u] >= 0 ? s_qvel[kk] : 0.f;
+      for (int e = 0; e < 6; ++e) { c[u][e] = s_cdof[6 * kk + e]; if (WITH_A) cd[u][e] = s_cdd[6 * kk + e]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      for (int e = 0; e < 6; ++e) { v[e] += c[u][e] * qv[u]; if (WITH_A) a[e] += cd[u][e] * qv[u]; }
+  }
 }
 
 __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d, const int flags) {
@@ -1427,13 +1479,14 @@ __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d,
   float* s_cvel = s_cdd + 6 * nv;
   float* s_cfrc = s_cvel + 6 * nb;
   float* s_cfs = s_cfrc + 6 * nb;
+  PROF_INIT();
   // ---- prologue: everything this lane needs from memory in any of its roles (body / dof /
   // actuator `lane`), as one batch of independent loads plus a short second one for values reached
   // through an index; the rest of the kernel only stores (see k_position)
   const float* qpos = d.qpos + (size_t)w * nq;
   const int rb = lane < nb ? lane : 0;  // body role
   const int b_snum = m.body_subtreenum[rb];
-  unsigned b_mlo = (unsigned)m.body_dofmask[2 * rb], b_mhi = (unsigned)m.body_dofmask[2 * rb + 1];
+  const unsigned b_mlo = (unsigned)m.body_dofmask[2 * rb], b_mhi = (unsigned)m.body_dofmask[2 * rb + 1];
   float b_in[10], b_xf[6];
   for (int k = 0; k < 10; ++k) b_in[k] = d.cinert[((size_t)w * nb + rb) * 10 + k];
   for (int k = 0; k < 6; ++k) b_xf[k] = d.xfrc_applied[((size_t)w * nb + rb) * 6 + k];
@@ -1450,7 +1503,7 @@ __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d,
   // second level
   const int v_type = m.jnt_type[v_jnt], v_dofadr = m.jnt_dofadr[v_jnt], v_qadr = m.jnt_qposadr[v_jnt];
   const float v_stiff = MF(jnt_stiffness)[v_jnt];
-  unsigned v_mlo = (unsigned)m.body_dofmask[2 * v_body], v_mhi = (unsigned)m.body_dofmask[2 * v_body + 1];
+  const unsigned v_mlo = (unsigned)m.body_dofmask[2 * v_body], v_mhi = (unsigned)m.body_dofmask[2 * v_body + 1];
   int a_qadr = 0, a_dadr = 0;
   float a_qpos = 0.f;
   if (lane < nu) {
@@ -1460,6 +1513,7 @@ __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d,
   }
   for (int i = lane; i < nv; i += 64) s_qact[i] = 0.f;
   __syncthreads();
+  PROF_MARK(0);
 
   // ---- mj_comVel / mj_rne without a level sweep.  cvel of a body is the sum of cdof_k qvel_k over
   // the dofs k of its ancestor chain (body_dofmask, ascending = root first, the order the
@@ -1469,29 +1523,23 @@ __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d,
     // dofs strictly before j; the three rotational dofs of a free joint all use the velocity after
     // its translations (mj_comVel), i.e. the prefix before the rotational block
     const int lim = (v_type == MJLAB_JNT_FREE && lane >= v_dofadr + 3) ? v_dofadr + 3 : lane;
-    unsigned lo = lim >= 32 ? v_mlo : (v_mlo & ((1u << lim) - 1u));
-    unsigned hi = lim >= 32 ? (v_mhi & ((1u << (lim - 32)) - 1u)) : 0u;
+    const unsigned long long mk = (((unsigned long long)v_mhi << 32) | v_mlo) & ((1ull << lim) - 1ull);  // lim < 64
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c6[6], cd[6];
-    for (int k = pop_lowest(lo, hi); k >= 0; k = pop_lowest(lo, hi)) {
-      const float qv = s_qvel[k];
-      for (int c = 0; c < 6; ++c) v[c] += s_cdof[6 * k + c] * qv;
-    }
+    chain_accum<false>(mk, s_qvel, s_cdof, s_cdd, v, cd);
     for (int c = 0; c < 6; ++c) c6[c] = s_cdof[6 * lane + c];
     cross_motion(cd, v, c6);
     const bool zero = v_type == MJLAB_JNT_FREE && lane < v_dofadr + 3;  // translations of a free joint
     for (int c = 0; c < 6; ++c) s_cdd[6 * lane + c] = zero ? 0.f : cd[c];
   }
   __syncthreads();
+  PROF_MARK(1);
   if (lane < nb) {
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a[6];
     for (int c = 0; c < 6; ++c) a[c] = c < 3 ? 0.f : -(float)m.opt.gravity[c - 3];
     if (lane == 0) {
       for (int c = 0; c < 6; ++c) { s_cvel[c] = 0.f; s_cfrc[c] = 0.f; }
     } else {
-      for (int k = pop_lowest(b_mlo, b_mhi); k >= 0; k = pop_lowest(b_mlo, b_mhi)) {
-        const float qv = s_qvel[k];
-        for (int c = 0; c < 6; ++c) { v[c] += s_cdof[6 * k + c] * qv; a[c] += s_cdd[6 * k + c] * qv; }
-      }
+      chain_accum<true>(((unsigned long long)b_mhi << 32) | b_mlo, s_qvel, s_cdof, s_cdd, v, a);
       float t1[6], t2[6], t3[6];
       mul_inert_vec(t1, b_in, a);
       mul_inert_vec(t2, b_in, v);
@@ -1500,6 +1548,7 @@ __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d,
     }
   }
   __syncthreads();
+  PROF_MARK(2);
   lds_to_global(d.cvel + (size_t)w * 6 * nb, s_cvel, 6 * nb, lane);
   lds_to_global(d.cdof_dot + (size_t)w * 6 * nv, s_cdd, 6 * nv, lane);
   // ---- up-sweep as subtree range sums (a subtree is a contiguous body-id range)
@@ -1514,6 +1563,7 @@ __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d,
     if (j < e) a0 += s_cfrc[6 * j + c];
     s_cfs[it] = a0 + a1;
   }
+  PROF_MARK(3);
   // ---- actuation
   for (int a0 = 0; a0 < nu; a0 += 64) {
     const int a = a0 + lane;
@@ -1568,6 +1618,8 @@ __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d,
     d.qfrc_actuator[(size_t)w * nv + i] = s_qact[i];
     d.qfrc_smooth[(size_t)w * nv + i] = smooth;
   }
+  PROF_MARK(4);
+  PROF_FLUSH(d.profile + (size_t)w * 64 + 24);
 }
 
 // ====================================================================================
@@ -1635,6 +1687,7 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
   if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ncm = m.size.nconmax, njm = m.size.njmax;
   const int nlim = constraint_nlim(m.size);
+  PROF_INIT();
   int* s_cadr = (int*)smem;                  // contact -> first efc row (or -1)
   int* s_ldof = s_cadr + ncm;                // limit row -> dof
   float* s_lsign = (float*)(s_ldof + nlim);  // limit row -> Jacobian entry (+-1)
@@ -1691,6 +1744,7 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
       for (int i = lane; i < nv; i += 64) J[(size_t)r * nv + i] = (i == dof) ? sg : 0.f;
     }
   }
+  PROF_MARK(0);
   // ---- contacts.  Phase A (lanes = contacts of a chunk): fetch the contact, its bodies'
   // chain masks and offsets, and evaluate everything that is per contact (impedance,
   // regulariser, reference stiffness/damping) once, into LDS.  Phase B (lanes = dofs): one
@@ -1777,6 +1831,7 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
     }
     unsigned long long todo = __ballot(adr >= 0 && c < ncon);
     __syncthreads();
+    PROF_MARK(1);
     while (todo) {
       const int i = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
@@ -1834,6 +1889,7 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
     }
     nefc += total;
     __syncthreads();
+    PROF_MARK(2);
   }
   if (lane == 0) d.nefc[w] = nefc;
   __syncthreads();
@@ -1862,6 +1918,8 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
     float* sd = d.sensordata + (size_t)w * m.size.nsensordata;
     for (int i = lane; i < dim; i += 64) sd[adr + i] = i == 0 ? (float)cnt : 0.f;
   }
+  PROF_MARK(3);
+  PROF_FLUSH(d.profile + (size_t)w * 64 + 40);
 }
 
 // ====================================================================================
@@ -2648,6 +2706,7 @@ static int check_model(const mjlab_model_t* m) {
   if (s.nv < 1 || s.nv > 64) return fail(-3, "nv must be in [1, 64] (one dof per lane)");
   if (s.nbody < 1 || s.nbody > 64) return fail(-13, "nbody must be in [1, 64] (one body per lane in the kinematics sweep)");
   if (s.njmax < 1 || s.nconmax < 1) return fail(-4, "njmax and nconmax must be >= 1");
+  if (s.ngeom > 65535) return fail(-19, "ngeom must be < 65536 (geom pairs are packed into one word)");
   if (m->opt.cone != 0) return fail(-5, "only the pyramidal friction cone is implemented");
   if (m->opt.integrator != MJLAB_INT_EULER && m->opt.integrator != MJLAB_INT_IMPLICITFAST)
     return fail(-6, "integrator must be Euler or implicitfast");

@@ -53,3 +53,14 @@ tot = pp.sum(axis=1)
 print(f"k_position mean cycles per world-step: {tot.mean():.0f}")
 for i, n in enumerate(PNAMES):
   print(f"  {n:28s} {pp[:, i].mean():10.0f} cycles  {100*pp[:, i].mean()/tot.mean():5.1f}%")
+
+for title, base, names in (
+  ("k_velocity", 24, ["prologue loads", "dof chain sums (cdof_dot)", "body chain sums (cvel, cfrc)", "writes + subtree sums", "actuation + bias + stores"]),
+  ("k_collision", 32, ["staging (poses, constants)", "static pair sweeps", "terrain + ncon"]),
+  ("k_constraint", 40, ["limits", "contacts phase A (per contact)", "contacts phase B (rows)", "nefc + sensors"]),
+):
+  pp = pall[:, base : base + len(names)]
+  tot = pp.sum(axis=1)
+  print(f"{title} mean cycles per world-step: {tot.mean():.0f}")
+  for i, n in enumerate(names):
+    print(f"  {n:36s} {pp[:, i].mean():10.0f} cycles  {100*pp[:, i].mean()/tot.mean():5.1f}%")
