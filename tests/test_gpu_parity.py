@@ -420,3 +420,72 @@ def test_parameter_branches_match_oracle(variant):
   ora.step(5)
   assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-5
   assert _rel(_np(sim.data.qvel), ora.qvel) < 2e-3
+
+
+MULTI_JOINT_XML = """
+<mujoco model="multi_joint">
+  <compiler angle="radian" autolimits="true"/>
+  <option timestep="0.002"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 0.01"/>
+    <body name="cart" pos="0 0 0.3">
+      <inertial pos="0 0 0" mass="2" diaginertia="0.02 0.02 0.02"/>
+      <joint name="sx" type="slide" axis="1 0 0"/>
+      <joint name="sy" type="slide" axis="0 1 0"/>
+      <geom name="cart_geom" type="sphere" size="0.1"/>
+      <body name="pole" pos="0 0 0.1" quat="0.9689124 0.2474040 0 0">
+        <inertial pos="0 0 0.3" mass="0.5" diaginertia="0.02 0.02 0.001"/>
+        <joint name="rx" type="hinge" axis="1 0 0" pos="0 0 0"/>
+        <joint name="ry" type="hinge" axis="0 1 0" pos="0 0 0.05" range="-0.4 0.4"/>
+        <geom name="pole_geom" type="capsule" size="0.03" fromto="0 0 0.05 0 0 0.6"/>
+        <body name="tip" pos="0 0 0.6">
+          <inertial pos="0 0 0" mass="0.2" diaginertia="0.001 0.001 0.001"/>
+          <joint name="tz" type="slide" axis="0 0 1" range="-0.1 0.1"/>
+          <joint name="rz" type="hinge" axis="0 0 1"/>
+          <geom name="tip_geom" type="sphere" size="0.05"/>
+        </body>
+      </body>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def test_bodies_with_several_joints():
+  """Bodies carrying two joints each (slide+slide, hinge+hinge with different anchors, slide+hinge):
+  the per-body joint loops of the kinematics and the chain sums of the velocity stage."""
+  import torch
+
+  from mjlab_amd import mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  spec = mjcf.Spec.from_string(MULTI_JOINT_XML)
+  spec.option.integrator = mjcf.INT_IMPLICITFAST
+  model = spec.compile()
+  assert model.nv == 6 and list(model.body_jntnum) == [0, 2, 2, 2]
+  nw = 64
+  rng = np.random.default_rng(0)
+  qpos = rng.normal(scale=0.6, size=(nw, model.nq))
+  qpos[:, 2] = rng.uniform(-3.0, 3.0, nw)  # swing the pole all the way round: it meets the floor
+  qvel = rng.normal(scale=1.0, size=(nw, model.nv))
+  sim = Simulation(nw, SimulationCfg(), model, "cuda:0")
+  ora = OracleSim(model, nw)
+  sim.data.qpos[:] = torch.from_numpy(qpos.astype(np.float32)).cuda()
+  sim.data.qvel[:] = torch.from_numpy(qvel.astype(np.float32)).cuda()
+  ora.qpos[:], ora.qvel[:] = qpos, qvel
+  sim.forward()
+  ora.forward()
+  assert ora.ncon.sum() > 10 and ora.nefc.max() > 4
+  assert np.array_equal(_np(sim.data.ncon).ravel(), ora.ncon.ravel())
+  assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
+  for f in KIN:
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 2e-6, f
+  for f in VEL:
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-5, f
+  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 1e-4
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
+  for _ in range(20):
+    sim.step()
+  ora.step(20)
+  assert _rel(_np(sim.data.qpos), ora.qpos) < 1e-4
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 2e-3

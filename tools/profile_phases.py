@@ -19,7 +19,9 @@ NAMES = ["M load+factor+qLD", "qacc_smooth solve", "warmstart", "init hessian pa
          "LS evals", "post-LS update + J^T f", "solve tail", "integrate", "ls evals (count)", "line searches (count)", "chol_factor (all sites)", "chol_solve (all sites)", "factor calls (count)", "solve calls (count)"]
 
 model = robots.load_model("g1_velocity_flat")
-sim = Simulation(4096, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
+import os
+NW = int(os.environ.get("NWORLD", "4096"))  # 256 = one wave per CU: pure single-wave latency
+sim = Simulation(NW, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
 roll = PhysicsRollout(sim, action_scale=g1_action_scale(model), seed=42)
 for _ in range(40):
   roll.step(roll.random_action())
