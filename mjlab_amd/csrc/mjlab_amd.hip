@@ -11,8 +11,12 @@
 // 64-lane wave, so every stage kernel launches `nworld` workgroups; with 4096 worlds that
 // is 16 waves per CU on the 256 CUs of an MI355X, all resident at once: every stage keeps
 // its LDS footprint at or below 10 KB and its registers at or below 128 (4 waves per SIMD).
-// Inside a wave, lanes own bodies (one per lane in the tree sweeps), dofs, candidate geom
-// pairs, contacts, constraint rows or matrix rows, depending on the stage.  Public mjData
+// Inside a wave, lanes own bodies, dofs, candidate geom pairs, contacts, constraint rows or
+// matrix rows, depending on the stage.  The tree recursions are not swept level by level: a
+// body composes the relative poses of its ancestors (kinematics) or sums over the dofs of its
+// ancestor chain (velocities) on its own, and the stage kernels request every model constant a
+// lane needs in one batch at kernel start -- at 4096 worlds these kernels are bound by
+// dependent latency (global round trips above all), not by throughput.  Public mjData
 // arrays are [nworld][n] row-major, so "lanes = elements of one world's row" gives coalesced
 // HBM traffic; intermediates that never leave a stage live in LDS or registers.  The only
 // GEMM-shaped work -- the Newton Hessian H = M + J^T D J over the ACTIVE constraint rows --
@@ -20,7 +24,7 @@
 //
 // Five stage kernels per physics step:
 //   k_position    kinematics, comPos, crb, dense M           (skipped after an unchanged forward())
-//   k_collision   static pair list, analytic primitives       (   "   )
+//   k_collision   static pair list + box terrain through an xy grid, analytic primitives (   "   )
 //   k_velocity    comVel, rne, actuation, qfrc_smooth
 //   k_constraint  limits + contacts -> efc rows, sensors      (   "   )
 //   k_solve_integrate<NVP>  Newton solver (LDL^T in registers/LDS, exact line search),
