@@ -489,3 +489,47 @@ def test_bodies_with_several_joints():
   ora.step(20)
   assert _rel(_np(sim.data.qpos), ora.qpos) < 1e-4
   assert _rel(_np(sim.data.qvel), ora.qvel) < 2e-3
+
+
+def test_more_geoms_sites_and_actuators_than_lanes():
+  """More than 128 moving geoms, more than 64 sites and more than 64 actuators: the rounds beyond
+  what the stage kernels pre-load into registers (in-place loads) give the same results."""
+  import torch
+
+  from mjlab_amd import mjcf
+  from mjlab_amd.mjcf import SpecActuator
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  spec = mjcf.Spec.from_string(MULTI_JOINT_XML)
+  spec.option.integrator = mjcf.INT_IMPLICITFAST
+  rng = np.random.default_rng(3)
+  bodies = [spec.body(n) for n in ("cart", "pole", "tip")]
+  for i in range(150):  # decoration geoms: never collide, but their poses are outputs
+    q = rng.normal(size=4)
+    spec.add_geom(bodies[i % 3], f"deco_{i}", mjcf.GEOM_SPHERE, (0.01,), pos=rng.normal(scale=0.2, size=3), quat=q / np.linalg.norm(q), contype=0, conaffinity=0)
+  for i in range(70):
+    q = rng.normal(size=4)
+    spec.add_site(bodies[i % 3], f"site_{i}", pos=rng.normal(scale=0.2, size=3), quat=q / np.linalg.norm(q))
+  joints = ["sx", "sy", "rx", "ry", "tz", "rz"]
+  for i in range(70):  # several actuators per joint
+    lim = i % 3 != 0
+    spec.actuators.append(SpecActuator(name=f"act_{i}", joint=joints[i % 6], gainprm0=1.0 + 0.1 * i, biasprm=(0.01 * i, -(1.0 + 0.1 * i), -0.05),
+                                       forcerange=(-2.0, 2.0) if lim else None, ctrlrange=(-0.5, 0.5) if i % 2 else None, gear=1.0 + 0.01 * i))
+  model = spec.compile()
+  assert model.ngeom - model.nstaticgeom > 128 and model.nsite > 64 and model.nu > 64
+  nw = 16
+  qpos = rng.normal(scale=0.4, size=(nw, model.nq))
+  qvel = rng.normal(scale=0.5, size=(nw, model.nv))
+  ctrl = rng.normal(scale=0.6, size=(nw, model.nu))
+  sim = Simulation(nw, SimulationCfg(), model, "cuda:0")
+  ora = OracleSim(model, nw)
+  for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+    getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+    getattr(ora, f)[:] = v
+  sim.forward()
+  ora.forward()
+  for f in ("geom_xpos", "geom_xmat", "site_xpos", "site_xmat"):
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 2e-6, f
+  for f in ("actuator_force", "qfrc_actuator", "qfrc_smooth"):
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-5, f
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
