@@ -1039,7 +1039,8 @@ __device__ __forceinline__ float seg_box_dist2(const float* pc, const float* h, 
 }
 // Capsule vs box: up to 4 sphere_box() contacts of spheres of the capsule's radius on its axis
 // (point cpos + axis * halflen * t): the two ends, plus the ends ta <= tb of the interval where
-// the axis is closest to the box when they are interior points outside the box.  The distance
+// the axis is closest to the box when they are interior points outside the box (if the axis runs
+// through the box with both ends outside: the inside point nearest to the capsule's centre).  The distance
 // along the axis is convex, so its slope is monotone: ta / tb come from two bisections.
 #define MJLAB_CAPBOX_ITERS 24
 __device__ __forceinline__ int capsule_box(RawCon* c, float margin, const float* cpos, const float* axis, const float* csize, const float* bpos,
@@ -1063,12 +1064,19 @@ __device__ __forceinline__ int capsule_box(RawCon* c, float margin, const float*
   const float ta = sm >= 0.f ? -1.f : (sp < 0.f ? 1.f : ahi);
   const float tb = sp <= 0.f ? 1.f : (sm > 0.f ? -1.f : blo);
   const float eps = 1e-6f;
-  const bool use_a = ta > -1.f + eps && ta < 1.f - eps && seg_box_dist2(pc, h, bsize, ta) > 0.f;
-  const bool use_b = tb > -1.f + eps && tb < 1.f - eps && tb - ta > eps && seg_box_dist2(pc, h, bsize, tb) > 0.f;
+  const bool ia = ta > -1.f + eps && ta < 1.f - eps, ib = tb > -1.f + eps && tb < 1.f - eps;
+  const bool oa = seg_box_dist2(pc, h, bsize, ta) > 0.f, ob = seg_box_dist2(pc, h, bsize, tb) > 0.f;
+  // the axis runs THROUGH the box with both ends outside (a thin capsule across an edge, deeper than
+  // its radius): the inside point nearest to the capsule's centre carries the contact (the middle of
+  // a chord through opposite faces would be equidistant from both)
+  const bool pierce = ia && ib && !oa && !ob;
+  const float tmid = pierce ? clipf(0.f, ta, tb) : ta;
+  const bool use_a = pierce || (ia && oa);
+  const bool use_b = ib && tb - ta > eps && ob;
   int n = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float t = q == 0 ? 1.f : (q == 1 ? -1.f : (q == 2 ? ta : tb));
+    const float t = q == 0 ? 1.f : (q == 1 ? -1.f : (q == 2 ? tmid : tb));
     const bool use = q < 2 ? true : (q == 2 ? use_a : use_b);
     float p[3];
     RawCon tc;

@@ -500,7 +500,10 @@ static inline real seg_box_dist2(const real* pc, const real* h, const real* bsiz
  * capsule lies over a face), plus the ends ta <= tb of the interval where the axis is closest to
  * the box -- the distance along the axis is convex, so its slope is monotone and ta / tb are found by
  * bisection -- when they are interior points OUTSIDE the box (a capsule crossing an edge or a
- * corner; where the axis itself pierces the box the end points carry the contact). */
+ * corner).  Where the axis itself enters the box, an end point inside it carries the contact; if
+ * both ends are outside, the point of the inside stretch nearest to the capsule's centre does (not
+ * its middle: the middle of a chord that enters through one face and leaves through the opposite
+ * one is equidistant from both, and "nearest face" would be decided by rounding). */
 #define MJO_CAPBOX_ITERS 24
 static int capsule_box(rawcon_t* c, real margin, const real* cpos, const real* cmat, const real* csize, const real* bpos,
                        const real* bmat, const real* bsize) {
@@ -535,9 +538,13 @@ static int capsule_box(rawcon_t* c, real margin, const real* cpos, const real* c
     tb = lo;
   }
   const real eps = (real)1e-6;
-  real ts[4] = {1, -1, ta, tb};
-  int use[4] = {1, 1, ta > -1 + eps && ta < 1 - eps && seg_box_dist2(pc, h, bsize, ta) > 0,
-                tb > -1 + eps && tb < 1 - eps && tb - ta > eps && seg_box_dist2(pc, h, bsize, tb) > 0};
+  const int ia = ta > -1 + eps && ta < 1 - eps, ib = tb > -1 + eps && tb < 1 - eps;
+  const int oa = seg_box_dist2(pc, h, bsize, ta) > 0, ob = seg_box_dist2(pc, h, bsize, tb) > 0;
+  /* the axis runs THROUGH the box with both ends outside (a thin capsule across an edge, deeper
+   * than its radius): the inside point nearest to the capsule's centre carries the contact */
+  const int pierce = ia && ib && !oa && !ob;
+  real ts[4] = {1, -1, pierce ? clipr(0, ta, tb) : ta, tb};
+  int use[4] = {1, 1, pierce || (ia && oa), ib && tb - ta > eps && ob};
   int n = 0;
   for (int q = 0; q < 4; q++) {
     if (!use[q]) continue;

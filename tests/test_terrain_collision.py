@@ -356,3 +356,46 @@ def test_g1_stands_and_walks_off_steps_on_rough_terrain():
   assert (height > 0.05).all() and (height > 0.5).mean() > 0.7  # a PD-only robot may sit down on a step edge
   # the foot sensors see the terrain body
   assert (o.sensordata.sum(axis=1) >= 1).mean() > 0.7
+
+
+def test_capsule_box_deepest_contact_is_the_true_distance():
+  """Property check against brute force: the smallest contact distance of capsule_box equals the
+  true capsule-box distance (min over the axis of point-box distance, minus the radius) whenever
+  the capsule does not pierce the box, and there is no contact when the capsule is clear."""
+  m = probes_on([[0.0, 0.0, 0.0, 0.3, 0.2, 0.1]])  # one box at the origin, half sizes 0.3 x 0.2 x 0.1
+  rng = np.random.default_rng(0)
+  nw = 400
+  o = OracleSim(m, nworld=nw)
+  o.qpos[:, :3] = [50, 0, 5]
+  o.qpos[:, 3] = 1
+  d = rng.normal(size=(nw, 3))
+  d /= np.linalg.norm(d, axis=1, keepdims=True)
+  o.qpos[:, 7:10] = d * rng.uniform(0.1, 0.6, (nw, 1))
+  q = rng.normal(size=(nw, 4))
+  o.qpos[:, 10:14] = q / np.linalg.norm(q, axis=1, keepdims=True)
+  o.forward()
+  cap = m.names["geom"].index("cap_geom")
+  half, r, s = 0.2, 0.05, np.array([0.3, 0.2, 0.1])
+  axis = o.geom_xmat[:, cap].reshape(nw, 3, 3)[:, :, 2]
+  centre = o.geom_xpos[:, cap]
+  t = np.linspace(-1, 1, 4001)
+  checked = clear = 0
+  for w in range(nw):
+    pts = centre[w] + np.outer(t * half, axis[w])
+    dist = np.linalg.norm(np.maximum(np.abs(pts) - s, 0.0), axis=1)
+    true = dist.min() - r
+    n = int(o.ncon[w, 0])
+    if dist.min() == 0.0:
+      assert n >= 1  # axis pierces the box: the end points carry the contact
+      continue
+    if true > 1e-6:
+      assert n == 0
+      clear += 1
+    elif true < -1e-6:
+      assert n >= 1
+      assert abs(o.contact_dist[w, :n].min() - true) < 2e-6, (w, o.contact_dist[w, :n], true)
+      # every contact is a real one: its depth is the sphere-box distance at some axis point
+      for k in range(n):
+        assert (np.abs(dist - r - o.contact_dist[w, k]) < 1e-4).any()
+      checked += 1
+  assert checked > 40 and clear > 40
