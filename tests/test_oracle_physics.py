@@ -350,3 +350,46 @@ def test_newton_solution_matches_independent_minimiser():
   got = s.qacc[0]
   assert cost(got)[0] <= cost(ref)[0] * (1 + 1e-9) + 1e-9  # at least as good as the reference minimiser
   assert np.abs(got - ref).max() / max(1.0, np.abs(ref).max()) < 1e-5
+
+
+def test_capsule_capsule_and_sphere_capsule_distance_by_brute_force():
+  """The contact distance of the capsule-capsule / sphere-capsule primitives equals the true
+  distance between the shapes (dense scan of both axes), and clear pairs give no contact."""
+  m = robots.mixed_model()
+  names = m.names["geom"]
+  gc1, gc2, gb = names.index("cap_geom"), names.index("cap2_geom"), names.index("ball_geom")
+  r1, h1 = m.geom_size[gc1][:2]
+  r2, h2 = m.geom_size[gc2][:2]
+  rb = m.geom_size[gb][0]
+  rng = np.random.default_rng(0)
+  nw = 300
+  o = OracleSim(m, nworld=nw)
+  o.reset()
+  adr = {n: m.jnt_qposadr[m.names["joint"].index(n)] for n in ("cap_root", "cap2_root", "ball_root")}
+  for name, scale in (("cap_root", 0.0), ("cap2_root", 0.25), ("ball_root", 0.25)):
+    a = adr[name]
+    o.qpos[:, a : a + 3] = rng.normal(scale=scale, size=(nw, 3)) + [0, 0, 3.0]  # far above the floor
+    q = rng.normal(size=(nw, 4))
+    o.qpos[:, a + 3 : a + 7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+  o.forward()
+  t = np.linspace(-1, 1, 401)
+  hit = clear = 0
+  for w in range(nw):
+    n = int(o.ncon[w, 0])
+    pairs = {tuple(g): o.contact_dist[w, k] for k, g in enumerate(o.contact_geom[w, :n].tolist())}
+    p1, a1 = o.geom_xpos[w, gc1], o.geom_xmat[w, gc1].reshape(3, 3)[:, 2]
+    p2, a2 = o.geom_xpos[w, gc2], o.geom_xmat[w, gc2].reshape(3, 3)[:, 2]
+    pb = o.geom_xpos[w, gb]
+    s1 = p1 + np.outer(t * h1, a1)
+    s2 = p2 + np.outer(t * h2, a2)
+    true_cc = np.sqrt(((s1[:, None, :] - s2[None, :, :]) ** 2).sum(axis=2).min()) - r1 - r2
+    for key, true in (((gc1, gc2), true_cc), ((gb, gc1), np.linalg.norm(s1 - pb, axis=1).min() - rb - r1),
+                      ((gb, gc2), np.linalg.norm(s2 - pb, axis=1).min() - rb - r2)):
+      got = pairs.get(key, pairs.get(key[::-1]))
+      if true > 1e-4:
+        assert got is None
+        clear += 1
+      elif true < -1e-4:
+        assert got is not None and abs(got - true) < 2e-4, (w, key, got, true)  # scan resolution ~1e-4
+        hit += 1
+  assert hit > 60 and clear > 60
