@@ -1361,6 +1361,7 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
       bbase += totalb;
     }
     __syncthreads();
+    PROF_MARK(3);
     for (int p0 = 0; p0 < pbase; p0 += 64) {        // lanes = candidate (geom, box) pairs
       const int p = p0 + lane;
       RawCon rc[4];

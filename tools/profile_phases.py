@@ -7,6 +7,8 @@ Run: MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so python tools/profile_phases.
 import sys
 from pathlib import Path
 
+import os
+
 import numpy as np
 import torch
 
@@ -18,8 +20,7 @@ from mjlab_amd.sim import Simulation, SimulationCfg  # noqa: E402
 NAMES = ["M load+factor+qLD", "qacc_smooth solve", "warmstart", "init hessian pass", "H factor+solve", "LS prep (Mv, Jv)",
          "LS evals", "post-LS update + J^T f", "solve tail", "integrate", "ls evals (count)", "line searches (count)", "chol_factor (all sites)", "chol_solve (all sites)", "factor calls (count)", "solve calls (count)"]
 
-model = robots.load_model("g1_velocity_flat")
-import os
+model = robots.load_model(os.environ.get("SCENE", "g1_velocity_flat"))
 NW = int(os.environ.get("NWORLD", "4096"))  # 256 = one wave per CU: pure single-wave latency
 sim = Simulation(NW, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
 roll = PhysicsRollout(sim, action_scale=g1_action_scale(model), seed=42)
@@ -58,7 +59,7 @@ for i, n in enumerate(PNAMES):
 
 for title, base, names in (
   ("k_velocity", 24, ["prologue loads", "dof chain sums (cdof_dot)", "body chain sums (cvel, cfrc)", "writes + subtree sums", "actuation + bias + stores"]),
-  ("k_collision", 32, ["staging (poses, constants)", "static pair sweeps", "terrain + ncon"]),
+  ("k_collision", 32, ["staging (poses, constants)", "static pair sweeps", "terrain narrow phase + ncon", "terrain grid walk"]),
   ("k_constraint", 40, ["limits", "contacts phase A (per contact)", "contacts phase B (rows)", "nefc + sensors"]),
 ):
   pp = pall[:, base : base + len(names)]
