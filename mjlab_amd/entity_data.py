@@ -37,7 +37,7 @@ class EntityReadback:
   robot attached after the terrain, reference scene/scene.py:133-147)."""
 
   def __init__(self, sim: Simulation, root_body: int | None = None) -> None:
-    m = sim.mj_model
+    m = sim.host_model
     if root_body is None:
       root_body = int(np.nonzero(np.asarray(m.body_parentid) == 0)[0][-1])
     nsub = int(m.body_subtreenum[root_body])

@@ -53,7 +53,7 @@ _GEOM_TYPES = {
 _JNT_TYPES = {"free": JNT_FREE, "ball": JNT_BALL, "slide": JNT_SLIDE, "hinge": JNT_HINGE}
 
 OBJ_BODY, OBJ_XBODY, OBJ_GEOM, OBJ_SITE = 1, 2, 5, 6  # mjtObj
-SENS_CONTACT = 42  # placeholder id for mjSENS_CONTACT (only its identity matters here)
+SENS_CONTACT = 42  # mjtSensor.mjSENS_CONTACT of the pinned mujoco build (reference typings/mujoco/_enums.pyi:5166)
 
 INT_EULER, INT_IMPLICITFAST = 0, 3  # mjtIntegrator
 SOL_PGS, SOL_CG, SOL_NEWTON = 0, 1, 2  # mjtSolver
@@ -811,6 +811,78 @@ def _compile_terrain(m: "Model", tids: np.ndarray, moving: list[int]) -> None:
   np.maximum.at(m.tgrid_ztop, cells, hi[items, 2])
 
 
+def finalize_topology(m: "Model", excl: set) -> None:
+  """Everything the kernels need beyond mjModel's own arrays, derived from them: tree levels,
+  subtree sizes (bodies are numbered depth first, so a subtree is an id range), the ancestor-dof
+  bit mask of every body, the leading run of static geoms, the static candidate pair list and the
+  terrain grid.  ``excl`` holds the excluded body pairs ``(min, max)``.  Shared by the MJCF compiler
+  below and by ``from_mujoco.model_from_mujoco`` (a model that arrives as ``mujoco.MjModel``)."""
+  nbody, nv, ngeom = m.nbody, m.nv, m.ngeom
+  # body level in the tree (world = 0); used by the level-parallel sweeps
+  m.body_depth = np.zeros(nbody, np.int32)
+  for i in range(1, nbody):
+    m.body_depth[i] = m.body_depth[m.body_parentid[i]] + 1
+
+  m.nlevel = int(m.body_depth.max()) + 1
+  order = np.argsort(m.body_depth, kind="stable").astype(np.int32)
+  m.level_body = order
+  m.level_adr = np.searchsorted(m.body_depth[order], np.arange(m.nlevel + 1)).astype(np.int32)
+  # bodies are in depth-first order, so a subtree is the contiguous id range [b, b + subtreenum[b])
+  m.body_subtreenum = np.ones(nbody, np.int32)
+  for i in range(nbody - 1, 0, -1):
+    m.body_subtreenum[m.body_parentid[i]] += m.body_subtreenum[i]
+
+  if nv > 64:
+    raise NotImplementedError("nv > 64 is not supported by the wave-per-world kernels")
+  # per-body bitmask of the dofs that move it (ancestor chain); nv <= 64
+  m.body_dofmask = np.zeros(nbody, np.uint64)
+  for i in range(1, nbody):
+    mask = int(m.body_dofmask[m.body_parentid[i]])
+    for k in range(m.body_dofnum[i]):
+      mask |= 1 << int(m.body_dofadr[i] + k)
+    m.body_dofmask[i] = np.uint64(mask)
+
+  # Static geoms (world body or welded to it) never move: their poses are computed once.  Static
+  # colliding BOXES are the terrain (reference src/mjlab/terrains/primitive_terrains.py: every
+  # terrain piece is a box under the static ``terrain`` body); there can be thousands, so they
+  # never enter the static pair list -- moving geoms find them through a uniform xy grid.
+  static = m.body_weldid[m.geom_bodyid] == 0
+  collides = (m.geom_contype != 0) | (m.geom_conaffinity != 0)
+  terrain = static & (m.geom_type == GEOM_BOX) & collides
+  m.nstaticgeom = int(np.argmin(static)) if not static.all() else ngeom  # leading run of static geoms
+  pairs = []
+  cand = [g for g in range(ngeom) if collides[g] and not terrain[g]]
+  for i1, g1 in enumerate(cand):
+    for g2 in cand[i1 + 1 :]:
+      ct1, ca1 = m.geom_contype[g1], m.geom_conaffinity[g1]
+      ct2, ca2 = m.geom_contype[g2], m.geom_conaffinity[g2]
+      if not ((ct1 & ca2) or (ct2 & ca1)):
+        continue
+      b1, b2 = m.geom_bodyid[g1], m.geom_bodyid[g2]
+      w1, w2 = m.body_weldid[b1], m.body_weldid[b2]
+      if w1 == w2:
+        continue  # same (welded) body, includes static-static
+      if w1 != 0 and w2 != 0:
+        pw1 = m.body_weldid[m.body_parentid[w1]]
+        pw2 = m.body_weldid[m.body_parentid[w2]]
+        if pw1 == w2 or pw2 == w1:
+          continue  # parent-child filter (only when neither is welded to the world)
+      if (min(b1, b2), max(b1, b2)) in excl:
+        continue
+      # collision functions are defined for type1 <= type2
+      a_, b_ = (g1, g2) if m.geom_type[g1] <= m.geom_type[g2] else (g2, g1)
+      t1, t2 = m.geom_type[a_], m.geom_type[b_]
+      if (t1, t2) not in _PAIR_FUNCS:
+        raise NotImplementedError(f"no collision function for geom types ({t1}, {t2}): '{m.names['geom'][a_]}' vs '{m.names['geom'][b_]}'")
+      pairs.append((a_, b_))
+  m.pair_geom = np.array(pairs, np.int32).reshape(len(pairs), 2)
+  m.npair = len(pairs)
+  _compile_terrain(m, np.flatnonzero(terrain), [g for g in cand if not static[g]])
+  # geoms [geom_lds0, ngeom) are the ones the collision stage keeps on chip
+  m.geom_lds0 = int(min(m.nstaticgeom, m.pair_geom.min())) if m.npair else m.nstaticgeom
+
+
+
 def _compile(spec: Spec) -> Model:
   m = Model()
   m.opt = Option(**spec.option.__dict__)
@@ -900,20 +972,6 @@ def _compile(spec: Spec) -> Model:
   for i in range(nbody - 1, 0, -1):
     m.body_subtreemass[m.body_parentid[i]] += m.body_subtreemass[i]
 
-  # body level in the tree (world = 0); used by the level-parallel sweeps
-  m.body_depth = np.zeros(nbody, np.int32)
-  for i in range(1, nbody):
-    m.body_depth[i] = m.body_depth[m.body_parentid[i]] + 1
-
-  m.nlevel = int(m.body_depth.max()) + 1
-  order = np.argsort(m.body_depth, kind="stable").astype(np.int32)
-  m.level_body = order
-  m.level_adr = np.searchsorted(m.body_depth[order], np.arange(m.nlevel + 1)).astype(np.int32)
-  # bodies are in depth-first order, so a subtree is the contiguous id range [b, b + subtreenum[b])
-  m.body_subtreenum = np.ones(nbody, np.int32)
-  for i in range(nbody - 1, 0, -1):
-    m.body_subtreenum[m.body_parentid[i]] += m.body_subtreenum[i]
-
   # ---- joints / dofs -------------------------------------------------------
   m.jnt_type = np.array(jnt_type, np.int32).reshape(njnt)
   m.jnt_qposadr = np.array(jnt_qposadr, np.int32).reshape(njnt)
@@ -965,16 +1023,6 @@ def _compile(spec: Spec) -> Model:
       last_dof_of_body[i] = a + m.body_dofnum[i] - 1
     else:
       last_dof_of_body[i] = inherited
-  if nv > 64:
-    raise NotImplementedError("nv > 64 is not supported by the wave-per-world kernels")
-  # per-body bitmask of the dofs that move it (ancestor chain); nv <= 64
-  m.body_dofmask = np.zeros(nbody, np.uint64)
-  for i in range(1, nbody):
-    mask = int(m.body_dofmask[m.body_parentid[i]])
-    for k in range(m.body_dofnum[i]):
-      mask |= 1 << int(m.body_dofadr[i] + k)
-    m.body_dofmask[i] = np.uint64(mask)
-
   # ---- geoms / sites -------------------------------------------------------
   m.geom_type = np.array([g.type for g in geoms], np.int32).reshape(ngeom)
   m.geom_bodyid = np.array([bid[id(g.body)] for g in geoms], np.int32).reshape(ngeom)
@@ -1080,44 +1128,8 @@ def _compile(spec: Spec) -> Model:
     ia, ib = m.names["body"].index(a), m.names["body"].index(b)
     excl.add((min(ia, ib), max(ia, ib)))
   m.nexclude = len(excl)
-  # Static geoms (world body or welded to it) never move: their poses are computed once.  Static
-  # colliding BOXES are the terrain (reference src/mjlab/terrains/primitive_terrains.py: every
-  # terrain piece is a box under the static ``terrain`` body); there can be thousands, so they
-  # never enter the static pair list -- moving geoms find them through a uniform xy grid.
-  static = m.body_weldid[m.geom_bodyid] == 0
-  collides = (m.geom_contype != 0) | (m.geom_conaffinity != 0)
-  terrain = static & (m.geom_type == GEOM_BOX) & collides
-  m.nstaticgeom = int(np.argmin(static)) if not static.all() else ngeom  # leading run of static geoms
-  pairs = []
-  cand = [g for g in range(ngeom) if collides[g] and not terrain[g]]
-  for i1, g1 in enumerate(cand):
-    for g2 in cand[i1 + 1 :]:
-      ct1, ca1 = m.geom_contype[g1], m.geom_conaffinity[g1]
-      ct2, ca2 = m.geom_contype[g2], m.geom_conaffinity[g2]
-      if not ((ct1 & ca2) or (ct2 & ca1)):
-        continue
-      b1, b2 = m.geom_bodyid[g1], m.geom_bodyid[g2]
-      w1, w2 = m.body_weldid[b1], m.body_weldid[b2]
-      if w1 == w2:
-        continue  # same (welded) body, includes static-static
-      if w1 != 0 and w2 != 0:
-        pw1 = m.body_weldid[m.body_parentid[w1]]
-        pw2 = m.body_weldid[m.body_parentid[w2]]
-        if pw1 == w2 or pw2 == w1:
-          continue  # parent-child filter (only when neither is welded to the world)
-      if (min(b1, b2), max(b1, b2)) in excl:
-        continue
-      # collision functions are defined for type1 <= type2
-      a_, b_ = (g1, g2) if m.geom_type[g1] <= m.geom_type[g2] else (g2, g1)
-      t1, t2 = m.geom_type[a_], m.geom_type[b_]
-      if (t1, t2) not in _PAIR_FUNCS:
-        raise NotImplementedError(f"no collision function for geom types ({t1}, {t2}): '{m.names['geom'][a_]}' vs '{m.names['geom'][b_]}'")
-      pairs.append((a_, b_))
-  m.pair_geom = np.array(pairs, np.int32).reshape(len(pairs), 2)
-  m.npair = len(pairs)
-  _compile_terrain(m, np.flatnonzero(terrain), [g for g in cand if not static[g]])
-  # geoms [geom_lds0, ngeom) are the ones the collision stage keeps on chip
-  m.geom_lds0 = int(min(m.nstaticgeom, m.pair_geom.min())) if m.npair else m.nstaticgeom
+  m.exclude_signature = np.array(sorted((a << 16) + b for a, b in excl), np.int32)  # mjModel's encoding
+  finalize_topology(m, excl)
 
   # ---- keyframes ----------------------------------------------------------------
   nkey = len(spec.keys)

@@ -25,7 +25,7 @@ class PhysicsRollout:
                episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0,
                masked_forward: bool = False, fused_reset: bool = True, min_up_z: float | None = None,
                max_init_terrain_level: int | None = 5) -> None:
-    m: Model = sim.mj_model
+    m: Model = sim.host_model
     dev = sim.data.qpos.device
     self.sim, self.m, self.decimation = sim, m, decimation
     self.gen = torch.Generator(device=dev)

@@ -164,6 +164,14 @@ class Simulation:
         f"mjlab_amd.Simulation needs a ROCm GPU device (got '{device}', "
         f"torch.cuda.is_available()={torch.cuda.is_available()}); there is no CPU fallback"
       )
+    # The reference hands over a ``mujoco.MjModel`` (sim/sim.py:97-99).  Anything that is not this
+    # package's own host model is read through mjModel's attribute names (from_mujoco.py); the
+    # object itself stays available as ``mj_model`` for viewers / exporters, as in the reference.
+    self._given_model = model
+    if not isinstance(model, Model):
+      from .from_mujoco import model_from_mujoco
+
+      model = model_from_mujoco(model)
     check_supported(model)
     self.cfg = cfg
     self.device = device
@@ -296,7 +304,13 @@ class Simulation:
       self.forward_graph = g2
 
   @property
-  def mj_model(self) -> Model:
+  def mj_model(self):
+    """The model object the caller passed in (reference sim/sim.py:145-150 keeps the MjModel)."""
+    return self._given_model
+
+  @property
+  def host_model(self) -> Model:
+    """This package's host-side model (mjModel-named numpy arrays + the derived tables)."""
     return self._mj_model
 
   @property

@@ -1,0 +1,135 @@
+"""``mujoco.MjModel`` -> host model (mjlab_amd/from_mujoco.py), the type the reference passes to
+``Simulation`` (src/mjlab/sim/sim.py:97-99).  The ``mujoco`` wheel is not installable here, so the
+test hands the converter an object that exposes mjModel's own attributes and nothing else -- the
+native arrays, ``opt``, ``stat``, the ``names`` blob with its ``name_*adr`` tables,
+``exclude_signature`` -- built from a compiled model, and requires the round trip to reproduce every
+derived table and the oracle's physics bit for bit.  Enum ids are pinned to the reference's stubs."""
+
+import json
+import types
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from mjlab_amd import from_mujoco, mjcf, robots
+from oracle.oracle import OracleSim
+
+PINS = json.loads((Path(__file__).parent / "golden" / "reference_constants.json").read_text())
+
+# attributes a real mjModel does NOT have: everything finalize_topology derives, plus host-side extras
+DERIVED = {"body_depth", "nlevel", "level_body", "level_adr", "body_subtreenum", "body_dofmask", "nstaticgeom", "geom_lds0", "pair_geom",
+           "npair", "nterrain", "ntgeom", "ntcell", "ntcellp1", "ntitem", "tgeom", "tbox_geom", "tbox_pos", "tbox_mat", "tbox_size",
+           "tbox_cell0", "tgrid_start", "tgrid_item", "tgrid_ztop", "tgrid_nx", "tgrid_ny", "tgrid_x0", "tgrid_y0", "tgrid_cell",
+           "meaninertia", "terrain_origins", "names", "opt"}  # fmt: skip
+
+
+def fake_mjmodel(m: mjcf.Model) -> types.SimpleNamespace:
+  ns = types.SimpleNamespace()
+  for k, v in m.__dict__.items():
+    if k in DERIVED:
+      continue
+    ns.__dict__[k] = v.astype(np.uint8) if k == "jnt_limited" else v  # mjModel stores flags as bytes
+  ns.npair = 0  # mjModel.npair counts explicit <pair> elements, not candidate pairs
+  ns.opt = types.SimpleNamespace(**m.opt.__dict__)
+  ns.opt.gravity = np.array(m.opt.gravity)
+  ns.stat = types.SimpleNamespace(meaninertia=m.meaninertia)
+  blob, adr = b"", {}
+  for kind, field in from_mujoco._NAME_ADR.items():
+    adr[field] = []
+    for name in m.names[kind]:
+      adr[field].append(len(blob))
+      blob += name.encode() + b"\0"
+  ns.names = blob
+  for field, a in adr.items():
+    ns.__dict__[field] = np.array(a, np.int32)
+  ns.actuator_trntype = np.zeros(m.nu, np.int32)
+  ns.actuator_gaintype = np.zeros(m.nu, np.int32)
+  ns.actuator_biastype = np.ones(m.nu, np.int32)
+  ns.actuator_dyntype = np.zeros(m.nu, np.int32)
+  return ns
+
+
+def test_enum_ids_match_the_pinned_mujoco_build():
+  e = PINS["enums"]
+  assert (mjcf.JNT_FREE, mjcf.JNT_BALL, mjcf.JNT_SLIDE, mjcf.JNT_HINGE) == (e["mjJNT_FREE"], e["mjJNT_BALL"], e["mjJNT_SLIDE"], e["mjJNT_HINGE"])
+  assert (mjcf.GEOM_PLANE, mjcf.GEOM_HFIELD, mjcf.GEOM_SPHERE, mjcf.GEOM_CAPSULE, mjcf.GEOM_ELLIPSOID, mjcf.GEOM_CYLINDER, mjcf.GEOM_BOX, mjcf.GEOM_MESH) == tuple(
+    e[k] for k in ("mjGEOM_PLANE", "mjGEOM_HFIELD", "mjGEOM_SPHERE", "mjGEOM_CAPSULE", "mjGEOM_ELLIPSOID", "mjGEOM_CYLINDER", "mjGEOM_BOX", "mjGEOM_MESH"))
+  assert (mjcf.OBJ_BODY, mjcf.OBJ_XBODY, mjcf.OBJ_GEOM, mjcf.OBJ_SITE) == (e["mjOBJ_BODY"], e["mjOBJ_XBODY"], e["mjOBJ_GEOM"], e["mjOBJ_SITE"])
+  assert mjcf.SENS_CONTACT == e["mjSENS_CONTACT"]
+  assert (mjcf.INT_EULER, mjcf.INT_IMPLICITFAST) == (e["mjINT_EULER"], e["mjINT_IMPLICITFAST"])
+  assert (mjcf.SOL_PGS, mjcf.SOL_CG, mjcf.SOL_NEWTON) == (e["mjSOL_PGS"], e["mjSOL_CG"], e["mjSOL_NEWTON"])
+  assert (mjcf.CONE_PYRAMIDAL, mjcf.CONE_ELLIPTIC) == (e["mjCONE_PYRAMIDAL"], e["mjCONE_ELLIPTIC"])
+  # the actuator checks of from_mujoco assume these
+  assert (e["mjTRN_JOINT"], e["mjGAIN_FIXED"], e["mjBIAS_NONE"], e["mjBIAS_AFFINE"], e["mjDYN_NONE"]) == (0, 0, 0, 1, 0)
+
+
+@pytest.mark.parametrize("name", ["g1_velocity_flat", "g1_tracking_flat", "go1_velocity_flat", "g1_velocity_rough", "mixed", "box"])
+def test_round_trip_reproduces_model_and_physics(name):
+  m = {"mixed": robots.mixed_model, "box": robots.box_model}.get(name, lambda: robots.load_model(name))()
+  fake = fake_mjmodel(m)
+  assert not (DERIVED - {"npair", "opt", "names"}) & set(fake.__dict__)  # nothing derived leaks through
+  m2 = from_mujoco.model_from_mujoco(fake)
+  assert m2.names == m.names
+  for k, v in m.__dict__.items():
+    if isinstance(v, np.ndarray) and k != "terrain_origins":
+      assert np.array_equal(np.asarray(getattr(m2, k)), v), k
+    elif isinstance(v, (int, float)) and not isinstance(v, bool):
+      assert getattr(m2, k) == v, k
+  assert m2.opt.__dict__ == m.opt.__dict__
+  # same physics through the oracle
+  nw = 4
+  rng = np.random.default_rng(0)
+  a, b = OracleSim(m, nw, njmax=300), OracleSim(m2, nw, njmax=300)
+  for o in (a, b):
+    o.reset(key=0 if m.nkey else None)
+    r = np.random.default_rng(1)
+    o.qvel[:] = r.normal(scale=0.2, size=o.qvel.shape)
+    if hasattr(m, "terrain_origins"):
+      o.qpos[:, :3] += m.terrain_origins[2, 9]
+    o.step(5)
+  np.testing.assert_array_equal(a.qpos, b.qpos)
+  np.testing.assert_array_equal(a.sensordata, b.sensordata)
+  del rng
+
+
+def test_unsupported_models_are_rejected():
+  m = robots.box_model()
+  for field, value, msg in (("neq", 1, "neq"), ("nmesh", 2, "nmesh"), ("npair", 1, "npair")):
+    fake = fake_mjmodel(m)
+    setattr(fake, field, value)
+    with pytest.raises(NotImplementedError, match=msg):
+      from_mujoco.model_from_mujoco(fake)
+  fake = fake_mjmodel(robots.mixed_model())
+  fake.actuator_dyntype = np.ones(fake.nu, np.int32)
+  with pytest.raises(NotImplementedError, match="actuators"):
+    from_mujoco.model_from_mujoco(fake)
+  fake = fake_mjmodel(m)
+  fake.geom_type = fake.geom_type.copy()
+  fake.geom_type[1] = mjcf.GEOM_MESH
+  with pytest.raises(NotImplementedError, match="geom types"):
+    from_mujoco.model_from_mujoco(fake)
+
+
+@pytest.mark.gpu
+def test_simulation_accepts_an_mjmodel_like_object():
+  """``Simulation(num_envs, cfg, mj_model, device)`` with the reference's argument type: same
+  device results as with this package's own host model, and ``sim.mj_model`` is the object given."""
+  import torch
+
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  m = robots.load_model("g1_velocity_flat")
+  fake = fake_mjmodel(m)
+  a = Simulation(16, SimulationCfg(njmax=300), m, "cuda:0")
+  b = Simulation(16, SimulationCfg(njmax=300), fake, "cuda:0")
+  assert b.mj_model is fake and a.mj_model is m and isinstance(b.host_model, mjcf.Model)
+  q = torch.from_numpy(np.tile(m.key_qpos[0], (16, 1)).astype(np.float32)).cuda()
+  q[:, 2] -= torch.linspace(0.0, 0.03, 16, device="cuda")
+  for s in (a, b):
+    s.data.qpos[:] = q
+    s.data.ctrl[:] = torch.from_numpy(m.key_ctrl[0].astype(np.float32)).cuda()
+    for _ in range(5):
+      s.step()
+  torch.cuda.synchronize()
+  assert torch.equal(a.data.qpos, b.data.qpos) and torch.equal(a.data.qvel, b.data.qvel)

@@ -134,6 +134,20 @@ def main() -> None:
     except Exception as e:  # noqa: BLE001
       out[key + "_error"] = repr(e)
   dst = ROOT / "tests" / "golden" / "reference_constants.json"
+  # enum values of the pinned mujoco build, from the reference's own type stubs
+  # (typings/mujoco/_enums.pyi): the ids that cross the boundary inside mjModel arrays
+  import re
+
+  enums = (REF / "typings" / "mujoco" / "_enums.pyi").read_text()
+  want = ["mjJNT_FREE", "mjJNT_BALL", "mjJNT_SLIDE", "mjJNT_HINGE", "mjGEOM_PLANE", "mjGEOM_HFIELD", "mjGEOM_SPHERE", "mjGEOM_CAPSULE",
+          "mjGEOM_ELLIPSOID", "mjGEOM_CYLINDER", "mjGEOM_BOX", "mjGEOM_MESH", "mjOBJ_BODY", "mjOBJ_XBODY", "mjOBJ_GEOM", "mjOBJ_SITE",
+          "mjSENS_CONTACT", "mjINT_EULER", "mjINT_IMPLICITFAST", "mjSOL_PGS", "mjSOL_CG", "mjSOL_NEWTON", "mjCONE_PYRAMIDAL", "mjCONE_ELLIPTIC",
+          "mjTRN_JOINT", "mjGAIN_FIXED", "mjBIAS_NONE", "mjBIAS_AFFINE", "mjDYN_NONE"]  # fmt: skip
+  out["enums"] = {}
+  for name in want:
+    mt = re.search(r"'%s': <\w+\.%s: (\d+)>" % (name, name), enums)
+    if mt:
+      out["enums"][name] = int(mt.group(1))
   dst.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
   print("wrote", dst, "keys:", sorted(out))
 
