@@ -30,6 +30,7 @@ import torch
 
 from . import _abi, native
 from .mjcf import CONE_ELLIPTIC, CONE_PYRAMIDAL, INT_EULER, INT_IMPLICITFAST, SOL_CG, SOL_NEWTON, SOL_PGS, Model, Spec
+from .nan_guard import NanGuard, NanGuardCfg
 from .sim_data import Bridge
 
 _CONE_MAP = {"pyramidal": CONE_PYRAMIDAL, "elliptic": CONE_ELLIPTIC}
@@ -76,6 +77,7 @@ class SimulationCfg:
   njmax: int | None = None
   ls_parallel: bool = True  # accepted for parity; the line search here is the exact (iterative) one
   mujoco: MujocoCfg = field(default_factory=MujocoCfg)
+  nan_guard: NanGuardCfg = field(default_factory=NanGuardCfg)
   use_graph: bool = True
   # step() right after forward() skips the stages that would reproduce that pass bit for bit
   # (include/mjlab_amd.h, mjlab_forward); False recomputes them like the reference does
@@ -231,6 +233,7 @@ class Simulation:
                                 on_access=self._on_model_access)
     self._data_bridge = Bridge("sim.data", self._data, {"nworld": num_envs, "njmax": self.njmax, "nconmax": self.nconmax})
 
+    self.nan_guard = NanGuard(cfg.nan_guard, num_envs, model)
     self.use_graph = bool(cfg.use_graph) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
     self.step_graph: torch.cuda.CUDAGraph | None = None
     self.forward_graph: torch.cuda.CUDAGraph | None = None
@@ -393,10 +396,17 @@ class Simulation:
 
   def step(self) -> None:
     with torch.cuda.device(self._dev):
-      if self.use_graph and self.step_graph is not None:
-        self.step_graph.replay()
+      if self.nan_guard.enabled:  # debugging aid (reference sim/sim.py:191); costs a host sync per step
+        with self.nan_guard.watch(self._data_bridge):
+          self._step_once()
       else:
-        self._launch_step(1)
+        self._step_once()
+
+  def _step_once(self) -> None:
+    if self.use_graph and self.step_graph is not None:
+      self.step_graph.replay()
+    else:
+      self._launch_step(1)
 
   def close(self) -> None:
     pass
