@@ -6,8 +6,8 @@ The reference obtains its ``mjModel`` from ``mujoco.MjSpec.compile()``
 the part of MuJoCo's model compiler that the benchmark scenes need:
 
 * ``<compiler angle=radian autolimits=true>``, nested ``<default>`` classes with
-  ``childclass``, bodies with explicit ``<inertial>``, ``<freejoint>``, hinge /
-  slide joints, sphere / capsule (``fromto``) / box / plane geoms, visual mesh
+  ``childclass``, bodies with ``<inertial>`` or with mass / inertia inferred from their
+  primitive geoms (``mass`` / ``density``), ``<freejoint>``, hinge / slide joints, sphere / capsule (``fromto``) / box / plane geoms, visual mesh
   geoms (kept for id parity, never collide), sites, ``<contact><exclude>``;
 * the spec edits mjlab applies (reference: src/mjlab/utils/spec_config.py:245-276
   collision attributes, :400-453 position actuators, :554-629 contact sensors);
@@ -168,6 +168,8 @@ class SpecGeom:
   gap: float = 0.0
   rgba: np.ndarray = field(default_factory=lambda: np.array([0.5, 0.5, 0.5, 1.0]))
   body: "SpecBody | None" = None
+  mass: float | None = None  # overrides density when given (MJCF geom/mass)
+  density: float = 1000.0
 
 
 @dataclass
@@ -604,6 +606,10 @@ class _MjcfParser:
       g.solimp = _floats(a["solimp"], 5, [0.9, 0.95, 0.001, 0.5, 2.0])
     if "rgba" in a:
       g.rgba = _floats(a["rgba"])
+    if "mass" in a:
+      g.mass = float(a["mass"])
+    if "density" in a:
+      g.density = float(a["density"])
     if gtype == GEOM_MESH and (g.contype or g.conaffinity):
       raise NotImplementedError("colliding mesh geoms are not supported")
     return g
@@ -726,6 +732,82 @@ _PAIR_FUNCS = {
 }  # fmt: skip
 TERRAIN_CELL = 0.5  # m, edge of a broadphase grid cell
 TCAND_MAX = 12  # terrain boxes kept per moving geom and step (the ones with the smallest ids)
+
+
+def _geom_mass_inertia(g: SpecGeom) -> tuple[float, np.ndarray]:
+  """Mass and principal moments (geom frame, about the geom centre) of a solid primitive."""
+  t, s = g.type, g.size
+  pi = math.pi
+  if t == GEOM_SPHERE:
+    vol, unit = 4.0 / 3.0 * pi * s[0] ** 3, np.full(3, 0.4 * s[0] ** 2)
+  elif t == GEOM_BOX:
+    vol = 8.0 * s[0] * s[1] * s[2]
+    unit = np.array([s[1] ** 2 + s[2] ** 2, s[0] ** 2 + s[2] ** 2, s[0] ** 2 + s[1] ** 2]) / 3.0
+  elif t == GEOM_ELLIPSOID:
+    vol = 4.0 / 3.0 * pi * s[0] * s[1] * s[2]
+    unit = np.array([s[1] ** 2 + s[2] ** 2, s[0] ** 2 + s[2] ** 2, s[0] ** 2 + s[1] ** 2]) / 5.0
+  elif t == GEOM_CYLINDER:
+    r, h = s[0], s[1]
+    vol = 2.0 * pi * r * r * h
+    unit = np.array([r * r / 4.0 + h * h / 3.0, r * r / 4.0 + h * h / 3.0, r * r / 2.0])
+  elif t == GEOM_CAPSULE:
+    r, h = s[0], s[1]
+    vc, vs = 2.0 * pi * r * r * h, 4.0 / 3.0 * pi * r**3  # cylinder + the two half spheres
+    vol = vc + vs
+    ixx = vc * (r * r / 4.0 + h * h / 3.0) + vs * (0.4 * r * r + h * h + 0.75 * h * r)
+    izz = vc * r * r / 2.0 + vs * 0.4 * r * r
+    unit = np.array([ixx, ixx, izz]) / vol
+  else:
+    return 0.0, np.zeros(3)  # planes, meshes, heightfields carry no inferred mass here
+  mass = g.mass if g.mass is not None else g.density * vol
+  return float(mass), unit * mass
+
+
+def inertia_from_geoms(geoms: list[SpecGeom]) -> tuple[float, np.ndarray, np.ndarray, np.ndarray]:
+  """Body mass, centre of mass, principal frame (quaternion) and principal moments from its geoms:
+  what the MJCF compiler derives when a body has no ``<inertial>`` (inertiafromgeom).  Principal
+  moments are listed in decreasing order, the frame is right handed."""
+  mass, first = 0.0, np.zeros(3)
+  parts = []
+  for g in geoms:
+    mg, ig = _geom_mass_inertia(g)
+    if mg <= 0.0:
+      continue
+    r = quat_to_mat(quat_normalize(g.quat))
+    parts.append((mg, np.asarray(g.pos, dtype=np.float64), r @ np.diag(ig) @ r.T))
+    mass += mg
+    first += mg * np.asarray(g.pos, dtype=np.float64)
+  if mass <= 0.0:
+    return 0.0, np.zeros(3), np.array([1.0, 0, 0, 0]), np.zeros(3)
+  com = first / mass
+  inertia = np.zeros((3, 3))
+  for mg, p, ig in parts:
+    d = p - com
+    inertia += ig + mg * (d @ d * np.eye(3) - np.outer(d, d))  # parallel axes
+  w, v = np.linalg.eigh(inertia)
+  w, v = w[::-1], v[:, ::-1]
+  if np.linalg.det(v) < 0:
+    v[:, 2] = -v[:, 2]
+  return mass, com, mat_to_quat(v), w
+
+
+def mat_to_quat(r: np.ndarray) -> np.ndarray:
+  """Rotation matrix -> unit quaternion (w, x, y, z), w >= 0."""
+  t = np.trace(r)
+  if t > 0:
+    s4 = math.sqrt(t + 1.0) * 2
+    q = np.array([0.25 * s4, (r[2, 1] - r[1, 2]) / s4, (r[0, 2] - r[2, 0]) / s4, (r[1, 0] - r[0, 1]) / s4])
+  else:
+    i = int(np.argmax(np.diag(r)))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s4 = math.sqrt(1.0 + r[i, i] - r[j, j] - r[k, k]) * 2
+    q = np.zeros(4)
+    q[0] = (r[k, j] - r[j, k]) / s4
+    q[1 + i] = 0.25 * s4
+    q[1 + j] = (r[j, i] + r[i, j]) / s4
+    q[1 + k] = (r[k, i] + r[i, k]) / s4
+  q = q / np.linalg.norm(q)
+  return q if q[0] >= 0 else -q
 
 
 def _static_body_poses(m: "Model") -> tuple[np.ndarray, np.ndarray]:
@@ -939,8 +1021,14 @@ def _compile(spec: Spec) -> Model:
       m.body_iquat[i] = quat_normalize(b.iquat)
       m.body_mass[i] = b.mass
       m.body_inertia[i] = b.inertia
+    elif b.geoms and (b.joints or any(g.mass is not None for g in b.geoms)):
+      # no <inertial>: mass and inertia from the body's geoms (MJCF compiler inertiafromgeom="auto")
+      mass, ipos, iquat, inertia = inertia_from_geoms(b.geoms)
+      if b.joints and mass <= 0.0:
+        raise ValueError(f"moving body '{b.name}' has no mass: give it an <inertial> or geoms with mass / density")
+      m.body_ipos[i], m.body_iquat[i], m.body_mass[i], m.body_inertia[i] = ipos, iquat, mass, inertia
     elif b.joints:
-      raise NotImplementedError(f"moving body '{b.name}' needs an explicit <inertial>")
+      raise ValueError(f"moving body '{b.name}' needs an <inertial> or geoms to take its inertia from")
     if i > 0:
       m.body_rootid[i] = i if p == 0 else m.body_rootid[p]
       m.body_weldid[i] = i if b.joints else m.body_weldid[p]

@@ -125,3 +125,62 @@ def test_model_roundtrip(tmp_path, g1):
   m2 = mjcf.Model.load(p)
   assert m2.opt.timestep == g1.opt.timestep and m2.opt.gravity == tuple(g1.opt.gravity)
   assert np.array_equal(m2.pair_geom, g1.pair_geom) and m2.names == g1.names
+
+
+def test_inertia_from_geoms_matches_numerical_integration():
+  """Bodies without <inertial>: mass, centre of mass and inertia come from the geoms (MJCF
+  inertiafromgeom).  Checked against a brute-force voxel integration of the same solids."""
+  import numpy as np
+
+  from mjlab_amd import mjcf
+
+  xml = """
+  <mujoco>
+    <worldbody>
+      <body name="b" pos="0 0 1">
+        <freejoint/>
+        <geom type="box" size="0.2 0.1 0.05" pos="0.1 0 0" density="500"/>
+        <geom type="capsule" size="0.05 0.15" pos="-0.1 0.05 0.1" quat="0.9238795 0.3826834 0 0" density="800"/>
+        <geom type="sphere" size="0.08" pos="0 -0.2 0" mass="0.3"/>
+        <geom type="cylinder" size="0.06 0.1" pos="0 0.2 -0.1" density="1200" contype="0" conaffinity="0"/>
+      </body>
+    </worldbody>
+  </mujoco>
+  """
+  spec = mjcf.Spec.from_string(xml)
+  m = spec.compile()
+  body = spec.body("b")
+  # voxel integration in the body frame
+  h = 0.005
+  ax = np.arange(-0.45, 0.45, h) + h / 2
+  X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+  P = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+  mass, first, second = 0.0, np.zeros(3), np.zeros((3, 3))
+  for g in body.geoms:
+    L = (P - g.pos) @ mjcf.quat_to_mat(mjcf.quat_normalize(g.quat))  # geom-frame coordinates
+    s = g.size
+    if g.type == mjcf.GEOM_BOX:
+      inside = (np.abs(L) <= s).all(axis=1)
+    elif g.type == mjcf.GEOM_SPHERE:
+      inside = (L**2).sum(axis=1) <= s[0] ** 2
+    elif g.type == mjcf.GEOM_CYLINDER:
+      inside = (L[:, 0] ** 2 + L[:, 1] ** 2 <= s[0] ** 2) & (np.abs(L[:, 2]) <= s[1])
+    else:  # capsule
+      zc = np.clip(L[:, 2], -s[1], s[1])
+      inside = L[:, 0] ** 2 + L[:, 1] ** 2 + (L[:, 2] - zc) ** 2 <= s[0] ** 2
+    vol = inside.sum() * h**3
+    rho = g.mass / vol if g.mass is not None else g.density
+    pts = P[inside]
+    mass += rho * vol
+    first += rho * h**3 * pts.sum(axis=0)
+    second += rho * h**3 * ((pts**2).sum() * np.eye(3) - pts.T @ pts)
+  com = first / mass
+  inertia = second - mass * (com @ com * np.eye(3) - np.outer(com, com))
+  assert abs(m.body_mass[1] - mass) / mass < 5e-3
+  np.testing.assert_allclose(m.body_ipos[1], com, atol=2e-3)
+  R = mjcf.quat_to_mat(m.body_iquat[1])
+  np.testing.assert_allclose(R @ np.diag(m.body_inertia[1]) @ R.T, inertia, rtol=0, atol=1e-2 * np.abs(inertia).max())
+  assert (np.diff(m.body_inertia[1]) <= 0).all() and np.isclose(np.linalg.det(R), 1.0)
+  # analytic single-geom cases
+  one = mjcf.Spec.from_string('<mujoco><worldbody><body><freejoint/><geom type="box" size="0.1 0.1 0.1" mass="0.1"/></body></worldbody></mujoco>').compile()
+  assert np.isclose(one.body_mass[1], 0.1) and np.allclose(one.body_inertia[1], 0.1 / 3 * 0.02)
