@@ -1,0 +1,392 @@
+// common.h -- wave-level helpers, small math, register-resident LDL^T factor / substitution.
+// Part of the single translation unit mjlab_amd.hip (included there, in this order); not a
+// stand-alone header.
+#pragma once
+
+// ------------------------------------------------------------------------------------
+// wave-level helpers (wave = 64 lanes)
+// ------------------------------------------------------------------------------------
+// Hides a per-lane index from the optimiser at the point of use: global addresses derived from it
+// are then formed where they are needed instead of being hoisted to the top of a long kernel and
+// kept alive (spilled) across all of it.
+__device__ __forceinline__ int launder(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+// DPP cross-lane moves (no LDS traffic): dpp_ctrl encodings of the GFX9 family --
+// quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141, row_bcast:15 0x142,
+// row_bcast:31 0x143.  Lanes disabled by row_mask receive `old` (= 0 here).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+// Sum over each row of 16 lanes (xor-butterfly 1,2 | half-mirror | mirror); every lane of the
+// row ends with the row total.
+__device__ __forceinline__ float group16_sum(float v) {
+  v += dpp_mov<0xB1, 0xF, true>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xF, true>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xF, true>(v);  // row_half_mirror
+  v += dpp_mov<0x140, 0xF, true>(v);  // row_mirror
+  return v;
+}
+// Sum over the wave; the result is made explicitly wave-uniform (SGPR) so that the solver's
+// control flow compiles to scalar branches.
+__device__ __forceinline__ float wave_sum(float v) {
+  v = group16_sum(v);
+  v += dpp_mov<0x142, 0xA, false>(v);  // rows 1,3 += lane 15 of rows 0,2
+  v += dpp_mov<0x143, 0xC, false>(v);  // rows 2,3 += lane 31
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// reference implementations through the LDS crossbar (used by the self-test only)
+__device__ __forceinline__ float wave_sum_shfl(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float group16_sum_shfl(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  *total = __shfl(incl, 63);
+  return incl - v;
+}
+__device__ __forceinline__ void lds_to_global(float* dst, const float* src, int n, int lane) {
+  for (int k = lane; k < n; k += 64) dst[k] = src[k];
+}
+__device__ __forceinline__ void global_to_lds(float* dst, const float* src, int n, int lane) {
+  for (int k = lane; k < n; k += 64) dst[k] = src[k];
+}
+
+// Dense n x n matrix copies between row-major global memory (leading dimension n) and LDS
+// (leading dimension ld); lanes walk consecutive global elements, (i, j) tracked without
+// integer division.
+__device__ __forceinline__ void dense_global_to_lds(float* dst, const float* src, int n, int ld, int lane, bool lower_only) {
+  lane = launder(lane);
+  int i = 0, j = lane;
+  while (j >= n) { j -= n; ++i; }
+  for (int k = lane; k < n * n; k += 64) {
+    if (!lower_only || j <= i) dst[i * ld + j] = src[k];
+    j += 64;
+    while (j >= n) { j -= n; ++i; }
+  }
+}
+__device__ __forceinline__ void dense_lds_to_global(float* dst, const float* src, int n, int ld, int lane, bool zero_upper) {
+  int i = 0, j = lane;
+  while (j >= n) { j -= n; ++i; }
+  for (int k = lane; k < n * n; k += 64) {
+    dst[k] = (zero_upper && j > i) ? 0.f : src[i * ld + j];
+    j += 64;
+    while (j >= n) { j -= n; ++i; }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// small math (quaternions w-x-y-z, row-major 3x3)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(float* r, const float* a, const float* b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ float normalize3(float* v) {
+  float n = sqrtf(dot3(v, v));
+  if (n < MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; return 0; }
+  float inv = 1.0f / n;
+  v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  return n;
+}
+__device__ __forceinline__ void normalize4(float* q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  float inv = 1.0f / n;
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+__device__ __forceinline__ void mul_quat(float* r, const float* a, const float* b) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+__device__ __forceinline__ void quat2mat(float* R, const float* q) {
+  float q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  float q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
+  float q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+  R[0] = q00 + q11 - q22 - q33; R[4] = q00 - q11 + q22 - q33; R[8] = q00 - q11 - q22 + q33;
+  R[1] = 2 * (q12 - q03); R[2] = 2 * (q13 + q02);
+  R[3] = 2 * (q12 + q03); R[5] = 2 * (q23 - q01);
+  R[6] = 2 * (q13 - q02); R[7] = 2 * (q23 + q01);
+}
+__device__ __forceinline__ void mul_mat_vec3(float* r, const float* R, const float* v) {
+  float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  float y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  float z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void rot_vec_quat(float* r, const float* v, const float* q) {
+  float R[9];
+  quat2mat(R, q);
+  mul_mat_vec3(r, R, v);
+}
+__device__ __forceinline__ void axis_angle2quat(float* q, const float* axis, float angle) {
+  float s, c;
+  sincosf(angle * 0.5f, &s, &c);
+  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+__device__ __forceinline__ float clipf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// spatial algebra; motion vectors are [angular(3), linear(3)] about subtree_com[root]
+__device__ __forceinline__ void mul_inert_vec(float* r, const float* i, const float* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+__device__ __forceinline__ void cross_motion(float* r, const float* vel, const float* v) {
+  r[0] = -vel[2] * v[1] + vel[1] * v[2];
+  r[1] = vel[2] * v[0] - vel[0] * v[2];
+  r[2] = -vel[1] * v[0] + vel[0] * v[1];
+  r[3] = -vel[2] * v[4] + vel[1] * v[5] - vel[5] * v[1] + vel[4] * v[2];
+  r[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
+  r[5] = -vel[1] * v[3] + vel[0] * v[4] - vel[4] * v[0] + vel[3] * v[1];
+}
+__device__ __forceinline__ void cross_force(float* r, const float* vel, const float* f) {
+  r[0] = -vel[2] * f[1] + vel[1] * f[2] - vel[5] * f[4] + vel[4] * f[5];
+  r[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
+  r[2] = -vel[1] * f[0] + vel[0] * f[1] - vel[4] * f[3] + vel[3] * f[4];
+  r[3] = -vel[2] * f[4] + vel[1] * f[5];
+  r[4] = vel[2] * f[3] - vel[0] * f[5];
+  r[5] = -vel[1] * f[3] + vel[0] * f[4];
+}
+
+__device__ __forceinline__ bool dof_in_chain(const Model& m, int body, int dof) {
+  unsigned lo = (unsigned)m.body_dofmask[2 * body], hi = (unsigned)m.body_dofmask[2 * body + 1];
+  return dof < 32 ? ((lo >> dof) & 1u) : ((hi >> (dof - 32)) & 1u);
+}
+
+// ------------------------------------------------------------------------------------
+// Dense Cholesky A = L L^T for one world, n <= 64, REGISTER-RESIDENT: lane i owns row i of
+// the lower triangle in NVP VGPRs (NVP = nv padded to a compile-time size; rows >= nv are
+// identity).  The left-looking column sweep is fully unrolled, so L[j][k] is a
+// v_readlane of lane j's k-th register feeding an FMA with an SGPR operand: no LDS traffic
+// and no barriers inside the factorization (about 2 instructions per multiply-add instead
+// of the ~12 an LDS-resident sweep needs).  The matrix travels through LDS only to move
+// between layouts: MFMA tiles -> rows (before), rows -> columns of L for the backward
+// substitution (after).  LDS leading dimension LD is a multiple of 4 with LD/4 odd, so the
+// per-lane 128-bit row accesses are bank-conflict free.
+// ------------------------------------------------------------------------------------
+template <int NVP>
+struct CholCfg {
+  static constexpr int LD = (NVP % 8 == 4) ? NVP : NVP + 4;
+  static constexpr int NB = (NVP + 15) / 16;  // 16-column blocks for the MFMA Hessian
+};
+
+// LDS-qualified views: the factor routines are out-of-line functions, and a generic `float*`
+// argument would make every access pay for an address-space check.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+template <int NVP>
+__device__ __forceinline__ void chol_pad_rows(float* A, int n, int lane) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  for (int k = n * LD + lane; k < NVP * LD; k += 64) A[k] = 0.f;
+}
+template <int NVP>
+__device__ __forceinline__ void chol_pad_diag(float* A, int n, int lane) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  if (lane >= n && lane < NVP) A[lane * LD + lane] = 1.f;
+}
+// Column sweep of the factorization below, written as compile-time recursion over the column J
+// and the batch BI so that every register-array index and the choice of ping-pong buffer is a
+// constant (the arrays must live in VGPRs, never in scratch).
+template <int NVP, int CB>
+struct CholSweep {
+  static constexpr int LD = CholCfg<NVP>::LD;
+  template <int R, int K0>
+  static __device__ __forceinline__ void load_batch(lds_f32* A, float (&dst)[CB]) {
+#pragma unroll
+    for (int q = 0; q < CB / 4; ++q) {
+      if (K0 + 4 * q < R) {
+        const f32x4 v = *(lds_f32x4*)(A + R * LD + K0 + 4 * q);
+        dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+      }
+    }
+  }
+  // batch BI of column J: request the next batch (same row, or first batch of row J+1) into
+  // `nxt`, feed `cur` to the FMAs, recurse with the buffers swapped
+  template <int J, int BI>
+  static __device__ __forceinline__ void batches(const float (&a)[NVP], f32x2& acc, float (&cur)[CB], float (&nxt)[CB], lds_f32* A) {
+    constexpr int NBJ = (J + CB - 1) / CB, K0 = BI * CB;
+    if constexpr (BI < NBJ) {
+      if constexpr (BI + 1 < NBJ) load_batch<J, K0 + CB>(A, nxt);
+      else if constexpr (J + 1 < NVP) load_batch<J + 1, 0>(A, nxt);
+#pragma unroll
+      for (int k = 0; k < CB; k += 2) {
+        if (K0 + k + 1 < J) {
+          const f32x2 av = {a[K0 + k], a[K0 + k + 1]};
+          const f32x2 sv = {cur[k], cur[k + 1]};
+          acc -= av * sv;
+        } else if (K0 + k < J) {
+          acc.x -= a[K0 + k] * cur[k];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      batches<J, BI + 1>(a, acc, nxt, cur, A);
+    }
+  }
+  // column J; `cur` holds (or is about to receive) the first batch of row J
+  template <int J>
+  static __device__ __forceinline__ void col(float (&a)[NVP], float (&cur)[CB], float (&oth)[CB], lds_f32* A, lds_f32* row, int rowid, float& myinvd) {
+    constexpr int NBJ = (J + CB - 1) / CB;
+    f32x2 acc = {a[J], 0.f};  // two accumulators, products in pairs (v_pk_fma_f32)
+    batches<J, 0>(a, acc, cur, oth, A);
+    const float t = acc.x + acc.y;
+    const float djj = fmaxf(lane_bcast(t, J), MINVAL);
+    float invd = __builtin_amdgcn_rcpf(djj);  // v_rcp_f32 (1 ulp) + one Newton step
+    invd = invd * (2.f - djj * invd);
+    a[J] = t;
+    const float lu = rowid > J ? t * invd : 0.f;
+    row[J] = lu;
+    myinvd = rowid == J ? invd : myinvd;
+    if constexpr (J + 1 < NVP) {
+      // after NBJ swaps the first batch of row J+1 sits in `cur` (NBJ even) or `oth` (NBJ odd)
+      if constexpr (NBJ == 0) {
+        load_batch<J + 1, 0>(A, cur);  // J == 0: nothing was in flight
+      } else if constexpr (J < CB) {   // entry written after the request: patch from lane J+1
+        const float e = lane_bcast(lu, J + 1);
+        if constexpr (NBJ % 2 == 0) cur[J] = e; else oth[J] = e;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NBJ % 2 == 0) col<J + 1>(a, cur, oth, A, row, rowid, myinvd);
+      else col<J + 1>(a, oth, cur, A, row, rowid, myinvd);
+    }
+  }
+};
+
+// A (LDS, lower triangle valid for rows < n) -> unit-lower factor of A = Lu D Lu^T in place:
+// Lu[i][j] (i > j), ZERO on and above the diagonal, s_invd[i] = 1 / D_i.  With the zero
+// diagonal the substitutions below are a bare v_readlane + v_fma per step.
+//
+// Lane i owns row i in NVP registers.  Left-looking column sweep, fully unrolled:
+//   t_i = A[i][j] - sum_{k<j} W[i][k] * Lu[j][k],   W[i][k] = t_i of step k (kept in a[k]),
+//   D_j = t_j,  Lu[i][j] = t_i / D_j  -> written to LDS column j by every lane.
+// Row j of Lu, which every lane needs in step j, is read back from LDS as 128-bit
+// *broadcast* reads (all lanes, same address: conflict-free), ceil(j/4) instructions instead
+// of j cross-lane v_readlane's; the wave's DS queue is in order, so the column written in
+// step j-1 is visible without a barrier.  No square roots (LDL^T).
+// Lanes >= NVP mirror lane NVP-1 (same row, same arithmetic, same values stored), which keeps
+// the sweep free of exec-mask branches.  Rows n <= i < NVP must hold identity rows on entry:
+// producers call chol_pad_rows() once per kernel (zero fill; the factor keeps those rows'
+// off-diagonals at zero) and chol_pad_diag() after every (re)write of the matrix.
+// Caller synchronises before and after.
+template <int NVP>
+__device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int lane) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  lds_f32* A = (lds_f32*)A_;
+  lds_f32* s_invd = (lds_f32*)s_invd_;
+  int rowid = lane < NVP ? lane : NVP - 1;
+  // opaque: otherwise the 2 NVP lane-mask compares below are loop invariant for the caller's
+  // solver loop, get hoisted out of it and live (spilled) in ~150 SGPRs
+  asm volatile("" : "+v"(rowid));
+  lds_f32* row = A + rowid * LD;
+  float a[NVP];
+#pragma unroll
+  for (int c = 0; c < NVP / 4; ++c) {
+    const f32x4 v = *(lds_f32x4*)(row + 4 * c);
+    a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+  }
+  (void)n;  // rows >= n are identity rows already (chol_pad_rows / chol_pad_diag by the producer)
+  float myinvd = 1.f;
+  // Row j of Lu is consumed in batches of CB columns.  The batches are software pipelined
+  // through two register buffers: while batch i feeds the FMAs, the reads of batch i+1 --
+  // the next batch of the same row, or the first batch of the next row -- are already in
+  // flight, so the sweep does not stall on an LDS round trip per column.  The first batch of
+  // row j+1 is requested before column j is written; its one missing entry Lu[j+1][j] is
+  // patched in from lane j+1's register.
+  float bufA[MJLAB_CB], bufB[MJLAB_CB];
+  CholSweep<NVP, MJLAB_CB>::template col<0>(a, bufA, bufB, A, row, rowid, myinvd);
+  s_invd[rowid] = myinvd;
+}
+// Solves Lu D Lu^T x = b with the factor in LDS (as left by chol_factor); lane i owns
+// b_i / x_i (lanes >= n must pass 0).  Forward substitution uses row i of Lu, backward
+// substitution row i of Lu^T (= column i of Lu, read with unit stride across lanes).
+template <int NVP>
+__device__ CHOL_INLINE float chol_solve(const float* L_, const float* s_invd_, int lane, float b) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  const lds_f32* L = (const lds_f32*)L_;
+  const lds_f32* s_invd = (const lds_f32*)s_invd_;
+  const int li = lane < NVP ? lane : NVP - 1;
+  const float invd = s_invd[li];
+  {
+    float a[NVP];
+#pragma unroll
+    for (int c = 0; c < NVP / 4; ++c) {
+      const f32x4 v = *(const lds_f32x4*)(L + li * LD + 4 * c);
+      a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) b = fmaf(-a[k], lane_bcast(b, k), b);  // a[k] = 0 for lanes <= k
+  }
+  b *= invd;
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float at[NVP];
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) at[k] = L[k * LD + li];  // Lu[k][i]: zero for k <= i
+#pragma unroll
+    for (int k = NVP - 1; k >= 0; --k) b = fmaf(-at[k], lane_bcast(b, k), b);
+  }
+  return b;
+}
+// y_i = sum_j M[i][j] v_j with M symmetric, dense row-major in GLOBAL memory (ld = n);
+// lane i owns v_i and y_i.  Row j is read coalesced (M[j][i] = M[i][j]), v_j comes from
+// lane j by v_readlane; fully unrolled so all loads are in flight together.
+template <int NVP>
+__device__ __forceinline__ float symm_mul_global(const float* M, int n, float v, int lane) {
+  // The element offset is made opaque to the optimiser: otherwise the NVP row addresses are
+  // loop-invariant 64-bit VGPR pairs that get hoisted out of the Newton loop and spilled.
+  int off = lane < n ? lane : 0;
+  asm volatile("" : "+v"(off));
+  constexpr int CH = 12;  // loads in flight per chunk
+  float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+  for (int j0 = 0; j0 < NVP; j0 += CH) {
+    float mv[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int j = j0 + u;
+      mv[u] = (j < NVP && j < n) ? M[j * n + off] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int j = j0 + u;
+      if (j < NVP) {
+        if (u & 1) y1 = fmaf(mv[u], lane_bcast(v, j), y1);
+        else y0 = fmaf(mv[u], lane_bcast(v, j), y0);
+      }
+    }
+  }
+  return lane < n ? y0 + y1 : 0.f;
+}
+
+// launch flags shared by the stage kernels
+enum {
+  FLAG_MASK = 1,      // skip worlds whose world_mask entry is 0 (mjlab_forward_masked)
+  FLAG_FOLD = 2,      // step(): reuse the position / collision / constraint stages of the last forward()
+                      // in worlds whose qpos and qvel are still bit-identical (fold_reuse, set by k_position)
+  FLAG_SNAPSHOT = 4   // forward(): record qpos / qvel next to the derived arrays (fold_valid = 1)
+};
+

@@ -1,0 +1,156 @@
+// extras.h -- fused entity read-back, masked reset, field tiling, self-test.
+// Part of the single translation unit mjlab_amd.hip (included there, in this order); not a
+// stand-alone header.
+#pragma once
+
+// ====================================================================================
+// Fused read-back of EntityData's derived quantities (extension, see include/mjlab_amd.h)
+// ====================================================================================
+__device__ __forceinline__ void quat_apply_dev(float* r, const float* q, const float* v, float sign) {
+  // reference third_party/isaaclab/.../math.py:623-662: t = 2 xyz x v;  v +- w t + xyz x t
+  float t[3], u[3];
+  cross3(t, q + 1, v);
+  for (int k = 0; k < 3; ++k) t[k] *= 2.f;
+  cross3(u, q + 1, t);
+  for (int k = 0; k < 3; ++k) r[k] = v[k] + sign * q[0] * t[k] + u[k];
+}
+// world-frame velocity at point `pos` from the c-frame spatial velocity (entity/data.py:20-31)
+__device__ __forceinline__ void vel_from_cvel(float* out6, const float* pos, const float* sub, const float* cv) {
+  float off[3] = {sub[0] - pos[0], sub[1] - pos[1], sub[2] - pos[2]}, c[3];
+  cross3(c, cv, off);
+  for (int k = 0; k < 3; ++k) { out6[k] = cv[3 + k] - c[k]; out6[3 + k] = cv[k]; }
+}
+
+__global__ __launch_bounds__(64) void k_entity_readback(const Model m, const Data d, const mjlab_entity_view_t v) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int nb = m.size.nbody, nq = m.size.nq, nv = m.size.nv;
+  const float* sub = d.subtree_com + ((size_t)w * nb + v.root_body_id) * 3;
+  const float sc[3] = {sub[0], sub[1], sub[2]};
+  const float* biq = MF(body_iquat);
+  for (int i = lane; i < v.nbody; i += 64) {
+    const int b = v.body_ids[i];
+    const size_t wb = (size_t)w * nb + b, wi = (size_t)w * v.nbody + i;
+    float pos[3], ipos[3], q[4], iq[4], cv[6], qc[4], o6[6];
+    for (int k = 0; k < 3; ++k) { pos[k] = d.xpos[3 * wb + k]; ipos[k] = d.xipos[3 * wb + k]; }
+    for (int k = 0; k < 4; ++k) { q[k] = d.xquat[4 * wb + k]; iq[k] = biq[4 * b + k]; }
+    for (int k = 0; k < 6; ++k) cv[k] = d.cvel[6 * wb + k];
+    if (v.body_link_pose_w) {
+      for (int k = 0; k < 3; ++k) v.body_link_pose_w[7 * wi + k] = pos[k];
+      for (int k = 0; k < 4; ++k) v.body_link_pose_w[7 * wi + 3 + k] = q[k];
+    }
+    if (v.body_link_vel_w) {
+      vel_from_cvel(o6, pos, sc, cv);
+      for (int k = 0; k < 6; ++k) v.body_link_vel_w[6 * wi + k] = o6[k];
+    }
+    if (v.body_com_pose_w) {
+      mul_quat(qc, q, iq);
+      for (int k = 0; k < 3; ++k) v.body_com_pose_w[7 * wi + k] = ipos[k];
+      for (int k = 0; k < 4; ++k) v.body_com_pose_w[7 * wi + 3 + k] = qc[k];
+    }
+    if (v.body_com_vel_w) {
+      vel_from_cvel(o6, ipos, sc, cv);
+      for (int k = 0; k < 6; ++k) v.body_com_vel_w[6 * wi + k] = o6[k];
+    }
+  }
+  if (v.root_derived && lane == 0) {
+    const size_t wb = (size_t)w * nb + v.root_body_id;
+    float pos[3], ipos[3], q[4], cv[6], lv[6], cvl[6], r[3];
+    for (int k = 0; k < 3; ++k) { pos[k] = d.xpos[3 * wb + k]; ipos[k] = d.xipos[3 * wb + k]; }
+    for (int k = 0; k < 4; ++k) q[k] = d.xquat[4 * wb + k];
+    for (int k = 0; k < 6; ++k) cv[k] = d.cvel[6 * wb + k];
+    vel_from_cvel(lv, pos, sc, cv);
+    vel_from_cvel(cvl, ipos, sc, cv);
+    float* o = v.root_derived + (size_t)w * 16;
+    quat_apply_dev(r, q, v.gravity_vec_w, -1.f);
+    for (int k = 0; k < 3; ++k) o[k] = r[k];
+    quat_apply_dev(r, q, v.forward_vec_b, 1.f);
+    o[3] = atan2f(r[1], r[0]);
+    quat_apply_dev(r, q, lv, -1.f);
+    for (int k = 0; k < 3; ++k) o[4 + k] = r[k];
+    quat_apply_dev(r, q, lv + 3, -1.f);
+    for (int k = 0; k < 3; ++k) o[7 + k] = r[k];
+    quat_apply_dev(r, q, cvl, -1.f);
+    for (int k = 0; k < 3; ++k) o[10 + k] = r[k];
+    quat_apply_dev(r, q, cvl + 3, -1.f);
+    for (int k = 0; k < 3; ++k) o[13 + k] = r[k];
+  }
+  for (int j = lane; j < v.njoint; j += 64) {
+    const size_t wj = (size_t)w * v.njoint + j;
+    if (v.joint_pos) v.joint_pos[wj] = d.qpos[(size_t)w * nq + v.joint_q_adr[j]];
+    if (v.joint_vel) v.joint_vel[wj] = d.qvel[(size_t)w * nv + v.joint_v_adr[j]];
+    if (v.joint_acc) v.joint_acc[wj] = d.qacc[(size_t)w * nv + v.joint_v_adr[j]];
+  }
+}
+
+// ====================================================================================
+// Masked termination + reset (extension, see include/mjlab_amd.h)
+// ====================================================================================
+__device__ __forceinline__ float nan_to_num_dev(float x) {
+  if (x != x) return 0.f;
+  if (x > 3.402823466e+38f) return 3.402823466e+38f;
+  if (x < -3.402823466e+38f) return -3.402823466e+38f;
+  return x;
+}
+__global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d, const float* key_qpos, const float* rnd3,
+                                                      int* episode_length, const int max_len, const float min_height, int* reset_mask,
+                                                      const float* env_origins, const float min_up_z) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int nq = m.size.nq, nv = m.size.nv;
+  const bool has_free = m.size.njnt > 0 && m.jnt_type[0] == MJLAB_JNT_FREE;
+  float* qpos = d.qpos + (size_t)w * nq;
+  float* qvel = d.qvel + (size_t)w * nv;
+  float* ws = d.qacc_warmstart + (size_t)w * nv;
+  bool bad = false;
+  for (int i = lane; i < nq; i += 64) {
+    const float x = qpos[i];
+    bad |= !(fabsf(x) <= 3.402823466e+38f);  // NaN or inf
+  }
+  const int elen = episode_length[w] + 1;
+  float org[3] = {0.f, 0.f, 0.f};
+  if (env_origins)
+    for (int k = 0; k < 3; ++k) org[k] = env_origins[3 * w + k];
+  // world z of the root's up axis = 1 - 2 (qx^2 + qy^2): the bad-orientation test of the
+  // reference (envs/mdp/terminations.py bad_orientation: projected gravity vs a limit angle)
+  const bool fell = has_free && (qpos[2] - org[2] < min_height || 1.f - 2.f * (qpos[4] * qpos[4] + qpos[5] * qpos[5]) < min_up_z);
+  const bool reset = __ballot(bad) != 0ull || fell || elen >= max_len;
+  if (reset) {
+    for (int i = lane; i < nq; i += 64) {
+      float x = key_qpos[i];
+      if (has_free) {
+        const float yaw = (rnd3[3 * w + 2] * 2.f - 1.f) * 3.14f;
+        if (i < 2) x += rnd3[3 * w + i] - 0.5f + org[i];
+        else if (i == 2) x += org[2];
+        else if (i == 3) x = cosf(yaw * 0.5f);
+        else if (i == 4 || i == 5) x = 0.f;
+        else if (i == 6) x = sinf(yaw * 0.5f);
+      }
+      qpos[i] = x;
+    }
+    for (int i = lane; i < nv; i += 64) { qvel[i] = 0.f; ws[i] = 0.f; }
+  } else {
+    for (int i = lane; i < nv; i += 64) { qvel[i] = nan_to_num_dev(qvel[i]); ws[i] = nan_to_num_dev(ws[i]); }
+  }
+  if (lane == 0) {
+    episode_length[w] = reset ? 0 : elen;
+    reset_mask[w] = reset ? 1 : 0;
+  }
+}
+
+// ====================================================================================
+// repeat_array_kernel replacement (reference src/mjlab/sim/randomization.py:9-17)
+// ====================================================================================
+template <typename T>
+__global__ void k_tile(T* dst, const T* src, long long nelem, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = src[i % nelem];
+}
+
+// self-test of the DPP reductions against the ds_bpermute versions
+__global__ void k_selftest(const float* in, int* nerr) {
+  const float v = in[blockIdx.x * 64 + threadIdx.x];
+  const float a = wave_sum(v), b = wave_sum_shfl(v);
+  const float c = group16_sum(v), e = group16_sum_shfl(v);
+  const float tol = 1e-4f * (1.f + fabsf(b));
+  if (fabsf(a - b) > tol || fabsf(c - e) > 1e-4f * (1.f + fabsf(e))) atomicAdd(nerr, 1);
+}
+

@@ -1,0 +1,602 @@
+// stage_solve.h -- stages 5+6: Newton solver and integration.
+// Part of the single translation unit mjlab_amd.hip (included there, in this order); not a
+// stand-alone header.
+#pragma once
+
+// ====================================================================================
+// Stage 5+6: Newton solver (mj_fwdConstraint) and integration (mj_Euler / mj_implicit)
+// ====================================================================================
+struct LsPnt { float alpha, cost, d0, d1; };
+
+// compile-time padded sizes the solve kernel is instantiated for
+__host__ __device__ inline int solve_nvp(int nv) {
+  const int sizes[] = {8, 16, 20, 24, 32, 36, 40, 48, 64};
+  for (int i = 0; i < 9; ++i) if (nv <= sizes[i]) return sizes[i];
+  return -1;
+}
+__host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
+  const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
+  return nvp * ld + nvp + 3 * s.njmax + 64;
+}
+
+template <int NVP>
+struct SolveCtx {
+  static constexpr int NB = CholCfg<NVP>::NB;
+  static constexpr int ld = CholCfg<NVP>::LD;
+  const float* J;  // global, row-major nefc x nv
+  const float* M;  // global, dense nv x nv
+  float *s_H, *s_invd, *s_jar, *s_jv, *s_D;
+  int nv, nefc, lane;
+  float quad_gauss[3];
+  int ls_iter;
+  // line search: quadratic coefficients of this lane's row (rows 0..63) for the current search
+  // direction, so that an evaluation touches LDS only for rows >= 64
+  float lj0, ljv, lq0, lq1, lq2;
+  float mj0, mjv, mq0, mq1, mq2;  // same for row 64 + lane (worlds with more than 64 rows set the kernel's tail)
+};
+
+// x16[cb] = x[16 cb + (lane & 15)], gathered from the lane-owned layout
+template <int NB>
+__device__ __forceinline__ void gather16(float x, float (&x16)[NB], int lane) {
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) x16[cb] = __shfl(x, 16 * cb + (lane & 15));
+}
+template <int NB>
+__device__ __forceinline__ float pick16(const float (&v)[NB], int lane) {
+  // a chain of v_cndmask; the index is re-laundered per step because the optimiser otherwise turns
+  // the chain into a per-lane indexed load from a scratch copy of v[] (a memory round trip in
+  // the middle of every Newton iteration)
+  float r = v[0];
+#pragma unroll
+  for (int cb = 1; cb < NB; ++cb) r = (launder(lane >> 4) == cb) ? v[cb] : r;
+  return r;
+}
+
+// Rows are walked 16 at a time (4 MFMA-shaped groups of 4 rows x 16 columns): the loads of a
+// 16-row block are issued together, so a pass over J exposes one memory round trip per 16 rows.
+#ifndef MJLAB_JU
+#define MJLAB_JU 4
+#endif
+constexpr int JU = MJLAB_JU;  // 4-row groups per unrolled block
+
+// out[r] = sum_i J[r][i] x_i (+ out2 for a second vector); lanes form 4 row groups x 16 columns
+template <int NVP, bool TWO>
+__device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x16)[CholCfg<NVP>::NB], const float (&y16)[CholCfg<NVP>::NB], float* out, float* out2) {
+  constexpr int NB = CholCfg<NVP>::NB;
+  const int sub = c.lane >> 4, col = launder(c.lane & 15);
+  for (int r0 = 0; r0 < c.nefc; r0 += 4 * JU) {
+    float jv[JU][NB];
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      const int r = r0 + 4 * u + sub;
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        const int cc = 16 * cb + col;
+        jv[u][cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      const int r = r0 + 4 * u + sub;
+      float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        acc += jv[u][cb] * x16[cb];
+        if (TWO) acc2 += jv[u][cb] * y16[cb];
+      }
+      acc = group16_sum(acc);
+      if (TWO) acc2 = group16_sum(acc2);
+      if (col == 0 && r < c.nefc) { out[r] = acc; if (TWO) out2[r] = acc2; }
+    }
+  }
+}
+
+// One pass over J: the lane-owned constraint force qfrc_constraint_i = sum_r J[r][i] f_r and,
+// if WITH_H, the tiles of J^T diag(D*active) J (lower-triangular 16x16 blocks) in `acc` via
+// fp32 MFMA.  The tiles stay in registers: hessian_store() adds M and lays them out in LDS
+// only when the Newton iteration actually needs a new factorization.
+// Only ACTIVE rows (jar < 0) contribute to J^T f and to J^T D J, and at a typical state they are
+// about a third of the rows, so the pass runs over a compacted list of active row indices
+// (built with wave ballots into the LDS area of s_jv, which is dead between two line searches).
+// Returns the number of active rows; the list is in increasing row order.
+template <int NVP>
+__device__ __forceinline__ int build_active_list(const SolveCtx<NVP>& c, int* s_act) {
+  int nact = 0;
+  for (int r0 = 0; r0 < c.nefc; r0 += 64) {
+    const int r = r0 + c.lane;
+    const bool act = r < c.nefc && c.s_jar[r] < 0.f;
+    const unsigned long long mask = __ballot(act);
+    if (act) s_act[nact + __popcll(mask & ((1ull << c.lane) - 1ull))] = r;
+    nact += __popcll(mask);
+  }
+  return nact;
+}
+
+template <int NVP, bool WITH_H>
+__device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2], const int* s_act, int nact) {
+  constexpr int NB = CholCfg<NVP>::NB;
+  constexpr int NT = NB * (NB + 1) / 2;
+  float jtf[NB];
+  if (WITH_H) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) jtf[cb] = 0.f;
+  const int sub = c.lane >> 4, col = launder(c.lane & 15);
+  for (int k0 = 0; k0 < nact; k0 += 4 * JU) {
+    float x[JU][NB], dact[JU], f[JU];
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      const int k = k0 + 4 * u + sub;
+      const bool valid = k < nact;
+      const int r = valid ? s_act[k] : 0;
+      dact[u] = 0.f; f[u] = 0.f;
+      if (valid) { dact[u] = c.s_D[r]; f[u] = -dact[u] * c.s_jar[r]; }
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        const int cc = 16 * cb + col;
+        x[u][cb] = (valid && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      float a[NB];
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        jtf[cb] += x[u][cb] * f[u];
+        a[cb] = dact[u] * x[u][cb];
+      }
+      if (WITH_H) {
+        int t = 0;
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+          for (int Jb = 0; Jb <= I; ++Jb) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[u][Jb], acc[t], 0, 0, 0);
+            ++t;
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) { jtf[cb] += __shfl_xor(jtf[cb], 16); jtf[cb] += __shfl_xor(jtf[cb], 32); }
+  return pick16<NB>(jtf, c.lane);
+}
+
+// H = M + tiles -> LDS (lower triangle only)
+template <int NVP>
+__device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2]) {
+  constexpr int NB = CholCfg<NVP>::NB;
+  const int sub = c.lane >> 4, col = c.lane & 15;
+  // per-lane part of the M offset, opaque so that the 4 NT addresses are not hoisted out of
+  // the Newton loop as 64-bit VGPR pairs (and then spilled)
+  int moff = sub * 4 * c.nv + col;
+  asm volatile("" : "+v"(moff));
+  int t = 0;
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int Jb = 0; Jb <= I; ++Jb) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
+        if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.M[(16 * I + k) * c.nv + 16 * Jb + moff];
+      }
+      ++t;
+    }
+}
+
+// cost of row r along the search direction: D/2 (j0 + alpha jv)^2 where that is negative
+template <int NVP>
+__device__ __forceinline__ void ls_prepare(SolveCtx<NVP>& c) {
+  const int r = c.lane;
+  float j0 = 1.f, jv = 0.f, Dr = 0.f;  // lanes beyond nefc: never active
+  if (r < c.nefc) { j0 = c.s_jar[r]; jv = c.s_jv[r]; Dr = c.s_D[r]; }
+  c.lj0 = j0; c.ljv = jv;
+  c.lq0 = 0.5f * Dr * j0 * j0; c.lq1 = Dr * j0 * jv; c.lq2 = 0.5f * Dr * jv * jv;
+  j0 = 1.f; jv = 0.f; Dr = 0.f;
+  if (r + 64 < c.nefc) { j0 = c.s_jar[r + 64]; jv = c.s_jv[r + 64]; Dr = c.s_D[r + 64]; }
+  c.mj0 = j0; c.mjv = jv;
+  c.mq0 = 0.5f * Dr * j0 * j0; c.mq1 = Dr * j0 * jv; c.mq2 = 0.5f * Dr * jv * jv;
+}
+__device__ __forceinline__ float ls_newton_step(float alpha, float d0, float d1) {
+  return alpha - d0 * __builtin_amdgcn_rcpf(d1);  // 1 ulp reciprocal: alpha only has to meet ls_tolerance
+}
+template <int NVP>
+__device__ __forceinline__ void ls_eval(SolveCtx<NVP>& c, LsPnt* p, float alpha) {
+  float cost = 0.f, d0 = 0.f, d1 = 0.f;
+  if (c.lj0 + alpha * c.ljv < 0.f) {
+    cost = alpha * alpha * c.lq2 + alpha * c.lq1 + c.lq0;
+    d0 = 2.f * alpha * c.lq2 + c.lq1;
+    d1 = 2.f * c.lq2;
+  }
+  if (c.nefc > 64 && c.mj0 + alpha * c.mjv < 0.f) {
+    cost += alpha * alpha * c.mq2 + alpha * c.mq1 + c.mq0;
+    d0 += 2.f * alpha * c.mq2 + c.mq1;
+    d1 += 2.f * c.mq2;
+  }
+  for (int r = c.lane + 128; r < c.nefc; r += 64) {
+    const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r];
+    const float x = j0 + alpha * jv;
+    if (x < 0.f) {
+      const float q0 = 0.5f * Dr * j0 * j0, q1 = Dr * j0 * jv, q2 = 0.5f * Dr * jv * jv;
+      cost += alpha * alpha * q2 + alpha * q1 + q0;
+      d0 += 2.f * alpha * q2 + q1;
+      d1 += 2.f * q2;
+    }
+  }
+  cost = wave_sum(cost); d0 = wave_sum(d0); d1 = wave_sum(d1);
+  cost += alpha * alpha * c.quad_gauss[2] + alpha * c.quad_gauss[1] + c.quad_gauss[0];
+  d0 += 2.f * alpha * c.quad_gauss[2] + c.quad_gauss[1];
+  d1 += 2.f * c.quad_gauss[2];
+  if (d1 <= 0.f) d1 = MINVAL;
+  p->alpha = alpha; p->cost = cost; p->d0 = d0; p->d1 = d1;
+  c.ls_iter++;
+}
+template <int NVP>
+__device__ __forceinline__ int update_bracket(SolveCtx<NVP>& c, LsPnt* p, const LsPnt* cand, LsPnt* pnext) {
+  int flag = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (p->d0 < 0.f && cand[i].d0 < 0.f && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
+    else if (p->d0 > 0.f && cand[i].d0 > 0.f && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
+  }
+  if (flag) ls_eval(c, pnext, ls_newton_step(p->alpha, p->d0, p->d1));
+  return flag;
+}
+// exact 1-D line search on the piecewise-quadratic cost (safeguarded Newton + bracketing)
+template <int NVP>
+__device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
+  LsPnt p0, p1, p2, pmid, p1next, p2next;
+  c.ls_iter = 0;
+  ls_prepare(c);
+  ls_eval(c, &p0, 0.f);
+  ls_eval(c, &p1, ls_newton_step(p0.alpha, p0.d0, p0.d1));
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabsf(p1.d0) < gtol) return p1.alpha;
+  const float dir = p1.d0 < 0.f ? 1.f : -1.f;
+  bool p2update = false;
+  p2 = p1;
+  while (p1.d0 * dir <= -gtol && c.ls_iter < lsmax) {
+    p2 = p1;
+    p2update = true;
+    ls_eval(c, &p1, ls_newton_step(p1.alpha, p1.d0, p1.d1));
+    if (fabsf(p1.d0) < gtol) return p1.alpha;
+  }
+  if (c.ls_iter >= lsmax) return p1.alpha;
+  if (!p2update) return p1.alpha;
+  p2next = p1;
+  ls_eval(c, &p1next, ls_newton_step(p1.alpha, p1.d0, p1.d1));
+  while (c.ls_iter < lsmax) {
+    ls_eval(c, &pmid, 0.5f * (p1.alpha + p2.alpha));
+    LsPnt cand[3] = {p1next, p2next, pmid};
+    float bestcost = 0.f, bestalpha = 0.f;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (fabsf(cand[i].d0) < gtol && (!found || cand[i].cost < bestcost)) { bestcost = cand[i].cost; bestalpha = cand[i].alpha; found = true; }
+    if (found) return bestalpha;
+    const int b1 = update_bracket(c, &p1, cand, &p1next);
+    const int b2 = update_bracket(c, &p2, cand, &p2next);
+    if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : 0.f;
+  }
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0.f;
+}
+
+// constraint cost sum_r s(jar_r) over rows held in LDS
+__device__ __forceinline__ float constraint_cost(const float* s_jar, const float* s_D, int nefc, int lane) {
+  float cost = 0.f;
+  for (int r = lane; r < nefc; r += 64) {
+    const float x = s_jar[r];
+    if (x < 0.f) cost += 0.5f * s_D[r] * x * x;
+  }
+  return wave_sum(cost);
+}
+
+// The kernel is written as a small state machine around ONE factor + substitution site:
+//   ST_SMOOTH     s_H = M,            rhs = qfrc_smooth          -> qacc_smooth
+//   ST_NEWTON     s_H = H (if new),   rhs = gradient             -> search direction, line
+//                 search, update, convergence test (repeats)
+//   ST_INTEGRATE  s_H = M + h*diag,   rhs = qfrc_smooth + J^T f  -> implicit acceleration
+// so the fully unrolled factorization is inlined exactly once: no call ABI, no callee-saved
+// registers through scratch memory, and the register allocator sees the whole kernel.
+enum { ST_SMOOTH = 0, ST_NEWTON = 1, ST_PREP_INTEGRATE = 2, ST_INTEGRATE = 3 };
+
+template <int NVP>
+__global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NB = CholCfg<NVP>::NB, ld = CholCfg<NVP>::LD;
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
+  SolveCtx<NVP> c;
+  c.s_H = smem;
+  c.s_invd = c.s_H + NVP * ld;
+  c.s_jar = c.s_invd + NVP;
+  c.s_jv = c.s_jar + njm;
+  c.s_D = c.s_jv + njm;
+  float* s_vec = c.s_D + njm;  // 64 floats of scratch (new qvel for the position update)
+  c.J = d.efc_J + (size_t)w * njm * nv;
+  c.M = d.qM + (size_t)w * nv * nv;
+  c.nv = nv; c.lane = lane;
+  const size_t wv = (size_t)w * nv + lane;
+  const size_t wr = (size_t)w * njm;
+  const bool own = lane < nv;
+  const float qs = own ? d.qfrc_smooth[wv] : 0.f;
+  const float h = (float)m.opt.timestep;
+  const float nvf = (float)(nv > 1 ? nv : 1), mi = (float)m.opt.meaninertia;
+  const float scale = 1.f / (mi * nvf), tol = (float)m.opt.tolerance, lstol = (float)m.opt.ls_tolerance;
+  const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
+  const int nefc = do_solve ? d.nefc[w] : 0;
+  c.nefc = nefc;
+  float qacc = 0.f, fc = 0.f, qas = 0.f, Ma = 0.f, cost = 0.f, gauss = 0.f, rhs = 0.f;
+  int iter = 0, state;
+  bool need_factor = true;
+  PROF_INIT();
+
+  if (do_solve) {
+    // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
+    dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
+    chol_pad_rows<NVP>(c.s_H, nv, lane);
+    chol_pad_diag<NVP>(c.s_H, nv, lane);
+    rhs = qs;
+    state = ST_SMOOTH;
+    PROF_MARK(0);
+  } else {
+    if (own) {
+      const size_t wve = (size_t)w * nv + launder(lane);
+      qacc = d.qacc[wve];
+      fc = d.qfrc_constraint[wve];
+    }
+    state = ST_PREP_INTEGRATE;
+  }
+
+  for (;;) {
+    bool skip_solve = false;
+    if (state == ST_PREP_INTEGRATE) {
+      // s_H = M + h * diag(-d qfrc_smooth / d qvel), rhs = qfrc_smooth + J^T f
+      if (!do_integrate) break;
+      // diagonal of -d(qfrc_smooth)/d(qvel): dof damping (+ actuator velocity gains for implicitfast)
+      float diag = own ? MF(dof_damping)[launder(lane)] : 0.f;
+      bool need = diag > 0.f;
+      if (m.opt.integrator == MJLAB_INT_IMPLICITFAST) {
+        // d(qfrc_actuator)/d(qvel) of the affine-bias actuators: lanes = actuators, scattered
+        // to the owning dof through LDS (clamped actuators have zero derivative)
+        need = true;
+        const float *biasprm = MF(actuator_biasprm), *gear = MF(actuator_gear), *frange = MF(actuator_forcerange);
+        __syncthreads();
+        s_vec[lane] = 0.f;
+        __syncthreads();
+        for (int k = lane; k < nu; k += 64) {
+          const int da = m.jnt_dofadr[m.actuator_trnid[2 * k]];
+          const float f = d.actuator_force[(size_t)w * nu + k];
+          if (m.actuator_forcelimited[k] && (f <= frange[2 * k] || f >= frange[2 * k + 1])) continue;
+          atomicAdd(&s_vec[da], -gear[6 * k] * gear[6 * k] * biasprm[10 * k + 2]);
+        }
+        __syncthreads();
+        diag += s_vec[lane];
+      }
+      state = ST_INTEGRATE;
+      if (__ballot(need)) {
+        __syncthreads();
+        dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
+        chol_pad_rows<NVP>(c.s_H, nv, lane);
+        chol_pad_diag<NVP>(c.s_H, nv, lane);
+        __syncthreads();
+        if (own) c.s_H[lane * ld + lane] += h * diag;
+        rhs = own ? qs + fc : 0.f;
+        need_factor = true;
+      } else {
+        skip_solve = true;  // explicit Euler without damping: a = qacc
+      }
+    }
+
+    float x = qacc;
+    if (!skip_solve) {
+      if (need_factor) {
+        __syncthreads();
+        chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
+        __syncthreads();
+        PROF_MARK(12);
+        PROF_COUNT(14);
+      }
+      x = chol_solve<NVP>(c.s_H, c.s_invd, lane, rhs);
+      PROF_MARK(13);
+      PROF_COUNT(15);
+    }
+
+    if (state == ST_INTEGRATE) {
+      // velocity / position update with acceleration x (mj_Euler / mj_implicit tail)
+      if (own) {
+        const size_t wvi = (size_t)w * nv + launder(lane);
+        const float qv = d.qvel[wvi] + h * x;
+        d.qvel[wvi] = qv;
+        s_vec[lane] = qv;
+      }
+      __syncthreads();
+      float* qpos = d.qpos + (size_t)w * nq;
+      for (int j = lane; j < nj; j += 64) {
+        const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+        if (m.jnt_type[j] == MJLAB_JNT_FREE) {
+          for (int k = 0; k < 3; ++k) qpos[qa + k] += h * s_vec[da + k];
+          float ax[3] = {s_vec[da + 3], s_vec[da + 4], s_vec[da + 5]}, q[4], qr[4], qn[4];
+          for (int k = 0; k < 4; ++k) q[k] = qpos[qa + 3 + k];
+          const float ang = h * normalize3(ax);
+          axis_angle2quat(qr, ax, ang);
+          normalize4(q);
+          mul_quat(qn, q, qr);
+          normalize4(qn);
+          for (int k = 0; k < 4; ++k) qpos[qa + 3 + k] = qn[k];
+        } else {
+          qpos[qa] += h * s_vec[da];
+        }
+      }
+      if (lane == 0) d.time[w] += h;
+      PROF_MARK(9);
+      break;
+    }
+
+    bool finished = false;  // constraint solve finished in this pass
+    if (state == ST_SMOOTH) {
+      qas = x;
+      __syncthreads();
+      const size_t wvs = (size_t)w * nv + launder(lane);
+      if (own) d.qacc_smooth[wvs] = qas;
+      if (nefc == 0) {
+        qacc = qas;
+        finished = true;
+      } else {
+        for (int r = launder(lane); r < nefc; r += 64) c.s_D[r] = d.efc_D[wr + r];
+        // ---- warmstart: better of qacc_warmstart and qacc_smooth
+        const float ws = own ? d.qacc_warmstart[wvs] : 0.f;
+        {
+          float x16[NB], y16[NB];
+          gather16<NB>(ws, x16, lane);
+          gather16<NB>(qas, y16, lane);
+          jac_mul<NVP, true>(c, x16, y16, c.s_jar, c.s_jv);
+        }
+        __syncthreads();
+        for (int r = launder(lane); r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
+        __syncthreads();
+        const float Ma_ws = symm_mul_global<NVP>(c.M, nv, ws, lane);
+        const float cost_ws = constraint_cost(c.s_jar, c.s_D, nefc, lane) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
+        const float cost_s = constraint_cost(c.s_jv, c.s_D, nefc, lane);
+        if (cost_ws > cost_s) {
+          qacc = qas;
+          Ma = qs;  // M qacc_smooth = qfrc_smooth
+          for (int r = lane; r < nefc; r += 64) c.s_jar[r] = c.s_jv[r];
+          __syncthreads();
+        } else {
+          qacc = ws;
+          Ma = Ma_ws;
+        }
+        PROF_MARK(2);
+        // ---- initial constraint state, gradient, Hessian
+        cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
+        gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
+        cost += gauss;
+        {
+          __syncthreads();
+          int* s_act = (int*)c.s_jv;
+          const int nact = build_active_list<NVP>(c, s_act);
+          __syncthreads();
+          f32x4 htile[NB * (NB + 1) / 2];
+          fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
+          rhs = own ? Ma - qs - fc : 0.f;
+          hessian_store<NVP>(c, htile);
+          chol_pad_diag<NVP>(c.s_H, nv, lane);
+        }
+        PROF_MARK(3);
+        need_factor = true;
+        state = ST_NEWTON;
+      }
+    } else {
+      // ---- ST_NEWTON: x = H^-1 grad -> line search along -x, update, convergence test
+      const float search = own ? -x : 0.f;
+      const float snorm = sqrtf(wave_sum(search * search));
+      float alpha = 0.f, Mv = 0.f;
+      if (snorm >= MINVAL) {
+        const float gtol = tol * lstol * snorm * mi * nvf;
+        Mv = symm_mul_global<NVP>(c.M, nv, search, lane);
+        {
+          float x16[NB];
+          gather16<NB>(search, x16, lane);
+          __syncthreads();
+          jac_mul<NVP, false>(c, x16, x16, c.s_jv, c.s_jv);
+        }
+        __syncthreads();
+        c.quad_gauss[0] = gauss;
+        c.quad_gauss[1] = wave_sum(own ? search * (Ma - qs) : 0.f);
+        c.quad_gauss[2] = wave_sum(own ? 0.5f * search * Mv : 0.f);
+        PROF_MARK(5);
+        alpha = line_search<NVP>(c, gtol, lsmax);
+        PROF_MARK(6);
+#ifdef MJLAB_PROFILE
+        prof_acc_[10] += (float)c.ls_iter;
+        prof_acc_[11] += 1.f;
+#endif
+      }
+      if (alpha == 0.f) {
+        finished = true;  // no direction or no progress: keep the current iterate
+      } else {
+        qacc += alpha * search;
+        Ma += alpha * Mv;
+        bool changed = false;  // did any row switch between active and satisfied?
+        for (int r = lane; r < nefc; r += 64) {
+          const float o = c.s_jar[r], nw = o + alpha * c.s_jv[r];
+          changed |= (o < 0.f) != (nw < 0.f);
+          c.s_jar[r] = nw;
+        }
+        const bool any_changed = __ballot(changed) != 0ull;
+        __syncthreads();
+        const float oldcost = cost;
+        cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
+        gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
+        cost += gauss;
+        // One pass over J gives J^T f for the convergence test and, if the active set
+        // changed, the new Hessian tiles (kept in registers).  Laying H out in LDS and its
+        // factorization happen only when another iteration follows; with an unchanged active
+        // set H is unchanged and the factor in LDS is reused.  (The two branches are spelled
+        // out so that the 24 tile registers are live only inside the branch that needs them.)
+        iter++;
+        int* s_act = (int*)c.s_jv;  // J search is dead until the next line search
+        const int nact = build_active_list<NVP>(c, s_act);
+        __syncthreads();
+        if (any_changed) {
+          f32x4 htile[NB * (NB + 1) / 2];
+          fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
+          rhs = own ? Ma - qs - fc : 0.f;
+          const float improvement = scale * (oldcost - cost);
+          const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
+          finished = improvement < tol || gradient < tol || iter >= maxiter;
+          if (!finished) {
+            __syncthreads();
+            hessian_store<NVP>(c, htile);
+            chol_pad_diag<NVP>(c.s_H, nv, lane);
+          }
+          need_factor = true;
+        } else {  // same active set -> same H -> the factor in LDS is still valid
+          f32x4 unused[NB * (NB + 1) / 2];
+          fc = hessian_accum<NVP, false>(c, unused, s_act, nact);
+          rhs = own ? Ma - qs - fc : 0.f;
+          const float improvement = scale * (oldcost - cost);
+          const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
+          finished = improvement < tol || gradient < tol || iter >= maxiter;
+          need_factor = false;
+        }
+        PROF_MARK(7);
+      }
+    }
+    if (finished) {  // publish the solve, then hand over to the integrator
+      if (lane == 0) d.solver_niter[w] = iter;
+      for (int r = launder(lane); r < nefc; r += 64) {
+        const float xr = c.s_jar[r];
+        d.efc_force[wr + r] = xr < 0.f ? -c.s_D[r] * xr : 0.f;
+      }
+      if (own) {
+        const size_t wvp = (size_t)w * nv + launder(lane);
+        d.qacc[wvp] = qacc;
+        d.qacc_warmstart[wvp] = qacc;
+        d.qfrc_constraint[wvp] = fc;
+      }
+      PROF_MARK(8);
+      state = ST_PREP_INTEGRATE;
+    }
+  }
+  if (do_integrate && lane == 0) d.fold_valid[w] = 0;  // the state moved on
+  PROF_FLUSH(d.profile + (size_t)w * 64);
+}
+
+// forward(): remember the qpos / qvel the pass was computed from (see FLAG_FOLD in k_position)
+__global__ __launch_bounds__(64) void k_fold_snapshot(const Model m, const Data d, const int flags) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  const int nq = m.size.nq, nv = m.size.nv;
+  for (int i = lane; i < nq; i += 64) d.sh_qpos[(size_t)w * nq + i] = d.qpos[(size_t)w * nq + i];
+  for (int i = lane; i < nv; i += 64) d.sh_qvel[(size_t)w * nv + i] = d.qvel[(size_t)w * nv + i];
+  if (lane == 0) d.fold_valid[w] = 1;
+}
+

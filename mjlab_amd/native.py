@@ -17,7 +17,8 @@ from . import _abi
 CSRC = Path(__file__).parent / "csrc"
 LIB_PATH = Path(os.environ.get("MJLAB_AMD_LIB", CSRC / "libmjlab_amd.so"))
 SOURCES = [CSRC / "mjlab_amd.hip"]
-HEADERS = [Path(__file__).parents[1] / "include" / "mjlab_amd.h", Path(__file__).parents[1] / "include" / "mjlab_fields.h"]
+HEADERS = [Path(__file__).parents[1] / "include" / "mjlab_amd.h", Path(__file__).parents[1] / "include" / "mjlab_fields.h",
+           *sorted(CSRC.glob("*.h"))]  # the stage files are included by mjlab_amd.hip (one translation unit)
 
 STAGE_POSITION, STAGE_COLLISION, STAGE_VELOCITY, STAGE_CONSTRAINT, STAGE_SOLVE, STAGE_INTEGRATE = 1, 2, 4, 8, 16, 32
 STAGE_FORWARD, STAGE_STEP = 31, 63
