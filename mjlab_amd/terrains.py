@@ -315,7 +315,9 @@ def env_origins_curriculum(num_envs: int, origins: np.ndarray, max_init_level: i
   num_rows, num_cols = origins.shape[:2]
   top = num_rows - 1 if max_init_level is None else min(max_init_level, num_rows - 1)
   levels = rng.integers(0, top + 1, size=num_envs)
-  types = np.floor(np.arange(num_envs) / (num_envs / num_cols)).astype(np.int64)
+  # the reference floors a float32 division (torch.div(arange, num_envs / num_cols, rounding_mode="floor")):
+  # with 4096 envs over 20 columns that differs from exact arithmetic at the column boundaries
+  types = np.floor_divide(np.arange(num_envs, dtype=np.float32), np.float32(num_envs / num_cols)).astype(np.int64)
   return origins[levels, types].astype(np.float64), levels, types
 
 
@@ -328,3 +330,62 @@ def env_origins_grid(num_envs: int, env_spacing: float) -> np.ndarray:
   out[:, 0] = -(ii.flatten()[:num_envs] - (num_rows - 1) / 2) * env_spacing
   out[:, 1] = (jj.flatten()[:num_envs] - (num_cols - 1) / 2) * env_spacing
   return out
+
+
+@dataclass
+class TerrainImporterCfg:
+  """Reference terrains/terrain_importer.py:36-54."""
+
+  terrain_type: str = "plane"  # "generator" | "plane"
+  terrain_generator: TerrainGeneratorCfg | None = None
+  env_spacing: float | None = 2.0
+  max_init_terrain_level: int | None = None
+  num_envs: int = 1
+
+
+class TerrainImporter:
+  """Terrain geometry + environment placement (reference terrains/terrain_importer.py:57-240): adds
+  the terrain to a scene ``Spec``, computes ``env_origins`` (sub-terrain origins by level / type for
+  generated terrains, a square grid for the plane) and moves environments between difficulty levels
+  (``update_env_origins``, driven by the reference's ``terrain_levels_vel`` curriculum term).
+  Origins are torch tensors on ``device`` like upstream; the random draws use a seeded generator."""
+
+  def __init__(self, cfg: TerrainImporterCfg, device: str, spec: Spec | None = None, seed: int = 0) -> None:
+    import torch
+
+    self.cfg, self.device = cfg, device
+    self.spec = spec if spec is not None else Spec()
+    self._gen = torch.Generator(device="cpu")
+    self._gen.manual_seed(seed)
+    self.terrain_origins = None
+    if cfg.terrain_type == "generator":
+      if cfg.terrain_generator is None:
+        raise ValueError("terrain_generator must be specified for terrain_type 'generator'")
+      self.terrain = TerrainGenerator(cfg.terrain_generator).compile(self.spec)
+      self.terrain_origins = torch.tensor(self.terrain.origins, dtype=torch.float, device=device)
+      num_rows, num_cols = self.terrain_origins.shape[:2]
+      top = num_rows - 1 if cfg.max_init_terrain_level is None else min(cfg.max_init_terrain_level, num_rows - 1)
+      self.max_terrain_level = num_rows
+      self.terrain_levels = torch.randint(0, top + 1, (cfg.num_envs,), generator=self._gen).to(device)
+      self.terrain_types = torch.div(torch.arange(cfg.num_envs, device=device), cfg.num_envs / num_cols, rounding_mode="floor").to(torch.long)
+      self.env_origins = self.terrain_origins[self.terrain_levels, self.terrain_types].clone()
+    elif cfg.terrain_type == "plane":
+      from .mjcf import GEOM_PLANE
+
+      self.spec.add_geom(self.spec.add_body("terrain"), "terrain", GEOM_PLANE, (0, 0, 0.01))
+      if cfg.env_spacing is None:
+        raise ValueError("Environment spacing must be specified for configuring grid-like origins.")
+      self.env_origins = torch.tensor(env_origins_grid(cfg.num_envs, cfg.env_spacing), dtype=torch.float, device=device)
+    else:
+      raise ValueError(f"Unknown terrain type: {cfg.terrain_type}")
+
+  def update_env_origins(self, env_ids, move_up, move_down) -> None:
+    """Promote / demote environments; one that outgrows the last level restarts at a random one."""
+    import torch
+
+    if self.terrain_origins is None:
+      return
+    lv = self.terrain_levels[env_ids] + 1 * move_up - 1 * move_down
+    rnd = torch.randint(0, self.max_terrain_level, (len(lv),), generator=self._gen).to(lv.device)
+    self.terrain_levels[env_ids] = torch.where(lv >= self.max_terrain_level, rnd, torch.clip(lv, 0))
+    self.env_origins[env_ids] = self.terrain_origins[self.terrain_levels[env_ids], self.terrain_types[env_ids]]

@@ -65,7 +65,9 @@ def test_env_origins():
   eo, levels, types = terrains.env_origins_curriculum(4096, origins, 5, rng)
   assert eo.shape == (4096, 3) and levels.max() <= 5 and levels.min() == 0
   # types are spread evenly over the columns in env order (terrain_importer.py:222-226)
-  assert np.array_equal(types, np.arange(4096) * 20 // 4096)
+  import torch
+
+  assert np.array_equal(types, torch.div(torch.arange(4096), 4096 / 20, rounding_mode="floor").long().numpy())
   np.testing.assert_array_equal(eo, origins[levels, types])
   g = terrains.env_origins_grid(16, 2.0)
   assert g.shape == (16, 3) and np.allclose(g.mean(axis=0), 0) and np.isclose(np.ptp(g[:, 0]), 6.0)
@@ -76,3 +78,32 @@ def test_seed_required():
   cfg.seed = None
   with pytest.raises(ValueError):
     terrains.TerrainGenerator(cfg)
+
+
+def test_terrain_importer_origins_and_level_updates():
+  import torch
+
+  cfg = terrains.TerrainImporterCfg(terrain_type="generator", terrain_generator=terrains.rough_terrains_cfg(seed=0), max_init_terrain_level=5, num_envs=64)
+  imp = terrains.TerrainImporter(cfg, device="cpu", seed=1)
+  assert imp.env_origins.shape == (64, 3) and int(imp.terrain_levels.max()) <= 5
+  assert torch.equal(imp.terrain_types, torch.div(torch.arange(64), 64 / 20, rounding_mode="floor").long())
+  _, _, types_np = terrains.env_origins_curriculum(64, np.zeros((10, 20, 3)), 5, np.random.default_rng(0))
+  assert np.array_equal(types_np, imp.terrain_types.numpy())  # the numpy helper floors like the reference's float32 division
+  assert torch.equal(imp.env_origins, imp.terrain_origins[imp.terrain_levels, imp.terrain_types])
+  assert len(imp.spec.body("terrain").geoms) == 3564
+  # promote env 0..3, demote 4..7 (reference terrain_importer.py:196-209)
+  ids = torch.arange(8)
+  before = imp.terrain_levels.clone()
+  up = torch.tensor([1, 1, 1, 1, 0, 0, 0, 0], dtype=torch.bool)
+  imp.update_env_origins(ids, up, ~up)
+  assert torch.equal(imp.terrain_levels[:4], before[:4] + 1)
+  assert torch.equal(imp.terrain_levels[4:8], torch.clip(before[4:8] - 1, 0))
+  assert torch.equal(imp.env_origins[:8], imp.terrain_origins[imp.terrain_levels[:8], imp.terrain_types[:8]])
+  # outgrowing the last level restarts at a random valid level
+  imp.terrain_levels[:] = 9
+  imp.update_env_origins(ids, torch.ones(8, dtype=torch.bool), torch.zeros(8, dtype=torch.bool))
+  assert (imp.terrain_levels[:8] >= 0).all() and (imp.terrain_levels[:8] <= 9).all()
+  # plane: grid origins
+  pl = terrains.TerrainImporter(terrains.TerrainImporterCfg(terrain_type="plane", num_envs=9, env_spacing=2.0), device="cpu")
+  assert pl.env_origins.shape == (9, 3) and pl.terrain_origins is None
+  pl.update_env_origins(ids[:2], up[:2], ~up[:2])  # no-op without sub-terrains
