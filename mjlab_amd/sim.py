@@ -28,7 +28,7 @@ from typing import Any, Literal
 import numpy as np
 import torch
 
-from . import _abi, native
+from . import _abi, device_state, native
 from .mjcf import CONE_ELLIPTIC, CONE_PYRAMIDAL, INT_EULER, INT_IMPLICITFAST, SOL_CG, SOL_NEWTON, SOL_PGS, Model, Spec
 from .nan_guard import NanGuard, NanGuardCfg
 from .sim_data import Bridge
@@ -153,7 +153,6 @@ class HostData:
     self.time = 0.0
 
 
-_EXTRA_MODEL_FIELDS = ("geom_rgba",)  # DR-able host fields not consumed by the kernels
 
 
 class Simulation:
@@ -188,44 +187,8 @@ class Simulation:
     self._dfields = {f.name: f for f in df}
     self.nconmax, self.njmax = _abi.default_capacities(model, cfg.nconmax, cfg.njmax)
 
-    with torch.cuda.device(dev):
-      # ---- model
-      self._m = MS()
-      self._m.size = _abi.fill_sizes(model, num_envs, self.nconmax, self.njmax)
-      self._m.opt = _abi.fill_option(model)
-      self._model_base: dict[str, torch.Tensor] = {}
-      self._model_view: dict[str, torch.Tensor] = {}
-      for f in mf:
-        if f.kind == "i":
-          t = torch.from_numpy(_abi.model_int_array(model, f.name)).to(dev)
-          self._model_base[f.name] = t
-          self._model_view[f.name] = t
-          setattr(self._m, f.name, t.data_ptr())
-        else:
-          host = np.ascontiguousarray(getattr(model, f.name), dtype=np.float32)
-          t = torch.from_numpy(host).to(dev).unsqueeze(0).contiguous()
-          self._model_base[f.name] = t
-          self._model_view[f.name] = t.expand(num_envs, *t.shape[1:])
-          setattr(self._m, f.name, t.data_ptr())
-          setattr(self._m, f.name + "_ws", 0)
-      for name in _EXTRA_MODEL_FIELDS:
-        host = np.ascontiguousarray(getattr(model, name), dtype=np.float32)
-        t = torch.from_numpy(host).to(dev).unsqueeze(0).contiguous()
-        self._model_base[name] = t
-        self._model_view[name] = t.expand(num_envs, *t.shape[1:])
-      # ---- data
-      self._d = DS()
-      self._data: dict[str, torch.Tensor] = {}
-      for f in df:
-        n = _abi.count_of(f.count, model, self.nconmax, self.njmax)
-        dtype = torch.int32 if f.kind == "i" else torch.float32
-        flat = torch.zeros((num_envs, n * f.ncol), dtype=dtype, device=dev)
-        setattr(self._d, f.name, flat.data_ptr())
-        self._data[f.name] = self._shape_view(f, flat, n)
-      self._data["qpos"][:] = torch.from_numpy(model.qpos0.astype(np.float32)).to(dev)
-      # activation state: na = 0 for every supported actuator (no dynamics), kept for API parity
-      # (reference entity/data.py reads data.act)
-      self._data["act"] = torch.zeros((num_envs, int(getattr(model, "na", 0))), dtype=torch.float32, device=dev)
+    self._m, self._model_base, self._model_view = device_state.upload_model(model, num_envs, self.nconmax, self.njmax, dev)
+    self._d, self._data = device_state.alloc_data(model, num_envs, self.nconmax, self.njmax, dev)
 
     scalars = {k: int(getattr(model, k)) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata")}
     self._expanded: set[str] = set()
@@ -251,22 +214,6 @@ class Simulation:
     not reuse it.  Shared fields are read-only broadcasts and do not matter."""
     if name in self._expanded:
       self._data["fold_valid"].zero_()
-
-  @staticmethod
-  def _shape_view(f: _abi.FieldSpec, flat: torch.Tensor, n: int) -> torch.Tensor:
-    nw = flat.shape[0]
-    if f.count == "one":
-      return flat.view(nw) if f.ncol == 1 else flat.view(nw, f.ncol)
-    if f.count == "nvnv":
-      nv = int(round(n**0.5))
-      return flat.view(nw, nv, nv)
-    if f.count == "njmaxnv":
-      return flat  # (nworld, njmax * nv), reshaped by users that need it
-    if f.ncol == 1:
-      return flat.view(nw, n)
-    if f.ncol == 9 and f.name.endswith("xmat") or f.name in ("ximat",):
-      return flat.view(nw, n, 3, 3)
-    return flat.view(nw, n, f.ncol)
 
   def _stream(self) -> int:
     return torch.cuda.current_stream(self._dev).cuda_stream
@@ -351,26 +298,8 @@ class Simulation:
       self._m.size.nstaticgeom = 0  # static geoms may now differ per world: recompute them every pass
     with torch.cuda.device(self._dev):
       for name in fields:
-        if name not in self._model_base:
-          host = np.ascontiguousarray(getattr(self._mj_model, name), dtype=np.float32)
-          self._model_base[name] = torch.from_numpy(host).to(self._dev).unsqueeze(0).contiguous()
-        base = self._model_base[name]
-        if base.dtype != torch.float32:
-          raise ValueError(f"Field '{name}' is an integer topology field and cannot be per-world")
-        if base.shape[0] == self.num_envs:
-          continue  # already expanded
-        nelem = base[0].numel()
-        dst = torch.empty((self.num_envs, *base.shape[1:]), dtype=base.dtype, device=self._dev)
-        native.check(
-          self._lib.mjlab_tile_field(dst.data_ptr(), base.data_ptr(), nelem, self.num_envs, 4, self._stream()),
-          "mjlab_tile_field",
-        )
-        self._model_base[name] = dst
-        self._model_view[name] = dst
-        self._expanded.add(name)
-        if name in self._mfields:
-          setattr(self._m, name, dst.data_ptr())
-          setattr(self._m, name + "_ws", int(nelem))
+        if device_state.expand_field(self._m, self._model_base, self._model_view, self._mj_model, name, self.num_envs, self._dev, self._stream()):
+          self._expanded.add(name)
       self._data["fold_valid"].zero_()
       # pointers changed: captured graphs are stale (the reference re-captures too:
       # envs/manager_based_rl_env.py:102-104)
