@@ -77,7 +77,7 @@ def model_from_mujoco(mjm: Any) -> Model:
   if m.nsensor and (m.sensor_type != mjcf.SENS_CONTACT).any():
     raise NotImplementedError("only contact sensors (mjSENS_CONTACT) are implemented")
   col = (m.geom_contype != 0) | (m.geom_conaffinity != 0)
-  bad = col & np.isin(m.geom_type, (mjcf.GEOM_HFIELD, mjcf.GEOM_ELLIPSOID, mjcf.GEOM_CYLINDER, mjcf.GEOM_MESH))
+  bad = col & np.isin(m.geom_type, (mjcf.GEOM_HFIELD, mjcf.GEOM_MESH))  # cylinders / ellipsoids: rejected only inside a candidate pair
   if bad.any():
     raise NotImplementedError(f"colliding geom types {sorted(set(m.geom_type[bad].tolist()))} are not implemented")
   if not np.isin(m.geom_condim[col], (1, 3)).all():

@@ -1141,8 +1141,11 @@ def _compile(spec: Spec) -> Model:
       m.geom_rbound[gi] = np.linalg.norm(s) if t == GEOM_BOX else max(s)
     elif t == GEOM_PLANE:
       m.geom_rbound[gi] = 0.0
-    if t in (GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_HFIELD) and (g.contype or g.conaffinity):
-      raise NotImplementedError(f"colliding geom type {t} is not supported")
+    # cylinders / ellipsoids may exist and even be collidable: finalize_topology rejects the model
+    # only if one of them ends up in a candidate pair (no collision function) -- a lone static
+    # cylinder, as in the reference's own fixtures (tests/test_entity.py:84), is harmless
+    if t == GEOM_HFIELD and (g.contype or g.conaffinity):
+      raise NotImplementedError("colliding height fields are not supported")
     if g.condim not in (1, 3):
       raise NotImplementedError("only condim 1 and 3 are supported")
   m.site_bodyid = np.array([bid[id(s.body)] for s in sites], np.int32).reshape(nsite)
