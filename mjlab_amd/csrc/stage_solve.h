@@ -305,6 +305,18 @@ __device__ __forceinline__ float constraint_cost(const float* s_jar, const float
 // registers through scratch memory, and the register allocator sees the whole kernel.
 enum { ST_SMOOTH = 0, ST_NEWTON = 1, ST_PREP_INTEGRATE = 2, ST_INTEGRATE = 3 };
 
+// Rounding noise of the gradient M a - qfrc_smooth - J^T f as evaluated in fp32: MJLAB_GNOISE ulps
+// of the terms it is the difference of.  A gradient below that cannot be reduced by another Newton
+// step -- the step itself would be noise -- so the iteration stops (the fp64 restatement applies
+// the same rule with its own epsilon, where it never binds before the tolerance does).
+#ifndef MJLAB_GNOISE
+#define MJLAB_GNOISE 4.f
+#endif
+__device__ __forceinline__ float grad_noise(float scale, bool own, float Ma, float qs, float fc) {
+  const float t = own ? fabsf(Ma) + fabsf(qs) + fabsf(fc) : 0.f;
+  return MJLAB_GNOISE * 5.9604645e-8f * scale * sqrtf(wave_sum(t * t));
+}
+
 template <int NVP>
 __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
-          finished = improvement < tol || gradient < tol || iter >= maxiter;
+          finished = improvement < tol || gradient < tol || gradient < grad_noise(scale, own, Ma, qs, fc) || iter >= maxiter;
           if (!finished) {
             __syncthreads();
             hessian_store<NVP>(c, htile);
@@ -564,7 +576,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
-          finished = improvement < tol || gradient < tol || iter >= maxiter;
+          finished = improvement < tol || gradient < tol || gradient < grad_noise(scale, own, Ma, qs, fc) || iter >= maxiter;
           need_factor = false;
         }
         PROF_MARK(7);

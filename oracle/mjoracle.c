@@ -1166,11 +1166,20 @@ static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
     real oldcost = c.cost;
     update_constraint(&c);
     update_gradient(&c);
-    real improvement = scale * (oldcost - c.cost), gn = 0;
-    for (int i = 0; i < nv; i++) gn += c.grad[i] * c.grad[i];
+    real improvement = scale * (oldcost - c.cost), gn = 0, tn = 0;
+    for (int i = 0; i < nv; i++) {
+      real t = fabs(c.Ma[i]) + fabs(c.qfrc_smooth[i]) + fabs(c.qfrc_constraint[i]);
+      gn += c.grad[i] * c.grad[i];
+      tn += t * t;
+    }
     real gradient = scale * sqrt(gn);
+    /* rounding noise of the gradient in this precision (4 ulps of the terms it is the difference
+     * of): below it another Newton step is noise.  Never binds before the tolerance in fp64; in
+     * fp32 (this file's MJO_FLOAT build, the HIP kernels) it is what ends the iteration, because
+     * neither `improvement` nor `gradient` can resolve 1e-8 there. */
+    real noise = 4 * (sizeof(real) == 4 ? (real)5.9604645e-8 : (real)1.1102230246251565e-16) * scale * sqrt(tn);
     iter++;
-    if (improvement < (real)m->opt.tolerance || gradient < (real)m->opt.tolerance) break;
+    if (improvement < (real)m->opt.tolerance || gradient < (real)m->opt.tolerance || gradient < noise) break;
   }
   d->solver_niter[w] = iter;
   memcpy(ws, qacc, sizeof(real) * nv);
