@@ -28,6 +28,7 @@ struct SolveCtx {
   float *s_H, *s_invd, *s_jar, *s_jv, *s_D;
   int nv, nefc, lane;
   float quad_gauss[3];
+  float dn1, dn2;  // rounding noise of the line-search derivative: d0_noise(alpha) = dn1 + |alpha| dn2
   int ls_iter;
   // line search: quadratic coefficients of this lane's row (rows 0..63) for the current search
   // direction, so that an evaluation touches LDS only for rows >= 64
@@ -188,6 +189,9 @@ __device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x
 }
 
 // cost of row r along the search direction: D/2 (j0 + alpha jv)^2 where that is negative
+#ifndef MJLAB_LSNOISE
+#define MJLAB_LSNOISE 4.f
+#endif
 template <int NVP>
 __device__ __forceinline__ void ls_prepare(SolveCtx<NVP>& c) {
   const int r = c.lane;
@@ -199,6 +203,17 @@ __device__ __forceinline__ void ls_prepare(SolveCtx<NVP>& c) {
   if (r + 64 < c.nefc) { j0 = c.s_jar[r + 64]; jv = c.s_jv[r + 64]; Dr = c.s_D[r + 64]; }
   c.mj0 = j0; c.mjv = jv;
   c.mq0 = 0.5f * Dr * j0 * j0; c.mq1 = Dr * j0 * jv; c.mq2 = 0.5f * Dr * jv * jv;
+  // The derivative d0(alpha) = sum_r (q1_r + 2 alpha q2_r) + Gauss terms is a sum of large terms
+  // that cancel at the minimiser: in fp32 it cannot get below MJLAB_LSNOISE ulps of them, while
+  // MuJoCo's gtol (tolerance * ls_tolerance * |search| * scale ~ 1e-7) asks for less.  Once
+  // |d0| is inside that noise band the search has found the minimiser as well as fp32 can tell.
+  float a1 = fabsf(c.lq1) + fabsf(c.mq1), a2 = fabsf(c.lq2) + fabsf(c.mq2);
+  for (int k = r + 128; k < c.nefc; k += 64) {
+    const float dj = c.s_D[k] * c.s_jv[k];
+    a1 += fabsf(dj * c.s_jar[k]); a2 += fabsf(0.5f * dj * c.s_jv[k]);
+  }
+  c.dn1 = MJLAB_LSNOISE * 5.9604645e-8f * (wave_sum(a1) + fabsf(c.quad_gauss[1]));
+  c.dn2 = MJLAB_LSNOISE * 5.9604645e-8f * 2.f * (wave_sum(a2) + fabsf(c.quad_gauss[2]));
 }
 __device__ __forceinline__ float ls_newton_step(float alpha, float d0, float d1) {
   return alpha - d0 * __builtin_amdgcn_rcpf(d1);  // 1 ulp reciprocal: alpha only has to meet ls_tolerance
@@ -246,6 +261,11 @@ __device__ __forceinline__ int update_bracket(SolveCtx<NVP>& c, LsPnt* p, const 
   return flag;
 }
 // exact 1-D line search on the piecewise-quadratic cost (safeguarded Newton + bracketing)
+// tolerance on the derivative at step alpha: MuJoCo's gtol, but never below what fp32 resolves
+template <int NVP>
+__device__ __forceinline__ float ls_tol(const SolveCtx<NVP>& c, float gtol, float alpha) {
+  return fmaxf(gtol, c.dn1 + fabsf(alpha) * c.dn2);
+}
 template <int NVP>
 __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
   LsPnt p0, p1, p2, pmid, p1next, p2next;
@@ -254,15 +274,15 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
   ls_eval(c, &p0, 0.f);
   ls_eval(c, &p1, ls_newton_step(p0.alpha, p0.d0, p0.d1));
   if (p0.cost < p1.cost) p1 = p0;
-  if (fabsf(p1.d0) < gtol) return p1.alpha;
+  if (fabsf(p1.d0) < ls_tol(c, gtol, p1.alpha)) return p1.alpha;
   const float dir = p1.d0 < 0.f ? 1.f : -1.f;
   bool p2update = false;
   p2 = p1;
-  while (p1.d0 * dir <= -gtol && c.ls_iter < lsmax) {
+  while (p1.d0 * dir <= -ls_tol(c, gtol, p1.alpha) && c.ls_iter < lsmax) {
     p2 = p1;
     p2update = true;
     ls_eval(c, &p1, ls_newton_step(p1.alpha, p1.d0, p1.d1));
-    if (fabsf(p1.d0) < gtol) return p1.alpha;
+    if (fabsf(p1.d0) < ls_tol(c, gtol, p1.alpha)) return p1.alpha;
   }
   if (c.ls_iter >= lsmax) return p1.alpha;
   if (!p2update) return p1.alpha;
@@ -275,7 +295,7 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
     bool found = false;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-      if (fabsf(cand[i].d0) < gtol && (!found || cand[i].cost < bestcost)) { bestcost = cand[i].cost; bestalpha = cand[i].alpha; found = true; }
+      if (fabsf(cand[i].d0) < ls_tol(c, gtol, cand[i].alpha) && (!found || cand[i].cost < bestcost)) { bestcost = cand[i].cost; bestalpha = cand[i].alpha; found = true; }
     if (found) return bestalpha;
     const int b1 = update_bracket(c, &p1, cand, &p1next);
     const int b2 = update_bracket(c, &p2, cand, &p2next);

@@ -1012,7 +1012,12 @@ static void update_gradient(nctx_t* c) {
   for (int i = 0; i < nv; i++) c->search[i] = -c->search[i];
 }
 
+/* debug counters (single-threaded runs only): line-search evaluations / searches */
+static long mjo_dbg_evals = 0, mjo_dbg_searches = 0;
+long mjo_debug_counter(int which, int reset) { long v = which ? mjo_dbg_searches : mjo_dbg_evals; if (reset) mjo_dbg_evals = mjo_dbg_searches = 0; return v; }
+
 static void ls_eval(nctx_t* c, lspnt_t* p, real alpha) {
+  mjo_dbg_evals++;
   real cost = alpha * alpha * c->quad_gauss[2] + alpha * c->quad_gauss[1] + c->quad_gauss[0];
   real d0 = 2 * alpha * c->quad_gauss[2] + c->quad_gauss[1], d1 = 2 * c->quad_gauss[2];
   for (int r = 0; r < c->nefc; r++) {
@@ -1045,6 +1050,7 @@ static real line_search(const mjo_model_t* m, nctx_t* c) {
   for (int i = 0; i < nv; i++) snorm += c->search[i] * c->search[i];
   snorm = sqrt(snorm);
   c->ls_iter = 0;
+  mjo_dbg_searches++;
   if (snorm < MINVAL) return 0;
   real scale = (real)m->opt.meaninertia * (nv > 1 ? nv : 1);
   real gtol = (real)m->opt.tolerance * (real)m->opt.ls_tolerance * snorm * scale;
@@ -1067,19 +1073,34 @@ static real line_search(const mjo_model_t* m, nctx_t* c) {
     c->quad_gauss[1] += c->search[i] * (c->Ma[i] - c->qfrc_smooth[i]);
     c->quad_gauss[2] += (real)0.5 * c->search[i] * c->Mv[i];
   }
+  /* The derivative d0(alpha) = sum_r (q1_r + 2 alpha q2_r) + Gauss terms is a sum of large terms
+   * that cancel at the minimiser: it cannot be evaluated below a few ulps of them.  The tolerance on
+   * it is MuJoCo's gtol, but never less than that noise band (4 ulps).  In fp64 the band is far
+   * below gtol and never binds; in fp32 (MJO_FLOAT build, the HIP kernels) gtol ~ 1e-7 is not
+   * resolvable and without the band the search burns its evaluations on noise. */
+  real dn1 = fabs(c->quad_gauss[1]), dn2 = fabs(c->quad_gauss[2]);
+  for (int r = 0; r < c->nefc; r++) {
+    real dj = c->Dv[r] * c->jv[r];
+    dn1 += fabs(dj * c->jar[r]);
+    dn2 += fabs((real)0.5 * dj * c->jv[r]);
+  }
+  const real ulp4 = 4 * (sizeof(real) == 4 ? (real)5.9604645e-8 : (real)1.1102230246251565e-16);
+  dn1 *= ulp4;
+  dn2 *= 2 * ulp4;
+#define LS_TOL(alpha_) (gtol > dn1 + fabs(alpha_) * dn2 ? gtol : dn1 + fabs(alpha_) * dn2)
   lspnt_t p0, p1, p2, pmid, p1next, p2next;
   ls_eval(c, &p0, 0);
   ls_eval(c, &p1, p0.alpha - p0.d0 / p0.d1);
   if (p0.cost < p1.cost) p1 = p0;
-  if (fabs(p1.d0) < gtol) return p1.alpha;
+  if (fabs(p1.d0) < LS_TOL(p1.alpha)) return p1.alpha;
   int dir = p1.d0 < 0 ? 1 : -1;
   int p2update = 0;
   p2 = p1;
-  while (p1.d0 * dir <= -gtol && c->ls_iter < lsmax) {
+  while (p1.d0 * dir <= -LS_TOL(p1.alpha) && c->ls_iter < lsmax) {
     p2 = p1;
     p2update = 1;
     ls_eval(c, &p1, p1.alpha - p1.d0 / p1.d1);
-    if (fabs(p1.d0) < gtol) return p1.alpha;
+    if (fabs(p1.d0) < LS_TOL(p1.alpha)) return p1.alpha;
   }
   if (c->ls_iter >= lsmax) return p1.alpha;
   if (!p2update) return p1.alpha;
@@ -1091,7 +1112,7 @@ static real line_search(const mjo_model_t* m, nctx_t* c) {
     real bestcost = 0;
     int best = -1;
     for (int i = 0; i < 3; i++)
-      if (fabs(cand[i].d0) < gtol && (best == -1 || cand[i].cost < bestcost)) { bestcost = cand[i].cost; best = i; }
+      if (fabs(cand[i].d0) < LS_TOL(cand[i].alpha) && (best == -1 || cand[i].cost < bestcost)) { bestcost = cand[i].cost; best = i; }
     if (best >= 0) return cand[best].alpha;
     int b1 = update_bracket(c, &p1, cand, &p1next);
     int b2 = update_bracket(c, &p2, cand, &p2next);
@@ -1100,6 +1121,7 @@ static real line_search(const mjo_model_t* m, nctx_t* c) {
   if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
   if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
   return 0;
+#undef LS_TOL
 }
 
 static real constraint_cost_at(nctx_t* c, const real* qacc, int with_gauss) {
