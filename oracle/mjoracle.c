@@ -1012,8 +1012,9 @@ static void update_gradient(nctx_t* c) {
   for (int i = 0; i < nv; i++) c->search[i] = -c->search[i];
 }
 
-/* debug counters (single-threaded runs only): line-search evaluations / searches */
-static long mjo_dbg_evals = 0, mjo_dbg_searches = 0;
+/* debug counters: line-search evaluations / searches of the CALLING thread (thread-local, so the
+ * worker threads of mjo_run do not fight over a cache line; meaningful for nthread = 1 runs) */
+static __thread long mjo_dbg_evals = 0, mjo_dbg_searches = 0;
 long mjo_debug_counter(int which, int reset) { long v = which ? mjo_dbg_searches : mjo_dbg_evals; if (reset) mjo_dbg_evals = mjo_dbg_searches = 0; return v; }
 
 static void ls_eval(nctx_t* c, lspnt_t* p, real alpha) {
