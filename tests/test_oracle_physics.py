@@ -393,3 +393,35 @@ def test_capsule_capsule_and_sphere_capsule_distance_by_brute_force():
         assert got is not None and abs(got - true) < 2e-4, (w, key, got, true)  # scan resolution ~1e-4
         hit += 1
   assert hit > 60 and clear > 60
+
+
+def test_fp32_build_does_not_burn_iterations_on_rounding_noise():
+  """MuJoCo's solver tolerances (1e-8 scaled) are below what fp32 resolves: without the
+  rounding-noise rules (gradient noise in the Newton termination, derivative noise in the line
+  search) an fp32 build needs ~13.5 line-search evaluations per search and one
+  more Newton iteration than fp64.  With them the two precisions do the same amount of work and
+  agree on the result."""
+  import ctypes
+
+  m = robots.load_model("g1_velocity_flat")
+  rng = np.random.default_rng(0)
+  jn = m.actuator_trnid[:, 0]
+  default = m.key_qpos[0][m.jnt_qposadr[jn]]
+  drop = rng.uniform(0, 0.03, 32)
+  ctrls = default + 0.3 * rng.uniform(-1, 1, (12, 32, m.nu))
+  stats = {}
+  for prec in ("f64", "f32"):
+    o = OracleSim(m, 32, njmax=300, precision=prec)
+    o.lib.mjo_debug_counter.restype = ctypes.c_long
+    o.reset(key=0)
+    o.qpos[:, 2] -= drop
+    for k in range(11):
+      o.ctrl[:] = ctrls[k]
+      o.step(4)
+    o.lib.mjo_debug_counter(0, 1)
+    o.ctrl[:] = ctrls[11]
+    o.step(4)
+    evals, searches = o.lib.mjo_debug_counter(0, 0), o.lib.mjo_debug_counter(1, 0)
+    stats[prec] = (evals / searches, float(o.solver_niter.mean()), o.qacc.copy())
+  assert stats["f32"][0] < 1.3 * stats["f64"][0] and stats["f32"][0] < 7.0, stats
+  assert abs(stats["f32"][1] - stats["f64"][1]) < 0.5
