@@ -68,11 +68,11 @@ int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void
  * mjlab_forward snapshots qpos / qvel per world (data.sh_qpos, sh_qvel, fold_valid); the first
  * sub-step of the next mjlab_step compares them bit by bit and skips those three stages where
  * nothing changed.  Velocity / actuation and the constraint solve always run, so the results are
- * bit-identical to a full recomputation.  Callers that modify per-world MODEL fields between
- * forward() and step() must zero data.fold_valid (mjlab_amd.sim.Simulation does);
- * mjlab_set_fold(0) disables the mechanism process-wide and returns the previous setting. */
+ * bit-identical to a full recomputation.  The mechanism is per model: it is active only when
+ * m->opt.flags has MJLAB_OPT_FOLD_FORWARD (mjlab_fields.h).  Callers that modify MODEL arrays between
+ * forward() and step() -- interval domain randomisation -- must zero data.fold_valid
+ * (mjlab_amd.sim.Simulation does whenever a writable model field is handed out). */
 int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream);
-int mjlab_set_fold(int enable);
 
 /* Extension (not in the reference API): mjlab_forward restricted to
  * the worlds whose d->world_mask entry is non-zero; the other worlds' arrays are left untouched.

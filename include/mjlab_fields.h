@@ -165,6 +165,7 @@
   X(world_mask, 1, one) /* mjlab_forward_masked: worlds with 0 are skipped */     \
   X(fold_valid, 1, one) /* 1: position / collision / constraint arrays are those of (sh_qpos, sh_qvel) */ \
   X(fold_reuse, 1, one) /* scratch of the current step: 1 = this world skips those three stages */ \
+  X(overflow, 1, one)   /* MJLAB_OVF_* bits of the last collision / constraint pass of this world */ \
   X(contact_dim, 1, nconmax)                                                    \
   X(contact_geom, 2, nconmax)                                                   \
   X(contact_efc_address, 1, nconmax)                                            \
@@ -195,6 +196,12 @@ typedef struct mjlab_sizes {
   int nterrain, ntgeom, ntcell, ntcellp1, ntitem, tgrid_nx, tgrid_ny;
 } mjlab_sizes_t;
 
+/* mjlab_data_t.overflow: capacity overflows, which DROP work silently otherwise */
+enum {
+  MJLAB_OVF_NCONMAX = 1, /* contacts beyond sizes.nconmax were dropped */
+  MJLAB_OVF_NJMAX = 2,   /* a limit row or a contact's rows did not fit sizes.njmax and were dropped */
+  MJLAB_OVF_TCAND = 4    /* a moving geom had more than MJLAB_TCAND_MAX terrain boxes within reach */
+};
 /* terrain boxes kept per moving geom and step: the MJLAB_TCAND_MAX with the smallest ids */
 #define MJLAB_TCAND_MAX 12
 
@@ -211,7 +218,23 @@ typedef struct mjlab_option {
   int ls_iterations;
   int integrator;
   int cone;
+  int flags; /* MJLAB_OPT_* bits below */
+  int pad_;
 } mjlab_option_t;
+/* mjlab_option_t.flags */
+enum {
+  /* step() right after forward() reuses the position / collision / constraint-build stages of that
+   * pass in worlds whose qpos and qvel are still bit-identical (see mjlab_forward in mjlab_amd.h) */
+  MJLAB_OPT_FOLD_FORWARD = 1,
+  /* MuJoCo's literal termination rules for the Newton iteration and the line search (tolerance /
+   * gtol only).  Default (bit clear): both are additionally bounded from below by the fp32 rounding
+   * noise of the quantity they test */
+  MJLAB_OPT_LITERAL_TERMINATION = 2,
+  /* qacc_warmstart <- qacc is written by the integrator's advance only, so forward() leaves it
+   * untouched.  Default (bit clear): written at the end of every constraint solve, forward()
+   * included (mj_fwdConstraint: "save result for next step warmstart") */
+  MJLAB_OPT_WARMSTART_AT_ADVANCE = 4
+};
 
 #define MJLAB_DECL_INT_(name, ncol, count) const int* name;
 #define MJLAB_DECL_REAL_(name, ncol, count) \

@@ -39,7 +39,15 @@ class Option(ctypes.Structure):
     ("ls_iterations", ctypes.c_int),
     ("integrator", ctypes.c_int),
     ("cone", ctypes.c_int),
+    ("flags", ctypes.c_int),
+    ("pad_", ctypes.c_int),
   ]
+
+
+# mjlab_option_t.flags (include/mjlab_fields.h)
+OPT_FOLD_FORWARD, OPT_LITERAL_TERMINATION, OPT_WARMSTART_AT_ADVANCE = 1, 2, 4
+# mjlab_data_t.overflow bits
+OVF_NCONMAX, OVF_NJMAX, OVF_TCAND = 1, 2, 4
 
 
 @dataclass(frozen=True)
@@ -110,6 +118,7 @@ def fill_option(m: Model) -> Option:
   o.ls_iterations = m.opt.ls_iterations
   o.integrator = m.opt.integrator
   o.cone = m.opt.cone
+  o.flags = 0
   return o
 
 

@@ -167,14 +167,6 @@ static int forward_stages_impl(const mjlab_model_t* m, const mjlab_data_t* d, in
   return 0;
 }
 
-// process-wide switch for "forward folded into the next step" (default on)
-static int g_fold = 1;
-int mjlab_set_fold(int enable) {
-  const int old = g_fold;
-  g_fold = enable != 0;
-  return old;
-}
-
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream) {
   // stage-by-stage execution (testing / profiling) leaves the derived arrays in a state the fold
   // bookkeeping does not describe: drop it
@@ -194,7 +186,7 @@ int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream) {
 int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void* stream) {
   if (nsubstep < 1) return fail(-8, "nsubstep must be >= 1");
   for (int k = 0; k < nsubstep; ++k) {
-    int rc = forward_stages_impl(m, d, MJLAB_STAGE_STEP, (k == 0 && g_fold) ? FLAG_FOLD : 0, stream);
+    int rc = forward_stages_impl(m, d, MJLAB_STAGE_STEP, (k == 0 && (m->opt.flags & MJLAB_OPT_FOLD_FORWARD)) ? FLAG_FOLD : 0, stream);
     if (rc) return rc;
   }
   return 0;

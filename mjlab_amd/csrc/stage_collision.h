@@ -192,7 +192,7 @@ __device__ __forceinline__ int capsule_box(RawCon* c, float margin, const float*
 // the (at most MJLAB_TCAND_MAX, smallest ids first) boxes within reach in ascending order in
 // `cand` (this lane's LDS slots).  A box listed in several cells is looked at once, in the lowest
 // cell the two footprints share.
-__device__ __forceinline__ int terrain_walk(const Model& m, const float* centre, float reach, int* cand) {
+__device__ __forceinline__ int terrain_walk(const Model& m, const float* centre, float reach, int* cand, bool* dropped) {
   const int nx = m.size.tgrid_nx, ny = m.size.tgrid_ny;
   const float x0 = (float)m.opt.tgrid_x0, y0 = (float)m.opt.tgrid_y0, inv = 1.0f / (float)m.opt.tgrid_cell;
   int ix0 = (int)floorf((centre[0] - reach - x0) * inv), ix1 = (int)floorf((centre[0] + reach - x0) * inv);
@@ -221,6 +221,7 @@ __device__ __forceinline__ int terrain_walk(const Model& m, const float* centre,
         // sorted insert, bounded: the largest id falls off the end
         int pos = n;
         while (pos > 0 && cand[pos - 1] > b) --pos;
+        *dropped |= n >= MJLAB_TCAND_MAX;  // this box or the largest id in the list falls off
         if (pos >= MJLAB_TCAND_MAX) continue;
         for (int q = n < MJLAB_TCAND_MAX ? n : MJLAB_TCAND_MAX - 1; q > pos; --q) cand[q] = cand[q - 1];
         cand[pos] = b;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
       }
     }
     const unsigned long long nm = __ballot(near);
-    if (near) s_near[nnear + __popcll(nm & ((1ull << lane) - 1ull))] = (g1 << 16) | g2;
+    if (near) s_near[nnear + __popcll(nm & ((1ull << lane) - 1ull))] = (int)(((unsigned)g1 << 16) | (unsigned)g2);
     nnear += __popcll(nm);
   }
   __syncthreads();
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
     int n = 0, g1 = 0, g2 = 0;
     float margin = 0.f, gap = 0.f;
     if (p < nnear) {
-      const int code = s_near[p];
-      g1 = code >> 16; g2 = code & 0xffff;
+      const unsigned code = (unsigned)s_near[p];  // unsigned: geom ids up to 65535 (check_model)
+      g1 = (int)(code >> 16); g2 = (int)(code & 0xffffu);
       const int l1 = g1 - g0, l2 = g2 - g0;
       const int t1 = ((const int*)s_gc)[8 * l1], t2 = ((const int*)s_gc)[8 * l2];
       margin = fmaxf(s_gc[8 * l1 + 5], s_gc[8 * l2 + 5]);
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
   PROF_MARK(1);
   // ---- box terrain: moving spheres / capsules vs static boxes found through the xy grid ----
   const int ntg = m.size.ntgeom;
+  bool tdrop = false;
   if (ntg > 0) {
     __syncthreads();  // the close-pair list shares its LDS with the lists built below
     int* s_cand = (int*)(s_gc + 8 * nl);            // [ntg][TCAND_MAX] box ids, ascending per geom
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
       if (ti < ntg) {
         const int g = m.tgeom[ti];
         isbox = ((const int*)s_gc)[8 * (g - g0)] == MJLAB_GEOM_BOX;
-        nc = terrain_walk(m, s_gx + 3 * (g - g0), s_gc[8 * (g - g0) + 4] + s_gc[8 * (g - g0) + 5], s_cand + ti * MJLAB_TCAND_MAX);
+        nc = terrain_walk(m, s_gx + 3 * (g - g0), s_gc[8 * (g - g0) + 4] + s_gc[8 * (g - g0) + 5], s_cand + ti * MJLAB_TCAND_MAX, &tdrop);
       }
       int total, totalb;
       const int off = wave_excl_scan(isbox ? 0 : nc, lane, &total);
@@ -527,7 +529,11 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
     }
   }
   const int ncm = m.size.nconmax;
-  if (lane == 0) d.ncon[w] = base < ncm ? base : ncm;
+  const bool anydrop = __ballot(tdrop) != 0ull;
+  if (lane == 0) {
+    d.ncon[w] = base < ncm ? base : ncm;
+    d.overflow[w] = (base > ncm ? MJLAB_OVF_NCONMAX : 0) | (anydrop ? MJLAB_OVF_TCAND : 0);  // k_constraint adds MJLAB_OVF_NJMAX
+  }
   PROF_MARK(2);
   PROF_FLUSH(d.profile + (size_t)w * 64 + 32);
 }

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
   float* J = d.efc_J + (size_t)w * njm * nv;
   const size_t wr = (size_t)w * njm;
   int nefc = 0;
+  bool rows_dropped = false;  // wave-uniform: something did not fit njmax
   // ---- joint limits: lanes = joints, rows assigned in (joint, side) order
   {
     const float *range = MF(jnt_range), *jmargin = MF(jnt_margin), *jsolref = MF(jnt_solref), *jsolimp = MF(jnt_solimp),
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
         d.efc_type[wr + r] = MJLAB_EFC_LIMIT;
         d.efc_id[wr + r] = j;
       }
+      rows_dropped |= nefc + total > njm;
       nefc = min(nefc + total, njm);
     }
     __syncthreads();
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
     int total;
     int adr = nefc + wave_excl_scan(nrow, lane, &total);
     if (nefc + total > njm) {  // rare: replay the sequential rule
+      rows_dropped = true;
       int run = nefc;
       for (int l = 0; l < 64; ++l) {
         const int nr = __shfl(nrow, l);
@@ -272,7 +275,10 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
     __syncthreads();
     PROF_MARK(2);
   }
-  if (lane == 0) d.nefc[w] = nefc;
+  if (lane == 0) {
+    d.nefc[w] = nefc;
+    if (rows_dropped) d.overflow[w] |= MJLAB_OVF_NJMAX;  // k_collision wrote the word earlier in this pass
+  }
   __syncthreads();
   // ---- contact sensors ("found" data spec): count of matching contacts that are in efc
   const int nsens = m.size.nsensor;

@@ -29,6 +29,7 @@ struct SolveCtx {
   int nv, nefc, lane;
   float quad_gauss[3];
   float dn1, dn2;  // rounding noise of the line-search derivative: d0_noise(alpha) = dn1 + |alpha| dn2
+  float noise_ulps;  // 0 under MJLAB_OPT_LITERAL_TERMINATION (MuJoCo's rules only), else 1
   int ls_iter;
   // line search: quadratic coefficients of this lane's row (rows 0..63) for the current search
   // direction, so that an evaluation touches LDS only for rows >= 64
@@ -212,8 +213,8 @@ __device__ __forceinline__ void ls_prepare(SolveCtx<NVP>& c) {
     const float dj = c.s_D[k] * c.s_jv[k];
     a1 += fabsf(dj * c.s_jar[k]); a2 += fabsf(0.5f * dj * c.s_jv[k]);
   }
-  c.dn1 = MJLAB_LSNOISE * 5.9604645e-8f * (wave_sum(a1) + fabsf(c.quad_gauss[1]));
-  c.dn2 = MJLAB_LSNOISE * 5.9604645e-8f * 2.f * (wave_sum(a2) + fabsf(c.quad_gauss[2]));
+  c.dn1 = c.noise_ulps * MJLAB_LSNOISE * 5.9604645e-8f * (wave_sum(a1) + fabsf(c.quad_gauss[1]));
+  c.dn2 = c.noise_ulps * MJLAB_LSNOISE * 5.9604645e-8f * 2.f * (wave_sum(a2) + fabsf(c.quad_gauss[2]));
 }
 __device__ __forceinline__ float ls_newton_step(float alpha, float d0, float d1) {
   return alpha - d0 * __builtin_amdgcn_rcpf(d1);  // 1 ulp reciprocal: alpha only has to meet ls_tolerance
@@ -332,9 +333,9 @@ enum { ST_SMOOTH = 0, ST_NEWTON = 1, ST_PREP_INTEGRATE = 2, ST_INTEGRATE = 3 };
 #ifndef MJLAB_GNOISE
 #define MJLAB_GNOISE 4.f
 #endif
-__device__ __forceinline__ float grad_noise(float scale, bool own, float Ma, float qs, float fc) {
+__device__ __forceinline__ float grad_noise(float ulps, float scale, bool own, float Ma, float qs, float fc) {
   const float t = own ? fabsf(Ma) + fabsf(qs) + fabsf(fc) : 0.f;
-  return MJLAB_GNOISE * 5.9604645e-8f * scale * sqrtf(wave_sum(t * t));
+  return ulps * MJLAB_GNOISE * 5.9604645e-8f * scale * sqrtf(wave_sum(t * t));
 }
 
 template <int NVP>
@@ -354,6 +355,8 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
   c.J = d.efc_J + (size_t)w * njm * nv;
   c.M = d.qM + (size_t)w * nv * nv;
   c.nv = nv; c.lane = lane;
+  c.noise_ulps = (m.opt.flags & MJLAB_OPT_LITERAL_TERMINATION) ? 0.f : 1.f;
+  const bool ws_at_advance = (m.opt.flags & MJLAB_OPT_WARMSTART_AT_ADVANCE) != 0;
   const size_t wv = (size_t)w * nv + lane;
   const size_t wr = (size_t)w * njm;
   const bool own = lane < nv;
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
         const size_t wvi = (size_t)w * nv + launder(lane);
         const float qv = d.qvel[wvi] + h * x;
         d.qvel[wvi] = qv;
+        if (ws_at_advance) d.qacc_warmstart[wvi] = qacc;
         s_vec[lane] = qv;
       }
       __syncthreads();
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
-          finished = improvement < tol || gradient < tol || gradient < grad_noise(scale, own, Ma, qs, fc) || iter >= maxiter;
+          finished = improvement < tol || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
           if (!finished) {
             __syncthreads();
             hessian_store<NVP>(c, htile);
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
-          finished = improvement < tol || gradient < tol || gradient < grad_noise(scale, own, Ma, qs, fc) || iter >= maxiter;
+          finished = improvement < tol || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
           need_factor = false;
         }
         PROF_MARK(7);
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
       if (own) {
         const size_t wvp = (size_t)w * nv + launder(lane);
         d.qacc[wvp] = qacc;
-        d.qacc_warmstart[wvp] = qacc;
+        if (!ws_at_advance) d.qacc_warmstart[wvp] = qacc;
         d.qfrc_constraint[wvp] = fc;
       }
       PROF_MARK(8);

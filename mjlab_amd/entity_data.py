@@ -32,6 +32,45 @@ class _View(ctypes.Structure):
   ]  # fmt: skip
 
 
+def entity_indexing(model, device: str | torch.device = "cpu", root_body: int | None = None) -> dict:
+  """Index tables of one entity, named and typed like the reference's ``EntityIndexing``
+  (src/mjlab/entity/entity.py:20-47, built at :588-652): what its ``EntityData`` and
+  ``randomize_field`` index ``sim.data`` / ``sim.model`` with.  The entity is the subtree of
+  ``root_body`` (default: the last child of the world body).  Returned as a dict of keyword
+  arguments, so ``EntityIndexing(bodies=..., joints=(), geoms=(), sites=(), actuators=None, **tables)``
+  works on the reference side; ``bodies`` here is a tuple of objects with an ``id`` (the only
+  attribute the reference reads, ``root_body_id``)."""
+  from types import SimpleNamespace
+
+  m = model
+  if root_body is None:
+    root_body = int(np.nonzero(np.asarray(m.body_parentid) == 0)[0][-1])
+  body_ids = np.arange(root_body, root_body + int(m.body_subtreenum[root_body]))
+  inb = lambda ids: np.isin(np.asarray(ids), body_ids)  # noqa: E731
+  it = lambda a: torch.tensor(np.asarray(a, dtype=np.int64), dtype=torch.int, device=device)  # noqa: E731
+  jb = np.asarray(m.jnt_bodyid)
+  jsel = [j for j in range(m.njnt) if inb(jb[j]) and m.jnt_type[j] != JNT_FREE]
+  fsel = [j for j in range(m.njnt) if inb(jb[j]) and m.jnt_type[j] == JNT_FREE]
+  fq = [a for j in fsel for a in range(int(m.jnt_qposadr[j]), int(m.jnt_qposadr[j]) + 7)]
+  fv = [a for j in fsel for a in range(int(m.jnt_dofadr[j]), int(m.jnt_dofadr[j]) + 6)]
+  sensors = {}
+  for k, name in enumerate(m.names.get("sensor", [])):
+    sensors[name.split("/")[-1]] = torch.arange(int(m.sensor_adr[k]), int(m.sensor_adr[k]) + int(m.sensor_dim[k]), dtype=torch.int, device=device)
+  return {
+    "bodies": tuple(SimpleNamespace(id=int(b)) for b in body_ids),
+    "body_ids": it(body_ids),
+    "geom_ids": it(np.nonzero(inb(m.geom_bodyid))[0]),
+    "site_ids": it(np.nonzero(inb(m.site_bodyid))[0]),
+    "ctrl_ids": it([a for a in range(m.nu) if inb(jb[m.actuator_trnid[a, 0]])]),
+    "joint_ids": it(jsel),
+    "joint_q_adr": it(np.asarray(m.jnt_qposadr)[jsel]),
+    "joint_v_adr": it(np.asarray(m.jnt_dofadr)[jsel]),
+    "free_joint_q_adr": it(fq),
+    "free_joint_v_adr": it(fv),
+    "sensor_adr": sensors,
+  }
+
+
 class EntityReadback:
   """Entity = the subtree of ``root_body`` (default: the last child of the world, i.e. the
   robot attached after the terrain, reference scene/scene.py:133-147)."""

@@ -46,7 +46,10 @@ class Model:
     self.__dict__.update(host=host, device=device, nworld=1, _expanded=set())
     struct, base, view = device_state.upload_model(host, 1, 1, 1, device)
     self.__dict__.update(struct=struct, _base=base, _view=view)
-    # the reference sets wp_model.opt.ls_parallel (sim/sim.py:111); accepted, the search here is exact
+    # the reference sets wp_model.opt.ls_parallel (sim/sim.py:111); accepted and ignored: the search here
+    # is the exact iterative one (deviations).  "Forward folded into the next step" stays
+    # OFF on this seam: nothing here sees writes to model arrays between forward() and step()
+    # (Simulation hooks its model bridge for that); set struct.opt.flags |= _abi.OPT_FOLD_FORWARD to opt in.
     self.__dict__["opt"] = SimpleNamespace(**host.opt.__dict__, ls_parallel=False)
 
   def __getattr__(self, name: str) -> Any:

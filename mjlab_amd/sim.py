@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import warnings
 from dataclasses import dataclass, field
 from typing import Any, Literal
 
@@ -30,7 +31,6 @@ import torch
 
 from . import _abi, device_state, native
 from .mjcf import CONE_ELLIPTIC, CONE_PYRAMIDAL, INT_EULER, INT_IMPLICITFAST, SOL_CG, SOL_NEWTON, SOL_PGS, Model, Spec
-from .nan_guard import NanGuard, NanGuardCfg
 from .sim_data import Bridge
 
 _CONE_MAP = {"pyramidal": CONE_PYRAMIDAL, "elliptic": CONE_ELLIPTIC}
@@ -68,6 +68,15 @@ class MujocoCfg:
     o.ls_tolerance = self.ls_tolerance
 
 
+@dataclass
+class NanGuardCfg:
+  """Placeholder for the reference's debugging aid (sim/sim.py:90,129,191), which is outside the
+  physics path and not provided: only ``enabled=False`` is accepted.  Non-finite states are handled
+  on the device by ``mjlab_masked_reset``; ``Simulation.post_step_hooks`` is the hook point."""
+
+  enabled: bool = False
+
+
 @dataclass(kw_only=True)
 class SimulationCfg:
   """Reference sim/sim.py:85-91.  ``nconmax`` is accepted for signature parity; contact
@@ -75,13 +84,22 @@ class SimulationCfg:
 
   nconmax: int | None = None
   njmax: int | None = None
-  ls_parallel: bool = True  # accepted for parity; the line search here is the exact (iterative) one
+  # The reference sets True (mujoco_warp's fixed-grid parallel line search).  Here the search is
+  # always MuJoCo's exact iterative one: True is accepted with a one-time warning (INTEGRATION.md,
+  # "deviations")
+  ls_parallel: bool = True
   mujoco: MujocoCfg = field(default_factory=MujocoCfg)
   nan_guard: NanGuardCfg = field(default_factory=NanGuardCfg)
   use_graph: bool = True
   # step() right after forward() skips the stages that would reproduce that pass bit for bit
   # (include/mjlab_amd.h, mjlab_forward); False recomputes them like the reference does
   fold_forward: bool = True
+  # MuJoCo's literal Newton / line-search termination (tolerance, gtol) without the fp32
+  # rounding-noise floors (MJLAB_OPT_LITERAL_TERMINATION)
+  literal_termination: bool = False
+  # qacc_warmstart is saved by the integrator's advance only (forward() leaves it untouched)
+  # instead of at the end of every constraint solve (MJLAB_OPT_WARMSTART_AT_ADVANCE)
+  warmstart_at_advance: bool = False
 
 
 def check_supported(model: Model) -> None:
@@ -112,6 +130,9 @@ def check_supported(model: Model) -> None:
     spec = np.asarray(model.sensor_intprm)[:, 0]
     if (spec != 1).any():
       raise NotImplementedError("contact sensors support only the 'found' data spec")
+
+
+_LS_PARALLEL_WARNED = False
 
 
 class _NumpyView:
@@ -181,13 +202,23 @@ class Simulation:
     self._mj_model = model
     self._mj_data = HostData(model)
     self._lib = native.lib()
-    self._lib.mjlab_set_fold(1 if cfg.fold_forward else 0)
+    global _LS_PARALLEL_WARNED
+    if cfg.ls_parallel and not _LS_PARALLEL_WARNED:
+      _LS_PARALLEL_WARNED = True
+      warnings.warn(
+        "SimulationCfg.ls_parallel=True: mjlab_amd always runs MuJoCo's exact iterative line search "
+        "(<= ls_iterations evaluations), not mujoco_warp's fixed-grid parallel search; iterates can differ "
+        "from the reference's beyond its ls_tolerance when the Newton iteration cap binds (INTEGRATION.md, deviations)",
+        stacklevel=2,
+      )
     mf, df, MS, DS = native.layouts()
     self._mfields = {f.name: f for f in mf}
     self._dfields = {f.name: f for f in df}
     self.nconmax, self.njmax = _abi.default_capacities(model, cfg.nconmax, cfg.njmax)
 
     self._m, self._model_base, self._model_view = device_state.upload_model(model, num_envs, self.nconmax, self.njmax, dev)
+    self._m.opt.flags = ((_abi.OPT_FOLD_FORWARD if cfg.fold_forward else 0) | (_abi.OPT_LITERAL_TERMINATION if cfg.literal_termination else 0)
+                         | (_abi.OPT_WARMSTART_AT_ADVANCE if cfg.warmstart_at_advance else 0))
     self._d, self._data = device_state.alloc_data(model, num_envs, self.nconmax, self.njmax, dev)
 
     scalars = {k: int(getattr(model, k)) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata")}
@@ -196,7 +227,9 @@ class Simulation:
                                 on_access=self._on_model_access)
     self._data_bridge = Bridge("sim.data", self._data, {"nworld": num_envs, "njmax": self.njmax, "nconmax": self.nconmax})
 
-    self.nan_guard = NanGuard(cfg.nan_guard, num_envs, model)
+    if getattr(cfg.nan_guard, "enabled", False):
+      raise NotImplementedError("nan_guard is not provided by mjlab_amd (append a callable to Simulation.post_step_hooks instead)")
+    self.post_step_hooks: list = []  # callables(sim) run after every step() (where the reference's NaN guard sits)
     self.use_graph = bool(cfg.use_graph) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
     self.step_graph: torch.cuda.CUDAGraph | None = None
     self.forward_graph: torch.cuda.CUDAGraph | None = None
@@ -212,8 +245,13 @@ class Simulation:
     """A per-world (expanded) model field handed out may be written through (domain
     randomisation): the last forward pass no longer describes the model, so the next step must
     not reuse it.  Shared fields are read-only broadcasts and do not matter."""
-    if name in self._expanded:
+    f = self._mfields.get(name)
+    if f is None or f.kind != "r":
+      return  # int topology fields are shared and read-only for the kernels' purposes
+    if name in self._expanded or self.num_envs == 1:  # writable storage (a 1-world view aliases the base array)
       self._data["fold_valid"].zero_()
+      if name == "dof_frictionloss":
+        self._frictionloss_handed_out = True
 
   def _stream(self) -> int:
     return torch.cuda.current_stream(self._dev).cuda_stream
@@ -325,11 +363,31 @@ class Simulation:
 
   def step(self) -> None:
     with torch.cuda.device(self._dev):
-      if self.nan_guard.enabled:  # debugging aid (reference sim/sim.py:191); costs a host sync per step
-        with self.nan_guard.watch(self._data_bridge):
-          self._step_once()
-      else:
-        self._step_once()
+      self._step_once()
+      for hook in self.post_step_hooks:
+        hook(self)
+
+  def invalidate_fold(self) -> None:
+    """Forget the last forward pass ("forward folded into the next step").  Needed only by callers
+    that write to a model tensor obtained EARLIER (a cached handle): every ``sim.model.<field>``
+    access of a writable field does this by itself."""
+    self._data["fold_valid"].zero_()
+
+  def check_model_writes(self) -> None:
+    """Host-side check (one sync) of per-world model values the kernels do not implement:
+    a non-zero ``dof_frictionloss`` written after construction (friction-loss rows are not built)."""
+    if getattr(self, "_frictionloss_handed_out", False) and bool((self._model_view["dof_frictionloss"] != 0).any()):
+      raise NotImplementedError("dof_frictionloss != 0 was written to sim.model: friction-loss constraint rows are not implemented")
+
+  def overflow_report(self) -> dict[str, int]:
+    """Worlds whose last collision / constraint pass dropped work for lack of capacity
+    (``data.overflow`` bits, include/mjlab_fields.h); one host sync.  Warns when any did."""
+    o = self._data["overflow"].view(-1)
+    rep = {"nconmax": int((o & _abi.OVF_NCONMAX).ne(0).sum()), "njmax": int((o & _abi.OVF_NJMAX).ne(0).sum()),
+           "terrain_candidates": int((o & _abi.OVF_TCAND).ne(0).sum())}
+    if any(rep.values()):
+      warnings.warn(f"capacity overflow (worlds affected): {rep}; raise SimulationCfg.njmax / nconmax", stacklevel=2)
+    return rep
 
   def _step_once(self) -> None:
     if self.use_graph and self.step_graph is not None:

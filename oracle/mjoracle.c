@@ -602,6 +602,7 @@ static void emit_contacts(const mjo_model_t* m, mjo_data_t* d, int w, int g1, in
       for (int k = 0; k < 2; k++) solref[k] = gsolref[2 * g1 + k] < gsolref[2 * g2 + k] ? gsolref[2 * g1 + k] : gsolref[2 * g2 + k];
     for (int k = 0; k < 5; k++) solimp[k] = mix * gsolimp[5 * g1 + k] + (1 - mix) * gsolimp[5 * g2 + k];
   }
+  if (ncon + n > ncm) d->overflow[w] |= MJLAB_OVF_NCONMAX;
   for (int i = 0; i < n && ncon < ncm; i++) {
     make_frame(rc[i].frame);
     D(contact_dist, ncm)[ncon] = rc[i].dist;
@@ -624,7 +625,7 @@ static void emit_contacts(const mjo_model_t* m, mjo_data_t* d, int w, int g1, in
 /* Terrain broadphase for one moving geom: walk the grid cells under its bounding sphere and keep
  * the (at most MJLAB_TCAND_MAX, smallest ids first) boxes within reach, in ascending order.  A box
  * listed in several cells is looked at once, in the lowest cell the two footprints share. */
-static int terrain_candidates(const mjo_model_t* m, const real* centre, real reach, int* cand) {
+static int terrain_candidates(const mjo_model_t* m, const real* centre, real reach, int* cand, int* dropped) {
   const mjlab_sizes_t* s = &m->size;
   const int nx = s->tgrid_nx, ny = s->tgrid_ny;
   const real x0 = (real)m->opt.tgrid_x0, y0 = (real)m->opt.tgrid_y0, inv = (real)1 / (real)m->opt.tgrid_cell;
@@ -652,6 +653,7 @@ static int terrain_candidates(const mjo_model_t* m, const real* centre, real rea
         /* sorted insert, bounded: the largest id falls off the end */
         int pos = n < MJLAB_TCAND_MAX ? n : MJLAB_TCAND_MAX;
         while (pos > 0 && cand[pos - 1] > b) pos--;
+        if (n >= MJLAB_TCAND_MAX) *dropped = 1; /* this box or the largest id in the list falls off */
         if (pos >= MJLAB_TCAND_MAX) continue;
         int last = n < MJLAB_TCAND_MAX ? n : MJLAB_TCAND_MAX - 1;
         for (int q = last; q > pos; q--) cand[q] = cand[q - 1];
@@ -666,7 +668,8 @@ static void collision(const mjo_model_t* m, mjo_data_t* d, int w) {
   const mjlab_sizes_t* s = &m->size;
   real *gx = D(geom_xpos, 3 * s->ngeom), *gm = D(geom_xmat, 9 * s->ngeom);
   const real *gsize = MF(geom_size, w), *rbound = MF(geom_rbound, w), *gmargin = MF(geom_margin, w), *ggap = MF(geom_gap, w);
-  int ncon = 0;
+  int ncon = 0, tdrop = 0;
+  d->overflow[w] = 0;
   for (int p = 0; p < s->npair; p++) {
     int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -703,7 +706,7 @@ static void collision(const mjo_model_t* m, mjo_data_t* d, int w) {
     int g = m->tgeom[ti], cand[MJLAB_TCAND_MAX];
     if ((m->geom_type[g] == MJLAB_GEOM_BOX) != (pass == 1)) continue;
     real margin = gmargin[g], gap = ggap[g];
-    int nc = terrain_candidates(m, gx + 3 * g, rbound[g] + margin, cand);
+    int nc = terrain_candidates(m, gx + 3 * g, rbound[g] + margin, cand, &tdrop);
     for (int q = 0; q < nc; q++) {
       int b = cand[q];
       rawcon_t rc[4];
@@ -783,6 +786,7 @@ static void make_constraint(const mjo_model_t* m, mjo_data_t* d, int w) {
     real value = qpos[m->jnt_qposadr[j]], mg = jmargin[j];
     for (int side = -1; side <= 1; side += 2) {
       real dist = side * (range[2 * j + (side + 1) / 2] - value);
+      if (dist < mg && nefc >= njm) d->overflow[w] |= MJLAB_OVF_NJMAX;
       if (dist < mg && nefc < njm) {
         real* row = J + (size_t)nefc * nv;
         memset(row, 0, sizeof(real) * nv);
@@ -801,7 +805,7 @@ static void make_constraint(const mjo_model_t* m, mjo_data_t* d, int w) {
     (d->contact_efc_address + (size_t)w * ncm)[c] = -1;
     if (dist >= inc) continue;
     int nrow = dim == 1 ? 1 : 2 * (dim - 1);
-    if (nefc + nrow > njm) continue;
+    if (nefc + nrow > njm) { d->overflow[w] |= MJLAB_OVF_NJMAX; continue; }
     int g1 = (d->contact_geom + (size_t)w * 2 * ncm)[2 * c], g2 = (d->contact_geom + (size_t)w * 2 * ncm)[2 * c + 1];
     int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
     const real *pos = D(contact_pos, 3 * ncm) + 3 * c, *frame = D(contact_frame, 9 * ncm) + 9 * c;
@@ -1085,7 +1089,7 @@ static real line_search(const mjo_model_t* m, nctx_t* c) {
     dn1 += fabs(dj * c->jar[r]);
     dn2 += fabs((real)0.5 * dj * c->jv[r]);
   }
-  const real ulp4 = 4 * (sizeof(real) == 4 ? (real)5.9604645e-8 : (real)1.1102230246251565e-16);
+  const real ulp4 = (m->opt.flags & MJLAB_OPT_LITERAL_TERMINATION) ? 0 : 4 * (sizeof(real) == 4 ? (real)5.9604645e-8 : (real)1.1102230246251565e-16);
   dn1 *= ulp4;
   dn2 *= 2 * ulp4;
 #define LS_TOL(alpha_) (gtol > dn1 + fabs(alpha_) * dn2 ? gtol : dn1 + fabs(alpha_) * dn2)
@@ -1150,7 +1154,7 @@ static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
   real* force = D(efc_force, njm);
   if (nefc == 0) {
     memcpy(qacc, qas, sizeof(real) * nv);
-    memcpy(ws, qas, sizeof(real) * nv);
+    if (!(m->opt.flags & MJLAB_OPT_WARMSTART_AT_ADVANCE)) memcpy(ws, qas, sizeof(real) * nv);
     memset(D(qfrc_constraint, nv), 0, sizeof(real) * nv);
     d->solver_niter[w] = 0;
     return;
@@ -1201,11 +1205,12 @@ static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
      * fp32 (this file's MJO_FLOAT build, the HIP kernels) it is what ends the iteration, because
      * neither `improvement` nor `gradient` can resolve 1e-8 there. */
     real noise = 4 * (sizeof(real) == 4 ? (real)5.9604645e-8 : (real)1.1102230246251565e-16) * scale * sqrt(tn);
+    if (m->opt.flags & MJLAB_OPT_LITERAL_TERMINATION) noise = 0;
     iter++;
     if (improvement < (real)m->opt.tolerance || gradient < (real)m->opt.tolerance || gradient < noise) break;
   }
   d->solver_niter[w] = iter;
-  memcpy(ws, qacc, sizeof(real) * nv);
+  if (!(m->opt.flags & MJLAB_OPT_WARMSTART_AT_ADVANCE)) memcpy(ws, qacc, sizeof(real) * nv);
   free(buf);
 }
 
@@ -1275,6 +1280,7 @@ static void integrate(const mjo_model_t* m, mjo_data_t* d, int w) {
     chol_factor(A, nv);
     chol_solve(A, nv, a);
   } else memcpy(a, qacc, sizeof(real) * nv);
+  if (m->opt.flags & MJLAB_OPT_WARMSTART_AT_ADVANCE) memcpy(D(qacc_warmstart, nv), qacc, sizeof(real) * nv);
   for (int i = 0; i < nv; i++) qvel[i] += h * a[i];
   for (int j = 0; j < s->njnt; j++) {
     int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];

@@ -38,7 +38,8 @@ class OracleSim:
   ``mjlab_amd.sim.Simulation`` (and like ``mjwarp.Data`` in the reference).
   """
 
-  def __init__(self, model: Model, nworld: int = 1, nconmax: int | None = None, njmax: int | None = None, precision: str = "f64"):
+  def __init__(self, model: Model, nworld: int = 1, nconmax: int | None = None, njmax: int | None = None, precision: str = "f64",
+               flags: int = 0):
     self.model = model
     self.nworld = nworld
     self.lib = _load(precision)
@@ -53,6 +54,7 @@ class OracleSim:
     self._m = MS()
     self._m.size = _abi.fill_sizes(model, nworld, self.nconmax, self.njmax)
     self._m.opt = _abi.fill_option(model)
+    self._m.opt.flags = flags  # MJLAB_OPT_LITERAL_TERMINATION / MJLAB_OPT_WARMSTART_AT_ADVANCE (fold is a device-side mechanism)
     self.mfield: dict[str, np.ndarray] = {}
     for f in mfields:
       if f.kind == "i":

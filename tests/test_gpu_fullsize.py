@@ -476,4 +476,17 @@ def test_forward_folded_into_next_step_is_bit_exact():
       assert int(s.data.fold_reuse.sum()) == 0
   for f in out[True]:
     assert torch.equal(out[True][f], out[False][f]), f
-  Simulation(1, SimulationCfg(), model, "cuda:0")  # restore the process-wide default (fold on)
+  # the switch is per Simulation (mjlab_option_t.flags), not process wide: two live sims do not interfere
+  a = Simulation(64, SimulationCfg(njmax=300, fold_forward=True), model, "cuda:0")
+  b = Simulation(64, SimulationCfg(njmax=300, fold_forward=False), model, "cuda:0")
+  for s in (a, b):
+    s.forward()
+    s.step()
+  torch.cuda.synchronize()
+  assert int(a.data.fold_reuse.sum()) == 64 and int(b.data.fold_reuse.sum()) == 0
+  # a one-world Simulation hands out writable model views without any expansion: touching one invalidates
+  c = Simulation(1, SimulationCfg(njmax=300), model, "cuda:0")
+  c.forward()
+  assert int(c.data.fold_valid.sum()) == 1
+  c.model.geom_friction[0, :, 0] *= 0.5
+  assert int(c.data.fold_valid.sum()) == 0
