@@ -35,7 +35,7 @@ sys.path.insert(0, str(ROOT))
 
 from mjlab_amd import dist as mdist  # noqa: E402
 from mjlab_amd import native, robots  # noqa: E402
-from mjlab_amd.rollout import PhysicsRollout, g1_action_scale, go1_action_scale  # noqa: E402
+from mjlab_amd.rollout import VELOCITY_TASK_EVENTS, PhysicsRollout, g1_action_scale, go1_action_scale  # noqa: E402
 from mjlab_amd.sim import Simulation, SimulationCfg  # noqa: E402
 
 # compulsory HBM traffic of the public mjData contract, fp32
@@ -103,6 +103,9 @@ def main() -> None:
                   "forward() even where qpos and qvel did not change (the reference's behaviour; results are bit-identical)")
   ap.add_argument("--masked-forward", action="store_true",
                   help="extension: forward() only on reset worlds (default: all worlds, like the reference)")
+  ap.add_argument("--no-task-events", action="store_true",
+                  help="leave out the velocity task's events (per-env foot friction, velocity pushes, 70 degree orientation "
+                  "termination): round-1 workload (root-height termination, shared model)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--seed", type=int, default=42)
   args = ap.parse_args()
@@ -119,29 +122,78 @@ def main() -> None:
   model = robots.load_model(args.scene)
   sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph, fold_forward=not args.no_fold), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else go1_action_scale(model)
+  robot = "g1" if args.scene.startswith("g1") else "go1"
+  events = {} if args.no_task_events else VELOCITY_TASK_EVENTS[robot]
   roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info),
                         masked_forward=args.masked_forward, fused_reset=not args.torch_reset,
-                        min_height=0.3 if args.scene.startswith("g1") else 0.15)
+                        min_height=0.3 if robot == "g1" else 0.15, **events)
   step_graph = not args.no_graph and not args.no_step_graph
   if step_graph:
     roll.capture_graph()
-  gather = info.world_size > 1 and not args.no_gather
+  exchange = info.world_size > 1 and not args.no_gather
+  nu = model.nu
+  learner_gen = torch.Generator(device=dev)
+  learner_gen.manual_seed(args.seed + 1000)
 
-  def env_step() -> None:
-    roll.step(roll.random_action())
-    if gather:
+  def env_step(with_rows: bool = False) -> None:
+    """One control step.  N > 1: the learner on rank 0 decides the actions of ALL envs, every rank
+    receives its slice (broadcast over RCCL), steps its shard, and the [obs | ...] rows travel back to
+    the learner (gather) -- the exchange SURVEY.md section 8e pairs with env sharding."""
+    if exchange:
+      a_all = torch.rand((info.global_envs, nu), device=dev, generator=learner_gen) * 2 - 1 if info.rank == 0 else None
+      action = mdist.scatter_actions(info, a_all, nu, dev)
+    else:
+      action = roll.random_action()
+    roll.step(action)
+    if exchange:
       mdist.gather_rollout(info, roll.observation_rows())
+    elif with_rows:
+      roll.observation_rows()
 
   for _ in range(args.warmup):
     env_step()
   mdist.barrier()
   torch.cuda.synchronize()
+  # chunk boundaries for the spread of the rate (events on the launch stream: the timed loop itself is unchanged)
+  nchunk = 5 if args.steps >= 10 else 1
+  marks = [torch.cuda.Event(enable_timing=True) for _ in range(nchunk + 1)]
+  bounds = [round(i * args.steps / nchunk) for i in range(nchunk + 1)]
   t0 = time.perf_counter()
-  for _ in range(args.steps):
+  marks[0].record()
+  for i in range(args.steps):
     env_step()
+    if i + 1 in bounds[1:]:
+      marks[bounds.index(i + 1)].record()
   torch.cuda.synchronize()
   mdist.barrier()
-  elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+  my_elapsed = time.perf_counter() - t0
+  elapsed = mdist.max_over_ranks(my_elapsed, dev)
+  rank_ms = mdist.all_rank_values(my_elapsed / args.steps * 1e3, dev)
+  chunk_rates = [args.envs_per_gpu * info.world_size * (bounds[i + 1] - bounds[i]) / (marks[i].elapsed_time(marks[i + 1]) * 1e-3)
+                 for i in range(nchunk)]
+  # second view: the same K steps with the per-env observation rows assembled every step (N = 1: what a
+  # learner on the same GPU would read; N > 1 the rows are already part of the exchange above)
+  value_with_rows = None
+  if not exchange:
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+      env_step(with_rows=True)
+    torch.cuda.synchronize()
+    value_with_rows = args.envs_per_gpu * args.steps / (time.perf_counter() - t1)
+  # the exchange alone (N > 1), so that a scaling curve can be read: broadcast of actions + gather of rows
+  comm_ms = None
+  if exchange:
+    rows = roll.observation_rows()
+    mdist.barrier()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(20):
+      a_all = torch.rand((info.global_envs, nu), device=dev, generator=learner_gen) * 2 - 1 if info.rank == 0 else None
+      mdist.scatter_actions(info, a_all, nu, dev)
+      mdist.gather_rollout(info, rows)
+    torch.cuda.synchronize()
+    comm_ms = mdist.max_over_ranks((time.perf_counter() - t2) / 20 * 1e3, dev)
 
   # ---- dominant-kernel timing with HIP events on the launch stream (instrumented pass:
   # same workload, stages launched one by one so the solve kernel can be bracketed)
@@ -172,11 +224,13 @@ def main() -> None:
     n_env = args.envs_per_gpu * info.world_size
     value = n_env * args.steps / elapsed
     algo = ALGO_BYTES_PER_WORLD_STEP.get(args.scene)
-    traffic = None
+    traffic, valu_busy = None, None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():
       try:
-        traffic = json.loads(tfile.read_text()).get(args.scene, {}).get("solve_integrate_bytes_per_launch")
+        ent = json.loads(tfile.read_text()).get(args.scene, {})
+        traffic = ent.get("solve_integrate_bytes_per_launch")
+        valu_busy = ent.get("solve_integrate_valu_busy")
       except Exception:  # noqa: BLE001
         traffic = None
     roof = None
@@ -190,6 +244,9 @@ def main() -> None:
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
+        # the bound that matters here (the HBM fraction is ~2 % by construction): share of the chip's VALU issue
+        # cycles the dominant kernel uses, from rocprofv3 SQ counters of the committed profile (tools/collect_profile.py)
+        "valu_busy": valu_busy,
         "algorithmic_bytes_per_launch": algo * args.envs_per_gpu,
         "kernel_ms": solve_ms,
         "stage_ms": stage_ms,
@@ -214,17 +271,24 @@ def main() -> None:
       "scaling": "weak",
       "vs_baseline": None,
       "dtype": "f32",
-      "data": "synthetic (random actions, keyframe resets; compiled model from the reference MJCF)",
+      "data": "synthetic (random actions, keyframe resets"
+      + ("" if args.no_task_events else ", per-env foot friction U(0.3,1.2), velocity pushes every U(1,3) s") + "; compiled model from the reference MJCF)",
       "config": {
-        "workload": f"{args.scene}: {args.envs_per_gpu} envs/GPU, timestep 0.005, decimation 4, Newton 10 it / 20 ls, implicitfast, pyramidal, njmax 300",
+        "workload": f"{args.scene}: {args.envs_per_gpu} envs/GPU, timestep 0.005, decimation 4, Newton 10 it / 20 ls, implicitfast, pyramidal, njmax 300"
+        + ("" if args.no_task_events else "; task events: DR friction (per-env geom_friction), pushes, bad_orientation 70 deg termination"),
         "global_envs": n_env,
-        "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL obs all-gather" if gather else ""),
+        "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL action broadcast and obs gather to the learner (rank 0) every control step" if exchange else ""),
         "graph": "one hipGraph per control step" if step_graph else ("per-call step/forward hipGraphs" if sim.use_graph else "none"),
         "forward_after_reset": "reset worlds only (extension)" if args.masked_forward else "all worlds (reference behaviour)",
         "forward_fold": "off" if args.no_fold else "step() after forward() skips the stages that depend on qpos/qvel only where both are unchanged (bit-exact)",
         "termination_and_reset": "torch ops" if args.torch_reset else "one fused launch (mjlab_masked_reset), mask based, no host sync",
       },
       "world_physics_steps_per_s": value * roll.decimation,
+      "value_with_gather": value if exchange else value_with_rows,
+      "std_over_5": float(np.std(chunk_rates)) if nchunk == 5 else None,
+      "chunk_values": chunk_rates,
+      "per_rank_ms_per_step": rank_ms,
+      "exchange_ms_per_step": comm_ms,
       "roofline": roof,
       "cpu_baseline": cpu,
     }

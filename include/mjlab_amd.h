@@ -124,6 +124,20 @@ int mjlab_masked_reset(const mjlab_model_t* m, const mjlab_data_t* d, const floa
                        int* episode_length, int max_len, float min_height, int* reset_mask, const float* env_origins,
                        float min_up_z, void* stream);
 
+/* Extension: the reference's interval event `push_robot` (envs/mdp/events.py:127-143
+ * push_by_setting_velocity, scheduled per env by managers/event_manager.py:116-138 with
+ * interval_range_s = (1, 3) s and velocity_range x, y = +-0.5 m/s for G1-flat:
+ * tasks/velocity/velocity_env_cfg.py:155-161, config/g1/flat_env_cfg.py:20-24) as one launch without a
+ * nonzero() host sync.  Per world: time_left[w] -= dt; where it drops below 1e-6 a new interval
+ * t_lo + U * (t_hi - t_lo) is drawn and the root velocity is kicked by U(range.lo, range.hi) per
+ * component [x, y, z, roll, pitch, yaw] (world frame; the angular part is rotated into the body frame
+ * qvel stores).  rnd7 = (nworld, 7) uniforms in [0, 1): 6 components + the next interval.  The model's
+ * first joint must be the free joint (otherwise an error is returned).  The reference reads the
+ * velocity it adds to from cvel, which equals qvel right after the forward() it calls on resets. */
+typedef struct mjlab_push_range { float lo[6], hi[6]; } mjlab_push_range_t;
+int mjlab_interval_push(const mjlab_model_t* m, const mjlab_data_t* d, float* time_left, const float* rnd7, float dt,
+                        float interval_lo, float interval_hi, const mjlab_push_range_t* range, int root_is_free, void* stream);
+
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);
 

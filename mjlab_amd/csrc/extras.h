@@ -136,6 +136,30 @@ __global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d
   }
 }
 
+// Interval push (reference envs/mdp/events.py:127-143 push_by_setting_velocity under the event
+// manager's per-env interval timer, managers/event_manager.py:116-138): see include/mjlab_amd.h.
+__global__ __launch_bounds__(64) void k_interval_push(const Model m, const Data d, float* time_left, const float* rnd7, const float dt,
+                                                       const float t_lo, const float t_hi, const mjlab_push_range_t range) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= m.size.nworld) return;
+  float t = time_left[w] - dt;
+  if (t < 1e-6f) {
+    const float* r = rnd7 + (size_t)w * 7;
+    t = t_lo + r[6] * (t_hi - t_lo);
+    float* qvel = d.qvel + (size_t)w * m.size.nv;
+    const float* q = d.qpos + (size_t)w * m.size.nq + 3;  // root quaternion (free joint first: checked by the caller)
+    float dv[6];
+    for (int k = 0; k < 6; ++k) dv[k] = range.lo[k] + r[k] * (range.hi[k] - range.lo[k]);
+    for (int k = 0; k < 3; ++k) qvel[k] += dv[k];  // linear: world frame, as qvel stores it
+    // angular: qvel holds it in the body frame; the kick is drawn in the world frame
+    const float qq[4] = {q[0], q[1], q[2], q[3]};
+    float wb[3];
+    quat_apply_dev(wb, qq, dv + 3, -1.f);
+    for (int k = 0; k < 3; ++k) qvel[3 + k] += wb[k];
+  }
+  time_left[w] = t;
+}
+
 // ====================================================================================
 // repeat_array_kernel replacement (reference src/mjlab/sim/randomization.py:9-17)
 // ====================================================================================

@@ -218,6 +218,19 @@ int mjlab_masked_reset(const mjlab_model_t* m, const mjlab_data_t* d, const floa
   return 0;
 }
 
+int mjlab_interval_push(const mjlab_model_t* m, const mjlab_data_t* d, float* time_left, const float* rnd7, float dt,
+                        float interval_lo, float interval_hi, const mjlab_push_range_t* range, int root_is_free, void* stream) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!time_left || !rnd7 || !range) return fail(-16, "interval_push: null argument");
+  if (!root_is_free || m->size.nq < 7 || m->size.nv < 6) return fail(-17, "interval_push: the first joint must be a free joint");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_interval_push, dim3((m->size.nworld + 63) / 64), dim3(64), 0, st, *m, *d, time_left, rnd7, dt, interval_lo, interval_hi, *range);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "k_interval_push launch failed");
+  return 0;
+}
+
 int mjlab_selftest(void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int nblk = 16, n = nblk * 64;

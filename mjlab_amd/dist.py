@@ -69,19 +69,28 @@ def device_index(info: ShardInfo) -> int:
 _GATHER_BUF: dict = {}  # receive buffers, reused across control steps (the result is valid until the next call)
 
 
-def gather_rollout(info: ShardInfo, rows: torch.Tensor) -> torch.Tensor:
-  """All-gather per-env rows ``(envs_per_rank, k)`` into ``(global_envs, k)`` in rank order.
+def gather_rollout(info: ShardInfo, rows: torch.Tensor, dst: int = 0, to_all: bool = False) -> torch.Tensor | None:
+  """Per-env rows ``(envs_per_rank, k)`` of every rank -> ``(global_envs, k)`` in rank order ON THE
+  LEARNER (rank ``dst``); the other ranks get None.  ``to_all=True`` delivers it to every rank
+  (all-gather: replicated learners).
 
-  One fused buffer per control step ([obs | reward | done] columns) instead of one
-  collective per tensor: xGMI is point-to-point, few larger transfers beat many small ones.
+  One fused buffer per control step ([obs | reward | done] columns) instead of one collective per
+  tensor.  The gather is what north_star asks for ("all-gather back to the learner"): each rank
+  sends its shard once, straight to the learner over its own xGMI link -- 1/world_size of the bytes
+  an all-gather moves, and no ring through links that are per-pair anyway.
   """
   if info.world_size == 1:
     return rows
+  rows = rows.contiguous()
   key = (rows.shape[1], rows.dtype, rows.device)
-  out = _GATHER_BUF.get(key)
-  if out is None or out.shape[0] != info.global_envs:
+  need = to_all or info.rank == dst
+  out = _GATHER_BUF.get(key) if need else None
+  if need and (out is None or out.shape[0] != info.global_envs):
     out = _GATHER_BUF[key] = torch.empty((info.global_envs, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-  dist.all_gather_into_tensor(out, rows.contiguous())
+  if to_all:
+    dist.all_gather_into_tensor(out, rows)
+    return out
+  dist.gather(rows, list(out.chunk(info.world_size)) if info.rank == dst else None, dst=dst)
   return out
 
 
@@ -109,6 +118,15 @@ def max_over_ranks(value: float, device) -> float:
   t = torch.tensor([value], dtype=torch.float64, device=device)
   dist.all_reduce(t, op=dist.ReduceOp.MAX)
   return float(t.item())
+
+
+def all_rank_values(value: float, device) -> list[float]:
+  """The same scalar from every rank, in rank order (diagnostics: per-rank step times)."""
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return [value]
+  out = torch.empty((dist.get_world_size(),), dtype=torch.float64, device=device)
+  dist.all_gather_into_tensor(out, torch.tensor([value], dtype=torch.float64, device=device))
+  return [float(v) for v in out.tolist()]
 
 
 def barrier() -> None:

@@ -20,11 +20,28 @@ from .mjcf import JNT_FREE, Model
 from .sim import Simulation
 
 
+class _PushRange(ctypes.Structure):
+  _fields_ = [("lo", ctypes.c_float * 6), ("hi", ctypes.c_float * 6)]
+
+
+# The velocity task's events that touch the physics state or model (reference
+# src/mjlab/tasks/velocity/velocity_env_cfg.py:136-172,219-223 and config/{g1,go1}/flat_env_cfg.py):
+# foot friction U(0.3, 1.2) per env and foot geom at startup, a root-velocity kick every U(1, 3) s,
+# termination on a 70 degree tilt.  (Go1 keeps the base class's +-1.0 m/s kick; G1-flat sets +-0.5.)
+VELOCITY_TASK_EVENTS = {
+  "g1": {"friction_range": (0.3, 1.2), "friction_geoms": r"(left|right)_foot[1-7]_collision$",
+         "push": {"interval_s": (1.0, 3.0), "velocity": {"x": (-0.5, 0.5), "y": (-0.5, 0.5)}}, "bad_orientation_deg": 70.0},
+  "go1": {"friction_range": (0.3, 1.2), "friction_geoms": r"[FR][LR]_foot_collision$",
+          "push": {"interval_s": (1.0, 3.0), "velocity": {"x": (-1.0, 1.0), "y": (-1.0, 1.0)}}, "bad_orientation_deg": 70.0},
+}  # fmt: skip
+
+
 class PhysicsRollout:
   def __init__(self, sim: Simulation, action_scale: np.ndarray | float = 0.25, decimation: int = 4,
                episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0,
                masked_forward: bool = False, fused_reset: bool = True, min_up_z: float | None = None,
-               max_init_terrain_level: int | None = 5) -> None:
+               max_init_terrain_level: int | None = 5, friction_range: tuple[float, float] | None = None,
+               friction_geoms: str | None = None, push: dict | None = None, bad_orientation_deg: float | None = None) -> None:
     m: Model = sim.host_model
     dev = sim.data.qpos.device
     self.sim, self.m, self.decimation = sim, m, decimation
@@ -62,7 +79,34 @@ class PhysicsRollout:
       self.env_origins = torch.tensor(eo, dtype=torch.float32, device=dev)
       if min_up_z is None:
         min_up_z, self.min_height = math.cos(math.radians(70.0)), -1.0e9
+    if bad_orientation_deg is not None and min_up_z is None:
+      # the reference's only state-based termination of the velocity task (bad_orientation, mdp/terminations.py:23-31)
+      min_up_z, self.min_height = math.cos(math.radians(bad_orientation_deg)), -1.0e9
     self.min_up_z = -2.0 if min_up_z is None else float(min_up_z)
+    # startup event: per-env, per-geom friction (randomize_field "abs" on axis 0 of geom_friction)
+    self.friction_geom_ids: np.ndarray | None = None
+    if friction_range is not None:
+      import re
+
+      pat = re.compile(friction_geoms or ".*")
+      gids = np.asarray([g for g, name in enumerate(m.names["geom"]) if name and pat.search(name)], dtype=np.int64)
+      if gids.size == 0:
+        raise ValueError(f"no geom name matches {friction_geoms!r}")
+      sim.expand_model_fields(["geom_friction"])
+      lo, hi = friction_range
+      vals = lo + (hi - lo) * torch.rand((n, gids.size), device=dev, generator=self.gen)
+      sim.model.geom_friction[:, torch.from_numpy(gids).to(dev), 0] = vals
+      sim.create_graph()  # pointers changed (the reference re-captures too: manager_based_rl_env.py:102-104)
+      self.friction_geom_ids = gids
+    # interval event: velocity kicks under a per-env timer (mjlab_interval_push)
+    self.push = None
+    if push is not None and self.has_free:
+      lo_t, hi_t = push["interval_s"]
+      rng6 = _PushRange()
+      for k, key_ in enumerate(("x", "y", "z", "roll", "pitch", "yaw")):
+        rng6.lo[k], rng6.hi[k] = push["velocity"].get(key_, (0.0, 0.0))
+      time_left = lo_t + (hi_t - lo_t) * torch.rand((n,), device=dev, generator=self.gen)
+      self.push = (float(lo_t), float(hi_t), rng6, time_left)
     self._graph: torch.cuda.CUDAGraph | None = None
     self._obs_buf: torch.Tensor | None = None
     # start at random episode phase like the reference (train.py:109-111 init_at_random_ep_len)
@@ -166,6 +210,15 @@ class PhysicsRollout:
       d.qacc_warmstart[:] = torch.where(rm, torch.zeros_like(d.qacc_warmstart), torch.nan_to_num(d.qacc_warmstart))
       self.episode_length.copy_(torch.where(reset, torch.zeros_like(self.episode_length), self.episode_length))
     self.sim.forward(reset if self.masked_forward else None)
+    if self.push is not None:  # interval events come after the reset's forward() (manager_based_rl_env.py:134-137)
+      lo_t, hi_t, rng6, time_left = self.push
+      rnd7 = torch.rand((self.sim.num_envs, 7), device=self.key_qpos.device, generator=self.gen)
+      s = self.sim
+      native.check(
+        s._lib.mjlab_interval_push(ctypes.byref(s._m), ctypes.byref(s._d), time_left.data_ptr(), rnd7.data_ptr(),
+                                   float(self.m.opt.timestep * self.decimation), lo_t, hi_t, ctypes.byref(rng6), 1, s._stream()),
+        "mjlab_interval_push",
+      )
     return reset
 
   def random_action(self) -> torch.Tensor:

@@ -35,8 +35,13 @@ def _worker(rank, world_size, port, out_dir):
   sim.ctrl[:] = model.key_qpos[0][model.jnt_qposadr[jn]] + 0.25 * mine.numpy().astype(np.float64)
   sim.step(4)
   rows = torch.from_numpy(np.concatenate([sim.qpos, sim.qvel], axis=1))
-  gathered = mdist.gather_rollout(info, rows)
-  assert gathered.shape == (8, model.nq + model.nv)
+  gathered = mdist.gather_rollout(info, rows)  # to the learner (rank 0) only
+  assert (gathered is None) == (rank != 0)
+  everywhere = mdist.gather_rollout(info, rows, to_all=True)
+  assert everywhere.shape == (8, model.nq + model.nv)
+  if rank == 0:
+    assert torch.equal(gathered, everywhere)
+  assert mdist.all_rank_values(float(rank), "cpu") == [0.0, 1.0]
   t = mdist.max_over_ranks(float(rank + 1), "cpu")
   assert t == float(world_size)
   mdist.barrier()

@@ -63,6 +63,25 @@ def main(tag: str, scene: str = "g1_velocity_flat") -> None:
   if solve:
     ent["solve_integrate_bytes_per_launch"] = solve[0][3] + solve[0][4]
   ent["all_stage_kernels_bytes_per_step"] = sum(r[3] + r[4] for r in rows)
+  # VALU issue share of the dominant kernel (bench.py roofline.valu_busy): a wave64 VALU instruction occupies
+  # its SIMD16 for 4 cycles; 256 CUs x 4 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines
+  sq = src / "pmc_SQ" / "pmc_counter_collection.csv"
+  if sq.exists():
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(sq)):
+      acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines = []
+    for k, d in sorted(acc.items()):
+      if not k.startswith("k_"):
+        continue
+      mean = {c: sum(v) / len(v) for c, v in d.items()}
+      lines.append(k + "\n" + "\n".join(f"   {c:28s} {v:16.0f}" for c, v in sorted(mean.items())))
+      if "SQ_INSTS_VALU" in mean and mean.get("SQ_BUSY_CYCLES"):
+        busy = 4.0 * mean["SQ_INSTS_VALU"] / (mean["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
+        lines.append(f"   {'valu_busy (4 x INSTS_VALU / (BUSY_CYCLES / 32 x 1024 SIMDs))':28s} {busy:16.3f}")
+        if k.startswith("k_solve") or k.startswith("k_step"):
+          ent["solve_integrate_valu_busy"] = busy
+    (dst / "sq_counters.txt").write_text("\n".join(lines) + "\n")
   traffic[scene] = ent
   tj.write_text(json.dumps(traffic, indent=1) + "\n")
   print(open(dst / "hbm_traffic.csv").read())

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-2 GPU pass: full GPU test suite (no -x, output kept), smoke, bench (task events on / off),
+# rocprofv3 kernel stats + HBM + SQ passes, phase profile.  Usage: gpurun --timeout 1800 -- 'bash tools/gpu_r02.sh <tag>'
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+R=$(pwd)
+timeout 1500 python -m pytest tests -m gpu -q -s -rA > $OUT/gputests.log 2>&1; echo "gputests rc=$?" | tee -a $OUT/status.txt
+grep -E "passed|failed" $OUT/gputests.log | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/status.txt
+timeout 600 python bench.py > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/status.txt
+tail -1 $OUT/bench.log > $OUT/bench.json
+timeout 600 python bench.py --no-task-events --no-cpu-baseline > $OUT/bench_noevents.log 2>&1; tail -1 $OUT/bench_noevents.log > $OUT/bench_noevents.json
+BCMD="python $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- $BCMD > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/status.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o pmc -- $BCMD > $R/$OUT/pmc_$C.log 2>&1); echo "pmc $C rc=$?" | tee -a $OUT/status.txt
+done
+(cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $R/$OUT/pmc_SQ -o pmc -- $BCMD > $R/$OUT/pmc_SQ.log 2>&1); echo "pmc SQ rc=$?" | tee -a $OUT/status.txt
+if [ -f gpurun_prof/libmjlab_amd_prof.so ]; then
+  MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/profile_phases.py > $OUT/phases.log 2>&1; echo "phases rc=$?" | tee -a $OUT/status.txt
+fi
+find $OUT -name "*.db" -delete; find $OUT -name "*.csv" -size +8M -delete
+cat $OUT/status.txt; cat $OUT/bench.json; cat $OUT/bench_noevents.json

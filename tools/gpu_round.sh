@@ -20,6 +20,9 @@ if [ -z "$QUICK" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o pmc -- $BCMD > $R/$OUT/pmc_$C.log 2>&1); echo "pmc $C rc=$?" | tee -a $OUT/status.txt
   done
+  if [ -n "$SQ" ]; then
+    (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $R/$OUT/pmc_SQ -o pmc -- $BCMD > $R/$OUT/pmc_SQ.log 2>&1); echo "pmc SQ rc=$?" | tee -a $OUT/status.txt
+  fi
   if [ -f gpurun_prof/libmjlab_amd_prof.so ]; then
     MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/profile_phases.py > $OUT/phases.log 2>&1; echo "phases rc=$?" | tee -a $OUT/status.txt
   fi
