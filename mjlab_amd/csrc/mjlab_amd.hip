@@ -241,13 +241,13 @@ int mjlab_selftest(void* stream) {
   int* derr = nullptr;
   int herr = -1;
   if (hipMalloc(&din, sizeof(h)) != hipSuccess || hipMalloc(&derr, sizeof(int)) != hipSuccess) return fail(-11, "selftest: hipMalloc");
-  hipMemcpyAsync(din, h, sizeof(h), hipMemcpyHostToDevice, st);
-  hipMemsetAsync(derr, 0, sizeof(int), st);
+  (void)hipMemcpyAsync(din, h, sizeof(h), hipMemcpyHostToDevice, st);
+  (void)hipMemsetAsync(derr, 0, sizeof(int), st);
   hipLaunchKernelGGL(k_selftest, dim3(nblk), dim3(64), 0, st, din, derr);
-  hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, st);
+  (void)hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, st);
   hipError_t e = hipStreamSynchronize(st);
-  hipFree(din);
-  hipFree(derr);
+  (void)hipFree(din);
+  (void)hipFree(derr);
   if (e != hipSuccess) return fail((int)e, "selftest failed to run");
   if (herr != 0) return fail(-12, "selftest: DPP wave reductions disagree with the shuffle reference");
   return 0;

@@ -1,9 +1,12 @@
 """HIP path vs the CPU oracle on seeded inputs, through the Simulation boundary / C ABI.
 
-Tolerances: the device computes in fp32, the oracle in fp64.  State-like outputs
-(qpos, qvel, kinematics) must agree to 1e-5 relative (north_star); quantities that pass
-through the iterative constraint solver (qacc, constraint forces) to 1e-3, because the
-fp32 termination test stops at a slightly different Newton iterate.
+Tolerances: the device computes in fp32, the oracle in fp64; north_star asks for 1e-5 relative.
+Every literal below is the worst relative error measured on the GPU (recorded per assertion in
+gpurun_out/parity_margins.txt by teardown_module; profiles/r02_v1/parity_margins.txt) times 3,
+rounded up to 1 / 2 / 5 x 10^k: kinematics and the mass matrix 1e-6, velocity-stage outputs 2e-6,
+efc_J 1e-6, qacc / qfrc_constraint 1e-5 .. 2e-5 on these seeded states (efc_D / efc_aref keep 1e-4:
+they are functions of penetration / 1 mm, which amplifies a 1e-7 position error 1e3-fold).  The
+distribution over rollout states is gated separately (tests/test_gpu_parity_gate.py).
 """
 
 import sys
@@ -82,18 +85,18 @@ def test_forward_all_fields(name):
   for f in KIN:
     assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 2e-6, f
   for f in VEL:
-    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-5, f
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 2e-06, f
   # constraint rows: same order by construction (pair order, limits first)
   nv = model.nv
   for w in range(sim.num_envs):
     n = int(ora.nefc[w, 0])
     Jg = _np(sim.data.efc_J)[w].reshape(-1, nv)[:n]
-    assert _rel(Jg, ora.efc_J[w].reshape(-1, nv)[:n]) < 1e-5
+    assert _rel(Jg, ora.efc_J[w].reshape(-1, nv)[:n]) < 1e-06
     for f in ("efc_D", "efc_aref", "efc_pos"):
       assert _rel(_np(getattr(sim.data, f))[w, :n], getattr(ora, f)[w, :n]) < 1e-4, f
-  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 1e-4
-  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
-  assert _rel(_np(sim.data.qfrc_constraint), ora.qfrc_constraint) < 1e-3
+  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 2e-05
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 2e-05
+  assert _rel(_np(sim.data.qfrc_constraint), ora.qfrc_constraint) < 1e-05
   assert np.array_equal(_np(sim.data.sensordata), ora.sensordata.astype(np.float32))
 
 
@@ -114,7 +117,7 @@ def test_rollout_state(name):
     nstep, tq, tv = 200, 1e-4, 1e-3
   else:
     sim, ora, model = _pair(name)
-    nstep, tq, tv = 10, 2e-5, 1e-3
+    nstep, tq, tv = 10, 5e-6, 2e-5
   for _ in range(nstep):
     sim.step()
   ora.step(nstep)
@@ -141,7 +144,7 @@ def test_single_world_and_odd_world_counts():
     sim, ora, _ = _pair("go1_velocity_flat", nworld=nworld)
     sim.step()
     ora.step()
-    assert _rel(_np(sim.data.qpos), ora.qpos) < 1e-5
+    assert _rel(_np(sim.data.qpos), ora.qpos) < 1e-06
 
 
 def test_row_capacity_overflow_is_consistent():
@@ -151,7 +154,7 @@ def test_row_capacity_overflow_is_consistent():
   ora.forward()
   assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
   assert _np(sim.data.nefc).max() <= 24
-  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 2e-05
   # ... and both say so (data.overflow, MJLAB_OVF_NJMAX), instead of dropping rows silently
   assert np.array_equal(_np(sim.data.overflow).ravel(), ora.overflow.ravel())
   assert (_np(sim.data.overflow).ravel() & 2).any()
@@ -170,7 +173,7 @@ def test_no_contact_state_and_zero_ctrl():
   sim.step()
   ora.step()
   assert int(_np(sim.data.ncon).max()) == 0
-  assert _rel(_np(sim.data.qvel), ora.qvel) < 1e-5
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 1e-05
   torch.cuda.synchronize()
 
 
@@ -189,8 +192,8 @@ def test_xfrc_and_qfrc_applied():
   ora.qfrc_applied[:] = qf
   sim.forward()
   ora.forward()
-  assert _rel(_np(sim.data.qfrc_smooth), ora.qfrc_smooth) < 1e-5
-  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 1e-4
+  assert _rel(_np(sim.data.qfrc_smooth), ora.qfrc_smooth) < 1e-06
+  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 1e-06
 
 
 def test_expand_model_fields_per_world_friction():
@@ -218,8 +221,8 @@ def test_expand_model_fields_per_world_friction():
   for _ in range(3):
     sim.step()
   ora.step(3)
-  assert _rel(_np(sim.data.qvel), ora.qvel) < 1e-3
-  assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-5
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 5e-06
+  assert _rel(_np(sim.data.qpos), ora.qpos) < 1e-06
   # and friction really matters: a world with different friction diverges from world-shared friction
   sim2, _, _ = _pair("g1_velocity_flat")
   for _ in range(3):
@@ -328,14 +331,14 @@ def test_every_domain_randomization_field_is_honoured_per_world():
   ora.forward()
   assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
   for f in ("xpos", "xipos", "geom_xpos", "site_xpos", "subtree_com", "qM", "qfrc_bias", "qfrc_passive", "qfrc_smooth"):
-    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 2e-5, f
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-06, f
   # different worlds really got different models
   assert float(sim.data.qM[0].sub(sim.data.qM[1]).abs().max()) > 1e-3
   for _ in range(2):
     sim.step()
   ora.step(2)
-  assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-5
-  assert _rel(_np(sim.data.qvel), ora.qvel) < 2e-3
+  assert _rel(_np(sim.data.qpos), ora.qpos) < 1e-06
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 1e-05
   assert sim.data.act.shape == (n, 0)
 
 
@@ -372,14 +375,14 @@ def test_capacity_paths_with_hundreds_of_contacts(njmax):
     assert np.array_equal(_np(sim.data.contact_efc_address)[w, :nc], ora.contact_efc_address[w, :nc])
     assert np.array_equal(_np(sim.data.efc_type)[w, :n], ora.efc_type[w, :n])
     Jg = _np(sim.data.efc_J)[w].reshape(-1, nv)[:n]
-    assert _rel(Jg, ora.efc_J[w].reshape(-1, nv)[:n]) < 1e-5
+    assert _rel(Jg, ora.efc_J[w].reshape(-1, nv)[:n]) < 2e-06
     for f in ("efc_D", "efc_aref", "efc_pos", "efc_margin"):
       assert _rel(_np(getattr(sim.data, f))[w, :n], getattr(ora, f)[w, :n]) < 2e-4, f
   assert np.array_equal(_np(sim.data.sensordata), ora.sensordata.astype(np.float32))
   # the solve itself: both sides stop at the 10-iteration cap on a 300-row problem, so only the
   # quality of the iterate is compared, not the iterate
   assert torch.isfinite(sim.data.qacc).all()
-  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 1e-4
+  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 2e-05
   d = sim.data
   M, qa, qs = d.qM.double(), d.qacc.double(), d.qfrc_smooth.double()
   J = d.efc_J.view(nworld, njmax, nv).double()
@@ -437,13 +440,13 @@ def test_parameter_branches_match_oracle(variant):
   for w in range(nworld):
     n = int(ora.nefc[w, 0])
     for f in ("efc_D", "efc_aref", "efc_pos", "efc_margin"):
-      assert _rel(_np(getattr(sim.data, f))[w, :n], getattr(ora, f)[w, :n]) < 2e-4, (variant, f)
-  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
+      assert _rel(_np(getattr(sim.data, f))[w, :n], getattr(ora, f)[w, :n]) < 2e-05, (variant, f)
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 5e-06
   for _ in range(5):
     sim.step()
   ora.step(5)
-  assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-5
-  assert _rel(_np(sim.data.qvel), ora.qvel) < 2e-3
+  assert _rel(_np(sim.data.qpos), ora.qpos) < 1e-06
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 5e-06
 
 
 MULTI_JOINT_XML = """
@@ -503,16 +506,16 @@ def test_bodies_with_several_joints():
   assert np.array_equal(_np(sim.data.ncon).ravel(), ora.ncon.ravel())
   assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
   for f in KIN:
-    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 2e-6, f
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-06, f
   for f in VEL:
-    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-5, f
-  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 1e-4
-  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-06, f
+  assert _rel(_np(sim.data.qacc_smooth), ora.qacc_smooth) < 5e-06
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 2e-05
   for _ in range(20):
     sim.step()
   ora.step(20)
-  assert _rel(_np(sim.data.qpos), ora.qpos) < 1e-4
-  assert _rel(_np(sim.data.qvel), ora.qvel) < 2e-3
+  assert _rel(_np(sim.data.qpos), ora.qpos) < 5e-06
+  assert _rel(_np(sim.data.qvel), ora.qvel) < 1e-05
 
 
 def test_more_geoms_sites_and_actuators_than_lanes():
@@ -555,8 +558,8 @@ def test_more_geoms_sites_and_actuators_than_lanes():
   for f in ("geom_xpos", "geom_xmat", "site_xpos", "site_xmat"):
     assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 2e-6, f
   for f in ("actuator_force", "qfrc_actuator", "qfrc_smooth"):
-    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-5, f
-  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-3
+    assert _rel(_np(getattr(sim.data, f)), getattr(ora, f)) < 1e-06, f
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 5e-05
 
 
 def test_host_side_guards_and_warnings():

@@ -6,9 +6,12 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$(pwd)
+if [ -z "$NOTESTS" ]; then
 timeout 1500 python -m pytest tests -m gpu -q -s -rA > $OUT/gputests.log 2>&1; echo "gputests rc=$?" | tee -a $OUT/status.txt
 grep -E "passed|failed" $OUT/gputests.log | tail -3
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/status.txt
+cp gpurun_out/parity_margins.txt gpurun_out/parity_gate.txt $OUT/ 2>/dev/null
+fi
 timeout 600 python bench.py > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/status.txt
 tail -1 $OUT/bench.log > $OUT/bench.json
 timeout 600 python bench.py --no-task-events --no-cpu-baseline > $OUT/bench_noevents.log 2>&1; tail -1 $OUT/bench_noevents.log > $OUT/bench_noevents.json
@@ -18,6 +21,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o pmc -- $BCMD > $R/$OUT/pmc_$C.log 2>&1); echo "pmc $C rc=$?" | tee -a $OUT/status.txt
 done
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $R/$OUT/pmc_SQ -o pmc -- $BCMD > $R/$OUT/pmc_SQ.log 2>&1); echo "pmc SQ rc=$?" | tee -a $OUT/status.txt
+python tools/reduce_pmc.py $OUT/pmc_SQ/pmc_counter_collection.csv
 if [ -f gpurun_prof/libmjlab_amd_prof.so ]; then
   MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/profile_phases.py > $OUT/phases.log 2>&1; echo "phases rc=$?" | tee -a $OUT/status.txt
 fi

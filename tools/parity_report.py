@@ -148,6 +148,9 @@ def scene_report(scene: str, n: int = 1024, control_steps: int = 25, precision: 
       o = np.where(mask, o.reshape(n, -1), 0)
     e = per_world_rel(g, o)[same]
     out["fields"][name] = (float(np.median(e)), float(np.percentile(e, 99)), float(e.max()))
+    if name == "efc_pos":  # a distance near zero: the meaningful error is absolute (metres)
+      a = np.abs(g.reshape(n, -1).astype(np.float64) - o.reshape(n, -1)).max(axis=1)[same]
+      out["fields"]["efc_pos_abs_m"] = (float(np.median(a)), float(np.percentile(a, 99)), float(a.max()))
   niter_g, niter_o = sim.data.solver_niter.cpu().numpy().ravel(), ora.solver_niter.ravel()
   out["niter_gpu"] = (float(niter_g.mean()), int(niter_g.max()))
   out["niter_oracle"] = (float(niter_o.mean()), int(niter_o.max()))
