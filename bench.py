@@ -106,6 +106,11 @@ def main() -> None:
   ap.add_argument("--no-task-events", action="store_true",
                   help="leave out the velocity task's events (per-env foot friction, velocity pushes, 70 degree orientation "
                   "termination): round-1 workload (root-height termination, shared model)")
+  ap.add_argument("--fuse", choices=["stage", "presolve", "step"], default="step",
+                  help="launch structure: one kernel per stage / the four pre-solve stages fused / a whole substep per kernel")
+  ap.add_argument("--substeps-per-call", type=int, default=4,
+                  help="physics steps per Simulation.step() call: 1 = the reference's call pattern (ctrl write + step(), 4 times), "
+                  "4 = one step(nsubstep=4) per control step (with --fuse step: one kernel launch for the 4 substeps)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--seed", type=int, default=42)
   args = ap.parse_args()
@@ -120,13 +125,13 @@ def main() -> None:
   torch.cuda.set_device(mdist.device_index(info))
 
   model = robots.load_model(args.scene)
-  sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph, fold_forward=not args.no_fold), model, dev)
+  sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph, fold_forward=not args.no_fold, fuse=args.fuse), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else go1_action_scale(model)
   robot = "g1" if args.scene.startswith("g1") else "go1"
   events = {} if args.no_task_events else VELOCITY_TASK_EVENTS[robot]
   roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info),
                         masked_forward=args.masked_forward, fused_reset=not args.torch_reset,
-                        min_height=0.3 if robot == "g1" else 0.15, **events)
+                        min_height=0.3 if robot == "g1" else 0.15, substeps_per_call=args.substeps_per_call, **events)
   step_graph = not args.no_graph and not args.no_step_graph
   if step_graph:
     roll.capture_graph()
@@ -195,14 +200,35 @@ def main() -> None:
     torch.cuda.synchronize()
     comm_ms = mdist.max_over_ranks((time.perf_counter() - t2) / 20 * 1e3, dev)
 
-  # ---- dominant-kernel timing with HIP events on the launch stream (instrumented pass:
-  # same workload, stages launched one by one so the solve kernel can be bracketed)
-  solve_ms, stage_ms = None, {}
+  # ---- dominant-kernel timing with HIP events on the launch stream.  With --fuse step the dominant
+  # kernel is k_substep<NVP, true>: `substeps_per_call` whole physics steps of every world per launch; it is
+  # bracketed here launch by launch on the same rollout (states keep evolving, resets included).  The
+  # per-stage figures come from a second pass that runs the stage kernels one by one (informational).
+  solve_ms, stage_ms, dom_ms, dom_name, dom_sub = None, {}, None, None, 1
   if info.rank == 0:
+    reps = max(5, min(args.steps, 25))
+    if args.fuse == "step":
+      acc, nl = 0.0, 0
+      sim_graph = sim.use_graph
+      sim.use_graph = False
+      for _ in range(reps):
+        sim.data.ctrl[:] = roll.default_joint + roll.random_action() * roll.action_scale
+        evs = []
+        for _ in range(roll.decimation // roll.substeps_per_call):
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record()
+          sim.step(roll.substeps_per_call)
+          e1.record()
+          evs.append((e0, e1))
+        torch.cuda.synchronize()
+        acc += sum(e0.elapsed_time(e1) for e0, e1 in evs)
+        nl += len(evs)
+      sim.use_graph = sim_graph
+      dom_ms, dom_sub = acc / nl, roll.substeps_per_call
+      dom_name = f"k_substep<{min(x for x in (8, 16, 20, 24, 32, 36, 40, 48, 64) if x >= model.nv)}, true>"
     stages = [("position", 1), ("collision", 2), ("velocity", 4), ("constraint", 8), ("solve_integrate", 48)]
     acc = {k: 0.0 for k, _ in stages}
     nlaunch = 0
-    reps = max(5, min(args.steps, 25))
     for _ in range(reps):
       sim.data.ctrl[:] = roll.default_joint + roll.random_action() * roll.action_scale
       for _ in range(roll.decimation):
@@ -219,6 +245,8 @@ def main() -> None:
         nlaunch += 1
     stage_ms = {k: v / nlaunch for k, v in acc.items()}
     solve_ms = stage_ms["solve_integrate"]
+    if dom_ms is None:
+      dom_ms, dom_name = solve_ms, "k_solve_integrate"
 
   if info.rank == 0:
     n_env = args.envs_per_gpu * info.world_size
@@ -229,16 +257,18 @@ def main() -> None:
     if tfile.exists():
       try:
         ent = json.loads(tfile.read_text()).get(args.scene, {})
-        traffic = ent.get("solve_integrate_bytes_per_launch")
-        valu_busy = ent.get("solve_integrate_valu_busy")
+        key = "substep" if args.fuse == "step" else "solve_integrate"
+        traffic = ent.get(key + "_bytes_per_launch")
+        valu_busy = ent.get(key + "_valu_busy")
       except Exception:  # noqa: BLE001
         traffic = None
     roof = None
-    if algo and solve_ms:
-      achieved = algo * args.envs_per_gpu / (solve_ms * 1e-3) / 1e9
+    if algo and dom_ms:
+      achieved = algo * dom_sub * args.envs_per_gpu / (dom_ms * 1e-3) / 1e9
       roof = {
         "bound": "hbm",
-        "kernel": "k_solve_integrate",
+        "kernel": dom_name,
+        "physics_steps_per_launch": dom_sub,
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -247,8 +277,8 @@ def main() -> None:
         # the bound that matters here (the HBM fraction is ~2 % by construction): share of the chip's VALU issue
         # cycles the dominant kernel uses, from rocprofv3 SQ counters of the committed profile (tools/collect_profile.py)
         "valu_busy": valu_busy,
-        "algorithmic_bytes_per_launch": algo * args.envs_per_gpu,
-        "kernel_ms": solve_ms,
+        "algorithmic_bytes_per_launch": algo * dom_sub * args.envs_per_gpu,
+        "kernel_ms": dom_ms,
         "stage_ms": stage_ms,
         "note": "latency/LDS-bound by construction (SURVEY.md 8d): lower HBM traffic is better",
       }
@@ -279,6 +309,8 @@ def main() -> None:
         "global_envs": n_env,
         "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL action broadcast and obs gather to the learner (rank 0) every control step" if exchange else ""),
         "graph": "one hipGraph per control step" if step_graph else ("per-call step/forward hipGraphs" if sim.use_graph else "none"),
+        "launches": {"stage": "one kernel per stage (5 per substep)", "presolve": "pre-solve stages fused (2 per substep)", "step": "one kernel per substep"}[args.fuse]
+        + (f", {args.substeps_per_call} substeps per Simulation.step() call" if args.substeps_per_call > 1 else ""),
         "forward_after_reset": "reset worlds only (extension)" if args.masked_forward else "all worlds (reference behaviour)",
         "forward_fold": "off" if args.no_fold else "step() after forward() skips the stages that depend on qpos/qvel only where both are unchanged (bit-exact)",
         "termination_and_reset": "torch ops" if args.torch_reset else "one fused launch (mjlab_masked_reset), mask based, no host sync",

@@ -233,7 +233,11 @@ enum {
   /* qacc_warmstart <- qacc is written by the integrator's advance only, so forward() leaves it
    * untouched.  Default (bit clear): written at the end of every constraint solve, forward()
    * included (mj_fwdConstraint: "save result for next step warmstart") */
-  MJLAB_OPT_WARMSTART_AT_ADVANCE = 4
+  MJLAB_OPT_WARMSTART_AT_ADVANCE = 4,
+  /* launch structure (results are bit-identical either way): the four pre-solve stages in one
+   * kernel, or a whole forward() / step() substep in one kernel, instead of one kernel per stage */
+  MJLAB_OPT_FUSE_PRESOLVE = 8,
+  MJLAB_OPT_FUSE_STEP = 16
 };
 
 #define MJLAB_DECL_INT_(name, ncol, count) const int* name;

@@ -45,7 +45,7 @@ class Option(ctypes.Structure):
 
 
 # mjlab_option_t.flags (include/mjlab_fields.h)
-OPT_FOLD_FORWARD, OPT_LITERAL_TERMINATION, OPT_WARMSTART_AT_ADVANCE = 1, 2, 4
+OPT_FOLD_FORWARD, OPT_LITERAL_TERMINATION, OPT_WARMSTART_AT_ADVANCE, OPT_FUSE_PRESOLVE, OPT_FUSE_STEP = 1, 2, 4, 8, 16
 # mjlab_data_t.overflow bits
 OVF_NCONMAX, OVF_NJMAX, OVF_TCAND = 1, 2, 4
 

@@ -83,6 +83,67 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #include "extras.h"  // fused entity read-back, masked reset, field tiling, self-test
 
 // ====================================================================================
+// Fused launches (MJLAB_OPT_FUSE_PRESOLVE / MJLAB_OPT_FUSE_STEP): the same stage bodies back to back
+// in one kernel, one world per wave as before.  No kernel boundary between the stages means a fast
+// world runs ahead instead of waiting for the slowest wave of every stage, and waves of one SIMD
+// drift into different phases (memory-bound prologues of one overlap the arithmetic of another).
+// The stages still hand their results over through the public mjData arrays (written anyway);
+// __syncthreads() between stages orders those global writes for the wave's other lanes and
+// separates the LDS lifetimes (every stage lays out the dynamic LDS block for itself).
+// ====================================================================================
+// Every stage of a fused kernel gets its arguments through FUSED_ARGS: the world / lane indices and
+// the address of the two argument structs are made opaque right before the stage.  Without that the
+// optimiser sees one long function (or, with several substeps, one loop body), hoists model constants
+// and addresses of LATER stages to the top and keeps them alive -- spilled -- across everything in
+// between (the multi-substep kernel: 405 spilled VGPRs, 2x slower than separate launches).  The two
+// structs are the first two kernel arguments (kernarg offsets 0 and sizeof(Model), 8-byte aligned);
+// reading them through the laundered kernarg pointer keeps the loads scalar.
+#define FUSED_ARGS                                                                                                   \
+  int w = blockIdx.x, lane = threadIdx.x;                                                                            \
+  unsigned long long ka_ = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();                               \
+  asm volatile("" : "+s"(w), "+v"(lane), "+s"(ka_));                                                                 \
+  const Model& m = *(const Model*)(const __attribute__((address_space(4))) Model*)(kptr_t)ka_;                       \
+  const Data& d = *(const Data*)(const __attribute__((address_space(4))) Data*)((kptr_t)ka_ + sizeof(Model))
+typedef const __attribute__((address_space(4))) char* kptr_t;
+static_assert(sizeof(Model) % 8 == 0 && alignof(Data) == 8, "kernarg layout assumed by FUSED_ARGS");
+
+__device__ __forceinline__ void fused_presolve(const int flags, float* smem) {
+  bool reuse;
+  { FUSED_ARGS; reuse = stage_position(m, d, w, lane, flags, smem); }
+  __syncthreads();
+  if (!reuse) {
+    { FUSED_ARGS; stage_collision(m, d, w, lane, flags, smem); }
+    __syncthreads();
+  }
+  { FUSED_ARGS; stage_velocity(m, d, w, lane, flags, smem); }
+  __syncthreads();
+  if (!reuse) {
+    { FUSED_ARGS; stage_constraint(m, d, w, lane, flags, smem); }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(64, 4) void k_presolve(const Model m_, const Data d_, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((flags & FLAG_MASK) && !d_.world_mask[blockIdx.x]) return;
+  fused_presolve(flags, smem);
+}
+// nsub physics steps of this world back to back (nsub > 1: mjlab_step's nsubstep; ctrl / qfrc_applied /
+// xfrc_applied are the same for all of them, as in the reference's decimation loop,
+// envs/manager_based_rl_env.py:109-114, where the action is fixed during a control step).
+// INTEGRATE = false is forward() (one pass, no integration); the two get different kernel names in profiles.
+template <int NVP, bool INTEGRATE>
+__global__ __launch_bounds__(64, 4) void k_substep(const Model m_, const Data d_, const int flags, const int nsub) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((flags & FLAG_MASK) && !d_.world_mask[blockIdx.x]) return;
+  for (int s = 0; s < nsub; ++s) {
+    const int f = s == 0 ? flags : (flags & ~FLAG_FOLD);
+    fused_presolve(f, smem);
+    { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 1, INTEGRATE ? 1 : 0, f, smem); }
+    __syncthreads();
+  }
+}
+
+// ====================================================================================
 // C ABI
 // ====================================================================================
 static thread_local char g_err[512] = "";
@@ -151,10 +212,44 @@ static int launch_solve(const mjlab_model_t* m, const mjlab_data_t* d, int do_so
   return 0;
 }
 
+static int max4(int a, int b, int c, int e) { return (a > b ? a : b) > (c > e ? c : e) ? (a > b ? a : b) : (c > e ? c : e); }
+static int presolve_lds_floats(const mjlab_sizes_t& s) {
+  return max4(position_lds_floats(s), collision_lds_floats(s), velocity_lds_floats(s), constraint_lds_floats(s));
+}
+static int launch_substep(const mjlab_model_t* m, const mjlab_data_t* d, int do_integrate, int flags, int nsub, hipStream_t st) {
+#define SUBSTEP_(N) do { if (do_integrate) LAUNCH((k_substep<N, true>), lds, *m, *d, flags, nsub); else LAUNCH((k_substep<N, false>), lds, *m, *d, flags, 1); } while (0)
+  const int a = presolve_lds_floats(m->size), b = solve_lds_floats(m->size), lds = a > b ? a : b;
+  switch (solve_nvp(m->size.nv)) {
+    case 8: SUBSTEP_(8); break;
+    case 16: SUBSTEP_(16); break;
+    case 20: SUBSTEP_(20); break;
+    case 24: SUBSTEP_(24); break;
+    case 32: SUBSTEP_(32); break;
+    case 36: SUBSTEP_(36); break;
+    case 40: SUBSTEP_(40); break;
+    case 48: SUBSTEP_(48); break;
+    case 64: SUBSTEP_(64); break;
+    default: return fail(-3, "nv must be in [1, 64]");
+  }
+  return 0;
+}
+
 static int forward_stages_impl(const mjlab_model_t* m, const mjlab_data_t* d, int stages, int flags, void* stream) {
   int rc = check_model(m);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  const int all = MJLAB_STAGE_FORWARD;
+  if ((stages & all) == all && (m->opt.flags & MJLAB_OPT_FUSE_STEP)) {  // a whole forward() / step() as ONE launch
+    rc = launch_substep(m, d, (stages & MJLAB_STAGE_INTEGRATE) != 0, flags, 1, st);
+    if (rc) return rc;
+    if (flags & FLAG_SNAPSHOT) LAUNCH(k_fold_snapshot, 0, *m, *d, flags);
+    return 0;
+  }
+  const int pre = MJLAB_STAGE_POSITION | MJLAB_STAGE_COLLISION | MJLAB_STAGE_VELOCITY | MJLAB_STAGE_CONSTRAINT;
+  if ((stages & pre) == pre && (m->opt.flags & MJLAB_OPT_FUSE_PRESOLVE)) {  // the four pre-solve stages as one launch
+    LAUNCH(k_presolve, presolve_lds_floats(m->size), *m, *d, flags);
+    stages &= ~pre;
+  }
   if (stages & MJLAB_STAGE_POSITION) LAUNCH(k_position, position_lds_floats(m->size), *m, *d, flags);
   if (stages & MJLAB_STAGE_COLLISION) LAUNCH(k_collision, collision_lds_floats(m->size), *m, *d, flags);
   if (stages & MJLAB_STAGE_VELOCITY) LAUNCH(k_velocity, velocity_lds_floats(m->size), *m, *d, flags);
@@ -185,6 +280,11 @@ int mjlab_forward(const mjlab_model_t* m, const mjlab_data_t* d, void* stream) {
 
 int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void* stream) {
   if (nsubstep < 1) return fail(-8, "nsubstep must be >= 1");
+  if (nsubstep > 1 && (m->opt.flags & MJLAB_OPT_FUSE_STEP)) {  // all substeps in one launch
+    int rc = check_model(m);
+    if (rc) return rc;
+    return launch_substep(m, d, 1, (m->opt.flags & MJLAB_OPT_FOLD_FORWARD) ? FLAG_FOLD : 0, nsubstep, (hipStream_t)stream);
+  }
   for (int k = 0; k < nsubstep; ++k) {
     int rc = forward_stages_impl(m, d, MJLAB_STAGE_STEP, (k == 0 && (m->opt.flags & MJLAB_OPT_FOLD_FORWARD)) ? FLAG_FOLD : 0, stream);
     if (rc) return rc;

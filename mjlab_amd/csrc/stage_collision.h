@@ -303,11 +303,7 @@ __device__ __forceinline__ void emit_contacts(const Model& m, const Data& d, int
   }
 }
 
-__global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d, const int flags) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int w = blockIdx.x, lane = threadIdx.x;
-  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
-  if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
+__device__ __forceinline__ void stage_collision(const Model& m, const Data& d, const int w, const int lane, const int flags, float* smem) {
   const int ng = m.size.ngeom, npair = m.size.npair;
   const int g0 = m.size.geom_lds0, nl = ng - g0;  // geoms [g0, ng) are staged; s_gx / s_gm are indexed by g - g0
   float* s_gx = smem;
@@ -538,3 +534,10 @@ __global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d
   PROF_FLUSH(d.profile + (size_t)w * 64 + 32);
 }
 
+__global__ __launch_bounds__(64, 4) void k_collision(const Model m, const Data d, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
+  stage_collision(m, d, w, lane, flags, smem);
+}

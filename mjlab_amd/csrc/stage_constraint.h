@@ -61,11 +61,7 @@ __host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) {
   return s.nconmax + 2 * constraint_nlim(s) + CC_NROWS * 64;
 }
 
-__global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data d, const int flags) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int w = blockIdx.x, lane = threadIdx.x;
-  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
-  if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
+__device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, const int w, const int lane, const int flags, float* smem) {
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ncm = m.size.nconmax, njm = m.size.njmax;
   const int nlim = constraint_nlim(m.size);
   PROF_INIT();
@@ -309,3 +305,10 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
   PROF_FLUSH(d.profile + (size_t)w * 64 + 40);
 }
 
+__global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data d, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
+  stage_constraint(m, d, w, lane, flags, smem);
+}

@@ -23,10 +23,11 @@ __host__ __device__ inline int position_lds_floats(const mjlab_sizes_t& s) {
   return persistent + (kin > mat ? kin : mat);
 }
 
-__global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d, const int flags) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int w = blockIdx.x, lane = threadIdx.x;
-  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+// Stage bodies are device functions of (world, lane): the per-stage kernels below are thin wrappers,
+// and k_presolve / k_substep (mjlab_amd.hip) run several of them back to back in one launch.
+// Returns true when FLAG_FOLD applies to this world (nothing was recomputed: the collision and
+// constraint-build stages are to be skipped too).
+__device__ __forceinline__ bool stage_position(const Model& m, const Data& d, const int w, const int lane, const int flags, float* smem) {
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ng = m.size.ngeom, ns = m.size.nsite;
   if (flags & FLAG_FOLD) {
     // The reference calls forward() on all worlds after resets and then, with a new action in
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d,
       reuse = __ballot(diff) == 0ull;
     }
     if (lane == 0) d.fold_reuse[w] = reuse;
-    if (reuse) return;
+    if (reuse) return true;
   }
   float* s_sub = smem;
   float* s_cinert = s_sub + 3 * nb;
@@ -446,5 +447,12 @@ __global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d,
   dense_lds_to_global(d.qM + (size_t)w * nv * nv, s_M, nv, ld, lane, false);
   PROF_MARK(7);
   PROF_FLUSH(d.profile + (size_t)w * 64 + 16);
+  return false;
 }
 
+__global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  (void)stage_position(m, d, w, lane, flags, smem);
+}

@@ -339,11 +339,9 @@ __device__ __forceinline__ float grad_noise(float ulps, float scale, bool own, f
 }
 
 template <int NVP>
-__global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate, const int flags) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const int w, const int lane, const int do_solve, const int do_integrate, const int flags,
+                                            float* smem) {
   constexpr int NB = CholCfg<NVP>::NB, ld = CholCfg<NVP>::LD;
-  const int w = blockIdx.x, lane = threadIdx.x;
-  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
   const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
   SolveCtx<NVP> c;
   c.s_H = smem;
@@ -624,6 +622,14 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
   }
   if (do_integrate && lane == 0) d.fold_valid[w] = 0;  // the state moved on
   PROF_FLUSH(d.profile + (size_t)w * 64);
+}
+
+template <int NVP>
+__global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  stage_solve<NVP>(m, d, w, lane, do_solve, do_integrate, flags, smem);
 }
 
 // forward(): remember the qpos / qvel the pass was computed from (see FLAG_FOLD in k_position)

@@ -50,10 +50,7 @@ __device__ __forceinline__ void chain_accum(unsigned long long mk, const float* 
   }
 }
 
-__global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d, const int flags) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int w = blockIdx.x, lane = threadIdx.x;
-  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+__device__ __forceinline__ void stage_velocity(const Model& m, const Data& d, const int w, const int lane, const int flags, float* smem) {
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nu = m.size.nu;
   float* s_qvel = smem;
   float* s_qact = s_qvel + nv;
@@ -205,3 +202,9 @@ __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d,
   PROF_FLUSH(d.profile + (size_t)w * 64 + 24);
 }
 
+__global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  stage_velocity(m, d, w, lane, flags, smem);
+}

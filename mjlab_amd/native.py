@@ -31,7 +31,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB_PATH
   hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
   cmd = [
-    hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
+    hipcc, "-O3", "-std=c++17", "-ffp-contract=on", "--offload-arch=gfx950", "-shared", "-fPIC",
     "-o", str(LIB_PATH), *[str(s) for s in SOURCES],
   ]  # fmt: skip
   if verbose:

@@ -41,10 +41,15 @@ class PhysicsRollout:
                episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0,
                masked_forward: bool = False, fused_reset: bool = True, min_up_z: float | None = None,
                max_init_terrain_level: int | None = 5, friction_range: tuple[float, float] | None = None,
-               friction_geoms: str | None = None, push: dict | None = None, bad_orientation_deg: float | None = None) -> None:
+               friction_geoms: str | None = None, push: dict | None = None, bad_orientation_deg: float | None = None,
+               substeps_per_call: int = 1) -> None:
     m: Model = sim.host_model
     dev = sim.data.qpos.device
     self.sim, self.m, self.decimation = sim, m, decimation
+    # 1 = the reference's call pattern (write ctrl, sim.step(), `decimation` times); `decimation` = one
+    # sim.step(nsubstep=decimation) call: the action is fixed during a control step, so the results are the same
+    assert decimation % substeps_per_call == 0
+    self.substeps_per_call = substeps_per_call
     self.gen = torch.Generator(device=dev)
     self.gen.manual_seed(seed)
     self.key_qpos = torch.tensor(m.key_qpos[key] if m.nkey else m.qpos0, dtype=torch.float32, device=dev)
@@ -179,9 +184,9 @@ class PhysicsRollout:
   def _step_eager(self, action: torch.Tensor) -> torch.Tensor:
     d = self.sim.data
     target = self.default_joint + action * self.action_scale
-    for _ in range(self.decimation):
+    for _ in range(self.decimation // self.substeps_per_call):
       d.ctrl[:] = target
-      self.sim.step()
+      self.sim.step(self.substeps_per_call)
     if self.fused_reset:
       rnd = torch.rand((self.sim.num_envs, 3), device=self.key_qpos.device, generator=self.gen)
       s = self.sim

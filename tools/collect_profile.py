@@ -58,10 +58,13 @@ def main(tag: str, scene: str = "g1_velocity_flat") -> None:
   traffic = json.loads(tj.read_text()) if tj.exists() else {}
   ent = {"source": f"profiles/{tag}/hbm_traffic.csv"}
   for r in rows:
-    ent[r[0].split("<")[0] + "_bytes_per_launch"] = r[3] + r[4]
-  solve = [r for r in rows if r[0].startswith("k_solve") or r[0].startswith("k_step")]
+    ent[r[0].replace("<", "_").replace(">", "").replace(", ", "_") + "_bytes_per_launch"] = r[3] + r[4]
+  solve = [r for r in rows if r[0].startswith("k_solve")]
   if solve:
     ent["solve_integrate_bytes_per_launch"] = solve[0][3] + solve[0][4]
+  sub = [r for r in rows if r[0].startswith("k_substep") and "true" in r[0]]  # the stepping launches (forward() is <.., false>)
+  if sub:
+    ent["substep_bytes_per_launch"] = sub[0][3] + sub[0][4]
   ent["all_stage_kernels_bytes_per_step"] = sum(r[3] + r[4] for r in rows)
   # VALU issue share of the dominant kernel (bench.py roofline.valu_busy): a wave64 VALU instruction occupies
   # its SIMD16 for 4 cycles; 256 CUs x 4 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines
@@ -79,8 +82,10 @@ def main(tag: str, scene: str = "g1_velocity_flat") -> None:
       if "SQ_INSTS_VALU" in mean and mean.get("SQ_BUSY_CYCLES"):
         busy = 4.0 * mean["SQ_INSTS_VALU"] / (mean["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)
         lines.append(f"   {'valu_busy (4 x INSTS_VALU / (BUSY_CYCLES / 32 x 1024 SIMDs))':28s} {busy:16.3f}")
-        if k.startswith("k_solve") or k.startswith("k_step"):
+        if k.startswith("k_solve"):
           ent["solve_integrate_valu_busy"] = busy
+        if k.startswith("k_substep") and "true" in k:
+          ent["substep_valu_busy"] = busy
     (dst / "sq_counters.txt").write_text("\n".join(lines) + "\n")
   traffic[scene] = ent
   tj.write_text(json.dumps(traffic, indent=1) + "\n")

@@ -1,6 +1,6 @@
 """Per-phase shader-clock breakdown of the solve kernel (GPU box).
 
-Build first (in the dev container):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMJLAB_PROFILE \
+Build first (in the dev container):  hipcc -O3 -std=c++17 -ffp-contract=on --offload-arch=gfx950 -DMJLAB_PROFILE \
     -shared -fPIC -o gpurun_prof/libmjlab_amd_prof.so mjlab_amd/csrc/mjlab_amd.hip
 Run: MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so python tools/profile_phases.py
 """
@@ -22,7 +22,7 @@ NAMES = ["M load+factor+qLD", "qacc_smooth solve", "warmstart", "init hessian pa
 
 model = robots.load_model(os.environ.get("SCENE", "g1_velocity_flat"))
 NW = int(os.environ.get("NWORLD", "4096"))  # 256 = one wave per CU: pure single-wave latency
-sim = Simulation(NW, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
+sim = Simulation(NW, SimulationCfg(njmax=300, use_graph=False, fuse=os.environ.get("FUSE", "stage")), model, "cuda:0")
 roll = PhysicsRollout(sim, action_scale=g1_action_scale(model), seed=42)
 for _ in range(40):
   roll.step(roll.random_action())
