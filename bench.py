@@ -111,6 +111,9 @@ def main() -> None:
   ap.add_argument("--substeps-per-call", type=int, default=4,
                   help="physics steps per Simulation.step() call: 1 = the reference's call pattern (ctrl write + step(), 4 times), "
                   "4 = one step(nsubstep=4) per control step (with --fuse step: one kernel launch for the 4 substeps)")
+  ap.add_argument("--no-control-kernel", action="store_true",
+                  help="separate library calls per phase of a control step (step, masked reset, forward, push) instead of one "
+                  "mjlab_control_step launch (bit-identical results)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--seed", type=int, default=42)
   args = ap.parse_args()
@@ -131,7 +134,8 @@ def main() -> None:
   events = {} if args.no_task_events else VELOCITY_TASK_EVENTS[robot]
   roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info),
                         masked_forward=args.masked_forward, fused_reset=not args.torch_reset,
-                        min_height=0.3 if robot == "g1" else 0.15, substeps_per_call=args.substeps_per_call, **events)
+                        min_height=0.3 if robot == "g1" else 0.15, substeps_per_call=args.substeps_per_call,
+                        control_kernel=not args.no_control_kernel and args.fuse == "step" and not args.torch_reset, **events)
   step_graph = not args.no_graph and not args.no_step_graph
   if step_graph:
     roll.capture_graph()
@@ -207,7 +211,24 @@ def main() -> None:
   solve_ms, stage_ms, dom_ms, dom_name, dom_sub = None, {}, None, None, 1
   if info.rank == 0:
     reps = max(5, min(args.steps, 25))
-    if args.fuse == "step":
+    if roll.control_kernel:
+      acc = 0.0
+      g, roll._graph = roll._graph, None  # eager launches for the bracketed pass
+      for _ in range(reps):
+        a = roll.random_action()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rnd_warm = torch.rand((4,), device=dev, generator=roll.gen)  # noqa: F841  (keeps the RNG launch out of the bracket below)
+        e0.record()
+        roll._step_eager(a)
+        e1.record()
+        torch.cuda.synchronize()
+        acc += e0.elapsed_time(e1)
+      roll._graph = g
+      # the bracket holds torch.rand (one small launch) + the control-step kernel; the kernel's own
+      # duration is what rocprofv3 reports (profiles/<tag>/kernel_stats.csv)
+      dom_ms, dom_sub = acc / reps, roll.decimation + 1
+      dom_name = f"k_control_step<{min(x for x in (8, 16, 20, 24, 32, 36, 40, 48, 64) if x >= model.nv)}>"
+    elif args.fuse == "step":
       acc, nl = 0.0, 0
       sim_graph = sim.use_graph
       sim.use_graph = False
@@ -310,7 +331,8 @@ def main() -> None:
         "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL action broadcast and obs gather to the learner (rank 0) every control step" if exchange else ""),
         "graph": "one hipGraph per control step" if step_graph else ("per-call step/forward hipGraphs" if sim.use_graph else "none"),
         "launches": {"stage": "one kernel per stage (5 per substep)", "presolve": "pre-solve stages fused (2 per substep)", "step": "one kernel per substep"}[args.fuse]
-        + (f", {args.substeps_per_call} substeps per Simulation.step() call" if args.substeps_per_call > 1 else ""),
+        + (", whole control step (action, 4 substeps, reset, forward, push) in ONE launch (mjlab_control_step)" if roll.control_kernel
+           else (f", {args.substeps_per_call} substeps per Simulation.step() call" if args.substeps_per_call > 1 else "")),
         "forward_after_reset": "reset worlds only (extension)" if args.masked_forward else "all worlds (reference behaviour)",
         "forward_fold": "off" if args.no_fold else "step() after forward() skips the stages that depend on qpos/qvel only where both are unchanged (bit-exact)",
         "termination_and_reset": "torch ops" if args.torch_reset else "one fused launch (mjlab_masked_reset), mask based, no host sync",

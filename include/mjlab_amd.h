@@ -138,6 +138,35 @@ typedef struct mjlab_push_range { float lo[6], hi[6]; } mjlab_push_range_t;
 int mjlab_interval_push(const mjlab_model_t* m, const mjlab_data_t* d, float* time_left, const float* rnd7, float dt,
                         float interval_lo, float interval_hi, const mjlab_push_range_t* range, int root_is_free, void* stream);
 
+/* Extension: the physics-facing part of one CONTROL step of the
+ * reference's ManagerBasedRlEnv.step (envs/manager_based_rl_env.py:106-139) as ONE launch, one world
+ * per wavefront, no kernel boundary between the phases (a fast world runs ahead instead of waiting
+ * for the slowest world of every kernel):
+ *   action != NULL:   ctrl[w][a] = action_offset[a] + action_scale[a] * action[w][a]   (JointPositionAction,
+ *                     envs/mdp/actions/joint_actions.py; ctrl is left as it is when action == NULL)
+ *   nsubstep x        one physics step (mjlab_step; the reference re-applies the same action before each)
+ *   key_qpos != NULL: termination test + reset, the arguments and semantics of mjlab_masked_reset
+ *   forward_mode:     0 none, 1 forward() on every world (the reference's behaviour whenever any env was
+ *                     reset), 2 on the reset worlds only (mjlab_forward_masked's extension)
+ *   push_time_left != NULL: the interval push, the arguments and semantics of mjlab_interval_push
+ * Results are bit-identical to the same sequence of separate calls. */
+typedef struct mjlab_control {
+  int nsubstep, forward_mode, max_len, pad_;
+  const float* action;        /* (nworld, nu) or NULL */
+  const float* action_offset; /* (nu) */
+  const float* action_scale;  /* (nu) */
+  const float* key_qpos;      /* (nq) or NULL: no termination / reset */
+  const float* rnd3;          /* (nworld, 3) uniforms in [0, 1) */
+  int* episode_length;        /* (nworld) */
+  int* reset_mask;            /* (nworld) out */
+  const float* env_origins;   /* (nworld, 3) or NULL */
+  float* push_time_left;      /* (nworld) or NULL: no push */
+  const float* rnd7;          /* (nworld, 7) */
+  float min_height, min_up_z, push_dt, push_interval_lo, push_interval_hi;
+  mjlab_push_range_t push_range;
+} mjlab_control_t;
+int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, void* stream);
+
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);
 

@@ -249,7 +249,7 @@ struct CholSweep {
   }
   // column J; `cur` holds (or is about to receive) the first batch of row J
   template <int J>
-  static __device__ __forceinline__ void col(float (&a)[NVP], float (&cur)[CB], float (&oth)[CB], lds_f32* A, lds_f32* row, int rowid, float& myinvd) {
+  static __device__ __forceinline__ void col(float (&a)[NVP], float (&cur)[CB], float (&oth)[CB], lds_f32* A, lds_f32* row, lds_f32* s_invd, int rowid) {
     constexpr int NBJ = (J + CB - 1) / CB;
     f32x2 acc = {a[J], 0.f};  // two accumulators, products in pairs (v_pk_fma_f32)
     batches<J, 0>(a, acc, cur, oth, A);
@@ -260,7 +260,7 @@ struct CholSweep {
     a[J] = t;
     const float lu = rowid > J ? t * invd : 0.f;
     row[J] = lu;
-    myinvd = rowid == J ? invd : myinvd;
+    s_invd[J] = invd;  // wave-uniform value, every lane stores it to the same address (one instruction, no select)
     if constexpr (J + 1 < NVP) {
       // after NBJ swaps the first batch of row J+1 sits in `cur` (NBJ even) or `oth` (NBJ odd)
       if constexpr (NBJ == 0) {
@@ -270,8 +270,8 @@ struct CholSweep {
         if constexpr (NBJ % 2 == 0) cur[J] = e; else oth[J] = e;
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (NBJ % 2 == 0) col<J + 1>(a, cur, oth, A, row, rowid, myinvd);
-      else col<J + 1>(a, oth, cur, A, row, rowid, myinvd);
+      if constexpr (NBJ % 2 == 0) col<J + 1>(a, cur, oth, A, row, s_invd, rowid);
+      else col<J + 1>(a, oth, cur, A, row, s_invd, rowid);
     }
   }
 };
@@ -309,7 +309,6 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
     a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
   }
   (void)n;  // rows >= n are identity rows already (chol_pad_rows / chol_pad_diag by the producer)
-  float myinvd = 1.f;
   // Row j of Lu is consumed in batches of CB columns.  The batches are software pipelined
   // through two register buffers: while batch i feeds the FMAs, the reads of batch i+1 --
   // the next batch of the same row, or the first batch of the next row -- are already in
@@ -317,8 +316,7 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
   // row j+1 is requested before column j is written; its one missing entry Lu[j+1][j] is
   // patched in from lane j+1's register.
   float bufA[MJLAB_CB], bufB[MJLAB_CB];
-  CholSweep<NVP, MJLAB_CB>::template col<0>(a, bufA, bufB, A, row, rowid, myinvd);
-  s_invd[rowid] = myinvd;
+  CholSweep<NVP, MJLAB_CB>::template col<0>(a, bufA, bufB, A, row, s_invd, rowid);
 }
 // Solves Lu D Lu^T x = b with the factor in LDS (as left by chol_factor); lane i owns
 // b_i / x_i (lanes >= n must pass 0).  Forward substitution uses row i of Lu, backward

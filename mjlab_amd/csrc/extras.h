@@ -91,10 +91,10 @@ __device__ __forceinline__ float nan_to_num_dev(float x) {
   if (x < -3.402823466e+38f) return -3.402823466e+38f;
   return x;
 }
-__global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d, const float* key_qpos, const float* rnd3,
-                                                      int* episode_length, const int max_len, const float min_height, int* reset_mask,
-                                                      const float* env_origins, const float min_up_z) {
-  const int w = blockIdx.x, lane = threadIdx.x;
+// Returns the (wave-uniform) reset decision of world w.
+__device__ __forceinline__ bool masked_reset_world(const Model& m, const Data& d, const int w, const int lane, const float* key_qpos, const float* rnd3,
+                                                   int* episode_length, const int max_len, const float min_height, int* reset_mask,
+                                                   const float* env_origins, const float min_up_z) {
   const int nq = m.size.nq, nv = m.size.nv;
   const bool has_free = m.size.njnt > 0 && m.jnt_type[0] == MJLAB_JNT_FREE;
   float* qpos = d.qpos + (size_t)w * nq;
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d
   // reference (envs/mdp/terminations.py bad_orientation: projected gravity vs a limit angle)
   const bool fell = has_free && (qpos[2] - org[2] < min_height || 1.f - 2.f * (qpos[4] * qpos[4] + qpos[5] * qpos[5]) < min_up_z);
   const bool reset = __ballot(bad) != 0ull || fell || elen >= max_len;
+  __syncthreads();  // every lane has read qpos[2..5] before any lane overwrites them
   if (reset) {
     for (int i = lane; i < nq; i += 64) {
       float x = key_qpos[i];
@@ -134,14 +135,18 @@ __global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d
     episode_length[w] = reset ? 0 : elen;
     reset_mask[w] = reset ? 1 : 0;
   }
+  return reset;
+}
+__global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d, const float* key_qpos, const float* rnd3,
+                                                      int* episode_length, const int max_len, const float min_height, int* reset_mask,
+                                                      const float* env_origins, const float min_up_z) {
+  (void)masked_reset_world(m, d, blockIdx.x, threadIdx.x, key_qpos, rnd3, episode_length, max_len, min_height, reset_mask, env_origins, min_up_z);
 }
 
 // Interval push (reference envs/mdp/events.py:127-143 push_by_setting_velocity under the event
 // manager's per-env interval timer, managers/event_manager.py:116-138): see include/mjlab_amd.h.
-__global__ __launch_bounds__(64) void k_interval_push(const Model m, const Data d, float* time_left, const float* rnd7, const float dt,
-                                                       const float t_lo, const float t_hi, const mjlab_push_range_t range) {
-  const int w = blockIdx.x * 64 + threadIdx.x;
-  if (w >= m.size.nworld) return;
+__device__ __forceinline__ void interval_push_world(const Model& m, const Data& d, const int w, float* time_left, const float* rnd7, const float dt,
+                                                    const float t_lo, const float t_hi, const mjlab_push_range_t& range) {
   float t = time_left[w] - dt;
   if (t < 1e-6f) {
     const float* r = rnd7 + (size_t)w * 7;
@@ -158,6 +163,12 @@ __global__ __launch_bounds__(64) void k_interval_push(const Model m, const Data 
     for (int k = 0; k < 3; ++k) qvel[3 + k] += wb[k];
   }
   time_left[w] = t;
+}
+__global__ __launch_bounds__(64) void k_interval_push(const Model m, const Data d, float* time_left, const float* rnd7, const float dt,
+                                                       const float t_lo, const float t_hi, const mjlab_push_range_t range) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= m.size.nworld) return;
+  interval_push_world(m, d, w, time_left, rnd7, dt, t_lo, t_hi, range);
 }
 
 // ====================================================================================

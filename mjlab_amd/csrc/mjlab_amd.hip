@@ -141,6 +141,44 @@ __global__ __launch_bounds__(64, 4) void k_substep(const Model m_, const Data d_
     { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 1, INTEGRATE ? 1 : 0, f, smem); }
     __syncthreads();
   }
+  if (!INTEGRATE && (flags & FLAG_SNAPSHOT)) { FUSED_ARGS; fold_snapshot(m, d, w, lane); }
+}
+
+// One CONTROL step of one world per wave (mjlab_control_step): action -> ctrl, nsubstep physics steps,
+// termination test + reset, forward(), interval push -- the physics-facing part of the reference's
+// ManagerBasedRlEnv.step (envs/manager_based_rl_env.py:106-139) without a kernel boundary in between.
+template <int NVP>
+__global__ __launch_bounds__(64, 4) void k_control_step(const Model m_, const Data d_, const mjlab_control_t c, const int fold) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (c.action) {
+    FUSED_ARGS;
+    const int nu = m.size.nu;
+    for (int a = lane; a < nu; a += 64) d.ctrl[(size_t)w * nu + a] = c.action_offset[a] + c.action_scale[a] * c.action[(size_t)w * nu + a];
+    __syncthreads();
+  }
+  for (int s = 0; s < c.nsubstep; ++s) {
+    const int f = (s == 0 && fold) ? FLAG_FOLD : 0;
+    fused_presolve(f, smem);
+    { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 1, 1, f, smem); }
+    __syncthreads();
+  }
+  bool reset = false;
+  if (c.key_qpos) {
+    FUSED_ARGS;
+    reset = masked_reset_world(m, d, w, lane, c.key_qpos, c.rnd3, c.episode_length, c.max_len, c.min_height, c.reset_mask, c.env_origins, c.min_up_z);
+    __syncthreads();
+  }
+  if (c.forward_mode == 1 || (c.forward_mode == 2 && reset)) {
+    fused_presolve(0, smem);
+    { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 1, 0, 0, smem); }
+    __syncthreads();
+    { FUSED_ARGS; fold_snapshot(m, d, w, lane); }
+  }
+  if (c.push_time_left) {
+    FUSED_ARGS;
+    __syncthreads();
+    if (lane == 0) interval_push_world(m, d, w, c.push_time_left, c.rnd7, c.push_dt, c.push_interval_lo, c.push_interval_hi, c.push_range);
+  }
 }
 
 // ====================================================================================
@@ -240,10 +278,7 @@ static int forward_stages_impl(const mjlab_model_t* m, const mjlab_data_t* d, in
   hipStream_t st = (hipStream_t)stream;
   const int all = MJLAB_STAGE_FORWARD;
   if ((stages & all) == all && (m->opt.flags & MJLAB_OPT_FUSE_STEP)) {  // a whole forward() / step() as ONE launch
-    rc = launch_substep(m, d, (stages & MJLAB_STAGE_INTEGRATE) != 0, flags, 1, st);
-    if (rc) return rc;
-    if (flags & FLAG_SNAPSHOT) LAUNCH(k_fold_snapshot, 0, *m, *d, flags);
-    return 0;
+    return launch_substep(m, d, (stages & MJLAB_STAGE_INTEGRATE) != 0, flags, 1, st);  // forward(): the snapshot is taken by the same launch
   }
   const int pre = MJLAB_STAGE_POSITION | MJLAB_STAGE_COLLISION | MJLAB_STAGE_VELOCITY | MJLAB_STAGE_CONSTRAINT;
   if ((stages & pre) == pre && (m->opt.flags & MJLAB_OPT_FUSE_PRESOLVE)) {  // the four pre-solve stages as one launch
@@ -328,6 +363,32 @@ int mjlab_interval_push(const mjlab_model_t* m, const mjlab_data_t* d, float* ti
   hipLaunchKernelGGL(k_interval_push, dim3((m->size.nworld + 63) / 64), dim3(64), 0, st, *m, *d, time_left, rnd7, dt, interval_lo, interval_hi, *range);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, "k_interval_push launch failed");
+  return 0;
+}
+
+int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, void* stream) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!c || c->nsubstep < 0) return fail(-20, "control_step: bad argument");
+  if (c->action && (!c->action_offset || !c->action_scale)) return fail(-20, "control_step: action without offset / scale");
+  if (c->key_qpos && (!c->rnd3 || !c->episode_length || !c->reset_mask)) return fail(-15, "control_step: reset arguments missing");
+  if (c->push_time_left && (!c->rnd7 || m->size.nq < 7 || m->size.nv < 6)) return fail(-17, "control_step: push needs rnd7 and a free root joint");
+  if (c->forward_mode < 0 || c->forward_mode > 2) return fail(-20, "control_step: forward_mode must be 0, 1 or 2");
+  hipStream_t st = (hipStream_t)stream;
+  const int a = presolve_lds_floats(m->size), b = solve_lds_floats(m->size), lds = a > b ? a : b;
+  const int fold = (m->opt.flags & MJLAB_OPT_FOLD_FORWARD) ? 1 : 0;
+  switch (solve_nvp(m->size.nv)) {
+    case 8: LAUNCH(k_control_step<8>, lds, *m, *d, *c, fold); break;
+    case 16: LAUNCH(k_control_step<16>, lds, *m, *d, *c, fold); break;
+    case 20: LAUNCH(k_control_step<20>, lds, *m, *d, *c, fold); break;
+    case 24: LAUNCH(k_control_step<24>, lds, *m, *d, *c, fold); break;
+    case 32: LAUNCH(k_control_step<32>, lds, *m, *d, *c, fold); break;
+    case 36: LAUNCH(k_control_step<36>, lds, *m, *d, *c, fold); break;
+    case 40: LAUNCH(k_control_step<40>, lds, *m, *d, *c, fold); break;
+    case 48: LAUNCH(k_control_step<48>, lds, *m, *d, *c, fold); break;
+    case 64: LAUNCH(k_control_step<64>, lds, *m, *d, *c, fold); break;
+    default: return fail(-3, "nv must be in [1, 64]");
+  }
   return 0;
 }
 

@@ -633,12 +633,15 @@ __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const 
 }
 
 // forward(): remember the qpos / qvel the pass was computed from (see FLAG_FOLD in k_position)
-__global__ __launch_bounds__(64) void k_fold_snapshot(const Model m, const Data d, const int flags) {
-  const int w = blockIdx.x, lane = threadIdx.x;
-  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+__device__ __forceinline__ void fold_snapshot(const Model& m, const Data& d, const int w, const int lane) {
   const int nq = m.size.nq, nv = m.size.nv;
   for (int i = lane; i < nq; i += 64) d.sh_qpos[(size_t)w * nq + i] = d.qpos[(size_t)w * nq + i];
   for (int i = lane; i < nv; i += 64) d.sh_qvel[(size_t)w * nv + i] = d.qvel[(size_t)w * nv + i];
   if (lane == 0) d.fold_valid[w] = 1;
+}
+__global__ __launch_bounds__(64) void k_fold_snapshot(const Model m, const Data d, const int flags) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  fold_snapshot(m, d, w, lane);
 }
 

@@ -74,6 +74,7 @@ def lib() -> ctypes.CDLL:
                                    ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
   L.mjlab_interval_push.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+  L.mjlab_control_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
   L.mjlab_forward_stages.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
   L.mjlab_tile_field.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
   L.mjlab_selftest.argtypes = [ctypes.c_void_p]
@@ -86,7 +87,7 @@ def lib() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = (
   "mjlab_abi_version", "mjlab_last_error", "mjlab_model_layout", "mjlab_data_layout", "mjlab_sizeof_model",
-  "mjlab_sizeof_data", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest",
+  "mjlab_sizeof_data", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest",
 )  # fmt: skip
 
 

@@ -24,6 +24,19 @@ class _PushRange(ctypes.Structure):
   _fields_ = [("lo", ctypes.c_float * 6), ("hi", ctypes.c_float * 6)]
 
 
+class _Control(ctypes.Structure):
+  """mjlab_control_t (include/mjlab_amd.h)."""
+
+  _fields_ = [
+    ("nsubstep", ctypes.c_int), ("forward_mode", ctypes.c_int), ("max_len", ctypes.c_int), ("pad_", ctypes.c_int),
+    ("action", ctypes.c_void_p), ("action_offset", ctypes.c_void_p), ("action_scale", ctypes.c_void_p),
+    ("key_qpos", ctypes.c_void_p), ("rnd3", ctypes.c_void_p), ("episode_length", ctypes.c_void_p), ("reset_mask", ctypes.c_void_p),
+    ("env_origins", ctypes.c_void_p), ("push_time_left", ctypes.c_void_p), ("rnd7", ctypes.c_void_p),
+    ("min_height", ctypes.c_float), ("min_up_z", ctypes.c_float), ("push_dt", ctypes.c_float),
+    ("push_interval_lo", ctypes.c_float), ("push_interval_hi", ctypes.c_float), ("push_range", _PushRange),
+  ]  # fmt: skip
+
+
 # The velocity task's events that touch the physics state or model (reference
 # src/mjlab/tasks/velocity/velocity_env_cfg.py:136-172,219-223 and config/{g1,go1}/flat_env_cfg.py):
 # foot friction U(0.3, 1.2) per env and foot geom at startup, a root-velocity kick every U(1, 3) s,
@@ -42,7 +55,7 @@ class PhysicsRollout:
                masked_forward: bool = False, fused_reset: bool = True, min_up_z: float | None = None,
                max_init_terrain_level: int | None = 5, friction_range: tuple[float, float] | None = None,
                friction_geoms: str | None = None, push: dict | None = None, bad_orientation_deg: float | None = None,
-               substeps_per_call: int = 1) -> None:
+               substeps_per_call: int = 1, control_kernel: bool = False) -> None:
     m: Model = sim.host_model
     dev = sim.data.qpos.device
     self.sim, self.m, self.decimation = sim, m, decimation
@@ -50,6 +63,9 @@ class PhysicsRollout:
     # sim.step(nsubstep=decimation) call: the action is fixed during a control step, so the results are the same
     assert decimation % substeps_per_call == 0
     self.substeps_per_call = substeps_per_call
+    # True: the whole control step (action -> ctrl, substeps, termination + reset, forward, push) is ONE
+    # library launch (mjlab_control_step); bit-identical to the call sequence below
+    self.control_kernel = control_kernel
     self.gen = torch.Generator(device=dev)
     self.gen.manual_seed(seed)
     self.key_qpos = torch.tensor(m.key_qpos[key] if m.nkey else m.qpos0, dtype=torch.float32, device=dev)
@@ -122,11 +138,15 @@ class PhysicsRollout:
   def _sample_reset_qpos(self, n: int) -> torch.Tensor:
     """Keyframe pose with x, y in U(-0.5, 0.5) and yaw in U(-3.14, 3.14)
     (reference src/mjlab/tasks/velocity/velocity_env_cfg.py:136-144)."""
+    return self._reset_qpos_from(torch.rand((n, 3), device=self.key_qpos.device, generator=self.gen))
+
+  def _reset_qpos_from(self, rnd3: torch.Tensor) -> torch.Tensor:
+    """The reset pose as mjlab_masked_reset computes it from 3 uniforms per world."""
+    n = rnd3.shape[0]
     q = self.key_qpos.unsqueeze(0).repeat(n, 1)
     if self.has_free:
-      dev = q.device
-      xy = torch.rand((n, 2), device=dev, generator=self.gen) - 0.5
-      yaw = (torch.rand((n,), device=dev, generator=self.gen) * 2 - 1) * 3.14
+      xy = rnd3[:, 0:2] - 0.5
+      yaw = (rnd3[:, 2] * 2 - 1) * 3.14
       q[:, 0:2] += xy
       if self.env_origins is not None:
         q[:, 0:3] += self.env_origins
@@ -183,15 +203,35 @@ class PhysicsRollout:
 
   def _step_eager(self, action: torch.Tensor) -> torch.Tensor:
     d = self.sim.data
+    s = self.sim
+    n = s.num_envs
+    dev = self.key_qpos.device
+    # one draw per control step for everything below: 3 uniforms per world for the reset pose, 7 for the push
+    rnd = torch.rand((n * 10,), device=dev, generator=self.gen)
+    rnd3, rnd7 = rnd[: 3 * n].view(n, 3), rnd[3 * n :].view(n, 7)
+    dt = float(self.m.opt.timestep * self.decimation)
+    if self.control_kernel and self.fused_reset:
+      c = _Control()
+      c.nsubstep, c.forward_mode, c.max_len = self.decimation, 2 if self.masked_forward else 1, self.max_len
+      self._action_in = action.contiguous()  # kept alive until the launch has been enqueued / captured
+      c.action, c.action_offset, c.action_scale = self._action_in.data_ptr(), self.default_joint.data_ptr(), self.action_scale.data_ptr()
+      c.key_qpos, c.rnd3 = self.key_qpos.data_ptr(), rnd3.data_ptr()
+      c.episode_length, c.reset_mask = self.episode_length.data_ptr(), self._reset_mask.data_ptr()
+      c.env_origins = 0 if self.env_origins is None else self.env_origins.data_ptr()
+      c.min_height, c.min_up_z = float(self.min_height), self.min_up_z
+      if self.push is not None:
+        lo_t, hi_t, rng6, time_left = self.push
+        c.push_time_left, c.rnd7, c.push_dt, c.push_interval_lo, c.push_interval_hi, c.push_range = time_left.data_ptr(), rnd7.data_ptr(), dt, lo_t, hi_t, rng6
+      with torch.cuda.device(dev):
+        native.check(s._lib.mjlab_control_step(ctypes.byref(s._m), ctypes.byref(s._d), ctypes.byref(c), s._stream()), "mjlab_control_step")
+      return self._reset_mask.bool()
     target = self.default_joint + action * self.action_scale
     for _ in range(self.decimation // self.substeps_per_call):
       d.ctrl[:] = target
       self.sim.step(self.substeps_per_call)
     if self.fused_reset:
-      rnd = torch.rand((self.sim.num_envs, 3), device=self.key_qpos.device, generator=self.gen)
-      s = self.sim
       native.check(
-        s._lib.mjlab_masked_reset(ctypes.byref(s._m), ctypes.byref(s._d), self.key_qpos.data_ptr(), rnd.data_ptr(),
+        s._lib.mjlab_masked_reset(ctypes.byref(s._m), ctypes.byref(s._d), self.key_qpos.data_ptr(), rnd3.data_ptr(),
                                   self.episode_length.data_ptr(), self.max_len, float(self.min_height),
                                   self._reset_mask.data_ptr(), 0 if self.env_origins is None else self.env_origins.data_ptr(),
                                   self.min_up_z, s._stream()),
@@ -208,7 +248,7 @@ class PhysicsRollout:
         fell = torch.zeros_like(self.episode_length, dtype=torch.bool)
       bad = ~torch.isfinite(d.qpos).all(dim=1)
       reset = fell | bad | (self.episode_length >= self.max_len)
-      fresh = self._sample_reset_qpos(self.sim.num_envs)
+      fresh = self._reset_qpos_from(rnd3)
       rm = reset.unsqueeze(1)
       d.qpos[:] = torch.where(rm, fresh, torch.nan_to_num(d.qpos))
       d.qvel[:] = torch.where(rm, torch.zeros_like(d.qvel), torch.nan_to_num(d.qvel))
@@ -217,11 +257,9 @@ class PhysicsRollout:
     self.sim.forward(reset if self.masked_forward else None)
     if self.push is not None:  # interval events come after the reset's forward() (manager_based_rl_env.py:134-137)
       lo_t, hi_t, rng6, time_left = self.push
-      rnd7 = torch.rand((self.sim.num_envs, 7), device=self.key_qpos.device, generator=self.gen)
-      s = self.sim
       native.check(
         s._lib.mjlab_interval_push(ctypes.byref(s._m), ctypes.byref(s._d), time_left.data_ptr(), rnd7.data_ptr(),
-                                   float(self.m.opt.timestep * self.decimation), lo_t, hi_t, ctypes.byref(rng6), 1, s._stream()),
+                                   dt, lo_t, hi_t, ctypes.byref(rng6), 1, s._stream()),
         "mjlab_interval_push",
       )
     return reset

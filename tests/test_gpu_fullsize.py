@@ -506,10 +506,15 @@ def test_fused_launch_structures_are_bit_identical(scene):
   model = robots.load_model(scene)
   fields = OUT + ("efc_J", "efc_aref", "efc_D", "nefc", "ncon", "xpos", "cvel", "qM", "sensordata", "qfrc_smooth", "contact_pos")
   out = {}
-  variants = (("stage", 1), ("presolve", 1), ("step", 1), ("stage", 4), ("step", 4))  # (launch structure, substeps per step() call)
+  # (launch structure, substeps per step() call; 0 = the whole control step as one mjlab_control_step launch)
+  variants = (("stage", 1), ("presolve", 1), ("step", 1), ("stage", 4), ("step", 4), ("step", 0))
+  robot = "g1" if scene.startswith("g1") else "go1"
+  from mjlab_amd.rollout import VELOCITY_TASK_EVENTS
+
   for fuse, nsub in variants:
     s = Simulation(256, SimulationCfg(njmax=300, fuse=fuse), model, "cuda:0")
-    roll = PhysicsRollout(s, action_scale=0.25, seed=9, min_height=0.3 if scene.startswith("g1") else 0.15, substeps_per_call=nsub)
+    roll = PhysicsRollout(s, action_scale=0.25, seed=9, min_height=0.3 if scene.startswith("g1") else 0.15, substeps_per_call=max(nsub, 1),
+                          control_kernel=nsub == 0, **VELOCITY_TASK_EVENTS[robot])
     for k in range(12):
       roll.step(roll.random_action())
     s.forward(torch.arange(256, device="cuda") % 3 == 0)  # masked forward through the same launch structure

@@ -62,7 +62,7 @@ def main(tag: str, scene: str = "g1_velocity_flat") -> None:
   solve = [r for r in rows if r[0].startswith("k_solve")]
   if solve:
     ent["solve_integrate_bytes_per_launch"] = solve[0][3] + solve[0][4]
-  sub = [r for r in rows if r[0].startswith("k_substep") and "true" in r[0]]  # the stepping launches (forward() is <.., false>)
+  sub = [r for r in rows if r[0].startswith("k_control_step")] or [r for r in rows if r[0].startswith("k_substep") and "true" in r[0]]  # forward() is <.., false>
   if sub:
     ent["substep_bytes_per_launch"] = sub[0][3] + sub[0][4]
   ent["all_stage_kernels_bytes_per_step"] = sum(r[3] + r[4] for r in rows)
@@ -84,7 +84,7 @@ def main(tag: str, scene: str = "g1_velocity_flat") -> None:
         lines.append(f"   {'valu_busy (4 x INSTS_VALU / (BUSY_CYCLES / 32 x 1024 SIMDs))':28s} {busy:16.3f}")
         if k.startswith("k_solve"):
           ent["solve_integrate_valu_busy"] = busy
-        if k.startswith("k_substep") and "true" in k:
+        if k.startswith("k_control_step") or (k.startswith("k_substep") and "true" in k and "substep_valu_busy" not in ent):
           ent["substep_valu_busy"] = busy
     (dst / "sq_counters.txt").write_text("\n".join(lines) + "\n")
   traffic[scene] = ent

@@ -17,7 +17,8 @@ tail -1 $OUT/bench.log > $OUT/bench.json
 timeout 600 python bench.py --no-task-events --no-cpu-baseline > $OUT/bench_noevents.log 2>&1; tail -1 $OUT/bench_noevents.log > $OUT/bench_noevents.json
 # A/B of the launch structure on this box (same build): one kernel per stage, reference call pattern
 timeout 600 python bench.py --fuse stage --substeps-per-call 1 --no-cpu-baseline > $OUT/bench_stage.log 2>&1; tail -1 $OUT/bench_stage.log > $OUT/bench_stage.json
-timeout 600 python bench.py --fuse step --substeps-per-call 1 --no-cpu-baseline > $OUT/bench_step1.log 2>&1; tail -1 $OUT/bench_step1.log > $OUT/bench_step1.json
+timeout 600 python bench.py --fuse step --substeps-per-call 1 --no-control-kernel --no-cpu-baseline > $OUT/bench_step1.log 2>&1; tail -1 $OUT/bench_step1.log > $OUT/bench_step1.json
+timeout 600 python bench.py --fuse step --substeps-per-call 4 --no-control-kernel --no-cpu-baseline > $OUT/bench_step4.log 2>&1; tail -1 $OUT/bench_step4.log > $OUT/bench_step4.json
 BCMD="python $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- $BCMD > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/status.txt
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -29,4 +30,4 @@ if [ -f gpurun_prof/libmjlab_amd_prof.so ]; then
   MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/profile_phases.py > $OUT/phases.log 2>&1; FUSE=step MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/profile_phases.py > $OUT/phases_fused.log 2>&1; echo "phases rc=$?" | tee -a $OUT/status.txt
 fi
 find $OUT -name "*.db" -delete; find $OUT -name "*.csv" -size +8M -delete
-cat $OUT/status.txt; for f in bench bench_noevents bench_stage bench_step1; do python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1], round(d['value']), d['ms_per_step'], d['roofline']['kernel'], d['roofline']['kernel_ms'], d['roofline']['frac'])" $OUT/$f.json; done
+cat $OUT/status.txt; for f in bench bench_noevents bench_stage bench_step1 bench_step4; do python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1], round(d['value']), d['ms_per_step'], d['roofline']['kernel'], d['roofline']['kernel_ms'], d['roofline']['frac'])" $OUT/$f.json; done
