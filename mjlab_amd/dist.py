@@ -82,6 +82,10 @@ def gather_rollout(info: ShardInfo, rows: torch.Tensor, dst: int = 0, to_all: bo
   if info.world_size == 1:
     return rows
   rows = rows.contiguous()
+  if rows.is_cuda and dist.get_backend() == "gloo":
+    # gloo has no device-side gather: testing path (several ranks sharing one GPU), staged through the host
+    out = gather_rollout(info, rows.cpu(), dst, to_all)
+    return None if out is None else out.to(rows.device)
   key = (rows.shape[1], rows.dtype, rows.device)
   need = to_all or info.rank == dst
   out = _GATHER_BUF.get(key) if need else None
@@ -107,14 +111,19 @@ def scatter_actions(info: ShardInfo, actions_global: torch.Tensor | None, action
     dist.broadcast(buf, src=src)
     out.copy_(buf[info.env_slice])
   else:
-    chunks = list(actions_global.chunk(info.world_size)) if info.rank == src else None
-    dist.scatter(out, chunks, src=src)
+    host = out.cpu() if out.is_cuda else out  # gloo scatters host tensors
+    chunks = [c.cpu().contiguous() for c in actions_global.chunk(info.world_size)] if info.rank == src else None
+    dist.scatter(host, chunks, src=src)
+    if out.is_cuda:
+      out.copy_(host)
   return out
 
 
 def max_over_ranks(value: float, device) -> float:
   if not dist.is_initialized() or dist.get_world_size() == 1:
     return value
+  if dist.get_backend() == "gloo":
+    device = "cpu"
   t = torch.tensor([value], dtype=torch.float64, device=device)
   dist.all_reduce(t, op=dist.ReduceOp.MAX)
   return float(t.item())
@@ -124,6 +133,8 @@ def all_rank_values(value: float, device) -> list[float]:
   """The same scalar from every rank, in rank order (diagnostics: per-rank step times)."""
   if not dist.is_initialized() or dist.get_world_size() == 1:
     return [value]
+  if dist.get_backend() == "gloo":
+    device = "cpu"
   out = torch.empty((dist.get_world_size(),), dtype=torch.float64, device=device)
   dist.all_gather_into_tensor(out, torch.tensor([value], dtype=torch.float64, device=device))
   return [float(v) for v in out.tolist()]

@@ -1,0 +1,33 @@
+"""bench.py's multi-rank path end to end on ONE GPU: two ranks share the device over the gloo backend
+(MJLAB_DIST_BACKEND=gloo; RCCL refuses two ranks on one device), launched exactly as the driver launches
+the scaling run.  Checks the contract line: n_gpus, the exchange on the timed path (action broadcast +
+observation gather to the learner), per-rank diagnostics."""
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_bench_two_ranks_on_one_gpu():
+  env = dict(os.environ, MJLAB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+  port = 29600 + os.getpid() % 300
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--envs-per-gpu", "256"]  # fmt: skip
+  p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert p.returncode == 0, p.stderr[-2000:]
+  line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+  d = json.loads(line)
+  assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 512 and d["scaling"] == "weak"
+  assert d["value"] > 0 and d["steps"] == 6 and d["warmup"] == 2
+  assert "action broadcast" in d["config"]["parallelism"] and "gather" in d["config"]["parallelism"]
+  assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
+  assert d["exchange_ms_per_step"] is not None and d["exchange_ms_per_step"] > 0
+  assert d["value_with_gather"] == d["value"]  # N > 1: the exchange is inside the timed region
+  assert d["cpu_baseline"] is None  # reported at N = 1 only
