@@ -58,6 +58,14 @@ int mjlab_sizeof_data(void);
  * decimation loop that calls it 4x per env step is envs/manager_based_rl_env.py:109-114. */
 int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void* stream);
 
+/* Contact generation.  Plane / sphere / capsule pairs restate MuJoCo's analytic primitives; sphere-box
+ * restates mjc_SphereBox.  Two primitives are NOT upstream-identical (documented rules of this library,
+ * mirrored by the test oracle): capsule-box (sphere-box contacts of axis points
+ * chosen by a convex 1-D search instead of mjc_CapsuleBox's case analysis) and box-box for a moving box
+ * against a static terrain box (corners of either box as points + the terrain box's edges clipped to the
+ * moving box, first 4 hits, instead of mjc_BoxBox's separating-axis + face clipping).  Contact SETS from
+ * these two can differ from upstream's on edges and corners even where the deepest penetration agrees. */
+
 /* Replaces mjwarp.forward: everything of a step except the integration
  * (reference: sim/sim.py:182-187).
  *

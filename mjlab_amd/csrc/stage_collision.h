@@ -188,6 +188,69 @@ __device__ __forceinline__ int capsule_box(RawCon* c, float margin, const float*
   return n;
 }
 
+// Moving box (geom1) vs a static terrain box (geom2): candidate `cand` of this repository's documented
+// rule (NOT mjc_BoxBox): 0..7 corners of the moving box as points against the
+// terrain box (on a face exactly the plane-box contacts), 8..15 corners of the terrain box against the moving
+// box (normal flipped), 16..39 the terrain box's 12 edges clipped to the inside of the moving box (slab
+// clipping; the points at 1/4 and 3/4 of the inside interval, each leaving through the moving box's nearest
+// face).  The first 4 hits in candidate order are the pair's contacts; the normal points into the terrain.
+#define MJLAB_BOXBOX_NCAND 40
+__device__ __forceinline__ int box_box_candidate(RawCon* c, int cand, float margin, const float* pos, const float* mat, const float* size,
+                                                 const float* bpos, const float* bmat, const float* bsize) {
+  if (cand < 8) {
+    float vec[3], corner[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vec[k] = ((cand >> k) & 1) ? size[k] : -size[k];
+    mul_mat_vec3(corner, mat, vec);
+    for (int k = 0; k < 3; ++k) corner[k] += pos[k];
+    return sphere_box(c, margin, corner, 0.f, bpos, bmat, bsize);
+  }
+  float pt[3];
+  if (cand < 16) {
+    const int i = cand - 8;
+    float vec[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vec[k] = ((i >> k) & 1) ? bsize[k] : -bsize[k];
+    mul_mat_vec3(pt, bmat, vec);
+    for (int k = 0; k < 3; ++k) pt[k] += bpos[k];
+  } else {
+    const int e = (cand - 16) >> 1, smp = (cand - 16) & 1, a = e >> 2;
+    float v0[3], v1[3], e0[3], e1[3], q0[3], q1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // axis a runs -size..+size; the other two sit at the extremes picked by the bits of e
+      const int rel = (k - a + 3) % 3;  // 0: the edge's own axis, 1 / 2: the other two (bit 0 / bit 1 of e)
+      const float ext = ((e >> (rel - 1)) & 1) ? bsize[k] : -bsize[k];
+      v0[k] = rel == 0 ? -bsize[k] : ext;
+      v1[k] = rel == 0 ? bsize[k] : ext;
+    }
+    mul_mat_vec3(e0, bmat, v0);
+    mul_mat_vec3(e1, bmat, v1);
+    for (int k = 0; k < 3; ++k) { e0[k] += bpos[k] - pos[k]; e1[k] += bpos[k] - pos[k]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      q0[i] = mat[i] * e0[0] + mat[3 + i] * e0[1] + mat[6 + i] * e0[2];
+      q1[i] = mat[i] * e1[0] + mat[3 + i] * e1[1] + mat[6 + i] * e1[2];
+    }
+    float t0 = 0.f, t1 = 1.f;
+    bool miss = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float h = q1[i] - q0[i];
+      if (fabsf(h) < MINVAL) { miss |= fabsf(q0[i]) > size[i]; continue; }
+      float ta = (-size[i] - q0[i]) / h, tb = (size[i] - q0[i]) / h;
+      if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
+      t0 = fmaxf(t0, ta);
+      t1 = fminf(t1, tb);
+    }
+    if (miss || t1 - t0 <= 1e-6f) return 0;
+    const float t = t0 + (t1 - t0) * (smp ? 0.75f : 0.25f);
+    for (int k = 0; k < 3; ++k) pt[k] = pos[k] + e0[k] + t * (e1[k] - e0[k]);
+  }
+  if (!sphere_box(c, margin, pt, 0.f, pos, mat, size)) return 0;
+  for (int k = 0; k < 3; ++k) c->frame[k] = -c->frame[k];
+  return 1;
+}
+
 // Terrain broadphase of one moving geom: walk the grid cells under its bounding sphere and keep
 // the (at most MJLAB_TCAND_MAX, smallest ids first) boxes within reach in ascending order in
 // `cand` (this lane's LDS slots).  A box listed in several cells is looked at once, in the lowest
@@ -486,41 +549,29 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
       if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix);
       base += total;
     }
-    // Moving boxes: the 8 corners of the box as points (sphere_box with radius 0), lanes = (pair,
-    // corner), 8 pairs per sweep; the first 4 hits of a pair in corner order are kept -- on a face
-    // exactly the plane-box contacts.  Not a full box-box test: see DESIGN.md section 7 (row 4).
-    for (int p0 = 0; p0 < 8 * bbase; p0 += 64) {
-      const int p = p0 + lane, corner_id = lane & 7;
+    // Moving boxes vs terrain boxes: one pair per sweep, lanes = the rule's 40 candidates (box_box_candidate);
+    // the first 4 hits in candidate order are the pair's contacts.  Not mjc_BoxBox: see DESIGN.md section 7 (row 4).
+    for (int p = 0; p < bbase; ++p) {
       RawCon rc[4];
-      int g = 0, gb = 0;
-      float margin = 0.f, gap = 0.f;
+      const int code = s_pairb[p], ti = code >> 24;
+      const int b = s_cand[ti * MJLAB_TCAND_MAX + (code & 0xffffff)];
+      const int g = m.tgeom[ti], gb = m.tbox_geom[b], l = g - g0;
+      const float margin = s_gc[8 * l + 5], gap = s_gc[8 * l + 6];
       bool hit = false;
-      if (p < 8 * bbase) {
-        const int code = s_pairb[p >> 3], ti = code >> 24;
-        const int b = s_cand[ti * MJLAB_TCAND_MAX + (code & 0xffffff)];
-        g = m.tgeom[ti];
-        gb = m.tbox_geom[b];
-        const int l = g - g0;
-        margin = s_gc[8 * l + 5];
-        gap = s_gc[8 * l + 6];
-        float cp[3], vec[3], corner[3], bpos[3], bmat[9], bsize[3];
+      if (lane < MJLAB_BOXBOX_NCAND) {
+        float cp[3], cs[3], cm[9], bpos[3], bmat[9], bsize[3];
         for (int k = 0; k < 3; ++k) {
-          const float sz = s_gc[8 * l + 1 + k];
-          cp[k] = s_gx[3 * l + k]; vec[k] = ((corner_id >> k) & 1) ? sz : -sz;
+          cp[k] = s_gx[3 * l + k]; cs[k] = s_gc[8 * l + 1 + k];
           bpos[k] = m.tbox_pos[3 * b + k]; bsize[k] = m.tbox_size[3 * b + k];
         }
-        mul_mat_vec3(corner, s_gm + 9 * l, vec);
-        for (int k = 0; k < 3; ++k) corner[k] += cp[k];
-        for (int k = 0; k < 9; ++k) bmat[k] = m.tbox_mat[9 * b + k];
-        hit = sphere_box(rc, margin, corner, 0.f, bpos, bmat, bsize) != 0;
+        for (int k = 0; k < 9; ++k) { cm[k] = s_gm[9 * l + k]; bmat[k] = m.tbox_mat[9 * b + k]; }
+        hit = box_box_candidate(rc, lane, margin, cp, cm, cs, bpos, bmat, bsize) != 0;
       }
-      // rank of this hit among the hits of the same pair (8 consecutive lanes)
       const unsigned long long hits = __ballot(hit);
-      const int rank = __popcll(hits & (0xffull << (lane & 56)) & ((1ull << lane) - 1ull));
+      const int rank = __popcll(hits & ((1ull << lane) - 1ull));
       const int n = hit && rank < 4 ? 1 : 0;
-      int total;
-      const int off = wave_excl_scan(n, lane, &total);
-      if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix);
+      const int total = min(__popcll(hits), 4);
+      if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + rank, gfri, gsolref, gsolimp, gsolmix);
       base += total;
     }
   }

@@ -555,20 +555,72 @@ static int capsule_box(rawcon_t* c, real margin, const real* cpos, const real* c
   return n;
 }
 
-/* Moving box vs static box: the moving box's corners as points against the static box (sphere_box
- * with radius 0), first 4 hits in corner order -- on a face exactly plane_box's contacts.  This is
- * NOT mjc_BoxBox: contacts where an edge or corner of the static box pokes into a FACE of the
- * moving box are not generated (in the reference's scenes the only moving box is Go1's trunk, which
- * meets the ground when the robot has already fallen).  geom1 = moving box, normal into the terrain. */
-static int box_corners_box(rawcon_t* c, real margin, const real* pos, const real* mat, const real* size, const real* bpos,
-                           const real* bmat, const real* bsize) {
-  int n = 0;
-  for (int i = 0; i < 8 && n < 4; i++) {
-    real vec[3] = {(i & 1) ? size[0] : -size[0], (i & 2) ? size[1] : -size[1], (i & 4) ? size[2] : -size[2]}, corner[3];
+/* Moving box (geom1, pose pos / mat, half sizes size) vs a static terrain box (geom2).  NOT
+ * mjc_BoxBox (upstream's separating-axis + face-clipping routine cannot be restated from its
+ * documentation): a documented rule of this repository, built from the two exact point / segment
+ * primitives above, the same on the HIP side (stage_collision.h box_box_candidate):
+ *   candidates  0.. 7  corners of the moving box as points against the terrain box (sphere_box, r = 0):
+ *                      on a face exactly plane_box's contacts;
+ *               8..15  corners of the TERRAIN box as points against the moving box, normal flipped
+ *                      (a stair corner poking into a trunk face);
+ *              16..39  the 12 edges of the terrain box clipped to the inside of the moving box (slab
+ *                      clipping, exact): where an edge runs through it, the points at 1/4 and 3/4 of the
+ *                      inside interval, each leaving through the moving box's nearest face (a stair EDGE
+ *                      across a trunk face: two support points along the edge);
+ *   the first 4 hits in candidate order are the pair's contacts (when 4 corners already touch, the
+ *   edge candidates add nothing new).  The contact normal points from the moving box into the terrain. */
+static int box_box_candidate(rawcon_t* c, int cand, real margin, const real* pos, const real* mat, const real* size, const real* bpos,
+                             const real* bmat, const real* bsize) {
+  if (cand < 8) {
+    real vec[3] = {(cand & 1) ? size[0] : -size[0], (cand & 2) ? size[1] : -size[1], (cand & 4) ? size[2] : -size[2]}, corner[3];
     mul_mat_vec3(corner, mat, vec);
     for (int k = 0; k < 3; k++) corner[k] += pos[k];
-    n += sphere_box(c + n, margin, corner, 0, bpos, bmat, bsize);
+    return sphere_box(c, margin, corner, 0, bpos, bmat, bsize);
   }
+  real pt[3];
+  if (cand < 16) {
+    int i = cand - 8;
+    real vec[3] = {(i & 1) ? bsize[0] : -bsize[0], (i & 2) ? bsize[1] : -bsize[1], (i & 4) ? bsize[2] : -bsize[2]};
+    mul_mat_vec3(pt, bmat, vec);
+    for (int k = 0; k < 3; k++) pt[k] += bpos[k];
+  } else {
+    /* edge e = (cand - 16) / 2 of the terrain box: axis a = e / 4, the other two coordinates at their
+     * +- extremes (bits of e % 4); sample s = (cand - 16) % 2 */
+    int e = (cand - 16) >> 1, smp = (cand - 16) & 1, a = e >> 2, b1 = (a + 1) % 3, b2 = (a + 2) % 3;
+    real v0[3], v1[3], e0[3], e1[3], q0[3], q1[3];
+    v0[a] = -bsize[a]; v1[a] = bsize[a];
+    v0[b1] = v1[b1] = (e & 1) ? bsize[b1] : -bsize[b1];
+    v0[b2] = v1[b2] = (e & 2) ? bsize[b2] : -bsize[b2];
+    mul_mat_vec3(e0, bmat, v0);
+    mul_mat_vec3(e1, bmat, v1);
+    for (int k = 0; k < 3; k++) { e0[k] += bpos[k] - pos[k]; e1[k] += bpos[k] - pos[k]; }
+    for (int i = 0; i < 3; i++) { /* into the moving box's frame */
+      q0[i] = mat[i] * e0[0] + mat[3 + i] * e0[1] + mat[6 + i] * e0[2];
+      q1[i] = mat[i] * e1[0] + mat[3 + i] * e1[1] + mat[6 + i] * e1[2];
+    }
+    real t0 = 0, t1 = 1;
+    for (int i = 0; i < 3; i++) {
+      real h = q1[i] - q0[i];
+      if (fabs(h) < MINVAL) { if (fabs(q0[i]) > size[i]) return 0; continue; }
+      real ta = (-size[i] - q0[i]) / h, tb = (size[i] - q0[i]) / h;
+      if (ta > tb) { real tmp = ta; ta = tb; tb = tmp; }
+      if (ta > t0) t0 = ta;
+      if (tb < t1) t1 = tb;
+    }
+    if (t1 - t0 <= (real)1e-6) return 0; /* the edge does not run through the moving box */
+    real t = t0 + (t1 - t0) * (smp ? (real)0.75 : (real)0.25);
+    for (int k = 0; k < 3; k++) pt[k] = pos[k] + e0[k] + t * (e1[k] - e0[k]);
+  }
+  /* a point of the terrain box against the moving box; geom order is (moving, terrain): flip the normal */
+  if (!sphere_box(c, margin, pt, 0, pos, mat, size)) return 0;
+  for (int k = 0; k < 3; k++) c->frame[k] = -c->frame[k];
+  return 1;
+}
+#define MJO_BOXBOX_NCAND 40
+static int box_box(rawcon_t* c, real margin, const real* pos, const real* mat, const real* size, const real* bpos, const real* bmat,
+                   const real* bsize) {
+  int n = 0;
+  for (int cand = 0; cand < MJO_BOXBOX_NCAND && n < 4; cand++) n += box_box_candidate(c + n, cand, margin, pos, mat, size, bpos, bmat, bsize);
   return n;
 }
 
@@ -716,7 +768,7 @@ static void collision(const mjo_model_t* m, mjo_data_t* d, int w) {
       else if (m->geom_type[g] == MJLAB_GEOM_CAPSULE)
         n = capsule_box(rc, margin, gx + 3 * g, gm + 9 * g, gsize + 3 * g, m->tbox_pos + 3 * b, m->tbox_mat + 9 * b, m->tbox_size + 3 * b);
       else if (m->geom_type[g] == MJLAB_GEOM_BOX)
-        n = box_corners_box(rc, margin, gx + 3 * g, gm + 9 * g, gsize + 3 * g, m->tbox_pos + 3 * b, m->tbox_mat + 9 * b, m->tbox_size + 3 * b);
+        n = box_box(rc, margin, gx + 3 * g, gm + 9 * g, gsize + 3 * g, m->tbox_pos + 3 * b, m->tbox_mat + 9 * b, m->tbox_size + 3 * b);
       if (n) emit_contacts(m, d, w, g, m->tbox_geom[b], margin, gap, rc, n, &ncon);
     }
   }

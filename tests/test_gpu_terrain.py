@@ -291,3 +291,59 @@ def test_rough_fullsize_rollout_is_stable():
   rel_z = qpos[:, 2] - ro.env_origins[:, 2].cpu().numpy()
   assert (rel_z > -1.2).all() and (rel_z < 1.5).all()
   assert nreset < 4096  # not everybody falls within 1.2 s
+
+
+def test_go1_trunk_resting_on_a_stair_edge_matches_oracle():
+  """box_box beyond corner contacts: Go1 on its back across a stair edge -- the
+  edge runs through the trunk box's face, no trunk corner touches anything; plus the free box of BOX_XML on a
+  stair edge and on a pillar.  Same contacts in the same order as the oracle, the trunk is carried."""
+  from mjlab_amd import mjcf
+
+  spec = mjcf.Spec.from_string(robots.BOX_XML)
+  spec.option.integrator = mjcf.INT_IMPLICITFAST
+  spec.world.geoms.clear()
+  terrains.add_boxes(spec, spec.add_body("terrain"), np.array([[-1.0, 0, -0.5, 1.0, 2.0, 0.5], [3.0, 0, -0.5, 0.025, 0.025, 0.5]]))
+  model = spec.compile()
+  sim, ora = _sims(model, 3)
+  pitch = np.deg2rad(25.0)
+  qpos = np.zeros((3, 7))
+  qpos[0] = [0, 0, 0.1 * np.cos(pitch) - 0.01, np.cos(pitch / 2), 0, np.sin(pitch / 2), 0]  # tilted over the edge at x = 0
+  qpos[1] = [-0.05, 0.03, 0.097, 1, 0, 0, 0]  # level, half over the edge: two corners + two edge points
+  qpos[2] = [3.0, 0, 0.092, 1, 0, 0, 0]  # on the 5 cm pillar: the pillar's corners poke into the bottom face
+  _set(sim, ora, qpos=qpos)
+  sim.forward()
+  ora.forward()
+  assert ora.ncon.ravel().tolist() == [2, 4, 4]
+  _contacts_match(sim, ora)
+  assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-4
+
+  # Go1 of the rough scene, rolled onto its back and pitched 25 degrees, its trunk box laid across the upper
+  # +x edge of randomly chosen terrain boxes: legs in the air, the edge runs through the trunk's (now lower) face
+  model = robots.load_model("go1_velocity_rough")
+  nw = 256
+  sim, ora = _sims(model, nw)
+  rng = np.random.default_rng(21)
+  trunk = model.names["geom"].index("robot/trunk_collision")
+  hz = float(model.geom_size[trunk][2])
+  pos, size = np.asarray(model.tbox_pos), np.asarray(model.tbox_size)
+  steps = np.flatnonzero((size[:, 0] > 0.1) & (size[:, 0] < 2.0) & (size[:, 1] > 0.3))
+  b = steps[rng.integers(0, len(steps), nw)]
+  qpos = np.tile(model.key_qpos[0], (nw, 1))
+  qpos[:, 0] = pos[b, 0] + size[b, 0]
+  qpos[:, 1] = pos[b, 1] + rng.uniform(-0.5, 0.5, nw) * size[b, 1]
+  qpos[:, 2] = pos[b, 2] + size[b, 2] + hz * np.cos(pitch) - rng.uniform(0.002, 0.02, nw)
+  roll = np.array([0.0, 1.0, 0.0, 0.0])  # 180 degrees about x
+  pq = np.array([np.cos(pitch / 2), 0, np.sin(pitch / 2), 0])
+  qpos[:, 3:7] = mjcf.quat_mul(pq, roll)
+  _set(sim, ora, qpos=qpos, qvel=np.zeros((nw, model.nv)), ctrl=np.tile(model.key_ctrl[0], (nw, 1)))
+  sim.forward()
+  ora.forward()
+  _contacts_match(sim, ora, tol=5e-5, ftol=3e-3)
+  edge_worlds = 0
+  for w in range(nw):
+    n = int(ora.ncon[w, 0])
+    on_trunk = ora.contact_geom[w, :n, 0] == trunk
+    tilted = np.abs(ora.contact_frame[w, :n, 2]) < 0.99  # normal = a face normal of the pitched trunk, not the terrain's vertical
+    edge_worlds += bool((on_trunk & tilted).any())
+  assert edge_worlds > nw // 4, edge_worlds  # a stair edge into a trunk FACE does make contact now
+  assert np.array_equal(_np(sim.data.sensordata), ora.sensordata.astype(np.float32))

@@ -399,3 +399,56 @@ def test_capsule_box_deepest_contact_is_the_true_distance():
         assert (np.abs(dist - r - o.contact_dist[w, k]) < 1e-4).any()
       checked += 1
   assert checked > 40 and clear > 40
+
+
+def _box_over(boxes) -> mjcf.Model:
+  """The 0.1 m free box of robots.BOX_XML over static terrain boxes (no floor plane)."""
+  spec = Spec.from_string(robots.BOX_XML)
+  spec.option.integrator = mjcf.INT_IMPLICITFAST
+  spec.world.geoms.clear()
+  terrains.add_boxes(spec, spec.add_body("terrain"), np.asarray(boxes, dtype=np.float64))
+  return spec.compile()
+
+
+def test_box_face_on_a_stair_edge_and_on_a_stair_corner():
+  """box_box beyond corners (the rule documented in oracle/mjoracle.c): a terrain EDGE running through the
+  moving box gives two contacts along the edge, a terrain CORNER poking into a face gives one; normals
+  point from the moving box into the terrain, depths are the distance to the face being entered."""
+  # a step whose top face is z = 0 for x <= 0: its upper edge runs along y at x = 0
+  m = _box_over([[-1.0, 0, -0.5, 1.0, 2.0, 0.5]])  # centre + half sizes
+  o = OracleSim(m, nworld=3)
+  pitch = np.deg2rad(25.0)
+  quat = np.array([np.cos(pitch / 2), 0, np.sin(pitch / 2), 0])  # nose down towards +x: no corner reaches the tread
+  # world 0: box centred over the edge, tilted, its bottom face 1 cm below the edge line
+  c = np.cos(pitch)
+  o.qpos[0, :3] = [0.0, 0.0, 0.1 * c - 0.01]
+  o.qpos[0, 3:7] = quat
+  # world 1: same, 5 cm higher: clear
+  o.qpos[1, :3] = [0.0, 0.0, 0.1 * c + 0.04]
+  o.qpos[1, 3:7] = quat
+  # world 2: flat on the tread (x = -0.5): four corner contacts, the plane-box case
+  o.qpos[2, :3] = [-0.5, 0.0, 0.095]
+  o.qpos[2, 3:7] = [1, 0, 0, 0]
+  o.forward()
+  k = contacts(o, 0)
+  assert k["n"] == 2 and int(o.ncon[1, 0]) == 0 and int(o.ncon[2, 0]) == 4
+  # both contacts sit on the edge line (x = 0, z ~ 0), at y = -+0.05 (1/4 and 3/4 of the 0.2 m the edge runs inside the box)
+  assert np.allclose(np.sort(k["pos"][:, 1]), [-0.05, 0.05], atol=1e-9)
+  assert np.allclose(k["pos"][:, 0], k["pos"][0, 0]) and abs(k["pos"][0, 0]) < 0.01
+  # normal = outward normal of the box's bottom face = the box's -z axis, pointing into the terrain (downwards)
+  nz = np.array([np.sin(pitch), 0, np.cos(pitch)])
+  assert np.allclose(k["frame"][:, :3], -nz, atol=1e-9)
+  depth = 0.1 - (0.1 * c - 0.01) * c  # the edge point's distance above the bottom face, along the face normal
+  assert np.allclose(k["dist"], -depth, atol=1e-12)
+  assert (o.efc_force[0, : int(o.nefc[0, 0])] > 0).any() and o.qacc[0, 2] > -9.81  # the edge carries the box
+  # a stair CORNER into the bottom face: small pillar under the box centre, box level, 8 mm into the pillar top
+  m2 = _box_over([[0, 0, -0.5, 0.025, 0.025, 0.5]])
+  o2 = OracleSim(m2, nworld=1)
+  o2.qpos[0, :3] = [0.0, 0.0, 0.1 - 0.008]
+  o2.forward()
+  k2 = contacts(o2, 0)
+  assert k2["n"] == 4  # the pillar's four top corners inside the bottom face (first 4 hits)
+  assert np.allclose(k2["frame"][:, :3], [0, 0, -1], atol=1e-12) and np.allclose(k2["dist"], -0.008, atol=1e-12)
+  assert np.allclose(np.abs(k2["pos"][:, :2]), 0.025, atol=1e-12)
+  o2.step(400)
+  assert abs(o2.qpos[0, 2] - 0.1) < 5e-3 and np.abs(o2.qvel).max() < 1e-2  # comes to rest on the pillar
