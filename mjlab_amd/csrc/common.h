@@ -254,9 +254,16 @@ struct CholSweep {
     f32x2 acc = {a[J], 0.f};  // two accumulators, products in pairs (v_pk_fma_f32)
     batches<J, 0>(a, acc, cur, oth, A);
     const float t = acc.x + acc.y;
+#ifdef MJLAB_CHOL_REFINE
     const float djj = fmaxf(lane_bcast(t, J), MINVAL);
     float invd = __builtin_amdgcn_rcpf(djj);  // v_rcp_f32 (1 ulp) + one Newton step
     invd = invd * (2.f - djj * invd);
+#else
+    // pivot clamped from below by one v_med3 (no canonicalising v_max pair), reciprocal = v_rcp_f32 (1 ulp):
+    // 3 of the ~14 scalar-like instructions every column costs on top of its multiply-adds
+    const float djj = __builtin_amdgcn_fmed3f(lane_bcast(t, J), MINVAL, 3.0e38f);
+    const float invd = __builtin_amdgcn_rcpf(djj);
+#endif
     a[J] = t;
     const float lu = rowid > J ? t * invd : 0.f;
     row[J] = lu;

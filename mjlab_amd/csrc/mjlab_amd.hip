@@ -156,23 +156,24 @@ __global__ __launch_bounds__(64, 4) void k_control_step(const Model m_, const Da
     for (int a = lane; a < nu; a += 64) d.ctrl[(size_t)w * nu + a] = c.action_offset[a] + c.action_scale[a] * c.action[(size_t)w * nu + a];
     __syncthreads();
   }
-  for (int s = 0; s < c.nsubstep; ++s) {
-    const int f = (s == 0 && fold) ? FLAG_FOLD : 0;
-    fused_presolve(f, smem);
-    { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 1, 1, f, smem); }
-    __syncthreads();
-  }
+  // ONE copy of the stage code: passes 0 .. nsubstep-1 are the physics steps, pass nsubstep is forward()
+  // (preceded by the termination test + reset); a second inlined copy doubled the kernel to 294 KB of code
   bool reset = false;
-  if (c.key_qpos) {
-    FUSED_ARGS;
-    reset = masked_reset_world(m, d, w, lane, c.key_qpos, c.rnd3, c.episode_length, c.max_len, c.min_height, c.reset_mask, c.env_origins, c.min_up_z);
+  for (int s = 0; s <= c.nsubstep; ++s) {
+    const bool fwd = s == c.nsubstep;
+    if (fwd) {
+      if (c.key_qpos) {
+        FUSED_ARGS;
+        reset = masked_reset_world(m, d, w, lane, c.key_qpos, c.rnd3, c.episode_length, c.max_len, c.min_height, c.reset_mask, c.env_origins, c.min_up_z);
+        __syncthreads();
+      }
+      if (!(c.forward_mode == 1 || (c.forward_mode == 2 && reset))) break;
+    }
+    const int f = (s == 0 && fold && !fwd) ? FLAG_FOLD : 0;
+    fused_presolve(f, smem);
+    { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 1, fwd ? 0 : 1, f, smem); }
     __syncthreads();
-  }
-  if (c.forward_mode == 1 || (c.forward_mode == 2 && reset)) {
-    fused_presolve(0, smem);
-    { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 1, 0, 0, smem); }
-    __syncthreads();
-    { FUSED_ARGS; fold_snapshot(m, d, w, lane); }
+    if (fwd) { FUSED_ARGS; fold_snapshot(m, d, w, lane); }
   }
   if (c.push_time_left) {
     FUSED_ARGS;
