@@ -114,6 +114,9 @@ def main() -> None:
   ap.add_argument("--no-control-kernel", action="store_true",
                   help="separate library calls per phase of a control step (step, masked reset, forward, push) instead of one "
                   "mjlab_control_step launch (bit-identical results)")
+  ap.add_argument("--balance-every", type=int, default=0,
+                  help="re-deal the worlds over the SIMDs by expected cost every this many control steps (0 = never; "
+                  "control kernel only; results unchanged)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--seed", type=int, default=42)
   args = ap.parse_args()
@@ -144,6 +147,8 @@ def main() -> None:
   learner_gen = torch.Generator(device=dev)
   learner_gen.manual_seed(args.seed + 1000)
 
+  step_no = [0]
+
   def env_step(with_rows: bool = False) -> None:
     """One control step.  N > 1: the learner on rank 0 decides the actions of ALL envs, every rank
     receives its slice (broadcast over RCCL), steps its shard, and the [obs | ...] rows travel back to
@@ -153,6 +158,10 @@ def main() -> None:
       action = mdist.scatter_actions(info, a_all, nu, dev)
     else:
       action = roll.random_action()
+    if args.balance_every and roll.control_kernel:
+      if step_no[0] % args.balance_every == 0:
+        roll.balance_worlds()
+      step_no[0] += 1
     roll.step(action)
     if exchange:
       mdist.gather_rollout(info, roll.observation_rows())

@@ -168,6 +168,8 @@ typedef struct mjlab_control {
   int* episode_length;        /* (nworld) */
   int* reset_mask;            /* (nworld) out */
   const float* env_origins;   /* (nworld, 3) or NULL */
+  const int* world_order;     /* (nworld) a permutation: workgroup b works on world world_order[b]; NULL = identity.
+                                 Results do not depend on it; it only decides which worlds share a SIMD (load balance) */
   float* push_time_left;      /* (nworld) or NULL: no push */
   const float* rnd7;          /* (nworld, 7) */
   float min_height, min_up_z, push_dt, push_interval_lo, push_interval_hi;

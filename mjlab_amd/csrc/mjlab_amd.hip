@@ -99,7 +99,7 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 // structs are the first two kernel arguments (kernarg offsets 0 and sizeof(Model), 8-byte aligned);
 // reading them through the laundered kernarg pointer keeps the loads scalar.
 #define FUSED_ARGS                                                                                                   \
-  int w = blockIdx.x, lane = threadIdx.x;                                                                            \
+  int w = wsel_, lane = threadIdx.x;                                                                                 \
   unsigned long long ka_ = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();                               \
   asm volatile("" : "+s"(w), "+v"(lane), "+s"(ka_));                                                                 \
   const Model& m = *(const Model*)(const __attribute__((address_space(4))) Model*)(kptr_t)ka_;                       \
@@ -107,7 +107,8 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 typedef const __attribute__((address_space(4))) char* kptr_t;
 static_assert(sizeof(Model) % 8 == 0 && alignof(Data) == 8, "kernarg layout assumed by FUSED_ARGS");
 
-__device__ __forceinline__ void fused_presolve(const int flags, float* smem) {
+// wsel_ = the world this wave works on (blockIdx.x, or mjlab_control_t.world_order[blockIdx.x])
+__device__ __forceinline__ void fused_presolve(const int wsel_, const int flags, float* smem) {
   bool reuse;
   { FUSED_ARGS; reuse = stage_position(m, d, w, lane, flags, smem); }
   __syncthreads();
@@ -125,7 +126,7 @@ __device__ __forceinline__ void fused_presolve(const int flags, float* smem) {
 __global__ __launch_bounds__(64, 4) void k_presolve(const Model m_, const Data d_, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((flags & FLAG_MASK) && !d_.world_mask[blockIdx.x]) return;
-  fused_presolve(flags, smem);
+  fused_presolve(blockIdx.x, flags, smem);
 }
 // nsub physics steps of this world back to back (nsub > 1: mjlab_step's nsubstep; ctrl / qfrc_applied /
 // xfrc_applied are the same for all of them, as in the reference's decimation loop,
@@ -135,9 +136,10 @@ template <int NVP, bool INTEGRATE>
 __global__ __launch_bounds__(64, 4) void k_substep(const Model m_, const Data d_, const int flags, const int nsub) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((flags & FLAG_MASK) && !d_.world_mask[blockIdx.x]) return;
+  const int wsel_ = blockIdx.x;
   for (int s = 0; s < nsub; ++s) {
     const int f = s == 0 ? flags : (flags & ~FLAG_FOLD);
-    fused_presolve(f, smem);
+    fused_presolve(wsel_, f, smem);
     { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 1, INTEGRATE ? 1 : 0, f, smem); }
     __syncthreads();
   }
@@ -150,6 +152,13 @@ __global__ __launch_bounds__(64, 4) void k_substep(const Model m_, const Data d_
 template <int NVP>
 __global__ __launch_bounds__(64, 4) void k_control_step(const Model m_, const Data d_, const mjlab_control_t c, const int fold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef MJLAB_PROFILE
+  const long long t_begin_ = clock64();
+#endif
+  // Which world this workgroup takes.  The launch ends with its slowest SIMD, and a SIMD's four waves share
+  // its issue slots: world_order lets the host deal the expensive worlds (many contacts last step) out evenly
+  // over the SIMDs instead of wherever their index happens to land them.
+  const int wsel_ = __builtin_amdgcn_readfirstlane(c.world_order ? c.world_order[blockIdx.x] : (int)blockIdx.x);
   if (c.action) {
     FUSED_ARGS;
     const int nu = m.size.nu;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(64, 4) void k_control_step(const Model m_, const Da
       if (!(c.forward_mode == 1 || (c.forward_mode == 2 && reset))) break;
     }
     const int f = (s == 0 && fold && !fwd) ? FLAG_FOLD : 0;
-    fused_presolve(f, smem);
+    fused_presolve(wsel_, f, smem);
     { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 1, fwd ? 0 : 1, f, smem); }
     __syncthreads();
     if (fwd) { FUSED_ARGS; fold_snapshot(m, d, w, lane); }
@@ -180,6 +189,9 @@ __global__ __launch_bounds__(64, 4) void k_control_step(const Model m_, const Da
     __syncthreads();
     if (lane == 0) interval_push_world(m, d, w, c.push_time_left, c.rnd7, c.push_dt, c.push_interval_lo, c.push_interval_hi, c.push_range);
   }
+#ifdef MJLAB_PROFILE
+  if (threadIdx.x == 0) d_.profile[(size_t)wsel_ * 64 + 63] += (float)(clock64() - t_begin_);  // this world's share of the launch
+#endif
 }
 
 // ====================================================================================

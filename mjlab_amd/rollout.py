@@ -31,7 +31,7 @@ class _Control(ctypes.Structure):
     ("nsubstep", ctypes.c_int), ("forward_mode", ctypes.c_int), ("max_len", ctypes.c_int), ("pad_", ctypes.c_int),
     ("action", ctypes.c_void_p), ("action_offset", ctypes.c_void_p), ("action_scale", ctypes.c_void_p),
     ("key_qpos", ctypes.c_void_p), ("rnd3", ctypes.c_void_p), ("episode_length", ctypes.c_void_p), ("reset_mask", ctypes.c_void_p),
-    ("env_origins", ctypes.c_void_p), ("push_time_left", ctypes.c_void_p), ("rnd7", ctypes.c_void_p),
+    ("env_origins", ctypes.c_void_p), ("world_order", ctypes.c_void_p), ("push_time_left", ctypes.c_void_p), ("rnd7", ctypes.c_void_p),
     ("min_height", ctypes.c_float), ("min_up_z", ctypes.c_float), ("push_dt", ctypes.c_float),
     ("push_interval_lo", ctypes.c_float), ("push_interval_hi", ctypes.c_float), ("push_range", _PushRange),
   ]  # fmt: skip
@@ -130,6 +130,9 @@ class PhysicsRollout:
       self.push = (float(lo_t), float(hi_t), rng6, time_left)
     self._graph: torch.cuda.CUDAGraph | None = None
     self._obs_buf: torch.Tensor | None = None
+    # load balance of the control kernel (mjlab_control_t.world_order): see balance_worlds()
+    self.world_order: torch.Tensor | None = None
+    self._slot_of_rank: torch.Tensor | None = None
     # start at random episode phase like the reference (train.py:109-111 init_at_random_ep_len)
     self.episode_length = torch.randint(0, self.max_len, (n,), device=dev, generator=self.gen).to(torch.int32)
     self._reset_mask = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -219,6 +222,7 @@ class PhysicsRollout:
       c.episode_length, c.reset_mask = self.episode_length.data_ptr(), self._reset_mask.data_ptr()
       c.env_origins = 0 if self.env_origins is None else self.env_origins.data_ptr()
       c.min_height, c.min_up_z = float(self.min_height), self.min_up_z
+      c.world_order = 0 if self.world_order is None else self.world_order.data_ptr()
       if self.push is not None:
         lo_t, hi_t, rng6, time_left = self.push
         c.push_time_left, c.rnd7, c.push_dt, c.push_interval_lo, c.push_interval_hi, c.push_range = time_left.data_ptr(), rnd7.data_ptr(), dt, lo_t, hi_t, rng6
@@ -263,6 +267,33 @@ class PhysicsRollout:
         "mjlab_interval_push",
       )
     return reset
+
+  def balance_worlds(self, simd_stride: int = 1024) -> None:
+    """Deal the worlds out over the SIMDs by expected cost (control kernel only; results unchanged).
+
+    The launch ends with its slowest SIMD, whose four waves share its issue slots.  With all nworld workgroups
+    resident at once (4096 = 256 CUs x 16), workgroups b, b + 1024, b + 2048, b + 3072 land on the same SIMD
+    (XCD = b % 8, CU and wave slot from b / 8 in dispatch order), so the worlds are ranked by the cost proxy
+    of their last pass -- rows x (Newton iterations + 2) -- and dealt out in snake order: SIMD k gets ranks
+    k, 2S-1-k, 2S+k, 4S-1-k.  Expensive worlds (fallen robots, many contacts) stay expensive for ~1 s, so
+    calling this every few control steps is enough.  The permutation lives in a fixed buffer the captured
+    graph reads, so it can be refreshed between replays."""
+    n = self.sim.num_envs
+    dev = self.key_qpos.device
+    if n % simd_stride or n // simd_stride != 4:
+      return  # the dispatch-order argument above needs exactly four workgroups per SIMD
+    if self.world_order is None:
+      self.world_order = torch.arange(n, dtype=torch.int32, device=dev)
+      k = torch.arange(simd_stride, device=dev)
+      S = simd_stride
+      ranks = torch.stack([k, 2 * S - 1 - k, 2 * S + k, 4 * S - 1 - k])  # [t][k] = rank served by workgroup k + S t
+      slot_of_rank = torch.empty(n, dtype=torch.long, device=dev)
+      slot_of_rank[ranks.reshape(-1)] = torch.arange(n, device=dev)
+      self._slot_of_rank = slot_of_rank
+    d = self.sim.data
+    cost = d.nefc.view(-1).float() * (d.solver_niter.view(-1).float() + 2.0)
+    idx = torch.argsort(cost, descending=True)
+    self.world_order[self._slot_of_rank] = idx.to(torch.int32)
 
   def random_action(self) -> torch.Tensor:
     """``2 U(0,1) - 1`` per actuator (reference scripts/play.py:159-172 "random" agent)."""

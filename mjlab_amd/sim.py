@@ -234,6 +234,7 @@ class Simulation:
 
     if getattr(cfg.nan_guard, "enabled", False):
       raise NotImplementedError("nan_guard is not provided by mjlab_amd (append a callable to Simulation.post_step_hooks instead)")
+    self._frictionloss_handed_out = False
     self.post_step_hooks: list = []  # callables(sim) run after every step() (where the reference's NaN guard sits)
     self.use_graph = bool(cfg.use_graph) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
     self.step_graph: torch.cuda.CUDAGraph | None = None
@@ -371,6 +372,9 @@ class Simulation:
     extension: that many steps with the inputs held fixed -- the reference's decimation loop
     (envs/manager_based_rl_env.py:109-114 re-applies the same action before each of them) as one call;
     with ``fuse="step"`` also ONE kernel launch."""
+    if self._frictionloss_handed_out:  # sim.model.dof_frictionloss was handed out (writable) since the last check
+      self.check_model_writes()
+      self._frictionloss_handed_out = False
     with torch.cuda.device(self._dev):
       if nsubstep == 1:
         self._step_once()
@@ -387,8 +391,10 @@ class Simulation:
 
   def check_model_writes(self) -> None:
     """Host-side check (one sync) of per-world model values the kernels do not implement:
-    a non-zero ``dof_frictionloss`` written after construction (friction-loss rows are not built)."""
-    if getattr(self, "_frictionloss_handed_out", False) and bool((self._model_view["dof_frictionloss"] != 0).any()):
+    a non-zero ``dof_frictionloss`` written after construction (friction-loss rows are not built).
+    ``step()`` calls it once after every hand-out of ``sim.model.dof_frictionloss``; a write through a
+    handle obtained earlier is only caught by calling it explicitly."""
+    if bool((self._model_view["dof_frictionloss"] != 0).any()):
       raise NotImplementedError("dof_frictionloss != 0 was written to sim.model: friction-loss constraint rows are not implemented")
 
   def overflow_report(self) -> dict[str, int]:

@@ -584,6 +584,10 @@ def test_host_side_guards_and_warnings():
   sim.model.dof_frictionloss[2, 7] = 0.1
   with pytest.raises(NotImplementedError, match="frictionloss"):
     sim.check_model_writes()
+  with pytest.raises(NotImplementedError, match="frictionloss"):
+    sim.step()  # the next step() after the hand-out checks by itself
+  sim.model.dof_frictionloss[:] = 0.0
+  sim.step()
   with pytest.raises(NotImplementedError, match="nan_guard"):
     from mjlab_amd.sim import NanGuardCfg
 
