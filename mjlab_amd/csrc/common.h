@@ -1,5 +1,5 @@
 // common.h -- wave-level helpers, small math, register-resident LDL^T factor / substitution.
-// Part of the single translation unit mjlab_amd.hip (included there, in this order); not a
+// Part of kernels.h (included there, in this order, by every translation unit of the library); not a
 // stand-alone header.
 #pragma once
 

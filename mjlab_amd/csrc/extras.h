@@ -1,5 +1,5 @@
 // extras.h -- fused entity read-back, masked reset, field tiling, self-test.
-// Part of the single translation unit mjlab_amd.hip (included there, in this order); not a
+// Part of kernels.h (included there, in this order, by every translation unit of the library); not a
 // stand-alone header.
 #pragma once
 
@@ -21,6 +21,7 @@ __device__ __forceinline__ void vel_from_cvel(float* out6, const float* pos, con
   for (int k = 0; k < 3; ++k) { out6[k] = cv[3 + k] - c[k]; out6[3 + k] = cv[k]; }
 }
 
+#ifdef MJLAB_MAIN_TU
 __global__ __launch_bounds__(64) void k_entity_readback(const Model m, const Data d, const mjlab_entity_view_t v) {
   const int w = blockIdx.x, lane = threadIdx.x;
   const int nb = m.size.nbody, nq = m.size.nq, nv = m.size.nv;
@@ -82,6 +83,8 @@ __global__ __launch_bounds__(64) void k_entity_readback(const Model m, const Dat
   }
 }
 
+#endif  // MJLAB_MAIN_TU
+
 // ====================================================================================
 // Masked termination + reset (extension, see include/mjlab_amd.h)
 // ====================================================================================
@@ -137,11 +140,13 @@ __device__ __forceinline__ bool masked_reset_world(const Model& m, const Data& d
   }
   return reset;
 }
+#ifdef MJLAB_MAIN_TU
 __global__ __launch_bounds__(64) void k_masked_reset(const Model m, const Data d, const float* key_qpos, const float* rnd3,
                                                       int* episode_length, const int max_len, const float min_height, int* reset_mask,
                                                       const float* env_origins, const float min_up_z) {
   (void)masked_reset_world(m, d, blockIdx.x, threadIdx.x, key_qpos, rnd3, episode_length, max_len, min_height, reset_mask, env_origins, min_up_z);
 }
+#endif  // MJLAB_MAIN_TU
 
 // Interval push (reference envs/mdp/events.py:127-143 push_by_setting_velocity under the event
 // manager's per-env interval timer, managers/event_manager.py:116-138): see include/mjlab_amd.h.
@@ -164,12 +169,14 @@ __device__ __forceinline__ void interval_push_world(const Model& m, const Data& 
   }
   time_left[w] = t;
 }
+#ifdef MJLAB_MAIN_TU
 __global__ __launch_bounds__(64) void k_interval_push(const Model m, const Data d, float* time_left, const float* rnd7, const float dt,
                                                        const float t_lo, const float t_hi, const mjlab_push_range_t range) {
   const int w = blockIdx.x * 64 + threadIdx.x;
   if (w >= m.size.nworld) return;
   interval_push_world(m, d, w, time_left, rnd7, dt, t_lo, t_hi, range);
 }
+#endif  // MJLAB_MAIN_TU
 
 // ====================================================================================
 // repeat_array_kernel replacement (reference src/mjlab/sim/randomization.py:9-17)
@@ -181,6 +188,7 @@ __global__ void k_tile(T* dst, const T* src, long long nelem, long long total) {
 }
 
 // self-test of the DPP reductions against the ds_bpermute versions
+#ifdef MJLAB_MAIN_TU
 __global__ void k_selftest(const float* in, int* nerr) {
   const float v = in[blockIdx.x * 64 + threadIdx.x];
   const float a = wave_sum(v), b = wave_sum_shfl(v);
@@ -188,4 +196,4 @@ __global__ void k_selftest(const float* in, int* nerr) {
   const float tol = 1e-4f * (1.f + fabsf(b));
   if (fabsf(a - b) > tol || fabsf(c - e) > 1e-4f * (1.f + fabsf(e))) atomicAdd(nerr, 1);
 }
-
+#endif  // MJLAB_MAIN_TU

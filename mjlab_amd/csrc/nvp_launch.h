@@ -1,0 +1,32 @@
+// nvp_launch.h -- host-side launch functions of the kernels that are instantiated per padded dof count NVP
+// (nvp_inst.hip: two translation units per size, compiled in parallel).  A kernel has to be launched from the
+// translation unit that holds its device code, so every size exports four plain host functions and
+// mjlab_amd.hip picks them from a table.
+#pragma once
+
+typedef hipError_t (*nvp_solve_fn)(const mjlab_model_t*, const mjlab_data_t*, int do_solve, int do_integrate, int flags, int lds_bytes, hipStream_t);
+typedef hipError_t (*nvp_substep_fn)(const mjlab_model_t*, const mjlab_data_t*, int flags, int nsub, int lds_bytes, hipStream_t);
+typedef hipError_t (*nvp_control_fn)(const mjlab_model_t*, const mjlab_data_t*, const mjlab_control_t*, int fold, int lds_bytes, hipStream_t);
+struct NvpLaunch {
+  nvp_solve_fn solve;      // k_solve_integrate<NVP>                      (part 0)
+  nvp_substep_fn forward;  // k_substep<NVP, false>: forward()            (part 0)
+  nvp_substep_fn step;     // k_substep<NVP, true>: nsub physics steps    (part 1)
+  nvp_control_fn control;  // k_control_step<NVP>                         (part 1)
+};
+#define MJLAB_NVP_SIZES(X) X(8) X(16) X(20) X(24) X(32) X(36) X(40) X(48) X(64)
+#define MJLAB_NVP_DECL_(N)                                                                                                        \
+  hipError_t mjlab_nvp_solve_##N(const mjlab_model_t*, const mjlab_data_t*, int, int, int, int, hipStream_t);                      \
+  hipError_t mjlab_nvp_forward_##N(const mjlab_model_t*, const mjlab_data_t*, int, int, int, hipStream_t);                         \
+  hipError_t mjlab_nvp_step_##N(const mjlab_model_t*, const mjlab_data_t*, int, int, int, hipStream_t);                            \
+  hipError_t mjlab_nvp_control_##N(const mjlab_model_t*, const mjlab_data_t*, const mjlab_control_t*, int, int, hipStream_t);
+MJLAB_NVP_SIZES(MJLAB_NVP_DECL_)
+#ifdef MJLAB_MAIN_TU
+static const NvpLaunch* nvp_launch(int nvp) {
+  switch (nvp) {
+#define MJLAB_NVP_CASE_(N) \
+  case N: { static const NvpLaunch t = {mjlab_nvp_solve_##N, mjlab_nvp_forward_##N, mjlab_nvp_step_##N, mjlab_nvp_control_##N}; return &t; }
+    MJLAB_NVP_SIZES(MJLAB_NVP_CASE_)
+  }
+  return nullptr;
+}
+#endif

@@ -1,5 +1,5 @@
 // stage_constraint.h -- stage 4: limits + contacts -> efc rows, contact sensors.
-// Part of the single translation unit mjlab_amd.hip (included there, in this order); not a
+// Part of kernels.h (included there, in this order, by every translation unit of the library); not a
 // stand-alone header.
 #pragma once
 
@@ -305,6 +305,7 @@ __device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, 
   PROF_FLUSH(d.profile + (size_t)w * 64 + 40);
 }
 
+#ifdef MJLAB_MAIN_TU
 __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
@@ -312,3 +313,4 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
   if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
   stage_constraint(m, d, w, lane, flags, smem);
 }
+#endif  // MJLAB_MAIN_TU

@@ -1,5 +1,5 @@
 // stage_position.h -- stage 1: kinematics, comPos, crb, dense M.
-// Part of the single translation unit mjlab_amd.hip (included there, in this order); not a
+// Part of kernels.h (included there, in this order, by every translation unit of the library); not a
 // stand-alone header.
 #pragma once
 
@@ -450,9 +450,11 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
   return false;
 }
 
+#ifdef MJLAB_MAIN_TU
 __global__ __launch_bounds__(64, 4) void k_position(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
   (void)stage_position(m, d, w, lane, flags, smem);
 }
+#endif  // MJLAB_MAIN_TU

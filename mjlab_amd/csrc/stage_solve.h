@@ -1,5 +1,5 @@
 // stage_solve.h -- stages 5+6: Newton solver and integration.
-// Part of the single translation unit mjlab_amd.hip (included there, in this order); not a
+// Part of kernels.h (included there, in this order, by every translation unit of the library); not a
 // stand-alone header.
 #pragma once
 
@@ -639,9 +639,11 @@ __device__ __forceinline__ void fold_snapshot(const Model& m, const Data& d, con
   for (int i = lane; i < nv; i += 64) d.sh_qvel[(size_t)w * nv + i] = d.qvel[(size_t)w * nv + i];
   if (lane == 0) d.fold_valid[w] = 1;
 }
+#ifdef MJLAB_MAIN_TU
 __global__ __launch_bounds__(64) void k_fold_snapshot(const Model m, const Data d, const int flags) {
   const int w = blockIdx.x, lane = threadIdx.x;
   if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
   fold_snapshot(m, d, w, lane);
 }
+#endif  // MJLAB_MAIN_TU
 

@@ -1,5 +1,5 @@
 // stage_velocity.h -- stage 3: comVel, rne, actuation, qfrc_smooth.
-// Part of the single translation unit mjlab_amd.hip (included there, in this order); not a
+// Part of kernels.h (included there, in this order, by every translation unit of the library); not a
 // stand-alone header.
 #pragma once
 
@@ -202,9 +202,11 @@ __device__ __forceinline__ void stage_velocity(const Model& m, const Data& d, co
   PROF_FLUSH(d.profile + (size_t)w * 64 + 24);
 }
 
+#ifdef MJLAB_MAIN_TU
 __global__ __launch_bounds__(64, 4) void k_velocity(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
   stage_velocity(m, d, w, lane, flags, smem);
 }
+#endif  // MJLAB_MAIN_TU

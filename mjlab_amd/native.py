@@ -16,28 +16,48 @@ from . import _abi
 
 CSRC = Path(__file__).parent / "csrc"
 LIB_PATH = Path(os.environ.get("MJLAB_AMD_LIB", CSRC / "libmjlab_amd.so"))
-SOURCES = [CSRC / "mjlab_amd.hip"]
+SOURCES = [CSRC / "mjlab_amd.hip", CSRC / "nvp_inst.hip"]
 HEADERS = [Path(__file__).parents[1] / "include" / "mjlab_amd.h", Path(__file__).parents[1] / "include" / "mjlab_fields.h",
-           *sorted(CSRC.glob("*.h"))]  # the stage files are included by mjlab_amd.hip (one translation unit)
+           *sorted(CSRC.glob("*.h"))]  # kernels.h includes the stage files
+NVP_SIZES = (8, 16, 20, 24, 32, 36, 40, 48, 64)  # padded dof counts the solve / substep / control kernels are instantiated for
+HIPCC_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=on", "--offload-arch=gfx950", "-fPIC"]
 
 STAGE_POSITION, STAGE_COLLISION, STAGE_VELOCITY, STAGE_CONSTRAINT, STAGE_SOLVE, STAGE_INTEGRATE = 1, 2, 4, 8, 16, 32
 STAGE_FORWARD, STAGE_STEP = 31, 63
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-  """Compile the HIP extension for gfx950 (cross-compiles without a GPU)."""
+def build(force: bool = False, verbose: bool = False, out: Path | None = None, defines: tuple[str, ...] = (), jobs: int | None = None) -> Path:
+  """Compile the HIP extension for gfx950 (cross-compiles without a GPU): mjlab_amd.hip (C ABI + the kernels that
+  do not depend on the padded dof count) and nvp_inst.hip twice per padded size, in parallel, then one link.
+  ``out`` / ``defines`` build a variant somewhere else (profiling build: ``defines=("MJLAB_PROFILE",)``)."""
+  from concurrent.futures import ThreadPoolExecutor
+
+  out = Path(out) if out is not None else LIB_PATH
   newest_src = max(p.stat().st_mtime for p in SOURCES + HEADERS)
-  if LIB_PATH.exists() and not force and LIB_PATH.stat().st_mtime >= newest_src:
-    return LIB_PATH
+  if out.exists() and not force and not defines and out.stat().st_mtime >= newest_src:
+    return out
   hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-  cmd = [
-    hipcc, "-O3", "-std=c++17", "-ffp-contract=on", "--offload-arch=gfx950", "-shared", "-fPIC",
-    "-o", str(LIB_PATH), *[str(s) for s in SOURCES],
-  ]  # fmt: skip
+  objdir = CSRC / "build" / (out.stem + ("_" + "_".join(defines) if defines else ""))
+  objdir.mkdir(parents=True, exist_ok=True)
+  dflags = [f"-D{x}" for x in defines]
+  units = [(CSRC / "mjlab_amd.hip", objdir / "abi.o", [])] + [
+    (CSRC / "nvp_inst.hip", objdir / f"nvp_{n}_{part}.o", [f"-DMJLAB_NVP={n}", f"-DMJLAB_NVP_PART={part}"]) for n in reversed(NVP_SIZES) for part in (1, 0)
+  ]  # largest first: the 64-dof instantiations are the critical path
+
+  def compile_one(unit):
+    src, obj, extra = unit
+    cmd = [hipcc, *HIPCC_FLAGS, *dflags, *extra, "-c", str(src), "-o", str(obj)]
+    if verbose:
+      print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+  with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 4)) as pool:
+    list(pool.map(compile_one, units))
+  cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(u[1]) for u in units]]
   if verbose:
-    print(" ".join(cmd))
+    print(" ".join(cmd), flush=True)
   subprocess.run(cmd, check=True)
-  return LIB_PATH
+  return out
 
 
 class NativeLibraryError(RuntimeError):
@@ -104,3 +124,11 @@ def layouts():
 def check(rc: int, what: str) -> None:
   if rc != 0:
     raise RuntimeError(f"{what} failed: {lib().mjlab_last_error().decode()}")
+
+
+if __name__ == "__main__":  # python -m mjlab_amd.native [--out lib.so] [-DNAME ...]
+  import sys
+
+  a = sys.argv[1:]
+  o = Path(a[a.index("--out") + 1]) if "--out" in a else None
+  print(build(force=True, verbose="-v" in a, out=o, defines=tuple(x[2:] for x in a if x.startswith("-D"))))

@@ -1,11 +1,15 @@
 #!/bin/bash
-# Build a library variant and print the register / scratch footprint of the G1 solve kernel.
+# Build a library variant and print the register / scratch footprint of the G1-sized (NVP = 36) kernels.
 # Usage: tools/kbuild.sh <out.so> [-DFOO ...]
 OUT=$(realpath -m $1); shift
-T=/tmp/kb_$(basename $OUT .so); mkdir -p $T
-( cd $T && /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=on --offload-arch=gfx950 -shared -fPIC "$@" --save-temps=obj /root/repo/mjlab_amd/csrc/mjlab_amd.hip -o $T/lib.so 2>&1 | grep -E "error" )
-cp $T/lib.so $OUT
-S=$(ls $T/*gfx950*.s | head -1)
-for K in _Z17k_solve_integrateILi36 _Z10k_position _Z12k_constraint _Z10k_velocity _Z11k_collision; do
-  echo "$K: $(grep -A14 "\.name: *$K" $S | grep -E "vgpr_count|vgpr_spill|sgpr_spill|private_seg" | tr -s ' ' | tr '\n' ' ')"
+python -m mjlab_amd.native --out $OUT "$@" > /dev/null || exit 1
+T=/tmp/kb_$(basename $OUT .so); rm -rf $T; mkdir -p $T
+for PART in 0 1; do
+  ( cd $T && /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=on --offload-arch=gfx950 -fPIC "$@" -DMJLAB_NVP=36 -DMJLAB_NVP_PART=$PART --save-temps=obj \
+      -c /root/repo/mjlab_amd/csrc/nvp_inst.hip -o $T/nvp36_$PART.o 2>&1 | grep -E "error" ) &
+done
+( cd $T && /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=on --offload-arch=gfx950 -fPIC "$@" --save-temps=obj -c /root/repo/mjlab_amd/csrc/mjlab_amd.hip -o $T/abi.o 2>&1 | grep -E "error" ) &
+wait
+for S in $T/*gfx950*.s; do
+  grep -E "^\s+\.(name|vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):" $S | paste - - - - - | sed 's/  */ /g' | grep -E "k_solve_integrate|k_substep|k_control_step|k_position|k_collision|k_velocity|k_constraint|k_presolve"
 done

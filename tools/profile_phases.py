@@ -1,7 +1,6 @@
 """Per-phase shader-clock breakdown of the solve kernel (GPU box).
 
-Build first (in the dev container):  hipcc -O3 -std=c++17 -ffp-contract=on --offload-arch=gfx950 -DMJLAB_PROFILE \
-    -shared -fPIC -o gpurun_prof/libmjlab_amd_prof.so mjlab_amd/csrc/mjlab_amd.hip
+Build first (in the dev container):  python -m mjlab_amd.native --out gpurun_prof/libmjlab_amd_prof.so -DMJLAB_PROFILE
 Run: MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so python tools/profile_phases.py
 """
 import sys
