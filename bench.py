@@ -157,7 +157,7 @@ def main() -> None:
       a_all = torch.rand((info.global_envs, nu), device=dev, generator=learner_gen) * 2 - 1 if info.rank == 0 else None
       action = mdist.scatter_actions(info, a_all, nu, dev)
     else:
-      action = roll.random_action()
+      action = roll.random_action(out=roll.action_buffer)
     if args.balance_every and roll.control_kernel:
       if step_no[0] % args.balance_every == 0:
         roll.balance_worlds()

@@ -66,6 +66,7 @@ def device_index(info: ShardInfo) -> int:
   return info.local_rank % n if n else 0
 
 
+_GATHER_SUPPORTED = True  # cleared when the backend turns out to have no gather (then: all-gather, rank dst keeps the result)
 _GATHER_BUF: dict = {}  # receive buffers, reused across control steps (the result is valid until the next call)
 
 
@@ -91,10 +92,19 @@ def gather_rollout(info: ShardInfo, rows: torch.Tensor, dst: int = 0, to_all: bo
   out = _GATHER_BUF.get(key) if need else None
   if need and (out is None or out.shape[0] != info.global_envs):
     out = _GATHER_BUF[key] = torch.empty((info.global_envs, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-  if to_all:
+  global _GATHER_SUPPORTED
+  if to_all or not _GATHER_SUPPORTED:
+    if out is None:  # a backend without gather: every rank has to take part in the all-gather
+      out = _GATHER_BUF[key] = torch.empty((info.global_envs, rows.shape[1]), dtype=rows.dtype, device=rows.device)
     dist.all_gather_into_tensor(out, rows)
-    return out
-  dist.gather(rows, list(out.chunk(info.world_size)) if info.rank == dst else None, dst=dst)
+    return out if (to_all or info.rank == dst) else None
+  try:
+    dist.gather(rows, list(out.chunk(info.world_size)) if info.rank == dst else None, dst=dst)
+  except (RuntimeError, NotImplementedError) as e:  # raised before anything is enqueued when the backend lacks the op
+    if "gather" not in str(e).lower() and "support" not in str(e).lower():
+      raise
+    _GATHER_SUPPORTED = False  # the same on every rank: all of them fall back to the all-gather from here on
+    return gather_rollout(info, rows, dst, to_all)
   return out
 
 

@@ -129,6 +129,7 @@ class PhysicsRollout:
       time_left = lo_t + (hi_t - lo_t) * torch.rand((n,), device=dev, generator=self.gen)
       self.push = (float(lo_t), float(hi_t), rng6, time_left)
     self._graph: torch.cuda.CUDAGraph | None = None
+    self._action_buf: torch.Tensor | None = None
     self._obs_buf: torch.Tensor | None = None
     # load balance of the control kernel (mjlab_control_t.world_order): see balance_worlds()
     self.world_order: torch.Tensor | None = None
@@ -168,14 +169,16 @@ class PhysicsRollout:
     self.sim.forward()
 
   def step(self, action: torch.Tensor) -> torch.Tensor:
-    """One control step; returns the boolean reset mask.
+    """One control step; returns the reset mask of shape ``(num_envs,)``: int32 (non-zero = reset) with the fused
+    reset -- the array the library wrote, no conversion launch -- and bool with ``fused_reset=False``.
 
     With ``capture_graph()`` done, the whole control step -- action processing, the
     ``decimation`` physics steps, termination test, masked reset and the forward pass -- is
     ONE hipGraph replay (resets are mask based, so there is no
     ``nonzero()`` host sync and nothing data dependent on the host side)."""
     if self._graph is not None:
-      self._action_buf.copy_(action)
+      if action is not self._action_buf:  # random_action(out=...) / a policy may write the static buffer directly
+        self._action_buf.copy_(action)
       self._graph.replay()
       return self._reset_buf
     return self._step_eager(action)
@@ -186,7 +189,8 @@ class PhysicsRollout:
     n = self.sim.num_envs
     dev = self.key_qpos.device
     self._action_buf = torch.zeros((n, self.m.nu), device=dev)
-    self._reset_buf = torch.zeros((n,), dtype=torch.bool, device=dev)
+    # with the fused reset the mask written by the library IS the result (int32, non-zero = reset): no conversion launch
+    self._reset_buf = self._reset_mask if self.fused_reset else torch.zeros((n,), dtype=torch.bool, device=dev)
     sim_graph = self.sim.use_graph
     self.sim.use_graph = False  # nested replays cannot be captured; record the raw launches
     try:
@@ -194,17 +198,23 @@ class PhysicsRollout:
       st = torch.cuda.Stream(device=dev)
       st.wait_stream(torch.cuda.current_stream(dev))
       with torch.cuda.stream(st):
-        self._reset_buf.copy_(self._step_eager(self._action_buf))
+        self._capture_body()
       torch.cuda.current_stream(dev).wait_stream(st)
       g = torch.cuda.CUDAGraph()
       g.register_generator_state(self.gen)
       with torch.cuda.graph(g):
-        self._reset_buf.copy_(self._step_eager(self._action_buf))
+        self._capture_body()
       self._graph = g
     finally:
       self.sim.use_graph = sim_graph
 
+  def _capture_body(self) -> None:
+    r = self._step_eager(self._action_buf)
+    if r is not self._reset_buf:
+      self._reset_buf.copy_(r)
+
   def _step_eager(self, action: torch.Tensor) -> torch.Tensor:
+    """-> the reset mask of this control step: int32 (non-zero = reset) with the fused reset, bool otherwise."""
     d = self.sim.data
     s = self.sim
     n = s.num_envs
@@ -228,7 +238,7 @@ class PhysicsRollout:
         c.push_time_left, c.rnd7, c.push_dt, c.push_interval_lo, c.push_interval_hi, c.push_range = time_left.data_ptr(), rnd7.data_ptr(), dt, lo_t, hi_t, rng6
       with torch.cuda.device(dev):
         native.check(s._lib.mjlab_control_step(ctypes.byref(s._m), ctypes.byref(s._d), ctypes.byref(c), s._stream()), "mjlab_control_step")
-      return self._reset_mask.bool()
+      return self._reset_mask
     target = self.default_joint + action * self.action_scale
     for _ in range(self.decimation // self.substeps_per_call):
       d.ctrl[:] = target
@@ -241,7 +251,7 @@ class PhysicsRollout:
                                   self.min_up_z, s._stream()),
         "mjlab_masked_reset",
       )
-      reset = self._reset_mask.bool()
+      reset = self._reset_mask
     else:
       self.episode_length.add_(1)
       if self.has_free:
@@ -295,9 +305,17 @@ class PhysicsRollout:
     idx = torch.argsort(cost, descending=True)
     self.world_order[self._slot_of_rank] = idx.to(torch.int32)
 
-  def random_action(self) -> torch.Tensor:
-    """``2 U(0,1) - 1`` per actuator (reference scripts/play.py:159-172 "random" agent)."""
-    return torch.rand((self.sim.num_envs, self.m.nu), device=self.key_qpos.device, generator=self.gen) * 2 - 1
+  def random_action(self, out: torch.Tensor | None = None) -> torch.Tensor:
+    """U(-1, 1) per actuator (reference scripts/play.py:159-172 "random" agent: ``2 rand - 1``), one launch;
+    ``out=self.action_buffer`` writes the captured graph's input in place."""
+    if out is None:
+      out = torch.empty((self.sim.num_envs, self.m.nu), device=self.key_qpos.device)
+    return out.uniform_(-1.0, 1.0, generator=self.gen)
+
+  @property
+  def action_buffer(self) -> torch.Tensor | None:
+    """The static action input of the captured control-step graph (None before capture_graph())."""
+    return self._action_buf if self._graph is not None else None
 
   def observation_rows(self) -> torch.Tensor:
     """A policy-observation-sized row per env (99 floats for G1) for the gather path."""

@@ -370,7 +370,7 @@ def test_fused_masked_reset_equals_torch_chain():
       for r in (a, b):
         r.sim.data.qpos[3, 10] = float("nan")
         r.sim.data.qpos[9, 2] = 0.1
-    ra, rb = a.step(act), b.step(act)
+    ra, rb = a.step(act).bool(), b.step(act).bool()  # fused reset: int32 mask (non-zero = reset); torch path: bool
     assert torch.equal(ra, rb), k
     keep = ~ra
     for f in ("qpos", "qvel", "qacc_warmstart"):
