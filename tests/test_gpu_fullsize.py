@@ -524,3 +524,42 @@ def test_fused_launch_structures_are_bit_identical(scene):
   for v in variants[1:]:
     for f in fields:
       assert torch.equal(out[variants[0]][f], out[v][f]), (v, f)
+
+
+def test_solver_optimality_conditions_at_full_size():
+  """Size-independent properties of the constraint solve at BASELINE's full size (4096 G1 worlds on rollout
+  states, no oracle involved): the published constraint force is J^T efc_force; efc_force is the penalty law of
+  the published row residuals (f = -D min(0, J qacc - aref), never negative); and the Newton iteration stopped
+  at a stationary point of MuJoCo's convex cost: the gradient M qacc - qfrc_smooth - J^T f, scaled as the
+  solver scales it (1 / (meaninertia nv)), is at rounding-noise level in all but the few worlds that ran into
+  the 10-iteration cap."""
+  import torch
+
+  src, _, model = _rollout_state("g1_velocity_flat", nworld=4096, steps=12)
+  sim = src
+  sim.forward()
+  torch.cuda.synchronize()
+  d = sim.data
+  n, nv, njmax = 4096, model.nv, sim.njmax
+  J = d.efc_J.view(n, njmax, nv)
+  rows = torch.arange(njmax, device="cuda")[None, :] < d.nefc.view(n, 1)
+  f = torch.where(rows, d.efc_force, torch.zeros_like(d.efc_force))
+  assert float(f.min()) >= 0.0
+  jtf = torch.einsum("wrn,wr->wn", torch.where(rows[..., None], J, torch.zeros_like(J)), f)
+  scale = d.qfrc_constraint.abs().amax(dim=1).clamp_min(1e-3)
+  assert float(((jtf - d.qfrc_constraint).abs().amax(dim=1) / scale).max()) < 2e-5
+  # penalty law of the rows, from the published J, qacc, aref, D
+  jar = torch.einsum("wrn,wn->wr", J, d.qacc) - d.efc_aref
+  law = torch.where(rows & (jar < 0), -d.efc_D * jar, torch.zeros_like(jar))
+  fscale = f.amax(dim=1).clamp_min(1.0)
+  assert float(((law - f).abs().amax(dim=1) / fscale).quantile(0.99)) < 2e-3  # fp32 J qacc - aref: a difference of large terms
+  # stationarity
+  grad = torch.einsum("wij,wj->wi", d.qM, d.qacc) - d.qfrc_smooth - d.qfrc_constraint
+  g = grad.norm(dim=1) / (float(model.meaninertia) * nv)
+  capped = d.solver_niter.view(-1) >= model.opt.iterations
+  assert float(capped.float().mean()) < 0.05
+  assert float(g[~capped].quantile(0.99)) < 1e-4 and float(g[~capped].median()) < 1e-5, (float(g.median()), float(g.quantile(0.99)))
+  # worlds without constraints: qacc is the unconstrained acceleration
+  free = d.nefc.view(-1) == 0
+  if bool(free.any()):
+    assert torch.equal(d.qacc[free], d.qacc_smooth[free])
