@@ -593,3 +593,69 @@ def test_host_side_guards_and_warnings():
 
     Simulation(1, SimulationCfg(nan_guard=NanGuardCfg(enabled=True)), model, "cuda:0")
   torch.cuda.synchronize()
+
+
+def _snake_model(nlink: int):
+  """Free base + a chain of `nlink` hinge links (alternating axes, limited, PD-actuated) lying on the plane:
+  nv = 6 + nlink, so that every padded size the solve / substep / control kernels are instantiated for is hit."""
+  from mjlab_amd import mjcf
+  from mjlab_amd.robots import ActuatorCfg, apply_actuators
+
+  body = ""
+  for i in range(nlink):
+    axis = "0 1 0" if i % 2 else "0 0 1"
+    body += (f'<body name="l{i}" pos="0.08 0 0"><inertial pos="0.04 0 0" mass="0.2" diaginertia="0.0002 0.0006 0.0006"/>'
+             f'<joint name="j{i}" type="hinge" axis="{axis}" range="-0.6 0.6" damping="0.05"/>'
+             f'<geom name="g{i}" type="capsule" size="0.025" fromto="0 0 0 0.08 0 0" contype="1" conaffinity="0"/>')
+  xml = (f'<mujoco model="snake"><compiler angle="radian" autolimits="true"/><option timestep="0.004"/><worldbody>'
+         f'<geom name="floor" type="plane" size="0 0 0.01" contype="0" conaffinity="1"/>'
+         f'<body name="base" pos="0 0 0.03"><inertial pos="0 0 0" mass="1" diaginertia="0.004 0.004 0.004"/><freejoint name="root"/>'
+         f'<geom name="gb" type="sphere" size="0.03" contype="1" conaffinity="0"/>{body}{"</body>" * nlink}</body></worldbody></mujoco>')
+  spec = mjcf.Spec.from_string(xml)
+  spec.option.integrator = mjcf.INT_IMPLICITFAST
+  apply_actuators(spec, (ActuatorCfg([f"j{i}" for i in range(nlink)], effort_limit=5.0, stiffness=8.0, damping=0.4, armature=0.005),))
+  return spec.compile()
+
+
+@pytest.mark.parametrize("nlink,nvp", [(2, 8), (9, 16), (13, 20), (17, 24), (25, 32), (29, 36), (33, 40), (41, 48), (57, 64)])
+def test_every_padded_size_of_the_solve_kernels(nlink, nvp):
+  """One model per template instantiation (nv = 6 + nlink -> NVP), through all three launch structures that
+  carry the solve stage: forward + steps vs the oracle, and the fused kernels bit-identical to the per-stage ones."""
+  import torch
+
+  from mjlab_amd.csrc_sizes import solve_nvp
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = _snake_model(nlink)
+  assert solve_nvp(model.nv) == nvp
+  nw = 16
+  rng = np.random.default_rng(nlink)
+  qpos = np.tile(model.qpos0, (nw, 1))
+  # chains beyond ~45 links lying on the floor give an fp32 Newton Hessian the fp32 build of the restatement cannot
+  # factor either (cond(M) 1e5 x contact stiffness): the long ones hover, their rows are joint limits (yaw beyond +-0.6)
+  lifted = nlink > 40
+  qpos[:, 2] = (0.3 if lifted else 0.024) + rng.uniform(0, 0.01, nw)
+  amp = np.where(np.arange(nlink) % 2, 0.01, 0.66 if lifted else 0.3)  # yaw joints bend the chain in the plane, pitch joints barely lift it
+  qpos[:, 7:] = rng.uniform(-1, 1, (nw, nlink)) * amp
+  qvel = rng.normal(0, 0.3, (nw, model.nv))
+  ctrl = rng.uniform(-0.4, 0.4, (nw, model.nu))
+  ora = OracleSim(model, nw, njmax=480)
+  ora.qpos[:], ora.qvel[:], ora.ctrl[:] = qpos, qvel, ctrl
+  ora.forward()
+  out = {}
+  for fuse in ("stage", "step"):
+    sim = Simulation(nw, SimulationCfg(njmax=480, fuse=fuse), model, "cuda:0")
+    for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+      getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+    sim.forward()
+    if fuse == "stage":
+      assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel()) and ora.nefc.mean() > (1 if lifted else 4) and ora.nefc.max() < 480
+      assert _rel(_np(sim.data.qM), ora.qM) < 2e-6
+      assert _rel(_np(sim.data.qacc), ora.qacc) < (2e-4 if nlink < 30 else 5e-3)  # long chains: cond(M) 1e4 .. 1e5
+    sim.step()
+    sim.step(3)
+    out[fuse] = {f: _np(getattr(sim.data, f)).copy() for f in ("qpos", "qvel", "qacc", "efc_force", "xpos")}
+  ora.step(4)
+  assert _rel(out["stage"]["qpos"], ora.qpos) < (2e-5 if nlink < 30 else 2e-4) and _rel(out["stage"]["qvel"], ora.qvel) < (2e-3 if nlink < 30 else 2e-2)
+  for f in out["stage"]:
+    assert np.array_equal(out["stage"][f], out["step"][f]), f
