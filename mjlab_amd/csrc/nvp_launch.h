@@ -13,8 +13,13 @@ struct NvpLaunch {
   nvp_substep_fn step;     // k_substep<NVP, true>: nsub physics steps    (part 1)
   nvp_control_fn control;  // k_control_step<NVP>                         (part 1)
 };
+#ifdef MJLAB_NVP_ONLY  // experiment builds (tools/ab_bench.sh): a library that carries one size only
+#define MJLAB_NVP_SIZES(X) X(MJLAB_NVP_ONLY)
+#else
 #define MJLAB_NVP_SIZES(X) X(8) X(16) X(20) X(24) X(32) X(36) X(40) X(48) X(64)
-#define MJLAB_NVP_DECL_(N)                                                                                                        \
+#endif
+#define MJLAB_NVP_DECL_(N) MJLAB_NVP_DECL2_(N)
+#define MJLAB_NVP_DECL2_(N)                                                                                                       \
   hipError_t mjlab_nvp_solve_##N(const mjlab_model_t*, const mjlab_data_t*, int, int, int, int, hipStream_t);                      \
   hipError_t mjlab_nvp_forward_##N(const mjlab_model_t*, const mjlab_data_t*, int, int, int, hipStream_t);                         \
   hipError_t mjlab_nvp_step_##N(const mjlab_model_t*, const mjlab_data_t*, int, int, int, hipStream_t);                            \
@@ -23,7 +28,8 @@ MJLAB_NVP_SIZES(MJLAB_NVP_DECL_)
 #ifdef MJLAB_MAIN_TU
 static const NvpLaunch* nvp_launch(int nvp) {
   switch (nvp) {
-#define MJLAB_NVP_CASE_(N) \
+#define MJLAB_NVP_CASE_(N) MJLAB_NVP_CASE2_(N)
+#define MJLAB_NVP_CASE2_(N) \
   case N: { static const NvpLaunch t = {mjlab_nvp_solve_##N, mjlab_nvp_forward_##N, mjlab_nvp_step_##N, mjlab_nvp_control_##N}; return &t; }
     MJLAB_NVP_SIZES(MJLAB_NVP_CASE_)
   }

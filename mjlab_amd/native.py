@@ -26,7 +26,8 @@ STAGE_POSITION, STAGE_COLLISION, STAGE_VELOCITY, STAGE_CONSTRAINT, STAGE_SOLVE, 
 STAGE_FORWARD, STAGE_STEP = 31, 63
 
 
-def build(force: bool = False, verbose: bool = False, out: Path | None = None, defines: tuple[str, ...] = (), jobs: int | None = None) -> Path:
+def build(force: bool = False, verbose: bool = False, out: Path | None = None, defines: tuple[str, ...] = (), jobs: int | None = None,
+          only_size: int | None = None) -> Path:
   """Compile the HIP extension for gfx950 (cross-compiles without a GPU): mjlab_amd.hip (C ABI + the kernels that
   do not depend on the padded dof count) and nvp_inst.hip twice per padded size, in parallel, then one link.
   ``out`` / ``defines`` build a variant somewhere else (profiling build: ``defines=("MJLAB_PROFILE",)``)."""
@@ -39,9 +40,10 @@ def build(force: bool = False, verbose: bool = False, out: Path | None = None, d
   hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
   objdir = CSRC / "build" / (out.stem + ("_" + "_".join(defines) if defines else ""))
   objdir.mkdir(parents=True, exist_ok=True)
-  dflags = [f"-D{x}" for x in defines]
+  dflags = [f"-D{x}" for x in defines] + ([f"-DMJLAB_NVP_ONLY={only_size}"] if only_size else [])
+  sizes = (only_size,) if only_size else NVP_SIZES  # only_size: an experiment library for models of one padded size (A/B runs)
   units = [(CSRC / "mjlab_amd.hip", objdir / "abi.o", [])] + [
-    (CSRC / "nvp_inst.hip", objdir / f"nvp_{n}_{part}.o", [f"-DMJLAB_NVP={n}", f"-DMJLAB_NVP_PART={part}"]) for n in reversed(NVP_SIZES) for part in (1, 0)
+    (CSRC / "nvp_inst.hip", objdir / f"nvp_{n}_{part}.o", [f"-DMJLAB_NVP={n}", f"-DMJLAB_NVP_PART={part}"]) for n in reversed(sizes) for part in (1, 0)
   ]  # largest first: the 64-dof instantiations are the critical path
 
   def compile_one(unit):
@@ -131,4 +133,5 @@ if __name__ == "__main__":  # python -m mjlab_amd.native [--out lib.so] [-DNAME 
 
   a = sys.argv[1:]
   o = Path(a[a.index("--out") + 1]) if "--out" in a else None
-  print(build(force=True, verbose="-v" in a, out=o, defines=tuple(x[2:] for x in a if x.startswith("-D"))))
+  only = int(a[a.index("--only") + 1]) if "--only" in a else None
+  print(build(force=True, verbose="-v" in a, out=o, defines=tuple(x[2:] for x in a if x.startswith("-D")), only_size=only))
