@@ -155,8 +155,11 @@ __global__ __launch_bounds__(64, 4) void k_substep(const Model m_, const Data d_
 // One CONTROL step of one world per wave (mjlab_control_step): action -> ctrl, nsubstep physics steps,
 // termination test + reset, forward(), interval push -- the physics-facing part of the reference's
 // ManagerBasedRlEnv.step (envs/manager_based_rl_env.py:106-139) without a kernel boundary in between.
+#ifndef MJLAB_WPE
+#define MJLAB_WPE 4  // waves per SIMD the fused kernels are compiled for (512 / MJLAB_WPE registers per lane)
+#endif
 template <int NVP>
-__global__ __launch_bounds__(64, 4) void k_control_step(const Model m_, const Data d_, const mjlab_control_t c, const int fold) {
+__global__ __launch_bounds__(64, MJLAB_WPE) void k_control_step(const Model m_, const Data d_, const mjlab_control_t c, const int fold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef MJLAB_PROFILE
   const long long t_begin_ = clock64();

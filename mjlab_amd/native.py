@@ -41,6 +41,7 @@ def build(force: bool = False, verbose: bool = False, out: Path | None = None, d
   objdir = CSRC / "build" / (out.stem + ("_" + "_".join(defines) if defines else ""))
   objdir.mkdir(parents=True, exist_ok=True)
   dflags = [f"-D{x}" for x in defines] + ([f"-DMJLAB_NVP_ONLY={only_size}"] if only_size else [])
+  dflags += os.environ.get("MJLAB_HIPCC_EXTRA", "").split()  # compiler-flag experiments
   sizes = (only_size,) if only_size else NVP_SIZES  # only_size: an experiment library for models of one padded size (A/B runs)
   units = [(CSRC / "mjlab_amd.hip", objdir / "abi.o", [])] + [
     (CSRC / "nvp_inst.hip", objdir / f"nvp_{n}_{part}.o", [f"-DMJLAB_NVP={n}", f"-DMJLAB_NVP_PART={part}"]) for n in reversed(sizes) for part in (1, 0)
