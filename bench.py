@@ -117,6 +117,9 @@ def main() -> None:
   ap.add_argument("--balance-every", type=int, default=0,
                   help="re-deal the worlds over the SIMDs by expected cost every this many control steps (0 = never; "
                   "control kernel only; results unchanged)")
+  ap.add_argument("--readback", action="store_true",
+                  help="refresh EntityData's derived quantities (body / root poses and velocities, projected gravity, joint state) "
+                  "in the control kernel's epilogue (mjlab_control_t.readback_on; control kernel only)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--seed", type=int, default=42)
   args = ap.parse_args()
@@ -139,6 +142,10 @@ def main() -> None:
                         masked_forward=args.masked_forward, fused_reset=not args.torch_reset,
                         min_height=0.3 if robot == "g1" else 0.15, substeps_per_call=args.substeps_per_call,
                         control_kernel=not args.no_control_kernel and args.fuse == "step" and not args.torch_reset, **events)
+  if args.readback and roll.control_kernel:
+    from mjlab_amd.entity_data import EntityReadback
+
+    roll.readback = EntityReadback(sim)
   step_graph = not args.no_graph and not args.no_step_graph
   if step_graph:
     roll.capture_graph()
@@ -340,7 +347,8 @@ def main() -> None:
         "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL action broadcast and obs gather to the learner (rank 0) every control step" if exchange else ""),
         "graph": "one hipGraph per control step" if step_graph else ("per-call step/forward hipGraphs" if sim.use_graph else "none"),
         "launches": {"stage": "one kernel per stage (5 per substep)", "presolve": "pre-solve stages fused (2 per substep)", "step": "one kernel per substep"}[args.fuse]
-        + (", whole control step (action, 4 substeps, reset, forward, push) in ONE launch (mjlab_control_step)" if roll.control_kernel
+        + (", whole control step (action, 4 substeps, reset, forward" + (", EntityData read-back" if roll.readback is not None else "")
+           + ", push) in ONE launch (mjlab_control_step)" if roll.control_kernel
            else (f", {args.substeps_per_call} substeps per Simulation.step() call" if args.substeps_per_call > 1 else "")),
         "forward_after_reset": "reset worlds only (extension)" if args.masked_forward else "all worlds (reference behaviour)",
         "forward_fold": "off" if args.no_fold else "step() after forward() skips the stages that depend on qpos/qvel only where both are unchanged (bit-exact)",

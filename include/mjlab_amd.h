@@ -156,6 +156,7 @@ int mjlab_interval_push(const mjlab_model_t* m, const mjlab_data_t* d, float* ti
  *   key_qpos != NULL: termination test + reset, the arguments and semantics of mjlab_masked_reset
  *   forward_mode:     0 none, 1 forward() on every world (the reference's behaviour whenever any env was
  *                     reset), 2 on the reset worlds only (mjlab_forward_masked's extension)
+ *   readback_on:      the fused EntityData read-back (mjlab_entity_readback) of the forwarded state
  *   push_time_left != NULL: the interval push, the arguments and semantics of mjlab_interval_push
  * Results are bit-identical to the same sequence of separate calls. */
 typedef struct mjlab_control {
@@ -174,8 +175,12 @@ typedef struct mjlab_control {
   const float* rnd7;          /* (nworld, 7) */
   float min_height, min_up_z, push_dt, push_interval_lo, push_interval_hi;
   mjlab_push_range_t push_range;
+  int readback_on, pad2_;       /* non-zero: mjlab_entity_readback's outputs are refreshed by the same launch, right after the
+                                   forward() pass ("emitted by the step kernel's epilogue") */
+  mjlab_entity_view_t readback; /* by value: the view's pointers are device pointers */
 } mjlab_control_t;
 int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, void* stream);
+int mjlab_sizeof_control(void); /* sizeof(mjlab_control_t), for bindings that mirror the struct */
 
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);

@@ -21,9 +21,7 @@ __device__ __forceinline__ void vel_from_cvel(float* out6, const float* pos, con
   for (int k = 0; k < 3; ++k) { out6[k] = cv[3 + k] - c[k]; out6[3 + k] = cv[k]; }
 }
 
-#ifdef MJLAB_MAIN_TU
-__global__ __launch_bounds__(64) void k_entity_readback(const Model m, const Data d, const mjlab_entity_view_t v) {
-  const int w = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void entity_readback_world(const Model& m, const Data& d, const mjlab_entity_view_t& v, const int w, const int lane) {
   const int nb = m.size.nbody, nq = m.size.nq, nv = m.size.nv;
   const float* sub = d.subtree_com + ((size_t)w * nb + v.root_body_id) * 3;
   const float sc[3] = {sub[0], sub[1], sub[2]};
@@ -82,7 +80,10 @@ __global__ __launch_bounds__(64) void k_entity_readback(const Model m, const Dat
     if (v.joint_acc) v.joint_acc[wj] = d.qacc[(size_t)w * nv + v.joint_v_adr[j]];
   }
 }
-
+#ifdef MJLAB_MAIN_TU
+__global__ __launch_bounds__(64) void k_entity_readback(const Model m, const Data d, const mjlab_entity_view_t v) {
+  entity_readback_world(m, d, v, blockIdx.x, threadIdx.x);
+}
 #endif  // MJLAB_MAIN_TU
 
 // ====================================================================================

@@ -193,6 +193,11 @@ __global__ __launch_bounds__(64, MJLAB_WPE) void k_control_step(const Model m_, 
     __syncthreads();
     if (fwd) { FUSED_ARGS; fold_snapshot(m, d, w, lane); }
   }
+  if (c.readback_on) {  // EntityData's derived quantities of the state just forwarded, before the push touches qvel
+    FUSED_ARGS;
+    __syncthreads();
+    entity_readback_world(m, d, c.readback, w, lane);
+  }
   if (c.push_time_left) {
     FUSED_ARGS;
     __syncthreads();

@@ -20,6 +20,12 @@ from .mjcf import JNT_FREE, Model
 from .sim import Simulation
 
 
+def _entity_view_struct():
+  from .entity_data import _View
+
+  return _View
+
+
 class _PushRange(ctypes.Structure):
   _fields_ = [("lo", ctypes.c_float * 6), ("hi", ctypes.c_float * 6)]
 
@@ -34,6 +40,7 @@ class _Control(ctypes.Structure):
     ("env_origins", ctypes.c_void_p), ("world_order", ctypes.c_void_p), ("push_time_left", ctypes.c_void_p), ("rnd7", ctypes.c_void_p),
     ("min_height", ctypes.c_float), ("min_up_z", ctypes.c_float), ("push_dt", ctypes.c_float),
     ("push_interval_lo", ctypes.c_float), ("push_interval_hi", ctypes.c_float), ("push_range", _PushRange),
+    ("readback_on", ctypes.c_int), ("pad2_", ctypes.c_int), ("readback", _entity_view_struct()),
   ]  # fmt: skip
 
 
@@ -132,6 +139,7 @@ class PhysicsRollout:
     self._action_buf: torch.Tensor | None = None
     self._obs_buf: torch.Tensor | None = None
     # load balance of the control kernel (mjlab_control_t.world_order): see balance_worlds()
+    self.readback = None  # an mjlab_amd.entity_data.EntityReadback to be refreshed by the control kernel
     self.world_order: torch.Tensor | None = None
     self._slot_of_rank: torch.Tensor | None = None
     # start at random episode phase like the reference (train.py:109-111 init_at_random_ep_len)
@@ -233,6 +241,9 @@ class PhysicsRollout:
       c.env_origins = 0 if self.env_origins is None else self.env_origins.data_ptr()
       c.min_height, c.min_up_z = float(self.min_height), self.min_up_z
       c.world_order = 0 if self.world_order is None else self.world_order.data_ptr()
+      if self.readback is not None:  # EntityReadback whose outputs this launch refreshes
+        c.readback_on = 1
+        ctypes.memmove(ctypes.byref(c.readback), ctypes.byref(self.readback._view), ctypes.sizeof(c.readback))
       if self.push is not None:
         lo_t, hi_t, rng6, time_left = self.push
         c.push_time_left, c.rnd7, c.push_dt, c.push_interval_lo, c.push_interval_hi, c.push_range = time_left.data_ptr(), rnd7.data_ptr(), dt, lo_t, hi_t, rng6

@@ -48,6 +48,17 @@ def test_no_cpu_fallback():
     Simulation(2, SimulationCfg(), robots.pendulum_model(), "cpu")
 
 
+def test_control_struct_mirror_matches_the_library():
+  import ctypes
+
+  from mjlab_amd.entity_data import _View
+  from mjlab_amd.rollout import _Control, _PushRange
+
+  L = native.lib()
+  assert ctypes.sizeof(_Control) == L.mjlab_sizeof_control()
+  assert ctypes.sizeof(_PushRange) == 48 and ctypes.sizeof(_View) % 8 == 0
+
+
 def test_product_does_not_import_oracle():
   for p in (ROOT / "mjlab_amd").rglob("*.py"):
     txt = p.read_text()

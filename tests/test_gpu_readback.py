@@ -121,3 +121,30 @@ def test_readback_matches_vectors_from_the_reference_code():
   for name in ("projected_gravity_b", "root_link_lin_vel_b", "root_link_ang_vel_b", "root_com_lin_vel_b", "root_com_ang_vel_b"):
     close(getattr(ent, name), name)
   close(ent.heading_w, "heading_w", 1e-5)
+
+
+def test_readback_from_the_control_kernel_epilogue_equals_the_separate_launch():
+  """SURVEY.md section 8f row 1 literally: the derived EntityData quantities "emitted by the step kernel's epilogue" --
+  mjlab_control_t.readback_on refreshes them inside the one control-step launch, right after the forward() pass
+  (before the interval push changes qvel); bit-identical to mjlab_entity_readback called after a forward()."""
+  import torch
+
+  from mjlab_amd import robots
+  from mjlab_amd.entity_data import EntityReadback
+  from mjlab_amd.rollout import VELOCITY_TASK_EVENTS, PhysicsRollout, g1_action_scale
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = robots.load_model("g1_velocity_flat")
+  sim = Simulation(512, SimulationCfg(njmax=300), model, "cuda:0")
+  ev = dict(VELOCITY_TASK_EVENTS["g1"])
+  ev["push"] = None  # so that the state after the launch is the state the epilogue saw
+  roll = PhysicsRollout(sim, action_scale=g1_action_scale(model), seed=5, substeps_per_call=4, control_kernel=True, **ev)
+  fused, separate = EntityReadback(sim), EntityReadback(sim)
+  roll.readback = fused
+  for _ in range(8):
+    roll.step(roll.random_action())
+  separate.update()
+  torch.cuda.synchronize()
+  for name in ("body_link_pose_w", "body_link_vel_w", "body_com_pose_w", "body_com_vel_w", "_root", "joint_pos", "joint_vel", "joint_acc"):
+    a, b = getattr(fused, name), getattr(separate, name)
+    assert float(a.abs().max()) > 0 and torch.equal(a, b), name
