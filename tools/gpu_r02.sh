@@ -27,7 +27,7 @@ done
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $R/$OUT/pmc_SQ -o pmc -- $BCMD > $R/$OUT/pmc_SQ.log 2>&1); echo "pmc SQ rc=$?" | tee -a $OUT/status.txt
 python tools/reduce_pmc.py $OUT/pmc_SQ/pmc_counter_collection.csv
 if [ -f gpurun_prof/libmjlab_amd_prof.so ]; then
-  MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/profile_phases.py > $OUT/phases.log 2>&1; FUSE=step MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/profile_phases.py > $OUT/phases_fused.log 2>&1; echo "phases rc=$?" | tee -a $OUT/status.txt
+  MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/tail_profile.py > $OUT/tail_profile.log 2>&1; MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/profile_phases.py > $OUT/phases.log 2>&1; FUSE=step MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 300 python tools/profile_phases.py > $OUT/phases_fused.log 2>&1; echo "phases rc=$?" | tee -a $OUT/status.txt
 fi
 find $OUT -name "*.db" -delete; find $OUT -name "*.csv" -size +8M -delete
 cat $OUT/status.txt; for f in bench bench_noevents bench_stage bench_step1 bench_step4; do python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1], round(d['value']), d['ms_per_step'], d['roofline']['kernel'], d['roofline']['kernel_ms'], d['roofline']['frac'])" $OUT/$f.json; done
