@@ -63,6 +63,7 @@
 /* ---- model: real; each carries a per-world stride (0 = shared, else elements) -- */
 #define MJLAB_MODEL_REAL_FIELDS(X)                                              \
   X(qpos0, 1, nq)                                                               \
+  X(qpos_spring, 1, nq) /* reference pose of the joint springs (springref) */    \
   X(body_pos, 3, nbody)                                                         \
   X(body_quat, 4, nbody)                                                        \
   X(body_ipos, 3, nbody)                                                        \

@@ -175,7 +175,7 @@ __device__ __forceinline__ void stage_velocity(const Model& m, const Data& d, co
     float bias = 0.f;
     for (int k = 0; k < 6; ++k) bias += c6[k] * s_cfs[6 * v_body + k];
     float passive = -v_damp * s_qvel[i];
-    if (v_type != MJLAB_JNT_FREE && v_stiff != 0.f) passive -= v_stiff * (qpos[v_qadr] - MF(qpos0)[v_qadr]);
+    if (v_type != MJLAB_JNT_FREE && v_stiff != 0.f) passive -= v_stiff * (qpos[v_qadr] - MF(qpos_spring)[v_qadr]);  // springref, not qpos0
     float smooth = passive - bias + v_applied + s_qact[i];
     if (xmask) {
       const float* xfrc = d.xfrc_applied + (size_t)w * 6 * nb;

@@ -29,7 +29,7 @@ _BASE_INT = (
   "sensor_type", "sensor_objtype", "sensor_objid", "sensor_reftype", "sensor_refid", "sensor_intprm", "sensor_dim", "sensor_adr",
 )  # fmt: skip
 _BASE_REAL = (
-  "qpos0", "body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_subtreemass", "body_inertia", "body_invweight0",
+  "qpos0", "qpos_spring", "body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_subtreemass", "body_inertia", "body_invweight0",
   "jnt_pos", "jnt_axis", "jnt_range", "jnt_margin", "jnt_stiffness", "jnt_solref", "jnt_solimp",
   "dof_armature", "dof_damping", "dof_frictionloss", "dof_invweight0", "dof_solref", "dof_solimp", "dof_M0",
   "geom_size", "geom_pos", "geom_quat", "geom_friction", "geom_solref", "geom_solimp", "geom_solmix", "geom_margin", "geom_gap",

@@ -143,6 +143,7 @@ class SpecJoint:
   stiffness: float = 0.0
   margin: float = 0.0
   ref: float = 0.0
+  springref: float = 0.0
   solref: np.ndarray = field(default_factory=lambda: np.array([0.02, 1.0]))
   solimp: np.ndarray = field(default_factory=lambda: np.array([0.9, 0.95, 0.001, 0.5, 2.0]))
   body: "SpecBody | None" = None
@@ -549,6 +550,7 @@ class _MjcfParser:
       stiffness=float(a.get("stiffness", 0)),
       margin=float(a.get("margin", 0)),
       ref=float(a.get("ref", 0)) * (self.angle_scale if jtype == JNT_HINGE else 1.0),
+      springref=float(a.get("springref", 0)) * (self.angle_scale if jtype == JNT_HINGE else 1.0),
       body=body,
     )
     if "solreflimit" in a:
@@ -716,6 +718,8 @@ class Model:
           setattr(m.opt, name, tuple(val) if isinstance(val, list) else val)
         elif kind == "n":
           m.names[name] = [str(s) for s in v.tolist()]
+    if not hasattr(m, "qpos_spring"):  # saved before the field existed: no springref in those models
+      m.qpos_spring = np.asarray(m.qpos0, dtype=np.float64).copy()
     if not hasattr(m, "tgrid_ztop"):  # saved before the static-geometry / terrain fields existed
       static = m.body_weldid[m.geom_bodyid] == 0
       m.nstaticgeom = int(np.argmin(static)) if not static.all() else m.ngeom
@@ -1075,6 +1079,7 @@ def _compile(spec: Spec) -> Model:
   m.jnt_solimp = np.array([j.solimp for j in joints], f64).reshape(njnt, 5)
 
   m.qpos0 = np.zeros(nq, f64)
+  m.qpos_spring = np.zeros(nq, f64)  # mjModel.qpos_spring: reference pose of the joint springs (springref; free joints: qpos0)
   m.dof_bodyid = np.zeros(nv, np.int32)
   m.dof_jntid = np.zeros(nv, np.int32)
   m.dof_parentid = np.full(nv, -1, np.int32)
@@ -1089,9 +1094,11 @@ def _compile(spec: Spec) -> Model:
       b = j.body
       m.qpos0[qa : qa + 3] = b.pos
       m.qpos0[qa + 3 : qa + 7] = quat_normalize(b.quat)
+      m.qpos_spring[qa : qa + 7] = m.qpos0[qa : qa + 7]
       nd = 6
     else:
       m.qpos0[qa] = j.ref
+      m.qpos_spring[qa] = j.springref
       nd = 1
     for k in range(nd):
       m.dof_bodyid[da + k] = m.jnt_bodyid[ji]

@@ -974,13 +974,13 @@ static void smooth_forces(const mjo_model_t* m, mjo_data_t* d, int w) {
   real *qpos = D(qpos, s->nq), *qvel = D(qvel, nv), *ctrl = D(ctrl, nu);
   real *passive = D(qfrc_passive, nv), *qact = D(qfrc_actuator, nv), *aforce = D(actuator_force, nu);
   real *smooth = D(qfrc_smooth, nv), *bias = D(qfrc_bias, nv), *applied = D(qfrc_applied, nv);
-  const real *damping = MF(dof_damping, w), *stiff = MF(jnt_stiffness, w), *qpos0 = MF(qpos0, w);
-  /* passive: joint springs (reference pose = qpos0) and dof damping */
+  const real *damping = MF(dof_damping, w), *stiff = MF(jnt_stiffness, w), *qspring = MF(qpos_spring, w);
+  /* passive: joint springs about mjModel.qpos_spring (springref, NOT qpos0) and dof damping */
   for (int i = 0; i < nv; i++) passive[i] = -damping[i] * qvel[i];
   for (int j = 0; j < s->njnt; j++) {
     if (stiff[j] == 0 || m->jnt_type[j] == MJLAB_JNT_FREE) continue;
     int qa = m->jnt_qposadr[j];
-    passive[m->jnt_dofadr[j]] -= stiff[j] * (qpos[qa] - qpos0[qa]);
+    passive[m->jnt_dofadr[j]] -= stiff[j] * (qpos[qa] - qspring[qa]);
   }
   /* actuation: joint transmission, fixed gain, affine bias */
   memset(qact, 0, sizeof(real) * nv);

@@ -400,7 +400,7 @@ def test_capacity_paths_with_hundreds_of_contacts(njmax):
     assert float(cost_gpu[w]) <= cost_o * 1.05 + 1e-6, (w, float(cost_gpu[w]), cost_o)
 
 
-@pytest.mark.parametrize("variant", ["impratio", "direct_solref", "margin_gap", "solimp_power", "euler_damped"])
+@pytest.mark.parametrize("variant", ["impratio", "direct_solref", "margin_gap", "solimp_power", "euler_damped", "springs"])
 def test_parameter_branches_match_oracle(variant):
   """Less-travelled branches of the constraint parameter code (impratio scaling of the pyramid
   regulariser, negative solref = direct stiffness/damping, geom margin/gap, solimp power != 2,
@@ -426,6 +426,11 @@ def test_parameter_branches_match_oracle(variant):
   elif variant == "euler_damped":
     model.opt.integrator = mjcf.INT_EULER
     model.dof_damping = np.where(np.arange(model.nv) >= model.nv - 2, 0.8, 0.0)
+  elif variant == "springs":  # joint springs pull towards mjModel.qpos_spring (springref), which is NOT qpos0
+    hinge_or_slide = np.asarray(model.jnt_type) != mjcf.JNT_FREE
+    model.jnt_stiffness = np.where(hinge_or_slide, 25.0, 0.0)
+    model.qpos_spring = np.asarray(model.qpos_spring, dtype=np.float64).copy()
+    model.qpos_spring[np.asarray(model.jnt_qposadr)[hinge_or_slide]] += 0.04
   nworld = 8
   qpos, qvel, ctrl = golden_inputs(model, nworld, 23)
   sim = Simulation(nworld, SimulationCfg(njmax=64, use_graph=False), model, "cuda:0")
