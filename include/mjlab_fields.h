@@ -82,6 +82,8 @@
   X(dof_armature, 1, nv)                                                        \
   X(dof_damping, 1, nv)                                                         \
   X(dof_frictionloss, 1, nv)                                                    \
+  X(dof_solref, 2, nv) /* solreffriction / solimpfriction of the dof's joint: friction-loss rows */ \
+  X(dof_solimp, 5, nv)                                                          \
   X(dof_invweight0, 1, nv)                                                      \
   X(geom_size, 3, ngeom)                                                        \
   X(geom_pos, 3, ngeom)                                                         \
@@ -154,6 +156,7 @@
   X(efc_D, 1, njmax)                                                            \
   X(efc_aref, 1, njmax)                                                         \
   X(efc_force, 1, njmax)                                                        \
+  X(efc_frictionloss, 1, njmax) /* written for the friction-loss rows only: rows [0, nf) */ \
   X(sh_qpos, 1, nq) /* qpos / qvel as they were at the last forward(): see fold_valid */ \
   X(sh_qvel, 1, nv)                                                             \
   X(profile, 64, one) /* per-world per-phase cycle counts; written only by -DMJLAB_PROFILE builds */
@@ -162,6 +165,7 @@
 #define MJLAB_DATA_INT_FIELDS(X)                                                \
   X(ncon, 1, one)                                                               \
   X(nefc, 1, one)                                                               \
+  X(nf, 1, one) /* friction-loss rows: the first nf of the nefc rows (dofs with dof_frictionloss > 0, dof order) */ \
   X(solver_niter, 1, one)                                                       \
   X(world_mask, 1, one) /* mjlab_forward_masked: worlds with 0 are skipped */     \
   X(fold_valid, 1, one) /* 1: position / collision / constraint arrays are those of (sh_qpos, sh_qvel) */ \
@@ -181,7 +185,8 @@ enum {
 };
 enum { MJLAB_OBJ_BODY = 1, MJLAB_OBJ_XBODY = 2, MJLAB_OBJ_GEOM = 5, MJLAB_OBJ_SITE = 6 };
 enum { MJLAB_INT_EULER = 0, MJLAB_INT_IMPLICITFAST = 3 };
-enum { MJLAB_EFC_LIMIT = 3, MJLAB_EFC_CONTACT_FRICTIONLESS = 4, MJLAB_EFC_CONTACT_PYRAMIDAL = 5 };
+/* mjtConstraint (reference typings/mujoco/_enums.pyi:1029): values of efc_type */
+enum { MJLAB_EFC_FRICTION_DOF = 1, MJLAB_EFC_LIMIT = 3, MJLAB_EFC_CONTACT_FRICTIONLESS = 5, MJLAB_EFC_CONTACT_PYRAMIDAL = 6 };
 
 /* Sizes shared by model and data (host struct, passed by pointer). */
 typedef struct mjlab_sizes {
@@ -200,7 +205,7 @@ typedef struct mjlab_sizes {
 /* mjlab_data_t.overflow: capacity overflows, which DROP work silently otherwise */
 enum {
   MJLAB_OVF_NCONMAX = 1, /* contacts beyond sizes.nconmax were dropped */
-  MJLAB_OVF_NJMAX = 2,   /* a limit row or a contact's rows did not fit sizes.njmax and were dropped */
+  MJLAB_OVF_NJMAX = 2,   /* a friction-loss row, a limit row or a contact's rows did not fit sizes.njmax and were dropped */
   MJLAB_OVF_TCAND = 4    /* a moving geom had more than MJLAB_TCAND_MAX terrain boxes within reach */
 };
 /* terrain boxes kept per moving geom and step: the MJLAB_TCAND_MAX with the smallest ids */
@@ -238,7 +243,12 @@ enum {
   /* launch structure (results are bit-identical either way): the four pre-solve stages in one
    * kernel, or a whole forward() / step() substep in one kernel, instead of one kernel per stage */
   MJLAB_OPT_FUSE_PRESOLVE = 8,
-  MJLAB_OPT_FUSE_STEP = 16
+  MJLAB_OPT_FUSE_STEP = 16,
+  /* model.dof_frictionloss may hold non-zero values: the constraint stage reads it and builds the friction-loss
+   * rows (mj_instantiateFriction).  Bit clear: the field is not read and no such rows exist (the reference's robots
+   * have none; its `randomize_field("dof_frictionloss")` is what sets values later -- the host side sets the bit
+   * when the field is non-zero at construction, expanded per world, or handed out writable) */
+  MJLAB_OPT_FRICTIONLOSS = 32
 };
 
 #define MJLAB_DECL_INT_(name, ncol, count) const int* name;

@@ -45,7 +45,7 @@ class Option(ctypes.Structure):
 
 
 # mjlab_option_t.flags (include/mjlab_fields.h)
-OPT_FOLD_FORWARD, OPT_LITERAL_TERMINATION, OPT_WARMSTART_AT_ADVANCE, OPT_FUSE_PRESOLVE, OPT_FUSE_STEP = 1, 2, 4, 8, 16
+OPT_FOLD_FORWARD, OPT_LITERAL_TERMINATION, OPT_WARMSTART_AT_ADVANCE, OPT_FUSE_PRESOLVE, OPT_FUSE_STEP, OPT_FRICTIONLOSS = 1, 2, 4, 8, 16, 32
 # mjlab_data_t.overflow bits
 OVF_NCONMAX, OVF_NJMAX, OVF_TCAND = 1, 2, 4
 
@@ -118,7 +118,9 @@ def fill_option(m: Model) -> Option:
   o.ls_iterations = m.opt.ls_iterations
   o.integrator = m.opt.integrator
   o.cone = m.opt.cone
-  o.flags = 0
+  import numpy as np
+
+  o.flags = OPT_FRICTIONLOSS if np.any(np.asarray(m.dof_frictionloss) != 0) else 0
   return o
 
 

@@ -1,10 +1,10 @@
-// stage_constraint.h -- stage 4: limits + contacts -> efc rows, contact sensors.
+// stage_constraint.h -- stage 4: friction loss + limits + contacts -> efc rows, contact sensors.
 // Part of kernels.h (included there, in this order, by every translation unit of the library); not a
 // stand-alone header.
 #pragma once
 
 // ====================================================================================
-// Stage 4: constraints (mj_makeConstraint: joint limits + contacts; contact sensors)
+// Stage 4: constraints (mj_makeConstraint: dof friction loss, joint limits, contacts; contact sensors)
 // ====================================================================================
 __device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
   const float dmin = clipf(solimp[0], MINIMP, MAXIMP), dmax = clipf(solimp[1], MINIMP, MAXIMP);
@@ -56,7 +56,8 @@ enum {
   CC_DIM = 27,    // condim (int bits)
   CC_NROWS = 28
 };
-__host__ __device__ inline int constraint_nlim(const mjlab_sizes_t& s) { return 2 * s.njnt < s.njmax ? 2 * s.njnt : s.njmax; }
+// capacity of the unit-row list: friction-loss rows (<= nv) + limit rows (<= 2 per joint)
+__host__ __device__ inline int constraint_nlim(const mjlab_sizes_t& s) { return s.nv + 2 * s.njnt < s.njmax ? s.nv + 2 * s.njnt : s.njmax; }
 __host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) {
   return s.nconmax + 2 * constraint_nlim(s) + CC_NROWS * 64;
 }
@@ -66,20 +67,46 @@ __device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, 
   const int nlim = constraint_nlim(m.size);
   PROF_INIT();
   int* s_cadr = (int*)smem;                  // contact -> first efc row (or -1)
-  int* s_ldof = s_cadr + ncm;                // limit row -> dof
-  float* s_lsign = (float*)(s_ldof + nlim);  // limit row -> Jacobian entry (+-1)
+  int* s_ldof = s_cadr + ncm;                // friction-loss / limit row -> dof
+  float* s_lsign = (float*)(s_ldof + nlim);  // friction-loss / limit row -> Jacobian entry (+-1)
   float* s_cc = s_lsign + nlim;              // staged contact chunk, [CC_NROWS][64]
   const float timestep = (float)m.opt.timestep;
   float* J = d.efc_J + (size_t)w * njm * nv;
   const size_t wr = (size_t)w * njm;
   int nefc = 0;
   bool rows_dropped = false;  // wave-uniform: something did not fit njmax
-  // ---- joint limits: lanes = joints, rows assigned in (joint, side) order
   {
     const float *range = MF(jnt_range), *jmargin = MF(jnt_margin), *jsolref = MF(jnt_solref), *jsolimp = MF(jnt_solimp),
                 *dinv = MF(dof_invweight0);
     const float* qpos = d.qpos + (size_t)w * nq;
     const float* qvel = d.qvel + (size_t)w * nv;
+    // ---- friction loss (mj_instantiateFriction): lanes = dofs (nv <= 64); one row per dof with dof_frictionloss > 0,
+    // in dof order, before every other row: J = unit vector of the dof, pos = margin = 0, solref / solimp of the dof
+    if (m.opt.flags & MJLAB_OPT_FRICTIONLOSS) {  // otherwise the field is not read and data.nf stays 0
+      const float fl = lane < nv ? MF(dof_frictionloss)[lane] : 0.f;
+      const int act = fl > 0.f;
+      int total;
+      const int r = wave_excl_scan(act, lane, &total);
+      if (total) {  // wave-uniform
+        if (act && r < njm) {
+          float aref, R;
+          row_params(timestep, MF(dof_solref) + 2 * lane, MF(dof_solimp) + 5 * lane, 0.f, 0.f, qvel[lane], dinv[lane], &aref, &R);
+          s_ldof[r] = lane;
+          s_lsign[r] = 1.f;
+          d.efc_pos[wr + r] = 0.f;
+          d.efc_margin[wr + r] = 0.f;
+          d.efc_D[wr + r] = 1.f / R;
+          d.efc_aref[wr + r] = aref;
+          d.efc_frictionloss[wr + r] = fl;
+          d.efc_type[wr + r] = MJLAB_EFC_FRICTION_DOF;
+          d.efc_id[wr + r] = lane;
+        }
+        rows_dropped |= total > njm;
+        nefc = min(total, njm);
+      }
+      if (lane == 0) d.nf[w] = nefc;
+    }
+    // ---- joint limits: lanes = joints, rows assigned in (joint, side) order
     for (int j0 = 0; j0 < nj; j0 += 64) {
       const int j = j0 + lane;
       float dist[2] = {0.f, 0.f};

@@ -16,7 +16,7 @@ __host__ __device__ inline int solve_nvp(int nv) {
 }
 __host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
   const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
-  return nvp * ld + nvp + 3 * s.njmax + 64;
+  return nvp * ld + nvp + 3 * s.njmax + 64 + 4 * nvp;
 }
 
 template <int NVP>
@@ -26,7 +26,14 @@ struct SolveCtx {
   const float* J;  // global, row-major nefc x nv
   const float* M;  // global, dense nv x nv
   float *s_H, *s_invd, *s_jar, *s_jv, *s_D;
+  // friction-loss rows (the first nf rows, nf <= nv): s_fl[r] = efc_frictionloss, s_fdof[r] = the row's dof (its Jacobian is
+  // that unit vector, so the row never goes through the J passes of the Hessian: its force and curvature are added to the
+  // dof's entries directly), s_ff[dof] / s_fD[dof] = current force / curvature of the dof's row (0 for dofs without one)
+  float *s_fl, *s_ff, *s_fD;
+  int* s_fdof;
   int nv, nefc, lane;
+  int nf;  // friction-loss rows: the first nf rows (nf <= nv <= 64).  Their cost is quadratic inside |jar| < f / D and
+           // linear outside (mj_constraintUpdate); all other rows are quadratic where jar < 0 and free otherwise
   float quad_gauss[3];
   float dn1, dn2;  // rounding noise of the line-search derivative: d0_noise(alpha) = dn1 + |alpha| dn2
   float noise_ulps;  // 0 under MJLAB_OPT_LITERAL_TERMINATION (MuJoCo's rules only), else 1
@@ -106,7 +113,7 @@ __device__ __forceinline__ int build_active_list(const SolveCtx<NVP>& c, int* s_
   int nact = 0;
   for (int r0 = 0; r0 < c.nefc; r0 += 64) {
     const int r = r0 + c.lane;
-    const bool act = r < c.nefc && c.s_jar[r] < 0.f;
+    const bool act = r < c.nefc && r >= c.nf && c.s_jar[r] < 0.f;  // friction-loss rows: friction_rows() below
     const unsigned long long mask = __ballot(act);
     if (act) s_act[nact + __popcll(mask & ((1ull << c.lane) - 1ull))] = r;
     nact += __popcll(mask);
@@ -166,6 +173,27 @@ __device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&a
   return pick16<NB>(jtf, c.lane);
 }
 
+// Friction-loss rows at the current residuals: force and curvature of every row, scattered to its dof.  Returns this
+// lane's (dof's) share of J^T f; the curvature is added to the diagonal of H by hessian_friction_diag().
+template <int NVP>
+__device__ __forceinline__ float friction_rows(const SolveCtx<NVP>& c) {
+  if (c.lane < c.nf) {
+    const int r = c.lane;
+    const float x = c.s_jar[r], Dr = c.s_D[r], fl = c.s_fl[r];
+    const bool lin = fabsf(x) >= fl / Dr;  // outside the quadratic zone: constant force, no curvature
+    const int dof = c.s_fdof[r];
+    c.s_ff[dof] = lin ? (x < 0.f ? fl : -fl) : -Dr * x;
+    c.s_fD[dof] = lin ? 0.f : Dr;
+  }
+  __syncthreads();
+  return c.lane < c.nv ? c.s_ff[c.lane] : 0.f;
+}
+template <int NVP>
+__device__ __forceinline__ void hessian_friction_diag(const SolveCtx<NVP>& c) {
+  __syncthreads();
+  if (c.lane < c.nv) c.s_H[c.lane * c.ld + c.lane] += c.s_fD[c.lane];
+}
+
 // H = M + tiles -> LDS (lower triangle only)
 template <int NVP>
 __device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2]) {
@@ -193,11 +221,13 @@ __device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x
 #ifndef MJLAB_LSNOISE
 #define MJLAB_LSNOISE 4.f
 #endif
-template <int NVP>
+// FL: the world has friction-loss rows (the line search is instantiated twice so that worlds without them -- every
+// world of the reference's own robots -- run exactly the code they ran before those rows existed)
+template <int NVP, bool FL>
 __device__ __forceinline__ void ls_prepare(SolveCtx<NVP>& c) {
   const int r = c.lane;
   float j0 = 1.f, jv = 0.f, Dr = 0.f;  // lanes beyond nefc: never active
-  if (r < c.nefc) { j0 = c.s_jar[r]; jv = c.s_jv[r]; Dr = c.s_D[r]; }
+  if (r < c.nefc && (!FL || r >= c.nf)) { j0 = c.s_jar[r]; jv = c.s_jv[r]; Dr = c.s_D[r]; }  // friction-loss rows: see ls_eval
   c.lj0 = j0; c.ljv = jv;
   c.lq0 = 0.5f * Dr * j0 * j0; c.lq1 = Dr * j0 * jv; c.lq2 = 0.5f * Dr * jv * jv;
   j0 = 1.f; jv = 0.f; Dr = 0.f;
@@ -209,6 +239,10 @@ __device__ __forceinline__ void ls_prepare(SolveCtx<NVP>& c) {
   // MuJoCo's gtol (tolerance * ls_tolerance * |search| * scale ~ 1e-7) asks for less.  Once
   // |d0| is inside that noise band the search has found the minimiser as well as fp32 can tell.
   float a1 = fabsf(c.lq1) + fabsf(c.mq1), a2 = fabsf(c.lq2) + fabsf(c.mq2);
+  if (FL && r < c.nf) {
+    const float dj = c.s_D[r] * c.s_jv[r];
+    a1 += fabsf(dj * c.s_jar[r]); a2 += fabsf(0.5f * dj * c.s_jv[r]);
+  }
   for (int k = r + 128; k < c.nefc; k += 64) {
     const float dj = c.s_D[k] * c.s_jv[k];
     a1 += fabsf(dj * c.s_jar[k]); a2 += fabsf(0.5f * dj * c.s_jv[k]);
@@ -219,7 +253,7 @@ __device__ __forceinline__ void ls_prepare(SolveCtx<NVP>& c) {
 __device__ __forceinline__ float ls_newton_step(float alpha, float d0, float d1) {
   return alpha - d0 * __builtin_amdgcn_rcpf(d1);  // 1 ulp reciprocal: alpha only has to meet ls_tolerance
 }
-template <int NVP>
+template <int NVP, bool FL>
 __device__ __forceinline__ void ls_eval(SolveCtx<NVP>& c, LsPnt* p, float alpha) {
   float cost = 0.f, d0 = 0.f, d1 = 0.f;
   if (c.lj0 + alpha * c.ljv < 0.f) {
@@ -231,6 +265,19 @@ __device__ __forceinline__ void ls_eval(SolveCtx<NVP>& c, LsPnt* p, float alpha)
     cost += alpha * alpha * c.mq2 + alpha * c.mq1 + c.mq0;
     d0 += 2.f * alpha * c.mq2 + c.mq1;
     d1 += 2.f * c.mq2;
+  }
+  if (FL && c.lane < c.nf) {  // friction loss (mj PrimalEval): linear outside |x| < f / D
+    const int r = c.lane;
+    const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r], fl = c.s_fl[r], rf = fl / Dr;
+    const float x = j0 + alpha * jv;
+    if (x <= -rf) { cost += fl * (-0.5f * rf - j0) - alpha * fl * jv; d0 -= fl * jv; }
+    else if (x >= rf) { cost += fl * (-0.5f * rf + j0) + alpha * fl * jv; d0 += fl * jv; }
+    else {
+      const float q0 = 0.5f * Dr * j0 * j0, q1 = Dr * j0 * jv, q2 = 0.5f * Dr * jv * jv;
+      cost += alpha * alpha * q2 + alpha * q1 + q0;
+      d0 += 2.f * alpha * q2 + q1;
+      d1 += 2.f * q2;
+    }
   }
   for (int r = c.lane + 128; r < c.nefc; r += 64) {
     const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r];
@@ -250,7 +297,7 @@ __device__ __forceinline__ void ls_eval(SolveCtx<NVP>& c, LsPnt* p, float alpha)
   p->alpha = alpha; p->cost = cost; p->d0 = d0; p->d1 = d1;
   c.ls_iter++;
 }
-template <int NVP>
+template <int NVP, bool FL>
 __device__ __forceinline__ int update_bracket(SolveCtx<NVP>& c, LsPnt* p, const LsPnt* cand, LsPnt* pnext) {
   int flag = 0;
 #pragma unroll
@@ -258,7 +305,7 @@ __device__ __forceinline__ int update_bracket(SolveCtx<NVP>& c, LsPnt* p, const 
     if (p->d0 < 0.f && cand[i].d0 < 0.f && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
     else if (p->d0 > 0.f && cand[i].d0 > 0.f && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
   }
-  if (flag) ls_eval(c, pnext, ls_newton_step(p->alpha, p->d0, p->d1));
+  if (flag) ls_eval<NVP, FL>(c, pnext, ls_newton_step(p->alpha, p->d0, p->d1));
   return flag;
 }
 // exact 1-D line search on the piecewise-quadratic cost (safeguarded Newton + bracketing)
@@ -267,13 +314,13 @@ template <int NVP>
 __device__ __forceinline__ float ls_tol(const SolveCtx<NVP>& c, float gtol, float alpha) {
   return fmaxf(gtol, c.dn1 + fabsf(alpha) * c.dn2);
 }
-template <int NVP>
+template <int NVP, bool FL>
 __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
   LsPnt p0, p1, p2, pmid, p1next, p2next;
   c.ls_iter = 0;
-  ls_prepare(c);
-  ls_eval(c, &p0, 0.f);
-  ls_eval(c, &p1, ls_newton_step(p0.alpha, p0.d0, p0.d1));
+  ls_prepare<NVP, FL>(c);
+  ls_eval<NVP, FL>(c, &p0, 0.f);
+  ls_eval<NVP, FL>(c, &p1, ls_newton_step(p0.alpha, p0.d0, p0.d1));
   if (p0.cost < p1.cost) p1 = p0;
   if (fabsf(p1.d0) < ls_tol(c, gtol, p1.alpha)) return p1.alpha;
   const float dir = p1.d0 < 0.f ? 1.f : -1.f;
@@ -282,15 +329,15 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
   while (p1.d0 * dir <= -ls_tol(c, gtol, p1.alpha) && c.ls_iter < lsmax) {
     p2 = p1;
     p2update = true;
-    ls_eval(c, &p1, ls_newton_step(p1.alpha, p1.d0, p1.d1));
+    ls_eval<NVP, FL>(c, &p1, ls_newton_step(p1.alpha, p1.d0, p1.d1));
     if (fabsf(p1.d0) < ls_tol(c, gtol, p1.alpha)) return p1.alpha;
   }
   if (c.ls_iter >= lsmax) return p1.alpha;
   if (!p2update) return p1.alpha;
   p2next = p1;
-  ls_eval(c, &p1next, ls_newton_step(p1.alpha, p1.d0, p1.d1));
+  ls_eval<NVP, FL>(c, &p1next, ls_newton_step(p1.alpha, p1.d0, p1.d1));
   while (c.ls_iter < lsmax) {
-    ls_eval(c, &pmid, 0.5f * (p1.alpha + p2.alpha));
+    ls_eval<NVP, FL>(c, &pmid, 0.5f * (p1.alpha + p2.alpha));
     LsPnt cand[3] = {p1next, p2next, pmid};
     float bestcost = 0.f, bestalpha = 0.f;
     bool found = false;
@@ -298,8 +345,8 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
     for (int i = 0; i < 3; ++i)
       if (fabsf(cand[i].d0) < ls_tol(c, gtol, cand[i].alpha) && (!found || cand[i].cost < bestcost)) { bestcost = cand[i].cost; bestalpha = cand[i].alpha; found = true; }
     if (found) return bestalpha;
-    const int b1 = update_bracket(c, &p1, cand, &p1next);
-    const int b2 = update_bracket(c, &p2, cand, &p2next);
+    const int b1 = update_bracket<NVP, FL>(c, &p1, cand, &p1next);
+    const int b2 = update_bracket<NVP, FL>(c, &p2, cand, &p2next);
     if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : 0.f;
   }
   if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
@@ -308,11 +355,17 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
 }
 
 // constraint cost sum_r s(jar_r) over rows held in LDS
-__device__ __forceinline__ float constraint_cost(const float* s_jar, const float* s_D, int nefc, int lane) {
+template <int NVP>
+__device__ __forceinline__ float constraint_cost(const SolveCtx<NVP>& c, const float* s_jar) {
   float cost = 0.f;
-  for (int r = lane; r < nefc; r += 64) {
-    const float x = s_jar[r];
-    if (x < 0.f) cost += 0.5f * s_D[r] * x * x;
+  for (int r = c.lane; r < c.nefc; r += 64) {
+    const float x = s_jar[r], Dr = c.s_D[r];
+    if (r < c.nf) {  // friction loss: Huber cost
+      const float fl = c.s_fl[r], rf = fl / Dr, ax = fabsf(x);
+      cost += ax >= rf ? fl * (ax - 0.5f * rf) : 0.5f * Dr * x * x;
+    } else if (x < 0.f) {
+      cost += 0.5f * Dr * x * x;
+    }
   }
   return wave_sum(cost);
 }
@@ -350,6 +403,10 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
   c.s_jv = c.s_jar + njm;
   c.s_D = c.s_jv + njm;
   float* s_vec = c.s_D + njm;  // 64 floats of scratch (new qvel for the position update)
+  c.s_fl = s_vec + 64;
+  c.s_ff = c.s_fl + NVP;
+  c.s_fD = c.s_ff + NVP;
+  c.s_fdof = (int*)(c.s_fD + NVP);
   c.J = d.efc_J + (size_t)w * njm * nv;
   c.M = d.qM + (size_t)w * nv * nv;
   c.nv = nv; c.lane = lane;
@@ -365,6 +422,11 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
   const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
   const int nefc = do_solve ? d.nefc[w] : 0;
   c.nefc = nefc;
+#ifdef MJLAB_NO_FRICTIONLOSS  // experiment builds: the cost of the friction-loss branches in a model without such rows
+  c.nf = 0;
+#else
+  c.nf = (do_solve && (m.opt.flags & MJLAB_OPT_FRICTIONLOSS)) ? d.nf[w] : 0;
+#endif
   float qacc = 0.f, fc = 0.f, qas = 0.f, Ma = 0.f, cost = 0.f, gauss = 0.f, rhs = 0.f;
   int iter = 0, state;
   bool need_factor = true;
@@ -484,6 +546,10 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
         finished = true;
       } else {
         for (int r = launder(lane); r < nefc; r += 64) c.s_D[r] = d.efc_D[wr + r];
+        if (c.nf > 0) {
+          if (lane < c.nf) { c.s_fl[lane] = d.efc_frictionloss[wr + launder(lane)]; c.s_fdof[lane] = d.efc_id[wr + launder(lane)]; }
+          if (lane < NVP) { c.s_ff[lane] = 0.f; c.s_fD[lane] = 0.f; }
+        }
         // ---- warmstart: better of qacc_warmstart and qacc_smooth
         const float ws = own ? d.qacc_warmstart[wvs] : 0.f;
         {
@@ -496,8 +562,8 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
         for (int r = launder(lane); r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
         __syncthreads();
         const float Ma_ws = symm_mul_global<NVP>(c.M, nv, ws, lane);
-        const float cost_ws = constraint_cost(c.s_jar, c.s_D, nefc, lane) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
-        const float cost_s = constraint_cost(c.s_jv, c.s_D, nefc, lane);
+        const float cost_ws = constraint_cost<NVP>(c, c.s_jar) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
+        const float cost_s = constraint_cost<NVP>(c, c.s_jv);
         if (cost_ws > cost_s) {
           qacc = qas;
           Ma = qs;  // M qacc_smooth = qfrc_smooth
@@ -509,7 +575,7 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
         }
         PROF_MARK(2);
         // ---- initial constraint state, gradient, Hessian
-        cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
+        cost = constraint_cost<NVP>(c, c.s_jar);
         gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
         cost += gauss;
         {
@@ -519,8 +585,10 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
           __syncthreads();
           f32x4 htile[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
+          if (c.nf > 0) fc += friction_rows<NVP>(c);
           rhs = own ? Ma - qs - fc : 0.f;
           hessian_store<NVP>(c, htile);
+          if (c.nf > 0) hessian_friction_diag<NVP>(c);
           chol_pad_diag<NVP>(c.s_H, nv, lane);
         }
         PROF_MARK(3);
@@ -546,7 +614,7 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
         c.quad_gauss[1] = wave_sum(own ? search * (Ma - qs) : 0.f);
         c.quad_gauss[2] = wave_sum(own ? 0.5f * search * Mv : 0.f);
         PROF_MARK(5);
-        alpha = line_search<NVP>(c, gtol, lsmax);
+        alpha = c.nf > 0 ? line_search<NVP, true>(c, gtol, lsmax) : line_search<NVP, false>(c, gtol, lsmax);
         PROF_MARK(6);
 #ifdef MJLAB_PROFILE
         prof_acc_[10] += (float)c.ls_iter;
@@ -561,13 +629,15 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
         bool changed = false;  // did any row switch between active and satisfied?
         for (int r = lane; r < nefc; r += 64) {
           const float o = c.s_jar[r], nw = o + alpha * c.s_jv[r];
-          changed |= (o < 0.f) != (nw < 0.f);
+          bool qo = o < 0.f, qn = nw < 0.f;  // in the quadratic zone before / after?
+          if (r < c.nf) { const float rf = c.s_fl[r] / c.s_D[r]; qo = fabsf(o) < rf; qn = fabsf(nw) < rf; }
+          changed |= qo != qn;
           c.s_jar[r] = nw;
         }
         const bool any_changed = __ballot(changed) != 0ull;
         __syncthreads();
         const float oldcost = cost;
-        cost = constraint_cost(c.s_jar, c.s_D, nefc, lane);
+        cost = constraint_cost<NVP>(c, c.s_jar);
         gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
         cost += gauss;
         // One pass over J gives J^T f for the convergence test and, if the active set
@@ -582,6 +652,7 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
         if (any_changed) {
           f32x4 htile[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
+          if (c.nf > 0) fc += friction_rows<NVP>(c);
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
@@ -589,12 +660,14 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
           if (!finished) {
             __syncthreads();
             hessian_store<NVP>(c, htile);
+            if (c.nf > 0) hessian_friction_diag<NVP>(c);
             chol_pad_diag<NVP>(c.s_H, nv, lane);
           }
           need_factor = true;
         } else {  // same active set -> same H -> the factor in LDS is still valid
           f32x4 unused[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, false>(c, unused, s_act, nact);
+          if (c.nf > 0) fc += friction_rows<NVP>(c);
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = scale * (oldcost - cost);
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
@@ -608,7 +681,9 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
       if (lane == 0) d.solver_niter[w] = iter;
       for (int r = launder(lane); r < nefc; r += 64) {
         const float xr = c.s_jar[r];
-        d.efc_force[wr + r] = xr < 0.f ? -c.s_D[r] * xr : 0.f;
+        float fr = xr < 0.f ? -c.s_D[r] * xr : 0.f;
+        if (r < c.nf) { const float fl = c.s_fl[r]; fr = fabsf(xr) >= fl / c.s_D[r] ? (xr < 0.f ? fl : -fl) : -c.s_D[r] * xr; }
+        d.efc_force[wr + r] = fr;
       }
       if (own) {
         const size_t wvp = (size_t)w * nv + launder(lane);

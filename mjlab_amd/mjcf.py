@@ -146,6 +146,8 @@ class SpecJoint:
   springref: float = 0.0
   solref: np.ndarray = field(default_factory=lambda: np.array([0.02, 1.0]))
   solimp: np.ndarray = field(default_factory=lambda: np.array([0.9, 0.95, 0.001, 0.5, 2.0]))
+  solref_friction: np.ndarray = field(default_factory=lambda: np.array([0.02, 1.0]))
+  solimp_friction: np.ndarray = field(default_factory=lambda: np.array([0.9, 0.95, 0.001, 0.5, 2.0]))
   body: "SpecBody | None" = None
 
 
@@ -557,6 +559,10 @@ class _MjcfParser:
       j.solref = _floats(a["solreflimit"])
     if "solimplimit" in a:
       j.solimp = _floats(a["solimplimit"], 5, [0.9, 0.95, 0.001, 0.5, 2.0])
+    if "solreffriction" in a:
+      j.solref_friction = _floats(a["solreffriction"])
+    if "solimpfriction" in a:
+      j.solimp_friction = _floats(a["solimpfriction"], 5, [0.9, 0.95, 0.001, 0.5, 2.0])
     if "actuatorfrcrange" in a:
       raise NotImplementedError("actuatorfrcrange is not supported")
     return j
@@ -720,6 +726,9 @@ class Model:
           m.names[name] = [str(s) for s in v.tolist()]
     if not hasattr(m, "qpos_spring"):  # saved before the field existed: no springref in those models
       m.qpos_spring = np.asarray(m.qpos0, dtype=np.float64).copy()
+    if not hasattr(m, "dof_solref"):  # saved before friction-loss rows existed: MuJoCo's defaults
+      m.dof_solref = np.tile([0.02, 1.0], (m.nv, 1))
+      m.dof_solimp = np.tile([0.9, 0.95, 0.001, 0.5, 2.0], (m.nv, 1))
     if not hasattr(m, "tgrid_ztop"):  # saved before the static-geometry / terrain fields existed
       static = m.body_weldid[m.geom_bodyid] == 0
       m.nstaticgeom = int(np.argmin(static)) if not static.all() else m.ngeom
@@ -1106,6 +1115,8 @@ def _compile(spec: Spec) -> Model:
       m.dof_armature[da + k] = j.armature
       m.dof_damping[da + k] = j.damping
       m.dof_frictionloss[da + k] = j.frictionloss
+      m.dof_solref[da + k] = j.solref_friction
+      m.dof_solimp[da + k] = j.solimp_friction
   # dof_parentid: previous dof in the same body, else last dof of nearest moving ancestor
   last_dof_of_body = np.full(nbody, -1, np.int32)
   for i in range(1, nbody):

@@ -46,6 +46,7 @@ class Model:
     self.__dict__.update(host=host, device=device, nworld=1, _expanded=set())
     struct, base, view = device_state.upload_model(host, 1, 1, 1, device)
     self.__dict__.update(struct=struct, _base=base, _view=view)
+    struct.opt.flags |= _abi.OPT_FRICTIONLOSS  # nothing on this seam sees a later write to dof_frictionloss: always read it
     # the reference sets wp_model.opt.ls_parallel (sim/sim.py:111); accepted and ignored: the search here
     # is the exact iterative one (deviations).  "Forward folded into the next step" stays
     # OFF on this seam: nothing here sees writes to model arrays between forward() and step()

@@ -122,8 +122,6 @@ def check_supported(model: Model) -> None:
     raise NotImplementedError(f"nbody = {model.nbody} > 64: one body per lane in the kinematics sweep")
   if (np.asarray(model.jnt_type) == 1).any():
     raise NotImplementedError("ball joints are not implemented")
-  if np.any(np.asarray(model.dof_frictionloss) != 0):
-    raise NotImplementedError("dof_frictionloss != 0 (friction-loss constraint rows) is not implemented")
   for name in ("neq", "ntendon", "nmocap", "nflex"):
     if int(getattr(model, name, 0)) != 0:
       raise NotImplementedError(f"{name} != 0 is not implemented")
@@ -221,7 +219,7 @@ class Simulation:
     self.nconmax, self.njmax = _abi.default_capacities(model, cfg.nconmax, cfg.njmax)
 
     self._m, self._model_base, self._model_view = device_state.upload_model(model, num_envs, self.nconmax, self.njmax, dev)
-    self._m.opt.flags = ((_abi.OPT_FOLD_FORWARD if cfg.fold_forward else 0) | (_abi.OPT_LITERAL_TERMINATION if cfg.literal_termination else 0)
+    self._m.opt.flags = ((self._m.opt.flags & _abi.OPT_FRICTIONLOSS) | (_abi.OPT_FOLD_FORWARD if cfg.fold_forward else 0) | (_abi.OPT_LITERAL_TERMINATION if cfg.literal_termination else 0)
                          | (_abi.OPT_WARMSTART_AT_ADVANCE if cfg.warmstart_at_advance else 0)
                          | {"stage": 0, "presolve": _abi.OPT_FUSE_PRESOLVE, "step": _abi.OPT_FUSE_STEP}[cfg.fuse])
     self._d, self._data = device_state.alloc_data(model, num_envs, self.nconmax, self.njmax, dev)
@@ -234,7 +232,6 @@ class Simulation:
 
     if getattr(cfg.nan_guard, "enabled", False):
       raise NotImplementedError("nan_guard is not provided by mjlab_amd (append a callable to Simulation.post_step_hooks instead)")
-    self._frictionloss_handed_out = False
     self.post_step_hooks: list = []  # callables(sim) run after every step() (where the reference's NaN guard sits)
     self.use_graph = bool(cfg.use_graph) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
     self.step_graph: torch.cuda.CUDAGraph | None = None
@@ -256,8 +253,10 @@ class Simulation:
       return  # int topology fields are shared and read-only for the kernels' purposes
     if name in self._expanded or self.num_envs == 1:  # writable storage (a 1-world view aliases the base array)
       self._data["fold_valid"].zero_()
-      if name == "dof_frictionloss":
-        self._frictionloss_handed_out = True
+      if name == "dof_frictionloss" and not self._m.opt.flags & _abi.OPT_FRICTIONLOSS:
+        self._m.opt.flags |= _abi.OPT_FRICTIONLOSS  # values may now be written: the constraint stage builds friction-loss rows
+        if self.step_graph is not None or self.forward_graph is not None:  # captured launches hold the old flags
+          self.create_graph()
 
   def _stream(self) -> int:
     return torch.cuda.current_stream(self._dev).cuda_stream
@@ -372,9 +371,6 @@ class Simulation:
     extension: that many steps with the inputs held fixed -- the reference's decimation loop
     (envs/manager_based_rl_env.py:109-114 re-applies the same action before each of them) as one call;
     with ``fuse="step"`` also ONE kernel launch."""
-    if self._frictionloss_handed_out:  # sim.model.dof_frictionloss was handed out (writable) since the last check
-      self.check_model_writes()
-      self._frictionloss_handed_out = False
     with torch.cuda.device(self._dev):
       if nsubstep == 1:
         self._step_once()
@@ -388,14 +384,6 @@ class Simulation:
     that write to a model tensor obtained EARLIER (a cached handle): every ``sim.model.<field>``
     access of a writable field does this by itself."""
     self._data["fold_valid"].zero_()
-
-  def check_model_writes(self) -> None:
-    """Host-side check (one sync) of per-world model values the kernels do not implement:
-    a non-zero ``dof_frictionloss`` written after construction (friction-loss rows are not built).
-    ``step()`` calls it once after every hand-out of ``sim.model.dof_frictionloss``; a write through a
-    handle obtained earlier is only caught by calling it explicitly."""
-    if bool((self._model_view["dof_frictionloss"] != 0).any()):
-      raise NotImplementedError("dof_frictionloss != 0 was written to sim.model: friction-loss constraint rows are not implemented")
 
   def overflow_report(self) -> dict[str, int]:
     """Worlds whose last collision / constraint pass dropped work for lack of capacity

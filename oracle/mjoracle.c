@@ -830,9 +830,23 @@ static void make_constraint(const mjo_model_t* m, mjo_data_t* d, int w) {
   real* J = D(efc_J, njm * nv);
   real *qpos = D(qpos, s->nq), *cdof = D(cdof, 6 * nv), *sub = D(subtree_com, 3 * nb);
   int nefc = 0;
-  /* joint limits (hinge / slide) */
   const real *range = MF(jnt_range, w), *jmargin = MF(jnt_margin, w), *jsolref = MF(jnt_solref, w),
              *jsolimp = MF(jnt_solimp, w), *dinv = MF(dof_invweight0, w);
+  /* friction loss (mj_instantiateFriction): one row per dof with dof_frictionloss > 0, in dof order, before
+   * every other row; J = unit vector of the dof, pos = margin = 0, solref / solimp of the dof */
+  const real *floss = MF(dof_frictionloss, w), *dsolref = MF(dof_solref, w), *dsolimp = MF(dof_solimp, w);
+  for (int i = 0; i < nv; i++) {
+    if (!(m->opt.flags & MJLAB_OPT_FRICTIONLOSS) || !(floss[i] > 0)) continue;
+    if (nefc >= njm) { d->overflow[w] |= MJLAB_OVF_NJMAX; continue; }
+    real* row = J + (size_t)nefc * nv;
+    memset(row, 0, sizeof(real) * nv);
+    row[i] = 1;
+    finish_row(m, d, w, nefc, 0, 0, dsolref + 2 * i, dsolimp + 5 * i, dinv[i], MJLAB_EFC_FRICTION_DOF, i);
+    D(efc_frictionloss, njm)[nefc] = floss[i];
+    nefc++;
+  }
+  d->nf[w] = nefc;
+  /* joint limits (hinge / slide) */
   for (int j = 0; j < s->njnt; j++) {
     if (!m->jnt_limited[j] || m->jnt_type[j] == MJLAB_JNT_FREE) continue;
     real value = qpos[m->jnt_qposadr[j]], mg = jmargin[j];
@@ -1021,26 +1035,42 @@ static void smooth_forces(const mjo_model_t* m, mjo_data_t* d, int w) {
 
 /* ------------------------------------------------------------------ Newton solver */
 typedef struct {
-  int nv, nefc, ls_iter;
-  const real *J, *Dv, *aref, *M, *qfrc_smooth, *qacc_smooth;
+  int nv, nefc, nf, ls_iter; /* rows [0, nf) are friction-loss rows */
+  const real *J, *Dv, *aref, *floss, *M, *qfrc_smooth, *qacc_smooth;
   real *qacc, *Ma, *jar, *grad, *search, *Mv, *jv, *force, *qfrc_constraint, *H;
   real quad_gauss[3], cost, gauss;
 } nctx_t;
 
 typedef struct { real alpha, cost, d0, d1; } lspnt_t;
 
+/* Cost of one row at residual x = (J qacc - aref)_r (mj_constraintUpdate): inequality rows are
+ * quadratic where x < 0 and free otherwise; friction-loss rows (r < nf) are quadratic inside
+ * |x| < R f (R = 1 / D, f = efc_frictionloss) and linear with slope -+f outside (a Huber cost).
+ * Returns 1 where the row is in its quadratic zone (those rows enter the Hessian). */
+static inline int row_cost(const nctx_t* c, int r, real x, real* cost, real* force) {
+  real Dr = c->Dv[r];
+  if (r < c->nf) {
+    real f = c->floss[r], rf = f / Dr;
+    if (x <= -rf) { *force = f; *cost = f * ((real)-0.5 * rf - x); return 0; }
+    if (x >= rf) { *force = -f; *cost = f * ((real)-0.5 * rf + x); return 0; }
+    *force = -Dr * x; *cost = (real)0.5 * Dr * x * x; return 1;
+  }
+  if (x < 0) { *force = -Dr * x; *cost = (real)0.5 * Dr * x * x; return 1; }
+  *force = 0; *cost = 0; return 0;
+}
+
 static void update_constraint(nctx_t* c) {
   int nv = c->nv;
   real cost = 0;
   memset(c->qfrc_constraint, 0, sizeof(real) * nv);
   for (int r = 0; r < c->nefc; r++) {
-    real x = c->jar[r];
-    if (x < 0) {
-      c->force[r] = -c->Dv[r] * x;
-      cost += (real)0.5 * c->Dv[r] * x * x;
+    real rc;
+    row_cost(c, r, c->jar[r], &rc, &c->force[r]);
+    cost += rc;
+    if (c->force[r] != 0) {
       const real* row = c->J + (size_t)r * nv;
       for (int i = 0; i < nv; i++) c->qfrc_constraint[i] += row[i] * c->force[r];
-    } else c->force[r] = 0;
+    }
   }
   real gauss = 0;
   for (int i = 0; i < nv; i++) gauss += (real)0.5 * (c->Ma[i] - c->qfrc_smooth[i]) * (c->qacc[i] - c->qacc_smooth[i]);
@@ -1053,7 +1083,8 @@ static void update_gradient(nctx_t* c) {
   for (int i = 0; i < nv; i++) c->grad[i] = c->Ma[i] - c->qfrc_smooth[i] - c->qfrc_constraint[i];
   memcpy(c->H, c->M, sizeof(real) * nv * nv);
   for (int r = 0; r < c->nefc; r++) {
-    if (c->jar[r] >= 0) continue;
+    real rc, rfo;
+    if (!row_cost(c, r, c->jar[r], &rc, &rfo)) continue;
     const real* row = c->J + (size_t)r * nv;
     real Dr = c->Dv[r];
     for (int i = 0; i < nv; i++) {
@@ -1079,7 +1110,12 @@ static void ls_eval(nctx_t* c, lspnt_t* p, real alpha) {
   real d0 = 2 * alpha * c->quad_gauss[2] + c->quad_gauss[1], d1 = 2 * c->quad_gauss[2];
   for (int r = 0; r < c->nefc; r++) {
     real x = c->jar[r] + alpha * c->jv[r];
-    if (x < 0) {
+    if (r < c->nf) { /* friction loss: linear outside |x| < R f (mj PrimalEval) */
+      real f = c->floss[r], rf = f / c->Dv[r];
+      if (x <= -rf) { cost += f * ((real)-0.5 * rf - c->jar[r]) - alpha * f * c->jv[r]; d0 -= f * c->jv[r]; continue; }
+      if (x >= rf) { cost += f * ((real)-0.5 * rf + c->jar[r]) + alpha * f * c->jv[r]; d0 += f * c->jv[r]; continue; }
+    }
+    if (x < 0 || r < c->nf) {
       real Dr = c->Dv[r], q0 = (real)0.5 * Dr * c->jar[r] * c->jar[r], q1 = Dr * c->jar[r] * c->jv[r], q2 = (real)0.5 * Dr * c->jv[r] * c->jv[r];
       cost += alpha * alpha * q2 + alpha * q1 + q0;
       d0 += 2 * alpha * q2 + q1;
@@ -1188,7 +1224,9 @@ static real constraint_cost_at(nctx_t* c, const real* qacc, int with_gauss) {
     const real* row = c->J + (size_t)r * nv;
     real x = -c->aref[r];
     for (int i = 0; i < nv; i++) x += row[i] * qacc[i];
-    if (x < 0) cost += (real)0.5 * c->Dv[r] * x * x;
+    real rc, rfo;
+    row_cost(c, r, x, &rc, &rfo);
+    cost += rc;
   }
   if (with_gauss)
     for (int i = 0; i < nv; i++) {
@@ -1212,8 +1250,8 @@ static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
     return;
   }
   nctx_t c;
-  c.nv = nv; c.nefc = nefc;
-  c.J = D(efc_J, njm * nv); c.Dv = D(efc_D, njm); c.aref = D(efc_aref, njm); c.M = D(qM, nv * nv);
+  c.nv = nv; c.nefc = nefc; c.nf = d->nf[w];
+  c.J = D(efc_J, njm * nv); c.Dv = D(efc_D, njm); c.aref = D(efc_aref, njm); c.floss = D(efc_frictionloss, njm); c.M = D(qM, nv * nv);
   c.qfrc_smooth = D(qfrc_smooth, nv); c.qacc_smooth = qas; c.qacc = qacc; c.force = force;
   c.qfrc_constraint = D(qfrc_constraint, nv);
   real* buf = (real*)calloc((size_t)5 * nv + 2 * nefc + (size_t)nv * nv, sizeof(real));

@@ -54,7 +54,7 @@ class OracleSim:
     self._m = MS()
     self._m.size = _abi.fill_sizes(model, nworld, self.nconmax, self.njmax)
     self._m.opt = _abi.fill_option(model)
-    self._m.opt.flags = flags  # MJLAB_OPT_LITERAL_TERMINATION / MJLAB_OPT_WARMSTART_AT_ADVANCE (fold is a device-side mechanism)
+    self._m.opt.flags |= flags  # MJLAB_OPT_LITERAL_TERMINATION / MJLAB_OPT_WARMSTART_AT_ADVANCE (fold is a device-side mechanism)
     self.mfield: dict[str, np.ndarray] = {}
     for f in mfields:
       if f.kind == "i":
@@ -87,6 +87,8 @@ class OracleSim:
     self.mfield[name] = arr
     setattr(self._m, name, arr.ctypes.data)
     setattr(self._m, name + "_ws", int(base.size))
+    if name == "dof_frictionloss":
+      self._m.opt.flags |= _abi.OPT_FRICTIONLOSS  # values may now be written: build the rows (as Simulation does)
     if name in ("geom_pos", "geom_quat", "body_pos", "body_quat"):
       self._m.size.nstaticgeom = 0  # static geoms may now differ per world: pose them every pass (as Simulation does)
     return arr

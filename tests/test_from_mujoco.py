@@ -6,6 +6,7 @@ native arrays, ``opt``, ``stat``, the ``names`` blob with its ``name_*adr`` tabl
 derived table and the oracle's physics bit for bit.  Enum ids are pinned to the reference's stubs."""
 
 import json
+import re
 import types
 from pathlib import Path
 
@@ -60,6 +61,11 @@ def test_enum_ids_match_the_pinned_mujoco_build():
   assert (mjcf.INT_EULER, mjcf.INT_IMPLICITFAST) == (e["mjINT_EULER"], e["mjINT_IMPLICITFAST"])
   assert (mjcf.SOL_PGS, mjcf.SOL_CG, mjcf.SOL_NEWTON) == (e["mjSOL_PGS"], e["mjSOL_CG"], e["mjSOL_NEWTON"])
   assert (mjcf.CONE_PYRAMIDAL, mjcf.CONE_ELLIPTIC) == (e["mjCONE_PYRAMIDAL"], e["mjCONE_ELLIPTIC"])
+  # efc_type values written by the constraint stage (include/mjlab_fields.h)
+  hdr = (Path(__file__).resolve().parents[1] / "include" / "mjlab_fields.h").read_text()
+  efc = {k: int(v) for k, v in re.findall(r"MJLAB_EFC_(\w+) = (\d+)", hdr)}
+  assert efc == {"FRICTION_DOF": e["mjCNSTR_FRICTION_DOF"], "LIMIT": e["mjCNSTR_LIMIT_JOINT"],
+                 "CONTACT_FRICTIONLESS": e["mjCNSTR_CONTACT_FRICTIONLESS"], "CONTACT_PYRAMIDAL": e["mjCNSTR_CONTACT_PYRAMIDAL"]}
   # the actuator checks of from_mujoco assume these
   assert (e["mjTRN_JOINT"], e["mjGAIN_FIXED"], e["mjBIAS_NONE"], e["mjBIAS_AFFINE"], e["mjDYN_NONE"]) == (0, 0, 0, 1, 0)
 

@@ -158,6 +158,81 @@ def test_joint_limit_pushes_back():
   assert s.qfrc_constraint[0, da] < 0
 
 
+def _friction_pendulum(fl, **joint_attrs):
+  from mjlab_amd.mjcf import Spec
+
+  extra = "".join(f' {k}="{v}"' for k, v in joint_attrs.items())
+  xml = robots.PENDULUM_XML.replace('axis="0 1 0"/>', f'axis="0 1 0" frictionloss="{fl}"{extra}/>')
+  return Spec.from_string(xml).compile()
+
+
+def test_friction_loss_row_slips_with_exactly_its_force():
+  """mj_instantiateFriction + the Huber cost of mj_constraintUpdate on a horizontal pendulum: gravity torque
+  m g l = 4.905 N m about the hinge; frictionloss 2 < 4.905 -> the row sits in its linear zone with force = +-2."""
+  m = _friction_pendulum(2.0)
+  s = OracleSim(m)
+  s.qpos[:] = np.pi / 2
+  s.forward()
+  assert s.nefc[0, 0] == 1 and s.nf[0, 0] == 1
+  assert s.efc_type[0, 0] == 1 and s.efc_id[0, 0] == 0 and s.efc_frictionloss[0, 0] == 2.0
+  assert s.efc_pos[0, 0] == 0 and s.efc_margin[0, 0] == 0 and s.efc_aref[0, 0] == 0  # aref = -b * qvel
+  inertia = 0.0841667 + 1.0 * 0.5**2
+  assert s.efc_D[0, 0] == pytest.approx(0.9 / 0.1 * inertia, rel=1e-9)  # 1 / R, R = (1 - imp) / imp * dof_invweight0, imp = solimp[0]
+  assert abs(s.efc_force[0, 0]) == pytest.approx(2.0, abs=1e-12)
+  tau_g = s.qfrc_smooth[0, 0]
+  assert abs(tau_g) == pytest.approx(1.0 * 9.81 * 0.5, rel=1e-6)
+  assert s.qacc[0, 0] == pytest.approx((tau_g - np.sign(tau_g) * 2.0) / inertia, rel=1e-9)
+
+
+def test_friction_loss_row_holds_below_its_limit_and_stops_a_swing():
+  m = _friction_pendulum(6.0)
+  s = OracleSim(m)
+  s.qpos[:] = np.pi / 2
+  s.forward()
+  f, D = s.efc_force[0, 0], s.efc_D[0, 0]
+  assert abs(f) < 6.0  # quadratic zone: |J qacc - aref| < R f
+  jar = s.qacc[0, 0] - s.efc_aref[0, 0]
+  assert f == pytest.approx(-D * jar, rel=1e-9) and abs(jar) < 6.0 / D
+  assert abs(s.qacc[0, 0]) < 0.1 * 4.905 / 0.3341667 * 3.1  # soft hold: a small fraction of the free acceleration (14.7)
+  s.step(500)
+  assert abs(s.qpos[0, 0] - np.pi / 2) < 0.03 and abs(s.qvel[0, 0]) < 0.05  # creeps, as MuJoCo's soft rows do
+  # a released pendulum with a weaker brake loses its energy and comes to rest away from the bottom
+  m = _friction_pendulum(1.0)
+  s = OracleSim(m)
+  s.qpos[:] = 1.2
+  e0 = None
+  for _ in range(8):
+    s.step(500)
+    e = 0.5 * 0.3341667 * s.qvel[0, 0] ** 2 + 1.0 * 9.81 * 0.5 * (1 - np.cos(s.qpos[0, 0]))
+    assert e0 is None or e <= e0 + 1e-9
+    e0 = e
+  assert abs(s.qvel[0, 0]) < 1e-2 and 1.0 * 9.81 * 0.5 * abs(np.sin(s.qpos[0, 0])) <= 1.0 + 1e-3
+
+
+def test_friction_loss_rows_come_first_in_dof_order_and_use_the_dof_solref():
+  m = robots.mixed_model()
+  m.dof_frictionloss = np.zeros(m.nv)
+  m.dof_frictionloss[[2, m.nv - 2, m.nv - 1]] = [0.05, 3.0, 0.3]
+  m.dof_solref[m.nv - 1] = [0.05, 0.7]
+  m.dof_solimp[m.nv - 2] = [0.8, 0.9, 0.001, 0.5, 2.0]
+  s = OracleSim(m)
+  s.qvel[0, m.nv - 1] = 0.4
+  s.forward()
+  nf = s.nf[0, 0]
+  assert nf == 3 and list(s.efc_type[0, :3]) == [1, 1, 1] and list(s.efc_id[0, :3]) == [2, m.nv - 2, m.nv - 1]
+  assert np.all(s.efc_type[0, 3 : s.nefc[0, 0]] >= 3)
+  J = s.efc_J[0].reshape(-1, m.nv)[:3]
+  assert np.array_equal(J, np.eye(m.nv)[[2, m.nv - 2, m.nv - 1]])
+  # aref = -b * qvel with b = 2 / (dmax * timeconst) of the dof's own solref; D from the dof's own solimp
+  assert s.efc_aref[0, 2] == pytest.approx(-2 / (0.95 * 0.05) * 0.4, rel=1e-9)
+  assert s.efc_D[0, 1] == pytest.approx(0.8 / 0.2 / m.dof_invweight0[m.nv - 2], rel=1e-9)
+  # stationarity with the Huber forces: M qacc = qfrc_smooth + J^T f
+  n = s.nefc[0, 0]
+  M, Jall = s.qM[0].reshape(m.nv, m.nv), s.efc_J[0].reshape(-1, m.nv)[:n]
+  assert M @ s.qacc[0] == pytest.approx(s.qfrc_smooth[0] + Jall.T @ s.efc_force[0, :n], rel=1e-6, abs=1e-6)
+  assert np.all(np.abs(s.efc_force[0, :3]) <= s.efc_frictionloss[0, :3] + 1e-12)
+
+
 def test_contact_primitives_and_sensor():
   m = robots.mixed_model()
   s = OracleSim(m)

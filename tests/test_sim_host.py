@@ -22,7 +22,6 @@ def test_supported_models_pass():
   [
     (lambda m: setattr(m.opt, "solver", 1), "Newton"),
     (lambda m: setattr(m.opt, "cone", 1), "pyramidal"),
-    (lambda m: m.dof_frictionloss.__setitem__(3, 0.1), "frictionloss"),
     (lambda m: m.jnt_type.__setitem__(2, 1), "ball"),
     (lambda m: m.geom_condim.__setitem__(slice(None), 4), "condim"),
     (lambda m: m.sensor_intprm.__setitem__((0, 0), 3), "found"),

@@ -142,7 +142,9 @@ def main() -> None:
   want = ["mjJNT_FREE", "mjJNT_BALL", "mjJNT_SLIDE", "mjJNT_HINGE", "mjGEOM_PLANE", "mjGEOM_HFIELD", "mjGEOM_SPHERE", "mjGEOM_CAPSULE",
           "mjGEOM_ELLIPSOID", "mjGEOM_CYLINDER", "mjGEOM_BOX", "mjGEOM_MESH", "mjOBJ_BODY", "mjOBJ_XBODY", "mjOBJ_GEOM", "mjOBJ_SITE",
           "mjSENS_CONTACT", "mjINT_EULER", "mjINT_IMPLICITFAST", "mjSOL_PGS", "mjSOL_CG", "mjSOL_NEWTON", "mjCONE_PYRAMIDAL", "mjCONE_ELLIPTIC",
-          "mjTRN_JOINT", "mjGAIN_FIXED", "mjBIAS_NONE", "mjBIAS_AFFINE", "mjDYN_NONE"]  # fmt: skip
+          "mjTRN_JOINT", "mjGAIN_FIXED", "mjBIAS_NONE", "mjBIAS_AFFINE", "mjDYN_NONE",
+          "mjCNSTR_EQUALITY", "mjCNSTR_FRICTION_DOF", "mjCNSTR_FRICTION_TENDON", "mjCNSTR_LIMIT_JOINT", "mjCNSTR_LIMIT_TENDON",
+          "mjCNSTR_CONTACT_FRICTIONLESS", "mjCNSTR_CONTACT_PYRAMIDAL", "mjCNSTR_CONTACT_ELLIPTIC"]  # fmt: skip
   out["enums"] = {}
   for name in want:
     mt = re.search(r"'%s': <\w+\.%s: (\d+)>" % (name, name), enums)
