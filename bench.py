@@ -134,7 +134,7 @@ def main() -> None:
   torch.cuda.set_device(mdist.device_index(info))
 
   model = robots.load_model(args.scene)
-  sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=300, use_graph=not args.no_graph, fold_forward=not args.no_fold, fuse=args.fuse), model, dev)
+  sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), use_graph=not args.no_graph, fold_forward=not args.no_fold, fuse=args.fuse), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else go1_action_scale(model)
   robot = "g1" if args.scene.startswith("g1") else "go1"
   events = {} if args.no_task_events else VELOCITY_TASK_EVENTS[robot]

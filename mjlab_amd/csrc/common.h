@@ -81,6 +81,26 @@ __device__ __forceinline__ void dense_global_to_lds(float* dst, const float* src
     while (j >= n) { j -= n; ++i; }
   }
 }
+// same copy (lower triangle), plus a packed copy of the lower triangle: element (i, j) at i (i + 1) / 2 + j
+__device__ __forceinline__ void dense_global_to_lds_packed(float* dst, float* packed, const float* src, int n, int ld, int lane) {
+  lane = launder(lane);
+  int i = 0, j = lane, tri = 0;
+  while (j >= n) { j -= n; ++i; tri += i; }
+  for (int k = lane; k < n * n; k += 64) {
+    if (j <= i) { const float x = src[k]; dst[i * ld + j] = x; packed[tri + j] = x; }
+    j += 64;
+    while (j >= n) { j -= n; ++i; tri += i; }
+  }
+}
+// packed lower triangle (LDS) -> lower triangle of a dense LDS matrix
+__device__ __forceinline__ void packed_to_lds(float* dst, const float* packed, int n, int ld, int lane) {
+  int i = 0, tri = 0;  // tri = i (i + 1) / 2
+  const int total = (n * (n + 1)) >> 1;
+  for (int k = launder(lane); k < total; k += 64) {
+    while (k >= tri + i + 1) { tri += i + 1; ++i; }
+    dst[i * ld + (k - tri)] = packed[k];
+  }
+}
 __device__ __forceinline__ void dense_lds_to_global(float* dst, const float* src, int n, int ld, int lane, bool zero_upper) {
   int i = 0, j = lane;
   while (j >= n) { j -= n; ++i; }
@@ -356,33 +376,21 @@ __device__ CHOL_INLINE float chol_solve(const float* L_, const float* s_invd_, i
   }
   return b;
 }
-// y_i = sum_j M[i][j] v_j with M symmetric, dense row-major in GLOBAL memory (ld = n);
-// lane i owns v_i and y_i.  Row j is read coalesced (M[j][i] = M[i][j]), v_j comes from
-// lane j by v_readlane; fully unrolled so all loads are in flight together.
+// y_i = sum_j M[i][j] v_j with M symmetric; lane i owns v_i and y_i, v_j comes from lane j by v_readlane.
+// M is a packed lower triangle in LDS: element (i, j), j <= i, at i (i + 1) / 2 + j.  Lane i reads
+// its own row for j <= i and column i of the rows below it for j > i (consecutive addresses across lanes).
 template <int NVP>
-__device__ __forceinline__ float symm_mul_global(const float* M, int n, float v, int lane) {
-  // The element offset is made opaque to the optimiser: otherwise the NVP row addresses are
-  // loop-invariant 64-bit VGPR pairs that get hoisted out of the Newton loop and spilled.
-  int off = lane < n ? lane : 0;
-  asm volatile("" : "+v"(off));
-  constexpr int CH = 12;  // loads in flight per chunk
+__device__ __forceinline__ float symm_mul_packed(const float* sM_, int n, float v, int lane) {
+  const lds_f32* sM = (const lds_f32*)sM_;
+  int li = lane < NVP ? lane : NVP - 1;
+  asm volatile("" : "+v"(li));
+  const int tri_i = (li * (li + 1)) >> 1;
   float y0 = 0.f, y1 = 0.f;
 #pragma unroll
-  for (int j0 = 0; j0 < NVP; j0 += CH) {
-    float mv[CH];
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int j = j0 + u;
-      mv[u] = (j < NVP && j < n) ? M[j * n + off] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int j = j0 + u;
-      if (j < NVP) {
-        if (u & 1) y1 = fmaf(mv[u], lane_bcast(v, j), y1);
-        else y0 = fmaf(mv[u], lane_bcast(v, j), y0);
-      }
-    }
+  for (int j = 0; j < NVP; ++j) {
+    const float mij = li >= j ? sM[tri_i + j] : sM[((j * (j + 1)) >> 1) + li];
+    if (j & 1) y1 = fmaf(mij, lane_bcast(v, j), y1);
+    else y0 = fmaf(mij, lane_bcast(v, j), y0);
   }
   return lane < n ? y0 + y1 : 0.f;
 }

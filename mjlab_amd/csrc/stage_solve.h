@@ -14,9 +14,18 @@ __host__ __device__ inline int solve_nvp(int nv) {
   for (int i = 0; i < 9; ++i) if (nv <= sizes[i]) return sizes[i];
   return -1;
 }
+// Rows the three per-row arrays (jar, jv, D) have room for in LDS.  A world with more rows than that (a robot lying on
+// the ground in a heap of contacts) runs the same solver code with the three arrays in global memory instead
+// (stage_solve's BIG instantiation).  128 = what the line search caches in registers, and what leaves room for M next to
+// H at 16 waves per CU (10 KB per wave) with the G1's 36 x 36 factor.
+#ifndef MJLAB_RCAP
+#define MJLAB_RCAP 128
+#endif
+__host__ __device__ inline int solve_lds_rows(const mjlab_sizes_t& s) { return s.njmax < MJLAB_RCAP ? s.njmax : MJLAB_RCAP; }
 __host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
   const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
-  return nvp * ld + nvp + 3 * s.njmax + 64 + 4 * nvp;
+  const int scratch = 4 * nvp > 64 ? 4 * nvp : 64;  // friction-loss arrays during the solve, 64 floats for the integrator after it
+  return nvp * ld + nvp + 3 * solve_lds_rows(s) + scratch + nvp * (nvp + 1) / 2;
 }
 
 template <int NVP>
@@ -24,8 +33,11 @@ struct SolveCtx {
   static constexpr int NB = CholCfg<NVP>::NB;
   static constexpr int ld = CholCfg<NVP>::LD;
   const float* J;  // global, row-major nefc x nv
-  const float* M;  // global, dense nv x nv
-  float *s_H, *s_invd, *s_jar, *s_jv, *s_D;
+  const float* M;  // global, dense nv x nv (read once per pass; the Newton loop works on the packed copy s_M)
+  float* s_M;      // LDS: M as a packed lower triangle, element (i, j), j <= i, at i (i + 1) / 2 + j
+  float *s_H, *s_invd;
+  float *s_jar, *s_jv;  // per-row arrays: LDS, or global scratch in the BIG instantiation (efc_force until the solve is
+  const float* s_D;     // published, efc_scratch, efc_D itself)
   // friction-loss rows (the first nf rows, nf <= nv): s_fl[r] = efc_frictionloss, s_fdof[r] = the row's dof (its Jacobian is
   // that unit vector, so the row never goes through the J passes of the Hessian: its force and curvature are added to the
   // dof's entries directly), s_ff[dof] / s_fD[dof] = current force / curvature of the dof's row (0 for dofs without one)
@@ -199,10 +211,6 @@ template <int NVP>
 __device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2]) {
   constexpr int NB = CholCfg<NVP>::NB;
   const int sub = c.lane >> 4, col = c.lane & 15;
-  // per-lane part of the M offset, opaque so that the 4 NT addresses are not hoisted out of
-  // the Newton loop as 64-bit VGPR pairs (and then spilled)
-  int moff = sub * 4 * c.nv + col;
-  asm volatile("" : "+v"(moff));
   int t = 0;
 #pragma unroll
   for (int I = 0; I < NB; ++I)
@@ -211,7 +219,7 @@ __device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
-        if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.M[(16 * I + k) * c.nv + 16 * Jb + moff];
+        if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.s_M[((row * (row + 1)) >> 1) + cc];
       }
       ++t;
     }
@@ -391,22 +399,32 @@ __device__ __forceinline__ float grad_noise(float ulps, float scale, bool own, f
   return ulps * MJLAB_GNOISE * 5.9604645e-8f * scale * sqrtf(wave_sum(t * t));
 }
 
-template <int NVP>
-__device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const int w, const int lane, const int do_solve, const int do_integrate, const int flags,
-                                            float* smem) {
+// BIG: this world has more rows than the LDS arrays hold; the three per-row arrays live in global memory
+template <int NVP, bool BIG>
+__device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, const int w, const int lane, const int do_solve, const int do_integrate, const int flags,
+                                                 float* smem) {
   constexpr int NB = CholCfg<NVP>::NB, ld = CholCfg<NVP>::LD;
   const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
   SolveCtx<NVP> c;
   c.s_H = smem;
   c.s_invd = c.s_H + NVP * ld;
-  c.s_jar = c.s_invd + NVP;
-  c.s_jv = c.s_jar + njm;
-  c.s_D = c.s_jv + njm;
-  float* s_vec = c.s_D + njm;  // 64 floats of scratch (new qvel for the position update)
-  c.s_fl = s_vec + 64;
+  const int nrl = solve_lds_rows(m.size);
+  float* s_rows = c.s_invd + NVP;
+  float* s_vec = s_rows + 3 * nrl;  // 64 floats of scratch for the integrator (new qvel for the position update) ...
+  c.s_fl = s_vec;                   // ... which the friction-loss arrays of the solve share (dead by then)
   c.s_ff = c.s_fl + NVP;
   c.s_fD = c.s_ff + NVP;
   c.s_fdof = (int*)(c.s_fD + NVP);
+  c.s_M = s_vec + (4 * NVP > 64 ? 4 * NVP : 64);
+  if (BIG) {
+    c.s_jar = d.efc_force + (size_t)w * njm;
+    c.s_jv = d.efc_scratch + (size_t)w * njm;
+    c.s_D = d.efc_D + (size_t)w * njm;
+  } else {
+    c.s_jar = s_rows;
+    c.s_jv = s_rows + nrl;
+    c.s_D = s_rows + 2 * nrl;
+  }
   c.J = d.efc_J + (size_t)w * njm * nv;
   c.M = d.qM + (size_t)w * nv * nv;
   c.nv = nv; c.lane = lane;
@@ -434,7 +452,8 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
 
   if (do_solve) {
     // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
-    dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
+    dense_global_to_lds_packed(c.s_H, c.s_M, c.M, nv, ld, lane);
+    for (int k = ((nv * (nv + 1)) >> 1) + lane; k < NVP * (NVP + 1) / 2; k += 64) c.s_M[k] = 0.f;
     chol_pad_rows<NVP>(c.s_H, nv, lane);
     chol_pad_diag<NVP>(c.s_H, nv, lane);
     rhs = qs;
@@ -477,7 +496,8 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
       state = ST_INTEGRATE;
       if (__ballot(need)) {
         __syncthreads();
-        dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
+        if (do_solve) packed_to_lds(c.s_H, c.s_M, nv, ld, lane);  // M is still on chip
+        else dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
         chol_pad_rows<NVP>(c.s_H, nv, lane);
         chol_pad_diag<NVP>(c.s_H, nv, lane);
         __syncthreads();
@@ -545,7 +565,7 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
         qacc = qas;
         finished = true;
       } else {
-        for (int r = launder(lane); r < nefc; r += 64) c.s_D[r] = d.efc_D[wr + r];
+        if (!BIG) for (int r = launder(lane); r < nefc; r += 64) s_rows[2 * nrl + r] = d.efc_D[wr + r];
         if (c.nf > 0) {
           if (lane < c.nf) { c.s_fl[lane] = d.efc_frictionloss[wr + launder(lane)]; c.s_fdof[lane] = d.efc_id[wr + launder(lane)]; }
           if (lane < NVP) { c.s_ff[lane] = 0.f; c.s_fD[lane] = 0.f; }
@@ -561,7 +581,7 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
         __syncthreads();
         for (int r = launder(lane); r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
         __syncthreads();
-        const float Ma_ws = symm_mul_global<NVP>(c.M, nv, ws, lane);
+        const float Ma_ws = symm_mul_packed<NVP>(c.s_M, nv, ws, lane);
         const float cost_ws = constraint_cost<NVP>(c, c.s_jar) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
         const float cost_s = constraint_cost<NVP>(c, c.s_jv);
         if (cost_ws > cost_s) {
@@ -602,7 +622,7 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
       float alpha = 0.f, Mv = 0.f;
       if (snorm >= MINVAL) {
         const float gtol = tol * lstol * snorm * mi * nvf;
-        Mv = symm_mul_global<NVP>(c.M, nv, search, lane);
+        Mv = symm_mul_packed<NVP>(c.s_M, nv, search, lane);
         {
           float x16[NB];
           gather16<NB>(search, x16, lane);
@@ -697,6 +717,14 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
   }
   if (do_integrate && lane == 0) d.fold_valid[w] = 0;  // the state moved on
   PROF_FLUSH(d.profile + (size_t)w * 64);
+}
+
+template <int NVP>
+__device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const int w, const int lane, const int do_solve, const int do_integrate, const int flags,
+                                            float* smem) {
+  // wave-uniform; the common instantiation is the one with the row arrays in LDS
+  if (do_solve && d.nefc[w] > solve_lds_rows(m.size)) stage_solve_impl<NVP, true>(m, d, w, lane, do_solve, do_integrate, flags, smem);
+  else stage_solve_impl<NVP, false>(m, d, w, lane, do_solve, do_integrate, flags, smem);
 }
 
 template <int NVP>
