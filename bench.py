@@ -149,7 +149,7 @@ def main() -> None:
   step_graph = not args.no_graph and not args.no_step_graph
   if step_graph:
     roll.capture_graph()
-  exchange = info.world_size > 1 and not args.no_gather
+  exchange = (info.world_size > 1 or bool(os.environ.get("MJLAB_DIST_FORCE"))) and not args.no_gather
   nu = model.nu
   learner_gen = torch.Generator(device=dev)
   learner_gen.manual_seed(args.seed + 1000)

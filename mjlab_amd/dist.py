@@ -40,7 +40,9 @@ def init_from_env(envs_per_rank: int, backend: str | None = None) -> ShardInfo:
   world_size = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  if world_size > 1 and not dist.is_initialized():
+  global _FORCE
+  _FORCE = bool(os.environ.get("MJLAB_DIST_FORCE"))  # exercise the collectives with ONE rank (RCCL smoke on a 1-GPU box)
+  if (world_size > 1 or _FORCE) and not dist.is_initialized():
     if backend is None:
       # MJLAB_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
       # ranks (several ranks share a device; RCCL refuses that)
@@ -66,6 +68,7 @@ def device_index(info: ShardInfo) -> int:
   return info.local_rank % n if n else 0
 
 
+_FORCE = False
 _GATHER_SUPPORTED = True  # cleared when the backend turns out to have no gather (then: all-gather, rank dst keeps the result)
 _GATHER_BUF: dict = {}  # receive buffers, reused across control steps (the result is valid until the next call)
 
@@ -80,7 +83,7 @@ def gather_rollout(info: ShardInfo, rows: torch.Tensor, dst: int = 0, to_all: bo
   sends its shard once, straight to the learner over its own xGMI link -- 1/world_size of the bytes
   an all-gather moves, and no ring through links that are per-pair anyway.
   """
-  if info.world_size == 1:
+  if info.world_size == 1 and not _FORCE:
     return rows
   rows = rows.contiguous()
   if rows.is_cuda and dist.get_backend() == "gloo":
@@ -110,7 +113,7 @@ def gather_rollout(info: ShardInfo, rows: torch.Tensor, dst: int = 0, to_all: bo
 
 def scatter_actions(info: ShardInfo, actions_global: torch.Tensor | None, action_dim: int, device, src: int = 0) -> torch.Tensor:
   """Learner (rank ``src``) -> each rank's ``(envs_per_rank, action_dim)`` slice."""
-  if info.world_size == 1:
+  if info.world_size == 1 and not _FORCE:
     assert actions_global is not None
     return actions_global
   out = torch.empty((info.envs_per_rank, action_dim), dtype=torch.float32, device=device)
@@ -130,7 +133,7 @@ def scatter_actions(info: ShardInfo, actions_global: torch.Tensor | None, action
 
 
 def max_over_ranks(value: float, device) -> float:
-  if not dist.is_initialized() or dist.get_world_size() == 1:
+  if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
     return value
   if dist.get_backend() == "gloo":
     device = "cpu"
@@ -141,7 +144,7 @@ def max_over_ranks(value: float, device) -> float:
 
 def all_rank_values(value: float, device) -> list[float]:
   """The same scalar from every rank, in rank order (diagnostics: per-rank step times)."""
-  if not dist.is_initialized() or dist.get_world_size() == 1:
+  if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
     return [value]
   if dist.get_backend() == "gloo":
     device = "cpu"
@@ -151,5 +154,5 @@ def all_rank_values(value: float, device) -> list[float]:
 
 
 def barrier() -> None:
-  if dist.is_initialized() and dist.get_world_size() > 1:
+  if dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE):
     dist.barrier()

@@ -31,3 +31,18 @@ def test_bench_two_ranks_on_one_gpu():
   assert d["exchange_ms_per_step"] is not None and d["exchange_ms_per_step"] > 0
   assert d["value_with_gather"] == d["value"]  # N > 1: the exchange is inside the timed region
   assert d["cpu_baseline"] is None  # reported at N = 1 only
+
+
+def test_bench_exchange_over_rccl_with_one_rank():
+  """The collectives of the N > 1 path (broadcast of the actions, gather to the learner, max / all-gather of the timings,
+  barrier) issued through RCCL itself -- backend "nccl" -- with a single rank, the only form a 1-GPU box allows."""
+  env = dict(os.environ, MJLAB_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+  env.pop("MJLAB_DIST_BACKEND", None)
+  port = 29900 + os.getpid() % 90
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--envs-per-gpu", "256", "--no-cpu-baseline"]  # fmt: skip
+  p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert p.returncode == 0, p.stderr[-2000:]
+  d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+  assert d["n_gpus"] == 1 and d["value"] > 0
+  assert d["exchange_ms_per_step"] is not None and d["exchange_ms_per_step"] > 0
