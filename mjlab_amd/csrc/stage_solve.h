@@ -21,12 +21,20 @@ __host__ __device__ inline int solve_nvp(int nv) {
 #ifndef MJLAB_RCAP
 #define MJLAB_RCAP 128
 #endif
-__host__ __device__ inline int solve_lds_rows(const mjlab_sizes_t& s) { return s.njmax < MJLAB_RCAP ? s.njmax : MJLAB_RCAP; }
-__host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
+// everything but the per-row arrays: H / factor, 1 / D, scratch (friction-loss arrays during the solve, 64 floats for the
+// integrator after it), packed M
+__host__ __device__ inline int solve_lds_fixed_floats(const mjlab_sizes_t& s) {
   const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
-  const int scratch = 4 * nvp > 64 ? 4 * nvp : 64;  // friction-loss arrays during the solve, 64 floats for the integrator after it
-  return nvp * ld + nvp + 3 * solve_lds_rows(s) + scratch + nvp * (nvp + 1) / 2;
+  const int scratch = 4 * nvp > 64 ? 4 * nvp : 64;
+  return nvp * ld + nvp + scratch + nvp * (nvp + 1) / 2;
 }
+// as many rows as fit next to that in 10 KB (models smaller than the G1: up to all of njmax), never fewer than MJLAB_RCAP
+__host__ __device__ inline int solve_lds_rows(const mjlab_sizes_t& s) {
+  int rows = (2528 - solve_lds_fixed_floats(s)) / 3;
+  if (rows < MJLAB_RCAP) rows = MJLAB_RCAP;
+  return s.njmax < rows ? s.njmax : rows;
+}
+__host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) { return solve_lds_fixed_floats(s) + 3 * solve_lds_rows(s); }
 
 template <int NVP>
 struct SolveCtx {
