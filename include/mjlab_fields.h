@@ -186,6 +186,7 @@ enum {
 };
 enum { MJLAB_OBJ_BODY = 1, MJLAB_OBJ_XBODY = 2, MJLAB_OBJ_GEOM = 5, MJLAB_OBJ_SITE = 6 };
 enum { MJLAB_INT_EULER = 0, MJLAB_INT_IMPLICITFAST = 3 };
+enum { MJLAB_SOL_CG = 1, MJLAB_SOL_NEWTON = 2 };
 /* mjtConstraint (reference typings/mujoco/_enums.pyi:1029): values of efc_type */
 enum { MJLAB_EFC_FRICTION_DOF = 1, MJLAB_EFC_LIMIT = 3, MJLAB_EFC_CONTACT_FRICTIONLESS = 5, MJLAB_EFC_CONTACT_PYRAMIDAL = 6 };
 
@@ -226,7 +227,7 @@ typedef struct mjlab_option {
   int integrator;
   int cone;
   int flags; /* MJLAB_OPT_* bits below */
-  int pad_;
+  int solver; /* mjtSolver: MJLAB_SOL_CG or MJLAB_SOL_NEWTON */
 } mjlab_option_t;
 /* mjlab_option_t.flags */
 enum {

@@ -40,7 +40,7 @@ class Option(ctypes.Structure):
     ("integrator", ctypes.c_int),
     ("cone", ctypes.c_int),
     ("flags", ctypes.c_int),
-    ("pad_", ctypes.c_int),
+    ("solver", ctypes.c_int),
   ]
 
 
@@ -118,6 +118,7 @@ def fill_option(m: Model) -> Option:
   o.ls_iterations = m.opt.ls_iterations
   o.integrator = m.opt.integrator
   o.cone = m.opt.cone
+  o.solver = m.opt.solver
   import numpy as np
 
   o.flags = OPT_FRICTIONLOSS if np.any(np.asarray(m.dof_frictionloss) != 0) else 0

@@ -408,7 +408,9 @@ __device__ __forceinline__ float grad_noise(float ulps, float scale, bool own, f
 }
 
 // BIG: this world has more rows than the LDS arrays hold; the three per-row arrays live in global memory
-template <int NVP, bool BIG>
+// CG: mjSOL_CG -- no Hessian; the direction is M^-1 grad (the factor of M from ST_SMOOTH stays in LDS for the whole solve)
+// combined with the previous direction by Polak-Ribiere (mj_solPrimal with flg_Newton = 0)
+template <int NVP, bool BIG, bool CG>
 __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, const int w, const int lane, const int do_solve, const int do_integrate, const int flags,
                                                  float* smem) {
   constexpr int NB = CholCfg<NVP>::NB, ld = CholCfg<NVP>::LD;
@@ -454,6 +456,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
   c.nf = (do_solve && (m.opt.flags & MJLAB_OPT_FRICTIONLOSS)) ? d.nf[w] : 0;
 #endif
   float qacc = 0.f, fc = 0.f, qas = 0.f, Ma = 0.f, cost = 0.f, gauss = 0.f, rhs = 0.f;
+  float cg_search = 0.f, cg_grad = 0.f, cg_Mgrad = 0.f;  // CG: the previous direction, gradient and M^-1 gradient
   int iter = 0, state;
   bool need_factor = true;
   PROF_INIT();
@@ -612,20 +615,32 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           const int nact = build_active_list<NVP>(c, s_act);
           __syncthreads();
           f32x4 htile[NB * (NB + 1) / 2];
-          fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
+          fc = hessian_accum<NVP, !CG>(c, htile, s_act, nact);
           if (c.nf > 0) fc += friction_rows<NVP>(c);
           rhs = own ? Ma - qs - fc : 0.f;
-          hessian_store<NVP>(c, htile);
-          if (c.nf > 0) hessian_friction_diag<NVP>(c);
-          chol_pad_diag<NVP>(c.s_H, nv, lane);
+          if (!CG) {
+            hessian_store<NVP>(c, htile);
+            if (c.nf > 0) hessian_friction_diag<NVP>(c);
+            chol_pad_diag<NVP>(c.s_H, nv, lane);
+          }
         }
         PROF_MARK(3);
-        need_factor = true;
+        need_factor = !CG;  // CG: the factor of M is what the gradient goes through
         state = ST_NEWTON;
       }
     } else {
-      // ---- ST_NEWTON: x = H^-1 grad -> line search along -x, update, convergence test
-      const float search = own ? -x : 0.f;
+      // ---- ST_NEWTON: x = H^-1 grad (CG: M^-1 grad) -> line search along the direction, update, convergence test
+      float search = own ? -x : 0.f;
+      if (CG) {  // Polak-Ribiere; rhs is the gradient x was solved from
+        const float Mgrad = own ? x : 0.f;
+        float beta = 0.f;
+        if (iter > 0) {
+          const float num = wave_sum(rhs * (Mgrad - cg_Mgrad)), den = wave_sum(cg_grad * cg_Mgrad);
+          beta = fmaxf(0.f, num / fmaxf(den, MINVAL));
+        }
+        search = beta * cg_search - Mgrad;
+        cg_search = search; cg_grad = rhs; cg_Mgrad = Mgrad;
+      }
       const float snorm = sqrtf(wave_sum(search * search));
       float alpha = 0.f, Mv = 0.f;
       if (snorm >= MINVAL) {
@@ -677,7 +692,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         int* s_act = (int*)c.s_jv;  // J search is dead until the next line search
         const int nact = build_active_list<NVP>(c, s_act);
         __syncthreads();
-        if (any_changed) {
+        if (!CG && any_changed) {
           f32x4 htile[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
           if (c.nf > 0) fc += friction_rows<NVP>(c);
@@ -731,8 +746,12 @@ template <int NVP>
 __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const int w, const int lane, const int do_solve, const int do_integrate, const int flags,
                                             float* smem) {
   // wave-uniform; the common instantiation is the one with the row arrays in LDS
-  if (do_solve && d.nefc[w] > solve_lds_rows(m.size)) stage_solve_impl<NVP, true>(m, d, w, lane, do_solve, do_integrate, flags, smem);
-  else stage_solve_impl<NVP, false>(m, d, w, lane, do_solve, do_integrate, flags, smem);
+  const bool big = do_solve && d.nefc[w] > solve_lds_rows(m.size);
+  if (m.opt.solver == MJLAB_SOL_CG) {
+    if (big) stage_solve_impl<NVP, true, true>(m, d, w, lane, do_solve, do_integrate, flags, smem);
+    else stage_solve_impl<NVP, false, true>(m, d, w, lane, do_solve, do_integrate, flags, smem);
+  } else if (big) stage_solve_impl<NVP, true, false>(m, d, w, lane, do_solve, do_integrate, flags, smem);
+  else stage_solve_impl<NVP, false, false>(m, d, w, lane, do_solve, do_integrate, flags, smem);
 }
 
 template <int NVP>

@@ -110,8 +110,8 @@ def check_supported(model: Model) -> None:
   """Reject, loudly, every model feature the HIP kernels do not implement (instead of
   silently simulating something else).  The supported set is what BASELINE.json's
   configurations use."""
-  if model.opt.solver != SOL_NEWTON:
-    raise NotImplementedError("only the Newton solver is implemented")
+  if model.opt.solver not in (SOL_NEWTON, SOL_CG):
+    raise NotImplementedError("only the Newton and CG solvers are implemented (PGS is not)")
   if model.opt.cone != CONE_PYRAMIDAL:
     raise NotImplementedError("only the pyramidal cone is implemented")
   if model.opt.integrator not in (INT_EULER, INT_IMPLICITFAST):

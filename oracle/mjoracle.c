@@ -1036,6 +1036,9 @@ static void smooth_forces(const mjo_model_t* m, mjo_data_t* d, int w) {
 /* ------------------------------------------------------------------ Newton solver */
 typedef struct {
   int nv, nefc, nf, ls_iter; /* rows [0, nf) are friction-loss rows */
+  int cg;                    /* mjSOL_CG: no Hessian, directions preconditioned by M (its factor: qLD) */
+  const real* L;
+  real *Mgrad, *gradold, *Mgradold;
   const real *J, *Dv, *aref, *floss, *M, *qfrc_smooth, *qacc_smooth;
   real *qacc, *Ma, *jar, *grad, *search, *Mv, *jv, *force, *qfrc_constraint, *H;
   real quad_gauss[3], cost, gauss;
@@ -1081,6 +1084,11 @@ static void update_constraint(nctx_t* c) {
 static void update_gradient(nctx_t* c) {
   int nv = c->nv;
   for (int i = 0; i < nv; i++) c->grad[i] = c->Ma[i] - c->qfrc_smooth[i] - c->qfrc_constraint[i];
+  if (c->cg) { /* Mgrad = M^-1 grad (mj_solveM); the caller combines it with the previous direction */
+    memcpy(c->Mgrad, c->grad, sizeof(real) * nv);
+    chol_solve(c->L, nv, c->Mgrad);
+    return;
+  }
   memcpy(c->H, c->M, sizeof(real) * nv * nv);
   for (int r = 0; r < c->nefc; r++) {
     real rc, rfo;
@@ -1254,9 +1262,12 @@ static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
   c.J = D(efc_J, njm * nv); c.Dv = D(efc_D, njm); c.aref = D(efc_aref, njm); c.floss = D(efc_frictionloss, njm); c.M = D(qM, nv * nv);
   c.qfrc_smooth = D(qfrc_smooth, nv); c.qacc_smooth = qas; c.qacc = qacc; c.force = force;
   c.qfrc_constraint = D(qfrc_constraint, nv);
-  real* buf = (real*)calloc((size_t)5 * nv + 2 * nefc + (size_t)nv * nv, sizeof(real));
+  c.cg = m->opt.solver == MJLAB_SOL_CG;
+  c.L = D(qLD, nv * nv);
+  real* buf = (real*)calloc((size_t)8 * nv + 2 * nefc + (size_t)nv * nv, sizeof(real));
   c.Ma = buf; c.grad = buf + nv; c.search = buf + 2 * nv; c.Mv = buf + 3 * nv;
-  c.jar = buf + 5 * nv; c.jv = c.jar + nefc; c.H = c.jv + nefc;
+  c.Mgrad = buf + 5 * nv; c.gradold = buf + 6 * nv; c.Mgradold = buf + 7 * nv;
+  c.jar = buf + 8 * nv; c.jv = c.jar + nefc; c.H = c.jv + nefc;
   /* warmstart: better of qacc_warmstart and qacc_smooth */
   real cw = constraint_cost_at(&c, ws, 1), cs = constraint_cost_at(&c, qas, 0);
   memcpy(qacc, cw > cs ? qas : ws, sizeof(real) * nv);
@@ -1274,6 +1285,7 @@ static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
   real scale = 1 / ((real)m->opt.meaninertia * (nv > 1 ? nv : 1));
   update_constraint(&c);
   update_gradient(&c);
+  if (c.cg) for (int i = 0; i < nv; i++) c.search[i] = -c.Mgrad[i];
   int iter = 0;
   while (iter < m->opt.iterations) {
     real alpha = line_search(m, &c);
@@ -1281,8 +1293,16 @@ static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
     for (int i = 0; i < nv; i++) { qacc[i] += alpha * c.search[i]; c.Ma[i] += alpha * c.Mv[i]; }
     for (int r = 0; r < nefc; r++) c.jar[r] += alpha * c.jv[r];
     real oldcost = c.cost;
+    if (c.cg) { memcpy(c.gradold, c.grad, sizeof(real) * nv); memcpy(c.Mgradold, c.Mgrad, sizeof(real) * nv); }
     update_constraint(&c);
     update_gradient(&c);
+    if (c.cg) { /* Polak-Ribiere: beta = grad . (Mgrad - Mgradold) / (gradold . Mgradold), clamped at 0 (mj_solPrimal) */
+      real num = 0, den = 0;
+      for (int i = 0; i < nv; i++) { num += c.grad[i] * (c.Mgrad[i] - c.Mgradold[i]); den += c.gradold[i] * c.Mgradold[i]; }
+      real beta = num / (den > MINVAL ? den : MINVAL);
+      if (beta < 0) beta = 0;
+      for (int i = 0; i < nv; i++) c.search[i] = -c.Mgrad[i] + beta * c.search[i];
+    }
     real improvement = scale * (oldcost - c.cost), gn = 0, tn = 0;
     for (int i = 0; i < nv; i++) {
       real t = fabs(c.Ma[i]) + fabs(c.qfrc_smooth[i]) + fabs(c.qfrc_constraint[i]);

@@ -543,6 +543,62 @@ def test_friction_loss_on_every_joint_of_the_g1_tracks_the_oracle():
   assert _rel(_np(sim.data.qacc), ora.qacc) < 2e-05
 
 
+@pytest.mark.parametrize("name,iterations", [("mixed", 100), ("g1_velocity_flat", 10), ("g1_velocity_flat", 100), ("go1_velocity_flat", 50)])
+def test_cg_solver_tracks_the_oracle_and_converges_to_newton(name, iterations):
+  """MujocoCfg(solver="cg") (reference sim/sim.py:56): the Polak-Ribiere CG of mj_solPrimal, preconditioned by M.
+  Device vs the restatement's CG on the same states and over a short rollout (fp32 and fp64 take different numbers of
+  iterations near the tolerance, so the iterate is compared where both converged and the COST everywhere), and CG with
+  enough iterations lands on the Newton solution."""
+  import copy
+
+  import torch
+
+  from mjlab_amd import mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = copy.deepcopy(models()[name])
+  model.opt.solver = mjcf.SOL_CG
+  model.opt.iterations = iterations
+  nworld = 16
+  qpos, qvel, ctrl = golden_inputs(model, nworld, 41)
+  sim = Simulation(nworld, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
+  ora = OracleSim(model, nworld, njmax=300, precision="f64")
+  ora32 = OracleSim(model, nworld, njmax=300, precision="f32")
+  for o in (ora, ora32):
+    for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+      getattr(o, f)[:] = v
+  for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+    getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+  sim.data.qacc_warmstart.zero_()  # the constructor's forward() left its own solution there; a capped CG depends on where it starts
+  sim.forward()
+  ora.forward()
+  ora32.forward()
+  it_g, it_o = _np(sim.data.solver_niter).ravel(), ora.solver_niter.ravel()
+  assert it_g.max() <= iterations and (it_g > 0).any()
+  if iterations >= 50:  # converged on both sides: same solution, and it is Newton's
+    # linear convergence + the fp32 noise floor of the termination test: the fp32 build of the restatement is itself
+    # 1e-3 .. 2e-3 from the fp64 one here (Newton: 1e-5)
+    assert _rel(_np(sim.data.qacc), ora.qacc) < 1e-02
+    newton = copy.deepcopy(model)
+    newton.opt.solver = mjcf.SOL_NEWTON
+    on = OracleSim(newton, nworld, njmax=300, precision="f64")
+    for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+      getattr(on, f)[:] = v
+    on.forward()
+    assert _rel(_np(sim.data.qacc), on.qacc) < 1e-02
+    assert abs(float(np.median(it_g)) - float(np.median(ora32.solver_niter))) <= max(6, iterations // 5)
+  else:  # both sides stop at the cap in most worlds: same iterate as the fp32 build of the restatement
+    assert (it_o == iterations).mean() > 0.3
+    assert _rel(_np(sim.data.qacc), ora32.qacc) < 2e-03  # 6e-5 after one iteration, growing along the CG path
+    return  # ten CG iterations leave the contacts unresolved: a rollout from there amplifies any difference
+  for _ in range(5):
+    sim.step()
+  ora.step(5)
+  ora32.step(5)
+  assert _rel(_np(sim.data.qpos), ora32.qpos) < 1e-03
+  assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-03
+
+
 MULTI_JOINT_XML = """
 <mujoco model="multi_joint">
   <compiler angle="radian" autolimits="true"/>

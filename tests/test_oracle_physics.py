@@ -233,6 +233,40 @@ def test_friction_loss_rows_come_first_in_dof_order_and_use_the_dof_solref():
   assert np.all(np.abs(s.efc_force[0, :3]) <= s.efc_frictionloss[0, :3] + 1e-12)
 
 
+def _primal_cost(s, m, w=0):
+  nv, n = m.nv, int(s.nefc[w, 0])
+  M, J = s.qM[w].reshape(nv, nv), s.efc_J[w].reshape(-1, nv)[:n]
+  da = s.qacc[w] - s.qacc_smooth[w]
+  jar = np.minimum(J @ s.qacc[w] - s.efc_aref[w, :n], 0)
+  return 0.5 * da @ M @ da + 0.5 * np.sum(s.efc_D[w, :n] * jar * jar)
+
+
+def test_cg_solver_descends_monotonically_to_the_newton_solution():
+  """mjSOL_CG (MujocoCfg.solver = "cg", reference sim/sim.py:56): Polak-Ribiere directions preconditioned by M.  The primal
+  cost never increases with the iteration cap, a capped run is what it says (solver_niter), and with enough iterations the
+  iterate is the Newton solution."""
+  from mjlab_amd import mjcf
+
+  m = robots.mixed_model()
+  ref = OracleSim(m)
+  ref.forward()
+  costs, last = [], None
+  for it in (1, 2, 4, 8, 16, 32, 200):
+    mc = robots.mixed_model()
+    mc.opt.solver, mc.opt.iterations = mjcf.SOL_CG, it
+    s = OracleSim(mc)
+    s.forward()
+    assert s.solver_niter[0, 0] <= it
+    costs.append(_primal_cost(s, mc))
+    last = s
+  assert all(b <= a * (1 + 1e-12) + 1e-12 for a, b in zip(costs, costs[1:]))
+  assert costs[0] > costs[-1] * 1.0001  # one iteration is not enough on this model
+  assert 10 < last.solver_niter[0, 0] < 200  # converged by the tolerance, not by the cap; Newton needs 5
+  # the scaled-improvement test ends a linearly converging method a little before the minimiser: 5e-5 of |qacc| here
+  assert np.abs(last.qacc[0] - ref.qacc[0]).max() < 2e-4 * np.abs(ref.qacc[0]).max()
+  assert _primal_cost(last, m) == pytest.approx(_primal_cost(ref, m), rel=1e-7)
+
+
 def test_contact_primitives_and_sensor():
   m = robots.mixed_model()
   s = OracleSim(m)

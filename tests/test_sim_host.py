@@ -20,7 +20,7 @@ def test_supported_models_pass():
 @pytest.mark.parametrize(
   "mutate, match",
   [
-    (lambda m: setattr(m.opt, "solver", 1), "Newton"),
+    (lambda m: setattr(m.opt, "solver", 0), "PGS"),
     (lambda m: setattr(m.opt, "cone", 1), "pyramidal"),
     (lambda m: m.jnt_type.__setitem__(2, 1), "ball"),
     (lambda m: m.geom_condim.__setitem__(slice(None), 4), "condim"),
