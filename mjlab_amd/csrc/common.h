@@ -18,15 +18,20 @@ __device__ __forceinline__ int launder(int x) {
 // a second trip and the line search leaves its register-cached rows.  Letting them issue ahead of the cheap worlds they
 // share a SIMD with (which have slack anyway) shortens the launch by 8-10 %; results do not depend
 // on it.  Set when a world's row count is known (start of every solve) and kept until the next solve.
+// With thresholds from the host (data.sched_thr: quantiles of the score over all worlds, refreshed every few steps) the
+// classes follow the batch at hand -- a Go1 world never has 32 rows, its expensive worlds are the ones whose solver
+// needs more iterations; without them the row-count thresholds above apply.
 #ifndef MJLAB_NO_WAVE_PRIORITY
-__device__ __forceinline__ void wave_priority(int nefc) {
-  if (nefc > 80) __builtin_amdgcn_s_setprio(3);
-  else if (nefc > 64) __builtin_amdgcn_s_setprio(2);
-  else if (nefc > 32) __builtin_amdgcn_s_setprio(1);
+__device__ __forceinline__ void wave_priority(int nefc, int niter_prev, const int* thr) {
+  int x = nefc, t1 = 32, t2 = 64, t3 = 80;
+  if (thr[2] > 0) { x = nefc * (niter_prev + 2); t1 = thr[0]; t2 = thr[1]; t3 = thr[2]; }
+  if (x > t3) __builtin_amdgcn_s_setprio(3);
+  else if (x > t2) __builtin_amdgcn_s_setprio(2);
+  else if (x > t1) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
 }
 #else
-__device__ __forceinline__ void wave_priority(int) {}
+__device__ __forceinline__ void wave_priority(int, int, const int*) {}
 #endif
 __device__ __forceinline__ float lane_bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));

@@ -747,7 +747,7 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
                                             float* smem) {
   // wave-uniform; the common instantiation is the one with the row arrays in LDS
   const bool big = do_solve && d.nefc[w] > solve_lds_rows(m.size);
-  if (do_solve) wave_priority(__builtin_amdgcn_readfirstlane(d.nefc[w]));
+  if (do_solve) wave_priority(__builtin_amdgcn_readfirstlane(d.nefc[w]), __builtin_amdgcn_readfirstlane(d.solver_niter[w]), d.sched_thr);
   if (m.opt.solver == MJLAB_SOL_CG) {
     if (big) stage_solve_impl<NVP, true, true>(m, d, w, lane, do_solve, do_integrate, flags, smem);
     else stage_solve_impl<NVP, false, true>(m, d, w, lane, do_solve, do_integrate, flags, smem);

@@ -184,6 +184,9 @@ class PhysicsRollout:
     ``decimation`` physics steps, termination test, masked reset and the forward pass -- is
     ONE hipGraph replay (resets are mask based, so there is no
     ``nonzero()`` host sync and nothing data dependent on the host side)."""
+    self._nstep = getattr(self, "_nstep", 0) + 1
+    if self._nstep % 16 == 0:  # wave-priority classes follow the batch (a few small device ops, outside the graph)
+      self.sim.update_priority_thresholds()
     if self._graph is not None:
       if action is not self._action_buf:  # random_action(out=...) / a policy may write the static buffer directly
         self._action_buf.copy_(action)

@@ -232,6 +232,10 @@ class Simulation:
 
     if getattr(cfg.nan_guard, "enabled", False):
       raise NotImplementedError("nan_guard is not provided by mjlab_amd (append a callable to Simulation.post_step_hooks instead)")
+    self._step_calls = 0
+    self.priority_refresh = not os.environ.get("MJLAB_NO_PRIORITY_REFRESH")
+    q = os.environ.get("MJLAB_PRIO_Q")
+    self._prio_q = torch.tensor([float(x) for x in q.split(",")] if q else list(self.PRIORITY_QUANTILES), device=dev)
     self.post_step_hooks: list = []  # callables(sim) run after every step() (where the reference's NaN guard sits)
     self.use_graph = bool(cfg.use_graph) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
     self.step_graph: torch.cuda.CUDAGraph | None = None
@@ -376,8 +380,25 @@ class Simulation:
         self._step_once()
       else:
         self._launch_step(nsubstep)
+      self._step_calls += 1
+      if self._step_calls % 64 == 0:
+        self.update_priority_thresholds()
       for hook in self.post_step_hooks:
         hook(self)
+
+  # quantiles of the per-world score nefc x (solver_niter + 2) that separate the wave-priority classes 0 | 1 | 2 | 3
+  PRIORITY_QUANTILES = (0.45, 0.85, 0.95)
+
+  def update_priority_thresholds(self) -> None:
+    """Refresh ``data.sched_thr`` (include/mjlab_fields.h) from the current batch: a handful of small device ops, no host
+    sync.  ``step()`` does it every 64th call, ``PhysicsRollout.step`` every 16th control step; the kernels use their
+    built-in row-count thresholds until the first refresh.  A scheduling hint: results do not depend on it."""
+    if self.num_envs < 64 or not self.priority_refresh:
+      return
+    d = self._data
+    score = (d["nefc"].view(-1) * (d["solver_niter"].view(-1) + 2)).float()
+    q = torch.quantile(score, self._prio_q)
+    d["sched_thr"].view(-1)[:3] = q.clamp_(min=1.0).to(torch.int32)
 
   def invalidate_fold(self) -> None:
     """Forget the last forward pass ("forward folded into the next step").  Needed only by callers

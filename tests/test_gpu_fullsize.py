@@ -343,6 +343,37 @@ def test_whole_step_graph_equals_eager_rollout():
     assert torch.equal(getattr(rolls[0].sim.data, f), getattr(rolls[1].sim.data, f)), f
 
 
+def test_wave_priorities_do_not_change_results():
+  """`data.sched_thr` (score quantiles written by `update_priority_thresholds`) only ranks the waves of a SIMD against each
+  other (s_setprio): a rollout with the refresh, one without it and one with absurd thresholds are bitwise the same."""
+  import torch
+
+  from mjlab_amd import robots
+  from mjlab_amd.rollout import VELOCITY_TASK_EVENTS, PhysicsRollout, go1_action_scale
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = robots.load_model("go1_velocity_flat")
+  rolls = []
+  for mode in ("refresh", "static", "absurd"):
+    sim = Simulation(1024, SimulationCfg(njmax=100), model, "cuda:0")
+    sim.priority_refresh = mode == "refresh"
+    if mode == "absurd":
+      sim.data.sched_thr.view(-1)[:3] = torch.tensor([1, 2, 3], dtype=torch.int32, device="cuda")  # every world in the top class
+    rolls.append(PhysicsRollout(sim, action_scale=go1_action_scale(model), seed=5, substeps_per_call=4, control_kernel=True, **VELOCITY_TASK_EVENTS["go1"]))
+  gen = torch.Generator(device="cuda").manual_seed(9)
+  for _ in range(40):
+    act = torch.rand((1024, model.nu), device="cuda", generator=gen) * 2 - 1
+    for r in rolls:
+      r.step(act)
+  torch.cuda.synchronize()
+  thr = rolls[0].sim.data.sched_thr.view(-1)[:3].tolist()
+  assert 0 < thr[0] <= thr[1] <= thr[2]  # refreshed at control steps 16 and 32 from the batch's own scores
+  assert rolls[1].sim.data.sched_thr.view(-1)[:3].tolist() == [0, 0, 0]
+  for f in ("qpos", "qvel", "qacc", "efc_force", "sensordata", "solver_niter"):
+    for r in rolls[1:]:
+      assert torch.equal(getattr(rolls[0].sim.data, f), getattr(r.sim.data, f)), f
+
+
 def test_fused_masked_reset_equals_torch_chain():
   """mjlab_masked_reset vs the same termination + reset logic as torch ops (the reference's
   style): identical reset decisions and untouched worlds; reset worlds carry a valid sample of
