@@ -393,7 +393,7 @@ class Simulation:
     """Refresh ``data.sched_thr`` (include/mjlab_fields.h) from the current batch: a handful of small device ops, no host
     sync.  ``step()`` does it every 64th call, ``PhysicsRollout.step`` every 16th control step; the kernels use their
     built-in row-count thresholds until the first refresh.  A scheduling hint: results do not depend on it."""
-    if self.num_envs < 64 or not self.priority_refresh:
+    if self.num_envs < 64 or not self.priority_refresh or torch.cuda.is_current_stream_capturing():
       return
     d = self._data
     score = (d["nefc"].view(-1) * (d["solver_niter"].view(-1) + 2)).float()
