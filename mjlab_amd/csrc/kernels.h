@@ -69,7 +69,7 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #define CHOL_INLINE __forceinline__
 
 #ifndef MJLAB_CB
-#define MJLAB_CB 12
+#define MJLAB_CB 8
 #endif
 #define MINVAL 1e-15f
 #define MINIMP 0.0001f
