@@ -158,7 +158,7 @@ def main() -> None:
 
   def env_step(with_rows: bool = False) -> None:
     """One control step.  N > 1: the learner on rank 0 decides the actions of ALL envs, every rank
-    receives its slice (broadcast over RCCL), steps its shard, and the [obs | ...] rows travel back to
+    receives its slice (scatter over RCCL), steps its shard, and the [obs | ...] rows travel back to
     the learner (gather) -- the exchange SURVEY.md section 8e pairs with env sharding."""
     if exchange:
       a_all = torch.rand((info.global_envs, nu), device=dev, generator=learner_gen) * 2 - 1 if info.rank == 0 else None
@@ -206,7 +206,7 @@ def main() -> None:
       env_step(with_rows=True)
     torch.cuda.synchronize()
     value_with_rows = args.envs_per_gpu * args.steps / (time.perf_counter() - t1)
-  # the exchange alone (N > 1), so that a scaling curve can be read: broadcast of actions + gather of rows
+  # the exchange alone (N > 1), so that a scaling curve can be read: scatter of actions + gather of rows
   comm_ms = None
   if exchange:
     rows = roll.observation_rows()
@@ -344,7 +344,7 @@ def main() -> None:
         "workload": f"{args.scene}: {args.envs_per_gpu} envs/GPU, timestep 0.005, decimation 4, Newton 10 it / 20 ls, implicitfast, pyramidal, njmax 300"
         + ("" if args.no_task_events else "; task events: DR friction (per-env geom_friction), pushes, bad_orientation 70 deg termination"),
         "global_envs": n_env,
-        "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL action broadcast and obs gather to the learner (rank 0) every control step" if exchange else ""),
+        "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL action scatter and obs gather to the learner (rank 0) every control step" if exchange else ""),
         "graph": "one hipGraph per control step" if step_graph else ("per-call step/forward hipGraphs" if sim.use_graph else "none"),
         "launches": {"stage": "one kernel per stage (5 per substep)", "presolve": "pre-solve stages fused (2 per substep)", "step": "one kernel per substep"}[args.fuse]
         + (", whole control step (action, 4 substeps, reset, forward" + (", EntityData read-back" if roll.readback is not None else "")

@@ -69,6 +69,7 @@ def device_index(info: ShardInfo) -> int:
 
 
 _FORCE = False
+_SCATTER_SUPPORTED = True
 _GATHER_SUPPORTED = True  # cleared when the backend turns out to have no gather (then: all-gather, rank dst keeps the result)
 _GATHER_BUF: dict = {}  # receive buffers, reused across control steps (the result is valid until the next call)
 
@@ -117,9 +118,20 @@ def scatter_actions(info: ShardInfo, actions_global: torch.Tensor | None, action
     assert actions_global is not None
     return actions_global
   out = torch.empty((info.envs_per_rank, action_dim), dtype=torch.float32, device=device)
+  global _SCATTER_SUPPORTED
   if dist.get_backend() == "nccl":
-    # RCCL has no scatter from a list on every version: broadcast + slice keeps it to one
-    # collective of N x action_dim floats (475 KB at 4096 x 29), far below link bandwidth.
+    # Scatter: every rank receives only its own slice (475 KB at 4096 x 29), sent by the learner over that rank's own xGMI
+    # link -- 1 / world_size of what a broadcast of all the actions moves through every link.  A build of the backend
+    # without scatter falls back to broadcast + slice (the same on every rank: the error is raised before anything is enqueued).
+    if _SCATTER_SUPPORTED:
+      try:
+        chunks = list(actions_global.contiguous().chunk(info.world_size)) if info.rank == src else None
+        dist.scatter(out, chunks, src=src)
+        return out
+      except (RuntimeError, NotImplementedError) as e:
+        if "scatter" not in str(e).lower() and "support" not in str(e).lower():
+          raise
+        _SCATTER_SUPPORTED = False
     buf = actions_global if info.rank == src else torch.empty((info.global_envs, action_dim), dtype=torch.float32, device=device)
     dist.broadcast(buf, src=src)
     out.copy_(buf[info.env_slice])

@@ -1,6 +1,6 @@
 """bench.py's multi-rank path end to end on ONE GPU: two ranks share the device over the gloo backend
 (MJLAB_DIST_BACKEND=gloo; RCCL refuses two ranks on one device), launched exactly as the driver launches
-the scaling run.  Checks the contract line: n_gpus, the exchange on the timed path (action broadcast +
+the scaling run.  Checks the contract line: n_gpus, the exchange on the timed path (action scatter +
 observation gather to the learner), per-rank diagnostics."""
 
 import json
@@ -26,7 +26,7 @@ def test_bench_two_ranks_on_one_gpu():
   d = json.loads(line)
   assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 512 and d["scaling"] == "weak"
   assert d["value"] > 0 and d["steps"] == 6 and d["warmup"] == 2
-  assert "action broadcast" in d["config"]["parallelism"] and "gather" in d["config"]["parallelism"]
+  assert "action scatter" in d["config"]["parallelism"] and "gather" in d["config"]["parallelism"]
   assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
   assert d["exchange_ms_per_step"] is not None and d["exchange_ms_per_step"] > 0
   assert d["value_with_gather"] == d["value"]  # N > 1: the exchange is inside the timed region
@@ -34,7 +34,7 @@ def test_bench_two_ranks_on_one_gpu():
 
 
 def test_bench_exchange_over_rccl_with_one_rank():
-  """The collectives of the N > 1 path (broadcast of the actions, gather to the learner, max / all-gather of the timings,
+  """The collectives of the N > 1 path (scatter of the actions, gather to the learner, max / all-gather of the timings,
   barrier) issued through RCCL itself -- backend "nccl" -- with a single rank, the only form a 1-GPU box allows."""
   env = dict(os.environ, MJLAB_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
   env.pop("MJLAB_DIST_BACKEND", None)
