@@ -203,6 +203,52 @@ def test_diverged_world_is_isolated():
     assert torch.equal(getattr(a.data, f)[keep], getattr(b.data, f)[keep]), f
 
 
+@pytest.mark.parametrize("scene", ["g1_velocity_rough", "go1_velocity_rough"])
+def test_garbage_states_on_the_terrain_neither_fault_nor_leak(scene):
+  """Worlds whose state is NaN / infinite / astronomically far away (what a diverged policy produces before the NaN guard
+  or the termination test sees it) must not take the launch down -- the terrain grid walk turns positions into cell
+  indices -- nor touch their neighbours: through the stage kernels and through the whole-control-step kernel."""
+  import torch
+
+  from mjlab_amd import robots
+  from mjlab_amd.rollout import VELOCITY_TASK_EVENTS, PhysicsRollout, g1_action_scale, go1_action_scale
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = robots.load_model(scene)
+  robot = "go1" if scene.startswith("go1") else "g1"
+  scale = go1_action_scale(model) if robot == "go1" else g1_action_scale(model)
+  n = 256
+  bad = {3: float("nan"), 40: float("inf"), 41: -float("inf"), 77: 3.0e38, 130: -1.0e30, 200: 1.0e9}
+  sims = []
+  for poison in (False, True):
+    sim = Simulation(n, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
+    roll = PhysicsRollout(sim, action_scale=scale, seed=3, substeps_per_call=4, control_kernel=True, episode_length_s=1e6, **VELOCITY_TASK_EVENTS[robot])
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for k in range(6):
+      if poison and k == 2:
+        for w, v in bad.items():
+          sim.data.qpos[w, :3] = v  # the floating base's position
+        sim.data.qvel[9, :] = float("nan")
+      act = torch.rand((n, model.nu), device="cuda", generator=gen) * 2 - 1
+      roll.step(act)
+      if poison and k == 3:  # and once through the per-stage kernels
+        sim2 = Simulation(n, SimulationCfg(njmax=300, use_graph=False, fuse="stage"), model, "cuda:0")
+        for f in ("qpos", "qvel", "ctrl"):
+          getattr(sim2.data, f)[:] = getattr(sim.data, f)
+        for w, v in bad.items():
+          sim2.data.qpos[w, :3] = v
+        sim2.step()
+        sim2.forward()
+        torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    sims.append(sim)
+  keep = torch.ones(n, dtype=torch.bool, device="cuda")
+  keep[list(bad) + [9]] = False
+  for f in ("qpos", "qvel", "qacc", "xpos", "sensordata"):
+    assert torch.equal(getattr(sims[0].data, f)[keep], getattr(sims[1].data, f)[keep]), f
+  assert torch.isfinite(sims[1].data.qpos[keep]).all()
+
+
 def test_forward_is_idempotent_and_stage_split_equals_step():
   import torch
 
