@@ -599,6 +599,67 @@ def test_cg_solver_tracks_the_oracle_and_converges_to_newton(name, iterations):
   assert _rel(_np(sim.data.qpos), ora.qpos) < 2e-03
 
 
+@pytest.mark.parametrize("solver", ["newton", "cg"])
+def test_every_solver_instantiation_with_friction_loss_and_hundreds_of_rows(solver):
+  """The four instantiations of the solver code (row arrays in LDS / in global memory for worlds with more rows than LDS
+  holds, Newton / CG) with friction-loss rows present: a large geom margin gives 150-300 rows per world (the global-memory
+  instantiation), the unmodified margin the usual 20-60.  Compared with the fp32 build of the restatement by the primal
+  cost reached (the iterates of capped solves differ) and, for Newton, by the iterate."""
+  import copy
+
+  import torch
+
+  from mjlab_amd import mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  for margin in (None, 0.25):
+    model = copy.deepcopy(models()["g1_velocity_flat"])
+    if margin is not None:
+      model.geom_margin = np.full_like(model.geom_margin, margin)
+    fl = np.zeros(model.nv)
+    fl[6:] = np.linspace(0.05, 1.0, model.nv - 6)
+    model.dof_frictionloss = fl
+    model.opt.solver = mjcf.SOL_CG if solver == "cg" else mjcf.SOL_NEWTON
+    model.opt.iterations = 60 if solver == "cg" else 10
+    nworld = 8
+    qpos, qvel, ctrl = golden_inputs(model, nworld, 13)
+    sim = Simulation(nworld, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
+    ora = OracleSim(model, nworld, njmax=300, precision="f32")
+    for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+      getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+      getattr(ora, f)[:] = v
+    sim.data.qacc_warmstart.zero_()
+    sim.forward()
+    ora.forward()
+    nefc = ora.nefc.ravel()
+    assert np.array_equal(_np(sim.data.nefc).ravel(), nefc) and np.array_equal(_np(sim.data.nf).ravel(), ora.nf.ravel())
+    assert (nefc > 128).all() if margin is not None else (nefc <= 128).sum() >= 4  # both instantiations, also within one launch
+    assert torch.isfinite(sim.data.qacc).all()
+    nv, nf = model.nv, int(ora.nf[0, 0])
+
+    def cost(qacc, w):  # primal cost with the Huber zones of the friction-loss rows, from the oracle's own arrays (fp64 arithmetic)
+      n = int(nefc[w])
+      M, J = ora.qM[w].reshape(nv, nv).astype(np.float64), ora.efc_J[w].reshape(-1, nv)[:n].astype(np.float64)
+      D, fl_ = ora.efc_D[w, :n].astype(np.float64), ora.efc_frictionloss[w, :n].astype(np.float64)
+      da = qacc.astype(np.float64) - ora.qacc_smooth[w]
+      x = J @ qacc.astype(np.float64) - ora.efc_aref[w, :n]
+      c = 0.5 * da @ M @ da
+      for r in range(n):
+        if r < nf:
+          rf = fl_[r] / D[r]
+          c += 0.5 * D[r] * x[r] ** 2 if abs(x[r]) < rf else fl_[r] * (abs(x[r]) - 0.5 * rf)
+        elif x[r] < 0:
+          c += 0.5 * D[r] * x[r] ** 2
+      return c
+
+    g = _np(sim.data.qacc)
+    for w in range(nworld):
+      cg_, co_ = cost(g[w], w), cost(ora.qacc[w], w)
+      assert cg_ <= co_ * 1.02 + 1e-6, (solver, margin, w, cg_, co_)
+    if solver == "newton" and margin is None:
+      assert _rel(g, ora.qacc) < 1e-04
+
+
 MULTI_JOINT_XML = """
 <mujoco model="multi_joint">
   <compiler angle="radian" autolimits="true"/>
