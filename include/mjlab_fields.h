@@ -157,7 +157,6 @@
   X(efc_aref, 1, njmax)                                                         \
   X(efc_force, 1, njmax)                                                        \
   X(efc_frictionloss, 1, njmax) /* written for the friction-loss rows only: rows [0, nf) */ \
-  X(efc_scratch, 1, njmax) /* solver scratch of the HIP kernels (rows beyond the LDS-resident ones); not an output */ \
   X(sh_qpos, 1, nq) /* qpos / qvel as they were at the last forward(): see fold_valid */ \
   X(sh_qvel, 1, nv)                                                             \
   X(profile, 64, one) /* per-world per-phase cycle counts; written only by -DMJLAB_PROFILE builds */

