@@ -204,7 +204,12 @@ __global__ __launch_bounds__(64, MJLAB_WPE) void k_control_step(const Model m_, 
     if (lane == 0) interval_push_world(m, d, w, c.push_time_left, c.rnd7, c.push_dt, c.push_interval_lo, c.push_interval_hi, c.push_range);
   }
 #ifdef MJLAB_PROFILE
-  if (threadIdx.x == 0) d_.profile[(size_t)wsel_ * 64 + 63] += (float)(clock64() - t_begin_);  // this world's share of the launch
+  if (threadIdx.x == 0) {
+    d_.profile[(size_t)wsel_ * 64 + 63] += (float)(clock64() - t_begin_);  // this world's share of the launch
+    // where the wave ran: HW_REG_HW_ID (wave / simd / cu / sh / se fields) and HW_REG_XCC_ID, of workgroup blockIdx.x
+    d_.profile[(size_t)blockIdx.x * 64 + 61] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff);
+    d_.profile[(size_t)blockIdx.x * 64 + 62] = (float)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf);
+  }
 #endif
 }
 
