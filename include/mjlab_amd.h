@@ -37,8 +37,8 @@ enum {
   MJLAB_STAGE_POSITION = 1,   /* kinematics, comPos, crb, factorM          */
   MJLAB_STAGE_COLLISION = 2,  /* broad + narrow phase -> contacts          */
   MJLAB_STAGE_VELOCITY = 4,   /* comVel, passive, rne, actuation, qacc_smooth */
-  MJLAB_STAGE_CONSTRAINT = 8, /* makeConstraint (limits + contacts), contact sensors */
-  MJLAB_STAGE_SOLVE = 16,     /* Newton solver -> qacc, efc_force          */
+  MJLAB_STAGE_CONSTRAINT = 8, /* makeConstraint (friction loss + limits + contacts), contact sensors */
+  MJLAB_STAGE_SOLVE = 16,     /* Newton / CG solver (mjlab_option_t.solver) -> qacc, efc_force */
   MJLAB_STAGE_INTEGRATE = 32, /* Euler / implicitfast position+velocity update */
   MJLAB_STAGE_FORWARD = 31,
   MJLAB_STAGE_STEP = 63
