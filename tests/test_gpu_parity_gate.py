@@ -71,6 +71,7 @@ CASES = [
   ("g1_velocity_flat", 25, "f64", ("geom_friction",)),
   ("g1_velocity_flat", 250, "f64", ("geom_friction",)),
   ("g1_velocity_flat", 250, "f32", ("geom_friction",)),
+  ("g1_velocity_flat", 250, "f64", ("geom_friction", "dof_frictionloss")),  # friction-loss rows (Huber cost) in the mix
   ("g1_tracking_flat", 25, "f64", ("geom_friction", "body_ipos", "qpos0")),
   ("g1_tracking_flat", 250, "f64", ("geom_friction", "body_ipos", "qpos0")),
   ("g1_tracking_flat", 250, "f32", ("geom_friction", "body_ipos", "qpos0")),
@@ -118,7 +119,13 @@ def test_rollout_state_parity(scene, steps, precision, expand):
 
   rough = scene.endswith("rough")
   r = scene_report(scene, N, steps, precision, expand=expand, spread=3.5 if rough else None)
-  _check(r, ROUGH if rough else FLAT)
+  tol = ROUGH if rough else FLAT
+  if "dof_frictionloss" in expand:
+    # ~15 more rows per world (mean 53, up to 128): one world in 1024 ends its Newton iteration at the cap of 10 on both
+    # sides, where the iterate depends on rounding (measured: qacc 3.3e-2 in that world, p99 9.4e-6 as without the rows).
+    # Median and p99 keep the literals of the flat scenes; only the worst-world bounds are those of a capped solve.
+    tol = dict(tol, qacc_max=1e-1, qfc_max=1e-1, step_qpos_max=5e-3, step_qvel_max=2.5e-1)
+  _check(r, tol)
   if rough:
     # the compared states really are on the stairs, not on the flat spawn platforms
     assert r["worlds_with_terrain_contact"] >= 0.8 * N

@@ -56,6 +56,9 @@ def randomize_model(sim: Simulation, ora: OracleSim, model, fields, seed: int) -
       new[:, root] += rng.uniform(-0.05, 0.05, (n, 3)) * np.array([0.5, 1.0, 1.0])
     elif f == "qpos0":
       new[:, 7:] += rng.uniform(-0.01, 0.01, (n, base.size - 7))
+    elif f == "dof_frictionloss":  # what randomize_field("dof_frictionloss") writes: friction-loss rows on about half of the joints
+      new = rng.uniform(0.02, 0.5, new.shape) * (rng.random(new.shape) < 0.5)
+      new[:, :6] = 0.0
     else:
       raise ValueError(f)
     getattr(sim.model, f)[:] = torch.from_numpy(new.astype(np.float32)).to(sim.data.qpos.device)
