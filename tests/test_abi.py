@@ -72,3 +72,22 @@ def test_default_capacities():
   m = robots.load_model("g1_velocity_flat")
   ncon, njmax = _abi.default_capacities(m, 140_000, 300)
   assert njmax == 300 and ncon == 300
+
+
+def test_every_bundled_scene_keeps_16_waves_per_cu_in_lds():
+  """One world per wave, all 4096 worlds of a 4096-env batch resident at once: 16 waves per CU, i.e. at most 10 KB of
+  LDS per wave in every stage (160 KB per CU).  The solve stage of the G1 is the tight one: H / factor, packed M,
+  128 rows of the three per-row arrays, scratch = 10 104 B."""
+  import ctypes
+
+  _, _, MS, _ = native.layouts()
+  L = native.lib()
+  stages = {"position": 1, "collision": 2, "velocity": 4, "constraint": 8, "solve": 16}
+  for scene in robots.SCENES:
+    model = robots.load_model(scene)
+    ms = MS()
+    ms.size = _abi.fill_sizes(model, 4096, *_abi.default_capacities(model, None, 300))
+    lds = {k: L.mjlab_lds_bytes(ctypes.byref(ms), v) for k, v in stages.items()}
+    assert all(0 < b <= 10240 for b in lds.values()), (scene, lds)
+    if scene.startswith("g1"):
+      assert lds["solve"] == 10104, lds
