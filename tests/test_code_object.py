@@ -1,0 +1,47 @@
+"""What the built library contains for gfx950 (no GPU needed: the ROCm LLVM tools read the code objects).  Guards the
+properties the design rests on: every kernel fits 4 waves per SIMD (<= 128 VGPRs, launch bound 64 x 4), uses dynamic LDS
+only, the solver kernels really carry the fp32 MFMA Hessian, DPP reductions, packed fp32 FMAs and the wave-priority
+instruction, and scratch (spill) space stays small."""
+
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tools"))
+
+from mjlab_amd import native  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def kernels():
+  import code_object
+
+  if not (code_object.LLVM / "llvm-objdump").exists():
+    pytest.skip("ROCm LLVM tools not installed")
+  native.lib()  # builds the library if it is missing
+  return code_object.kernels(ROOT / "mjlab_amd" / "csrc" / "libmjlab_amd.so")
+
+
+def test_every_kernel_fits_four_waves_per_simd(kernels):
+  assert len(kernels) >= 40  # 9 padded sizes x (solve, forward, step, control step) + the size-independent kernels
+  for name, md in kernels.items():
+    assert md["vgpr_count"] <= 128, (name, md)
+    assert md["group_segment_fixed_size"] == 0, (name, md)  # LDS is laid out per model at launch (mjlab_lds_bytes)
+    assert md["private_segment_fixed_size"] <= 512, (name, md)
+
+
+def test_g1_kernels_are_cdna4_code(kernels):
+  g1 = {n: md for n, md in kernels.items() if "ILi36E" in n}
+  names = " ".join(g1)
+  assert all(k in names for k in ("k_solve_integrate", "k_substep", "k_control_step"))
+  for name, md in g1.items():
+    ins = md["insts"]
+    assert ins.get("mfma", 0) >= 24, (name, ins)      # J^T D J: 6 lower 16 x 16 tiles x 4 row groups per block
+    assert ins.get("dpp", 0) >= 200, (name, ins)      # wave / row reductions without LDS
+    assert ins.get("pk_fma", 0) >= 300, (name, ins)   # the register-resident LDL^T sweep
+    assert ins.get("setprio", 0) >= 4, (name, ins)    # wave issue priority by the world's constraint rows
+    assert md["private_segment_fixed_size"] <= 256, (name, md)
+  ctrl = next(md for n, md in g1.items() if "k_control_step" in n)
+  assert ctrl["vgpr_count"] == 128 and ctrl["vgpr_spill_count"] <= 40, ctrl
