@@ -171,7 +171,7 @@
   X(fold_valid, 1, one) /* 1: position / collision / constraint arrays are those of (sh_qpos, sh_qvel) */ \
   X(fold_reuse, 1, one) /* scratch of the current step: 1 = this world skips those three stages */ \
   X(overflow, 1, one)   /* MJLAB_OVF_* bits of the last collision / constraint pass of this world */ \
-  X(sched_thr, 1, one)  /* elements 0..2 (NOT per world): thresholds of the wave-priority classes 1..3 on the score      \
+  X(sched_thr, 4, one)  /* elements 0..2 (NOT per world; 4 ints per world are allocated so that the three exist even for nworld = 1): thresholds of the wave-priority classes 1..3 on the score      \
                            nefc x (solver_niter + 2), written by the host from the score's quantiles; all 0 = the built-in \
                            row-count thresholds (common.h::wave_priority).  Scheduling hint only: results do not depend on it */ \
   X(contact_dim, 1, nconmax)                                                    \

@@ -47,6 +47,8 @@ static int check_model(const mjlab_model_t* m) {
   if (m->opt.cone != 0) return fail(-5, "only the pyramidal friction cone is implemented");
   if (m->opt.integrator != MJLAB_INT_EULER && m->opt.integrator != MJLAB_INT_IMPLICITFAST)
     return fail(-6, "integrator must be Euler or implicitfast");
+  if (m->opt.solver != MJLAB_SOL_CG && m->opt.solver != MJLAB_SOL_NEWTON)
+    return fail(-20, "opt.solver must be MJLAB_SOL_NEWTON or MJLAB_SOL_CG (PGS is not implemented)");
   for (int st = 1; st <= 16; st <<= 1)
     if (mjlab_lds_bytes(m, st) > 160 * 1024) return fail(-7, "model too large for the LDS-resident stage kernels");
   return 0;

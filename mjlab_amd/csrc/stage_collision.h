@@ -219,7 +219,7 @@ __device__ __forceinline__ int box_box_candidate(RawCon* c, int cand, float marg
 #pragma unroll
     for (int k = 0; k < 3; ++k) {  // axis a runs -size..+size; the other two sit at the extremes picked by the bits of e
       const int rel = (k - a + 3) % 3;  // 0: the edge's own axis, 1 / 2: the other two (bit 0 / bit 1 of e)
-      const float ext = ((e >> (rel - 1)) & 1) ? bsize[k] : -bsize[k];
+      const float ext = ((e >> (rel == 2 ? 1 : 0)) & 1) ? bsize[k] : -bsize[k];  // rel == 0: unused (no shift by -1)
       v0[k] = rel == 0 ? -bsize[k] : ext;
       v1[k] = rel == 0 ? bsize[k] : ext;
     }

@@ -31,6 +31,7 @@ import torch
 
 from . import _abi, device_state, native
 from .mjcf import CONE_ELLIPTIC, CONE_PYRAMIDAL, INT_EULER, INT_IMPLICITFAST, SOL_CG, SOL_NEWTON, SOL_PGS, Model, Spec
+from .nan_guard import NanGuard, NanGuardCfg
 from .sim_data import Bridge
 
 _CONE_MAP = {"pyramidal": CONE_PYRAMIDAL, "elliptic": CONE_ELLIPTIC}
@@ -66,15 +67,6 @@ class MujocoCfg:
     o.tolerance = self.tolerance
     o.ls_iterations = self.ls_iterations
     o.ls_tolerance = self.ls_tolerance
-
-
-@dataclass
-class NanGuardCfg:
-  """Placeholder for the reference's debugging aid (sim/sim.py:90,129,191), which is outside the
-  physics path and not provided: only ``enabled=False`` is accepted.  Non-finite states are handled
-  on the device by ``mjlab_masked_reset``; ``Simulation.post_step_hooks`` is the hook point."""
-
-  enabled: bool = False
 
 
 @dataclass(kw_only=True)
@@ -230,8 +222,8 @@ class Simulation:
                                 on_access=self._on_model_access)
     self._data_bridge = Bridge("sim.data", self._data, {"nworld": num_envs, "njmax": self.njmax, "nconmax": self.nconmax})
 
-    if getattr(cfg.nan_guard, "enabled", False):
-      raise NotImplementedError("nan_guard is not provided by mjlab_amd (append a callable to Simulation.post_step_hooks instead)")
+    # reference sim/sim.py:129 (opt-in; its history ring and non-finite flag live on the device, nan_guard.py)
+    self.nan_guard = NanGuard(cfg.nan_guard, num_envs, model)
     self._step_calls = 0
     self.priority_refresh = not os.environ.get("MJLAB_NO_PRIORITY_REFRESH")
     q = os.environ.get("MJLAB_PRIO_Q")
@@ -381,10 +373,14 @@ class Simulation:
     (envs/manager_based_rl_env.py:109-114 re-applies the same action before each of them) as one call;
     with ``fuse="step"`` also ONE kernel launch."""
     with torch.cuda.device(self._dev):
+      if self.nan_guard.enabled:
+        self.nan_guard.capture(self._data_bridge)
       if nsubstep == 1:
         self._step_once()
       else:
         self._launch_step(nsubstep)
+      if self.nan_guard.enabled:
+        self.nan_guard.check_and_dump(self._data_bridge)
       self._step_calls += 1
       if self._step_calls % 64 == 0:
         self.update_priority_thresholds()

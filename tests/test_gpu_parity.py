@@ -790,11 +790,42 @@ def test_host_side_guards_and_warnings():
     warnings.simplefilter("error")
     Simulation(4, SimulationCfg(njmax=100, ls_parallel=False), model, "cuda:0")
   sim.step()
-  with pytest.raises(NotImplementedError, match="nan_guard"):
-    from mjlab_amd.sim import NanGuardCfg
-
-    Simulation(1, SimulationCfg(nan_guard=NanGuardCfg(enabled=True)), model, "cuda:0")
   torch.cuda.synchronize()
+
+
+def test_nan_guard_dumps_the_device_ring(tmp_path):
+  """reference sim/sim.py:129,191 + utils/nan_guard.py: cfg fields, `sim.nan_guard.watch`, one dump with the
+  pre-step states of the last steps; the history ring stays on the device until the dump."""
+  import torch
+
+  from mjlab_amd.sim import NanGuardCfg, Simulation, SimulationCfg
+
+  model = models()["go1_velocity_flat"]
+  cfg = SimulationCfg(njmax=100, ls_parallel=False, nan_guard=NanGuardCfg(enabled=True, buffer_size=4, output_dir=str(tmp_path), max_envs_to_capture=3))
+  sim = Simulation(8, cfg, model, "cuda:0")
+  assert sim.nan_guard.enabled and sim.nan_guard._ring is None
+  sim.data.qpos[:] = torch.tensor(model.key_qpos[0], dtype=torch.float32, device="cuda")
+  for _ in range(6):
+    sim.step()
+  assert sim.nan_guard._ring.is_cuda and not list(tmp_path.iterdir())
+  sim.data.qvel[5, 2] = float("nan")
+  sim.step()
+  dumps = sorted(tmp_path.glob("nan_dump_*.npz"))
+  assert len(dumps) == 1
+  z = np.load(dumps[0], allow_pickle=True)
+  meta = z["_metadata"].item()
+  assert 5 in meta["nan_env_ids"] and meta["num_envs_captured"] == 3 and meta["state_size"] == model.nq + model.nv
+  keys = sorted(k for k in z.files if k.startswith("states_step_"))
+  assert keys == [f"states_step_{i:06d}" for i in (3, 4, 5, 6)]
+  assert z[keys[-1]].shape == (3, model.nq + model.nv) and np.isfinite(z[keys[-1]]).all()
+  sim.step()  # one dump per run
+  assert len(list(tmp_path.glob("nan_dump_*.npz"))) == 1
+  assert (tmp_path / meta["model_file"]).exists()
+  # disabled guard: nothing allocated, watch() is a no-op context
+  sim2 = Simulation(2, SimulationCfg(njmax=100, ls_parallel=False), model, "cuda:0")
+  with sim2.nan_guard.watch(sim2.data):
+    pass
+  assert not sim2.nan_guard.enabled
 
 
 def _snake_model(nlink: int):

@@ -59,3 +59,36 @@ def test_bridge_is_read_only_and_views_are_stable():
   with pytest.raises(AttributeError):
     _ = b.nope
   assert np.array_equal(b.qpos.numpy()[0], np.zeros(3))
+
+
+def test_nan_guard_on_host_tensors(tmp_path):
+  """The guard itself is device-agnostic torch code: exercised here on CPU tensors (reference cfg fields
+  utils/nan_guard.py:18-25; dump keys read by scripts/nan_viz.py)."""
+  import types
+
+  import torch
+
+  from mjlab_amd.nan_guard import NanGuard, NanGuardCfg
+  from mjlab_amd.sim import SimulationCfg
+
+  assert SimulationCfg().nan_guard == NanGuardCfg() and not NanGuardCfg().enabled
+  cfg = NanGuardCfg(enabled=True, buffer_size=3, output_dir=str(tmp_path), max_envs_to_capture=2, check_every=2)
+  m = robots.pendulum_model()
+  g = NanGuard(cfg, 4, m)
+  data = types.SimpleNamespace(qpos=torch.zeros(4, m.nq), qvel=torch.zeros(4, m.nv), qacc=torch.zeros(4, m.nv), qacc_warmstart=torch.zeros(4, m.nv))
+  for k in range(5):
+    with g.watch(data):
+      data.qpos += 1.0
+      if k == 2:
+        data.qacc[3, 0] = float("inf")  # seen at the next read-back (check_every = 2), remembered in between
+  dumps = list(tmp_path.glob("nan_dump_*.npz"))
+  assert len(dumps) == 1
+  z = np.load(dumps[0], allow_pickle=True)
+  meta = z["_metadata"].item()
+  assert meta["nan_env_ids"] == [3] and meta["detection_step"] == 4
+  assert sorted(k for k in z.files if k != "_metadata") == ["states_step_000001", "states_step_000002", "states_step_000003"]
+  assert z["states_step_000003"][0, 0] == 3.0  # pre-step state of step 3
+  off = NanGuard(NanGuardCfg(), 4, m)
+  with off.watch(data):
+    pass
+  assert not off.check_and_dump(data)
