@@ -202,6 +202,9 @@ typedef struct mjlab_sizes {
   /* static geometry: geoms [0, nstaticgeom) hang off the world (poses written once, at
    * construction); the collision stage stages geoms [geom_lds0, ngeom) on chip */
   int nstaticgeom, geom_lds0;
+  /* sites [0, nstaticsite) hang off static bodies as well (the reference's scenes carry one marker site per environment
+   * origin on the world body: terrains/terrain_importer.py:96-120 -- num_envs of them): posed once, like the static geoms */
+  int nstaticsite;
   /* box terrain (static colliding boxes) and its uniform xy broadphase grid */
   int nterrain, ntgeom, ntcell, ntcellp1, ntitem, tgrid_nx, tgrid_ny;
 } mjlab_sizes_t;

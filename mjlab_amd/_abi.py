@@ -16,7 +16,7 @@ from .mjcf import TCAND_MAX, Model
 _SIZE_FIELDS = (
   "nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata", "npair",
   "nlevel", "nworld", "nconmax", "njmax",
-  "nstaticgeom", "geom_lds0", "nterrain", "ntgeom", "ntcell", "ntcellp1", "ntitem", "tgrid_nx", "tgrid_ny",
+  "nstaticgeom", "geom_lds0", "nstaticsite", "nterrain", "ntgeom", "ntcell", "ntcellp1", "ntitem", "tgrid_nx", "tgrid_ny",
 )  # fmt: skip
 
 

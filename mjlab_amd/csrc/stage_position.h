@@ -98,13 +98,14 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
       for (int k = 0; k < 4; ++k) g_quat[r][k] = ng > 0 ? gquat[4 * g + k] : 0.f;
     }
   }
+  const int ns0 = m.size.nstaticsite;  // sites of static bodies keep the poses written at construction
   int t_body = 0;
   float t_pos[3] = {0.f, 0.f, 0.f}, t_quat[4] = {1.f, 0.f, 0.f, 0.f};
-  if (lane < ns) {
+  if (ns0 + lane < ns) {
     const float *spos = MF(site_pos), *squat = MF(site_quat);
-    t_body = m.site_bodyid[lane];
-    for (int k = 0; k < 3; ++k) t_pos[k] = spos[3 * lane + k];
-    for (int k = 0; k < 4; ++k) t_quat[k] = squat[4 * lane + k];
+    t_body = m.site_bodyid[ns0 + lane];
+    for (int k = 0; k < 3; ++k) t_pos[k] = spos[3 * (ns0 + lane) + k];
+    for (int k = 0; k < 4; ++k) t_quat[k] = squat[4 * (ns0 + lane) + k];
   }
   // second level: reached through an index loaded above
   const int v_dofadr = m.jnt_dofadr[v_jnt], v_type = m.jnt_type[v_jnt], v_root = m.body_rootid[v_body];
@@ -274,18 +275,18 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
     }
     float* sx = d.site_xpos + (size_t)w * 3 * ns;
     float* sm = d.site_xmat + (size_t)w * 9 * ns;
-    if (lane < ns) {
-      const int b = t_body;
+    if (ns0 + lane < ns) {
+      const int b = t_body, g = ns0 + lane;
       float bp[3], bq[4], bm[9], xp[3], xm[9];
       for (int k = 0; k < 3; ++k) bp[k] = s_xpos[3 * b + k];
       for (int k = 0; k < 4; ++k) bq[k] = s_xquat[4 * b + k];
       for (int k = 0; k < 9; ++k) bm[k] = s_xmat[9 * b + k];
       local2global(xp, xm, bp, bq, bm, t_pos, t_quat);
-      for (int k = 0; k < 3; ++k) sx[3 * lane + k] = xp[k];
-      for (int k = 0; k < 9; ++k) sm[9 * lane + k] = xm[k];
+      for (int k = 0; k < 3; ++k) sx[3 * g + k] = xp[k];
+      for (int k = 0; k < 9; ++k) sm[9 * g + k] = xm[k];
     }
     const float *spos = MF(site_pos), *squat = MF(site_quat);
-    for (int g = 64 + lane; g < ns; g += 64) {  // models with more than 64 sites
+    for (int g = ns0 + 64 + lane; g < ns; g += 64) {  // models with more than 64 moving sites
       const int b = m.site_bodyid[g];
       float bp[3], bq[4], bm[9], ip[3], iq[4], xp[3], xm[9];
       for (int k = 0; k < 3; ++k) { bp[k] = s_xpos[3 * b + k]; ip[k] = spos[3 * g + k]; }

@@ -198,6 +198,30 @@ class SpecBody:
   sites: list[SpecSite] = field(default_factory=list)
   children: list["SpecBody"] = field(default_factory=list)
 
+  # ``mujoco.MjsBody``-style editing (keyword names of the reference's call sites: terrains/terrain_importer.py:113-120,
+  # 157-163, terrains/utils.py:28-105, utils/spec_config.py:311-361); rendering-only arguments are accepted and dropped
+  def add_body(self, name: str = "", pos=(0.0, 0.0, 0.0), quat=(1.0, 0.0, 0.0, 0.0), **_: Any) -> "SpecBody":
+    b = SpecBody(name, np.array(pos, dtype=np.float64), np.array(quat, dtype=np.float64), parent=self)
+    self.children.append(b)
+    return b
+
+  def add_geom(self, name: str = "", type: int = GEOM_SPHERE, size=(0.0, 0.0, 0.0), pos=(0.0, 0.0, 0.0), quat=(1.0, 0.0, 0.0, 0.0),
+               rgba=None, material: str | None = None, **kw: Any) -> SpecGeom:
+    sz = np.zeros(3)
+    size = np.atleast_1d(np.asarray(size, dtype=np.float64))
+    sz[: len(size)] = size
+    keep = {k: v for k, v in kw.items() if k in SpecGeom.__dataclass_fields__}
+    g = SpecGeom(name, int(type), sz, np.array(pos, dtype=np.float64), np.array(quat, dtype=np.float64), body=self, **keep)
+    if rgba is not None:
+      g.rgba = np.array(rgba, dtype=np.float64)
+    self.geoms.append(g)
+    return g
+
+  def add_site(self, name: str = "", pos=(0.0, 0.0, 0.0), quat=(1.0, 0.0, 0.0, 0.0), **_: Any) -> SpecSite:
+    s = SpecSite(name, np.array(pos, dtype=np.float64), np.array(quat, dtype=np.float64), body=self)
+    self.sites.append(s)
+    return s
+
 
 @dataclass
 class SpecActuator:
@@ -729,6 +753,9 @@ class Model:
     if not hasattr(m, "dof_solref"):  # saved before friction-loss rows existed: MuJoCo's defaults
       m.dof_solref = np.tile([0.02, 1.0], (m.nv, 1))
       m.dof_solimp = np.tile([0.9, 0.95, 0.001, 0.5, 2.0], (m.nv, 1))
+    if not hasattr(m, "nstaticsite"):  # saved before static sites were told apart
+      sstatic = m.body_weldid[m.site_bodyid] == 0
+      m.nstaticsite = (int(np.argmin(sstatic)) if not sstatic.all() else int(m.nsite)) if m.nsite else 0
     if not hasattr(m, "tgrid_ztop"):  # saved before the static-geometry / terrain fields existed
       static = m.body_weldid[m.geom_bodyid] == 0
       m.nstaticgeom = int(np.argmin(static)) if not static.all() else m.ngeom
@@ -945,6 +972,8 @@ def finalize_topology(m: "Model", excl: set) -> None:
   collides = (m.geom_contype != 0) | (m.geom_conaffinity != 0)
   terrain = static & (m.geom_type == GEOM_BOX) & collides
   m.nstaticgeom = int(np.argmin(static)) if not static.all() else ngeom  # leading run of static geoms
+  sstatic = m.body_weldid[m.site_bodyid] == 0
+  m.nstaticsite = (int(np.argmin(sstatic)) if not sstatic.all() else int(m.nsite)) if m.nsite else 0  # leading run of static sites
   pairs = []
   cand = [g for g in range(ngeom) if collides[g] and not terrain[g]]
   for i1, g1 in enumerate(cand):
@@ -988,6 +1017,10 @@ def _compile(spec: Spec) -> Model:
   geoms = [g for b in bodies for g in b.geoms]
   sites = [s for b in bodies for s in b.sites]
   njnt, ngeom, nsite = len(joints), len(geoms), len(sites)
+  # element ids, valid after compile like mujoco's `Mjs*.id` (reference use: entity/entity.py:589-600)
+  for seq in (bodies, joints, geoms, sites, spec.actuators, spec.sensors, spec.keys):
+    for i, e in enumerate(seq):
+      e.id = i
 
   m.names = {
     "body": [b.name for b in bodies],

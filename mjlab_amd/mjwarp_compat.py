@@ -125,10 +125,10 @@ def _static_geoms(m: Model, d: Data) -> None:
   """First use of a Data: pose the static geoms (world / terrain bodies) once."""
   if d._static_done:
     return
-  keep = m.struct.size.nstaticgeom
-  m.struct.size.nstaticgeom = 0
+  keep, keep_s = m.struct.size.nstaticgeom, m.struct.size.nstaticsite
+  m.struct.size.nstaticgeom = m.struct.size.nstaticsite = 0
   native.check(native.lib().mjlab_forward_stages(ctypes.byref(m.struct), ctypes.byref(d.struct), native.STAGE_POSITION, _stream(d)), "mjlab_forward_stages")
-  m.struct.size.nstaticgeom = keep
+  m.struct.size.nstaticgeom, m.struct.size.nstaticsite = keep, keep_s
   d._static_done = True
 
 
@@ -158,6 +158,8 @@ def expand_model_fields(m: Model, nworld: int, fields_to_expand: list[str]) -> N
     if m.host.nterrain:
       raise NotImplementedError(f"per-world {moves_static} with a box terrain: terrain boxes are static and shared by all worlds")
     m.struct.size.nstaticgeom = 0
+  if any(f in ("site_pos", "site_quat", "body_pos", "body_quat") for f in fields_to_expand):
+    m.struct.size.nstaticsite = 0
   m.__dict__["nworld"] = nworld
   with torch.cuda.device(m.device):
     for name in fields_to_expand:

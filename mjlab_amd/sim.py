@@ -211,9 +211,14 @@ class Simulation:
     self.nconmax, self.njmax = _abi.default_capacities(model, cfg.nconmax, cfg.njmax)
 
     self._m, self._model_base, self._model_view = device_state.upload_model(model, num_envs, self.nconmax, self.njmax, dev)
-    self._m.opt.flags = ((self._m.opt.flags & _abi.OPT_FRICTIONLOSS) | (_abi.OPT_FOLD_FORWARD if cfg.fold_forward else 0) | (_abi.OPT_LITERAL_TERMINATION if cfg.literal_termination else 0)
-                         | (_abi.OPT_WARMSTART_AT_ADVANCE if cfg.warmstart_at_advance else 0)
-                         | {"stage": 0, "presolve": _abi.OPT_FUSE_PRESOLVE, "step": _abi.OPT_FUSE_STEP}[cfg.fuse])
+    # `cfg` may be the reference's own SimulationCfg (sim/sim.py:85-91: nconmax, njmax, ls_parallel, mujoco, nan_guard) when its
+    # environment classes construct this Simulation (tools/reference_env.py): this package's extra switches then take their defaults
+    ext = SimulationCfg()
+    opt = lambda name: getattr(cfg, name, getattr(ext, name))  # noqa: E731
+    self._m.opt.flags = ((self._m.opt.flags & _abi.OPT_FRICTIONLOSS) | (_abi.OPT_FOLD_FORWARD if opt("fold_forward") else 0)
+                         | (_abi.OPT_LITERAL_TERMINATION if opt("literal_termination") else 0)
+                         | (_abi.OPT_WARMSTART_AT_ADVANCE if opt("warmstart_at_advance") else 0)
+                         | {"stage": 0, "presolve": _abi.OPT_FUSE_PRESOLVE, "step": _abi.OPT_FUSE_STEP}[opt("fuse")])
     self._d, self._data = device_state.alloc_data(model, num_envs, self.nconmax, self.njmax, dev)
 
     scalars = {k: int(getattr(model, k)) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata")}
@@ -229,14 +234,14 @@ class Simulation:
     q = os.environ.get("MJLAB_PRIO_Q")
     self._prio_q = torch.tensor([float(x) for x in q.split(",")] if q else list(self.PRIORITY_QUANTILES), device=dev)
     self.post_step_hooks: list = []  # callables(sim) run after every step() (where the reference's NaN guard sits)
-    self.use_graph = bool(cfg.use_graph) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
+    self.use_graph = bool(opt("use_graph")) and not os.environ.get("MJLAB_AMD_NO_GRAPH")
     self.step_graph: torch.cuda.CUDAGraph | None = None
     self.forward_graph: torch.cuda.CUDAGraph | None = None
     # populate derived fields like mjwarp.put_data does from mj_forward; this first pass also
     # writes the poses of the static geoms (world / terrain bodies), which later passes skip
-    self._m.size.nstaticgeom = 0
+    self._m.size.nstaticgeom = self._m.size.nstaticsite = 0
     self.forward()
-    self._m.size.nstaticgeom = int(model.nstaticgeom)
+    self._m.size.nstaticgeom, self._m.size.nstaticsite = int(model.nstaticgeom), int(model.nstaticsite)
     self.create_graph()
     # pay the one-time start-up cost of the device ops of update_priority_thresholds() here, outside any timed loop; the
     # thresholds themselves stay unset (all worlds are identical at this point): the kernels' row-count classes apply
@@ -340,6 +345,8 @@ class Simulation:
       if self._mj_model.nterrain:
         raise NotImplementedError(f"per-world {moves_static} with a box terrain: terrain boxes are static and shared by all worlds")
       self._m.size.nstaticgeom = 0  # static geoms may now differ per world: recompute them every pass
+    if any(f in ("site_pos", "site_quat", "body_pos", "body_quat") for f in fields):
+      self._m.size.nstaticsite = 0
     with torch.cuda.device(self._dev):
       for name in fields:
         if device_state.expand_field(self._m, self._model_base, self._model_view, self._mj_model, name, self.num_envs, self._dev, self._stream()):

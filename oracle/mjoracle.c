@@ -202,7 +202,7 @@ static void kinematics(const mjo_model_t* m, mjo_data_t* d, int w) {
                  MF(geom_quat, w) + 4 * g);
   }
   real *sx = D(site_xpos, 3 * s->nsite), *sm = D(site_xmat, 9 * s->nsite);
-  for (int g = 0; g < s->nsite; g++) {
+  for (int g = s->nstaticsite; g < s->nsite; g++) { /* static sites: posed once, like the static geoms */
     int b = m->site_bodyid[g];
     local2global(sx + 3 * g, sm + 9 * g, xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, MF(site_pos, w) + 3 * g,
                  MF(site_quat, w) + 4 * g);
@@ -1459,6 +1459,22 @@ void mjo_static_geoms(const mjo_model_t* m, mjo_data_t* d) {
       }
       quat2mat(mat, quat);
       local2global(gx + 3 * g, gm + 9 * g, pos, quat, mat, MF(geom_pos, w) + 3 * g, MF(geom_quat, w) + 4 * g);
+    }
+    real *sx = D(site_xpos, 3 * s->nsite), *sm = D(site_xmat, 9 * s->nsite);
+    for (int g = 0; g < s->nstaticsite; g++) {
+      real pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0}, mat[9];
+      int chain[64], n = 0;
+      for (int b = m->site_bodyid[g]; b > 0 && n < 64; b = m->body_parentid[b]) chain[n++] = b;
+      for (int k = n - 1; k >= 0; k--) {
+        real p[3], q[4];
+        rot_vec_quat(p, MF(body_pos, w) + 3 * chain[k], quat);
+        for (int i = 0; i < 3; i++) pos[i] += p[i];
+        mul_quat(q, quat, MF(body_quat, w) + 4 * chain[k]);
+        normalize4(q);
+        memcpy(quat, q, sizeof(q));
+      }
+      quat2mat(mat, quat);
+      local2global(sx + 3 * g, sm + 9 * g, pos, quat, mat, MF(site_pos, w) + 3 * g, MF(site_quat, w) + 4 * g);
     }
   }
 }

@@ -91,6 +91,8 @@ class OracleSim:
       self._m.opt.flags |= _abi.OPT_FRICTIONLOSS  # values may now be written: build the rows (as Simulation does)
     if name in ("geom_pos", "geom_quat", "body_pos", "body_quat"):
       self._m.size.nstaticgeom = 0  # static geoms may now differ per world: pose them every pass (as Simulation does)
+    if name in ("site_pos", "site_quat", "body_pos", "body_quat"):
+      self._m.size.nstaticsite = 0
     return arr
 
   def reset(self, key: int | None = None) -> None:

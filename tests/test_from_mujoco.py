@@ -19,7 +19,7 @@ from oracle.oracle import OracleSim
 PINS = json.loads((Path(__file__).parent / "golden" / "reference_constants.json").read_text())
 
 # attributes a real mjModel does NOT have: everything finalize_topology derives, plus host-side extras
-DERIVED = {"body_depth", "nlevel", "level_body", "level_adr", "body_subtreenum", "body_dofmask", "nstaticgeom", "geom_lds0", "pair_geom",
+DERIVED = {"body_depth", "nlevel", "level_body", "level_adr", "body_subtreenum", "body_dofmask", "nstaticgeom", "geom_lds0", "nstaticsite", "pair_geom",
            "npair", "nterrain", "ntgeom", "ntcell", "ntcellp1", "ntitem", "tgeom", "tbox_geom", "tbox_pos", "tbox_mat", "tbox_size",
            "tbox_cell0", "tgrid_start", "tgrid_item", "tgrid_ztop", "tgrid_nx", "tgrid_ny", "tgrid_x0", "tgrid_y0", "tgrid_cell",
            "meaninertia", "terrain_origins", "names", "opt"}  # fmt: skip

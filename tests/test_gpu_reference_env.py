@@ -1,0 +1,52 @@
+"""Row N1 on the MI355X: the reference's registered task ``Mjlab-Velocity-Flat-Unitree-G1`` -- its own ManagerBasedRlEnv, Scene,
+Entity, managers and MDP terms, unmodified -- stepped over ``mjlab_amd.sim.Simulation`` ("do this" item 3).
+
+The reference source cannot be committed and ``/root/reference`` does not exist on the GPU box: ``tools/stage_reference.sh``
+copies it next to the repository (``gpurun_ref/``, git-ignored) for the duration of one ``gpurun`` call; without it the test
+skips (the same stack runs over the CPU oracle in tests/test_reference_env.py every round).  The log of the staged run is
+committed under profiles/."""
+
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tools"))
+
+import reference_env  # noqa: E402
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(reference_env.locate_reference() is None, reason="reference source not staged (tools/stage_reference.sh)")]
+
+
+def test_registered_g1_velocity_task_runs_over_the_hip_simulation():
+  import torch
+
+  from mjlab_amd.sim import Simulation
+
+  env = reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=256, device="cuda:0")
+  assert isinstance(env.sim, Simulation) and env.sim.num_envs == 256
+  assert env.sim.host_model.nstaticsite == 256  # the reference's env-origin marker sites: posed once, not 256 x 256 per step
+  d = env.sim.data
+  ptr = {f: getattr(d, f).data_ptr() for f in ("qpos", "qvel", "ctrl", "xfrc_applied", "sensordata", "xpos", "cvel")}
+  resets, finite = [], []
+
+  def on_step(k, obs, rew, terminated, time_out):
+    resets.append(int((terminated | time_out).sum()))
+    finite.append(bool(torch.isfinite(rew).all()) and all(bool(torch.isfinite(o).all()) for o in obs.values()))
+
+  out = reference_env.random_rollout(env, 100, seed=1, on_step=on_step)
+  torch.cuda.synchronize()
+  assert all(finite), "non-finite observations / rewards"
+  for name, o in out["obs"].items():
+    assert o.shape == (256, 99) and o.is_cuda, name
+  assert {f: getattr(d, f).data_ptr() for f in ptr} == ptr  # in-place writes only: graph-safe (sim_data.py:181-185)
+  assert sum(resets) > 0, "no env terminated in 100 steps of random actions"
+  assert env.sim.overflow_report() == {"nconmax": 0, "njmax": 0, "terrain_candidates": 0}
+  # the robots stand on the plane or are being reset: nobody fell through it or flew away
+  z = d.qpos[:, 2]
+  assert bool(((z > 0.05) & (z < 1.2)).all()), (float(z.min()), float(z.max()))
+  # per-env friction drawn by the reference's startup event reached the device tables
+  fr = env.sim.model.geom_friction[:, :, 0]
+  assert float(fr.std()) > 0.0
+  print(f"reference G1 velocity task over mjlab_amd.Simulation: 100 env steps x 256 envs, {sum(resets)} resets, mean reward {out['mean_reward']:.4f}")

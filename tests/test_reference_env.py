@@ -1,0 +1,126 @@
+"""Row N1 ("existing tasks run unmodified"): the reference's OWN ``ManagerBasedRlEnv`` -- Scene, Entity, every manager, the MDP
+terms and the registered task configuration, imported unmodified from the reference checkout -- constructed and stepped over
+this repository's boundary: ``mjlab_amd.mujoco_shim`` as ``mujoco`` (model building) and a ``Simulation``-shaped object.
+
+Here, without a GPU, the Simulation is tests/_oracle_simulation.py (the CPU oracle behind the same Bridges; test
+infrastructure).  tests/test_gpu_reference_env.py runs the same stack over ``mjlab_amd.sim.Simulation`` on the MI355X.
+Reference call sites: envs/manager_based_rl_env.py:84-147, envs/manager_based_env.py:54-160, scene/scene.py:25-147,
+entity/entity.py:120-214,325-423,588-652."""
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tools"))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import reference_env  # noqa: E402
+
+pytestmark = pytest.mark.skipif(reference_env.locate_reference() is None, reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def g1_env():
+  from _oracle_simulation import OracleSimulation
+
+  return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=16, device="cpu", sim_cls=OracleSimulation)
+
+
+def test_scene_compiled_by_the_reference_equals_the_committed_model(g1_env):
+  """The model the reference's Scene / Entity / spec_config code builds through the shim is, field for field, the model
+  mjlab_amd/assets/g1_velocity_flat.npz holds (which the parity tests and bench.py run on) -- plus the reference's marker sites."""
+  from mjlab_amd import robots
+
+  m, ref = g1_env.sim.mj_model, robots.load_model("g1_velocity_flat")
+  n = g1_env.num_envs
+  assert (m.nq, m.nv, m.nu, m.nbody, m.ngeom, m.npair, m.nsensor) == (ref.nq, ref.nv, ref.nu, ref.nbody, ref.ngeom, ref.npair, ref.nsensor)
+  assert m.nsite == ref.nsite + n and m.nstaticsite == n  # one env_origin site per environment on the world body, posed once
+  for kind in ("body", "joint", "geom", "actuator", "sensor"):
+    assert m.names[kind] == ref.names[kind], kind
+  skip = {"site_bodyid", "site_pos", "site_quat"}
+  for k, v in ref.__dict__.items():
+    if not isinstance(v, np.ndarray) or k in skip:
+      continue
+    a = getattr(m, k)
+    assert a.shape == v.shape, k
+    if v.dtype.kind == "f":
+      np.testing.assert_allclose(a, v, rtol=1e-12, atol=1e-14, err_msg=k)
+    else:
+      assert np.array_equal(a, v), k
+  assert m.opt.__dict__ == ref.opt.__dict__
+  assert np.array_equal(m.site_bodyid[n:], ref.site_bodyid) and np.allclose(m.site_pos[n:], ref.site_pos)
+
+
+def test_entity_indexing_and_spec_views_after_attach(g1_env):
+  """mujoco's attach-by-reference semantics the reference relies on: the entity's own spec keeps listing its elements, with
+  prefixed names and the ids of the compiled SCENE (entity/entity.py:189-214,588-652)."""
+  robot = g1_env.scene["robot"]
+  m = g1_env.sim.mj_model
+  assert robot.joint_names[0] == "left_hip_pitch_joint" and len(robot.joint_names) == 29 and robot.num_actuators == 29
+  assert robot.spec.bodies[1].name == "robot/pelvis" and robot.indexing.root_body_id == m.names["body"].index("robot/pelvis")
+  assert robot.indexing.body_ids.tolist() == list(range(2, 32))  # world, terrain, then the robot's 30 bodies
+  assert robot.indexing.ctrl_ids.tolist() == list(range(29))
+  assert robot.indexing.free_joint_q_adr.tolist() == list(range(7)) and robot.indexing.joint_q_adr.tolist() == list(range(7, 36))
+  assert set(robot.indexing.sensor_adr) == {"left_foot_ground_contact", "right_foot_ground_contact"}
+  # the foot sensors reference the SCENE's terrain body, which is outside the robot spec: the name keeps no prefix
+  assert m.sensor_refid.tolist() == [1, 1] and m.names["body"][1] == "terrain"
+  # startup domain randomisation went through expand_model_fields + randomize_field on the per-world friction table
+  fr = g1_env.sim.model.geom_friction
+  assert fr.shape[0] == g1_env.num_envs and fr.stride(0) > 0 and float(fr[:, :, 0].std()) > 0.0
+
+
+def test_step_the_registered_task(g1_env):
+  import torch
+
+  env = g1_env
+  ptr = {f: getattr(env.sim.data, f).data_ptr() for f in ("qpos", "qvel", "ctrl", "xfrc_applied", "sensordata")}
+  calls0 = env.sim.step_calls
+  seen_reset = []
+  out = reference_env.random_rollout(env, 25, seed=3, on_step=lambda k, o, r, t, to: seen_reset.append(int((t | to).sum())))
+  assert env.sim.step_calls - calls0 == 25 * env.cfg.decimation  # 4 physics steps per env step (manager_based_rl_env.py:109-114)
+  for name, o in out["obs"].items():
+    assert o.shape == (env.num_envs, 99) and bool(torch.isfinite(o).all()), name
+  assert {f: getattr(env.sim.data, f).data_ptr() for f in ptr} == ptr  # in-place writes only (tests/test_sim_data.py:62-70)
+  assert np.isfinite(out["mean_reward"])
+  # force terminations: tip every robot over -> fell_over fires, the reset events write the keyframe state back
+  env.sim.data.qpos[:, 3:7] = torch.tensor([0.0, 1.0, 0.0, 0.0])
+  fwd0 = env.sim.forward_calls
+  _, _, terminated, _, _ = env.step(torch.zeros(env.num_envs, 29))
+  assert bool(terminated.all()) and env.sim.forward_calls == fwd0 + 1  # forward() after the reset (manager_based_rl_env.py:128-132)
+  z = env.sim.data.qpos[:, 2]
+  assert bool(((z > 0.7) & (z < 0.85)).all()) and bool((env.episode_length_buf == 0).all())
+
+
+_GO1_SCRIPT = """
+import json, sys
+import numpy as np
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env
+from _oracle_simulation import OracleSimulation
+from mjlab_amd import robots
+env = reference_env.make_env("Mjlab-Velocity-Flat-Unitree-Go1", num_envs=4, device="cpu", sim_cls=OracleSimulation)
+ref, m = robots.load_model("go1_velocity_flat"), env.sim.mj_model
+sizes = [(int(getattr(m, k)), int(getattr(ref, k))) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair", "nsensordata")]
+worst = max(float(np.abs(np.asarray(getattr(m, k), float) - np.asarray(getattr(ref, k), float)).max()) for k in
+            ("body_mass", "body_inertia", "dof_armature", "actuator_gainprm", "actuator_biasprm", "geom_friction", "geom_condim", "pair_geom", "dof_invweight0"))
+out = reference_env.random_rollout(env, 5)
+print("RESULT " + json.dumps({{"sizes": sizes, "worst": worst, "finite": all(bool(np.isfinite(o.numpy()).all()) for o in out["obs"].values())}}))
+"""
+
+
+def test_go1_task_constructs_and_steps():
+  """A second registered task (config 2's robot).  In its own process: the reference's task configs share mutable default
+  objects between robots (the velocity task's `foot_friction` SceneEntityCfg is edited in place by each robot's cfg), so two
+  different tasks cannot be built in one interpreter -- with any engine."""
+  import json
+  import subprocess
+
+  code = _GO1_SCRIPT.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-2000:]
+  res = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  assert all(a == b for a, b in res["sizes"]), res["sizes"]
+  assert res["worst"] < 1e-12 and res["finite"]
