@@ -227,6 +227,7 @@ typedef struct mjlab_option {
   double ls_tolerance;
   double meaninertia; /* mjModel.stat.meaninertia */
   double tgrid_x0, tgrid_y0, tgrid_cell; /* terrain grid: origin (lowest corner) and cell edge */
+  double ls_parallel_min_step; /* MJLAB_OPT_LS_PARALLEL: smallest step of the log-spaced grid (mujoco_warp Option.ls_parallel_min_step, 1e-6) */
   int iterations;
   int ls_iterations;
   int integrator;
@@ -255,7 +256,14 @@ enum {
    * rows (mj_instantiateFriction).  Bit clear: the field is not read and no such rows exist (the reference's robots
    * have none; its `randomize_field("dof_frictionloss")` is what sets values later -- the host side sets the bit
    * when the field is non-zero at construction, expanded per world, or handed out writable) */
-  MJLAB_OPT_FRICTIONLOSS = 32
+  MJLAB_OPT_FRICTIONLOSS = 32,
+  /* mujoco_warp's PARALLEL line search, what the reference configures (`wp_model.opt.ls_parallel = cfg.ls_parallel`, reference
+   * src/mjlab/sim/sim.py:89,111): the cost along the search direction is evaluated at `ls_iterations` step sizes, log-spaced
+   * from ls_parallel_min_step to 1, alpha_i = exp(log(min_step) + i (log 1 - log(min_step)) / max(1, ls_iterations - 1)), and the
+   * step with the lowest cost is taken (first one on ties).  Restated from memory of mujoco_warp's solver (`_log_scale`,
+   * `linesearch_parallel_best_alpha`); the pinned source is not available here, so the grid is UNVERIFIED.
+   * Bit clear: MuJoCo's exact iterative search (mj_solPrimal's bracketing Newton search, <= ls_iterations evaluations) */
+  MJLAB_OPT_LS_PARALLEL = 64
 };
 
 #define MJLAB_DECL_INT_(name, ncol, count) const int* name;

@@ -35,6 +35,7 @@ class Option(ctypes.Structure):
     ("tgrid_x0", ctypes.c_double),
     ("tgrid_y0", ctypes.c_double),
     ("tgrid_cell", ctypes.c_double),
+    ("ls_parallel_min_step", ctypes.c_double),
     ("iterations", ctypes.c_int),
     ("ls_iterations", ctypes.c_int),
     ("integrator", ctypes.c_int),
@@ -45,7 +46,7 @@ class Option(ctypes.Structure):
 
 
 # mjlab_option_t.flags (include/mjlab_fields.h)
-OPT_FOLD_FORWARD, OPT_LITERAL_TERMINATION, OPT_WARMSTART_AT_ADVANCE, OPT_FUSE_PRESOLVE, OPT_FUSE_STEP, OPT_FRICTIONLOSS = 1, 2, 4, 8, 16, 32
+OPT_FOLD_FORWARD, OPT_LITERAL_TERMINATION, OPT_WARMSTART_AT_ADVANCE, OPT_FUSE_PRESOLVE, OPT_FUSE_STEP, OPT_FRICTIONLOSS, OPT_LS_PARALLEL = 1, 2, 4, 8, 16, 32, 64
 # mjlab_data_t.overflow bits
 OVF_NCONMAX, OVF_NJMAX, OVF_TCAND = 1, 2, 4
 
@@ -114,6 +115,7 @@ def fill_option(m: Model) -> Option:
   o.ls_tolerance = m.opt.ls_tolerance
   o.meaninertia = m.meaninertia
   o.tgrid_x0, o.tgrid_y0, o.tgrid_cell = m.tgrid_x0, m.tgrid_y0, m.tgrid_cell
+  o.ls_parallel_min_step = float(getattr(m.opt, "ls_parallel_min_step", 1.0e-6))
   o.iterations = m.opt.iterations
   o.ls_iterations = m.opt.ls_iterations
   o.integrator = m.opt.integrator

@@ -390,6 +390,41 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
   return 0.f;
 }
 
+// mujoco_warp's parallel line search (MJLAB_OPT_LS_PARALLEL, include/mjlab_fields.h): cost at `lsmax` log-spaced step sizes in
+// [min_step, 1], the lowest cost wins (the first one on ties).  Only the cost is needed: one wave reduction per candidate.
+template <int NVP, bool FL>
+__device__ __forceinline__ float ls_cost(const SolveCtx<NVP>& c, float alpha) {
+  float cost = 0.f;
+  if (c.lj0 + alpha * c.ljv < 0.f) cost = alpha * alpha * c.lq2 + alpha * c.lq1 + c.lq0;
+  if (c.nefc > 64 && c.mj0 + alpha * c.mjv < 0.f) cost += alpha * alpha * c.mq2 + alpha * c.mq1 + c.mq0;
+  if (FL && c.lane < c.nf) {
+    const int r = c.lane;
+    const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r], fl = c.s_fl[r], rf = fl / Dr;
+    const float x = j0 + alpha * jv;
+    if (x <= -rf) cost += fl * (-0.5f * rf - j0) - alpha * fl * jv;
+    else if (x >= rf) cost += fl * (-0.5f * rf + j0) + alpha * fl * jv;
+    else cost += alpha * alpha * (0.5f * Dr * jv * jv) + alpha * (Dr * j0 * jv) + 0.5f * Dr * j0 * j0;
+  }
+  for (int r = c.lane + 128; r < c.nefc; r += 64) {
+    const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r];
+    if (j0 + alpha * jv < 0.f) cost += alpha * alpha * (0.5f * Dr * jv * jv) + alpha * (Dr * j0 * jv) + 0.5f * Dr * j0 * j0;
+  }
+  return wave_sum(cost) + alpha * alpha * c.quad_gauss[2] + alpha * c.quad_gauss[1] + c.quad_gauss[0];
+}
+template <int NVP, bool FL>
+__device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsmax) {
+  ls_prepare<NVP, FL>(c);
+  const float lo = logf(min_step), step = (0.f - lo) / (float)(lsmax > 1 ? lsmax - 1 : 1);
+  float best_alpha = 0.f, best_cost = 0.f;
+  for (int i = 0; i < lsmax; ++i) {
+    const float alpha = expf(lo + (float)i * step);
+    const float cost = ls_cost<NVP, FL>(c, alpha);
+    if (i == 0 || cost < best_cost) { best_cost = cost; best_alpha = alpha; }
+  }
+  c.ls_iter = lsmax;
+  return best_alpha;
+}
+
 // constraint cost sum_r s(jar_r) over rows held in LDS
 template <int NVP>
 __device__ __forceinline__ float constraint_cost(const SolveCtx<NVP>& c, const float* s_jar) {
@@ -675,7 +710,10 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         c.quad_gauss[1] = wave_sum(own ? search * (Ma - qs) : 0.f);
         c.quad_gauss[2] = wave_sum(own ? 0.5f * search * Mv : 0.f);
         PROF_MARK(5);
-        alpha = c.nf > 0 ? line_search<NVP, true>(c, gtol, lsmax) : line_search<NVP, false>(c, gtol, lsmax);
+        if (m.opt.flags & MJLAB_OPT_LS_PARALLEL)
+          alpha = c.nf > 0 ? line_search_parallel<NVP, true>(c, (float)m.opt.ls_parallel_min_step, lsmax) : line_search_parallel<NVP, false>(c, (float)m.opt.ls_parallel_min_step, lsmax);
+        else
+          alpha = c.nf > 0 ? line_search<NVP, true>(c, gtol, lsmax) : line_search<NVP, false>(c, gtol, lsmax);
         PROF_MARK(6);
 #ifdef MJLAB_PROFILE
         prof_acc_[10] += (float)c.ls_iter;

@@ -47,8 +47,8 @@ class Model:
     struct, base, view = device_state.upload_model(host, 1, 1, 1, device)
     self.__dict__.update(struct=struct, _base=base, _view=view)
     struct.opt.flags |= _abi.OPT_FRICTIONLOSS  # nothing on this seam sees a later write to dof_frictionloss: always read it
-    # the reference sets wp_model.opt.ls_parallel (sim/sim.py:111); accepted and ignored: the search here
-    # is the exact iterative one (deviations).  "Forward folded into the next step" stays
+    # the reference sets wp_model.opt.ls_parallel (sim/sim.py:111): read at every step() / forward() (_sync_opt).
+    # "Forward folded into the next step" stays
     # OFF on this seam: nothing here sees writes to model arrays between forward() and step()
     # (Simulation hooks its model bridge for that); set struct.opt.flags |= _abi.OPT_FOLD_FORWARD to opt in.
     self.__dict__["opt"] = SimpleNamespace(**host.opt.__dict__, ls_parallel=False)
@@ -132,9 +132,20 @@ def _static_geoms(m: Model, d: Data) -> None:
   d._static_done = True
 
 
+def _sync_opt(m: Model) -> None:
+  """`wp_model.opt.ls_parallel = cfg.ls_parallel` (reference sim/sim.py:111) is a plain attribute write: mirror it into the flags."""
+  import os
+
+  env_ls = os.environ.get("MJLAB_LS_PARALLEL")
+  on = bool(int(env_ls)) if env_ls not in (None, "") else bool(getattr(m.opt, "ls_parallel", False))
+  m.struct.opt.flags = (m.struct.opt.flags | _abi.OPT_LS_PARALLEL) if on else (m.struct.opt.flags & ~_abi.OPT_LS_PARALLEL)
+  m.struct.opt.ls_parallel_min_step = float(getattr(m.opt, "ls_parallel_min_step", 1.0e-6))
+
+
 def forward(m: Model, d: Data) -> None:
   with torch.cuda.device(d.device):
     _bind(m, d)
+    _sync_opt(m)
     _static_geoms(m, d)
     native.check(native.lib().mjlab_forward(ctypes.byref(m.struct), ctypes.byref(d.struct), _stream(d)), "mjlab_forward")
 
@@ -142,6 +153,7 @@ def forward(m: Model, d: Data) -> None:
 def step(m: Model, d: Data) -> None:
   with torch.cuda.device(d.device):
     _bind(m, d)
+    _sync_opt(m)
     _static_geoms(m, d)
     native.check(native.lib().mjlab_step(ctypes.byref(m.struct), ctypes.byref(d.struct), 1, _stream(d)), "mjlab_step")
 

@@ -76,10 +76,12 @@ class SimulationCfg:
 
   nconmax: int | None = None
   njmax: int | None = None
-  # The reference sets True (mujoco_warp's fixed-grid parallel line search).  Here the search is
-  # always MuJoCo's exact iterative one: True is accepted with a one-time warning (INTEGRATION.md,
-  # "deviations")
+  # True (the reference's default, sim/sim.py:89): mujoco_warp's parallel line search -- the cost at `ls_iterations` log-spaced
+  # step sizes in [ls_parallel_min_step, 1], lowest cost wins (MJLAB_OPT_LS_PARALLEL, include/mjlab_fields.h; grid restated from
+  # memory of mujoco_warp, unverified).  False: MuJoCo's exact iterative search (mj_solPrimal).  The environment variable
+  # MJLAB_LS_PARALLEL=0|1 overrides the configuration (the parity suites pin the exact search with it: tests/conftest.py)
   ls_parallel: bool = True
+  ls_parallel_min_step: float = 1.0e-6  # mujoco_warp Option.ls_parallel_min_step (not a field of the reference's cfg)
   mujoco: MujocoCfg = field(default_factory=MujocoCfg)
   nan_guard: NanGuardCfg = field(default_factory=NanGuardCfg)
   use_graph: bool = True
@@ -124,9 +126,6 @@ def check_supported(model: Model) -> None:
     spec = np.asarray(model.sensor_intprm)[:, 0]
     if (spec != 1).any():
       raise NotImplementedError("contact sensors support only the 'found' data spec")
-
-
-_LS_PARALLEL_WARNED = False
 
 
 class _NumpyView:
@@ -196,15 +195,8 @@ class Simulation:
     self._mj_model = model
     self._mj_data = HostData(model)
     self._lib = native.lib()
-    global _LS_PARALLEL_WARNED
-    if cfg.ls_parallel and not _LS_PARALLEL_WARNED:
-      _LS_PARALLEL_WARNED = True
-      warnings.warn(
-        "SimulationCfg.ls_parallel=True: mjlab_amd always runs MuJoCo's exact iterative line search "
-        "(<= ls_iterations evaluations), not mujoco_warp's fixed-grid parallel search; iterates can differ "
-        "from the reference's beyond its ls_tolerance when the Newton iteration cap binds (INTEGRATION.md, deviations)",
-        stacklevel=2,
-      )
+    env_ls = os.environ.get("MJLAB_LS_PARALLEL")
+    self.ls_parallel = bool(int(env_ls)) if env_ls not in (None, "") else bool(getattr(cfg, "ls_parallel", True))
     mf, df, MS, DS = native.layouts()
     self._mfields = {f.name: f for f in mf}
     self._dfields = {f.name: f for f in df}
@@ -215,9 +207,11 @@ class Simulation:
     # environment classes construct this Simulation (tools/reference_env.py): this package's extra switches then take their defaults
     ext = SimulationCfg()
     opt = lambda name: getattr(cfg, name, getattr(ext, name))  # noqa: E731
+    self._m.opt.ls_parallel_min_step = float(opt("ls_parallel_min_step"))
     self._m.opt.flags = ((self._m.opt.flags & _abi.OPT_FRICTIONLOSS) | (_abi.OPT_FOLD_FORWARD if opt("fold_forward") else 0)
                          | (_abi.OPT_LITERAL_TERMINATION if opt("literal_termination") else 0)
                          | (_abi.OPT_WARMSTART_AT_ADVANCE if opt("warmstart_at_advance") else 0)
+                         | (_abi.OPT_LS_PARALLEL if self.ls_parallel else 0)
                          | {"stage": 0, "presolve": _abi.OPT_FUSE_PRESOLVE, "step": _abi.OPT_FUSE_STEP}[opt("fuse")])
     self._d, self._data = device_state.alloc_data(model, num_envs, self.nconmax, self.njmax, dev)
 

