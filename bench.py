@@ -44,6 +44,9 @@ from mjlab_amd.sim import Simulation, SimulationCfg  # noqa: E402
 ALGO_BYTES_PER_WORLD_STEP = {"g1_velocity_flat": 10156, "g1_tracking_flat": 10716, "go1_velocity_flat": 5672, "g1_velocity_rough": 10108,
                              "go1_velocity_rough": 5624}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3  # vector fp32: 256 CUs x 4 SIMDs x 64 lanes x 2 flop / 2 cycles x 2.4 GHz (same guide)
+# a forward() pass reads the same inputs and writes every derived field but not the integrated state (qpos, qvel, time)
+FORWARD_LESS_BYTES = {"g1": (36 + 35 + 1) * 4, "go1": (19 + 18 + 1) * 4}
 
 
 def cpu_baseline(scene: str, seed: int) -> dict:
@@ -121,6 +124,9 @@ def main() -> None:
                   help="refresh EntityData's derived quantities (body / root poses and velocities, projected gravity, joint state) "
                   "in the control kernel's epilogue (mjlab_control_t.readback_on; control kernel only)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-full-env", action="store_true",
+                  help="skip value_full_env (the reference's own ManagerBasedRlEnv of the same task stepped over this Simulation; "
+                  "only measured where the reference source is reachable: MJLAB_REFERENCE_SRC / gpurun_ref, tools/stage_reference.sh)")
   ap.add_argument("--settle", type=int, default=200, help="untimed control steps of set-up before the warm-up steps (start-up transient of the rollout)")
   ap.add_argument("--seed", type=int, default=42)
   args = ap.parse_args()
@@ -209,6 +215,8 @@ def main() -> None:
   # learner on the same GPU would read; N > 1 the rows are already part of the exchange above)
   value_with_rows = None
   if not exchange:
+    for _ in range(3):  # untimed: the first assembly of the rows allocates its output (torch.cat)
+      env_step(with_rows=True)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(args.steps):
@@ -298,36 +306,84 @@ def main() -> None:
     n_env = args.envs_per_gpu * info.world_size
     value = n_env * args.steps / elapsed
     algo = ALGO_BYTES_PER_WORLD_STEP.get(args.scene)
-    traffic, valu_busy = None, None
+    traffic, valu_busy, prof = None, None, {}
     tfile = ROOT / "profiles" / "traffic.json"
+    key = "substep" if args.fuse == "step" else "solve_integrate"
     if tfile.exists():
       try:
-        ent = json.loads(tfile.read_text()).get(args.scene, {})
-        key = "substep" if args.fuse == "step" else "solve_integrate"
-        traffic = ent.get(key + "_bytes_per_launch")
-        valu_busy = ent.get(key + "_valu_busy")
+        prof = json.loads(tfile.read_text()).get(args.scene, {})
+        traffic = prof.get(key + "_bytes_per_launch")
+        valu_busy = prof.get(key + "_valu_busy")
       except Exception:  # noqa: BLE001
         traffic = None
     roof = None
     if algo and dom_ms:
-      achieved = algo * dom_sub * args.envs_per_gpu / (dom_ms * 1e-3) / 1e9
+      # units of one launch of the dominant kernel: physics steps (SURVEY 8(d)'s unit) and, in the control kernel, the
+      # forward() pass after the resets, counted apart with its own (smaller) contract
+      nstep = dom_sub - 1 if roll.control_kernel else dom_sub
+      nfwd = 1 if roll.control_kernel else 0
+      fwd_bytes = algo - FORWARD_LESS_BYTES[robot]
+      algo_launch = (nstep * algo + nfwd * fwd_bytes) * args.envs_per_gpu
+      achieved = algo_launch / (dom_ms * 1e-3) / 1e9
+      flops_launch = prof.get(key + "_flops_per_launch")
       roof = {
         "bound": "hbm",
         "kernel": dom_name,
-        "physics_steps_per_launch": dom_sub,
+        "units": {"physics_steps_per_launch": nstep, "forward_passes_per_launch": nfwd, "worlds": args.envs_per_gpu,
+                  "bytes_per_world_step": algo, "bytes_per_world_forward": fwd_bytes},
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
+        "frac_physics_steps_only": nstep * algo * args.envs_per_gpu / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # NOT measured in this run: read from the committed rocprofv3 counter passes of the profile named in traffic_source
+        # (FETCH_SIZE x 2.0 + WRITE_SIZE x 1.0, factors measured on known byte counts: profiles/calibration.json)
         "traffic": traffic,
-        # the bound that matters here (the HBM fraction is ~2 % by construction): share of the chip's VALU issue
-        # cycles the dominant kernel uses, from rocprofv3 SQ counters of the committed profile (tools/collect_profile.py)
+        "traffic_source": prof.get("source"),
+        # the bound that matters here (the HBM fraction is ~2 % by construction): share of the chip's VALU issue cycles the
+        # dominant kernel uses -- SQ_INSTS_VALU x the issue cycles of its static instruction mix (same committed profile)
         "valu_busy": valu_busy,
-        "algorithmic_bytes_per_launch": algo * dom_sub * args.envs_per_gpu,
+        "valu_busy_2cycle_lower_bound": prof.get(key + "_valu_busy_2cycle_lower_bound"),
+        # issued fp32 operations (static mix x SQ_INSTS_VALU + 2048 x MFMA of the committed profile) over THIS
+        # run's kernel time, against the vector fp32 peak
+        "flops": None if not flops_launch else {"achieved": flops_launch / (dom_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": flops_launch / (dom_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flops_per_launch": flops_launch},
+        "algorithmic_bytes_per_launch": algo_launch,
         "kernel_ms": dom_ms,
         "stage_ms": stage_ms,
-        "note": "latency/LDS-bound by construction (SURVEY.md 8d): lower HBM traffic is better",
+        "note": "latency-bound by construction (SURVEY.md 8d): 4 waves per SIMD, one world per wave; lower HBM traffic is better",
       }
+    # ---- the reference's OWN environment of the same task (ManagerBasedRlEnv, Scene, Entity, managers, MDP terms: unmodified
+    # reference code, ~150 small torch kernels per control step around the physics) stepped over this Simulation: the full
+    # env-steps/s SURVEY 8(d) asks for next to the physics-only `value`.  Only where the reference source is reachable
+    # (tools/reference_env.py: MJLAB_REFERENCE_SRC / gpurun_ref staged by tools/stage_reference.sh); the driver's box has none.
+    full_env, full_env_note = None, None
+    task = {"g1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-G1", "go1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-Go1",
+            "g1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-G1", "go1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-Go1"}.get(args.scene)
+    if not args.no_full_env and info.world_size == 1 and task is not None:
+      sys.path.insert(0, str(ROOT / "tools"))
+      import reference_env
+
+      if reference_env.locate_reference() is None:
+        full_env_note = "not measured: the reference's source is not on this machine (tools/stage_reference.sh stages it for one gpurun call)"
+      else:
+        try:
+          env = reference_env.make_env(task, num_envs=args.envs_per_gpu, device=dev, seed=args.seed)
+          na = sum(env.action_manager.action_term_dim)
+          gen = torch.Generator(device=dev)
+          gen.manual_seed(args.seed)
+          env.reset()
+          nfull = max(20, min(args.steps, 100))
+          for k in range(20 + nfull):
+            if k == 20:
+              torch.cuda.synchronize()
+              tf = time.perf_counter()
+            env.step(2.0 * torch.rand((args.envs_per_gpu, na), device=dev, generator=gen) - 1.0)
+          torch.cuda.synchronize()
+          full_env = args.envs_per_gpu * nfull / (time.perf_counter() - tf)
+          full_env_note = f"{task}: the reference's ManagerBasedRlEnv.step over mjlab_amd.Simulation, {nfull} timed steps after 20, random policy"
+        except Exception as e:  # noqa: BLE001
+          full_env_note = f"failed: {type(e).__name__}: {e}"
     cpu = None
     if not args.no_cpu_baseline and info.world_size == 1:  # reported at N = 1 only
       try:
@@ -351,7 +407,9 @@ def main() -> None:
       "data": "synthetic (random actions, keyframe resets"
       + ("" if args.no_task_events else ", per-env foot friction U(0.3,1.2), velocity pushes every U(1,3) s") + "; compiled model from the reference MJCF)",
       "config": {
-        "workload": f"{args.scene}: {args.envs_per_gpu} envs/GPU, timestep 0.005, decimation 4, Newton 10 it / 20 ls, implicitfast, pyramidal, njmax 300"
+        "workload": f"{args.scene}: {args.envs_per_gpu} envs/GPU, timestep 0.005, decimation 4, Newton 10 it / 20 ls "
+        + ("(ls_parallel: mujoco_warp's grid search, the reference's setting)" if sim.ls_parallel else "(exact iterative line search; ls_parallel off)")
+        + ", implicitfast, pyramidal, njmax 300"
         + ("" if args.no_task_events else "; task events: DR friction (per-env geom_friction), pushes, bad_orientation 70 deg termination"),
         "global_envs": n_env,
         "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL action scatter and obs gather to the learner (rank 0) every control step" if exchange else ""),
@@ -366,6 +424,8 @@ def main() -> None:
       },
       "world_physics_steps_per_s": value * roll.decimation,
       "value_with_gather": value if exchange else value_with_rows,
+      "value_full_env": full_env,
+      "value_full_env_note": full_env_note,
       "std_over_5": float(np.std(chunk_rates)) if nchunk == 5 else None,
       "chunk_values": chunk_rates,
       "per_rank_ms_per_step": rank_ms,

@@ -38,6 +38,33 @@ def device_objects(lib: Path) -> list[bytes]:
   return out
 
 
+# Issue cost (SIMD cycles per wave64 instruction) and issued fp32 operations per lane of the VALU instruction classes.  Cycles:
+# measured with tools/ubench.hip on one MI355X at 4 waves per SIMD (profiles/r03_ubench/report.txt, profiles/README.md
+# "calibration"): v_fma_f32 2 (the guide's figure, MI355X_MICROARCH.md:52-53), v_pk_fma_f32 4 (1.87 x the v_fma rate: NO
+# throughput gain per flop over v_fma_f32), DPP-modified VALU 4 (1.62 x), v_readlane_b32 -> SGPR -> v_fma pair 7 (readlane 5),
+# v_mfma_f32_16x16x4_f32 32 (29-34 measured).  Transcendentals (quarter rate, 8) are the guide's figure, not measured here.
+def valu_class(op: str, line: str) -> tuple[str, float, float]:
+  """-> (class, cycles, flops per lane) of one disassembled VALU instruction."""
+  if "mfma" in op:
+    return "mfma", 32.0, 2048.0 / 64.0
+  dpp = "dpp" in line
+  if op.startswith(("v_readlane", "v_readfirstlane", "v_writelane")):
+    return "readlane", 5.0, 0.0
+  if op.startswith("v_pk_fma_f32"):
+    return "pk_fma", 4.0, 4.0
+  if op.startswith(("v_pk_mul_f32", "v_pk_add_f32")):
+    return "pk_other", 4.0, 2.0
+  if op.startswith(("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")):
+    return "trans", 8.0, 1.0
+  if op.startswith(("v_fma_f32", "v_fmac_f32", "v_mad_f32", "v_mac_f32")):
+    return ("dpp" if dpp else "fma"), (4.0 if dpp else 2.0), 2.0
+  if op.startswith(("v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_max_f32", "v_min_f32", "v_med3_f32", "v_mul_legacy_f32")):
+    return ("dpp" if dpp else "f32_1op"), (4.0 if dpp else 2.0), 1.0
+  if op.endswith(("_b64", "_u64", "_i64", "_f64")) or "u64" in op:
+    return "wide", 4.0, 0.0
+  return ("dpp" if dpp else "other"), (4.0 if dpp else 2.0), 0.0
+
+
 def kernels(lib: Path) -> dict[str, dict]:
   """kernel name (demangled-ish: the mangled symbol) -> metadata fields + instruction counts."""
   res: dict[str, dict] = {}
@@ -70,7 +97,22 @@ def kernels(lib: Path) -> dict[str, dict]:
           if pat in op or (key == "dpp" and "dpp" in line):
             c[key] = c.get(key, 0) + 1
         c["total"] = c.get("total", 0) + 1
+        if op.startswith("v_"):
+          cls, cyc, fl = valu_class(op, line)
+          v = res[cur].setdefault("valu", {})
+          e = v.setdefault(cls, [0, 0.0, 0.0])  # count, cycles, lane-flops
+          e[0] += 1; e[1] += cyc; e[2] += fl
   return res
+
+
+def valu_mix(md: dict) -> dict:
+  """Static mix of a kernel's VALU instructions: average issue cycles and issued fp32 operations (x 64 lanes) per VALU
+  instruction (MFMA kept apart: SQ_INSTS_MFMA counts it separately)."""
+  v = {k: e for k, e in md.get("valu", {}).items() if k != "mfma"}
+  n = sum(e[0] for e in v.values())
+  return {"valu_insts_static": n, "cycles_per_valu_inst": sum(e[1] for e in v.values()) / max(n, 1),
+          "flops_per_valu_inst_wave": 64.0 * sum(e[2] for e in v.values()) / max(n, 1),
+          "classes": {k: e[0] for k, e in sorted(md.get("valu", {}).items())}}
 
 
 if __name__ == "__main__":
@@ -78,4 +120,4 @@ if __name__ == "__main__":
   sub = sys.argv[2] if len(sys.argv) > 2 else ""
   for name, md in sorted(kernels(lib).items()):
     if sub in name:
-      print(name, {k: v for k, v in md.items() if k != "insts"}, md.get("insts", {}))
+      print(name, {k: v for k, v in md.items() if k not in ("insts", "valu")}, md.get("insts", {}), valu_mix(md))
