@@ -157,6 +157,17 @@
   X(efc_aref, 1, njmax)                                                         \
   X(efc_force, 1, njmax)                                                        \
   X(efc_frictionloss, 1, njmax) /* written for the friction-loss rows only: rows [0, nf) */ \
+  /* PRIVATE hand-over arrays of the pipeline, in the world's LOCAL FRAME: positions minus xorigin, the free base's position     \
+   * rounded to whole metres (0 for models without a floating base).  A robot standing 100 m from the origin has fp32 world       \
+   * coordinates that resolve 7.6 um; offsets between its bodies (contact point - centre of mass, geom - terrain box) formed     \
+   * from them lose 2-3 digits.  The stages therefore compute in the local frame, hand these arrays to each other, and add        \
+   * xorigin only when they write the public world-frame arrays (xpos, xipos, xanchor, subtree_com, geom_xpos, site_xpos,         \
+   * contact_pos), which nothing inside the step reads back */                                                                    \
+  X(xorigin, 3, one)                                                            \
+  X(geom_xrel, 3, ngeom)      /* geoms [nstaticgeom, ngeom): geom_xpos - xorigin */ \
+  X(subtree_crel, 3, nbody)   /* subtree_com - xorigin */                         \
+  X(xipos_rel, 3, nbody)      /* xipos - xorigin */                               \
+  X(contact_prel, 3, nconmax) /* contact_pos - xorigin */                         \
   X(sh_qpos, 1, nq) /* qpos / qvel as they were at the last forward(): see fold_valid */ \
   X(sh_qvel, 1, nv)                                                             \
   X(profile, 64, one) /* per-world per-phase cycle counts; written only by -DMJLAB_PROFILE builds */
@@ -263,7 +274,12 @@ enum {
    * step with the lowest cost is taken (first one on ties).  Restated from memory of mujoco_warp's solver (`_log_scale`,
    * `linesearch_parallel_best_alpha`); the pinned source is not available here, so the grid is UNVERIFIED.
    * Bit clear: MuJoCo's exact iterative search (mj_solPrimal's bracketing Newton search, <= ls_iterations evaluations) */
-  MJLAB_OPT_LS_PARALLEL = 64
+  MJLAB_OPT_LS_PARALLEL = 64,
+  /* xorigin = 0: the stages compute in plain world coordinates (what they did before the local frame existed, and what the
+   * reference's engine does).  The host sets it for the ONE pass that poses the static geoms and sites (world / terrain
+   * bodies), so that their stored world poses do not depend on where the robots happen to be at construction; it is also
+   * the switch for A/B runs of the local frame (SimulationCfg.local_frame = False) */
+  MJLAB_OPT_WORLD_FRAME = 128
 };
 
 #define MJLAB_DECL_INT_(name, ncol, count) const int* name;

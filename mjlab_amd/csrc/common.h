@@ -60,6 +60,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_mov<0x143, 0xC, false>(v);  // rows 2,3 += lane 31
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// Minimum over the wave, wave-uniform.  Same DPP pattern; lanes a step does not write keep their own value (`old` operand).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov_keep(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+__device__ __forceinline__ float wave_min(float v) {
+  v = fminf(v, dpp_mov_keep<0xB1, 0xF, true>(v));
+  v = fminf(v, dpp_mov_keep<0x4E, 0xF, true>(v));
+  v = fminf(v, dpp_mov_keep<0x141, 0xF, true>(v));
+  v = fminf(v, dpp_mov_keep<0x140, 0xF, true>(v));
+  v = fminf(v, dpp_mov_keep<0x142, 0xA, false>(v));  // rows 1,3: min with lane 15 of rows 0,2
+  v = fminf(v, dpp_mov_keep<0x143, 0xC, false>(v));  // rows 2,3: min with lane 31
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// value of lane `src` (wave-uniform, not a compile-time constant)
+__device__ __forceinline__ float lane_bcast_dyn(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(src)));
+}
 // reference implementations through the LDS crossbar (used by the self-test only)
 __device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
@@ -83,6 +101,13 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
 }
 __device__ __forceinline__ void lds_to_global(float* dst, const float* src, int n, int lane) {
   for (int k = lane; k < n; k += 64) dst[k] = src[k];
+}
+// rows of 3 (positions in the world's local frame) -> public world-frame array: element k gets org[k mod 3] added
+__device__ __forceinline__ void lds3_to_global_org(float* dst, const float* src, int n, int lane, const float (&org)[3]) {
+  for (int k = lane; k < n; k += 64) {
+    const int c = k - 3 * (k / 3);
+    dst[k] = src[k] + (c == 0 ? org[0] : c == 1 ? org[1] : org[2]);
+  }
 }
 __device__ __forceinline__ void global_to_lds(float* dst, const float* src, int n, int lane) {
   for (int k = lane; k < n; k += 64) dst[k] = src[k];

@@ -255,9 +255,12 @@ __device__ __forceinline__ int box_box_candidate(RawCon* c, int cand, float marg
 // the (at most MJLAB_TCAND_MAX, smallest ids first) boxes within reach in ascending order in
 // `cand` (this lane's LDS slots).  A box listed in several cells is looked at once, in the lowest
 // cell the two footprints share.
-__device__ __forceinline__ int terrain_walk(const Model& m, const float* centre, float reach, int* cand, bool* dropped) {
+// `lc` = the geom's centre in the world's local frame (world = lc + org): grid cells and box tops are looked up in world
+// coordinates, distances are formed in the local frame.
+__device__ __forceinline__ int terrain_walk(const Model& m, const float* lc, const float (&org)[3], float reach, int* cand, bool* dropped) {
   const int nx = m.size.tgrid_nx, ny = m.size.tgrid_ny;
   const float x0 = (float)m.opt.tgrid_x0, y0 = (float)m.opt.tgrid_y0, inv = 1.0f / (float)m.opt.tgrid_cell;
+  const float centre[3] = {lc[0] + org[0], lc[1] + org[1], lc[2] + org[2]};
   int ix0 = (int)floorf((centre[0] - reach - x0) * inv), ix1 = (int)floorf((centre[0] + reach - x0) * inv);
   int iy0 = (int)floorf((centre[1] - reach - y0) * inv), iy1 = (int)floorf((centre[1] + reach - y0) * inv);
   ix0 = min(max(ix0, 0), nx - 1); ix1 = min(max(ix1, 0), nx - 1);
@@ -273,7 +276,7 @@ __device__ __forceinline__ int terrain_walk(const Model& m, const float* centre,
         const int bx = m.tbox_cell0[2 * b], by = m.tbox_cell0[2 * b + 1];
         if (ix != max(ix0, bx) || iy != max(iy0, by)) continue;
         const float *bpos = m.tbox_pos + 3 * b, *bmat = m.tbox_mat + 9 * b, *bsize = m.tbox_size + 3 * b;
-        const float dif[3] = {centre[0] - bpos[0], centre[1] - bpos[1], centre[2] - bpos[2]};
+        const float dif[3] = {lc[0] - (bpos[0] - org[0]), lc[1] - (bpos[1] - org[1]), lc[2] - (bpos[2] - org[2])};
         float d2 = 0.f;
         for (int i = 0; i < 3; ++i) {
           const float loc = bmat[i] * dif[0] + bmat[3 + i] * dif[1] + bmat[6 + i] * dif[2];
@@ -318,7 +321,8 @@ __host__ __device__ inline int collision_lds_floats(const mjlab_sizes_t& s) {
 // Contact parameters (mj_contactParam) of the pair (g1, g2) + ordered append of this lane's n
 // raw contacts at slots base + off ..
 __device__ __forceinline__ void emit_contacts(const Model& m, const Data& d, int w, int g1, int g2, float margin, float gap, const RawCon (&rc)[4],
-                                              int n, int first, const float* gfri, const float* gsolref, const float* gsolimp, const float* gsolmix) {
+                                              int n, int first, const float* gfri, const float* gsolref, const float* gsolimp, const float* gsolmix,
+                                              const float (&org)[3]) {
   const int ncm = m.size.nconmax;
   int condim;
   float fri[3], solref[2], solimp[5];
@@ -352,7 +356,7 @@ __device__ __forceinline__ void emit_contacts(const Model& m, const Data& d, int
     make_frame(f9, rc[i].frame);
     const size_t wc = (size_t)w * ncm + c;
     d.contact_dist[wc] = rc[i].dist;
-    for (int k = 0; k < 3; ++k) d.contact_pos[3 * wc + k] = rc[i].pos[k];
+    for (int k = 0; k < 3; ++k) { d.contact_pos[3 * wc + k] = rc[i].pos[k] + org[k]; d.contact_prel[3 * wc + k] = rc[i].pos[k]; }
     for (int k = 0; k < 9; ++k) d.contact_frame[9 * wc + k] = f9[k];
     d.contact_includemargin[wc] = margin - gap;
     float* f5 = d.contact_friction + 5 * wc;
@@ -380,7 +384,18 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
   // finds all of its operands on chip.
   int ng1 = 0, ng2 = 0;  // geoms of pair (sweep 0, this lane)
   if (lane < npair) { ng1 = m.pair_geom[2 * lane]; ng2 = m.pair_geom[2 * lane + 1]; }
-  global_to_lds(s_gx, d.geom_xpos + ((size_t)w * ng + g0) * 3, 3 * nl, lane);
+  // geom positions in the world's local frame: moving geoms as the position stage left them, static ones (posed once, in
+  // world coordinates) minus the origin
+  float org[3];
+  for (int k = 0; k < 3; ++k) org[k] = d.xorigin[(size_t)w * 3 + k];
+  {
+    const int ng0 = m.size.nstaticgeom;
+    const float *gxw = d.geom_xpos + (size_t)w * ng * 3, *gxr = d.geom_xrel + (size_t)w * ng * 3;
+    for (int k = lane; k < 3 * nl; k += 64) {
+      const int e = 3 * g0 + k, g = e / 3, c = e - 3 * g;
+      s_gx[k] = g < ng0 ? gxw[e] - (c == 0 ? org[0] : c == 1 ? org[1] : org[2]) : gxr[e];
+    }
+  }
   global_to_lds(s_gm, d.geom_xmat + ((size_t)w * ng + g0) * 9, 9 * nl, lane);
   for (int l = lane; l < nl; l += 64) {
     const int g = g0 + l;
@@ -490,7 +505,7 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
     }
     int total;
     const int off = wave_excl_scan(n, lane, &total);
-    if (n > 0) emit_contacts(m, d, w, g1, g2, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix);
+    if (n > 0) emit_contacts(m, d, w, g1, g2, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix, org);
     base += total;
   }
   PROF_MARK(1);
@@ -510,7 +525,7 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
       if (ti < ntg) {
         const int g = m.tgeom[ti];
         isbox = ((const int*)s_gc)[8 * (g - g0)] == MJLAB_GEOM_BOX;
-        nc = terrain_walk(m, s_gx + 3 * (g - g0), s_gc[8 * (g - g0) + 4] + s_gc[8 * (g - g0) + 5], s_cand + ti * MJLAB_TCAND_MAX, &tdrop);
+        nc = terrain_walk(m, s_gx + 3 * (g - g0), org, s_gc[8 * (g - g0) + 4] + s_gc[8 * (g - g0) + 5], s_cand + ti * MJLAB_TCAND_MAX, &tdrop);
       }
       int total, totalb;
       const int off = wave_excl_scan(isbox ? 0 : nc, lane, &total);
@@ -538,7 +553,7 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
         float cp[3], cz[3], cs[3], bpos[3], bmat[9], bsize[3];
         for (int k = 0; k < 3; ++k) {
           cp[k] = s_gx[3 * l + k]; cz[k] = s_gm[9 * l + 3 * k + 2]; cs[k] = s_gc[8 * l + 1 + k];
-          bpos[k] = m.tbox_pos[3 * b + k]; bsize[k] = m.tbox_size[3 * b + k];
+          bpos[k] = m.tbox_pos[3 * b + k] - org[k]; bsize[k] = m.tbox_size[3 * b + k];
         }
         for (int k = 0; k < 9; ++k) bmat[k] = m.tbox_mat[9 * b + k];
         if (((const int*)s_gc)[8 * l] == MJLAB_GEOM_SPHERE) n = sphere_box(rc, margin, cp, cs[0], bpos, bmat, bsize);
@@ -546,7 +561,7 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
       }
       int total;
       const int off = wave_excl_scan(n, lane, &total);
-      if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix);
+      if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + off, gfri, gsolref, gsolimp, gsolmix, org);
       base += total;
     }
     // Moving boxes vs terrain boxes: one pair per sweep, lanes = the rule's 40 candidates (box_box_candidate);
@@ -562,7 +577,7 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
         float cp[3], cs[3], cm[9], bpos[3], bmat[9], bsize[3];
         for (int k = 0; k < 3; ++k) {
           cp[k] = s_gx[3 * l + k]; cs[k] = s_gc[8 * l + 1 + k];
-          bpos[k] = m.tbox_pos[3 * b + k]; bsize[k] = m.tbox_size[3 * b + k];
+          bpos[k] = m.tbox_pos[3 * b + k] - org[k]; bsize[k] = m.tbox_size[3 * b + k];
         }
         for (int k = 0; k < 9; ++k) { cm[k] = s_gm[9 * l + k]; bmat[k] = m.tbox_mat[9 * b + k]; }
         hit = box_box_candidate(rc, lane, margin, cp, cm, cs, bpos, bmat, bsize) != 0;
@@ -571,7 +586,7 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
       const int rank = __popcll(hits & ((1ull << lane) - 1ull));
       const int n = hit && rank < 4 ? 1 : 0;
       const int total = min(__popcll(hits), 4);
-      if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + rank, gfri, gsolref, gsolimp, gsolmix);
+      if (n > 0) emit_contacts(m, d, w, g, gb, margin, gap, rc, n, base + rank, gfri, gsolref, gsolimp, gsolmix, org);
       base += total;
     }
   }

@@ -157,7 +157,7 @@ __device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, 
   // contact at a time, Jacobian rows from LDS operands only.
   const int ncon = d.ncon[w];
   const float* binv = MF(body_invweight0);
-  const float* sub = d.subtree_com + (size_t)w * 3 * nb;
+  const float* sub = d.subtree_crel + (size_t)w * 3 * nb;  // local frame, like contact_prel
   const float impratio_rs = sqrtf(1.f / (float)m.opt.impratio);
   float c6[6], qv = 0.f;  // this lane's dof (nv <= 64)
   for (int k = 0; k < 6; ++k) c6[k] = lane < nv ? d.cdof[((size_t)w * nv + lane) * 6 + k] : 0.f;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, 
       const float dist = d.contact_dist[wc], inc = d.contact_includemargin[wc];
       const int g1 = d.contact_geom[2 * wc], g2 = d.contact_geom[2 * wc + 1];
       float pos[3], solref[2], solimp[5];
-      for (int k = 0; k < 3; ++k) pos[k] = d.contact_pos[3 * wc + k];
+      for (int k = 0; k < 3; ++k) pos[k] = d.contact_prel[3 * wc + k];
       for (int k = 0; k < 9; ++k) s_cc[(CC_FRAME + k) * 64 + lane] = d.contact_frame[9 * wc + k];
       const float mu0 = d.contact_friction[5 * wc], mu1 = d.contact_friction[5 * wc + 1];
       for (int k = 0; k < 2; ++k) solref[k] = d.contact_solref[2 * wc + k];

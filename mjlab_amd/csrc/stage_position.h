@@ -119,8 +119,21 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
   }
 
   global_to_lds(s_qpos, d.qpos + (size_t)w * nq, nq, lane);
+  // The world's LOCAL FRAME (include/mjlab_fields.h, xorigin): the position of the first floating base, rounded to whole
+  // metres.  qpos - org is exact in fp32 (both are multiples of the same ulp and the difference is small), every pose below is
+  // composed from it and from body-relative offsets, so offsets between bodies keep full fp32 precision wherever the robot
+  // stands; the public world-frame arrays get org added back when they are written.
+  float org[3] = {0.f, 0.f, 0.f};
+  {
+    const bool floating = lane < nb && b_jn == 1 && b_jtype == MJLAB_JNT_FREE && b_pid == 0;
+    const unsigned long long fm = __ballot(floating);
+    if (fm && !(m.opt.flags & MJLAB_OPT_WORLD_FRAME)) {
+      const int src = (int)__builtin_ctzll(fm);
+      for (int k = 0; k < 3; ++k) org[k] = rintf(lane_bcast_dyn(floating ? d.qpos[(size_t)w * nq + b_qadr + k] : 0.f, src));  // wave-uniform (SGPRs)
+    }
+  }
   if (lane == 0) {
-    s_xpos[0] = s_xpos[1] = s_xpos[2] = 0.f;
+    for (int k = 0; k < 3; ++k) { s_xpos[k] = -org[k]; d.xorigin[(size_t)w * 3 + k] = org[k]; }
     s_xquat[0] = 1.f; s_xquat[1] = s_xquat[2] = s_xquat[3] = 0.f;
   }
   if (lane < 9) s_xmat[lane] = (lane % 4 == 0) ? 1.f : 0.f;
@@ -180,6 +193,11 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
           }
           for (int k = 0; k < 3; ++k) { s_xanchor[3 * j + k] = anc[k]; s_xaxis[3 * j + k] = xax[k]; }  // parent frame
         }
+      }
+      if (pid == 0 && b > 0) {  // children of the world: into the local frame (exact for the floating base)
+        for (int k = 0; k < 3; ++k) pos[k] -= org[k];
+        if (jn == 1 && b_jtype == MJLAB_JNT_FREE) for (int k = 0; k < 3; ++k) s_xanchor[3 * ja + k] = pos[k];
+        else for (int j = ja; j < ja + jn; ++j) for (int k = 0; k < 3; ++k) s_xanchor[3 * j + k] -= org[k];
       }
       for (int k = 0; k < 3; ++k) s_lpos[3 * b + k] = pos[k];
       for (int k = 0; k < 4; ++k) s_lquat[4 * b + k] = quat[k];
@@ -246,6 +264,7 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
   }
   {
     float* gx = d.geom_xpos + (size_t)w * 3 * ng;
+    float* gxr = d.geom_xrel + (size_t)w * 3 * ng;  // local frame: what the collision stage reads
     float* gm = d.geom_xmat + (size_t)w * 9 * ng;
     // geoms of static bodies keep the poses written at construction (sizes.nstaticgeom)
 #pragma unroll
@@ -258,7 +277,7 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
         for (int k = 0; k < 4; ++k) bq[k] = s_xquat[4 * b + k];
         for (int k = 0; k < 9; ++k) bm[k] = s_xmat[9 * b + k];
         local2global(xp, xm, bp, bq, bm, g_pos[r], g_quat[r]);
-        for (int k = 0; k < 3; ++k) gx[3 * g + k] = xp[k];
+        for (int k = 0; k < 3; ++k) { gx[3 * g + k] = xp[k] + org[k]; gxr[3 * g + k] = xp[k]; }
         for (int k = 0; k < 9; ++k) gm[9 * g + k] = xm[k];
       }
     }
@@ -270,7 +289,7 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
       for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; iq[k] = gquat[4 * g + k]; }
       for (int k = 0; k < 9; ++k) bm[k] = s_xmat[9 * b + k];
       local2global(xp, xm, bp, bq, bm, ip, iq);
-      for (int k = 0; k < 3; ++k) gx[3 * g + k] = xp[k];
+      for (int k = 0; k < 3; ++k) { gx[3 * g + k] = xp[k] + org[k]; gxr[3 * g + k] = xp[k]; }
       for (int k = 0; k < 9; ++k) gm[9 * g + k] = xm[k];
     }
     float* sx = d.site_xpos + (size_t)w * 3 * ns;
@@ -282,7 +301,7 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
       for (int k = 0; k < 4; ++k) bq[k] = s_xquat[4 * b + k];
       for (int k = 0; k < 9; ++k) bm[k] = s_xmat[9 * b + k];
       local2global(xp, xm, bp, bq, bm, t_pos, t_quat);
-      for (int k = 0; k < 3; ++k) sx[3 * g + k] = xp[k];
+      for (int k = 0; k < 3; ++k) sx[3 * g + k] = xp[k] + org[k];
       for (int k = 0; k < 9; ++k) sm[9 * g + k] = xm[k];
     }
     const float *spos = MF(site_pos), *squat = MF(site_quat);
@@ -293,18 +312,19 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
       for (int k = 0; k < 4; ++k) { bq[k] = s_xquat[4 * b + k]; iq[k] = squat[4 * g + k]; }
       for (int k = 0; k < 9; ++k) bm[k] = s_xmat[9 * b + k];
       local2global(xp, xm, bp, bq, bm, ip, iq);
-      for (int k = 0; k < 3; ++k) sx[3 * g + k] = xp[k];
+      for (int k = 0; k < 3; ++k) sx[3 * g + k] = xp[k] + org[k];
       for (int k = 0; k < 9; ++k) sm[9 * g + k] = xm[k];
     }
   }
   __syncthreads();
   PROF_MARK(1);
-  lds_to_global(d.xpos + (size_t)w * 3 * nb, s_xpos, 3 * nb, lane);
+  lds3_to_global_org(d.xpos + (size_t)w * 3 * nb, s_xpos, 3 * nb, lane, org);
   lds_to_global(d.xquat + (size_t)w * 4 * nb, s_xquat, 4 * nb, lane);
   lds_to_global(d.xmat + (size_t)w * 9 * nb, s_xmat, 9 * nb, lane);
-  lds_to_global(d.xipos + (size_t)w * 3 * nb, s_xipos, 3 * nb, lane);
+  lds3_to_global_org(d.xipos + (size_t)w * 3 * nb, s_xipos, 3 * nb, lane, org);
+  lds_to_global(d.xipos_rel + (size_t)w * 3 * nb, s_xipos, 3 * nb, lane);
   lds_to_global(d.ximat + (size_t)w * 9 * nb, s_ximat, 9 * nb, lane);
-  lds_to_global(d.xanchor + (size_t)w * 3 * nj, s_xanchor, 3 * nj, lane);
+  lds3_to_global_org(d.xanchor + (size_t)w * 3 * nj, s_xanchor, 3 * nj, lane, org);
   lds_to_global(d.xaxis + (size_t)w * 3 * nj, s_xaxis, 3 * nj, lane);
 
   PROF_MARK(2);
@@ -320,16 +340,22 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
     if (it >= 3 * nb) continue;
     const int b = bq_, c = it - 3 * b, e = b + snum;
     // four independent partial sums: the LDS reads of a group are in flight together
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
     int j = b;
     for (; j + 3 < e; j += 4) {
       a0 += s_mass[j] * s_xipos[3 * j + c];
       a1 += s_mass[j + 1] * s_xipos[3 * j + 3 + c];
       a2 += s_mass[j + 2] * s_xipos[3 * j + 6 + c];
       a3 += s_mass[j + 3] * s_xipos[3 * j + 9 + c];
+      m0 += s_mass[j]; m1 += s_mass[j + 1]; m2 += s_mass[j + 2]; m3 += s_mass[j + 3];
     }
-    for (; j < e; ++j) a0 += s_mass[j] * s_xipos[3 * j + c];
-    const float acc = (a0 + a1) + (a2 + a3);
+    for (; j < e; ++j) { a0 += s_mass[j] * s_xipos[3 * j + c]; m0 += s_mass[j]; }
+    float acc = (a0 + a1) + (a2 + a3);
+    // mj_comPos divides the mass-weighted sum of WORLD positions by body_subtreemass.  With positions in the local frame that
+    // is the same number only if body_subtreemass is the sum of the masses; a model whose body_mass was randomised per world
+    // without it (randomize_field writes one field) keeps MuJoCo's value through the missing term org (sum m - subtreemass)
+    const float msum = (m0 + m1) + (m2 + m3), oc = c == 0 ? org[0] : (c == 1 ? org[1] : org[2]);
+    if (fabsf(msum - sm_) > 2e-5f * sm_) acc += oc * (msum - sm_);
     s_sub[it] = sm_ < MINVAL ? s_xipos[it] : acc / sm_;
   }
   __syncthreads();
@@ -385,7 +411,8 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
   }
   __syncthreads();
   PROF_MARK(3);
-  lds_to_global(d.subtree_com + (size_t)w * 3 * nb, s_sub, 3 * nb, lane);
+  lds3_to_global_org(d.subtree_com + (size_t)w * 3 * nb, s_sub, 3 * nb, lane, org);
+  lds_to_global(d.subtree_crel + (size_t)w * 3 * nb, s_sub, 3 * nb, lane);
   lds_to_global(d.cinert + (size_t)w * 10 * nb, s_cinert, 10 * nb, lane);
   lds_to_global(d.cdof + (size_t)w * 6 * nv, s_cdof, 6 * nv, lane);
 

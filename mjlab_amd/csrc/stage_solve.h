@@ -390,36 +390,62 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
   return 0.f;
 }
 
-// mujoco_warp's parallel line search (MJLAB_OPT_LS_PARALLEL, include/mjlab_fields.h): cost at `lsmax` log-spaced step sizes in
-// [min_step, 1], the lowest cost wins (the first one on ties).  Only the cost is needed: one wave reduction per candidate.
-template <int NVP, bool FL>
-__device__ __forceinline__ float ls_cost(const SolveCtx<NVP>& c, float alpha) {
-  float cost = 0.f;
-  if (c.lj0 + alpha * c.ljv < 0.f) cost = alpha * alpha * c.lq2 + alpha * c.lq1 + c.lq0;
-  if (c.nefc > 64 && c.mj0 + alpha * c.mjv < 0.f) cost += alpha * alpha * c.mq2 + alpha * c.mq1 + c.mq0;
-  if (FL && c.lane < c.nf) {
-    const int r = c.lane;
-    const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r], fl = c.s_fl[r], rf = fl / Dr;
-    const float x = j0 + alpha * jv;
-    if (x <= -rf) cost += fl * (-0.5f * rf - j0) - alpha * fl * jv;
-    else if (x >= rf) cost += fl * (-0.5f * rf + j0) + alpha * fl * jv;
-    else cost += alpha * alpha * (0.5f * Dr * jv * jv) + alpha * (Dr * j0 * jv) + 0.5f * Dr * j0 * j0;
-  }
-  for (int r = c.lane + 128; r < c.nefc; r += 64) {
-    const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r];
-    if (j0 + alpha * jv < 0.f) cost += alpha * alpha * (0.5f * Dr * jv * jv) + alpha * (Dr * j0 * jv) + 0.5f * Dr * j0 * j0;
-  }
-  return wave_sum(cost) + alpha * alpha * c.quad_gauss[2] + alpha * c.quad_gauss[1] + c.quad_gauss[0];
-}
+#ifndef MJLAB_LSP_U
+#define MJLAB_LSP_U 4
+#endif
+// mujoco_warp's parallel line search (MJLAB_OPT_LS_PARALLEL, include/mjlab_fields.h): the cost at `lsmax` log-spaced step sizes in
+// [min_step, 1], the lowest cost wins (the first one on ties).  LANES ARE CANDIDATES: lane c + lsmax g evaluates step size c over
+// the rows g, g + G, g + 2 G, ... (G = up to 4 row groups, as many as fit in the wave), reading the per-row arrays from LDS -- all
+// lanes of a group read the same address (a broadcast), so one trip over the rows prices every candidate at once: ~4 VALU + 3 LDS
+// instructions per row trip instead of one wave reduction per candidate (20 of them for the reference's ls_iterations).
 template <int NVP, bool FL>
 __device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsmax) {
-  ls_prepare<NVP, FL>(c);
+  const int nc = lsmax < 64 ? (lsmax > 1 ? lsmax : 1) : 64;  // candidates per pass over the rows
+  const int G = 1 + (2 * nc <= 64) + (3 * nc <= 64) + (4 * nc <= 64);  // min(4, 64 / nc) without an integer division
   const float lo = logf(min_step), step = (0.f - lo) / (float)(lsmax > 1 ? lsmax - 1 : 1);
+  const int g = (c.lane >= nc) + (c.lane >= 2 * nc) + (c.lane >= 3 * nc) + (c.lane >= 4 * nc), cnd = c.lane - g * nc;
+  const bool valid = g < G;
+  const lds_f32 *s_jar = (const lds_f32*)c.s_jar, *s_jv = (const lds_f32*)c.s_jv, *s_D = (const lds_f32*)c.s_D, *s_fl = (const lds_f32*)c.s_fl;
   float best_alpha = 0.f, best_cost = 0.f;
-  for (int i = 0; i < lsmax; ++i) {
-    const float alpha = expf(lo + (float)i * step);
-    const float cost = ls_cost<NVP, FL>(c, alpha);
-    if (i == 0 || cost < best_cost) { best_cost = cost; best_alpha = alpha; }
+  bool have = false;
+  for (int c0 = 0; c0 < lsmax; c0 += nc) {  // one trip for lsmax <= 64
+    const int ci = c0 + cnd;
+    const float alpha = expf(lo + (float)ci * step);
+    float acc = 0.f;
+    constexpr int U = MJLAB_LSP_U;  // row trips in flight (their LDS reads are issued together)
+    for (int r0 = 0; r0 < c.nefc; r0 += U * G) {
+      float j0[U], jv[U], Dr[U], fl[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + u * G + g;
+        const bool on = valid && r < c.nefc;
+        const int rr = on ? r : 0;
+        j0[u] = s_jar[rr]; jv[u] = s_jv[rr];
+        Dr[u] = s_D[rr] * (on ? 1.f : 0.f);
+        if (FL) fl[u] = (on && r < c.nf) ? s_fl[r] : -1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float x = fmaf(alpha, jv[u], j0[u]);
+        const float xm = fminf(x, 0.f);
+        float t = Dr[u] * xm * xm;
+        if (FL && fl[u] >= 0.f) {  // friction loss (mj PrimalEval): Huber cost, linear beyond |x| = f / D
+          const float rf = fl[u] / Dr[u], ax = fabsf(x);
+          t = ax >= rf ? 2.f * fl[u] * (ax - 0.5f * rf) : Dr[u] * x * x;
+        }
+        acc += t;
+      }
+    }
+    {  // lanes of group 0 collect their candidate's row groups (from the partial sums as they stand: the shuffles wrap around)
+      const float part = acc;
+      for (int k = 1; k < G; ++k) acc += __shfl(part, c.lane + k * nc);
+    }
+    float cost = 0.5f * acc + alpha * alpha * c.quad_gauss[2] + alpha * c.quad_gauss[1] + c.quad_gauss[0];
+    if (!(g == 0 && ci < lsmax)) cost = 3.0e38f;
+    const float cmin = wave_min(cost);
+    const unsigned long long hit = __ballot(cost == cmin && g == 0 && ci < lsmax);
+    const int first = hit ? (int)__builtin_ctzll(hit) : 0;  // lane = candidate index within this trip: the first one on ties
+    if (hit && (!have || cmin < best_cost)) { best_cost = cmin; best_alpha = lane_bcast_dyn(alpha, first); have = true; }
   }
   c.ls_iter = lsmax;
   return best_alpha;

@@ -179,8 +179,8 @@ __device__ __forceinline__ void stage_velocity(const Model& m, const Data& d, co
     float smooth = passive - bias + v_applied + s_qact[i];
     if (xmask) {
       const float* xfrc = d.xfrc_applied + (size_t)w * 6 * nb;
-      const float* xipos = d.xipos + (size_t)w * 3 * nb;
-      const float* sub = d.subtree_com + (size_t)w * 3 * nb;
+      const float* xipos = d.xipos_rel + (size_t)w * 3 * nb;  // both in the world's local frame
+      const float* sub = d.subtree_crel + (size_t)w * 3 * nb;
       for (int b = 1; b < nb; ++b) {
         if (!((xmask >> b) & 1ull) || !dof_in_chain(m, b, i)) continue;
         float f[6];

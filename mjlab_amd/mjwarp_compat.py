@@ -127,7 +127,10 @@ def _static_geoms(m: Model, d: Data) -> None:
     return
   keep, keep_s = m.struct.size.nstaticgeom, m.struct.size.nstaticsite
   m.struct.size.nstaticgeom = m.struct.size.nstaticsite = 0
+  flags = m.struct.opt.flags
+  m.struct.opt.flags = flags | _abi.OPT_WORLD_FRAME  # stored world poses must not depend on where the robots are right now
   native.check(native.lib().mjlab_forward_stages(ctypes.byref(m.struct), ctypes.byref(d.struct), native.STAGE_POSITION, _stream(d)), "mjlab_forward_stages")
+  m.struct.opt.flags = flags
   m.struct.size.nstaticgeom, m.struct.size.nstaticsite = keep, keep_s
   d._static_done = True
 

@@ -82,6 +82,11 @@ class SimulationCfg:
   # MJLAB_LS_PARALLEL=0|1 overrides the configuration (the parity suites pin the exact search with it: tests/conftest.py)
   ls_parallel: bool = True
   ls_parallel_min_step: float = 1.0e-6  # mujoco_warp Option.ls_parallel_min_step (not a field of the reference's cfg)
+  # True: the stages compute positions in each world's local frame (origin = the floating base's position rounded to whole
+  # metres: include/mjlab_fields.h, xorigin) and add the origin back in the public world-frame arrays -- a robot 100 m from
+  # the origin (most of the reference's 4096 environments) is solved as accurately as one at the origin.  False: plain fp32
+  # world coordinates, like the reference's engine (MJLAB_OPT_WORLD_FRAME)
+  local_frame: bool = True
   mujoco: MujocoCfg = field(default_factory=MujocoCfg)
   nan_guard: NanGuardCfg = field(default_factory=NanGuardCfg)
   use_graph: bool = True
@@ -212,6 +217,7 @@ class Simulation:
                          | (_abi.OPT_LITERAL_TERMINATION if opt("literal_termination") else 0)
                          | (_abi.OPT_WARMSTART_AT_ADVANCE if opt("warmstart_at_advance") else 0)
                          | (_abi.OPT_LS_PARALLEL if self.ls_parallel else 0)
+                         | (0 if (opt("local_frame") and os.environ.get("MJLAB_LOCAL_FRAME", "1") != "0") else _abi.OPT_WORLD_FRAME)
                          | {"stage": 0, "presolve": _abi.OPT_FUSE_PRESOLVE, "step": _abi.OPT_FUSE_STEP}[opt("fuse")])
     self._d, self._data = device_state.alloc_data(model, num_envs, self.nconmax, self.njmax, dev)
 
@@ -234,8 +240,13 @@ class Simulation:
     # populate derived fields like mjwarp.put_data does from mj_forward; this first pass also
     # writes the poses of the static geoms (world / terrain bodies), which later passes skip
     self._m.size.nstaticgeom = self._m.size.nstaticsite = 0
+    flags = self._m.opt.flags
+    self._m.opt.flags = flags | _abi.OPT_WORLD_FRAME  # stored world poses must not depend on where the robots are right now
     self.forward()
+    self._m.opt.flags = flags
     self._m.size.nstaticgeom, self._m.size.nstaticsite = int(model.nstaticgeom), int(model.nstaticsite)
+    if not (flags & _abi.OPT_WORLD_FRAME):
+      self.forward()  # the same state in the local frame (xorigin, the hand-over arrays)
     self.create_graph()
     # pay the one-time start-up cost of the device ops of update_priority_thresholds() here, outside any timed loop; the
     # thresholds themselves stay unset (all worlds are identical at this point): the kernels' row-count classes apply

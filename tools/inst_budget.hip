@@ -70,11 +70,9 @@ KB(kb_lseval) {
   LsPnt p; ls_eval<N, false>(c, &p, c.quad_gauss[1]);
   a.out[threadIdx.x] = p.cost + p.d0 + p.d1 + c.quad_gauss[0] + c.s_jar[threadIdx.x];
 }
-KB(kb_lscost) {
+KB(kb_lspar) {  // the whole parallel (grid) line search: 20 candidates priced in one trip over the rows
   SMEM; SolveCtx<N> c = make_ctx(a, smem);
-  c.lj0 = c.s_jar[threadIdx.x]; c.ljv = c.s_jv[threadIdx.x]; c.lq0 = c.s_D[threadIdx.x]; c.lq1 = c.s_fl[threadIdx.x]; c.lq2 = c.s_ff[threadIdx.x];
-  c.mj0 = c.s_jar[threadIdx.x + 64]; c.mjv = c.s_jv[threadIdx.x + 64]; c.mq0 = c.s_D[threadIdx.x + 64]; c.mq1 = c.s_fl[threadIdx.x + 1]; c.mq2 = c.s_ff[threadIdx.x + 1];
-  a.out[threadIdx.x] = ls_cost<N, false>(c, c.quad_gauss[1]) + c.quad_gauss[0] + c.s_jar[threadIdx.x];
+  a.out[threadIdx.x] = line_search_parallel<N, false>(c, c.quad_gauss[1], a.nact) + c.quad_gauss[0] + c.s_jar[threadIdx.x];
 }
 KB(kb_loadM) {
   SMEM; SolveCtx<N> c = make_ctx(a, smem);
