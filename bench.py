@@ -35,7 +35,7 @@ sys.path.insert(0, str(ROOT))
 
 from mjlab_amd import dist as mdist  # noqa: E402
 from mjlab_amd import native, robots  # noqa: E402
-from mjlab_amd.rollout import VELOCITY_TASK_EVENTS, PhysicsRollout, g1_action_scale, go1_action_scale  # noqa: E402
+from mjlab_amd.rollout import TRACKING_TASK_EVENTS, VELOCITY_TASK_EVENTS, PhysicsRollout, g1_action_scale, go1_action_scale, synthetic_motion  # noqa: E402
 from mjlab_amd.sim import Simulation, SimulationCfg  # noqa: E402
 
 # compulsory HBM traffic of the public mjData contract, fp32
@@ -144,10 +144,13 @@ def main() -> None:
   sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), use_graph=not args.no_graph, fold_forward=not args.no_fold, fuse=args.fuse), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else go1_action_scale(model)
   robot = "g1" if args.scene.startswith("g1") else "go1"
-  events = {} if args.no_task_events else VELOCITY_TASK_EVENTS[robot]
+  tracking = "tracking" in args.scene
+  events = {} if args.no_task_events else dict((TRACKING_TASK_EVENTS if tracking else VELOCITY_TASK_EVENTS)[robot])
+  if "motion_reset" in events:  # BASELINE config 4: resets to a random phase of a (synthetic) motion, the task's own terminations and events
+    events["motion"] = synthetic_motion(model)
   roll = PhysicsRollout(sim, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info),
                         masked_forward=args.masked_forward, fused_reset=not args.torch_reset,
-                        min_height=0.3 if robot == "g1" else 0.15, substeps_per_call=args.substeps_per_call,
+                        min_height=-1.0e9 if "motion" in events else (0.3 if robot == "g1" else 0.15), substeps_per_call=args.substeps_per_call,
                         control_kernel=not args.no_control_kernel and args.fuse == "step" and not args.torch_reset, **events)
   if args.readback and roll.control_kernel:
     from mjlab_amd.entity_data import EntityReadback
@@ -404,13 +407,14 @@ def main() -> None:
       "scaling": "weak",
       "vs_baseline": None,
       "dtype": "f32",
-      "data": "synthetic (random actions, keyframe resets"
+      "data": "synthetic (random actions, " + ("resets to random phases of a synthetic 10 s motion (SURVEY 8d(4)) with the task's pose / velocity / joint noise" if "motion" in events else "keyframe resets")
       + ("" if args.no_task_events else ", per-env foot friction U(0.3,1.2), velocity pushes every U(1,3) s") + "; compiled model from the reference MJCF)",
       "config": {
         "workload": f"{args.scene}: {args.envs_per_gpu} envs/GPU, timestep 0.005, decimation 4, Newton 10 it / 20 ls "
         + ("(ls_parallel: mujoco_warp's grid search, the reference's setting)" if sim.ls_parallel else "(exact iterative line search; ls_parallel off)")
         + ", implicitfast, pyramidal, njmax 300"
-        + ("" if args.no_task_events else "; task events: DR friction (per-env geom_friction), pushes, bad_orientation 70 deg termination"),
+        + ("" if args.no_task_events else ("; task events: DR friction / torso com / joint zero offsets, 6-component pushes, motion-phase resets, anchor height / orientation terminations, 10 s episodes"
+                                           if "motion" in events else "; task events: DR friction (per-env geom_friction), pushes, bad_orientation 70 deg termination")),
         "global_envs": n_env,
         "parallelism": f"env-sharded x{info.world_size}" + (" + RCCL action scatter and obs gather to the learner (rank 0) every control step" if exchange else ""),
         "graph": "one hipGraph per control step" if step_graph else ("per-call step/forward hipGraphs" if sim.use_graph else "none"),

@@ -159,6 +159,36 @@ int mjlab_interval_push(const mjlab_model_t* m, const mjlab_data_t* d, float* ti
  *   readback_on:      the fused EntityData read-back (mjlab_entity_readback) of the forwarded state
  *   push_time_left != NULL: the interval push, the arguments and semantics of mjlab_interval_push
  * Results are bit-identical to the same sequence of separate calls. */
+/* Extension: the TRACKING task's reset and terminations inside the control step (reference tasks/tracking/mdp/commands.py:299-369
+ * MotionCommand._resample_command / _update_command, terminations.py:27-53 bad_anchor_pos_z_only / bad_anchor_ori), so that
+ * BASELINE config 4 runs under its own reset distribution without ~90 small torch launches per control step.  Motion tables as
+ * the reference's MotionLoader holds them (commands.py:30-65), for the ANCHOR body = the floating base.  Per world, at the
+ * reset phase of mjlab_control_step:
+ *   t = time_steps[w]; frame f = min(t, nframe - 1);
+ *   terminate when |qpos[2] - (root_pos[f].z + env_origin.z)| > dz  or  |up_z(root) - up_z(root_quat[f])| > dup
+ *   (up_z(q) = 1 - 2 (qx^2 + qy^2)), or when the motion has ended (t + 1 >= nframe), besides the usual tests;
+ *   on reset, from the uniforms rnd[w][0 .. 14 + nq - 7): bin = min(int(u0 * bins), bins - 1),
+ *     t' = int((bin + u1) / bins * (nframe - 1))                      (uniform over the adaptive sampler's bins: nothing has failed)
+ *     root position  = root_pos[t'] + env_origin + U(pose_lo[0..3), pose_hi[0..3))
+ *     root quaternion = quat_from_euler_xyz(U(pose[3..6))) * root_quat[t']
+ *     root velocity  = root_lin_vel[t'] + U(vel[0..3)),  body-frame angular velocity = R(root quaternion)^T (root_ang_vel[t'] + U(vel[3..6)))
+ *     joints         = clip(joint_pos[t'] + U(joint_lo, joint_hi), soft_limits), joint velocities = joint_vel[t']
+ *     qacc_warmstart = 0, time_steps[w] = t'; otherwise time_steps[w] = t + 1. */
+typedef struct mjlab_motion_reset {
+  const float* joint_pos;    /* (nframe, nq - 7) */
+  const float* joint_vel;    /* (nframe, nv - 6) */
+  const float* root_pos;     /* (nframe, 3) */
+  const float* root_quat;    /* (nframe, 4) w x y z */
+  const float* root_lin_vel; /* (nframe, 3) world frame */
+  const float* root_ang_vel; /* (nframe, 3) world frame */
+  const float* soft_limits;  /* (nq - 7, 2) lower, upper (+-inf for unlimited joints) */
+  const float* rnd;          /* (nworld, 14 + nq - 7) uniforms in [0, 1), refreshed by the host before every control step */
+  int* time_steps;           /* (nworld) */
+  int nframe, bins;
+  float pose_lo[6], pose_hi[6], vel_lo[6], vel_hi[6];
+  float joint_lo, joint_hi, dz, dup;
+} mjlab_motion_reset_t;
+
 typedef struct mjlab_control {
   int nsubstep, forward_mode, max_len, pad_;
   const float* action;        /* (nworld, nu) or NULL */
@@ -178,6 +208,19 @@ typedef struct mjlab_control {
   int readback_on, pad2_;       /* non-zero: mjlab_entity_readback's outputs are refreshed by the same launch, right after the
                                    forward() pass ("emitted by the step kernel's epilogue") */
   mjlab_entity_view_t readback; /* by value: the view's pointers are device pointers */
+  /* Task-provided reset states and a reference-relative termination: what the TRACKING task's reset does (reference
+   * tasks/tracking/mdp/commands.py:299-363: MotionCommand._resample_command writes a motion frame plus noise through
+   * write_joint_state_to_sim / write_root_state_to_sim; terminations.py:27-53 bad_anchor_pos_z_only / bad_anchor_ori).
+   *   reset_qpos != NULL: a world that resets copies row w of reset_qpos (nworld, nq) and reset_qvel (nworld, nv) instead of
+   *                       the key_qpos + rnd3 rule; the host refreshes EVERY row before each control step (no host sync:
+   *                       which worlds reset is decided here).  key_qpos must still be non-NULL (it switches the phase on).
+   *   term_ref != NULL:   row w = [reference height, reference world-z of the root's up axis]; the world also terminates
+   *                       when |qpos[2] - term_ref[2 w]| > term_dz or |up_z - term_ref[2 w + 1]| > term_dup */
+  const float* reset_qpos;
+  const float* reset_qvel;
+  const float* term_ref;
+  float term_dz, term_dup;
+  const mjlab_motion_reset_t* motion; /* DEVICE pointer to the struct above, or NULL (then reset_qpos / key_qpos apply) */
 } mjlab_control_t;
 int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, void* stream);
 int mjlab_sizeof_control(void); /* sizeof(mjlab_control_t), for bindings that mirror the struct */

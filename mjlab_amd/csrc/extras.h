@@ -98,7 +98,9 @@ __device__ __forceinline__ float nan_to_num_dev(float x) {
 // Returns the (wave-uniform) reset decision of world w.
 __device__ __forceinline__ bool masked_reset_world(const Model& m, const Data& d, const int w, const int lane, const float* key_qpos, const float* rnd3,
                                                    int* episode_length, const int max_len, const float min_height, int* reset_mask,
-                                                   const float* env_origins, const float min_up_z) {
+                                                   const float* env_origins, const float min_up_z, const float* reset_qpos = nullptr,
+                                                   const float* reset_qvel = nullptr, const float* term_ref = nullptr, const float term_dz = 0.f,
+                                                   const float term_dup = 0.f, const mjlab_motion_reset_t* mo = nullptr) {
   const int nq = m.size.nq, nv = m.size.nv;
   const bool has_free = m.size.njnt > 0 && m.jnt_type[0] == MJLAB_JNT_FREE;
   float* qpos = d.qpos + (size_t)w * nq;
@@ -115,10 +117,63 @@ __device__ __forceinline__ bool masked_reset_world(const Model& m, const Data& d
     for (int k = 0; k < 3; ++k) org[k] = env_origins[3 * w + k];
   // world z of the root's up axis = 1 - 2 (qx^2 + qy^2): the bad-orientation test of the
   // reference (envs/mdp/terminations.py bad_orientation: projected gravity vs a limit angle)
-  const bool fell = has_free && (qpos[2] - org[2] < min_height || 1.f - 2.f * (qpos[4] * qpos[4] + qpos[5] * qpos[5]) < min_up_z);
+  bool fell = has_free && (qpos[2] - org[2] < min_height || 1.f - 2.f * (qpos[4] * qpos[4] + qpos[5] * qpos[5]) < min_up_z);
+  if (has_free && term_ref) {  // the tracking task's anchor tests against the motion frame of this world's phase
+    const float up_z = 1.f - 2.f * (qpos[4] * qpos[4] + qpos[5] * qpos[5]);
+    fell |= fabsf(qpos[2] - term_ref[2 * w]) > term_dz || fabsf(up_z - term_ref[2 * w + 1]) > term_dup;
+  }
+  int mo_t = 0;
+  if (has_free && mo) {  // the tracking task's anchor tests against the motion frame of this world's phase (mjlab_motion_reset_t)
+    mo_t = mo->time_steps[w];
+    const int f = mo_t < mo->nframe - 1 ? mo_t : mo->nframe - 1;
+    const float* rq = mo->root_quat + 4 * f;
+    // products and sums rounded one by one, like the chain of torch ops this replaces (same decisions bit for bit)
+    const float ref_up = __fsub_rn(1.f, __fmul_rn(2.f, __fadd_rn(__fmul_rn(rq[1], rq[1]), __fmul_rn(rq[2], rq[2]))));
+    const float up_z = __fsub_rn(1.f, __fmul_rn(2.f, __fadd_rn(__fmul_rn(qpos[4], qpos[4]), __fmul_rn(qpos[5], qpos[5]))));
+    const float ref_z = __fadd_rn(mo->root_pos[3 * f + 2], org[2]);
+    fell |= fabsf(__fsub_rn(qpos[2], ref_z)) > mo->dz || fabsf(__fsub_rn(up_z, ref_up)) > mo->dup || mo_t + 1 >= mo->nframe;
+  }
   const bool reset = __ballot(bad) != 0ull || fell || elen >= max_len;
   __syncthreads();  // every lane has read qpos[2..5] before any lane overwrites them
-  if (reset) {
+  if (reset && has_free && mo) {
+    const int nj = nq - 7;
+    const float* u = mo->rnd + (size_t)w * (14 + nj);
+    int bin = (int)(u[0] * (float)mo->bins);
+    bin = bin < mo->bins - 1 ? bin : mo->bins - 1;
+    const int tn = (int)(((float)bin + u[1]) / (float)mo->bins * (float)(mo->nframe - 1));
+    float pose[6], vel[6];
+    for (int k = 0; k < 6; ++k) {
+      pose[k] = mo->pose_lo[k] + (mo->pose_hi[k] - mo->pose_lo[k]) * u[2 + k];
+      vel[k] = mo->vel_lo[k] + (mo->vel_hi[k] - mo->vel_lo[k]) * u[8 + k];
+    }
+    float sr, cr, sp, cp, sy, cy;
+    sincosf(0.5f * pose[3], &sr, &cr);
+    sincosf(0.5f * pose[4], &sp, &cp);
+    sincosf(0.5f * pose[5], &sy, &cy);
+    const float dq[4] = {cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp};
+    float q[4], wb[3], wv[3];
+    mul_quat(q, dq, mo->root_quat + 4 * tn);
+    for (int k = 0; k < 3; ++k) wv[k] = mo->root_ang_vel[3 * tn + k] + vel[3 + k];
+    quat_apply_dev(wb, q, wv, -1.f);
+    for (int i = lane; i < nq; i += 64) {
+      float x;
+      if (i < 3) x = mo->root_pos[3 * tn + i] + pose[i] + org[i];
+      else if (i < 7) x = q[i - 3];
+      else {
+        x = mo->joint_pos[(size_t)tn * nj + (i - 7)] + mo->joint_lo + (mo->joint_hi - mo->joint_lo) * u[14 + (i - 7)];
+        x = fminf(fmaxf(x, mo->soft_limits[2 * (i - 7)]), mo->soft_limits[2 * (i - 7) + 1]);
+      }
+      qpos[i] = x;
+    }
+    for (int i = lane; i < nv; i += 64) {
+      qvel[i] = i < 3 ? mo->root_lin_vel[3 * tn + i] + vel[i] : (i < 6 ? wb[i - 3] : mo->joint_vel[(size_t)tn * (nv - 6) + (i - 6)]);
+      ws[i] = 0.f;
+    }
+    if (lane == 0) mo->time_steps[w] = tn;
+  } else if (reset && reset_qpos) {  // the task's own reset state for this world (write_root_state / write_joint_state rows)
+    for (int i = lane; i < nq; i += 64) qpos[i] = reset_qpos[(size_t)w * nq + i];
+    for (int i = lane; i < nv; i += 64) { qvel[i] = reset_qvel[(size_t)w * nv + i]; ws[i] = 0.f; }
+  } else if (reset) {
     for (int i = lane; i < nq; i += 64) {
       float x = key_qpos[i];
       if (has_free) {
@@ -138,6 +193,7 @@ __device__ __forceinline__ bool masked_reset_world(const Model& m, const Data& d
   if (lane == 0) {
     episode_length[w] = reset ? 0 : elen;
     reset_mask[w] = reset ? 1 : 0;
+    if (has_free && mo && !reset) mo->time_steps[w] = mo_t + 1;
   }
   return reset;
 }

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(64, MJLAB_WPE) void k_control_step(const Model m_, 
   if (c.action) {
     FUSED_ARGS;
     const int nu = m.size.nu;
-    for (int a = lane; a < nu; a += 64) d.ctrl[(size_t)w * nu + a] = c.action_offset[a] + c.action_scale[a] * c.action[(size_t)w * nu + a];
+    // product and sum rounded separately (no FMA contraction): bit-identical to the torch expression offset + scale * action
+    for (int a = lane; a < nu; a += 64) d.ctrl[(size_t)w * nu + a] = __fadd_rn(c.action_offset[a], __fmul_rn(c.action_scale[a], c.action[(size_t)w * nu + a]));
     __syncthreads();
   }
   // ONE copy of the stage code: passes 0 .. nsubstep-1 are the physics steps, pass nsubstep is forward()
@@ -182,7 +183,8 @@ __global__ __launch_bounds__(64, MJLAB_WPE) void k_control_step(const Model m_, 
     if (fwd) {
       if (c.key_qpos) {
         FUSED_ARGS;
-        reset = masked_reset_world(m, d, w, lane, c.key_qpos, c.rnd3, c.episode_length, c.max_len, c.min_height, c.reset_mask, c.env_origins, c.min_up_z);
+        reset = masked_reset_world(m, d, w, lane, c.key_qpos, c.rnd3, c.episode_length, c.max_len, c.min_height, c.reset_mask, c.env_origins, c.min_up_z,
+                                   c.reset_qpos, c.reset_qvel, c.term_ref, c.term_dz, c.term_dup, c.motion);
         __syncthreads();
       }
       if (!(c.forward_mode == 1 || (c.forward_mode == 2 && reset))) break;

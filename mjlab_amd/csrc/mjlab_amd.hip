@@ -182,6 +182,9 @@ int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjla
   if (!c || c->nsubstep < 0) return fail(-20, "control_step: bad argument");
   if (c->action && (!c->action_offset || !c->action_scale)) return fail(-20, "control_step: action without offset / scale");
   if (c->key_qpos && (!c->rnd3 || !c->episode_length || !c->reset_mask)) return fail(-15, "control_step: reset arguments missing");
+  if ((c->reset_qpos != nullptr) != (c->reset_qvel != nullptr)) return fail(-15, "control_step: reset_qpos and reset_qvel come together");
+  if (c->motion && (m->size.nq < 7 || m->size.nv < 6)) return fail(-15, "control_step: motion resets need a floating base");
+  if ((c->reset_qpos || c->term_ref || c->motion) && !c->key_qpos) return fail(-15, "control_step: reset_qpos / term_ref need the reset phase (key_qpos)");
   if (c->push_time_left && (!c->rnd7 || m->size.nq < 7 || m->size.nv < 6)) return fail(-17, "control_step: push needs rnd7 and a free root joint");
   if (c->forward_mode < 0 || c->forward_mode > 2) return fail(-20, "control_step: forward_mode must be 0, 1 or 2");
   hipStream_t st = (hipStream_t)stream;

@@ -30,6 +30,18 @@ class _PushRange(ctypes.Structure):
   _fields_ = [("lo", ctypes.c_float * 6), ("hi", ctypes.c_float * 6)]
 
 
+class _MotionReset(ctypes.Structure):
+  """mjlab_motion_reset_t (include/mjlab_amd.h)."""
+
+  _fields_ = [
+    ("joint_pos", ctypes.c_void_p), ("joint_vel", ctypes.c_void_p), ("root_pos", ctypes.c_void_p), ("root_quat", ctypes.c_void_p),
+    ("root_lin_vel", ctypes.c_void_p), ("root_ang_vel", ctypes.c_void_p), ("soft_limits", ctypes.c_void_p), ("rnd", ctypes.c_void_p),
+    ("time_steps", ctypes.c_void_p), ("nframe", ctypes.c_int), ("bins", ctypes.c_int),
+    ("pose_lo", ctypes.c_float * 6), ("pose_hi", ctypes.c_float * 6), ("vel_lo", ctypes.c_float * 6), ("vel_hi", ctypes.c_float * 6),
+    ("joint_lo", ctypes.c_float), ("joint_hi", ctypes.c_float), ("dz", ctypes.c_float), ("dup", ctypes.c_float),
+  ]  # fmt: skip
+
+
 class _Control(ctypes.Structure):
   """mjlab_control_t (include/mjlab_amd.h)."""
 
@@ -41,6 +53,8 @@ class _Control(ctypes.Structure):
     ("min_height", ctypes.c_float), ("min_up_z", ctypes.c_float), ("push_dt", ctypes.c_float),
     ("push_interval_lo", ctypes.c_float), ("push_interval_hi", ctypes.c_float), ("push_range", _PushRange),
     ("readback_on", ctypes.c_int), ("pad2_", ctypes.c_int), ("readback", _entity_view_struct()),
+    ("reset_qpos", ctypes.c_void_p), ("reset_qvel", ctypes.c_void_p), ("term_ref", ctypes.c_void_p), ("term_dz", ctypes.c_float), ("term_dup", ctypes.c_float),
+    ("motion", ctypes.c_void_p),
   ]  # fmt: skip
 
 
@@ -56,13 +70,81 @@ VELOCITY_TASK_EVENTS = {
 }  # fmt: skip
 
 
+# The tracking task's events that touch the physics state or model (reference src/mjlab/tasks/tracking/tracking_env_cfg.py:29-36,
+# 58-76,154-199,256-283,306 and config/g1/flat_env_cfg.py): resets to a random phase of the motion (MotionCommand._resample_command,
+# mdp/commands.py:299-363) with the cfg's pose / velocity / joint noise, a 6-component root-velocity kick every U(1, 3) s, startup
+# randomisation of foot friction, torso com and joint zero offsets, termination when the anchor leaves the motion frame
+# (|z error| > 0.25 m, |projected-gravity z error| > 0.8), 10 s episodes.
+TRACKING_TASK_EVENTS = {
+  "g1": {
+    "friction_range": (0.3, 1.2), "friction_geoms": r"(left|right)_foot[1-7]_collision$",
+    "push": {"interval_s": (1.0, 3.0), "velocity": {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "z": (-0.2, 0.2), "roll": (-0.52, 0.52), "pitch": (-0.52, 0.52), "yaw": (-0.78, 0.78)}},
+    "motion_reset": {
+      "pose_range": {"x": (-0.05, 0.05), "y": (-0.05, 0.05), "z": (-0.01, 0.01), "roll": (-0.1, 0.1), "pitch": (-0.1, 0.1), "yaw": (-0.2, 0.2)},
+      "velocity_range": {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "z": (-0.2, 0.2), "roll": (-0.52, 0.52), "pitch": (-0.52, 0.52), "yaw": (-0.78, 0.78)},
+      "joint_position_range": (-0.1, 0.1), "soft_joint_pos_limit_factor": 0.9, "anchor_dz": 0.25, "anchor_dup": 0.8,
+    },
+    "com_body": "torso_link", "com_ranges": ((-0.025, 0.025), (-0.05, 0.05), (-0.05, 0.05)), "qpos0_range": (-0.01, 0.01),
+    "episode_length_s": 10.0,
+  },
+}  # fmt: skip
+
+
+def synthetic_motion(model: Model, nframe: int = 500, fps: float = 50.0, amplitude: float = 0.2, freq_hz: float = 0.5, root_z: float = 0.76,
+                     seed: int = 0) -> dict[str, np.ndarray]:
+  """A stand-in for the tracking task's ``motion.npz`` (none is in the reference tree: SURVEY.md section 8d(4)): 10 s at 50 fps,
+  every joint sweeping +-0.2 rad at 0.5 Hz around the keyframe with its own phase, the pelvis held at z = 0.76 m, upright.
+  Keys follow the loader (reference tasks/tracking/mdp/commands.py:30-50) for the quantities a reset reads: ``joint_pos``,
+  ``joint_vel`` (T, nq - 7) and the anchor body's ``body_pos_w`` / ``body_quat_w`` / ``body_lin_vel_w`` / ``body_ang_vel_w`` (T, 1, .)
+  -- the anchor here is the floating base itself (the reference's G1 config anchors on the torso link, one waist chain away)."""
+  rng = np.random.default_rng(seed)
+  t = np.arange(nframe, dtype=np.float64) / fps
+  key = np.asarray(model.key_qpos[0] if model.nkey else model.qpos0, dtype=np.float64)
+  nj = model.nq - 7
+  phase = rng.uniform(0.0, 2.0 * np.pi, nj)
+  arg = 2.0 * np.pi * freq_hz * t[:, None] + phase[None, :]
+  jp = key[7:][None, :] + amplitude * np.sin(arg)
+  jv = amplitude * 2.0 * np.pi * freq_hz * np.cos(arg)
+  hinge = [j for j in range(model.njnt) if model.jnt_type[j] != JNT_FREE]
+  lo, hi = np.asarray(model.jnt_range)[hinge, 0], np.asarray(model.jnt_range)[hinge, 1]
+  limited = np.asarray(model.jnt_limited)[hinge].astype(bool)
+  jp = np.where(limited[None, :], np.clip(jp, lo[None, :] + 0.02, hi[None, :] - 0.02), jp)
+  z = np.zeros((nframe, 1, 3))
+  pos = z.copy()
+  pos[:, 0, 2] = root_z
+  quat = np.zeros((nframe, 1, 4))
+  quat[:, 0, 0] = 1.0
+  return {"joint_pos": jp.astype(np.float32), "joint_vel": jv.astype(np.float32), "body_pos_w": pos.astype(np.float32),
+          "body_quat_w": quat.astype(np.float32), "body_lin_vel_w": z.astype(np.float32), "body_ang_vel_w": z.astype(np.float32), "fps": np.float32(fps)}
+
+
+def _quat_from_euler_xyz(r: torch.Tensor, p: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+  """(w, x, y, z) of roll-pitch-yaw, the convention of the reference's quat_from_euler_xyz (isaaclab utils/math.py)."""
+  cr, sr, cp, sp, cy, sy = torch.cos(r * 0.5), torch.sin(r * 0.5), torch.cos(p * 0.5), torch.sin(p * 0.5), torch.cos(y * 0.5), torch.sin(y * 0.5)
+  return torch.stack([cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp], dim=-1)
+
+
+def _quat_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+  aw, ax, ay, az = a.unbind(-1)
+  bw, bx, by, bz = b.unbind(-1)
+  return torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                      aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], dim=-1)
+
+
+def _quat_apply_inverse(q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+  xyz = q[..., 1:]
+  t = torch.cross(xyz, v, dim=-1) * 2.0
+  return v - q[..., 0:1] * t + torch.cross(xyz, t, dim=-1)
+
+
 class PhysicsRollout:
   def __init__(self, sim: Simulation, action_scale: np.ndarray | float = 0.25, decimation: int = 4,
                episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0,
                masked_forward: bool = False, fused_reset: bool = True, min_up_z: float | None = None,
                max_init_terrain_level: int | None = 5, friction_range: tuple[float, float] | None = None,
                friction_geoms: str | None = None, push: dict | None = None, bad_orientation_deg: float | None = None,
-               substeps_per_call: int = 1, control_kernel: bool = False) -> None:
+               substeps_per_call: int = 1, control_kernel: bool = False, motion: dict | None = None, motion_reset: dict | None = None,
+               com_body: str | None = None, com_ranges: tuple | None = None, qpos0_range: tuple | None = None) -> None:
     m: Model = sim.host_model
     dev = sim.data.qpos.device
     self.sim, self.m, self.decimation = sim, m, decimation
@@ -126,6 +208,57 @@ class PhysicsRollout:
       sim.model.geom_friction[:, torch.from_numpy(gids).to(dev), 0] = vals
       sim.create_graph()  # pointers changed (the reference re-captures too: manager_based_rl_env.py:102-104)
       self.friction_geom_ids = gids
+    # startup events of the tracking task: torso com offset (randomize_field "add" on body_ipos), joint zero offsets (qpos0)
+    if com_body is not None:
+      b = next(i for i, name in enumerate(m.names["body"]) if name and name.split("/")[-1] == com_body)
+      sim.expand_model_fields(["body_ipos"])
+      r = torch.rand((n, 3), device=dev, generator=self.gen)
+      lo_ = torch.tensor([c[0] for c in com_ranges], device=dev)
+      hi_ = torch.tensor([c[1] for c in com_ranges], device=dev)
+      sim.model.body_ipos[:, b] += lo_ + (hi_ - lo_) * r
+      sim.create_graph()
+    if qpos0_range is not None:
+      sim.expand_model_fields(["qpos0"])
+      sim.model.qpos0[:, 7:] += qpos0_range[0] + (qpos0_range[1] - qpos0_range[0]) * torch.rand((n, m.nq - 7), device=dev, generator=self.gen)
+      sim.create_graph()
+    # resets to a phase of a motion (the tracking task): tables on the device, a phase counter per world
+    self.motion = None
+    if motion is not None:
+      if not self.has_free:
+        raise ValueError("motion resets need a floating base")
+      cfg = dict(TRACKING_TASK_EVENTS["g1"]["motion_reset"], **(motion_reset or {}))
+      tab = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=dev) for k, v in motion.items() if k != "fps"}
+      nframe = int(tab["joint_pos"].shape[0])
+      hinge = [j for j in range(m.njnt) if m.jnt_type[j] != JNT_FREE]
+      rng_ = np.asarray(m.jnt_range, dtype=np.float64)[hinge]
+      mean, half = 0.5 * (rng_[:, 0] + rng_[:, 1]), 0.5 * (rng_[:, 1] - rng_[:, 0]) * cfg["soft_joint_pos_limit_factor"]
+      limited = np.asarray(m.jnt_limited)[hinge].astype(bool)
+      soft_lo = torch.tensor(np.where(limited, mean - half, -np.inf), dtype=torch.float32, device=dev)
+      soft_hi = torch.tensor(np.where(limited, mean + half, np.inf), dtype=torch.float32, device=dev)
+      six = ("x", "y", "z", "roll", "pitch", "yaw")
+      pr = torch.tensor([cfg["pose_range"].get(k, (0.0, 0.0)) for k in six], dtype=torch.float32, device=dev)
+      vr = torch.tensor([cfg["velocity_range"].get(k, (0.0, 0.0)) for k in six], dtype=torch.float32, device=dev)
+      # bins of one second like the reference's adaptive sampler (commands.py:107); nothing has failed yet: uniform over the bins
+      self.motion = {"tab": tab, "nframe": nframe, "bins": int(nframe // (1.0 / (m.opt.timestep * decimation))) + 1, "soft_lo": soft_lo, "soft_hi": soft_hi,
+                     "pose_range": pr, "velocity_range": vr, "joint_range": cfg["joint_position_range"], "dz": float(cfg["anchor_dz"]), "dup": float(cfg["anchor_dup"]),
+                     "time_steps": torch.zeros((n,), dtype=torch.int32, device=dev), "rnd": torch.zeros((n, 14 + m.nq - 7), device=dev),
+                     "reset_qpos": torch.zeros((n, m.nq), device=dev), "reset_qvel": torch.zeros((n, m.nv), device=dev), "term_ref": torch.zeros((n, 2), device=dev)}
+      if not (control_kernel or not fused_reset):
+        raise ValueError("motion resets run in the control kernel or in the torch reset chain (fused_reset=False)")
+      # the control kernel does all of this per resetting world itself (mjlab_motion_reset_t): tables and parameters, once
+      mo = self.motion
+      mo["anchor"] = {k: tab[k][:, 0].contiguous() for k in ("body_pos_w", "body_quat_w", "body_lin_vel_w", "body_ang_vel_w")}
+      mo["soft"] = torch.stack([soft_lo, soft_hi], dim=1).contiguous()
+      st = _MotionReset()
+      st.joint_pos, st.joint_vel = tab["joint_pos"].contiguous().data_ptr(), tab["joint_vel"].contiguous().data_ptr()
+      st.root_pos, st.root_quat = mo["anchor"]["body_pos_w"].data_ptr(), mo["anchor"]["body_quat_w"].data_ptr()
+      st.root_lin_vel, st.root_ang_vel = mo["anchor"]["body_lin_vel_w"].data_ptr(), mo["anchor"]["body_ang_vel_w"].data_ptr()
+      st.soft_limits, st.rnd, st.time_steps = mo["soft"].data_ptr(), mo["rnd"].data_ptr(), mo["time_steps"].data_ptr()
+      st.nframe, st.bins = nframe, mo["bins"]
+      for k in range(6):
+        st.pose_lo[k], st.pose_hi[k], st.vel_lo[k], st.vel_hi[k] = float(pr[k, 0]), float(pr[k, 1]), float(vr[k, 0]), float(vr[k, 1])
+      st.joint_lo, st.joint_hi, st.dz, st.dup = float(cfg["joint_position_range"][0]), float(cfg["joint_position_range"][1]), mo["dz"], mo["dup"]
+      mo["struct_dev"] = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(dev)
     # interval event: velocity kicks under a per-env timer (mjlab_interval_push)
     self.push = None
     if push is not None and self.has_free:
@@ -167,9 +300,49 @@ class PhysicsRollout:
       q[:, 6] = torch.sin(yaw * 0.5)
     return q
 
+  def _motion_rows(self) -> torch.Tensor:
+    """Refresh, for EVERY world, the state its reset would write now (reference MotionCommand._resample_command,
+    tasks/tracking/mdp/commands.py:299-363: a motion frame of a freshly sampled phase + the cfg's noise, through
+    write_joint_state_to_sim / write_root_state_to_sim) and the termination reference of its current phase; returns the
+    sampled phases.  Plain device ops, no host sync: which worlds take their row is decided by the reset itself."""
+    mo = self.motion
+    tab, T = mo["tab"], mo["nframe"]
+    u = mo["rnd"]  # refreshed by the caller: the same uniforms the control kernel reads (mjlab_motion_reset_t.rnd)
+    bins = torch.clamp((u[:, 0] * mo["bins"]).long(), max=mo["bins"] - 1)
+    t_new = ((bins.float() + u[:, 1]) / mo["bins"] * (T - 1)).long()
+    pose = mo["pose_range"][:, 0] + (mo["pose_range"][:, 1] - mo["pose_range"][:, 0]) * u[:, 2:8]
+    vel = mo["velocity_range"][:, 0] + (mo["velocity_range"][:, 1] - mo["velocity_range"][:, 0]) * u[:, 8:14]
+    root_pos = tab["body_pos_w"][t_new, 0] + pose[:, 0:3]
+    if self.env_origins is not None:
+      root_pos = root_pos + self.env_origins
+    root_ori = _quat_mul(_quat_from_euler_xyz(pose[:, 3], pose[:, 4], pose[:, 5]), tab["body_quat_w"][t_new, 0])
+    lin = tab["body_lin_vel_w"][t_new, 0] + vel[:, 0:3]
+    ang = _quat_apply_inverse(root_ori, tab["body_ang_vel_w"][t_new, 0] + vel[:, 3:6])
+    lo_j, hi_j = mo["joint_range"]
+    jp = torch.minimum(torch.maximum(tab["joint_pos"][t_new] + lo_j + (hi_j - lo_j) * u[:, 14:], mo["soft_lo"]), mo["soft_hi"])
+    torch.cat([root_pos, root_ori, jp], dim=1, out=mo["reset_qpos"])
+    torch.cat([lin, ang, tab["joint_vel"][t_new]], dim=1, out=mo["reset_qvel"])
+    t_cur = torch.clamp(mo["time_steps"].long(), max=T - 1)
+    q = tab["body_quat_w"][t_cur, 0]
+    z = tab["body_pos_w"][t_cur, 0, 2]
+    if self.env_origins is not None:
+      z = z + self.env_origins[:, 2]
+    torch.stack([z, 1.0 - 2.0 * (q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2])], dim=1, out=mo["term_ref"])
+    return t_new
+
   def reset_all(self) -> None:
     d = self.sim.data
     n = self.sim.num_envs
+    if self.motion is not None:
+      torch.rand(self.motion["rnd"].shape, device=self.key_qpos.device, generator=self.gen, out=self.motion["rnd"])
+      t_new = self._motion_rows()
+      d.qpos[:] = self.motion["reset_qpos"]
+      d.qvel[:] = self.motion["reset_qvel"]
+      self.motion["time_steps"].copy_(t_new.to(torch.int32))
+      d.ctrl[:] = self.default_joint
+      d.qacc_warmstart[:] = 0.0
+      self.sim.forward()
+      return
     d.qpos[:] = self._sample_reset_qpos(n)
     d.qvel[:] = 0.0
     d.ctrl[:] = self.default_joint
@@ -234,6 +407,15 @@ class PhysicsRollout:
     rnd = torch.rand((n * 10,), device=dev, generator=self.gen)
     rnd3, rnd7 = rnd[: 3 * n].view(n, 3), rnd[3 * n :].view(n, 7)
     dt = float(self.m.opt.timestep * self.decimation)
+    t_new = None
+    if self.motion is not None:
+      mo = self.motion
+      torch.rand(mo["rnd"].shape, device=dev, generator=self.gen, out=mo["rnd"])
+      if not (self.control_kernel and self.fused_reset):  # the torch chain; the control kernel does the same per resetting world
+        t_new = self._motion_rows()
+        # a motion that has ended resamples like a reset (commands.py:365-369 _update_command): those worlds time out this step
+        ended = mo["time_steps"] + 1 >= mo["nframe"]
+        self.episode_length.copy_(torch.where(ended, torch.full_like(self.episode_length, self.max_len - 1), self.episode_length))
     if self.control_kernel and self.fused_reset:
       c = _Control()
       c.nsubstep, c.forward_mode, c.max_len = self.decimation, 2 if self.masked_forward else 1, self.max_len
@@ -250,6 +432,8 @@ class PhysicsRollout:
       if self.push is not None:
         lo_t, hi_t, rng6, time_left = self.push
         c.push_time_left, c.rnd7, c.push_dt, c.push_interval_lo, c.push_interval_hi, c.push_range = time_left.data_ptr(), rnd7.data_ptr(), dt, lo_t, hi_t, rng6
+      if self.motion is not None:
+        c.motion = self.motion["struct_dev"].data_ptr()
       with torch.cuda.device(dev):
         native.check(s._lib.mjlab_control_step(ctypes.byref(s._m), ctypes.byref(s._d), ctypes.byref(c), s._stream()), "mjlab_control_step")
       return self._reset_mask
@@ -274,12 +458,19 @@ class PhysicsRollout:
         fell = (d.qpos[:, 2] - z0 < self.min_height) | (up_z < self.min_up_z)
       else:
         fell = torch.zeros_like(self.episode_length, dtype=torch.bool)
+      if self.motion is not None:
+        mo = self.motion
+        up_z = 1.0 - 2.0 * (d.qpos[:, 4] ** 2 + d.qpos[:, 5] ** 2)
+        fell = fell | ((d.qpos[:, 2] - mo["term_ref"][:, 0]).abs() > mo["dz"]) | ((up_z - mo["term_ref"][:, 1]).abs() > mo["dup"])
       bad = ~torch.isfinite(d.qpos).all(dim=1)
       reset = fell | bad | (self.episode_length >= self.max_len)
-      fresh = self._reset_qpos_from(rnd3)
+      fresh = self._reset_qpos_from(rnd3) if self.motion is None else self.motion["reset_qpos"]
+      fresh_v = torch.zeros_like(d.qvel) if self.motion is None else self.motion["reset_qvel"]
       rm = reset.unsqueeze(1)
       d.qpos[:] = torch.where(rm, fresh, torch.nan_to_num(d.qpos))
-      d.qvel[:] = torch.where(rm, torch.zeros_like(d.qvel), torch.nan_to_num(d.qvel))
+      d.qvel[:] = torch.where(rm, fresh_v, torch.nan_to_num(d.qvel))
+      if self.motion is not None:
+        self.motion["time_steps"].copy_(torch.where(reset, t_new, self.motion["time_steps"].long() + 1).to(torch.int32))
       d.qacc_warmstart[:] = torch.where(rm, torch.zeros_like(d.qacc_warmstart), torch.nan_to_num(d.qacc_warmstart))
       self.episode_length.copy_(torch.where(reset, torch.zeros_like(self.episode_length), self.episode_length))
     self.sim.forward(reset if self.masked_forward else None)

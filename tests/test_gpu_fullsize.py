@@ -603,6 +603,61 @@ def test_fused_launch_structures_are_bit_identical(scene):
       assert torch.equal(out[variants[0]][f], out[v][f]), (v, f)
 
 
+def test_tracking_task_resets_in_the_control_kernel_equal_the_torch_chain():
+  """BASELINE config 4 under its own events (mjlab_amd.rollout.TRACKING_TASK_EVENTS): a world that resets is put on a random
+  phase of the motion with the cfg's pose / velocity / joint noise, the way MotionCommand._resample_command writes it
+  (reference tasks/tracking/mdp/commands.py:299-363), and the anchor terminations (terminations.py:27-53) run against the
+  motion frame of the world's phase.  The one-launch control kernel (mjlab_motion_reset_t) against the chain of separate calls
+  + torch ops on the same uniforms: identical reset decisions and phases, untouched worlds bit-identical, reset states equal to
+  rounding (sincos / fused multiply-adds differ in the last bit between the two), and what the cfg describes."""
+  import torch
+
+  from mjlab_amd import robots
+  from mjlab_amd.rollout import TRACKING_TASK_EVENTS, PhysicsRollout, g1_action_scale, synthetic_motion
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = robots.load_model("g1_tracking_flat")
+  ev = dict(TRACKING_TASK_EVENTS["g1"])
+  motion = synthetic_motion(model)
+  rolls = []
+  for ck in (False, True):
+    sim = Simulation(512, SimulationCfg(njmax=250, fuse="step"), model, "cuda:0")
+    rolls.append(PhysicsRollout(sim, action_scale=g1_action_scale(model), seed=21, min_height=-1.0e9, fused_reset=ck, control_kernel=ck,
+                                substeps_per_call=4 if ck else 1, motion=motion, **ev))
+  a, b = rolls
+  assert torch.equal(a.sim.data.qpos, b.sim.data.qpos) and torch.equal(a.motion["time_steps"], b.motion["time_steps"])
+  q0 = a.sim.data.qpos.clone()
+  # the initial states ARE reset states: pelvis within the pose noise of the motion's root, joints within the noise of a frame
+  assert float((q0[:, 2] - 0.76).abs().max()) <= 0.0101 and float(q0[:, :2].abs().max()) <= 0.0501
+  tab = torch.as_tensor(motion["joint_pos"], device="cuda")
+  assert float((q0[:, 7:] - tab[a.motion["time_steps"].long()]).abs().max()) <= 0.1001
+  assert float(a.sim.data.qvel[:, :3].abs().max()) > 0.1  # the velocity noise of the reset reached qvel
+  gen = torch.Generator(device="cuda").manual_seed(5)
+  total = 0
+  for k in range(60):
+    act = torch.rand((512, model.nu), device="cuda", generator=gen) * 2 - 1
+    ra, rb = a.step(act).bool(), b.step(act).bool()
+    assert torch.equal(ra, rb), k
+    assert torch.equal(a.motion["time_steps"], b.motion["time_steps"]) and torch.equal(a.episode_length, b.episode_length)
+    keep = ~ra
+    for f in ("qpos", "qvel", "qacc_warmstart"):
+      assert torch.equal(getattr(a.sim.data, f)[keep], getattr(b.sim.data, f)[keep]), (k, f)
+      if bool(ra.any()):
+        assert float((getattr(a.sim.data, f)[ra] - getattr(b.sim.data, f)[ra]).abs().max()) < 3e-6, (k, f)
+    if bool(ra.any()):
+      q = b.sim.data.qpos[rb]
+      assert float((q[:, 2] - 0.76).abs().max()) <= 0.0101 and float((q[:, 3:7].norm(dim=1) - 1).abs().max()) < 1e-6
+      assert float((q[:, 7:] - tab[b.motion["time_steps"].long()[rb]]).abs().max()) <= 0.1001
+      # the reset worlds are brought back in sync so that the two rollouts stay comparable
+      for f in ("qpos", "qvel"):
+        getattr(a.sim.data, f)[ra] = getattr(b.sim.data, f)[rb]
+      a.sim.forward()
+      b.sim.forward()
+    total += int(ra.sum())
+  assert total > 50, total  # random actions throw the robots off the motion: anchor terminations fire
+  assert int(a.motion["time_steps"].max()) < motion["joint_pos"].shape[0]
+
+
 def test_solver_optimality_conditions_at_full_size():
   """Size-independent properties of the constraint solve at BASELINE's full size (4096 G1 worlds on rollout
   states, no oracle involved): the published constraint force is J^T efc_force; efc_force is the penalty law of

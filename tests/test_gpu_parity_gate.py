@@ -19,7 +19,7 @@ the GPU (profiles/r02_v1/parity_gate.txt: 12 runs of 1024 worlds) times 3, round
   efc_pos                  ABSOLUTE, metres: a distance near zero has no relative scale
   efc_D / efc_aref         functions of penetration / 1 mm (solimp width): a 1e-7 position error is
                            amplified 1e3-fold; gated at p99 (3e-4 / 4e-5 measured)
-  qacc, qfrc_constraint    median <= 1e-5 (measured 2.5e-6), p99 <= 4e-5 (1.3e-5), max <= 5e-4
+  qacc, qfrc_constraint    median <= 1e-5 (measured 2.5e-6), p99 <= 1.5e-5 (1.0-1.25e-5; north_star's 1e-5 is the line), max <= 5e-4
                            (2e-5 typical; 1.6e-4 in one world of 12 288 whose Newton iteration ran
                            into the 10-iteration cap on a different iterate)
   one step later           qpos p99 <= 1e-6 (2.5e-7), qvel p99 <= 3e-5 (1e-5); max 3e-5 / 1.5e-3
@@ -28,11 +28,19 @@ the GPU (profiles/r02_v1/parity_gate.txt: 12 runs of 1024 worlds) times 3, round
 The 25-step horizon meets the round-1 judge's wish list (qacc p99 <= 1e-5, max <= 5e-5) on the Go1
 scene only; with fallen, self-colliding robots in the sample (250 steps) the p99 is 1.0-1.3e-5.
 
-On the rough scenes the robots are ~100 m from the origin, where fp32 world coordinates resolve
-7.6 um: kinematics stay relative-exact, but a 1 cm edge normal is only good to ~1e-3, and contact
-depths (with them efc_J on edge contacts, efc_D, qacc) lose two to three digits -- on BOTH sides of
-any fp32-vs-fp32 comparison, the reference's own engine included.  Separate, looser literals below,
-same structure, same measured-x3 rule.
+On the rough scenes the robots are ~100 m from the origin, where fp32 world coordinates resolve 7.6 um.  Since round 3 the
+stages compute in each world's local frame (include/mjlab_fields.h, xorigin), so the smooth dynamics and the flat-top contacts
+there are as accurate as on the plane (qacc_smooth, qM, step_qpos: the flat literals); what is left is the conditioning of
+edge / corner contacts themselves -- a normal formed from a centimetre-sized offset is good to 1e-4 at best wherever the robot
+stands -- so efc_J / efc_aref / qacc on edge contacts keep looser literals (measured x 3: profiles/r03_v4/parity_gate.txt;
+round 2, in world coordinates: qacc median 1.5e-5, p99 1.2e-4 -- now 3.5e-6 / 3.3e-5).
+
+Worlds whose qacc is off by more than north_star's 1e-5 are counted and classified by
+tools/parity_report.py: Newton iteration at its cap, different final active set, different iteration count, or none of these
+("unexplained": the fp32 rounding of a converged solve).  Measured on the flat scenes: 7-17 of 1024 worlds, nearly all of them
+UNEXPLAINED and within 2.9e-5 -- the tail of the noise distribution whose p99 sits at 1.0-1.25e-5, not solver artefacts; the
+worlds far out (1e-3 and more) are the capped ones.  The gate asserts exactly that: p99 <= 1.5e-5, at most 2.5 % of the worlds
+above 1e-5, the unexplained ones below 5e-5, anything beyond only in capped / different-active-set worlds.
 """
 
 import sys
@@ -51,18 +59,28 @@ FLAT = {
   "kin_max": 1e-6, "qM_max": 1e-6,
   "vel_max": 4e-5,
   "efc_J_max": 1e-5, "efc_pos_abs_max": 5e-6, "efc_D_p99": 1e-3, "efc_aref_p99": 2e-4,
-  "qacc_med": 1e-5, "qacc_p99": 4e-5, "qacc_max": 5e-4, "qfc_max": 6e-3,
+  "qacc_med": 1e-5, "qacc_p99": 1.5e-5, "qacc_max": 5e-4, "qfc_max": 6e-3,
   "step_qpos_p99": 1e-6, "step_qpos_max": 3e-5, "step_qvel_p99": 3e-5, "step_qvel_max": 1.5e-3,
   "edge_frac": 0.0,
+  "off_frac": 0.025, "unexplained_max": 5e-5,
 }  # fmt: skip
 ROUGH = {
   "same_frac": 0.98,
-  "kin_max": 1e-6, "qM_max": 1e-5,
-  "vel_max": 2e-4,
-  "efc_J_max": 5e-3, "efc_pos_abs_max": 1e-4, "efc_D_p99": 1e-2, "efc_aref_p99": 1.2e-2,
-  "qacc_med": 5e-5, "qacc_p99": 4e-4, "qacc_max": 3e-3, "qfc_max": 5e-3,
-  "step_qpos_p99": 1e-6, "step_qpos_max": 2e-5, "step_qvel_p99": 4e-4, "step_qvel_max": 2e-2,
+  "kin_max": 1e-6, "qM_max": 1e-6,
+  "vel_max": 4e-5,
+  "efc_J_max": 1.2e-3, "efc_pos_abs_max": 7e-6, "efc_D_p99": 1.5e-3, "efc_aref_p99": 6e-3,
+  "qacc_med": 1.2e-5, "qacc_p99": 1e-4, "qacc_max": 4e-4, "qfc_max": 5e-4,
+  "step_qpos_p99": 1e-6, "step_qpos_max": 1e-6, "step_qvel_p99": 1.2e-4, "step_qvel_max": 1e-3,
+  "off_frac": 0.12, "unexplained_max": 4e-4,
 }  # fmt: skip
+
+# BASELINE config 4 under its OWN reset distribution (random phases of a motion + pose / velocity / joint noise, anchor
+# terminations: 6 500 resets per 250 steps x 1024 worlds under random actions).  Reset robots regularly start with their feet
+# INSIDE each other (thin foot capsules, noisy leg joints): two capsule axes 0.4 mm apart give a contact normal that fp32
+# resolves to 1e-3 at best (the fp32 build of the restatement shows the same: efc_J 7e-4 on such rows), in ~1 % of the worlds.
+# Median and the smooth chain keep the flat literals; the row / solve tails are the measured ones x 3 (profiles/r03_v5).
+TRACKING = dict(FLAT, efc_J_max=0.2, efc_J_p99=1e-4, efc_pos_abs_max=1.5e-5, qacc_p99=2.5e-5, qacc_max=5e-2, qfc_max=0.12,
+                step_qpos_max=8e-4, step_qvel_max=3e-2, off_frac=0.05, unexplained_max=3e-4)
 
 CASES = [
   # scene, control steps, oracle precision, expanded model fields
@@ -99,7 +117,7 @@ def _check(r, tol):
     assert f[k][2] <= (tol["qM_max"] if k == "qM" else tol["kin_max"]), (k, f[k])
   for k in VEL:
     assert f[k][2] <= tol["vel_max"], (k, f[k])
-  assert f["efc_J"][2] <= tol["efc_J_max"], f["efc_J"]
+  assert f["efc_J"][2] <= tol["efc_J_max"] and f["efc_J"][1] <= tol.get("efc_J_p99", tol["efc_J_max"]), f["efc_J"]
   assert f["efc_pos_abs_m"][2] <= tol["efc_pos_abs_max"], f["efc_pos_abs_m"]
   assert f["efc_D"][1] <= tol["efc_D_p99"], f["efc_D"]
   assert f["efc_aref"][1] <= tol["efc_aref_p99"], f["efc_aref"]
@@ -109,6 +127,10 @@ def _check(r, tol):
   assert q[0] <= tol["qacc_med"] and q[1] <= 2 * tol["qacc_p99"] and q[2] <= tol["qfc_max"], q
   assert f["step_qpos"][1] <= tol["step_qpos_p99"] and f["step_qpos"][2] <= tol["step_qpos_max"], f["step_qpos"]
   assert f["step_qvel"][1] <= tol["step_qvel_p99"] and f["step_qvel"][2] <= tol["step_qvel_max"], f["step_qvel"]
+  # worlds above north_star's 1e-5: few, and beyond the noise tail only where the solve itself explains it
+  off = r["qacc_off"]
+  assert off["above_1e-5"] <= tol["off_frac"] * n, off
+  assert off["unexplained_max"] <= tol["unexplained_max"], off
   # the Newton iteration does the same amount of work on both sides
   assert abs(r["niter_gpu"][0] - r["niter_oracle"][0]) < 0.25, (r["niter_gpu"], r["niter_oracle"])
 
@@ -119,7 +141,7 @@ def test_rollout_state_parity(scene, steps, precision, expand):
 
   rough = scene.endswith("rough")
   r = scene_report(scene, N, steps, precision, expand=expand, spread=3.5 if rough else None)
-  tol = ROUGH if rough else FLAT
+  tol = ROUGH if rough else (TRACKING if scene == "g1_tracking_flat" else FLAT)
   if "dof_frictionloss" in expand:
     # ~15 more rows per world (mean 53, up to 128): one world in 1024 ends its Newton iteration at the cap of 10 on both
     # sides, where the iterate depends on rounding (measured: qacc 3.3e-2 in that world, p99 9.4e-6 as without the rows).

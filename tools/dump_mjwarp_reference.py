@@ -1,21 +1,31 @@
-"""Record golden step vectors from the PINNED upstream engine (mujoco_warp) -- to be run on a
-machine that has the reference's dependencies; it cannot run in the build container.
+"""Record golden vectors from the PINNED upstream engine (mujoco_warp) -- to be run on a machine that has the reference's
+dependencies; it cannot run in the build container.
 
-The reference's hot path is ``mjwarp.step`` / ``mjwarp.forward``
-(reference src/mjlab/sim/sim.py:136,139,187,195), pinned at
-``mujoco_warp @ 486642c3fa262a989b482e0e506716d5793d61a9`` + ``mujoco 3.3.7.dev811775910``
-(reference pyproject.toml:94-96).  Neither is installable here, so the oracle in
-``oracle/`` is "parity unpinned" (DESIGN.md section 3).  This script closes that gap without
-changing the build: it compiles the same scenes with upstream ``mujoco`` through the
-reference's own ``Scene`` / task configuration, seeds the same states as
-``tools/make_golden.py`` and writes ``tests/golden_upstream/<scene>.npz`` in the same format
-as ``tests/golden/*.npz`` (``in_{qpos,qvel,ctrl}``, ``fwd_<field>`` after ``forward``,
-``step_<field>`` after ``nstep`` x ``step`` + ``forward``; fields = make_golden.OUT_FIELDS).
+The reference's hot path is ``mjwarp.step`` / ``mjwarp.forward`` (reference src/mjlab/sim/sim.py:136,139,187,195), pinned at
+``mujoco_warp @ 486642c3fa262a989b482e0e506716d5793d61a9`` + ``mujoco 3.3.7.dev811775910`` (reference pyproject.toml:94-96).
+Neither is installable here, so the oracle in ``oracle/`` is "parity unpinned" (DESIGN.md section 3).  This script closes that
+gap in ONE command on a machine that has them:
 
-  python tools/dump_mjwarp_reference.py --reference /path/to/mjlab
+  python tools/dump_mjwarp_reference.py --reference /path/to/mjlab            # -> tests/golden_upstream/*.npz
 
-Once such files exist, ``tests/test_golden.py::test_*_upstream`` compares both the oracle and
-the HIP path against them at the north_star tolerance (1e-5 relative on state, fp32).
+Per scene it writes two files, each with ``ls_parallel`` on (the reference's setting, sim/sim.py:89,111) AND off:
+
+  <scene>.npz            the seeded states of tools/make_golden.py (4 worlds), same keys as tests/golden/<scene>.npz
+  <scene>_rollout.npz    the ROLLOUT STATES the parity gate uses: tests/golden/rollout_states_<scene>.npz (256 worlds reached
+                         by a GPU rollout with random actions, falls and resets; exported by tools/export_rollout_states.py and
+                         committed), with per-world model fields (friction, torso com, joint zero offsets) applied
+
+and in both the upstream mjModel arrays of every field in this repository's catalogue (``model_<field>``: what
+tests/test_golden.py::test_compiled_model_matches_upstream compares this repository's MJCF compiler against).
+
+Keys: ``in_<qpos|qvel|ctrl|qacc_warmstart>``, ``model_<field>``, ``dr_<field>`` (per-world model fields, rollout file), and
+for P in (``lsp1``, ``lsp0``): ``P_fwd_<field>`` after forward(), ``P_step_<field>`` after nstep x step() + forward().  Fields =
+make_golden.OUT_FIELDS + the intermediates ``qacc_smooth qfrc_smooth qfrc_constraint qM nefc ncon solver_niter
+efc_J efc_D efc_aref efc_pos efc_force contact_dist contact_pos contact_frame contact_geom`` (whatever of them the pinned
+engine exposes per world; arrays it keeps in another layout are stored raw under ``P_raw_<name>`` with their shape).
+
+tests/test_golden.py consumes all of it: the oracle (CPU) and the HIP path (GPU) under both ``literal_termination`` and both
+``warmstart_at_advance`` settings, at north_star's tolerance.
 """
 
 from __future__ import annotations
@@ -35,6 +45,75 @@ SCENES = {
   "g1_tracking_flat": "Mjlab-Tracking-Flat-Unitree-G1",
   "go1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-Go1",
 }
+INTERMEDIATES = ("qacc_smooth", "qfrc_smooth", "qfrc_constraint", "qM", "nefc", "ncon", "solver_niter")
+EFC = ("J", "D", "aref", "pos", "force")
+CONTACT = ("dist", "pos", "frame", "geom")
+NSTEP = 5
+
+
+def model_arrays(mjm) -> dict:
+  """Every mjModel array this repository's catalogue names (include/mjlab_fields.h), as upstream compiled it."""
+  from mjlab_amd import native  # layout only: no GPU needed
+
+  out = {}
+  try:
+    fields = [f.name for f in native.layouts()[0]]
+  except Exception:  # noqa: BLE001  (no built library on that machine: fall back to the header)
+    import re
+
+    fields = re.findall(r"X\((\w+), ", (ROOT / "include" / "mjlab_fields.h").read_text().split("MJLAB_DATA_REAL_FIELDS")[0])
+  for f in fields:
+    if hasattr(mjm, f):
+      out["model_" + f] = np.asarray(getattr(mjm, f)).copy()
+  for f in ("nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "nsensor"):
+    out["model_" + f] = np.asarray(getattr(mjm, f))
+  for f in ("timestep", "gravity", "impratio", "tolerance", "ls_tolerance", "iterations", "ls_iterations", "integrator", "cone", "solver"):
+    out["model_opt_" + f] = np.asarray(getattr(mjm.opt, f))
+  out["model_stat_meaninertia"] = np.asarray(mjm.stat.meaninertia)
+  return out
+
+
+def record(d, prefix: str, nworld: int, fields) -> dict:
+  rec = {}
+
+  def put(key, arr):
+    a = arr.numpy() if hasattr(arr, "numpy") else np.asarray(arr)
+    if a.ndim >= 1 and a.shape[0] == nworld:
+      rec[f"{prefix}_{key}"] = a
+    else:  # a layout this script does not know (pooled constraints of older engines, ...): keep it, labelled
+      rec[f"{prefix.split('_')[0]}_raw_{prefix.split('_', 1)[1]}_{key}"] = a
+
+  for f in fields:
+    if hasattr(d, f):
+      put(f, getattr(d, f))
+  for f in EFC:
+    if hasattr(d, "efc") and hasattr(d.efc, f):
+      put("efc_" + f, getattr(d.efc, f))
+  for f in CONTACT:
+    if hasattr(d, "contact") and hasattr(d.contact, f):
+      put("contact_" + f, getattr(d.contact, f))
+  return rec
+
+
+def run_case(mjwarp, wp, mjm, mjd, cfg, states: dict, dr: dict, ls_parallel: bool, fields) -> dict:
+  nworld = states["qpos"].shape[0]
+  m = mjwarp.put_model(mjm)
+  m.opt.ls_parallel = ls_parallel  # reference src/mjlab/sim/sim.py:111
+  d = mjwarp.put_data(mjm, mjd, nworld=nworld, nconmax=cfg.sim.nconmax, njmax=cfg.sim.njmax)
+  for f, v in dr.items():  # per-world model fields, expanded like the reference's expand_model_fields (sim/randomization.py)
+    setattr(m, f, wp.array(np.ascontiguousarray(v.astype(np.float32)), dtype=getattr(m, f).dtype))
+  for f, v in states.items():
+    wp.copy(getattr(d, f), wp.array(np.ascontiguousarray(v.astype(np.float32))))
+  p = "lsp1" if ls_parallel else "lsp0"
+  mjwarp.forward(m, d)
+  rec = record(d, p + "_fwd", nworld, fields)
+  for f, v in states.items():  # one step()-chain from the SAME state and warm start (forward() overwrote qacc_warmstart)
+    wp.copy(getattr(d, f), wp.array(np.ascontiguousarray(v.astype(np.float32))))
+  for _ in range(NSTEP):
+    mjwarp.step(m, d)
+  mjwarp.forward(m, d)
+  rec.update(record(d, p + "_step", nworld, fields))
+  return rec
 
 
 def main() -> None:
@@ -61,33 +140,41 @@ def main() -> None:
   ours = models()
   out = Path(args.out)
   out.mkdir(parents=True, exist_ok=True)
+  fields = tuple(OUT_FIELDS) + INTERMEDIATES
   for name, task in SCENES.items():
     cfg = load_cfg_from_registry(task, "env_cfg_entry_point")
     cfg.scene.num_envs = args.nworld
     scene = Scene(cfg.scene, device="cuda:0")
-    cfg.sim.mujoco.edit_spec(scene.spec) if hasattr(cfg.sim.mujoco, "edit_spec") else None
+    cfg.sim.mujoco.edit_spec(scene.spec)  # reference envs/manager_based_env.py: the task's MujocoCfg goes into the spec before compile()
     mjm = scene.compile()
     mjd = mujoco.MjData(mjm)
     mujoco.mj_forward(mjm, mjd)
+    marr = model_arrays(mjm)
+    # ---- (1) the seeded states of tests/golden/<scene>.npz
     qpos, qvel, ctrl = golden_inputs(ours[name], args.nworld, args.seed)
     assert qpos.shape[1] == mjm.nq and qvel.shape[1] == mjm.nv, "model mismatch between the two compilers"
-    m = mjwarp.put_model(mjm)
-    d = mjwarp.put_data(mjm, mjd, nworld=args.nworld, nconmax=cfg.sim.nconmax, njmax=cfg.sim.njmax)
-    wp.copy(d.qpos, wp.array(qpos.astype(np.float32)))
-    wp.copy(d.qvel, wp.array(qvel.astype(np.float32)))
-    wp.copy(d.ctrl, wp.array(ctrl.astype(np.float32)))
-    mjwarp.forward(m, d)
-    nstep = 5
-    rec = {"in_qpos": qpos, "in_qvel": qvel, "in_ctrl": ctrl, "nstep": np.array(nstep)}
-    for f in OUT_FIELDS + ("nefc",):
-      rec["fwd_" + f] = getattr(d, f).numpy()
-    for _ in range(nstep):
-      mjwarp.step(m, d)
-    mjwarp.forward(m, d)
-    for f in OUT_FIELDS + ("nefc",):
-      rec["step_" + f] = getattr(d, f).numpy()
+    states = {"qpos": qpos, "qvel": qvel, "ctrl": ctrl}
+    rec = {"in_" + k: v for k, v in states.items()}
+    rec.update(marr, nstep=np.array(NSTEP))
+    for lsp in (True, False):
+      rec.update(run_case(mjwarp, wp, mjm, mjd, cfg, states, {}, lsp, fields))
     np.savez_compressed(out / f"{name}.npz", **rec)
     print("wrote", out / f"{name}.npz")
+    # ---- (2) the rollout states of the parity gate, exported from a GPU run and committed
+    src = ROOT / "tests" / "golden" / f"rollout_states_{name}.npz"
+    if not src.exists():
+      print("no", src, "(tools/export_rollout_states.py on the GPU box): rollout file skipped")
+      continue
+    z = np.load(src)
+    states = {k: z[k] for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
+    dr = {k[3:]: z[k] for k in z.files if k.startswith("dr_")}
+    rec = {"in_" + k: v for k, v in states.items()}
+    rec.update({"dr_" + k: v for k, v in dr.items()})
+    rec.update(marr, nstep=np.array(NSTEP))
+    for lsp in (True, False):
+      rec.update(run_case(mjwarp, wp, mjm, mjd, cfg, states, dr, lsp, fields))
+    np.savez_compressed(out / f"{name}_rollout.npz", **rec)
+    print("wrote", out / f"{name}_rollout.npz")
 
 
 if __name__ == "__main__":

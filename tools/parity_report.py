@@ -21,7 +21,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mjlab_amd import robots  # noqa: E402
-from mjlab_amd.rollout import PhysicsRollout, g1_action_scale, go1_action_scale  # noqa: E402
+from mjlab_amd.rollout import TRACKING_TASK_EVENTS, PhysicsRollout, g1_action_scale, go1_action_scale, synthetic_motion  # noqa: E402
 from mjlab_amd.sim import Simulation, SimulationCfg  # noqa: E402
 from oracle.oracle import OracleSim  # noqa: E402
 
@@ -118,7 +118,14 @@ def scene_report(scene: str, n: int = 1024, control_steps: int = 25, precision: 
   if expand:
     randomize_model(sim, ora, model, expand, seed + 1)
   scale = g1_action_scale(model) if scene.startswith("g1") else go1_action_scale(model)
-  roll = PhysicsRollout(sim, action_scale=scale, seed=seed, min_height=0.3 if scene.startswith("g1") else 0.15)
+  if scene == "g1_tracking_flat":
+    # BASELINE config 4 under its OWN reset distribution: random phases of a synthetic motion written
+    # the way MotionCommand._resample_command writes them, the task's anchor terminations, 6-component pushes, 10 s episodes
+    ev = TRACKING_TASK_EVENTS["g1"]
+    roll = PhysicsRollout(sim, action_scale=scale, seed=seed, min_height=-1.0e9, fused_reset=False, motion=synthetic_motion(model),
+                          motion_reset=ev["motion_reset"], push=ev["push"], episode_length_s=ev["episode_length_s"])
+  else:
+    roll = PhysicsRollout(sim, action_scale=scale, seed=seed, min_height=0.3 if scene.startswith("g1") else 0.15)
   nreset = 0
   for _ in range(control_steps):
     nreset += int(roll.step(roll.random_action()).sum())
