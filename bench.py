@@ -123,6 +123,9 @@ def main() -> None:
   ap.add_argument("--readback", action="store_true",
                   help="refresh EntityData's derived quantities (body / root poses and velocities, projected gravity, joint state) "
                   "in the control kernel's epilogue (mjlab_control_t.readback_on; control kernel only)")
+  ap.add_argument("--no-pipeline", action="store_true",
+                  help="N > 1: skip the second view in which each rank's worlds are two half batches whose learner round trips are "
+                  "interleaved (mjlab_amd.dist.pingpong_steps; key `pipelined`).  `value` is always the plain synchronous exchange")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-full-env", action="store_true",
                   help="skip value_full_env (the reference's own ManagerBasedRlEnv of the same task stepped over this Simulation; "
@@ -239,6 +242,61 @@ def main() -> None:
       mdist.gather_rollout(info, rows)
     torch.cuda.synchronize()
     comm_ms = mdist.max_over_ranks((time.perf_counter() - t2) / 20 * 1e3, dev)
+
+  # ---- N > 1, second view: the rank's worlds as TWO HALF BATCHES whose learner round trips are interleaved -- while the rows of
+  # one half travel to the learner and its next actions travel back (side stream, ordered by events), the other half steps
+  # (mjlab_amd.dist.pingpong_steps; nobody acts on a stale observation).  Reported next to `value`, never instead of it.
+  pipelined = None
+  if exchange and not args.no_pipeline and args.envs_per_gpu % 2 == 0:
+    try:
+      nh = args.envs_per_gpu // 2
+      halves, hrolls = [], []
+      for h in range(2):
+        hs = Simulation(nh, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), fold_forward=not args.no_fold, fuse=args.fuse), model, dev)
+        ev_h = {k: v for k, v in events.items()}
+        hr = PhysicsRollout(hs, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info) + 7919 * (h + 1), fused_reset=True,
+                            min_height=-1.0e9 if "motion" in events else (0.3 if robot == "g1" else 0.15), substeps_per_call=args.substeps_per_call,
+                            control_kernel=roll.control_kernel, **ev_h)
+        if step_graph:
+          hr.capture_graph()
+        hrolls.append(hr)
+        halves.append((hr.step, hr.observation_rows))
+      gens = [torch.Generator(device=dev) for _ in range(2)]
+      for h, g in enumerate(gens):
+        g.manual_seed(args.seed + 2000 + h)
+
+      def learner(h, k, rows_all):
+        return torch.rand((info.world_size * nh, nu), device=dev, generator=gens[h]) * 2 - 1
+
+      def timed(overlap: bool, n: int) -> float:
+        mdist.pingpong_steps(info, max(2, args.warmup // 2), halves, learner, nu, dev, overlap=overlap)
+        mdist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        mdist.pingpong_steps(info, n, halves, learner, nu, dev, overlap=overlap)
+        torch.cuda.synchronize()
+        mdist.barrier()
+        return mdist.max_over_ranks((time.perf_counter() - t) / n * 1e3, dev)
+
+      for hr in hrolls:  # the same start-up transient as the main rollout
+        for _ in range(min(args.settle, 100)):
+          hr.step(hr.random_action(out=hr.action_buffer))
+      t_seq, t_pipe = timed(False, args.steps), timed(True, args.steps)
+      torch.cuda.synchronize()
+      t0h = time.perf_counter()
+      for _ in range(args.steps):  # compute only: the two halves back to back, no exchange
+        for hr in hrolls:
+          hr.step(hr.random_action(out=hr.action_buffer))
+      torch.cuda.synchronize()
+      t_comp = mdist.max_over_ranks((time.perf_counter() - t0h) / args.steps * 1e3, dev)
+      exch = max(t_seq - t_comp, 1e-9)
+      pipelined = {"value": args.envs_per_gpu * info.world_size / (t_pipe * 1e-3), "ms_per_step": t_pipe, "ms_per_step_same_halves_sequential_exchange": t_seq,
+                   "ms_per_step_halves_compute_only": t_comp, "exchange_overlap_frac": float(min(1.0, max(0.0, (t_seq - t_pipe) / exch))),
+                   "note": "two half batches per rank; the exchange of one half overlaps the physics of the other (side stream + events); "
+                   "exchange_overlap_frac = (sequential - pipelined) / (sequential - compute only)"}
+      del hrolls, halves
+    except Exception as e:  # noqa: BLE001
+      pipelined = {"error": f"{type(e).__name__}: {e}"}
 
   # ---- dominant-kernel timing with HIP events on the launch stream.  With --fuse step the dominant
   # kernel is k_substep<NVP, true>: `substeps_per_call` whole physics steps of every world per launch; it is
@@ -434,6 +492,7 @@ def main() -> None:
       "chunk_values": chunk_rates,
       "per_rank_ms_per_step": rank_ms,
       "exchange_ms_per_step": comm_ms,
+      "pipelined": pipelined,
       "roofline": roof,
       "cpu_baseline": cpu,
     }

@@ -54,7 +54,31 @@ def init_from_env(envs_per_rank: int, backend: str | None = None) -> ShardInfo:
     elif torch.cuda.is_available():
       torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
+    probe_collectives()
   return ShardInfo(rank, world_size, local_rank, envs_per_rank)
+
+
+def probe_collectives() -> None:
+  """Decide ONCE, and the same way on every rank, whether the backend has scatter / gather (an RCCL build may lack them): each
+  is tried on a tiny tensor and the outcomes are agreed on with an all-reduce (MIN), so that no rank can end up in a fallback
+  collective while its peers sit in the primary one.  gloo has both (host tensors)."""
+  global _SCATTER_SUPPORTED, _GATHER_SUPPORTED
+  if not dist.is_initialized() or dist.get_backend() != "nccl":
+    return
+  dev = torch.device("cuda", torch.cuda.current_device())
+  n, r = dist.get_world_size(), dist.get_rank()
+  ok = torch.ones((2,), dtype=torch.int32, device=dev)
+  try:
+    out = torch.empty((1,), device=dev)
+    dist.scatter(out, [torch.full((1,), float(k), device=dev) for k in range(n)] if r == 0 else None, src=0)
+  except (RuntimeError, NotImplementedError):
+    ok[0] = 0
+  try:
+    dist.gather(torch.zeros((1,), device=dev), [torch.empty((1,), device=dev) for _ in range(n)] if r == 0 else None, dst=0)
+  except (RuntimeError, NotImplementedError):
+    ok[1] = 0
+  dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+  _SCATTER_SUPPORTED, _GATHER_SUPPORTED = bool(ok[0].item()), bool(ok[1].item())
 
 
 def seed_for_rank(seed: int, info: ShardInfo) -> int:
@@ -74,7 +98,7 @@ _GATHER_SUPPORTED = True  # cleared when the backend turns out to have no gather
 _GATHER_BUF: dict = {}  # receive buffers, reused across control steps (the result is valid until the next call)
 
 
-def gather_rollout(info: ShardInfo, rows: torch.Tensor, dst: int = 0, to_all: bool = False) -> torch.Tensor | None:
+def gather_rollout(info: ShardInfo, rows: torch.Tensor, dst: int = 0, to_all: bool = False, tag: int = 0) -> torch.Tensor | None:
   """Per-env rows ``(envs_per_rank, k)`` of every rank -> ``(global_envs, k)`` in rank order ON THE
   LEARNER (rank ``dst``); the other ranks get None.  ``to_all=True`` delivers it to every rank
   (all-gather: replicated learners).
@@ -89,26 +113,26 @@ def gather_rollout(info: ShardInfo, rows: torch.Tensor, dst: int = 0, to_all: bo
   rows = rows.contiguous()
   if rows.is_cuda and dist.get_backend() == "gloo":
     # gloo has no device-side gather: testing path (several ranks sharing one GPU), staged through the host
-    out = gather_rollout(info, rows.cpu(), dst, to_all)
+    out = gather_rollout(info, rows.cpu(), dst, to_all, tag)
     return None if out is None else out.to(rows.device)
-  key = (rows.shape[1], rows.dtype, rows.device)
+  key = (rows.shape[1], rows.dtype, rows.device, tag)  # `tag`: callers with several exchanges in flight keep their results apart
   need = to_all or info.rank == dst
   out = _GATHER_BUF.get(key) if need else None
   if need and (out is None or out.shape[0] != info.global_envs):
     out = _GATHER_BUF[key] = torch.empty((info.global_envs, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-  global _GATHER_SUPPORTED
   if to_all or not _GATHER_SUPPORTED:
     if out is None:  # a backend without gather: every rank has to take part in the all-gather
       out = _GATHER_BUF[key] = torch.empty((info.global_envs, rows.shape[1]), dtype=rows.dtype, device=rows.device)
     dist.all_gather_into_tensor(out, rows)
     return out if (to_all or info.rank == dst) else None
-  try:
-    dist.gather(rows, list(out.chunk(info.world_size)) if info.rank == dst else None, dst=dst)
-  except (RuntimeError, NotImplementedError) as e:  # raised before anything is enqueued when the backend lacks the op
-    if "gather" not in str(e).lower() and "support" not in str(e).lower():
-      raise
-    _GATHER_SUPPORTED = False  # the same on every rank: all of them fall back to the all-gather from here on
-    return gather_rollout(info, rows, dst, to_all)
+  dist.gather(rows, list(out.chunk(info.world_size)) if info.rank == dst else None, dst=dst)
+  return out
+
+
+def all_gather_rollout(info: ShardInfo, rows: torch.Tensor) -> torch.Tensor:
+  """The rows of every rank on EVERY rank (replicated learners; round 1's exchange): ``gather_rollout(..., to_all=True)``."""
+  out = gather_rollout(info, rows, to_all=True)
+  assert out is not None
   return out
 
 
@@ -118,20 +142,14 @@ def scatter_actions(info: ShardInfo, actions_global: torch.Tensor | None, action
     assert actions_global is not None
     return actions_global
   out = torch.empty((info.envs_per_rank, action_dim), dtype=torch.float32, device=device)
-  global _SCATTER_SUPPORTED
   if dist.get_backend() == "nccl":
     # Scatter: every rank receives only its own slice (475 KB at 4096 x 29), sent by the learner over that rank's own xGMI
     # link -- 1 / world_size of what a broadcast of all the actions moves through every link.  A build of the backend
     # without scatter falls back to broadcast + slice (the same on every rank: the error is raised before anything is enqueued).
-    if _SCATTER_SUPPORTED:
-      try:
-        chunks = list(actions_global.contiguous().chunk(info.world_size)) if info.rank == src else None
-        dist.scatter(out, chunks, src=src)
-        return out
-      except (RuntimeError, NotImplementedError) as e:
-        if "scatter" not in str(e).lower() and "support" not in str(e).lower():
-          raise
-        _SCATTER_SUPPORTED = False
+    if _SCATTER_SUPPORTED:  # decided once for all ranks by probe_collectives()
+      chunks = list(actions_global.contiguous().chunk(info.world_size)) if info.rank == src else None
+      dist.scatter(out, chunks, src=src)
+      return out
     buf = actions_global if info.rank == src else torch.empty((info.global_envs, action_dim), dtype=torch.float32, device=device)
     dist.broadcast(buf, src=src)
     out.copy_(buf[info.env_slice])
@@ -142,6 +160,74 @@ def scatter_actions(info: ShardInfo, actions_global: torch.Tensor | None, action
     if out.is_cuda:
       out.copy_(host)
   return out
+
+
+def pingpong_steps(info: ShardInfo, nsteps: int, halves: list, learner_actions, action_dim: int, device, overlap: bool = True,
+                   comm_stream=None) -> list:
+  """`nsteps` control steps of a rank's worlds split into HALF BATCHES whose learner round trips are interleaved: while the rows
+  of one half travel to the learner (rank 0), the learner decides that half's next actions and they travel back, the other
+  half steps -- the learner-faithful way to hide the round trip (every half still acts on its own latest observation; nothing
+  is stale).  `halves[h]` = (step_fn(actions) -> None, rows_fn() -> tensor (envs_per_half, k)); `learner_actions(h, k, rows_all)`
+  is called on rank 0 only and returns the actions of ALL ranks' half h for control step k, (world_size * envs_per_half,
+  action_dim), from the rows gathered after step k - 1 (None for k = 0).  With `overlap=False` the same dependency chain runs
+  strictly in sequence (the reference for bit-equality: results are identical by construction, only the timing differs).
+  On RCCL the exchange of a half is issued on `comm_stream` (default: a side stream), ordered against the physics by events;
+  gloo (CPU tests) runs everything in issue order.  Returns the rows gathered after the last step per half (rank 0; None elsewhere)."""
+  nh = len(halves)
+  sub = ShardInfo(info.rank, info.world_size, info.local_rank, info.envs_per_rank // nh)
+  cuda = torch.cuda.is_available() and str(device).startswith("cuda") and dist.is_initialized() and dist.get_backend() == "nccl"
+  main = torch.cuda.current_stream(device) if cuda else None
+  side = (comm_stream or torch.cuda.Stream(device=device)) if (cuda and overlap) else main
+  gathered: list = [None] * nh
+  act: list = [None] * nh
+  ready: list = [None] * nh  # event: the actions of half h have arrived (recorded on the exchange stream)
+
+  def exchange(h: int, k: int, rows) -> None:
+    """rows of half h after step k - 1 (None at k = 0) -> learner -> actions of half h for step k."""
+    ctx = torch.cuda.stream(side) if cuda else _null()
+    with ctx:
+      if cuda and rows is not None:
+        side.wait_event(rows[1])
+      if rows is not None:
+        gathered[h] = gather_rollout(sub, rows[0], tag=h)
+      a_all = learner_actions(h, k, gathered[h]) if info.rank == 0 else None
+      act[h] = scatter_actions(sub, a_all, action_dim, device)
+      if cuda:
+        ready[h] = torch.cuda.Event()
+        ready[h].record(side)
+
+  for h in range(nh):
+    exchange(h, 0, None)
+  for k in range(nsteps):
+    for h in range(nh):
+      step_fn, rows_fn = halves[h]
+      if cuda:
+        main.wait_event(ready[h])
+      step_fn(act[h])
+      r = rows_fn()
+      ev = None
+      if cuda:
+        ev = torch.cuda.Event()
+        ev.record(main)
+      if k + 1 < nsteps:
+        exchange(h, k + 1, (r, ev))
+      else:  # the last rows still travel to the learner
+        ctx = torch.cuda.stream(side) if cuda else _null()
+        with ctx:
+          if cuda:
+            side.wait_event(ev)
+          gathered[h] = gather_rollout(sub, r, tag=h)
+  if cuda:
+    main.wait_stream(side)
+  return gathered
+
+
+class _null:
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *a):
+    return False
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -73,6 +73,87 @@ def test_two_rank_shard_equals_single_process(tmp_path):
   assert np.array_equal(got, expect)
 
 
+def _pingpong_worker(rank, world_size, port, out_dir):
+  sys.path.insert(0, str(ROOT))
+  os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  from mjlab_amd import dist as mdist
+  from mjlab_amd import robots
+  from oracle.oracle import OracleSim
+
+  info = mdist.init_from_env(envs_per_rank=4, backend="gloo")
+  model = robots.load_model("go1_velocity_flat")
+  jn = model.actuator_trnid[:, 0]
+  default = model.key_qpos[0][model.jnt_qposadr[jn]]
+  res = {}
+  for overlap in (False, True):
+    rng = np.random.default_rng(123)
+    q = rng.normal(0, 0.05, (2, 4, model.nq - 7))  # [half][global world of the half]
+    sims = []
+    for h in range(2):
+      s = OracleSim(model, 2)
+      s.reset(key=0)
+      s.qpos[:, 7:] += q[h, rank * 2 : rank * 2 + 2]
+      sims.append(s)
+    gens = [np.random.default_rng(1000 + h) for h in range(2)]
+    log = []
+
+    def learner(h, k, rows_all):  # rank 0 only: a policy that depends on what it last saw of THIS half
+      a = gens[h].uniform(-1, 1, (4, model.nu)).astype(np.float32)
+      if rows_all is not None:
+        a += 0.1 * np.tanh(rows_all.numpy()[:, : model.nu]).astype(np.float32)
+      log.append((h, k, a.copy()))
+      return torch.from_numpy(a)
+
+    def make(h):
+      def step(a):
+        sims[h].ctrl[:] = default + 0.25 * a.numpy().astype(np.float64)
+        sims[h].step(4)
+
+      return step, lambda: torch.from_numpy(np.concatenate([sims[h].qpos, sims[h].qvel], axis=1))
+
+    out = mdist.pingpong_steps(info, 3, [make(0), make(1)], learner, model.nu, "cpu", overlap=overlap)
+    res[overlap] = ([None if o is None else o.numpy().copy() for o in out], log)
+  if rank == 0:
+    for h in range(2):
+      assert np.array_equal(res[False][0][h], res[True][0][h])
+      np.save(Path(out_dir) / f"pp_rows_{h}.npy", res[True][0][h])
+    for (h0, k0, a0), (h1, k1, a1) in zip(res[False][1], res[True][1]):
+      assert (h0, k0) == (h1, k1) and np.array_equal(a0, a1)
+    np.save(Path(out_dir) / "pp_actions.npy", np.stack([a for _, _, a in res[True][1]]))
+    np.save(Path(out_dir) / "pp_order.npy", np.array([(h, k) for h, k, _ in res[True][1]]))
+  else:
+    assert all(o is None for o in res[True][0])
+  mdist.barrier()
+  dist.destroy_process_group()
+
+
+def test_pingpong_half_batches_equal_the_sequential_exchange(tmp_path):
+  """mjlab_amd.dist.pingpong_steps: two half batches per rank whose learner round trips are interleaved (the exchange of one half
+  in flight while the other steps).  Two gloo ranks: the interleaved schedule gives the rows and the learner the actions of the
+  strictly sequential one, bit for bit, and both equal a single process stepping the 8 worlds with those actions."""
+  port = 29711 + os.getpid() % 200
+  mp.spawn(_pingpong_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  sys.path.insert(0, str(ROOT))
+  from mjlab_amd import robots
+  from oracle.oracle import OracleSim
+
+  model = robots.load_model("go1_velocity_flat")
+  jn = model.actuator_trnid[:, 0]
+  default = model.key_qpos[0][model.jnt_qposadr[jn]]
+  rng = np.random.default_rng(123)
+  q = rng.normal(0, 0.05, (2, 4, model.nq - 7))
+  actions, order = np.load(tmp_path / "pp_actions.npy"), np.load(tmp_path / "pp_order.npy")
+  for h in range(2):
+    sim = OracleSim(model, 4)  # the half's 4 global worlds (2 per rank, rank order)
+    sim.reset(key=0)
+    sim.qpos[:, 7:] += q[h]
+    for (hh, k), a in zip(order, actions):
+      if hh == h:
+        sim.ctrl[:] = default + 0.25 * a.astype(np.float64)
+        sim.step(4)
+    assert np.array_equal(np.load(tmp_path / f"pp_rows_{h}.npy"), np.concatenate([sim.qpos, sim.qvel], axis=1))
+
+
 def test_single_rank_passthrough():
   from mjlab_amd import dist as mdist
 

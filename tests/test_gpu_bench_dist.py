@@ -31,6 +31,10 @@ def test_bench_two_ranks_on_one_gpu():
   assert d["exchange_ms_per_step"] is not None and d["exchange_ms_per_step"] > 0
   assert d["value_with_gather"] == d["value"]  # N > 1: the exchange is inside the timed region
   assert d["cpu_baseline"] is None  # reported at N = 1 only
+  # the second view: two half batches per rank with interleaved learner round trips (gloo: the schedule, not the overlap)
+  pl = d["pipelined"]
+  assert "error" not in pl, pl
+  assert pl["value"] > 0 and 0.0 <= pl["exchange_overlap_frac"] <= 1.0 and pl["ms_per_step_halves_compute_only"] > 0
 
 
 def test_bench_exchange_over_rccl_with_one_rank():
@@ -46,3 +50,7 @@ def test_bench_exchange_over_rccl_with_one_rank():
   d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
   assert d["n_gpus"] == 1 and d["value"] > 0
   assert d["exchange_ms_per_step"] is not None and d["exchange_ms_per_step"] > 0
+  assert "error" not in d["pipelined"], d["pipelined"]  # the side-stream exchange over RCCL, ordered by events
+  out = ROOT / "gpurun_out"
+  if out.is_dir():  # what a 1-GPU box can say about the exchange: recorded next to the run (copied to profiles/)
+    (out / "exchange_one_rank_rccl.json").write_text(json.dumps({k: d[k] for k in ("value", "ms_per_step", "exchange_ms_per_step", "pipelined", "config")}, indent=1))
