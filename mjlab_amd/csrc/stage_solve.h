@@ -193,11 +193,19 @@ __device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&a
         a[cb] = dact[u] * x[u][cb];
       }
       if (WITH_H) {
+#ifdef MJLAB_HSKIP  // experiment: skip the tiles of 16-column blocks that are all zero in this 4-row group
+        bool nz[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) nz[cb] = __ballot(x[u][cb] != 0.f) != 0ull;
+#endif
         int t = 0;
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int Jb = 0; Jb <= I; ++Jb) {
+#ifdef MJLAB_HSKIP
+            if (nz[I] && nz[Jb])
+#endif
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[u][Jb], acc[t], 0, 0, 0);
             ++t;
           }

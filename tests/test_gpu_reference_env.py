@@ -50,3 +50,41 @@ def test_registered_g1_velocity_task_runs_over_the_hip_simulation():
   fr = env.sim.model.geom_friction[:, :, 0]
   assert float(fr.std()) > 0.0
   print(f"reference G1 velocity task over mjlab_amd.Simulation: 100 env steps x 256 envs, {sum(resets)} resets, mean reward {out['mean_reward']:.4f}")
+
+
+_TRACKING_GPU = """
+import json, sys
+import torch
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env
+from _motion_fixture import write_full_motion
+write_full_motion({motion!r})
+def edit(cfg):
+  cfg.commands.motion.motion_file = {motion!r}
+env = reference_env.make_env("Mjlab-Tracking-Flat-Unitree-G1", num_envs=256, device="cuda:0", cfg_edit=edit)
+from mjlab_amd.sim import Simulation
+assert isinstance(env.sim, Simulation)
+fin = []
+out = reference_env.random_rollout(env, 60, seed=2, on_step=lambda k, o, r, t, to: fin.append(bool(torch.isfinite(r).all()) and all(bool(torch.isfinite(x).all()) for x in o.values())))
+torch.cuda.synchronize()
+cmd = env.command_manager.get_term("motion")
+z = env.sim.data.qpos[:, 2]
+print("RESULT " + json.dumps({{"finite": all(fin), "resets": out["resets"], "obs": {{k: list(v.shape) for k, v in out["obs"].items()}}, "zmin": float(z.min()), "zmax": float(z.max()),
+      "overflow": env.sim.overflow_report(), "phase_max": int(cmd.time_steps.max()), "mean_reward": out["mean_reward"], "sensor": float(env.sim.data.sensordata.abs().max())}}))
+"""
+
+
+def test_registered_g1_tracking_task_runs_over_the_hip_simulation(tmp_path):
+  """BASELINE config 4's task, Mjlab-Tracking-Flat-Unitree-G1, unmodified over ``mjlab_amd.sim.Simulation`` on the MI355X (own
+  process: the reference's task configs share mutable defaults between tasks).  The motion file is synthetic
+  (tests/_motion_fixture.py: the oracle's forward kinematics of mjlab_amd.rollout.synthetic_motion)."""
+  import json
+  import subprocess
+
+  code = _TRACKING_GPU.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"), motion=str(tmp_path / "motion.npz"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  res = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  assert res["finite"] and res["resets"] > 0 and res["obs"] == {"policy": [256, 160], "critic": [256, 286]}
+  assert res["overflow"] == {"nconmax": 0, "njmax": 0, "terrain_candidates": 0} and 0.0 < res["zmin"] and res["zmax"] < 1.3 and res["phase_max"] < 500
+  print(f"reference G1 tracking task over mjlab_amd.Simulation: 60 env steps x 256 envs, {res['resets']} resets, mean reward {res['mean_reward']:.4f}")

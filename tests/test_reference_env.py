@@ -124,3 +124,47 @@ def test_go1_task_constructs_and_steps():
   res = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
   assert all(a == b for a, b in res["sizes"]), res["sizes"]
   assert res["worst"] < 1e-12 and res["finite"]
+
+
+_TRACKING_SCRIPT = """
+import json, sys
+import numpy as np
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env
+from _motion_fixture import write_full_motion
+from _oracle_simulation import OracleSimulation
+from mjlab_amd import robots
+write_full_motion({motion!r})
+def edit(cfg):
+  cfg.commands.motion.motion_file = {motion!r}
+env = reference_env.make_env("Mjlab-Tracking-Flat-Unitree-G1", num_envs=8, device="cpu", sim_cls=OracleSimulation, cfg_edit=edit)
+ref, m = robots.load_model("g1_tracking_flat"), env.sim.mj_model
+sizes = [(int(getattr(m, k)), int(getattr(ref, k))) for k in ("nq", "nv", "nu", "nbody", "ngeom", "npair", "nsensor", "nsensordata")]
+worst = max(float(np.abs(np.asarray(getattr(m, k), float) - np.asarray(getattr(ref, k), float)).max()) for k in
+            ("body_mass", "body_inertia", "dof_armature", "actuator_gainprm", "actuator_biasprm", "geom_friction", "geom_condim", "pair_geom", "dof_invweight0", "sensor_intprm"))
+cmd = env.command_manager.get_term("motion")
+q0 = env.sim.data.qpos.clone()
+out = reference_env.random_rollout(env, 12)
+print("RESULT " + json.dumps({{"sizes": sizes, "worst": worst, "finite": all(bool(np.isfinite(o.numpy()).all()) for o in out["obs"].values()),
+      "obs": {{k: list(v.shape) for k, v in out["obs"].items()}}, "resets": out["resets"], "frames": int(cmd.motion.time_step_total),
+      "phase_max": int(cmd.time_steps.max()), "dr": [float(env.sim.model.body_ipos.std(dim=0).max()), float(env.sim.model.qpos0.std(dim=0).max())]}}))
+"""
+
+
+def test_tracking_task_constructs_and_steps(tmp_path):
+  """The SECOND task north_star names, Mjlab-Tracking-Flat-Unitree-G1 (BASELINE config 4): the reference's MotionCommand,
+  its body-tracking rewards, anchor / end-effector terminations, the self-collision contact sensor and the startup
+  randomisation of torso com and joint zero offsets, unmodified, over the boundary -- fed with a synthetic motion file
+  (tests/_motion_fixture.py; none is in the reference tree).  Own process: see test_go1_task_constructs_and_steps."""
+  import json
+  import subprocess
+
+  code = _TRACKING_SCRIPT.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"), motion=str(tmp_path / "motion.npz"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-2000:]
+  res = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  assert all(a == b for a, b in res["sizes"]), res["sizes"]
+  assert res["worst"] < 1e-12 and res["finite"]
+  assert res["obs"] == {"policy": [8, 160], "critic": [8, 286]} and res["frames"] == 500 and res["phase_max"] < 500
+  assert res["resets"] > 0  # random actions leave the motion: the anchor terminations fire, MotionCommand resamples a phase
+  assert res["dr"][0] > 0.0 and res["dr"][1] > 0.0  # per-world body_ipos and qpos0 went through expand_model_fields

@@ -118,6 +118,22 @@ def main() -> None:
     from mjlab.tasks.tracking import tracking_env_cfg as t
 
     out["tracking"] = {"sim": _plain(t.SIM_CFG)}
+    tc = t.TrackingEnvCfg()
+    mc = tc.commands.motion
+    out["tracking"].update({
+      "decimation": tc.decimation, "episode_length_s": tc.episode_length_s,
+      "pose_range": _plain(mc.pose_range), "velocity_range": _plain(mc.velocity_range), "joint_position_range": _plain(mc.joint_position_range),
+      "push_interval_range_s": _plain(tc.events.push_robot.interval_range_s), "push_velocity_range": _plain(tc.events.push_robot.params["velocity_range"]),
+      "base_com_ranges": _plain(tc.events.base_com.params["ranges"]), "qpos0_ranges": _plain(tc.events.add_joint_default_pos.params["ranges"]),
+      "foot_friction_ranges": _plain(tc.events.foot_friction.params["ranges"]),
+      "anchor_pos_threshold": tc.terminations.anchor_pos.params["threshold"], "anchor_ori_threshold": tc.terminations.anchor_ori.params["threshold"],
+    })
+    from mjlab.tasks.tracking.config.g1 import flat_env_cfg as tg1
+
+    g = tg1.G1FlatEnvCfg()
+    out["tracking"]["g1"] = {"anchor_body_name": g.commands.motion.anchor_body_name, "base_com_body": _plain(g.events.base_com.params["asset_cfg"].body_names),
+                             "foot_friction_geoms": _plain(g.events.foot_friction.params["asset_cfg"].geom_names),
+                             "soft_joint_pos_limit_factor": g1.G1_ARTICULATION.soft_joint_pos_limit_factor}
   except Exception as e:  # noqa: BLE001
     out["tracking_error"] = repr(e)
   for key, mod in (("g1_flat_sensors", "mjlab.tasks.velocity.config.g1.rough_env_cfg"), ("go1_flat_sensors", "mjlab.tasks.velocity.config.go1.rough_env_cfg"),
