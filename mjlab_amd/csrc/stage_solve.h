@@ -404,8 +404,9 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
 // mujoco_warp's parallel line search (MJLAB_OPT_LS_PARALLEL, include/mjlab_fields.h): the cost at `lsmax` log-spaced step sizes in
 // [min_step, 1], the lowest cost wins (the first one on ties).  LANES ARE CANDIDATES: lane c + lsmax g evaluates step size c over
 // the rows g, g + G, g + 2 G, ... (G = up to 4 row groups, as many as fit in the wave), reading the per-row arrays from LDS -- all
-// lanes of a group read the same address (a broadcast), so one trip over the rows prices every candidate at once: ~4 VALU + 3 LDS
+// lanes of a group read the same address (a broadcast), so one trip over the rows prices every candidate at once: ~6 VALU + 3 LDS
 // instructions per row trip instead of one wave reduction per candidate (20 of them for the reference's ls_iterations).
+// Candidates are compared by cost(alpha) - cost(0): the same argmin, without the common constant (see the row loop).
 template <int NVP, bool FL>
 __device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsmax) {
   const int nc = lsmax < 64 ? (lsmax > 1 ? lsmax : 1) : 64;  // candidates per pass over the rows
@@ -434,12 +435,17 @@ __device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsma
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        // cost(alpha) - cost(0) of the row, formed as a product of differences: the rows' constant terms (0.5 D jar^2, ~1e2..1e5
+        // summed) are common to all candidates and would bury the candidates' differences under fp32 rounding -- near the
+        // minimiser the LITERAL sum of costs cannot tell the candidates apart and the solve stalls at 1e-4
         const float x = fmaf(alpha, jv[u], j0[u]);
-        const float xm = fminf(x, 0.f);
-        float t = Dr[u] * xm * xm;
+        const float xm = fminf(x, 0.f), xm0 = fminf(j0[u], 0.f);
+        float t = Dr[u] * (xm - xm0) * (xm + xm0);
         if (FL && fl[u] >= 0.f) {  // friction loss (mj PrimalEval): Huber cost, linear beyond |x| = f / D
-          const float rf = fl[u] / Dr[u], ax = fabsf(x);
-          t = ax >= rf ? 2.f * fl[u] * (ax - 0.5f * rf) : Dr[u] * x * x;
+          const float rf = fl[u] / Dr[u], ax = fabsf(x), a0 = fabsf(j0[u]);
+          const float ha = ax >= rf ? 2.f * fl[u] * (ax - 0.5f * rf) : Dr[u] * x * x;
+          const float h0 = a0 >= rf ? 2.f * fl[u] * (a0 - 0.5f * rf) : Dr[u] * j0[u] * j0[u];
+          t = ha - h0;
         }
         acc += t;
       }
@@ -448,7 +454,7 @@ __device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsma
       const float part = acc;
       for (int k = 1; k < G; ++k) acc += __shfl(part, c.lane + k * nc);
     }
-    float cost = 0.5f * acc + alpha * alpha * c.quad_gauss[2] + alpha * c.quad_gauss[1] + c.quad_gauss[0];
+    float cost = 0.5f * acc + alpha * (alpha * c.quad_gauss[2] + c.quad_gauss[1]);  // relative to the cost at alpha = 0
     if (!(g == 0 && ci < lsmax)) cost = 3.0e38f;
     const float cmin = wave_min(cost);
     const unsigned long long hit = __ballot(cost == cmin && g == 0 && ci < lsmax);

@@ -19,7 +19,7 @@ def test_bench_two_ranks_on_one_gpu():
   env = dict(os.environ, MJLAB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
   port = 29600 + os.getpid() % 300
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--envs-per-gpu", "256"]  # fmt: skip
+         "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--envs-per-gpu", "256", "--no-full-env"]  # fmt: skip
   p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
   assert p.returncode == 0, p.stderr[-2000:]
   line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
@@ -44,7 +44,7 @@ def test_bench_exchange_over_rccl_with_one_rank():
   env.pop("MJLAB_DIST_BACKEND", None)
   port = 29900 + os.getpid() % 90
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-         "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--envs-per-gpu", "256", "--no-cpu-baseline"]  # fmt: skip
+         "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--envs-per-gpu", "256", "--no-cpu-baseline", "--no-full-env"]  # fmt: skip
   p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
   assert p.returncode == 0, p.stderr[-2000:]
   d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])

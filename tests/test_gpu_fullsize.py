@@ -649,7 +649,7 @@ def test_tracking_task_resets_in_the_control_kernel_equal_the_torch_chain():
       assert float((q[:, 2] - 0.76).abs().max()) <= 0.0101 and float((q[:, 3:7].norm(dim=1) - 1).abs().max()) < 1e-6
       assert float((q[:, 7:] - tab[b.motion["time_steps"].long()[rb]]).abs().max()) <= 0.1001
       # the reset worlds are brought back in sync so that the two rollouts stay comparable
-      for f in ("qpos", "qvel"):
+      for f in ("qpos", "qvel", "qacc_warmstart"):  # (the warm start too: the forward() below starts its Newton iteration from it)
         getattr(a.sim.data, f)[ra] = getattr(b.sim.data, f)[rb]
       a.sim.forward()
       b.sim.forward()

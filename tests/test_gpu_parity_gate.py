@@ -155,6 +155,20 @@ def test_rollout_state_parity(scene, steps, precision, expand):
     assert r["worlds_with_edge_contact"] >= (0.1 if scene.startswith("g1") else 0.03) * N, r["worlds_with_edge_contact"]
 
 
+@pytest.mark.parametrize("scene", ["g1_velocity_flat", "go1_velocity_flat"])
+def test_rollout_state_parity_with_the_grid_line_search(scene, monkeypatch):
+  """The same gate with `ls_parallel=True` on both sides -- the search the reference configures (sim/sim.py:89,111) and bench.py
+  runs: mujoco_warp's grid search on the device (candidates compared by cost differences) against the
+  restatement's literal grid search in fp64.  A grid of 20 step sizes leaves the last Newton iterations a coarser choice than
+  the exact search, so more worlds end at the iteration cap on slightly different iterates; median and p99 are held to the
+  exact search's literals, the worst-world bounds are those of capped solves."""
+  from parity_report import scene_report
+
+  monkeypatch.delenv("MJLAB_LS_PARALLEL", raising=False)  # tests/conftest.py pins the exact search for the rest of the suite
+  r = scene_report(scene, N, 250, "f64", expand=("geom_friction",), flags={"ls_parallel": True})
+  _check(r, dict(FLAT, qacc_p99=2e-5, qacc_max=5e-3, qfc_max=2e-2, step_qpos_max=2e-4, step_qvel_max=1e-2, off_frac=0.04, unexplained_max=1e-4))
+
+
 def test_literal_termination_switch_matches_the_literal_oracle():
   """MJLAB_OPT_LITERAL_TERMINATION: MuJoCo's tolerance / gtol rules only, on both sides.  The fp32
   solver then runs into the iteration caps more often (it cannot resolve 1e-8), but lands on the

@@ -74,10 +74,12 @@ def short(name: str) -> str:
 
 
 def pmc_mean(path: Path) -> dict:
-  acc = collections.defaultdict(list)
+  acc, n = collections.defaultdict(list), collections.defaultdict(int)
   for r in csv.DictReader(open(path)):
-    acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-  return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+    k = short(r["Kernel_Name"])
+    acc[k].append(float(r["Counter_Value"]))
+    n[k] += int(float(r.get("Launches") or 1))  # files condensed by tools/reduce_pmc.py carry the mean and the launch count
+  return {k: (sum(v) / len(v), n[k]) for k, v in acc.items()}
 
 
 def main(tag: str, scene: str = "g1_velocity_flat") -> None:

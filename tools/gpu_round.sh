@@ -16,9 +16,9 @@ timeout 600 python bench.py --scene $SCENE > $OUT/bench.log 2>&1; echo "bench rc
 tail -1 $OUT/bench.log > $OUT/bench.json
 if [ -z "$QUICK" ]; then
   BCMD="python $R/bench.py --scene $SCENE --steps 40 --warmup 10 --no-cpu-baseline --no-full-env"  # (the full-env leg is ~25 k small torch launches: minutes under --pmc)
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- $BCMD > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/status.txt
+  (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- $BCMD > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/status.txt
   for C in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 300 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o pmc -- $BCMD > $R/$OUT/pmc_$C.log 2>&1); echo "pmc $C rc=$?" | tee -a $OUT/status.txt
+    (cd /tmp && timeout 150 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o pmc -- $BCMD > $R/$OUT/pmc_$C.log 2>&1); echo "pmc $C rc=$?" | tee -a $OUT/status.txt
   done
   if [ -n "$SQ" ]; then
     P1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"
@@ -26,7 +26,7 @@ if [ -z "$QUICK" ]; then
     i=0
     for P in "$P1" "$P2"; do
       i=$((i+1))
-      (cd /tmp && timeout 300 rocprofv3 --pmc $P --output-format csv -d $R/$OUT/pmc_SQ$i -o pmc -- $BCMD > $R/$OUT/pmc_SQ$i.log 2>&1); echo "pmc SQ$i rc=$?" | tee -a $OUT/status.txt
+      (cd /tmp && timeout 150 rocprofv3 --pmc $P --output-format csv -d $R/$OUT/pmc_SQ$i -o pmc -- $BCMD > $R/$OUT/pmc_SQ$i.log 2>&1); echo "pmc SQ$i rc=$?" | tee -a $OUT/status.txt
       python tools/reduce_pmc.py $OUT/pmc_SQ$i/pmc_counter_collection.csv
     done
   fi

@@ -114,7 +114,7 @@ def scene_report(scene: str, n: int = 1024, control_steps: int = 25, precision: 
   flags = flags or {}
   sim = Simulation(n, SimulationCfg(njmax=njmax, use_graph=False, **flags), model, "cuda:0")
   oflags = (2 if flags.get("literal_termination") else 0) | (4 if flags.get("warmstart_at_advance") else 0)
-  ora = OracleSim(model, n, njmax=njmax, precision=precision, flags=oflags)
+  ora = OracleSim(model, n, njmax=njmax, precision=precision, flags=oflags, ls_parallel=sim.ls_parallel)  # the same line search on both sides
   if expand:
     randomize_model(sim, ora, model, expand, seed + 1)
   scale = g1_action_scale(model) if scene.startswith("g1") else go1_action_scale(model)
