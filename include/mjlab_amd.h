@@ -224,6 +224,7 @@ typedef struct mjlab_control {
 } mjlab_control_t;
 int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, void* stream);
 int mjlab_sizeof_control(void); /* sizeof(mjlab_control_t), for bindings that mirror the struct */
+int mjlab_sizeof_motion_reset(void); /* sizeof(mjlab_motion_reset_t) */
 
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);

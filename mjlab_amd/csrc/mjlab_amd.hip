@@ -24,6 +24,7 @@ const char* mjlab_data_layout(void) { return MJLAB_DATA_LAYOUT_STRING; }
 int mjlab_sizeof_model(void) { return (int)sizeof(mjlab_model_t); }
 int mjlab_sizeof_data(void) { return (int)sizeof(mjlab_data_t); }
 int mjlab_sizeof_control(void) { return (int)sizeof(mjlab_control_t); }
+int mjlab_sizeof_motion_reset(void) { return (int)sizeof(mjlab_motion_reset_t); }
 
 int mjlab_lds_bytes(const mjlab_model_t* m, int stage) {
   switch (stage) {

@@ -110,7 +110,7 @@ def lib() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = (
   "mjlab_abi_version", "mjlab_last_error", "mjlab_model_layout", "mjlab_data_layout", "mjlab_sizeof_model",
-  "mjlab_sizeof_data", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest",
+  "mjlab_sizeof_data", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_sizeof_motion_reset", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest",
 )  # fmt: skip
 
 

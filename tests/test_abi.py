@@ -56,6 +56,9 @@ def test_control_struct_mirror_matches_the_library():
 
   L = native.lib()
   assert ctypes.sizeof(_Control) == L.mjlab_sizeof_control()
+  from mjlab_amd.rollout import _MotionReset
+
+  assert ctypes.sizeof(_MotionReset) == L.mjlab_sizeof_motion_reset()  # mjlab_control_t.motion points to one of these on the device
   assert ctypes.sizeof(_PushRange) == 48 and ctypes.sizeof(_View) % 8 == 0
 
 

@@ -1,11 +1,12 @@
 #!/bin/bash
-# round 3: the counter passes of the final build (tools/gpu_round.sh's, with hard per-pass limits and a GPU sanity gate first)
-TAG=r03_v8; OUT=gpurun_out/$TAG; mkdir -p $OUT
+# The counter passes of a build with hard per-pass limits (tools/gpu_round.sh's passes; condensed by tools/collect_profile.py <tag>):
+# rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE / WRITE_SIZE, two SQ passes, phase and tail profiles of the profiling library
+# (python -m mjlab_amd.native --out gpurun_prof/libmjlab_amd_prof.so -DMJLAB_PROFILE).  Usage: gpurun --timeout 480 -- 'bash tools/gpu_profile.sh <tag>'
+TAG=${1:-profile}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 R=$(pwd)
 timeout 90 python -c "import torch; x = torch.ones(1024, device='cuda'); print('gpu ok', float((x * 2).sum()))" || { echo "GPU SANITY FAILED" | tee -a $OUT/status.txt; exit 9; }
-timeout 120 python tools/diag_lsp_step.py > $OUT/diag_lsp_step.txt 2>&1; cat $OUT/diag_lsp_step.txt | grep -v amdgpu.ids
-BCMD="python $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-full-env"
+BCMD="python $R/bench.py --scene ${SCENE:-g1_velocity_flat} --steps 40 --warmup 10 --no-cpu-baseline --no-full-env"
 (cd /tmp && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- $BCMD > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/status.txt
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 120 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o pmc -- $BCMD > $R/$OUT/pmc_$C.log 2>&1); echo "pmc $C rc=$?" | tee -a $OUT/status.txt
@@ -16,10 +17,10 @@ i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
   (cd /tmp && timeout 120 rocprofv3 --pmc $P --output-format csv -d $R/$OUT/pmc_SQ$i -o pmc -- $BCMD > $R/$OUT/pmc_SQ$i.log 2>&1); echo "pmc SQ$i rc=$?" | tee -a $OUT/status.txt
-  [ -f $OUT/pmc_SQ$i/pmc_counter_collection.csv ] && python tools/reduce_pmc.py $OUT/pmc_SQ$i/pmc_counter_collection.csv
 done
-for f in $OUT/pmc_FETCH_SIZE/pmc_counter_collection.csv $OUT/pmc_WRITE_SIZE/pmc_counter_collection.csv; do [ -f $f ] && python tools/reduce_pmc.py $f; done
-MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 90 python tools/profile_phases.py > $OUT/phases.log 2>&1; echo "phases rc=$?" | tee -a $OUT/status.txt
-MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 90 python tools/tail_profile.py > $OUT/tail_profile.log 2>&1; echo "tail rc=$?" | tee -a $OUT/status.txt
+for f in $OUT/pmc_*/pmc_counter_collection.csv; do [ -f $f ] && python tools/reduce_pmc.py $f; done
+if [ -f gpurun_prof/libmjlab_amd_prof.so ]; then
+  MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 90 python tools/profile_phases.py > $OUT/phases.log 2>&1; echo "phases rc=$?" | tee -a $OUT/status.txt
+  MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof.so timeout 90 python tools/tail_profile.py > $OUT/tail_profile.log 2>&1; echo "tail rc=$?" | tee -a $OUT/status.txt
+fi
 find $OUT -name "*.db" -delete; find $OUT -name "*.csv" -size +8M -delete
-tail -3 $OUT/phases.log; tail -3 $OUT/tail_profile.log
