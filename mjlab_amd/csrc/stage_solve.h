@@ -412,7 +412,7 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
 // instructions per row trip instead of one wave reduction per candidate (20 of them for the reference's ls_iterations).
 // Candidates are compared by cost(alpha) - cost(0): the same argmin, without the common constant (see the row loop).
 template <int NVP, bool FL>
-__device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsmax) {
+__device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsmax, float* best_diff) {
   const int nc = lsmax < 64 ? (lsmax > 1 ? lsmax : 1) : 64;  // candidates per pass over the rows
   const int G = 1 + (2 * nc <= 64) + (3 * nc <= 64) + (4 * nc <= 64);  // min(4, 64 / nc) without an integer division
   const float lo = logf(min_step), step = (0.f - lo) / (float)(lsmax > 1 ? lsmax - 1 : 1);
@@ -466,6 +466,7 @@ __device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsma
     if (hit && (!have || cmin < best_cost)) { best_cost = cmin; best_alpha = lane_bcast_dyn(alpha, first); have = true; }
   }
   c.ls_iter = lsmax;
+  *best_diff = best_cost;  // cost(best alpha) - cost(0): the caller's cost bookkeeping for this iteration
   return best_alpha;
 }
 
@@ -506,6 +507,11 @@ __device__ __forceinline__ float grad_noise(float ulps, float scale, bool own, f
   return ulps * MJLAB_GNOISE * 5.9604645e-8f * scale * sqrtf(wave_sum(t * t));
 }
 
+#ifndef MJLAB_NO_LSDIFF_COST
+#define IMPROVEMENT ((m.opt.flags & MJLAB_OPT_LS_PARALLEL) ? -scale * ls_diff : scale * (oldcost - cost))
+#else
+#define IMPROVEMENT (scale * (oldcost - cost))
+#endif
 // BIG: this world has more rows than fit in LDS next to M: all njmax rows in LDS instead, M from global memory
 // CG: mjSOL_CG -- no Hessian; the direction is M^-1 grad (the factor of M from ST_SMOOTH stays in LDS for the whole solve)
 // combined with the previous direction by Polak-Ribiere (mj_solPrimal with flg_Newton = 0)
@@ -739,7 +745,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         cg_search = search; cg_grad = rhs; cg_Mgrad = Mgrad;
       }
       const float snorm = sqrtf(wave_sum(search * search));
-      float alpha = 0.f, Mv = 0.f;
+      float alpha = 0.f, Mv = 0.f, ls_diff = 0.f;
       if (snorm >= MINVAL) {
         const float gtol = tol * lstol * snorm * mi * nvf;
         Mv = BIG ? symm_mul_global<NVP>(c.M, nv, search, lane) : symm_mul_packed<NVP>(c.s_M, nv, search, lane);
@@ -755,7 +761,8 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         c.quad_gauss[2] = wave_sum(own ? 0.5f * search * Mv : 0.f);
         PROF_MARK(5);
         if (m.opt.flags & MJLAB_OPT_LS_PARALLEL)
-          alpha = c.nf > 0 ? line_search_parallel<NVP, true>(c, (float)m.opt.ls_parallel_min_step, lsmax) : line_search_parallel<NVP, false>(c, (float)m.opt.ls_parallel_min_step, lsmax);
+          alpha = c.nf > 0 ? line_search_parallel<NVP, true>(c, (float)m.opt.ls_parallel_min_step, lsmax, &ls_diff)
+                           : line_search_parallel<NVP, false>(c, (float)m.opt.ls_parallel_min_step, lsmax, &ls_diff);
         else
           alpha = c.nf > 0 ? line_search<NVP, true>(c, gtol, lsmax) : line_search<NVP, false>(c, gtol, lsmax);
         PROF_MARK(6);
@@ -780,9 +787,19 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         const bool any_changed = __ballot(changed) != 0ull;
         __syncthreads();
         const float oldcost = cost;
-        cost = constraint_cost<NVP>(c, c.s_jar);
-        gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
-        cost += gauss;
+#ifndef MJLAB_NO_LSDIFF_COST
+        if (m.opt.flags & MJLAB_OPT_LS_PARALLEL) {
+          // the grid search has just priced this very step: cost(alpha) - cost(0), formed from differences.  The improvement
+          // test below reads it directly (no second trip over the rows, no Gauss reduction, and no difference of two totals
+          // of 1e3..1e5 that differ in the 6th digit); the Gauss term itself is not needed by this search
+          cost = oldcost + ls_diff;
+        } else
+#endif
+        {
+          cost = constraint_cost<NVP>(c, c.s_jar);
+          gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
+          cost += gauss;
+        }
         // One pass over J gives J^T f for the convergence test and, if the active set
         // changed, the new Hessian tiles (kept in registers).  Laying H out in LDS and its
         // factorization happen only when another iteration follows; with an unchanged active
@@ -797,7 +814,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
           if (c.nf > 0) fc += friction_rows<NVP>(c);
           rhs = own ? Ma - qs - fc : 0.f;
-          const float improvement = scale * (oldcost - cost);
+          const float improvement = IMPROVEMENT;
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
           finished = improvement < tol || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
           if (!finished) {
@@ -812,7 +829,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           fc = hessian_accum<NVP, false>(c, unused, s_act, nact);
           if (c.nf > 0) fc += friction_rows<NVP>(c);
           rhs = own ? Ma - qs - fc : 0.f;
-          const float improvement = scale * (oldcost - cost);
+          const float improvement = IMPROVEMENT;
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
           finished = improvement < tol || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
           need_factor = false;
