@@ -403,7 +403,7 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
 }
 
 #ifndef MJLAB_LSP_U
-#define MJLAB_LSP_U 4
+#define MJLAB_LSP_U 2
 #endif
 // mujoco_warp's parallel line search (MJLAB_OPT_LS_PARALLEL, include/mjlab_fields.h): the cost at `lsmax` log-spaced step sizes in
 // [min_step, 1], the lowest cost wins (the first one on ties).  LANES ARE CANDIDATES: lane c + lsmax g evaluates step size c over
