@@ -208,3 +208,16 @@ def test_hip_matches_upstream(name, lsp, lit, wsa):
   sim.forward()
   for f in ("qpos", "xpos", "xquat"):
     assert _rel(getattr(sim.data, f).cpu().numpy(), z[f"lsp{lsp}_step_{f}"]) <= 2e-5, ("step", f)
+
+
+def test_upstream_dump_tool_stops_cleanly_without_the_engine():
+  """tools/dump_mjwarp_reference.py is one command on a machine that has mujoco + mujoco_warp; here it must say so and stop (no
+  traceback, no partial files)."""
+  import subprocess
+
+  r = subprocess.run([sys.executable, str(ROOT / "tools" / "dump_mjwarp_reference.py"), "--reference", "/nonexistent"], capture_output=True, text=True, timeout=120)
+  try:
+    import mujoco_warp  # noqa: F401
+  except ImportError:
+    assert r.returncode != 0 and "upstream engine not importable" in (r.stderr + r.stdout) and "Traceback" not in r.stderr
+    assert not (ROOT / "tests" / "golden_upstream").exists()
