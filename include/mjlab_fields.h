@@ -157,6 +157,7 @@
   X(efc_aref, 1, njmax)                                                         \
   X(efc_force, 1, njmax)                                                        \
   X(efc_frictionloss, 1, njmax) /* written for the friction-loss rows only: rows [0, nf) */ \
+  X(efc_B, 1, njmaxnv) /* MJLAB_SOL_PGS only: row r = M^-1 J_r^T (the dual solver walks AR = J M^-1 J^T + R row by row) */ \
   /* PRIVATE hand-over arrays of the pipeline, in the world's LOCAL FRAME: positions minus xorigin, the free base's position     \
    * rounded to whole metres (0 for models without a floating base).  A robot standing 100 m from the origin has fp32 world       \
    * coordinates that resolve 7.6 um; offsets between its bodies (contact point - centre of mass, geom - terrain box) formed     \
@@ -199,7 +200,7 @@ enum {
 };
 enum { MJLAB_OBJ_BODY = 1, MJLAB_OBJ_XBODY = 2, MJLAB_OBJ_GEOM = 5, MJLAB_OBJ_SITE = 6 };
 enum { MJLAB_INT_EULER = 0, MJLAB_INT_IMPLICITFAST = 3 };
-enum { MJLAB_SOL_CG = 1, MJLAB_SOL_NEWTON = 2 };
+enum { MJLAB_SOL_PGS = 0, MJLAB_SOL_CG = 1, MJLAB_SOL_NEWTON = 2 };
 /* mjtConstraint (reference typings/mujoco/_enums.pyi:1029): values of efc_type */
 enum { MJLAB_EFC_FRICTION_DOF = 1, MJLAB_EFC_LIMIT = 3, MJLAB_EFC_CONTACT_FRICTIONLESS = 5, MJLAB_EFC_CONTACT_PYRAMIDAL = 6 };
 
@@ -244,7 +245,8 @@ typedef struct mjlab_option {
   int integrator;
   int cone;
   int flags; /* MJLAB_OPT_* bits below */
-  int solver; /* mjtSolver: MJLAB_SOL_CG or MJLAB_SOL_NEWTON */
+  int solver; /* mjtSolver: MJLAB_SOL_NEWTON, MJLAB_SOL_CG, or MJLAB_SOL_PGS (the dual solver: only with one kernel per stage, i.e.
+                 neither MJLAB_OPT_FUSE_PRESOLVE nor MJLAB_OPT_FUSE_STEP, and not through mjlab_control_step) */
 } mjlab_option_t;
 /* mjlab_option_t.flags */
 enum {

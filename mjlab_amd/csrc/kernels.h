@@ -84,6 +84,7 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #include "stage_velocity.h"  // stage 3: comVel, rne, actuation, qfrc_smooth
 #include "stage_constraint.h"  // stage 4: limits + contacts -> efc rows, contact sensors
 #include "stage_solve.h"  // stages 5+6: Newton solver and integration
+#include "stage_pgs.h"  // the dual PGS solver (one kernel per stage only)
 #include "extras.h"  // fused entity read-back, masked reset, field tiling, self-test
 
 // ====================================================================================

@@ -26,6 +26,11 @@ int mjlab_sizeof_data(void) { return (int)sizeof(mjlab_data_t); }
 int mjlab_sizeof_control(void) { return (int)sizeof(mjlab_control_t); }
 int mjlab_sizeof_motion_reset(void) { return (int)sizeof(mjlab_motion_reset_t); }
 
+// the solve kernel's LDS block: the primal solvers' layout, or the dual solver's where that one is configured
+static int solve_stage_lds_floats(const mjlab_model_t* m) {
+  const int a = solve_lds_floats(m->size), b = m->opt.solver == MJLAB_SOL_PGS ? pgs_lds_floats(m->size) : 0;
+  return a > b ? a : b;
+}
 int mjlab_lds_bytes(const mjlab_model_t* m, int stage) {
   switch (stage) {
     case MJLAB_STAGE_POSITION: return 4 * position_lds_floats(m->size);
@@ -33,7 +38,7 @@ int mjlab_lds_bytes(const mjlab_model_t* m, int stage) {
     case MJLAB_STAGE_VELOCITY: return 4 * velocity_lds_floats(m->size);
     case MJLAB_STAGE_CONSTRAINT: return 4 * constraint_lds_floats(m->size);
     case MJLAB_STAGE_SOLVE:
-    case MJLAB_STAGE_INTEGRATE: return 4 * solve_lds_floats(m->size);
+    case MJLAB_STAGE_INTEGRATE: return 4 * solve_stage_lds_floats(m);
   }
   return -1;
 }
@@ -48,8 +53,10 @@ static int check_model(const mjlab_model_t* m) {
   if (m->opt.cone != 0) return fail(-5, "only the pyramidal friction cone is implemented");
   if (m->opt.integrator != MJLAB_INT_EULER && m->opt.integrator != MJLAB_INT_IMPLICITFAST)
     return fail(-6, "integrator must be Euler or implicitfast");
-  if (m->opt.solver != MJLAB_SOL_CG && m->opt.solver != MJLAB_SOL_NEWTON)
-    return fail(-20, "opt.solver must be MJLAB_SOL_NEWTON or MJLAB_SOL_CG (PGS is not implemented)");
+  if (m->opt.solver != MJLAB_SOL_CG && m->opt.solver != MJLAB_SOL_NEWTON && m->opt.solver != MJLAB_SOL_PGS)
+    return fail(-20, "opt.solver must be MJLAB_SOL_NEWTON, MJLAB_SOL_CG or MJLAB_SOL_PGS");
+  if (m->opt.solver == MJLAB_SOL_PGS && (m->opt.flags & (MJLAB_OPT_FUSE_PRESOLVE | MJLAB_OPT_FUSE_STEP)))
+    return fail(-20, "MJLAB_SOL_PGS runs with one kernel per stage only (clear MJLAB_OPT_FUSE_PRESOLVE / MJLAB_OPT_FUSE_STEP)");
   for (int st = 1; st <= 16; st <<= 1)
     if (mjlab_lds_bytes(m, st) > 160 * 1024) return fail(-7, "model too large for the LDS-resident stage kernels");
   return 0;
@@ -65,7 +72,7 @@ static int check_model(const mjlab_model_t* m) {
 static int launch_solve(const mjlab_model_t* m, const mjlab_data_t* d, int do_solve, int do_integrate, int flags, hipStream_t st) {
   const NvpLaunch* L = nvp_launch(solve_nvp(m->size.nv));
   if (!L) return fail(-3, "nv must be in [1, 64]");
-  hipError_t e = L->solve(m, d, do_solve, do_integrate, flags, 4 * solve_lds_floats(m->size), st);
+  hipError_t e = L->solve(m, d, do_solve, do_integrate, flags, 4 * solve_stage_lds_floats(m), st);
   if (e != hipSuccess) return fail((int)e, "k_solve_integrate launch failed");
   return 0;
 }
@@ -181,6 +188,7 @@ int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjla
   int rc = check_model(m);
   if (rc) return rc;
   if (!c || c->nsubstep < 0) return fail(-20, "control_step: bad argument");
+  if (m->opt.solver == MJLAB_SOL_PGS) return fail(-20, "control_step: the control kernel carries the primal solvers only (MJLAB_SOL_PGS: separate calls)");
   if (c->action && (!c->action_offset || !c->action_scale)) return fail(-20, "control_step: action without offset / scale");
   if (c->key_qpos && (!c->rnd3 || !c->episode_length || !c->reset_mask)) return fail(-15, "control_step: reset arguments missing");
   if ((c->reset_qpos != nullptr) != (c->reset_qvel != nullptr)) return fail(-15, "control_step: reset_qpos and reset_qvel come together");

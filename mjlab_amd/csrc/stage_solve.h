@@ -874,10 +874,20 @@ __device__ __forceinline__ void stage_solve(const Model& m, const Data& d, const
 }
 
 template <int NVP>
+__device__ __forceinline__ void stage_solve_pgs(const Model& m, const Data& d, const int w, const int lane, float* smem);  // stage_pgs.h
+template <int NVP>
 __global__ __launch_bounds__(64, 4) void k_solve_integrate(const Model m, const Data d, const int do_solve, const int do_integrate, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  if (m.opt.solver == MJLAB_SOL_PGS) {  // the dual solver (stage_pgs.h), then the integrator of the primal path with the solve switched off
+    if (do_solve) {
+      stage_solve_pgs<NVP>(m, d, w, lane, smem);
+      __syncthreads();
+    }
+    if (do_integrate) stage_solve<NVP>(m, d, w, lane, 0, 1, flags, smem);
+    return;
+  }
   stage_solve<NVP>(m, d, w, lane, do_solve, do_integrate, flags, smem);
 }
 

@@ -109,8 +109,8 @@ def check_supported(model: Model) -> None:
   """Reject, loudly, every model feature the HIP kernels do not implement (instead of
   silently simulating something else).  The supported set is what BASELINE.json's
   configurations use."""
-  if model.opt.solver not in (SOL_NEWTON, SOL_CG):
-    raise NotImplementedError("only the Newton and CG solvers are implemented (PGS is not)")
+  if model.opt.solver not in (SOL_NEWTON, SOL_CG, SOL_PGS):
+    raise NotImplementedError("opt.solver must be Newton, CG or PGS")
   if model.opt.cone != CONE_PYRAMIDAL:
     raise NotImplementedError("only the pyramidal cone is implemented")
   if model.opt.integrator not in (INT_EULER, INT_IMPLICITFAST):
@@ -212,13 +212,15 @@ class Simulation:
     # environment classes construct this Simulation (tools/reference_env.py): this package's extra switches then take their defaults
     ext = SimulationCfg()
     opt = lambda name: getattr(cfg, name, getattr(ext, name))  # noqa: E731
+    # the dual solver (MujocoCfg.solver = "pgs") exists as a stage kernel only: the fused launch structures carry the primal solvers
+    self.fuse = "stage" if model.opt.solver == SOL_PGS else opt("fuse")
     self._m.opt.ls_parallel_min_step = float(opt("ls_parallel_min_step"))
     self._m.opt.flags = ((self._m.opt.flags & _abi.OPT_FRICTIONLOSS) | (_abi.OPT_FOLD_FORWARD if opt("fold_forward") else 0)
                          | (_abi.OPT_LITERAL_TERMINATION if opt("literal_termination") else 0)
                          | (_abi.OPT_WARMSTART_AT_ADVANCE if opt("warmstart_at_advance") else 0)
                          | (_abi.OPT_LS_PARALLEL if self.ls_parallel else 0)
                          | (0 if (opt("local_frame") and os.environ.get("MJLAB_LOCAL_FRAME", "1") != "0") else _abi.OPT_WORLD_FRAME)
-                         | {"stage": 0, "presolve": _abi.OPT_FUSE_PRESOLVE, "step": _abi.OPT_FUSE_STEP}[opt("fuse")])
+                         | {"stage": 0, "presolve": _abi.OPT_FUSE_PRESOLVE, "step": _abi.OPT_FUSE_STEP}[self.fuse])
     self._d, self._data = device_state.alloc_data(model, num_envs, self.nconmax, self.njmax, dev)
 
     scalars = {k: int(getattr(model, k)) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nsensor", "nsensordata")}

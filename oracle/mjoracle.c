@@ -1269,6 +1269,81 @@ static real constraint_cost_at(nctx_t* c, const real* qacc, int with_gauss) {
   return cost;
 }
 
+/* ------------------------------------------------------------------ PGS (dual) solver: mj_solPGS with scalar rows
+ * (pyramidal / frictionless contacts, limits, friction loss: every row is its own block).  AR = J M^-1 J^T + diag(R), R = 1 / D,
+ * b = J qacc_smooth - aref.  Warm start (mj_fwdConstraint's warmstart()): forces of the constraint update at qacc_warmstart,
+ * kept if their dual cost 0.5 f' AR f + f' b is negative (cost of zero force = 0), else zero.  Sweep: row by row
+ * f_r -= res_r / AR_rr with res_r = b_r + (AR f)_r, projected on f >= 0 (inequality rows) or |f| <= frictionloss; a row
+ * update that would raise the cost by more than 1e-10 is undone (costChange); stop when the cost improvement of a sweep, scaled
+ * by 1 / (meaninertia max(1, nv)), drops below tolerance.  Then qfrc_constraint = J' f, qacc = qacc_smooth + M^-1 J' f.
+ * AR is never formed: B_r = M^-1 J_r' is kept per row (data.efc_B) and v = sum_r f_r B_r = M^-1 J' f is carried along. */
+static void solve_pgs(const mjo_model_t* m, mjo_data_t* d, int w) {
+  const mjlab_sizes_t* s = &m->size;
+  int nv = s->nv, njm = s->njmax, nefc = d->nefc[w], nf = d->nf[w];
+  real *qacc = D(qacc, nv), *ws = D(qacc_warmstart, nv), *qas = D(qacc_smooth, nv), *force = D(efc_force, njm), *fc = D(qfrc_constraint, nv);
+  const real *J = D(efc_J, njm * nv), *Dv = D(efc_D, njm), *aref = D(efc_aref, njm), *floss = D(efc_frictionloss, njm), *L = D(qLD, nv * nv);
+  real* B = D(efc_B, njm * nv);
+  real* buf = (real*)calloc((size_t)nv + 2 * (size_t)nefc, sizeof(real));
+  real *v = buf, *b = buf + nv, *ARinv = b + nefc;
+  for (int r = 0; r < nefc; r++) {
+    const real* row = J + (size_t)r * nv;
+    real* Br = B + (size_t)r * nv;
+    memcpy(Br, row, sizeof(real) * nv);
+    chol_solve(L, nv, Br);
+    real arr = 1 / Dv[r], br = -aref[r], x = -aref[r];
+    for (int i = 0; i < nv; i++) { arr += row[i] * Br[i]; br += row[i] * qas[i]; x += row[i] * ws[i]; }
+    ARinv[r] = 1 / arr;
+    b[r] = br;
+    /* constraint update at the warm-start acceleration (row_cost's force rule) */
+    real f;
+    if (r < nf) { real rf = floss[r] / Dv[r]; f = x <= -rf ? floss[r] : (x >= rf ? -floss[r] : -Dv[r] * x); }
+    else f = x < 0 ? -Dv[r] * x : 0;
+    force[r] = f;
+    for (int i = 0; i < nv; i++) v[i] += f * Br[i];
+  }
+  real cost = 0;
+  for (int r = 0; r < nefc; r++) {
+    const real* row = J + (size_t)r * nv;
+    real jv = 0;
+    for (int i = 0; i < nv; i++) jv += row[i] * v[i];
+    cost += force[r] * ((real)0.5 * (jv + force[r] / Dv[r]) + b[r]);
+  }
+  if (cost > 0) {
+    for (int r = 0; r < nefc; r++) force[r] = 0;
+    for (int i = 0; i < nv; i++) v[i] = 0;
+  }
+  real scale = 1 / ((real)m->opt.meaninertia * (nv > 1 ? nv : 1));
+  int iter = 0;
+  while (iter < m->opt.iterations) {
+    real improvement = 0;
+    for (int r = 0; r < nefc; r++) {
+      const real *row = J + (size_t)r * nv, *Br = B + (size_t)r * nv;
+      real res = b[r] + force[r] / Dv[r];
+      for (int i = 0; i < nv; i++) res += row[i] * v[i];
+      real old = force[r], f = old - res * ARinv[r];
+      if (r < nf) { if (f < -floss[r]) f = -floss[r]; else if (f > floss[r]) f = floss[r]; }
+      else if (f < 0) f = 0;
+      real delta = f - old, change = (real)0.5 * delta * delta / ARinv[r] + delta * res;
+      if (change > (real)1e-10) { f = old; delta = 0; change = 0; }
+      if (delta != 0) for (int i = 0; i < nv; i++) v[i] += delta * Br[i];
+      force[r] = f;
+      improvement -= change;
+    }
+    iter++;
+    if (scale * improvement < (real)m->opt.tolerance) break;
+  }
+  memset(fc, 0, sizeof(real) * nv);
+  for (int r = 0; r < nefc; r++) {
+    if (force[r] == 0) continue;
+    const real* row = J + (size_t)r * nv;
+    for (int i = 0; i < nv; i++) fc[i] += row[i] * force[r];
+  }
+  for (int i = 0; i < nv; i++) qacc[i] = qas[i] + v[i];
+  d->solver_niter[w] = iter;
+  if (!(m->opt.flags & MJLAB_OPT_WARMSTART_AT_ADVANCE)) memcpy(ws, qacc, sizeof(real) * nv);
+  free(buf);
+}
+
 static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
   const mjlab_sizes_t* s = &m->size;
   int nv = s->nv, njm = s->njmax, nefc = d->nefc[w];
@@ -1281,6 +1356,7 @@ static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
     d->solver_niter[w] = 0;
     return;
   }
+  if (m->opt.solver == MJLAB_SOL_PGS) { solve_pgs(m, d, w); return; }
   nctx_t c;
   c.nv = nv; c.nefc = nefc; c.nf = d->nf[w];
   c.J = D(efc_J, njm * nv); c.Dv = D(efc_D, njm); c.aref = D(efc_aref, njm); c.floss = D(efc_frictionloss, njm); c.M = D(qM, nv * nv);

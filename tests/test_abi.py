@@ -90,6 +90,7 @@ def test_every_bundled_scene_keeps_16_waves_per_cu_in_lds():
     model = robots.load_model(scene)
     ms = MS()
     ms.size = _abi.fill_sizes(model, 4096, *_abi.default_capacities(model, None, 300))
+    ms.opt = _abi.fill_option(model)  # (the solve stage's LDS block depends on the solver: the dual solver has its own layout)
     lds = {k: L.mjlab_lds_bytes(ctypes.byref(ms), v) for k, v in stages.items()}
     assert all(0 < b <= 10240 for b in lds.values()), (scene, lds)
     if scene.startswith("g1"):

@@ -883,6 +883,73 @@ def test_local_frame_keeps_full_precision_far_from_the_origin():
       assert far[f].max() < 3.0 * near[f].max() + 1e-6, f
 
 
+@pytest.mark.parametrize("name", ["mixed", "go1_velocity_flat", "g1_velocity_flat"])
+def test_pgs_solver_tracks_the_restatement_and_converges_to_newton(name):
+  """MujocoCfg(solver="pgs") (reference sim/sim.py:56; north_star: "the PGS/Newton constraint solver"): mj_solPGS with scalar rows
+  as a stage kernel (stage_pgs.h; Simulation switches to one kernel per stage for it).  Device vs the restatement's PGS after a
+  few sweeps from the same warm start (Gauss-Seidel in fp32 follows the fp64 path row by row: 1e-4), identical force bounds, and
+  with enough sweeps both land on the Newton solution (the dual optimum is the primal one).  Then a short rollout."""
+  import copy
+
+  import torch
+
+  from mjlab_amd import mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  base = copy.deepcopy(models()[name])
+  if name == "go1_velocity_flat":  # friction-loss rows (two-sided bounds) in the mix
+    base.dof_frictionloss = np.asarray(base.dof_frictionloss, dtype=np.float64).copy()
+    base.dof_frictionloss[6:] = 0.2
+  nworld = 16
+  qpos, qvel, ctrl = golden_inputs(base, nworld, 41)
+  per_world = lambda a, b: np.abs(a.astype(np.float64) - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-6)  # noqa: E731
+  for iterations in (4, 600):
+    model = copy.deepcopy(base)
+    model.opt.solver, model.opt.iterations = mjcf.SOL_PGS, iterations
+    sim = Simulation(nworld, SimulationCfg(njmax=300, use_graph=False), model, "cuda:0")
+    assert sim.fuse == "stage"
+    ora = OracleSim(model, nworld, njmax=300, precision="f64", flags=_abi_flags_frictionloss())
+    for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+      getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+      getattr(ora, f)[:] = v.astype(np.float32)
+    sim.data.qacc_warmstart.zero_()  # the constructor's forward() left its own solution there
+    sim.forward()
+    ora.forward(nthread=8)
+    assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
+    it_g, it_o = _np(sim.data.solver_niter).ravel(), ora.solver_niter.ravel()
+    assert it_g.max() <= iterations and (it_g[ora.nefc.ravel() > 0] >= 1).all()
+    fg = _np(sim.data.efc_force)
+    for w in range(nworld):
+      n, nf = int(ora.nefc[w, 0]), int(ora.nf[w, 0])
+      assert (fg[w, nf:n] >= 0).all() and (np.abs(fg[w, :nf]) <= _np(sim.data.efc_frictionloss)[w, :nf] + 1e-6).all()
+    err = per_world(_np(sim.data.qacc), ora.qacc)
+    if iterations == 4:
+      assert np.abs(it_g - it_o).max() <= 1
+      assert err.max() < 5e-4, err  # four sweeps of the same row-by-row path in fp32 (the fp32 build of the restatement: 1.4e-5)
+    else:
+      newton = copy.deepcopy(base)
+      newton.opt.iterations = 100
+      on = OracleSim(newton, nworld, njmax=300, precision="f64", flags=_abi_flags_frictionloss())
+      for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+        getattr(on, f)[:] = v.astype(np.float32)
+      on.forward(nthread=8)
+      print(f"{name}: PGS, {iterations} sweeps: device vs restatement median {np.median(err):.2e} max {err.max():.2e}; device vs Newton max {per_world(_np(sim.data.qacc), on.qacc).max():.2e}; "
+            f"sweeps device {it_g.mean():.1f} restatement {it_o.mean():.1f}")
+      # a linearly converging method stopped by an improvement test that fp32 resolves to ~1e-6 of the cost
+      assert np.median(per_world(_np(sim.data.qacc), on.qacc)) < 2e-3 and per_world(_np(sim.data.qacc), on.qacc).max() < 5e-2
+      for _ in range(5):
+        sim.step()
+      ora.step(5, nthread=8)
+      assert np.isfinite(_np(sim.data.qpos)).all()
+      assert np.median(per_world(_np(sim.data.qpos), ora.qpos)) < 1e-3
+
+
+def _abi_flags_frictionloss():
+  from mjlab_amd import _abi
+
+  return _abi.OPT_FRICTIONLOSS
+
+
 def test_nan_guard_dumps_the_device_ring(tmp_path):
   """reference sim/sim.py:129,191 + utils/nan_guard.py: cfg fields, `sim.nan_guard.watch`, one dump with the
   pre-step states of the last steps; the history ring stays on the device until the dump."""

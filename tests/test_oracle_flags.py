@@ -98,3 +98,45 @@ def test_ls_parallel_grid_search_descends_to_the_same_minimum():
   one_e, _ = solve(1, False)
   assert (rel(one_p, one_e) > 1e-6).mean() > 0.5  # the two searches take different first steps
   del rng
+
+
+def test_pgs_restatement_reaches_the_newton_solution():
+  """MJLAB_SOL_PGS in the restatement (mj_solPGS with scalar rows over AR = J M^-1 J^T + R, never formed: B = M^-1 J^T per row).
+  The dual problem's optimum is the primal one: with enough sweeps PGS lands on the Newton solution on every model (friction-loss
+  rows included); the iteration cap binds; forces respect their bounds after every sweep."""
+  import copy
+  import sys
+  from pathlib import Path
+
+  sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+  from make_golden import golden_inputs, models
+
+  from mjlab_amd import mjcf
+  from oracle.oracle import OracleSim
+
+  rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-9)  # noqa: E731
+  for name in ("box", "mixed", "go1_velocity_flat"):
+    base = copy.deepcopy(models()[name])
+    if name == "go1_velocity_flat":  # friction-loss rows (bounded on both sides) in the mix
+      base.dof_frictionloss = np.asarray(base.dof_frictionloss, dtype=np.float64).copy()
+      base.dof_frictionloss[6:] = 0.2
+    nw = 8
+    qpos, qvel, ctrl = golden_inputs(base, nw, 41)
+    out = {}
+    for solver, iters in ((mjcf.SOL_NEWTON, 100), (mjcf.SOL_PGS, 3), (mjcf.SOL_PGS, 4000)):
+      m = copy.deepcopy(base)
+      m.opt.solver, m.opt.iterations = solver, iters
+      o = OracleSim(m, nw, njmax=300, flags=_abi.OPT_FRICTIONLOSS)
+      o.qpos[:], o.qvel[:], o.ctrl[:] = qpos, qvel, ctrl
+      o.forward(nthread=4)
+      out[(solver, iters)] = (o.qacc.copy(), o.solver_niter.ravel().copy(), o.efc_force.copy(), o.nefc.ravel().copy(), o.nf.ravel().copy(), o.efc_frictionloss.copy())
+    newton, few, many = out[(mjcf.SOL_NEWTON, 100)], out[(mjcf.SOL_PGS, 3)], out[(mjcf.SOL_PGS, 4000)]
+    assert rel(many[0], newton[0]) < 2e-5, name
+    assert (few[1] <= 3).all() and (few[1][few[3] > 0] >= 1).all()
+    assert rel(few[0], newton[0]) > rel(many[0], newton[0])  # three sweeps are not converged
+    for w in range(nw):
+      for which in (few, many):
+        f, nefc, nf, fl = which[2][w], int(which[3][w]), int(which[4][w]), which[5][w]
+        assert (f[nf:nefc] >= 0).all() and (np.abs(f[:nf]) <= fl[:nf] + 1e-12).all()
+    if name == "go1_velocity_flat":
+      assert int(many[4].max()) > 0 and rel(many[2], newton[2]) < 1e-3

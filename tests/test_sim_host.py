@@ -13,6 +13,9 @@ from mjlab_amd.sim_data import Bridge
 def test_supported_models_pass():
   for name in robots.SCENES:
     check_supported(robots.load_model(name))
+  pgs = copy.deepcopy(robots.load_model("go1_velocity_flat"))
+  pgs.opt.solver = 0  # mjSOL_PGS: the dual solver exists since round 3 (one kernel per stage: stage_pgs.h)
+  check_supported(pgs)
   for m in (robots.box_model(), robots.mixed_model(), robots.pendulum_model()):
     check_supported(m)
 
@@ -20,7 +23,7 @@ def test_supported_models_pass():
 @pytest.mark.parametrize(
   "mutate, match",
   [
-    (lambda m: setattr(m.opt, "solver", 0), "PGS"),
+    (lambda m: setattr(m.opt, "solver", 3), "solver"),
     (lambda m: setattr(m.opt, "cone", 1), "pyramidal"),
     (lambda m: m.jnt_type.__setitem__(2, 1), "ball"),
     (lambda m: m.geom_condim.__setitem__(slice(None), 4), "condim"),
