@@ -143,11 +143,22 @@ sizes = [(int(getattr(m, k)), int(getattr(ref, k))) for k in ("nq", "nv", "nu", 
 worst = max(float(np.abs(np.asarray(getattr(m, k), float) - np.asarray(getattr(ref, k), float)).max()) for k in
             ("body_mass", "body_inertia", "dof_armature", "actuator_gainprm", "actuator_biasprm", "geom_friction", "geom_condim", "pair_geom", "dof_invweight0", "sensor_intprm"))
 cmd = env.command_manager.get_term("motion")
+env.reset()
+# what the REFERENCE's reset wrote (MotionCommand._resample_command): the invariants tests/test_gpu_fullsize.py asserts for
+# this repository's in-kernel restatement of it (mjlab_motion_reset_t)
+t = cmd.time_steps
 q0 = env.sim.data.qpos.clone()
+root = env.scene["robot"].indexing.root_body_id
+ref_z = cmd.motion.body_pos_w[t, 0, 2] + env.scene.env_origins[:, 2]
+anchor_joint_dev = float((q0[:, 7:] - cmd.motion.joint_pos[t]).abs().max())
+root_xy_dev = float((q0[:, :2] - (cmd.motion._body_pos_w[t, 0, :2] + env.scene.env_origins[:, :2])).abs().max())
+root_z_dev = float((q0[:, 2] - (cmd.motion._body_pos_w[t, 0, 2] + env.scene.env_origins[:, 2])).abs().max())
+qvel_root = float(env.sim.data.qvel[:, :3].abs().max())
 out = reference_env.random_rollout(env, 12)
 print("RESULT " + json.dumps({{"sizes": sizes, "worst": worst, "finite": all(bool(np.isfinite(o.numpy()).all()) for o in out["obs"].values()),
       "obs": {{k: list(v.shape) for k, v in out["obs"].items()}}, "resets": out["resets"], "frames": int(cmd.motion.time_step_total),
-      "phase_max": int(cmd.time_steps.max()), "dr": [float(env.sim.model.body_ipos.std(dim=0).max()), float(env.sim.model.qpos0.std(dim=0).max())]}}))
+      "phase_max": int(cmd.time_steps.max()), "dr": [float(env.sim.model.body_ipos.std(dim=0).max()), float(env.sim.model.qpos0.std(dim=0).max())],
+      "reset": [anchor_joint_dev, root_xy_dev, root_z_dev, qvel_root]}}))
 """
 
 
@@ -168,3 +179,8 @@ def test_tracking_task_constructs_and_steps(tmp_path):
   assert res["obs"] == {"policy": [8, 160], "critic": [8, 286]} and res["frames"] == 500 and res["phase_max"] < 500
   assert res["resets"] > 0  # random actions leave the motion: the anchor terminations fire, MotionCommand resamples a phase
   assert res["dr"][0] > 0.0 and res["dr"][1] > 0.0  # per-world body_ipos and qpos0 went through expand_model_fields
+  # the reference's own reset, read back: joints within the cfg's +-0.1 of the sampled motion frame, the root within the pose
+  # noise (x, y +-0.05, z +-0.01) of the motion's root, a velocity kick in qvel -- the same invariants the GPU test asserts for
+  # the in-kernel restatement (mjlab_motion_reset_t)
+  jdev, xy, z, v = res["reset"]
+  assert jdev <= 0.1 + 1e-5 and xy <= 0.05 + 1e-5 and z <= 0.01 + 1e-5 and 0.05 < v <= 0.5 + 1e-5, res["reset"]
