@@ -669,6 +669,13 @@ class Model:
     self.opt = Option()
     self.meaninertia = 1.0
 
+  @property
+  def stat(self):
+    """``mjModel.stat`` (the subset that exists here): ``meaninertia`` scales the solver's tolerances, ``extent`` the viewers."""
+    import types
+
+    return types.SimpleNamespace(meaninertia=self.meaninertia, extent=float(getattr(self, "stat_extent", None) or 1.0))
+
   # name lookups (reference use: src/mjlab/entity/entity.py:611-634)
   def _id(self, kind: str, name: str) -> int:
     try:

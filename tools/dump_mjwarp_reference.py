@@ -8,6 +8,11 @@ gap in ONE command on a machine that has them:
 
   python tools/dump_mjwarp_reference.py --reference /path/to/mjlab            # -> tests/golden_upstream/*.npz
 
+``--dry-run`` runs the SAME code path here -- the reference's task registry, Scene and MujocoCfg over this repository's
+``mujoco`` shim, and tools/fake_mjwarp.py (``mujoco_warp`` + ``warp`` backed by the fp32 oracle) in place of the engine -- and
+writes tests/golden_upstream_dryrun/ (git-ignored).  tests/test_upstream_dryrun.py does that in CI and feeds the output through
+the very comparison code the upstream tests use, so every line of this tool and of its consumers has executed before the real run.
+
 Per scene it writes two files, each with ``ls_parallel`` on (the reference's setting, sim/sim.py:89,111) AND off:
 
   <scene>.npz            the seeded states of tools/make_golden.py (4 worlds), same keys as tests/golden/<scene>.npz
@@ -77,7 +82,7 @@ def record(d, prefix: str, nworld: int, fields) -> dict:
   rec = {}
 
   def put(key, arr):
-    a = arr.numpy() if hasattr(arr, "numpy") else np.asarray(arr)
+    a = np.array(arr.numpy() if hasattr(arr, "numpy") else arr)  # a COPY: host-resident engines hand out live views
     if a.ndim >= 1 and a.shape[0] == nworld:
       rec[f"{prefix}_{key}"] = a
     else:  # a layout this script does not know (pooled constraints of older engines, ...): keep it, labelled
@@ -116,36 +121,59 @@ def run_case(mjwarp, wp, mjm, mjd, cfg, states: dict, dr: dict, ls_parallel: boo
   return rec
 
 
-def main() -> None:
-  ap = argparse.ArgumentParser()
-  ap.add_argument("--reference", required=True, help="checkout of mujocolab/mjlab with its pinned deps installed")
-  ap.add_argument("--nworld", type=int, default=4)
-  ap.add_argument("--seed", type=int, default=7)
-  ap.add_argument("--out", default=str(ROOT / "tests" / "golden_upstream"))
-  args = ap.parse_args()
+def load_engine(dry_run: bool, reference_src: Path):
+  """-> (mujoco, mjwarp, wp).  Real run: the pinned wheels.  ``--dry-run``: this repository's ``mujoco`` shim, the gym / warp /
+  prettytable stubs of tools/reference_env.py and tools/fake_mjwarp.py (``mujoco_warp`` backed by the fp32 CPU oracle), so that
+  every line below executes in the build container; its output pins nothing to upstream."""
+  if dry_run:
+    import fake_mjwarp
+    import reference_env
 
+    reference_env.install_stubs(reference_src)
+    mjwarp, wp = fake_mjwarp.install()
+    import mujoco
+
+    return mujoco, mjwarp, wp
   try:
     import mujoco
     import mujoco_warp as mjwarp
     import warp as wp
   except ImportError as e:  # the expected outcome in the build container
-    raise SystemExit(f"upstream engine not importable here ({e}); run this where mjlab's pinned deps are installed")
+    raise SystemExit(f"upstream engine not importable here ({e}); run this where mjlab's pinned deps are installed, or pass --dry-run")
+  sys.path.insert(0, str(reference_src))
+  return mujoco, mjwarp, wp
 
-  sys.path.insert(0, str(Path(args.reference) / "src"))
+
+def main() -> None:
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--reference", required=True, help="checkout of mujocolab/mjlab with its pinned deps installed")
+  ap.add_argument("--nworld", type=int, default=4)
+  ap.add_argument("--seed", type=int, default=7)
+  ap.add_argument("--out", default=None, help="default: tests/golden_upstream (tests/golden_upstream_dryrun with --dry-run)")
+  ap.add_argument("--device", default=None, help="default: cuda:0 (cpu with --dry-run)")
+  ap.add_argument("--dry-run", action="store_true", help="run the whole tool over the oracle-backed fake engine (CI; pins nothing)")
+  ap.add_argument("--rollout-worlds", type=int, default=0, help="use only the first N rollout states (0 = all)")
+  args = ap.parse_args()
+  device = args.device or ("cpu" if args.dry_run else "cuda:0")
+  out = Path(args.out or (ROOT / "tests" / ("golden_upstream_dryrun" if args.dry_run else "golden_upstream")))
+
+  mujoco, mjwarp, wp = load_engine(args.dry_run, Path(args.reference) / "src")
+  # the reference's own way from a task id to its configuration (scripts/train.py:18,129) and from there to the compiled model
+  # (envs/manager_based_env.py:63-70): importing mjlab.tasks registers every task with gymnasium
+  import mjlab.tasks  # type: ignore  # noqa: F401
   from mjlab.scene import Scene  # type: ignore
-  from mjlab.tasks.registry import load_cfg_from_registry  # type: ignore
+  from mjlab.third_party.isaaclab.isaaclab_tasks.utils.parse_cfg import load_cfg_from_registry  # type: ignore
 
   from make_golden import OUT_FIELDS, golden_inputs, models  # same seeded inputs as the oracle fixtures
 
   ours = models()
-  out = Path(args.out)
   out.mkdir(parents=True, exist_ok=True)
   fields = tuple(OUT_FIELDS) + INTERMEDIATES
   for name, task in SCENES.items():
     cfg = load_cfg_from_registry(task, "env_cfg_entry_point")
     cfg.scene.num_envs = args.nworld
-    scene = Scene(cfg.scene, device="cuda:0")
-    cfg.sim.mujoco.edit_spec(scene.spec)  # reference envs/manager_based_env.py: the task's MujocoCfg goes into the spec before compile()
+    scene = Scene(cfg.scene, device=device)
+    cfg.sim.mujoco.edit_spec(scene.spec)  # reference envs/manager_based_env.py:63: the task's MujocoCfg goes into the spec before compile()
     mjm = scene.compile()
     mjd = mujoco.MjData(mjm)
     mujoco.mj_forward(mjm, mjd)
@@ -155,7 +183,7 @@ def main() -> None:
     assert qpos.shape[1] == mjm.nq and qvel.shape[1] == mjm.nv, "model mismatch between the two compilers"
     states = {"qpos": qpos, "qvel": qvel, "ctrl": ctrl}
     rec = {"in_" + k: v for k, v in states.items()}
-    rec.update(marr, nstep=np.array(NSTEP))
+    rec.update(marr, nstep=np.array(NSTEP), dry_run=np.array(int(args.dry_run)))
     for lsp in (True, False):
       rec.update(run_case(mjwarp, wp, mjm, mjd, cfg, states, {}, lsp, fields))
     np.savez_compressed(out / f"{name}.npz", **rec)
@@ -166,11 +194,12 @@ def main() -> None:
       print("no", src, "(tools/export_rollout_states.py on the GPU box): rollout file skipped")
       continue
     z = np.load(src)
-    states = {k: z[k] for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
-    dr = {k[3:]: z[k] for k in z.files if k.startswith("dr_")}
+    sl = slice(0, args.rollout_worlds or None)
+    states = {k: z[k][sl] for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
+    dr = {k[3:]: z[k][sl] for k in z.files if k.startswith("dr_")}
     rec = {"in_" + k: v for k, v in states.items()}
     rec.update({"dr_" + k: v for k, v in dr.items()})
-    rec.update(marr, nstep=np.array(NSTEP))
+    rec.update(marr, nstep=np.array(NSTEP), dry_run=np.array(int(args.dry_run)))
     for lsp in (True, False):
       rec.update(run_case(mjwarp, wp, mjm, mjd, cfg, states, dr, lsp, fields))
     np.savez_compressed(out / f"{name}_rollout.npz", **rec)

@@ -126,6 +126,13 @@ def _gymnasium_stub() -> types.ModuleType:
   registry: dict[str, dict] = {}
   gym.Env, gym.spaces, gym.vector, gym.registry, gym.Space = Env, spaces, vector, registry, object
   gym.register = lambda id, **kw: registry.__setitem__(id, kw)
+
+  def spec(id: str):  # gymnasium.spec(): the registered EnvSpec; the reference reads .kwargs of it (isaaclab_tasks/utils/parse_cfg.py:54)
+    if id not in registry:
+      raise KeyError(f"No registered env with id: {id}")
+    return types.SimpleNamespace(id=id, entry_point=registry[id].get("entry_point"), kwargs=dict(registry[id].get("kwargs", {})))
+
+  gym.spec = spec
   gym.Wrapper = type("Wrapper", (), {})
   sys.modules.update({"gymnasium.spaces": spaces, "gymnasium.vector": vector, "gymnasium.vector.utils": vutils})
   return gym
