@@ -132,6 +132,8 @@ def main() -> None:
                   "only measured where the reference source is reachable: MJLAB_REFERENCE_SRC / gpurun_ref, tools/stage_reference.sh)")
   ap.add_argument("--settle", type=int, default=200, help="untimed control steps of set-up before the warm-up steps (start-up transient of the rollout)")
   ap.add_argument("--seed", type=int, default=42)
+  ap.add_argument("--exact-ls", action="store_true",
+                  help="MuJoCo's exact iterative line search (SimulationCfg.ls_parallel=False) instead of the reference's setting, the grid search")
   args = ap.parse_args()
 
   info = mdist.init_from_env(args.envs_per_gpu)
@@ -144,7 +146,7 @@ def main() -> None:
   torch.cuda.set_device(mdist.device_index(info))
 
   model = robots.load_model(args.scene)
-  sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), use_graph=not args.no_graph, fold_forward=not args.no_fold, fuse=args.fuse), model, dev)
+  sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), use_graph=not args.no_graph, fold_forward=not args.no_fold, fuse=args.fuse, ls_parallel=not args.exact_ls), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else go1_action_scale(model)
   robot = "g1" if args.scene.startswith("g1") else "go1"
   tracking = "tracking" in args.scene
@@ -252,7 +254,7 @@ def main() -> None:
       nh = args.envs_per_gpu // 2
       halves, hrolls = [], []
       for h in range(2):
-        hs = Simulation(nh, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), fold_forward=not args.no_fold, fuse=args.fuse), model, dev)
+        hs = Simulation(nh, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), fold_forward=not args.no_fold, fuse=args.fuse, ls_parallel=not args.exact_ls), model, dev)
         ev_h = {k: v for k, v in events.items()}
         hr = PhysicsRollout(hs, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info) + 7919 * (h + 1), fused_reset=True,
                             min_height=-1.0e9 if "motion" in events else (0.3 if robot == "g1" else 0.15), substeps_per_call=args.substeps_per_call,

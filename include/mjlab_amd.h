@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MJLAB_ABI_VERSION 1
+#define MJLAB_ABI_VERSION 2 /* 2: the round-3 struct layouts (option: ls_parallel_min_step; sizes: nstaticsite; control: motion, read-back) */
 
 /* stage bits for mjlab_forward_stages (testing / profiling of single stages) */
 enum {
@@ -52,6 +52,8 @@ const char* mjlab_model_layout(void);
 const char* mjlab_data_layout(void);
 int mjlab_sizeof_model(void);
 int mjlab_sizeof_data(void);
+int mjlab_sizeof_option(void); /* sizeof(mjlab_option_t), sizeof(mjlab_sizes_t): bindings that mirror the two host structs by hand check them at load */
+int mjlab_sizeof_sizes(void);
 
 /* Replaces mjwarp.step: advance every world by `nsubstep` physics steps
  * (forward dynamics + integration each).  Reference: sim/sim.py:189-195; the

@@ -23,6 +23,8 @@ const char* mjlab_model_layout(void) { return MJLAB_MODEL_LAYOUT_STRING; }
 const char* mjlab_data_layout(void) { return MJLAB_DATA_LAYOUT_STRING; }
 int mjlab_sizeof_model(void) { return (int)sizeof(mjlab_model_t); }
 int mjlab_sizeof_data(void) { return (int)sizeof(mjlab_data_t); }
+int mjlab_sizeof_option(void) { return (int)sizeof(mjlab_option_t); }
+int mjlab_sizeof_sizes(void) { return (int)sizeof(mjlab_sizes_t); }
 int mjlab_sizeof_control(void) { return (int)sizeof(mjlab_control_t); }
 int mjlab_sizeof_motion_reset(void) { return (int)sizeof(mjlab_motion_reset_t); }
 
@@ -93,6 +95,7 @@ static int launch_substep(const mjlab_model_t* m, const mjlab_data_t* d, int do_
 static int forward_stages_impl(const mjlab_model_t* m, const mjlab_data_t* d, int stages, int flags, void* stream) {
   int rc = check_model(m);
   if (rc) return rc;
+  if (m->opt.solver == MJLAB_SOL_PGS && !d->efc_B) return fail(-21, "MJLAB_SOL_PGS needs mjlab_data_t.efc_B (njmax x nv reals per world); it may be NULL for the primal solvers only");
   hipStream_t st = (hipStream_t)stream;
   const int all = MJLAB_STAGE_FORWARD;
   if ((stages & all) == all && (m->opt.flags & MJLAB_OPT_FUSE_STEP)) {  // a whole forward() / step() as ONE launch

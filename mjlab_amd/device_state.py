@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _abi, native
-from .mjcf import Model
+from .mjcf import SOL_PGS, Model
 
 EXTRA_MODEL_FIELDS = ("geom_rgba",)  # DR-able host fields not consumed by the kernels
 
@@ -74,6 +74,12 @@ def alloc_data(model: Model, num_envs: int, nconmax: int, njmax: int, dev: torch
     for f in df:
       n = _abi.count_of(f.count, model, nconmax, njmax)
       dtype = torch.int32 if f.kind == "i" else torch.float32
+      if f.name == "efc_B" and model.opt.solver != SOL_PGS:
+        # njmax x nv floats per world that only the dual solver reads (172 MB at 4096 G1 worlds): NULL for the primal solvers
+        # (the library refuses MJLAB_SOL_PGS with a NULL efc_B)
+        setattr(d, f.name, None)
+        data[f.name] = torch.zeros((num_envs, 0), dtype=dtype, device=dev)
+        continue
       flat = torch.zeros((num_envs, n * f.ncol), dtype=dtype, device=dev)
       setattr(d, f.name, flat.data_ptr())
       data[f.name] = shape_view(f, flat, n)

@@ -62,7 +62,8 @@ def probe_collectives() -> None:
   """Decide ONCE, and the same way on every rank, whether the backend has scatter / gather (an RCCL build may lack them): each
   is tried on a tiny tensor and the outcomes are agreed on with an all-reduce (MIN), so that no rank can end up in a fallback
   collective while its peers sit in the primary one.  gloo has both (host tensors)."""
-  global _SCATTER_SUPPORTED, _GATHER_SUPPORTED
+  global _SCATTER_SUPPORTED, _GATHER_SUPPORTED, _PROBED
+  _PROBED = True
   if not dist.is_initialized() or dist.get_backend() != "nccl":
     return
   dev = torch.device("cuda", torch.cuda.current_device())
@@ -93,6 +94,7 @@ def device_index(info: ShardInfo) -> int:
 
 
 _FORCE = False
+_PROBED = False  # probe_collectives() has run in this process group (init_from_env does it; otherwise the first exchange does)
 _SCATTER_SUPPORTED = True
 _GATHER_SUPPORTED = True  # cleared when the backend turns out to have no gather (then: all-gather, rank dst keeps the result)
 _GATHER_BUF: dict = {}  # receive buffers, reused across control steps (the result is valid until the next call)
@@ -110,6 +112,8 @@ def gather_rollout(info: ShardInfo, rows: torch.Tensor, dst: int = 0, to_all: bo
   """
   if info.world_size == 1 and not _FORCE:
     return rows
+  if not _PROBED:  # a process group the caller initialised itself (torchrun user code): every rank reaches its first exchange together
+    probe_collectives()
   rows = rows.contiguous()
   if rows.is_cuda and dist.get_backend() == "gloo":
     # gloo has no device-side gather: testing path (several ranks sharing one GPU), staged through the host
@@ -141,6 +145,8 @@ def scatter_actions(info: ShardInfo, actions_global: torch.Tensor | None, action
   if info.world_size == 1 and not _FORCE:
     assert actions_global is not None
     return actions_global
+  if not _PROBED:
+    probe_collectives()
   out = torch.empty((info.envs_per_rank, action_dim), dtype=torch.float32, device=device)
   if dist.get_backend() == "nccl":
     # Scatter: every rank receives only its own slice (475 KB at 4096 x 29), sent by the learner over that rank's own xGMI
@@ -174,6 +180,8 @@ def pingpong_steps(info: ShardInfo, nsteps: int, halves: list, learner_actions, 
   On RCCL the exchange of a half is issued on `comm_stream` (default: a side stream), ordered against the physics by events;
   gloo (CPU tests) runs everything in issue order.  Returns the rows gathered after the last step per half (rank 0; None elsewhere)."""
   nh = len(halves)
+  if info.envs_per_rank % nh:
+    raise ValueError(f"pingpong_steps: envs_per_rank = {info.envs_per_rank} is not divisible by the {nh} part batches")
   sub = ShardInfo(info.rank, info.world_size, info.local_rank, info.envs_per_rank // nh)
   cuda = torch.cuda.is_available() and str(device).startswith("cuda") and dist.is_initialized() and dist.get_backend() == "nccl"
   main = torch.cuda.current_stream(device) if cuda else None

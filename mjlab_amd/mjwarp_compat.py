@@ -137,10 +137,7 @@ def _static_geoms(m: Model, d: Data) -> None:
 
 def _sync_opt(m: Model) -> None:
   """`wp_model.opt.ls_parallel = cfg.ls_parallel` (reference sim/sim.py:111) is a plain attribute write: mirror it into the flags."""
-  import os
-
-  env_ls = os.environ.get("MJLAB_LS_PARALLEL")
-  on = bool(int(env_ls)) if env_ls not in (None, "") else bool(getattr(m.opt, "ls_parallel", False))
+  on = bool(getattr(m.opt, "ls_parallel", False))
   m.struct.opt.flags = (m.struct.opt.flags | _abi.OPT_LS_PARALLEL) if on else (m.struct.opt.flags & ~_abi.OPT_LS_PARALLEL)
   m.struct.opt.ls_parallel_min_step = float(getattr(m.opt, "ls_parallel_min_step", 1.0e-6))
 

@@ -22,6 +22,8 @@ HEADERS = [Path(__file__).parents[1] / "include" / "mjlab_amd.h", Path(__file__)
 NVP_SIZES = (8, 16, 20, 24, 32, 36, 40, 48, 64)  # padded dof counts the solve / substep / control kernels are instantiated for
 HIPCC_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=on", "--offload-arch=gfx950", "-fPIC"]
 
+ABI_VERSION = 2  # include/mjlab_amd.h MJLAB_ABI_VERSION
+
 STAGE_POSITION, STAGE_COLLISION, STAGE_VELOCITY, STAGE_CONSTRAINT, STAGE_SOLVE, STAGE_INTEGRATE = 1, 2, 4, 8, 16, 32
 STAGE_FORWARD, STAGE_STEP = 31, 63
 
@@ -75,6 +77,10 @@ def lib() -> ctypes.CDLL:
   global _LIB
   if _LIB is not None:
     return _LIB
+  stale = LIB_PATH.exists() and "MJLAB_AMD_LIB" not in os.environ and shutil.which("hipcc") is not None \
+    and LIB_PATH.stat().st_mtime < max(p.stat().st_mtime for p in SOURCES + HEADERS)
+  if stale and not os.environ.get("MJLAB_AMD_NO_AUTOBUILD"):  # a library older than its sources is rebuilt, never driven with newer struct mirrors
+    build()
   if not LIB_PATH.exists():
     if os.environ.get("MJLAB_AMD_NO_AUTOBUILD"):
       raise NativeLibraryError(f"{LIB_PATH} is missing; run `python -c 'import __graft_entry__ as g; g.build()'`")
@@ -102,15 +108,23 @@ def lib() -> ctypes.CDLL:
   L.mjlab_tile_field.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
   L.mjlab_selftest.argtypes = [ctypes.c_void_p]
   L.mjlab_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
-  if L.mjlab_abi_version() != 1:
-    raise NativeLibraryError("ABI version mismatch")
+  if L.mjlab_abi_version() != ABI_VERSION:
+    raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.mjlab_abi_version()}, this package speaks {ABI_VERSION}; rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+  # the two host structs and the control-step structs are mirrored by hand in ctypes (_abi.Option / _abi.Sizes, rollout._Control /
+  # _MotionReset): a library built from other headers would be driven with shifted fields -- refuse it here instead
+  from .rollout import _Control as Control, _MotionReset as MotionReset  # (imported here: rollout imports this module)
+
+  for what, mine, theirs in (("mjlab_option_t", ctypes.sizeof(_abi.Option), L.mjlab_sizeof_option()), ("mjlab_sizes_t", ctypes.sizeof(_abi.Sizes), L.mjlab_sizeof_sizes()),
+                             ("mjlab_control_t", ctypes.sizeof(Control), L.mjlab_sizeof_control()), ("mjlab_motion_reset_t", ctypes.sizeof(MotionReset), L.mjlab_sizeof_motion_reset())):
+    if mine != theirs:
+      raise NativeLibraryError(f"{LIB_PATH}: sizeof({what}) is {theirs} in the library, {mine} in the Python mirror; rebuild the library")
   _LIB = L
   return L
 
 
 EXPORTED_SYMBOLS = (
   "mjlab_abi_version", "mjlab_last_error", "mjlab_model_layout", "mjlab_data_layout", "mjlab_sizeof_model",
-  "mjlab_sizeof_data", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_sizeof_motion_reset", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest",
+  "mjlab_sizeof_data", "mjlab_sizeof_option", "mjlab_sizeof_sizes", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_sizeof_motion_reset", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest",
 )  # fmt: skip
 
 

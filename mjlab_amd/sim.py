@@ -69,6 +69,11 @@ class MujocoCfg:
     o.ls_tolerance = self.ls_tolerance
 
 
+# Default of SimulationCfg.ls_parallel: True like the reference's (sim/sim.py:89).  tests/conftest.py sets it to False for the suites
+# that compare with the oracle's default (exact) search; bench.py, smoke() and every user run True
+DEFAULT_LS_PARALLEL = True
+
+
 @dataclass(kw_only=True)
 class SimulationCfg:
   """Reference sim/sim.py:85-91.  ``nconmax`` is accepted for signature parity; contact
@@ -78,9 +83,10 @@ class SimulationCfg:
   njmax: int | None = None
   # True (the reference's default, sim/sim.py:89): mujoco_warp's parallel line search -- the cost at `ls_iterations` log-spaced
   # step sizes in [ls_parallel_min_step, 1], lowest cost wins (MJLAB_OPT_LS_PARALLEL, include/mjlab_fields.h; grid restated from
-  # memory of mujoco_warp, unverified).  False: MuJoCo's exact iterative search (mj_solPrimal).  The environment variable
-  # MJLAB_LS_PARALLEL=0|1 overrides the configuration (the parity suites pin the exact search with it: tests/conftest.py)
-  ls_parallel: bool = True
+  # memory of mujoco_warp, unverified).  False: MuJoCo's exact iterative search (mj_solPrimal).  What the configuration says is
+  # what runs: no environment variable overrides it (round 4; the test suite changes DEFAULT_LS_PARALLEL, the default of THIS
+  # field, through a fixture -- an explicit value, and the reference's own SimulationCfg, always win)
+  ls_parallel: bool = field(default_factory=lambda: DEFAULT_LS_PARALLEL)
   ls_parallel_min_step: float = 1.0e-6  # mujoco_warp Option.ls_parallel_min_step (not a field of the reference's cfg)
   # True: the stages compute positions in each world's local frame (origin = the floating base's position rounded to whole
   # metres: include/mjlab_fields.h, xorigin) and add the origin back in the public world-frame arrays -- a robot 100 m from
@@ -200,8 +206,7 @@ class Simulation:
     self._mj_model = model
     self._mj_data = HostData(model)
     self._lib = native.lib()
-    env_ls = os.environ.get("MJLAB_LS_PARALLEL")
-    self.ls_parallel = bool(int(env_ls)) if env_ls not in (None, "") else bool(getattr(cfg, "ls_parallel", True))
+    self.ls_parallel = bool(getattr(cfg, "ls_parallel", True))
     mf, df, MS, DS = native.layouts()
     self._mfields = {f.name: f for f in mf}
     self._dfields = {f.name: f for f in df}

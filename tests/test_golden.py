@@ -37,17 +37,36 @@ def test_oracle_reproduces_golden(name):
     assert _rel(getattr(s, f), z["step_" + f]) < 1e-8, f
 
 
+def _golden_or_grid_oracle(name, lsp):
+  """The committed vectors (fp64 oracle, exact search) -- or, for the grid search the reference configures, the same fp64 oracle
+  run here with ls_parallel on the same inputs (4 worlds x 6 passes: milliseconds), keyed like the file."""
+  z = dict(np.load(ROOT / "tests" / "golden" / f"{name}.npz"))
+  if not lsp:
+    return z
+  s = OracleSim(models()[name], z["in_qpos"].shape[0], njmax=300, precision="f64", ls_parallel=True)
+  s.qpos[:], s.qvel[:], s.ctrl[:] = z["in_qpos"], z["in_qvel"], z["in_ctrl"]
+  s.forward()
+  for f in OUT_FIELDS + ("nefc",):
+    z["fwd_" + f] = getattr(s, f).copy()
+  s.step(int(z["nstep"]))
+  s.forward()
+  for f in OUT_FIELDS + ("nefc",):
+    z["step_" + f] = getattr(s, f).copy()
+  return z
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("lsp", [False, True], ids=["exact_ls", "grid_ls"])
 @pytest.mark.parametrize("name", NAMES)
-def test_hip_matches_golden(name):
+def test_hip_matches_golden(name, lsp):
   import torch
 
   from mjlab_amd.sim import Simulation, SimulationCfg
 
-  z = np.load(ROOT / "tests" / "golden" / f"{name}.npz")
+  z = _golden_or_grid_oracle(name, lsp)
   model = models()[name]
   nworld = z["in_qpos"].shape[0]
-  sim = Simulation(nworld, SimulationCfg(njmax=300), model, "cuda:0")
+  sim = Simulation(nworld, SimulationCfg(njmax=300, ls_parallel=lsp), model, "cuda:0")
   for f in ("qpos", "qvel", "ctrl"):
     getattr(sim.data, f)[:] = torch.from_numpy(z["in_" + f].astype(np.float32)).cuda()
   sim.forward()

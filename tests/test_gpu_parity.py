@@ -64,15 +64,18 @@ def teardown_module(module):
         f.write(f"{v:10.3e}  {test}:{line}\n")
 
 
-def _pair(name, nworld=8, seed=11, graph=False, njmax=300):
+def _pair(name, nworld=8, seed=11, graph=False, njmax=300, lsp=False):
+  """`lsp`: the line search, the SAME one on both sides (True = mujoco_warp's grid search: what the reference configures and what
+  bench.py / every default Simulation run; False = MuJoCo's exact search)."""
   import torch
 
   from mjlab_amd.sim import Simulation, SimulationCfg
 
   model = models()[name]
   qpos, qvel, ctrl = golden_inputs(model, nworld, seed)
-  sim = Simulation(nworld, SimulationCfg(njmax=njmax, use_graph=graph), model, "cuda:0")
-  ora = OracleSim(model, nworld, njmax=njmax, precision="f64")
+  sim = Simulation(nworld, SimulationCfg(njmax=njmax, use_graph=graph, ls_parallel=lsp), model, "cuda:0")
+  assert sim.ls_parallel == lsp
+  ora = OracleSim(model, nworld, njmax=njmax, precision="f64", ls_parallel=lsp)
   for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
     getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
     getattr(ora, f)[:] = v
@@ -86,9 +89,10 @@ def _np(t):
   return t.cpu().numpy()
 
 
+@pytest.mark.parametrize("lsp", [False, True], ids=["exact_ls", "grid_ls"])
 @pytest.mark.parametrize("name", ["box", "mixed", "go1_velocity_flat", "g1_velocity_flat", "g1_tracking_flat"])
-def test_forward_all_fields(name):
-  sim, ora, model = _pair(name)
+def test_forward_all_fields(name, lsp):
+  sim, ora, model = _pair(name, lsp=lsp)
   sim.forward()
   ora.forward()
   assert np.array_equal(_np(sim.data.ncon).ravel(), ora.ncon.ravel())
@@ -118,8 +122,9 @@ def test_forward_all_fields(name):
     assert _elem(_np(getattr(sim.data, f)), getattr(ora, f), f) <= 30.0, f
 
 
+@pytest.mark.parametrize("lsp", [False, True], ids=["exact_ls", "grid_ls"])
 @pytest.mark.parametrize("name", ["pendulum", "box", "mixed", "go1_velocity_flat", "g1_velocity_flat"])
-def test_rollout_state(name):
+def test_rollout_state(name, lsp):
   if name == "pendulum":
     import torch
 
@@ -127,14 +132,14 @@ def test_rollout_state(name):
     from mjlab_amd.sim import Simulation, SimulationCfg
 
     model = robots.pendulum_model()
-    sim = Simulation(3, SimulationCfg(), model, "cuda:0")
-    ora = OracleSim(model, 3)
+    sim = Simulation(3, SimulationCfg(ls_parallel=lsp), model, "cuda:0")
+    ora = OracleSim(model, 3, ls_parallel=lsp)
     q0 = np.array([[0.5], [-1.0], [2.5]])
     sim.data.qpos[:] = torch.from_numpy(q0.astype(np.float32)).cuda()
     ora.qpos[:] = q0
     nstep, tq, tv = 200, 1e-4, 1e-3
   else:
-    sim, ora, model = _pair(name)
+    sim, ora, model = _pair(name, lsp=lsp)
     nstep, tq, tv = 10, 5e-6, 2e-5
   for _ in range(nstep):
     sim.step()
@@ -802,7 +807,6 @@ def test_ls_parallel_is_executed_and_matches_the_restatement(monkeypatch):
 
   from mjlab_amd.sim import Simulation, SimulationCfg
 
-  monkeypatch.delenv("MJLAB_LS_PARALLEL", raising=False)  # tests/conftest.py pins the exact search for the rest of the suite
   import copy
 
   base = models()["g1_velocity_flat"]

@@ -82,6 +82,45 @@ ROUGH = {
 TRACKING = dict(FLAT, efc_J_max=0.2, efc_J_p99=1e-4, efc_pos_abs_max=1.5e-5, qacc_p99=2.5e-5, qacc_max=5e-2, qfc_max=0.12,
                 step_qpos_max=8e-4, step_qvel_max=3e-2, off_frac=0.05, unexplained_max=3e-4)
 
+# ---- element-wise contract.  north_star's "1e-5 rel fp32" holds per world in max-norm at the
+# p99 (the literals above).  ELEMENT by element -- |gpu - oracle| <= atol(field) + 1e-5 |oracle| for every entry,
+# tools/parity_report.py::ATOL -- it holds in EVERY world for every kinematic and velocity-stage field, and in a measured fraction
+# of the worlds for the solutions of the ill-conditioned systems (qacc_smooth = M^-1 f, qacc, qfrc_constraint, the step's qvel) and for
+# efc_pos at its 0.1 um floor: the fp32 build of the restatement shows the same fractions against its own fp64 build, i.e. this is
+# fp32 rounding of the solve, not the kernels.  The floors below are the fractions measured on the GPU (profiles/r03_v15/parity_gate.txt:
+# worst of the runs of a class) minus 3 percentage points, so that a regression of the arithmetic is caught; fields not listed must
+# pass in every world.
+ELEM_ALL = ("xpos", "xquat", "xipos", "subtree_com", "geom_xpos", "site_xpos", "qM", "cvel", "qfrc_bias", "actuator_force", "qfrc_smooth")
+ELEM_FLOOR = {
+  # class: {field: floor}            measured (worst run of the class)
+  "go1_flat": {"qacc_smooth": 1.0, "efc_J": 1.0, "efc_pos": 1.0, "qacc": 0.965, "qfrc_constraint": 0.969, "step_qpos": 1.0, "step_qvel": 0.969},  # qacc .9951, qfc .999, qvel .999
+  "g1_flat": {"qacc_smooth": 0.83, "efc_J": 0.969, "efc_pos": 0.45, "qacc": 0.48, "qfrc_constraint": 0.91, "step_qpos": 0.969, "step_qvel": 0.87},  # .8631 .999 .4844 .5137 .9434 .999 .9014
+  "g1_flat_f32": {"qacc_smooth": 0.65, "efc_J": 0.969, "efc_pos": 0.45, "qacc": 0.43, "qfrc_constraint": 0.92, "step_qpos": 0.969, "step_qvel": 0.865},  # .6865 .999 .5508 .4619 .9502 1 .8975
+  "g1_tracking": {"qacc_smooth": 0.84, "efc_J": 0.89, "efc_pos": 0.51, "qacc": 0.52, "qfrc_constraint": 0.92, "step_qpos": 0.968, "step_qvel": 0.86},  # .873 .9268 .5889 .5557 .9502 .998 .8896
+  "g1_tracking_f32": {"qacc_smooth": 0.73, "efc_J": 0.89, "efc_pos": 0.51, "qacc": 0.448, "qfrc_constraint": 0.92, "step_qpos": 0.968, "step_qvel": 0.838},  # .7656 .9258 .5488 .4785 .9512 .998 .8682
+  "g1_rough": {"qacc_smooth": 0.88, "efc_J": 0.73, "efc_pos": 0.23, "qacc": 0.30, "qfrc_constraint": 0.81, "step_qpos": 0.969, "step_qvel": 0.79},  # .9169 .7617 .262 .3311 .8398 .999 .8232
+  "go1_rough": {"qacc_smooth": 1.0, "efc_J": 0.938, "efc_pos": 0.947, "qacc": 0.946, "qfrc_constraint": 0.964, "step_qpos": 1.0, "step_qvel": 0.958},  # 1 .9688 .9775 .9766 .9941 1 .9883
+}
+
+
+def _elem_class(scene, precision):
+  robot = "go1" if scene.startswith("go1") else "g1"
+  kind = "rough" if scene.endswith("rough") else ("tracking" if "tracking" in scene else "flat")
+  key = f"{robot}_{kind}"
+  return key + "_f32" if precision == "f32" and key + "_f32" in ELEM_FLOOR else key
+
+
+def _check_elem(r):
+  """Assert the element-wise fractions (the report prints them; until round 4 nothing read them)."""
+  floors = ELEM_FLOOR[_elem_class(r["scene"], r["precision"])]
+  el = r["elem"]
+  for k in ELEM_ALL:
+    assert el[k][3] == 1.0, (k, el[k], "an element of a kinematic / velocity-stage field is outside 1e-5 rel + floor")
+  for k, floor in floors.items():
+    assert el[k][3] >= floor, (k, el[k], floor)
+  assert set(el) == set(ELEM_ALL) | set(floors), sorted(set(el) ^ (set(ELEM_ALL) | set(floors)))
+
+
 CASES = [
   # scene, control steps, oracle precision, expanded model fields
   ("go1_velocity_flat", 25, "f64", ("geom_friction",)),
@@ -133,6 +172,7 @@ def _check(r, tol):
   assert off["unexplained_max"] <= tol["unexplained_max"], off
   # the Newton iteration does the same amount of work on both sides
   assert abs(r["niter_gpu"][0] - r["niter_oracle"][0]) < 0.25, (r["niter_gpu"], r["niter_oracle"])
+  _check_elem(r)
 
 
 @pytest.mark.parametrize("scene,steps,precision,expand", CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}" for c in CASES])
@@ -155,18 +195,33 @@ def test_rollout_state_parity(scene, steps, precision, expand):
     assert r["worlds_with_edge_contact"] >= (0.1 if scene.startswith("g1") else 0.03) * N, r["worlds_with_edge_contact"]
 
 
-@pytest.mark.parametrize("scene", ["g1_velocity_flat", "go1_velocity_flat"])
-def test_rollout_state_parity_with_the_grid_line_search(scene, monkeypatch):
+# the grid search's worst-world bounds: a grid of 20 step sizes leaves the last Newton iterations a coarser choice than the exact
+# search, so more worlds end at the iteration cap on slightly different iterates; median and p99 keep the exact search's literals
+GRID = dict(qacc_p99=2e-5, qacc_max=5e-3, qfc_max=2e-2, step_qpos_max=2e-4, step_qvel_max=1e-2, off_frac=0.04, unexplained_max=1e-4)
+GRID_CASES = [
+  ("g1_velocity_flat", ("geom_friction",)),
+  ("go1_velocity_flat", ("geom_friction",)),
+  ("g1_tracking_flat", ("geom_friction", "body_ipos", "qpos0")),  # BASELINE config 4 as bench.py runs it
+  ("g1_velocity_rough", ("geom_friction",)),
+  ("go1_velocity_rough", ("geom_friction",)),
+]
+
+
+@pytest.mark.parametrize("scene,expand", GRID_CASES, ids=[c[0] for c in GRID_CASES])
+def test_rollout_state_parity_with_the_grid_line_search(scene, expand):
   """The same gate with `ls_parallel=True` on both sides -- the search the reference configures (sim/sim.py:89,111) and bench.py
-  runs: mujoco_warp's grid search on the device (candidates compared by cost differences) against the
-  restatement's literal grid search in fp64.  A grid of 20 step sizes leaves the last Newton iterations a coarser choice than
-  the exact search, so more worlds end at the iteration cap on slightly different iterates; median and p99 are held to the
-  exact search's literals, the worst-world bounds are those of capped solves."""
+  and every default Simulation run: mujoco_warp's grid search on the device (candidates compared by cost differences, DESIGN.md
+  section 3) against the restatement's literal grid search in fp64 -- on every scene class, BASELINE config 4 and the rough
+  scenes included."""
   from parity_report import scene_report
 
-  monkeypatch.delenv("MJLAB_LS_PARALLEL", raising=False)  # tests/conftest.py pins the exact search for the rest of the suite
-  r = scene_report(scene, N, 250, "f64", expand=("geom_friction",), flags={"ls_parallel": True})
-  _check(r, dict(FLAT, qacc_p99=2e-5, qacc_max=5e-3, qfc_max=2e-2, step_qpos_max=2e-4, step_qvel_max=1e-2, off_frac=0.04, unexplained_max=1e-4))
+  rough = scene.endswith("rough")
+  r = scene_report(scene, N, 250, "f64", expand=expand, flags={"ls_parallel": True}, spread=3.5 if rough else None)
+  base = ROUGH if rough else (TRACKING if scene == "g1_tracking_flat" else FLAT)
+  tol = dict(base)
+  for k, v in GRID.items():
+    tol[k] = max(v, base.get(k, 0.0))
+  _check(r, tol)
 
 
 def test_literal_termination_switch_matches_the_literal_oracle():
