@@ -24,7 +24,9 @@ class OracleSimulation:
     self.cfg, self.device, self.num_envs = cfg, "cpu", num_envs
     self._mj_model = model
     self.nconmax, self.njmax = _abi.default_capacities(model, getattr(cfg, "nconmax", None), getattr(cfg, "njmax", None))
-    self.ora = OracleSim(model, num_envs, nconmax=self.nconmax, njmax=self.njmax, precision="f32")
+    # the line search the configuration asks for (the reference's SimulationCfg: ls_parallel=True, sim/sim.py:89), like Simulation
+    self.ls_parallel = bool(getattr(cfg, "ls_parallel", True))
+    self.ora = OracleSim(model, num_envs, nconmax=self.nconmax, njmax=self.njmax, precision="f32", ls_parallel=self.ls_parallel)
     mfields = _abi.parse_layout(self.ora.lib.mjo_model_layout().decode())
     dfields = _abi.parse_layout(self.ora.lib.mjo_data_layout().decode())
     self._mfields = {f.name: f for f in mfields}

@@ -18,7 +18,7 @@ def test_facade_equals_simulation_and_accepts_mjmodel_like_input():
 
   host = robots.load_model("g1_velocity_rough")
   nw = 32
-  sim = Simulation(nw, SimulationCfg(njmax=300, use_graph=False), host, "cuda:0")
+  sim = Simulation(nw, SimulationCfg(njmax=300, use_graph=False, ls_parallel=True), host, "cuda:0")
   m = mjwarp.put_model(fake_mjmodel(host))
   m.opt.ls_parallel = True  # the reference sets it (sim/sim.py:111)
   d = mjwarp.put_data(fake_mjmodel(host), None, nworld=nw, nconmax=140_000, njmax=300)
