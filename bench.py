@@ -127,6 +127,7 @@ def main() -> None:
                   help="N > 1: skip the second view in which each rank's worlds are two half batches whose learner round trips are "
                   "interleaved (mjlab_amd.dist.pingpong_steps; key `pipelined`).  `value` is always the plain synchronous exchange")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-latency-bound", action="store_true", help="skip the one-wave-per-SIMD launch that measures roofline.latency")
   ap.add_argument("--no-full-env", action="store_true",
                   help="skip value_full_env (the reference's own ManagerBasedRlEnv of the same task stepped over this Simulation; "
                   "only measured where the reference source is reachable: MJLAB_REFERENCE_SRC / gpurun_ref, tools/stage_reference.sh)")
@@ -304,7 +305,7 @@ def main() -> None:
   # kernel is k_substep<NVP, true>: `substeps_per_call` whole physics steps of every world per launch; it is
   # bracketed here launch by launch on the same rollout (states keep evolving, resets included).  The
   # per-stage figures come from a second pass that runs the stage kernels one by one (informational).
-  solve_ms, stage_ms, dom_ms, dom_name, dom_sub = None, {}, None, None, 1
+  solve_ms, stage_ms, dom_ms, dom_name, dom_sub, lat = None, {}, None, None, 1, None
   if info.rank == 0:
     reps = max(5, min(args.steps, 25))
     if roll.control_kernel:
@@ -343,6 +344,40 @@ def main() -> None:
       sim.use_graph = sim_graph
       dom_ms, dom_sub = acc / nl, roll.substeps_per_call
       dom_name = f"k_substep<{min(x for x in (8, 16, 20, 24, 32, 36, 40, 48, 64) if x >= model.nv)}, true>"
+    # ---- the bound of the regime the kernel is in.  One world per wave and 4 waves per SIMD at 4096 worlds: the
+    # launch ends when its slowest wave does, and a wave's lifetime is set by its own dependent chain (LDS / DPP / global round trips,
+    # the sequential pivots of the factorization), not by the SIMD's issue rate.  The chain is measured, not modelled: the SAME control
+    # kernel on a quarter of the worlds -- one wave per SIMD, nothing to share the issue port with -- of the same task, seed and
+    # steady state.  critical_path = that launch time; frac = critical_path / measured: the share of the full launch a wave needs when
+    # it has its SIMD to itself.  What is left (1 - frac) is what four waves cost each other (issue contention, LDS / L2 queueing).
+    lat = None
+    if roll.control_kernel and not args.no_latency_bound and args.envs_per_gpu % 4 == 0 and args.envs_per_gpu >= 1024:
+      try:
+        nq = args.envs_per_gpu // 4
+        qs = Simulation(nq, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), use_graph=False, fold_forward=not args.no_fold, fuse=args.fuse, ls_parallel=not args.exact_ls), model, dev)
+        qr = PhysicsRollout(qs, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info), fused_reset=True,
+                            min_height=-1.0e9 if "motion" in events else (0.3 if robot == "g1" else 0.15), substeps_per_call=args.substeps_per_call,
+                            control_kernel=True, **events)
+        for _ in range(args.settle + args.warmup):
+          qr._step_eager(qr.random_action())
+        accq = 0.0
+        for _ in range(reps):
+          a = qr.random_action()
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          rnd_warm = torch.rand((4,), device=dev, generator=qr.gen)  # noqa: F841
+          e0.record()
+          qr._step_eager(a)
+          e1.record()
+          torch.cuda.synchronize()
+          accq += e0.elapsed_time(e1)
+        mhz = torch.cuda.get_device_properties(dev).clock_rate / 1e3
+        lat = {"critical_path_ms": accq / reps, "measured_ms": dom_ms, "frac": (accq / reps) / dom_ms,
+               "critical_path_cycles": accq / reps * 1e-3 * mhz * 1e6, "measured_cycles": dom_ms * 1e-3 * mhz * 1e6, "clock_mhz": mhz,
+               "waves_per_simd": {"critical_path": nq / 1024.0, "measured": args.envs_per_gpu / 1024.0},
+               "how": f"same kernel, task, seed and steady state on {nq} worlds (one wave per SIMD): a wave's dependent chain without issue contention"}
+        del qs, qr
+      except Exception as e:  # noqa: BLE001
+        lat = {"error": f"{type(e).__name__}: {e}"}
     stages = [("position", 1), ("collision", 2), ("velocity", 4), ("constraint", 8), ("solve_integrate", 48)]
     acc = {k: 0.0 for k, _ in stages}
     nlaunch = 0
@@ -390,7 +425,10 @@ def main() -> None:
       achieved = algo_launch / (dom_ms * 1e-3) / 1e9
       flops_launch = prof.get(key + "_flops_per_launch")
       roof = {
-        "bound": "hbm",
+        # "latency": the regime the kernel is in (see `latency` below).  achieved / peak / frac stay the HBM figures the contract asks for
+        # (algorithmic bytes over the launch time against 8 TB/s) -- ~2 % by construction, SURVEY.md 8(d)'s consistency warning
+        "bound": "latency" if lat and "frac" in lat else "hbm",
+        "latency": lat,
         "kernel": dom_name,
         "units": {"physics_steps_per_launch": nstep, "forward_passes_per_launch": nfwd, "worlds": args.envs_per_gpu,
                   "bytes_per_world_step": algo, "bytes_per_world_forward": fwd_bytes},

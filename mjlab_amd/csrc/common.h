@@ -253,6 +253,16 @@ __device__ __forceinline__ bool dof_in_chain(const Model& m, int body, int dof) 
 // substitution (after).  LDS leading dimension LD is a multiple of 4 with LD/4 odd, so the
 // per-lane 128-bit row accesses are bank-conflict free.
 // ------------------------------------------------------------------------------------
+#ifndef MJLAB_CHOL_ACC
+#define MJLAB_CHOL_ACC 1
+#endif
+// the sweep's scheduling fences (between batches and between columns): experiment switch MJLAB_CHOL_NOBARRIER lets the
+// compiler's scheduler move one column's first multiply-adds under the previous column's pivot chain
+#ifdef MJLAB_CHOL_NOBARRIER
+#define CHOL_SCHED_BARRIER() ((void)0)
+#else
+#define CHOL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int NVP>
 struct CholCfg {
   static constexpr int LD = (NVP % 8 == 4) ? NVP : NVP + 4;
@@ -292,23 +302,27 @@ struct CholSweep {
   }
   // batch BI of column J: request the next batch (same row, or first batch of row J+1) into
   // `nxt`, feed `cur` to the FMAs, recurse with the buffers swapped
+  // MJLAB_CHOL_ACC pairs of accumulators (default 2 = four partial sums): the products of a column's dot product go round-robin into
+  // independent v_pk_fma_f32 chains, so the dependent chain of a column is J / (2 ACC) multiply-adds long instead of J / 2
   template <int J, int BI>
-  static __device__ __forceinline__ void batches(const float (&a)[NVP], f32x2& acc, float (&cur)[CB], float (&nxt)[CB], lds_f32* A) {
+  static __device__ __forceinline__ void batches(const float (&a)[NVP], f32x2 (&acc)[MJLAB_CHOL_ACC], float (&cur)[CB], float (&nxt)[CB], lds_f32* A) {
     constexpr int NBJ = (J + CB - 1) / CB, K0 = BI * CB;
     if constexpr (BI < NBJ) {
       if constexpr (BI + 1 < NBJ) load_batch<J, K0 + CB>(A, nxt);
       else if constexpr (J + 1 < NVP) load_batch<J + 1, 0>(A, nxt);
 #pragma unroll
       for (int k = 0; k < CB; k += 2) {
+        constexpr int dummy = 0; (void)dummy;
+        const int slot = ((K0 + k) >> 1) % MJLAB_CHOL_ACC;
         if (K0 + k + 1 < J) {
           const f32x2 av = {a[K0 + k], a[K0 + k + 1]};
           const f32x2 sv = {cur[k], cur[k + 1]};
-          acc -= av * sv;
+          acc[slot] -= av * sv;
         } else if (K0 + k < J) {
-          acc.x -= a[K0 + k] * cur[k];
+          acc[slot].x -= a[K0 + k] * cur[k];
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      CHOL_SCHED_BARRIER();
       batches<J, BI + 1>(a, acc, nxt, cur, A);
     }
   }
@@ -316,9 +330,15 @@ struct CholSweep {
   template <int J>
   static __device__ __forceinline__ void col(float (&a)[NVP], float (&cur)[CB], float (&oth)[CB], lds_f32* A, lds_f32* row, lds_f32* s_invd, int rowid) {
     constexpr int NBJ = (J + CB - 1) / CB;
-    f32x2 acc = {a[J], 0.f};  // two accumulators, products in pairs (v_pk_fma_f32)
+    f32x2 acc[MJLAB_CHOL_ACC];  // products in pairs (v_pk_fma_f32), round-robin over MJLAB_CHOL_ACC independent chains
+    acc[0] = (f32x2){a[J], 0.f};
+#pragma unroll
+    for (int q = 1; q < MJLAB_CHOL_ACC; ++q) acc[q] = (f32x2){0.f, 0.f};
     batches<J, 0>(a, acc, cur, oth, A);
-    const float t = acc.x + acc.y;
+    f32x2 accs = acc[0];
+#pragma unroll
+    for (int q = 1; q < MJLAB_CHOL_ACC; ++q) if (2 * q < J) accs += acc[q];
+    const float t = accs.x + accs.y;
 #ifdef MJLAB_CHOL_REFINE
     const float djj = fmaxf(lane_bcast(t, J), MINVAL);
     float invd = __builtin_amdgcn_rcpf(djj);  // v_rcp_f32 (1 ulp) + one Newton step
@@ -341,7 +361,7 @@ struct CholSweep {
         const float e = lane_bcast(lu, J + 1);
         if constexpr (NBJ % 2 == 0) cur[J] = e; else oth[J] = e;
       }
-      __builtin_amdgcn_sched_barrier(0);
+      CHOL_SCHED_BARRIER();
       if constexpr (NBJ % 2 == 0) col<J + 1>(a, cur, oth, A, row, s_invd, rowid);
       else col<J + 1>(a, oth, cur, A, row, s_invd, rowid);
     }

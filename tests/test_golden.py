@@ -261,8 +261,11 @@ def test_hip_matches_upstream(tag, name, lsp, lit, wsa):
   for _ in range(int(z["nstep"])):
     sim.step()
   sim.forward()
-  for f in ("qpos", "xpos", "xquat"):  # five steps of a harsh seeded state (measured under the grid search: 2.2e-5)
-    assert _rel(getattr(sim.data, f).cpu().numpy(), z[f"lsp{lsp}_step_{f}"]) <= (5e-5 if lsp else 2e-5), ("step", f)
+  # five steps.  Exact search: 2e-5.  Grid search (measured): 2.2e-5 on the seeded states; on the rollout states -- fallen, self-colliding
+  # robots, worlds at the iteration cap -- the worst of the 16 worlds is 1.8e-4 / 6e-4 after five steps (one step: gate GRID literal 2e-4)
+  tol_step = (2e-3 if name.endswith("_rollout") else 5e-5) if lsp else 2e-5
+  for f in ("qpos", "xpos", "xquat"):
+    assert _rel(getattr(sim.data, f).cpu().numpy(), z[f"lsp{lsp}_step_{f}"]) <= tol_step, ("step", f)
 
 
 def test_upstream_dump_tool_stops_cleanly_without_the_engine():

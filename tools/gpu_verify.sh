@@ -23,4 +23,4 @@ if [ -n "$SCENES" ]; then
   timeout 200 python bench.py --envs-per-gpu 2048 --steps 100 --warmup 20 --no-cpu-baseline --no-full-env 2>/dev/null | tail -1 > $T/bench_envs2048.json; line $T/bench_envs2048.json "g1_velocity_flat, 2048 envs"
   timeout 200 python bench.py --exact-ls --steps 150 --warmup 30 --no-cpu-baseline --no-full-env 2>/dev/null | tail -1 > $T/bench_exact_ls.json; line $T/bench_exact_ls.json "g1_velocity_flat, exact line search (ls_parallel off)"
 fi
-if ls gpurun_prof/ab_*.so > /dev/null 2>&1; then NOSMOKE=1 bash tools/ab_bench.sh --no-full-env 2>&1 | tee $T/ab.txt; fi
+if ls gpurun_prof/ab_*.so > /dev/null 2>&1; then NOSMOKE=1 bash tools/ab_bench.sh --no-full-env --no-latency-bound 2>&1 | tee $T/ab.txt; fi
