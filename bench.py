@@ -458,7 +458,7 @@ def main() -> None:
     # reference code, ~150 small torch kernels per control step around the physics) stepped over this Simulation: the full
     # env-steps/s SURVEY 8(d) asks for next to the physics-only `value`.  Only where the reference source is reachable
     # (tools/reference_env.py: MJLAB_REFERENCE_SRC / gpurun_ref staged by tools/stage_reference.sh); the driver's box has none.
-    full_env, full_env_note = None, None
+    full_env, full_env_note, full_env_graphed, full_env_graphed_note = None, None, None, None
     task = {"g1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-G1", "go1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-Go1",
             "g1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-G1", "go1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-Go1"}.get(args.scene)
     if not args.no_full_env and info.world_size == 1 and task is not None:
@@ -485,6 +485,24 @@ def main() -> None:
           full_env_note = f"{task}: the reference's ManagerBasedRlEnv.step over mjlab_amd.Simulation, {nfull} timed steps after 20, random policy"
         except Exception as e:  # noqa: BLE001
           full_env_note = f"failed: {type(e).__name__}: {e}"
+        # the same environment object with its whole control step captured into ONE hipGraph (mjlab_amd/graphed_env.py: the
+        # reference's action / termination / reward / observation managers as they are, resets / command resampling / pushes mask based)
+        if full_env is not None:
+          try:
+            from mjlab_amd.graphed_env import GraphedRlEnv
+
+            genv = GraphedRlEnv(env)
+            ngr = max(50, min(args.steps, 200))
+            for k in range(20 + ngr):
+              if k == 20:
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+              genv.step(2.0 * torch.rand((args.envs_per_gpu, na), device=dev, generator=gen) - 1.0)
+            torch.cuda.synchronize()
+            full_env_graphed = args.envs_per_gpu * ngr / (time.perf_counter() - tg)
+            full_env_graphed_note = f"the same environment, GraphedRlEnv.step (one hipGraph per control step), {ngr} timed steps after 20; x{full_env_graphed / full_env:.1f} of value_full_env"
+          except Exception as e:  # noqa: BLE001
+            full_env_graphed_note = f"failed: {type(e).__name__}: {e}"
     cpu = None
     if not args.no_cpu_baseline and info.world_size == 1:  # reported at N = 1 only
       try:
@@ -528,6 +546,8 @@ def main() -> None:
       "value_with_gather": value if exchange else value_with_rows,
       "value_full_env": full_env,
       "value_full_env_note": full_env_note,
+      "value_full_env_graphed": full_env_graphed,
+      "value_full_env_graphed_note": full_env_graphed_note,
       "std_over_5": float(np.std(chunk_rates)) if nchunk == 5 else None,
       "chunk_values": chunk_rates,
       "per_rank_ms_per_step": rank_ms,

@@ -1,0 +1,358 @@
+"""The WHOLE control step of the reference's ``ManagerBasedRlEnv`` -- action processing, 4 physics substeps, terminations,
+rewards, resets, ``forward()``, command update, interval events, observations -- captured into ONE hipGraph (SURVEY.md section 8f
+row 3; VERDICT round 3 "do this" item 5).
+
+``GraphedRlEnv(env)`` wraps an environment object the reference built (its own ``ManagerBasedRlEnv`` over
+``mjlab_amd.Simulation``: tools/reference_env.py); nothing inside ``mjlab.*`` is edited.  ``step(action)`` copies the action into
+a static buffer and replays the graph.  What the graph holds:
+
+  reference code, captured as it is (pure torch, no host round trip):
+    ``ActionManager.process_action`` / ``apply_action``        (reference envs/manager_based_rl_env.py:107-111)
+    ``TerminationManager.compute``, ``RewardManager.compute``   (:121-126; every term function of the task's cfg)
+    ``ObservationManager.compute``                              (:140; every term, noise model, concatenation)
+    ``CommandTerm._update_metrics``, every ``EntityData`` property the terms read
+  this package's physics:
+    ``Simulation.step(decimation)`` -- one launch for the 4 substeps (the action is constant across them; bit-identical to
+    the reference's 4 x [apply_action, sim.step()]), ``Simulation.forward(env_mask)``
+  MASK-BASED restatements of the parts of the reference that index with variable-length id lists -- ``reset_buf.nonzero()``
+  (:128), ``(time_left <= 0).nonzero()`` (managers/command_manager.py:57, event_manager.py:129), ``.item()`` in the managers'
+  ``reset()`` logging, ``torch.tensor(..., device=)`` uploads inside event functions -- none of which can be captured:
+    ``_reset_idx``                      (:214-249)  every manager's reset with ``torch.where(mask, ...)``
+    ``reset_root_state_uniform`` / ``reset_joints_by_scale`` / ``push_by_setting_velocity``   (envs/mdp/events.py:42-143)
+    ``CommandTerm.reset / compute / _resample`` (managers/command_manager.py:44-66) and ``UniformVelocityCommand``'s
+    ``_resample_command`` / ``_update_command`` (tasks/velocity/mdp/velocity_command.py:64-102)
+    ``EventManager.apply(mode="interval")`` (managers/event_manager.py:116-138)
+  with the same arithmetic in the same order per environment (the reference's own quaternion / sampling helpers are called);
+  what differs is which random numbers an environment draws (every environment draws, the mask selects), so environments that
+  reset, resample or get pushed in a step match the reference IN DISTRIBUTION, all others bit for bit
+  (tests/test_gpu_reference_env.py::test_graphed_env_matches_the_reference_env).
+
+``sim.forward()`` after the resets runs on all worlds exactly when some environment reset, like the reference (:129-132), decided
+on the device (``mask.any()`` broadcast into the forward mask).  A term the restatements do not know (another event function,
+another command class, curriculum terms, observation history) raises NotImplementedError at construction -- nothing is silently
+skipped.  ``extras["log"]`` holds 0-dim device tensors (the reference's floats would need a host sync per step).
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any
+
+import torch
+
+SUPPORTED_RESET_EVENTS = ("reset_root_state_uniform", "reset_joints_by_scale")
+SUPPORTED_INTERVAL_EVENTS = ("push_by_setting_velocity",)
+_AXES = ("x", "y", "z", "roll", "pitch", "yaw")
+
+
+def _range_tensors(rng: dict, device) -> tuple[torch.Tensor, torch.Tensor]:
+  r = torch.tensor([rng.get(k, (0.0, 0.0)) for k in _AXES], dtype=torch.float32)
+  return r[:, 0].to(device), r[:, 1].to(device)
+
+
+def _state_tensors(obj: Any, n: int, seen: set, out: list, depth: int = 0, path: str = "", dev_type: str | None = None) -> None:
+  """(owner, attribute | key, tensor) for every torch tensor with leading dimension n reachable from `obj` through attributes,
+  dicts and lists of objects defined in the reference's packages."""
+  if depth > 6 or id(obj) in seen:
+    return
+  seen.add(id(obj))
+  items: list = []
+  if isinstance(obj, dict):
+    items = [(obj, k, v) for k, v in obj.items()]
+  elif isinstance(obj, (list, tuple)):
+    items = [(obj, i, v) for i, v in enumerate(obj)]
+  elif hasattr(obj, "__dict__") and type(obj).__module__.split(".")[0] in ("mjlab", "mjlab_amd", "__main__"):
+    items = [(obj, k, v) for k, v in vars(obj).items()]
+  for owner, key, v in items:
+    if isinstance(v, torch.Tensor):
+      if v.dim() >= 1 and v.shape[0] == n and (dev_type is None or v.device.type == dev_type):
+        out.append((owner, key, v, f"{path}.{key}"))
+    elif isinstance(key, str) and key in ("_env", "env", "cfg", "scene", "sim", "_asset", "robot", "_entities"):
+      continue  # back references / configuration / the physics: not manager state
+    elif isinstance(v, (dict, list, tuple)) or hasattr(v, "__dict__"):
+      _state_tensors(v, n, seen, out, depth + 1, f"{path}.{key}", dev_type)
+
+
+class GraphedRlEnv:
+  def __init__(self, env: Any, capture: bool = True, warmup: int = 2) -> None:
+    from mjlab.third_party.isaaclab.isaaclab.utils import math as rmath  # the reference's own helpers (pure torch)
+
+    self.env, self._m = env, rmath
+    self.n, self.device = env.num_envs, env.device
+    self.dt = float(env.step_dt)
+    self._robot = env.scene["robot"]
+    self._action_in = torch.zeros((self.n, sum(env.action_manager.action_term_dim)), device=self.device)
+    self._check_supported()
+    self._prepare_events()
+    self.graph: torch.cuda.CUDAGraph | None = None
+    self._keep: list = []
+    env.sim.use_graph = False  # the launches are captured here, once, for the whole control step
+    if capture:
+      self.capture(warmup)
+
+  # ------------------------------------------------------------------------------------------------------------ construction
+  def _check_supported(self) -> None:
+    env = self.env
+    ev = env.event_manager
+    for mode, names in ev.active_terms.items():
+      for name, cfg in zip(names, ev._mode_term_cfgs[mode], strict=True):
+        fn = getattr(cfg.func, "__name__", type(cfg.func).__name__)
+        ok = mode == "startup" or (mode == "reset" and fn in SUPPORTED_RESET_EVENTS and cfg.min_step_count_between_reset == 0) \
+          or (mode == "interval" and fn in SUPPORTED_INTERVAL_EVENTS and not cfg.is_global_time)
+        if not ok:
+          raise NotImplementedError(f"event '{name}' ({mode}: {fn}) has no mask-based restatement in GraphedRlEnv")
+    if any(ev._mode_class_term_cfgs.get(m) for m in ("reset", "interval")):
+      raise NotImplementedError("class-based reset / interval event terms are not supported by GraphedRlEnv")
+    for name in env.command_manager.active_terms:
+      if type(env.command_manager.get_term(name)).__name__ != "UniformVelocityCommand":
+        raise NotImplementedError(f"command term '{name}' ({type(env.command_manager.get_term(name)).__name__}) has no mask-based restatement")
+    if getattr(env.curriculum_manager, "active_terms", None):
+      raise NotImplementedError("curriculum terms are not supported by GraphedRlEnv")
+    om = env.observation_manager
+    if any(om._group_obs_term_history_buffer[g] for g in om._group_obs_term_history_buffer) or any(om._group_obs_class_term_cfgs[g] for g in om._group_obs_class_term_cfgs):
+      raise NotImplementedError("observation history buffers / class-based observation terms are not supported by GraphedRlEnv")
+    if getattr(om, "_group_obs_class_instances", None):
+      raise NotImplementedError("stateful observation modifiers are not supported by GraphedRlEnv")
+    if env.termination_manager._class_term_cfgs:
+      raise NotImplementedError("class-based termination terms are not supported by GraphedRlEnv")
+
+  def _prepare_events(self) -> None:
+    """Everything the event restatements need that the reference builds per call with ``torch.tensor(..., device=)``."""
+    ev, dev = self.env.event_manager, self.device
+    self._reset_terms, self._interval_terms = [], []
+    for cfg in ev._mode_term_cfgs.get("reset", []):
+      p, fn = cfg.params, cfg.func.__name__
+      if fn == "reset_root_state_uniform":
+        self._reset_terms.append((fn, {"pose": _range_tensors(p["pose_range"], dev), "vel": _range_tensors(p["velocity_range"], dev)}))
+      else:
+        ids = p["asset_cfg"].joint_ids
+        ids = slice(None) if isinstance(ids, slice) else torch.as_tensor(ids, device=dev, dtype=torch.long)
+        self._reset_terms.append((fn, {"position_range": p["position_range"], "velocity_range": p["velocity_range"], "joint_ids": ids}))
+    for index, cfg in enumerate(ev._mode_term_cfgs.get("interval", [])):
+      self._interval_terms.append((index, cfg.interval_range_s, _range_tensors(cfg.params["velocity_range"], dev)))
+
+  # ---------------------------------------------------------------------------------------------------------------- capture
+  def capture(self, warmup: int = 2) -> None:
+    """Warm-up passes on a side stream (allocator, lazy initialisation inside the reference's properties), then the capture."""
+    s = torch.cuda.Stream(device=self.device)
+    s.wait_stream(torch.cuda.current_stream(self.device))
+    with torch.cuda.stream(s):
+      for _ in range(warmup):
+        self._body()
+    torch.cuda.current_stream(self.device).wait_stream(s)
+    torch.cuda.synchronize(self.device)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+      self._body()
+    self.graph = g
+    self._out = (self.env.obs_buf, self.env.reward_buf, self.env.reset_terminated, self.env.reset_time_outs)
+
+  def step(self, action: torch.Tensor):
+    env = self.env
+    self._action_in.copy_(action)
+    if self.graph is not None:
+      self.graph.replay()
+    else:
+      self._body()
+    env._sim_step_counter += env.cfg.decimation
+    env.common_step_counter += 1
+    if env.common_step_counter % 16 == 0 and hasattr(env.sim, "update_priority_thresholds"):
+      env.sim.update_priority_thresholds()  # scheduling hint of the physics kernels (not part of the graph: it reads quantiles)
+    return env.obs_buf, env.reward_buf, env.reset_terminated, env.reset_time_outs, env.extras
+
+  # ------------------------------------------------------------------------------------------------------------------- body
+  def _body(self) -> None:
+    """reference envs/manager_based_rl_env.py:106-147, in its order."""
+    env = self.env
+    before = self._snapshot_bindings()
+    env.action_manager.process_action(self._action_in)
+    env.action_manager.apply_action()  # the same ctrl before each of the substeps (:109-113)
+    env.scene.write_data_to_sim()
+    env.sim.step(env.cfg.decimation)
+    env.scene.update(dt=env.physics_dt)
+    env.episode_length_buf += 1
+    env.reset_buf = env.termination_manager.compute()
+    env.reset_terminated = env.termination_manager.terminated
+    env.reset_time_outs = env.termination_manager.time_outs
+    env.reward_buf = env.reward_manager.compute(dt=self.dt)
+    mask = env.reset_buf
+    self._masked_reset(mask)
+    env.scene.write_data_to_sim()
+    env.sim.forward(env_mask=mask.any().expand(self.n))  # all worlds iff some environment reset (:129-132)
+    self._command_compute()
+    self._interval_events()
+    env.obs_buf = env.observation_manager.compute(update_history=True)
+    self._restore_bindings(before)
+
+  # State the reference carries by REBINDING an attribute to a new tensor (``self.x = torch.where(...)``) would be lost between
+  # replays (the captured kernels read the tensor the attribute pointed to at capture time): after the body such attributes
+  # get their new value copied into the original tensor and are bound back to it.
+  def _snapshot_bindings(self) -> list:
+    env, out = self.env, []
+    for mgr in (env.action_manager, env.reward_manager, env.termination_manager, env.command_manager, env.observation_manager, env.event_manager):
+      _state_tensors(mgr, self.n, set(), out)
+    return out
+
+  def _restore_bindings(self, before: list) -> None:
+    for owner, key, old, _ in before:
+      new = owner[key] if isinstance(owner, (dict, list)) else getattr(owner, key)
+      if new is not old and isinstance(new, torch.Tensor) and new.shape == old.shape:
+        old.copy_(new)
+        if isinstance(owner, (dict, list)):
+          owner[key] = old
+        else:
+          setattr(owner, key, old)
+
+  # ------------------------------------------------------------------------------------------------------------------ reset
+  def _masked_reset(self, mask: torch.Tensor) -> None:
+    """``_reset_idx`` (:214-249) for the environments of `mask`, in its order."""
+    env, m1 = self.env, mask[:, None]
+    cnt = mask.sum().clamp(min=1).to(torch.float32)
+    log: dict = {}
+    # scene.reset -> Entity.clear_state (entity/data.py:171-181)
+    d, ix = self._robot.data.data, self._robot.indexing
+    keep = (~mask).to(torch.float32)
+    d.qfrc_applied[:, ix.free_joint_v_adr] = d.qfrc_applied[:, ix.free_joint_v_adr] * keep[:, None]
+    d.xfrc_applied[:, ix.body_ids] = d.xfrc_applied[:, ix.body_ids] * keep[:, None, None]
+    d.ctrl[:, ix.ctrl_ids] = d.ctrl[:, ix.ctrl_ids] * keep[:, None]
+    # reset-mode events (managers/event_manager.py:139-148 with min_step_count 0)
+    step_count = env._sim_step_counter // env.cfg.decimation  # (baked in at capture; read by nothing the supported terms use)
+    for index, (fn, prm) in enumerate(self._reset_terms):
+      env.event_manager._reset_term_last_triggered_step_id[index].masked_fill_(mask, step_count)
+      env.event_manager._reset_term_last_triggered_once[index].masked_fill_(mask, True)
+      getattr(self, "_" + fn)(mask, **prm)
+    # observation manager: nothing stateful (checked at construction).  action manager (managers/action_manager.py:101-110):
+    am = env.action_manager
+    am._prev_action.masked_fill_(m1, 0.0)
+    am._action.masked_fill_(m1, 0.0)
+    for term in am._terms.values():
+      term._raw_actions.masked_fill_(m1, 0.0)
+    # reward manager (managers/reward_manager.py:60-74)
+    rm = env.reward_manager
+    for key, sums in rm._episode_sums.items():
+      log["Episode_Reward/" + key] = (sums * mask).sum() / cnt / env.max_episode_length_s
+      sums.masked_fill_(mask, 0.0)
+    for cfg in rm._class_term_cfgs:
+      self._masked_class_reset(cfg.func, mask)
+    # command manager (managers/command_manager.py:44-53)
+    for name in env.command_manager.active_terms:
+      term = env.command_manager.get_term(name)
+      for metric, value in term.metrics.items():
+        log[f"Metrics/{name}/{metric}"] = (value * mask).sum() / cnt
+        value.masked_fill_(mask, 0.0)
+      term.command_counter.masked_fill_(mask, 0)
+      self._command_resample(term, mask)
+    # termination manager (managers/termination_manager.py:73-85)
+    for key, dones in env.termination_manager._term_dones.items():
+      log["Episode_Termination/" + key] = (dones & mask).sum()
+    env.extras["log"] = log
+    env.episode_length_buf.masked_fill_(mask, 0)
+
+  def _masked_class_reset(self, func: Any, mask: torch.Tensor) -> None:
+    """A class-based term's own ``reset()`` run on ALL environments, kept only where `mask` is set."""
+    state: list = []
+    _state_tensors(func, self.n, set(), state)
+    saved = [(owner, key, t, t.clone()) for owner, key, t, _ in state]
+    func.reset(env_ids=None)
+    for owner, key, t, old in saved:
+      cur = owner[key] if isinstance(owner, (dict, list)) else getattr(owner, key)
+      mm = mask.view(-1, *([1] * (t.dim() - 1)))
+      t.copy_(torch.where(mm, cur, old))
+      if cur is not t:
+        if isinstance(owner, (dict, list)):
+          owner[key] = t
+        else:
+          setattr(owner, key, t)
+
+  def _reset_root_state_uniform(self, mask: torch.Tensor, pose, vel) -> None:
+    """envs/mdp/events.py:42-91."""
+    env, rm, robot = self.env, self._m, self._robot
+    d, ix = robot.data.data, robot.indexing
+    root = robot.data.default_root_state
+    rs = rm.sample_uniform(pose[0], pose[1], (self.n, 6), device=self.device)
+    positions = root[:, 0:3] + rs[:, 0:3] + env.scene.env_origins
+    orientations = rm.quat_mul(root[:, 3:7], rm.quat_from_euler_xyz(rs[:, 3], rs[:, 4], rs[:, 5]))
+    velocities = root[:, 7:13] + rm.sample_uniform(vel[0], vel[1], (self.n, 6), device=self.device)
+    velocities = torch.cat([velocities[:, :3], rm.quat_apply_inverse(orientations, velocities[:, 3:])], dim=-1)
+    m1 = mask[:, None]
+    d.qpos[:, ix.free_joint_q_adr] = torch.where(m1, torch.cat([positions, orientations], dim=-1), d.qpos[:, ix.free_joint_q_adr])
+    d.qvel[:, ix.free_joint_v_adr] = torch.where(m1, velocities, d.qvel[:, ix.free_joint_v_adr])
+
+  def _reset_joints_by_scale(self, mask: torch.Tensor, position_range, velocity_range, joint_ids) -> None:
+    """envs/mdp/events.py:94-124."""
+    rm, robot = self._m, self._robot
+    d, ix = robot.data.data, robot.indexing
+    jp = robot.data.default_joint_pos[:, joint_ids].clone()
+    jv = robot.data.default_joint_vel[:, joint_ids].clone()
+    jp *= rm.sample_uniform(*position_range, jp.shape, self.device)
+    jv *= rm.sample_uniform(*velocity_range, jv.shape, self.device)
+    lim = robot.data.soft_joint_pos_limits[:, joint_ids]
+    jp = jp.clamp_(lim[..., 0], lim[..., 1])
+    qa, va, m1 = ix.joint_q_adr[joint_ids], ix.joint_v_adr[joint_ids], mask[:, None]
+    d.qpos[:, qa] = torch.where(m1, jp, d.qpos[:, qa])
+    d.qvel[:, va] = torch.where(m1, jv, d.qvel[:, va])
+
+  # --------------------------------------------------------------------------------------------------------------- commands
+  def _command_resample(self, term: Any, mask: torch.Tensor) -> None:
+    """CommandTerm._resample (managers/command_manager.py:62-66) + UniformVelocityCommand._resample_command
+    (tasks/velocity/mdp/velocity_command.py:64-90) for the environments of `mask`."""
+    cfg, n, dev = term.cfg, self.n, self.device
+    u = lambda lo, hi: torch.rand(n, device=dev) * (hi - lo) + lo  # noqa: E731
+    term.time_left.copy_(torch.where(mask, u(*cfg.resampling_time_range), term.time_left))
+    v = term.vel_command_b
+    v[:, 0] = torch.where(mask, u(*cfg.ranges.lin_vel_x), v[:, 0])
+    v[:, 1] = torch.where(mask, u(*cfg.ranges.lin_vel_y), v[:, 1])
+    v[:, 2] = torch.where(mask, u(*cfg.ranges.ang_vel_z), v[:, 2])
+    if cfg.heading_command:
+      term.heading_target.copy_(torch.where(mask, u(*cfg.ranges.heading), term.heading_target))
+      term.is_heading_env.copy_(torch.where(mask, u(0.0, 1.0) <= cfg.rel_heading_envs, term.is_heading_env))
+    term.is_standing_env.copy_(torch.where(mask, u(0.0, 1.0) <= cfg.rel_standing_envs, term.is_standing_env))
+    if cfg.init_velocity_prob > 0.0:
+      rm, rd = self._m, term.robot.data
+      d, ix = rd.data, term.robot.indexing
+      im = mask & (u(0.0, 1.0) < cfg.init_velocity_prob)
+      lin_b = rd.root_link_lin_vel_b.clone()
+      lin_b[:, :2] = v[:, :2]
+      ang_b = rd.root_link_ang_vel_b.clone()
+      ang_b[:, 2] = v[:, 2]
+      state = torch.cat([rd.root_link_pos_w, rd.root_link_quat_w], dim=-1)
+      vel = torch.cat([rm.quat_apply(rd.root_link_quat_w, lin_b), ang_b], dim=-1)
+      d.qpos[:, ix.free_joint_q_adr] = torch.where(im[:, None], state, d.qpos[:, ix.free_joint_q_adr])
+      d.qvel[:, ix.free_joint_v_adr] = torch.where(im[:, None], vel, d.qvel[:, ix.free_joint_v_adr])
+    term.command_counter += mask.to(term.command_counter.dtype)
+
+  def _command_compute(self) -> None:
+    """CommandManager.compute -> CommandTerm.compute (managers/command_manager.py:55-60) + UniformVelocityCommand._update_command
+    (tasks/velocity/mdp/velocity_command.py:92-102)."""
+    rm = self._m
+    for name in self.env.command_manager.active_terms:
+      term = self.env.command_manager.get_term(name)
+      cfg = term.cfg
+      term._update_metrics()  # the reference's own
+      term.time_left -= self.dt
+      self._command_resample(term, term.time_left <= 0.0)
+      v = term.vel_command_b
+      if cfg.heading_command:
+        err = rm.wrap_to_pi(term.heading_target - term.robot.data.heading_w)
+        yaw = torch.clip(cfg.heading_control_stiffness * err, min=cfg.ranges.ang_vel_z[0], max=cfg.ranges.ang_vel_z[1])
+        v[:, 2] = torch.where(term.is_heading_env, yaw, v[:, 2])
+      v.masked_fill_(term.is_standing_env[:, None], 0.0)
+
+  # ---------------------------------------------------------------------------------------------------------------- interval
+  def _interval_events(self) -> None:
+    """EventManager.apply(mode="interval") (managers/event_manager.py:116-138) + push_by_setting_velocity
+    (envs/mdp/events.py:127-143)."""
+    rm, robot, ev = self._m, self._robot, self.env.event_manager
+    d, ix = robot.data.data, robot.indexing
+    for index, (lo, hi), (vlo, vhi) in self._interval_terms:
+      time_left = ev._interval_term_time_left[index]
+      time_left -= self.dt
+      trig = time_left < 1e-6
+      time_left.copy_(torch.where(trig, torch.rand(self.n, device=self.device) * (hi - lo) + lo, time_left))
+      vel_w = robot.data.root_link_vel_w + rm.sample_uniform(vlo, vhi, (self.n, 6), device=self.device)
+      vel_w = torch.cat([vel_w[:, :3], rm.quat_apply_inverse(robot.data.root_link_quat_w, vel_w[:, 3:])], dim=-1)
+      d.qvel[:, ix.free_joint_v_adr] = torch.where(trig[:, None], vel_w, d.qvel[:, ix.free_joint_v_adr])
+
+
+def max_episode_steps(env: Any) -> int:
+  return int(math.ceil(env.max_episode_length_s / env.step_dt))

@@ -1,0 +1,139 @@
+"""TEST INFRASTRUCTURE shared by the CPU and the GPU test of ``mjlab_amd.graphed_env.GraphedRlEnv``: the graph-captured control
+step against the reference's own ``ManagerBasedRlEnv.step``, teacher-forced.
+
+Two environments of the same registered task are built with the same seed: A is stepped by the reference's ``env.step`` (eager,
+index lists, host syncs), B by ``GraphedRlEnv.step`` (mask based; one hipGraph on the GPU, the same Python body uncaptured on the
+CPU).  Before every step the COMPLETE state of A -- every mjData array, every manager / term buffer, the counters -- is copied
+into B, both get the same action, and the outputs are compared:
+
+  * ``terminated``, ``time_outs`` and ``reward`` are computed before any random number is drawn: equal bit for bit in EVERY env;
+  * environments that did not reset, resample their command or get pushed in this step drew no random numbers: their
+    observations, state and commands are equal bit for bit;
+  * the others match in distribution, checked against the event / command configuration (reset pose inside the cfg's ranges
+    around the default root state, default joints, zero velocity, zeroed action history and episode length; commands inside
+    their ranges; pushes inside the velocity range).
+"""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tools"))
+
+from mjlab_amd.graphed_env import GraphedRlEnv, _state_tensors  # noqa: E402
+
+
+def _edit(cfg):
+  for group in ("policy", "critic"):
+    getattr(cfg.observations, group).enable_corruption = False  # (noise draws differ between the two by construction)
+  cfg.episode_length_s = 0.6  # 30 control steps: time-outs in every run
+  cfg.events.push_robot.interval_range_s = (0.1, 0.4)  # pushes every 5..20 steps
+  cfg.commands.twist.resampling_time_range = (0.2, 0.5)  # command resampling inside an episode, not only at resets
+
+
+def _managers(env):
+  return (env.action_manager, env.reward_manager, env.termination_manager, env.command_manager, env.observation_manager, env.event_manager)
+
+
+def _sync(a, b) -> None:
+  """Everything env.step reads: mjData, manager / term state, counters."""
+  for k, t in a.sim._data.items():
+    b.sim._data[k].copy_(t)
+  n = a.num_envs
+  sa, sb = [], []
+  for ma, mb in zip(_managers(a), _managers(b), strict=True):
+    _state_tensors(ma, n, set(), sa)
+    _state_tensors(mb, n, set(), sb)
+  assert [p for *_, p in sa] == [p for *_, p in sb], "the two environments do not hold the same state tensors"
+  for (_, _, ta, _), (_, _, tb, _) in zip(sa, sb, strict=True):
+    tb.copy_(ta)
+  b.episode_length_buf.copy_(a.episode_length_buf)
+  b._sim_step_counter, b.common_step_counter = a._sim_step_counter, a.common_step_counter
+
+
+def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: bool = True) -> dict:
+  torch.manual_seed(0)
+  a = make_env(num_envs, device, _edit)
+  b = make_env(num_envs, device, _edit)
+  a.reset()
+  b.reset()
+  g = GraphedRlEnv(b, capture=capture)
+  gen = torch.Generator(device=device)
+  gen.manual_seed(3)
+  robot = a.scene["robot"]
+  ix = robot.indexing
+  cmd_a, cmd_b = a.command_manager.get_term("twist"), b.command_manager.get_term("twist")
+  ev = a.event_manager
+  push_cfg = next(c for c in ev._mode_term_cfgs["interval"])
+  reset_cfg = next(c for c in ev._mode_term_cfgs["reset"] if c.func.__name__ == "reset_root_state_uniform")
+  stats = {"resets": 0, "resamples": 0, "pushes": 0, "quiet_env_steps": 0, "forward_steps": 0}
+  dt = a.step_dt
+  for k in range(steps):
+    _sync(a, b)
+    action = torch.rand((num_envs, 29), device=device, generator=gen) * 2 - 1
+    if k > 20:
+      action[: num_envs // 8] *= 6.0  # a few robots flail and fall: fell_over terminations besides the time-outs
+    # which envs will draw random numbers in this step (a function of the synced pre-step state)
+    resample = (cmd_a.time_left - dt) <= 0.0
+    push = (ev._interval_term_time_left[0] - dt) < 1e-6
+    obs_a, rew_a, term_a, to_a, _ = a.step(action.clone())
+    obs_b, rew_b, term_b, to_b, _ = g.step(action.clone())
+    if device != "cpu":
+      torch.cuda.synchronize()
+    assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b), k
+    assert torch.equal(rew_a, rew_b), (k, (rew_a - rew_b).abs().max())
+    reset = term_a | to_a
+    noisy = reset | resample | push
+    quiet = ~noisy
+    for grp in obs_a:
+      assert torch.equal(obs_a[grp][quiet], obs_b[grp][quiet]), (k, grp, (obs_a[grp][quiet] - obs_b[grp][quiet]).abs().max())
+    for f in ("qpos", "qvel", "ctrl", "xpos", "cvel", "qacc_warmstart"):
+      assert torch.equal(getattr(a.sim.data, f)[quiet], getattr(b.sim.data, f)[quiet]), (k, f)
+    assert torch.equal(cmd_a.command[quiet], cmd_b.command[quiet]) and torch.equal(cmd_a.time_left[quiet], cmd_b.time_left[quiet])
+    assert torch.equal(a.episode_length_buf, b.episode_length_buf)
+    assert torch.equal(a.action_manager.action, b.action_manager.action) and torch.equal(a.action_manager.prev_action, b.action_manager.prev_action)
+    # ---- the environments that drew random numbers: same distribution, checked against the configuration
+    for env in (a, b):
+      d = env.sim.data
+      if reset.any():
+        q, v = d.qpos[reset], d.qvel[reset]
+        root0 = env.scene["robot"].data.default_root_state[reset]
+        org = env.scene.env_origins[reset]
+        pr = reset_cfg.params["pose_range"]
+        dx = q[:, 0:3] - root0[:, 0:3] - org
+        assert bool((dx[:, 0].abs() <= pr["x"][1] + 1e-6).all()) and bool((dx[:, 1].abs() <= pr["y"][1] + 1e-6).all()) and bool((dx[:, 2].abs() <= 1e-6).all())
+        assert bool(((q[:, 3:7].norm(dim=1) - 1).abs() < 1e-5).all()) and bool((q[:, 4:6].abs() < 1e-6).all())  # a yaw rotation of the default orientation
+        pushed_now = push[reset]
+        assert bool((v[~pushed_now] == 0).all())  # velocity_range {} and joint velocity scale (0, 0); a push may follow in the same step
+        jp = q[:, 7:]
+        lim = env.scene["robot"].data.soft_joint_pos_limits[reset]
+        exp = env.scene["robot"].data.default_joint_pos[reset].clamp(lim[..., 0], lim[..., 1])
+        assert torch.equal(jp, exp)
+        assert bool((env.episode_length_buf[reset] == 0).all()) and bool((env.action_manager.action[reset] == 0).all())
+      cm = env.command_manager.get_term("twist")
+      c, rg = cm.command, cm.cfg.ranges
+      assert bool((c[:, 0] >= rg.lin_vel_x[0] - 1e-6).all()) and bool((c[:, 0] <= rg.lin_vel_x[1] + 1e-6).all())
+      assert bool((c[:, 1] >= rg.lin_vel_y[0] - 1e-6).all()) and bool((c[:, 1] <= rg.lin_vel_y[1] + 1e-6).all())
+      assert bool((c[:, 2] >= rg.ang_vel_z[0] - 1e-6).all()) and bool((c[:, 2] <= rg.ang_vel_z[1] + 1e-6).all())
+      rs = resample | reset
+      if rs.any():
+        lo, hi = cm.cfg.resampling_time_range  # (a reset resamples, then the same step's compute() takes dt off)
+        assert bool((cm.time_left[rs] >= lo - dt - 1e-6).all()) and bool((cm.time_left[rs] <= hi + 1e-6).all())
+      if push.any():
+        tl = env.event_manager._interval_term_time_left[0][push]
+        assert bool((tl >= push_cfg.interval_range_s[0] - 1e-6).all()) and bool((tl <= push_cfg.interval_range_s[1] + 1e-6).all())
+    if (push & ~reset).any():
+      # a push adds U(range) to the root's world velocity: A and B differ there by at most the width of the range, x and y only
+      m = push & ~reset
+      dv = (a.sim.data.qvel[m][:, :3] - b.sim.data.qvel[m][:, :3]).abs()
+      w = push_cfg.params["velocity_range"]
+      assert bool((dv[:, 0] <= w["x"][1] - w["x"][0] + 1e-5).all()) and bool((dv[:, 1] <= w["y"][1] - w["y"][0] + 1e-5).all()) and bool((dv[:, 2] <= 1e-5).all())
+      assert dv.max() > 0, "two independent pushes came out identical"
+    stats["resets"] += int(reset.sum()); stats["resamples"] += int((resample & ~reset).sum()); stats["pushes"] += int(push.sum())
+    stats["quiet_env_steps"] += int(quiet.sum()); stats["forward_steps"] += int(reset.any())
+  stats["graph"] = g.graph is not None
+  return stats

@@ -75,14 +75,20 @@ class OracleSimulation:
   def reset(self) -> None:
     pass
 
-  def forward(self) -> None:
+  def forward(self, env_mask=None) -> None:
+    """``env_mask`` as in mjlab_amd.Simulation.forward (extension): here all-or-nothing, which is what its callers pass."""
+    if env_mask is not None:
+      m = torch.as_tensor(env_mask).bool()
+      assert bool(m.all()) or not bool(m.any()), "the CPU stand-in recomputes all worlds or none"
+      if not bool(m.any()):
+        return
     self.forward_calls += 1
     self.ora.forward(nthread=self.nthread)
 
-  def step(self) -> None:
-    self.step_calls += 1
+  def step(self, nsubstep: int = 1) -> None:
+    self.step_calls += nsubstep
     with self.nan_guard.watch(self.data):
-      self.ora.step(1, nthread=self.nthread)
+      self.ora.step(nsubstep, nthread=self.nthread)
 
   def close(self) -> None:
     pass

@@ -52,6 +52,22 @@ def test_registered_g1_velocity_task_runs_over_the_hip_simulation():
   print(f"reference G1 velocity task over mjlab_amd.Simulation: 100 env steps x 256 envs, {sum(resets)} resets, mean reward {out['mean_reward']:.4f}")
 
 
+def test_graphed_env_matches_the_reference_env():
+  """the whole control step of the reference's environment as ONE hipGraph (mjlab_amd/graphed_env.py) against the
+  reference's own eager ``env.step`` over the same Simulation class, teacher-forced (tests/_graphed_check.py): terminations and
+  rewards bit for bit in every environment, observations / state / commands bit for bit in every environment that drew no random
+  number in the step, the others in distribution against the task's event and command configuration."""
+  sys.path.insert(0, str(ROOT / "tests"))
+  import _graphed_check
+
+  def make(n, device, edit):
+    return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=n, device=device, seed=11, cfg_edit=edit)
+
+  st = _graphed_check.run(make, "cuda:0", num_envs=256, steps=70, capture=True)
+  print("graphed env vs reference env:", st)
+  assert st["graph"] and st["resets"] >= 256 and st["pushes"] >= 256 and st["resamples"] >= 8 and st["quiet_env_steps"] >= 4000 and 0 < st["forward_steps"] < 70
+
+
 _TRACKING_GPU = """
 import json, sys
 import torch

@@ -205,7 +205,12 @@ def make_env(task: str = "Mjlab-Velocity-Flat-Unitree-G1", num_envs: int = 256, 
   from mjlab.envs import ManagerBasedRlEnv
 
   modname, clsname = TASKS[task]
-  cfg = getattr(importlib.import_module(modname), clsname)()
+  import copy
+
+  # a private copy: the reference's task configs hold shared default objects (SceneEntityCfg, term params) that the managers
+  # resolve IN PLACE while an environment is built -- a second environment of the task in the same process would otherwise
+  # receive half-resolved ones
+  cfg = copy.deepcopy(getattr(importlib.import_module(modname), clsname)())
   cfg.scene.num_envs = num_envs
   cfg.seed = seed
   if cfg_edit is not None:
