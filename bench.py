@@ -370,7 +370,7 @@ def main() -> None:
           e1.record()
           torch.cuda.synchronize()
           accq += e0.elapsed_time(e1)
-        mhz = torch.cuda.get_device_properties(dev).clock_rate / 1e3
+        mhz = 2400.0  # MI355X peak engine clock (/opt/skills/guides/MI355X_MICROARCH.md); the cycle figures are ms x this
         lat = {"critical_path_ms": accq / reps, "measured_ms": dom_ms, "frac": (accq / reps) / dom_ms,
                "critical_path_cycles": accq / reps * 1e-3 * mhz * 1e6, "measured_cycles": dom_ms * 1e-3 * mhz * 1e6, "clock_mhz": mhz,
                "waves_per_simd": {"critical_path": nq / 1024.0, "measured": args.envs_per_gpu / 1024.0},

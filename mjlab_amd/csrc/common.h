@@ -384,6 +384,35 @@ struct CholSweep {
 // producers call chol_pad_rows() once per kernel (zero fill; the factor keeps those rows'
 // off-diagonals at zero) and chol_pad_diag() after every (re)write of the matrix.
 // Caller synchronises before and after.
+// MJLAB_CHOL_RL: RIGHT-LOOKING sweep, register resident, no LDS round trip inside the factorization (round 4).
+// Measured on one wave per SIMD (profiles/r04_v3/latency_table.md) the left-looking sweep above takes 9.4 k cycles per 36 x 36
+// factorization: every batch of a column's dot product waits for an LDS broadcast read issued one batch earlier (~2.7 exposed round
+// trips per column), and the kernel's launch time is set by exactly such dependent latency.  Here lane i still owns row i in NVP
+// registers, but column J is eliminated the other way round: once its pivot is known every lane scales its own entry
+// (lu = t / D_J) and applies the rank-1 update a_i[k] -= t_i * Lu[k][J] to the columns k > J of its row, with Lu[k][J] taken
+// from lane k by v_readlane (a scalar operand of the multiply-add).  The only dependent chain is pivot -> reciprocal -> scale ->
+// update of column J+1 -> next pivot (~6 operations per column); the other NVP - J - 2 updates of a column are independent
+// multiply-adds that fill its latency.  Twice the instructions of the LDS-broadcast sweep (a v_readlane per multiply-add instead of
+// a 128-bit broadcast read per four), none of them waiting on memory.  Same LDL^T, same storage (unit-lower Lu with a zero
+// diagonal + 1 / D in LDS, as chol_solve reads it); the sums are formed in a different order, so results differ in the last bits.
+template <int NVP>
+struct CholRL {
+  template <int J>
+  static __device__ __forceinline__ void col(float (&a)[NVP], lds_f32* row, lds_f32* s_invd, int rowid) {
+    const float t = a[J];
+    const float djj = __builtin_amdgcn_fmed3f(lane_bcast(t, J), MINVAL, 3.0e38f);
+    const float invd = __builtin_amdgcn_rcpf(djj);
+    const float lu = rowid > J ? t * invd : 0.f;
+    row[J] = lu;
+    s_invd[J] = invd;
+    if constexpr (J + 1 < NVP) {
+#pragma unroll
+      for (int k = J + 1; k < NVP; ++k) a[k] = fmaf(-t, lane_bcast(lu, k), a[k]);
+      col<J + 1>(a, row, s_invd, rowid);
+    }
+  }
+};
+
 template <int NVP>
 __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int lane) {
   constexpr int LD = CholCfg<NVP>::LD;
@@ -401,6 +430,9 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
     a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
   }
   (void)n;  // rows >= n are identity rows already (chol_pad_rows / chol_pad_diag by the producer)
+#ifdef MJLAB_CHOL_RL
+  CholRL<NVP>::template col<0>(a, row, s_invd, rowid);
+#else
   // Row j of Lu is consumed in batches of CB columns.  The batches are software pipelined
   // through two register buffers: while batch i feeds the FMAs, the reads of batch i+1 --
   // the next batch of the same row, or the first batch of the next row -- are already in
@@ -409,6 +441,7 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
   // patched in from lane j+1's register.
   float bufA[MJLAB_CB], bufB[MJLAB_CB];
   CholSweep<NVP, MJLAB_CB>::template col<0>(a, bufA, bufB, A, row, s_invd, rowid);
+#endif
 }
 // Solves Lu D Lu^T x = b with the factor in LDS (as left by chol_factor); lane i owns
 // b_i / x_i (lanes >= n must pass 0).  Forward substitution uses row i of Lu, backward

@@ -84,6 +84,7 @@ class GraphedRlEnv:
     self._action_in = torch.zeros((self.n, sum(env.action_manager.action_term_dim)), device=self.device)
     self._check_supported()
     self._prepare_events()
+    self._upload_index_lists()
     self.graph: torch.cuda.CUDAGraph | None = None
     self._keep: list = []
     env.sim.use_graph = False  # the launches are captured here, once, for the whole control step
@@ -130,6 +131,35 @@ class GraphedRlEnv:
         self._reset_terms.append((fn, {"position_range": p["position_range"], "velocity_range": p["velocity_range"], "joint_ids": ids}))
     for index, cfg in enumerate(ev._mode_term_cfgs.get("interval", [])):
       self._interval_terms.append((index, cfg.interval_range_s, _range_tensors(cfg.params["velocity_range"], dev)))
+
+  def _upload_index_lists(self) -> None:
+    """Index lists in the terms' ``SceneEntityCfg`` parameters (``joint_ids = [0, 1, ...]``, resolved by the managers at
+    construction) become device tensors ONCE: indexing a device tensor with a Python list uploads the list at every call, which a
+    capture cannot hold.  Same indexing semantics."""
+    env, seen = self.env, set()
+
+    def visit(obj: Any, depth: int = 0) -> None:
+      if depth > 5 or id(obj) in seen:
+        return
+      seen.add(id(obj))
+      if type(obj).__name__ == "SceneEntityCfg":
+        for k, v in vars(obj).items():
+          if k.endswith("_ids") and isinstance(v, list) and v and all(isinstance(x, int) for x in v):
+            setattr(obj, k, torch.tensor(v, device=self.device, dtype=torch.long))
+        return
+      if isinstance(obj, dict):
+        for v in obj.values():
+          visit(v, depth + 1)
+      elif isinstance(obj, (list, tuple)):
+        for v in obj:
+          visit(v, depth + 1)
+      elif hasattr(obj, "__dict__") and type(obj).__module__.split(".")[0] == "mjlab":
+        for k, v in vars(obj).items():
+          if k not in ("_env", "env", "scene", "sim", "_asset", "robot"):
+            visit(v, depth + 1)
+
+    for mgr in (env.reward_manager, env.termination_manager, env.observation_manager, env.command_manager, env.action_manager, env.event_manager):
+      visit(mgr)
 
   # ---------------------------------------------------------------------------------------------------------------- capture
   def capture(self, warmup: int = 2) -> None:
