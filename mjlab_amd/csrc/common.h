@@ -384,7 +384,11 @@ struct CholSweep {
 // producers call chol_pad_rows() once per kernel (zero fill; the factor keeps those rows'
 // off-diagonals at zero) and chol_pad_diag() after every (re)write of the matrix.
 // Caller synchronises before and after.
-// MJLAB_CHOL_RL: RIGHT-LOOKING sweep, register resident, no LDS round trip inside the factorization (round 4).
+// MJLAB_CHOL_RL (experiment, MEASURED SLOWER, not the default): RIGHT-LOOKING sweep, register resident, no LDS round trip inside
+// the factorization (round 4).  Result (profiles/r04_v5/ab_chol_rl.txt, phases_rl_*.txt): 13.4 k cycles per factorization on one
+// wave per SIMD against 9.4 k for the left-looking LDS-broadcast sweep -- a v_readlane feeding a multiply-add through an SGPR
+// costs ~21 cycles per pair in a single wave, far more than the ~7 its issue cycles suggest -- and 1.361 vs 1.210 ms per control
+// step.  Kept behind the switch as the record of that measurement.  The idea:
 // Measured on one wave per SIMD (profiles/r04_v3/latency_table.md) the left-looking sweep above takes 9.4 k cycles per 36 x 36
 // factorization: every batch of a column's dot product waits for an LDS broadcast read issued one batch earlier (~2.7 exposed round
 // trips per column), and the kernel's launch time is set by exactly such dependent latency.  Here lane i still owns row i in NVP
@@ -395,26 +399,31 @@ struct CholSweep {
 // multiply-adds that fill its latency.  Twice the instructions of the LDS-broadcast sweep (a v_readlane per multiply-add instead of
 // a 128-bit broadcast read per four), none of them waiting on memory.  Same LDL^T, same storage (unit-lower Lu with a zero
 // diagonal + 1 / D in LDS, as chol_solve reads it); the sums are formed in a different order, so results differ in the last bits.
+// FWD: the forward substitution of ONE right-hand side rides along (lane i owns b_i): once column J is scaled, b_i -= Lu[i][J] y_J
+// with y_J = b of lane J, which by then has received the updates of all columns < J.  One v_readlane + one multiply-add per
+// column on a chain of its own, next to the pivot chain -- the solve that follows the factorization then only scales by 1 / D and
+// substitutes backwards (chol_solve_back).
 template <int NVP>
 struct CholRL {
-  template <int J>
-  static __device__ __forceinline__ void col(float (&a)[NVP], lds_f32* row, lds_f32* s_invd, int rowid) {
+  template <int J, bool FWD>
+  static __device__ __forceinline__ void col(float (&a)[NVP], lds_f32* row, lds_f32* s_invd, int rowid, float& b) {
     const float t = a[J];
     const float djj = __builtin_amdgcn_fmed3f(lane_bcast(t, J), MINVAL, 3.0e38f);
     const float invd = __builtin_amdgcn_rcpf(djj);
     const float lu = rowid > J ? t * invd : 0.f;
     row[J] = lu;
     s_invd[J] = invd;
+    if constexpr (FWD) b = fmaf(-lu, lane_bcast(b, J), b);  // lu = 0 for lanes <= J: their b is final
     if constexpr (J + 1 < NVP) {
 #pragma unroll
       for (int k = J + 1; k < NVP; ++k) a[k] = fmaf(-t, lane_bcast(lu, k), a[k]);
-      col<J + 1>(a, row, s_invd, rowid);
+      col<J + 1, FWD>(a, row, s_invd, rowid, b);
     }
   }
 };
 
-template <int NVP>
-__device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int lane) {
+template <int NVP, bool FWD = false>
+__device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int lane, float* fwd = nullptr) {
   constexpr int LD = CholCfg<NVP>::LD;
   lds_f32* A = (lds_f32*)A_;
   lds_f32* s_invd = (lds_f32*)s_invd_;
@@ -431,8 +440,11 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
   }
   (void)n;  // rows >= n are identity rows already (chol_pad_rows / chol_pad_diag by the producer)
 #ifdef MJLAB_CHOL_RL
-  CholRL<NVP>::template col<0>(a, row, s_invd, rowid);
+  float b = FWD ? *fwd : 0.f;
+  CholRL<NVP>::template col<0, FWD>(a, row, s_invd, rowid, b);
+  if (FWD) *fwd = b;
 #else
+  static_assert(!FWD, "the fused forward substitution exists in the right-looking sweep only");
   // Row j of Lu is consumed in batches of CB columns.  The batches are software pipelined
   // through two register buffers: while batch i feeds the FMAs, the reads of batch i+1 --
   // the next batch of the same row, or the first batch of the next row -- are already in
@@ -472,6 +484,21 @@ __device__ CHOL_INLINE float chol_solve(const float* L_, const float* s_invd_, i
 #pragma unroll
     for (int k = NVP - 1; k >= 0; --k) b = fmaf(-at[k], lane_bcast(b, k), b);
   }
+  return b;
+}
+// The second half of chol_solve for a right-hand side whose forward substitution was done by chol_factor<NVP, true>: y -> x.
+template <int NVP>
+__device__ CHOL_INLINE float chol_solve_back(const float* L_, const float* s_invd_, int lane, float y) {
+  constexpr int LD = CholCfg<NVP>::LD;
+  const lds_f32* L = (const lds_f32*)L_;
+  const lds_f32* s_invd = (const lds_f32*)s_invd_;
+  const int li = lane < NVP ? lane : NVP - 1;
+  float b = y * s_invd[li];
+  float at[NVP];
+#pragma unroll
+  for (int k = 0; k < NVP; ++k) at[k] = L[k * LD + li];  // Lu[k][i]: zero for k <= i
+#pragma unroll
+  for (int k = NVP - 1; k >= 0; --k) b = fmaf(-at[k], lane_bcast(b, k), b);
   return b;
 }
 // y_i = sum_j M[i][j] v_j with M symmetric, dense row-major in GLOBAL memory (ld = n) -- worlds with more rows than

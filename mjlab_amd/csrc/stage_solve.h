@@ -625,6 +625,21 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
 
     float x = qacc;
     if (!skip_solve) {
+#if defined(MJLAB_CHOL_RL) && defined(MJLAB_CHOL_FWD)
+      if (need_factor) {  // the right-hand side is known when the factorization starts: its forward substitution rides along
+        __syncthreads();
+        float y = rhs;
+        chol_factor<NVP, true>(c.s_H, c.s_invd, nv, lane, &y);
+        __syncthreads();
+        PROF_MARK(12);
+        PROF_COUNT(14);
+        x = chol_solve_back<NVP>(c.s_H, c.s_invd, lane, y);
+      } else {
+        x = chol_solve<NVP>(c.s_H, c.s_invd, lane, rhs);
+      }
+      PROF_MARK(13);
+      PROF_COUNT(15);
+#else
       if (need_factor) {
         __syncthreads();
         chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
@@ -635,6 +650,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
       x = chol_solve<NVP>(c.s_H, c.s_invd, lane, rhs);
       PROF_MARK(13);
       PROF_COUNT(15);
+#endif
     }
 
     if (state == ST_INTEGRATE) {

@@ -177,8 +177,11 @@ def pingpong_steps(info: ShardInfo, nsteps: int, halves: list, learner_actions, 
   is called on rank 0 only and returns the actions of ALL ranks' half h for control step k, (world_size * envs_per_half,
   action_dim), from the rows gathered after step k - 1 (None for k = 0).  With `overlap=False` the same dependency chain runs
   strictly in sequence (the reference for bit-equality: results are identical by construction, only the timing differs).
-  On RCCL the exchange of a half is issued on `comm_stream` (default: a side stream), ordered against the physics by events;
-  gloo (CPU tests) runs everything in issue order.  Returns the rows gathered after the last step per half (rank 0; None elsewhere)."""
+  On RCCL the exchange of a half is issued on `comm_stream` (default: a side stream), ordered against the physics by events, and
+  (round 4) each half steps on a COMPUTE STREAM OF ITS OWN: a half batch is 2 waves per SIMD and the physics kernel is bound by
+  each wave's own latency, so two half-batch launches one after the other take ~1.8 x a full launch (2048 worlds: 1.12 ms against
+  1.25 ms for 4096, profiles/r03_v8/scenes.txt) -- the two launches have to share the chip at the same time for the pipeline to
+  cost nothing; only then does hiding the exchange pay.  gloo (CPU tests) runs everything in issue order.  Returns the rows gathered after the last step per half (rank 0; None elsewhere)."""
   nh = len(halves)
   if info.envs_per_rank % nh:
     raise ValueError(f"pingpong_steps: envs_per_rank = {info.envs_per_rank} is not divisible by the {nh} part batches")
@@ -186,6 +189,10 @@ def pingpong_steps(info: ShardInfo, nsteps: int, halves: list, learner_actions, 
   cuda = torch.cuda.is_available() and str(device).startswith("cuda") and dist.is_initialized() and dist.get_backend() == "nccl"
   main = torch.cuda.current_stream(device) if cuda else None
   side = (comm_stream or torch.cuda.Stream(device=device)) if (cuda and overlap) else main
+  comp = [torch.cuda.Stream(device=device) for _ in range(nh)] if (cuda and overlap) else [main] * nh
+  if cuda and overlap:
+    for cs in comp:
+      cs.wait_stream(main)  # whatever prepared the halves' state was enqueued on the caller's stream
   gathered: list = [None] * nh
   act: list = [None] * nh
   ready: list = [None] * nh  # event: the actions of half h have arrived (recorded on the exchange stream)
@@ -209,14 +216,19 @@ def pingpong_steps(info: ShardInfo, nsteps: int, halves: list, learner_actions, 
   for k in range(nsteps):
     for h in range(nh):
       step_fn, rows_fn = halves[h]
-      if cuda:
-        main.wait_event(ready[h])
-      step_fn(act[h])
-      r = rows_fn()
-      ev = None
-      if cuda:
-        ev = torch.cuda.Event()
-        ev.record(main)
+      with (torch.cuda.stream(comp[h]) if cuda else _null()):
+        if cuda:
+          comp[h].wait_event(ready[h])
+          if act[h] is not None and act[h].is_cuda:
+            act[h].record_stream(comp[h])  # allocated on the exchange stream, read by this half's launch
+        step_fn(act[h])
+        r = rows_fn()
+        ev = None
+        if cuda:
+          ev = torch.cuda.Event()
+          ev.record(comp[h])
+          if side is not comp[h]:
+            r.record_stream(side)  # allocated here, read by the gather on the exchange stream
       if k + 1 < nsteps:
         exchange(h, k + 1, (r, ev))
       else:  # the last rows still travel to the learner
@@ -227,6 +239,9 @@ def pingpong_steps(info: ShardInfo, nsteps: int, halves: list, learner_actions, 
           gathered[h] = gather_rollout(sub, r, tag=h)
   if cuda:
     main.wait_stream(side)
+    for cs in comp:
+      if cs is not main:
+        main.wait_stream(cs)
   return gathered
 
 
