@@ -1,9 +1,7 @@
-T=gpurun_out/r04_v5; mkdir -p $T
-timeout 90 python -c "import torch; x = torch.ones(1024, device='cuda'); print('gpu ok', float((x * 2).sum()))" || exit 9
-timeout 300 python -m pytest tests/test_env_golden.py -m gpu -q -rs > $T/gputests.log 2>&1; echo "gputests rc=$?"; tail -3 $T/gputests.log; grep -n "^E  " $T/gputests.log | cut -c1-300 | head -5
+bash tools/gpu_verify.sh r04_v6
 cat gpurun_out/env_golden_margins.txt
-bash tools/ab_bench.sh --no-full-env --no-latency-bound 2>&1 | tee $T/ab_chol_rl.txt
-for NW in 1024 4096; do
-  NWORLD=$NW MJLAB_AMD_LIB=gpurun_prof/libmjlab_amd_prof_rl.so timeout 120 python tools/profile_phases.py > $T/phases_rl_$NW.txt 2>&1
-done
-grep -n "chol_factor\|chol_solve\|mean cycles per world-step in k_solve" $T/phases_rl_*.txt
+python -c "
+import json; d=json.load(open('gpurun_out/r04_v6/exchange_one_rank_rccl.json')); p=d['pipelined']; print({k: p.get(k) for k in ('ms_per_step','ms_per_step_same_halves_sequential_exchange','ms_per_step_halves_compute_only','ms_per_step_halves_concurrent_compute_only','exchange_overlap_frac','error')}, d['ms_per_step'], d['exchange_ms_per_step'])"
+MJLAB_DIST_FORCE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29733 bench.py --gpus 1 --steps 100 --warmup 20 --no-cpu-baseline --no-full-env --no-latency-bound 2>/dev/null | tail -1 > gpurun_out/r04_v6/exchange_4096_one_rank_rccl.json
+python -c "
+import json; d=json.load(open('gpurun_out/r04_v6/exchange_4096_one_rank_rccl.json')); p=d['pipelined']; print('4096:', {k: p.get(k) for k in ('ms_per_step','ms_per_step_same_halves_sequential_exchange','ms_per_step_halves_compute_only','ms_per_step_halves_concurrent_compute_only','exchange_overlap_frac','error')}, d['ms_per_step'], d['exchange_ms_per_step'])"
