@@ -99,42 +99,97 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
   *total = __shfl(incl, 63);
   return incl - v;
 }
+// ---- copies between global memory and LDS.  A rolled `dst[k] = src[k]` loop over generic pointers cannot be pipelined by the
+// compiler (the store of one trip may alias the load of the next as far as it can tell), so every trip waits for its own memory
+// round trip -- ~600 cycles from L2 per 64 floats on the way in, an LDS round trip per 64 floats on the way out.  With
+// MJLAB_COPY_BATCH > 1 that many independent accesses are issued before the first dependent instruction (copies only: results
+// are bit-identical).  MEASURED (round 4, profiles/r04_v8, r04_v9): with batches of 4 the solve stage's load of M drops from 17.7 k
+// to 8.4 k cycles on one wave per SIMD and the four pre-solve STAGE KERNELS get 4-8 % shorter (418.5 k -> 412.7 k cycles per step
+// summed over the stage kernels), but the fused control kernel -- the default path, at the 128-register cap -- is 0.4 % SLOWER
+// (3.341 vs 3.356 M env-steps/s, three interleaved repetitions): the four extra live registers per copy move its spills into the
+// Newton loop (LS prep +4 k, post-LS +3 k cycles).  The default therefore stays 1 (the rolled loop); the switch is the record.
+#ifndef MJLAB_COPY_BATCH
+#define MJLAB_COPY_BATCH 1
+#endif
+constexpr int CPB = MJLAB_COPY_BATCH;
+#ifndef MJLAB_COPY_BATCH_M
+#define MJLAB_COPY_BATCH_M MJLAB_COPY_BATCH
+#endif
+constexpr int CPBM = MJLAB_COPY_BATCH_M;  // the solve stage's load of M (its register allocation is the tightest of the kernel)
 __device__ __forceinline__ void lds_to_global(float* dst, const float* src, int n, int lane) {
-  for (int k = lane; k < n; k += 64) dst[k] = src[k];
+  for (int k0 = lane; k0 < n; k0 += 64 * CPB) {
+    float v[CPB];
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) { const int k = k0 + 64 * u; v[u] = k < n ? src[k] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) { const int k = k0 + 64 * u; if (k < n) dst[k] = v[u]; }
+  }
 }
 // rows of 3 (positions in the world's local frame) -> public world-frame array: element k gets org[k mod 3] added
 __device__ __forceinline__ void lds3_to_global_org(float* dst, const float* src, int n, int lane, const float (&org)[3]) {
-  for (int k = lane; k < n; k += 64) {
-    const int c = k - 3 * (k / 3);
-    dst[k] = src[k] + (c == 0 ? org[0] : c == 1 ? org[1] : org[2]);
+  for (int k0 = lane; k0 < n; k0 += 64 * CPB) {
+    float v[CPB];
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) { const int k = k0 + 64 * u; v[u] = k < n ? src[k] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) {
+      const int k = k0 + 64 * u;
+      const int c = k - 3 * (k / 3);
+      if (k < n) dst[k] = v[u] + (c == 0 ? org[0] : c == 1 ? org[1] : org[2]);
+    }
   }
 }
 __device__ __forceinline__ void global_to_lds(float* dst, const float* src, int n, int lane) {
-  for (int k = lane; k < n; k += 64) dst[k] = src[k];
+  for (int k0 = lane; k0 < n; k0 += 64 * CPB) {
+    float v[CPB];
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) { const int k = k0 + 64 * u; v[u] = k < n ? src[k] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) { const int k = k0 + 64 * u; if (k < n) dst[k] = v[u]; }
+  }
 }
 
 // Dense n x n matrix copies between row-major global memory (leading dimension n) and LDS
-// (leading dimension ld); lanes walk consecutive global elements, (i, j) tracked without
-// integer division.
+// (leading dimension ld); lanes walk consecutive global elements.  (i, j) of element k advance by 64 per step:
+// j += 64 mod n, i += 64 div n, one conditional carry -- no division and no data-dependent loop inside the batches.
+struct RowCol {
+  int i, j, q, r, n;
+  __device__ __forceinline__ RowCol(int lane, int n_) : n(n_) {
+    q = 64 / n_; r = 64 - q * n_;  // wave-uniform
+    i = lane / n_; j = lane - i * n_;
+  }
+  __device__ __forceinline__ void next() {
+    j += r; i += q;
+    if (j >= n) { j -= n; ++i; }
+  }
+};
 __device__ __forceinline__ void dense_global_to_lds(float* dst, const float* src, int n, int ld, int lane, bool lower_only) {
   lane = launder(lane);
-  int i = 0, j = lane;
-  while (j >= n) { j -= n; ++i; }
-  for (int k = lane; k < n * n; k += 64) {
-    if (!lower_only || j <= i) dst[i * ld + j] = src[k];
-    j += 64;
-    while (j >= n) { j -= n; ++i; }
+  RowCol rc(lane, n);
+  for (int k0 = lane; k0 < n * n; k0 += 64 * CPBM) {
+    float v[CPBM];
+#pragma unroll
+    for (int u = 0; u < CPBM; ++u) { const int k = k0 + 64 * u; v[u] = k < n * n ? src[k] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < CPBM; ++u) {
+      if (k0 + 64 * u < n * n && (!lower_only || rc.j <= rc.i)) dst[rc.i * ld + rc.j] = v[u];
+      rc.next();
+    }
   }
 }
 // same copy (lower triangle), plus a packed copy of the lower triangle: element (i, j) at i (i + 1) / 2 + j
 __device__ __forceinline__ void dense_global_to_lds_packed(float* dst, float* packed, const float* src, int n, int ld, int lane) {
   lane = launder(lane);
-  int i = 0, j = lane, tri = 0;
-  while (j >= n) { j -= n; ++i; tri += i; }
-  for (int k = lane; k < n * n; k += 64) {
-    if (j <= i) { const float x = src[k]; dst[i * ld + j] = x; packed[tri + j] = x; }
-    j += 64;
-    while (j >= n) { j -= n; ++i; tri += i; }
+  RowCol rc(lane, n);
+  for (int k0 = lane; k0 < n * n; k0 += 64 * CPBM) {
+    float v[CPBM];
+#pragma unroll
+    for (int u = 0; u < CPBM; ++u) { const int k = k0 + 64 * u; v[u] = k < n * n ? src[k] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < CPBM; ++u) {
+      if (k0 + 64 * u < n * n && rc.j <= rc.i) { dst[rc.i * ld + rc.j] = v[u]; packed[((rc.i * (rc.i + 1)) >> 1) + rc.j] = v[u]; }
+      rc.next();
+    }
   }
 }
 // packed lower triangle (LDS) -> lower triangle of a dense LDS matrix
@@ -147,12 +202,16 @@ __device__ __forceinline__ void packed_to_lds(float* dst, const float* packed, i
   }
 }
 __device__ __forceinline__ void dense_lds_to_global(float* dst, const float* src, int n, int ld, int lane, bool zero_upper) {
-  int i = 0, j = lane;
-  while (j >= n) { j -= n; ++i; }
-  for (int k = lane; k < n * n; k += 64) {
-    dst[k] = (zero_upper && j > i) ? 0.f : src[i * ld + j];
-    j += 64;
-    while (j >= n) { j -= n; ++i; }
+  RowCol rc(lane, n);
+  for (int k0 = lane; k0 < n * n; k0 += 64 * CPB) {
+    float v[CPB];
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) {
+      v[u] = (k0 + 64 * u < n * n && !(zero_upper && rc.j > rc.i)) ? src[rc.i * ld + rc.j] : 0.f;
+      rc.next();
+    }
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) { const int k = k0 + 64 * u; if (k < n * n) dst[k] = v[u]; }
   }
 }
 

@@ -391,19 +391,37 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
   {
     const int ng0 = m.size.nstaticgeom;
     const float *gxw = d.geom_xpos + (size_t)w * ng * 3, *gxr = d.geom_xrel + (size_t)w * ng * 3;
-    for (int k = lane; k < 3 * nl; k += 64) {
-      const int e = 3 * g0 + k, g = e / 3, c = e - 3 * g;
-      s_gx[k] = g < ng0 ? gxw[e] - (c == 0 ? org[0] : c == 1 ? org[1] : org[2]) : gxr[e];
+    for (int k0 = lane; k0 < 3 * nl; k0 += 64 * CPB) {  // batches of independent loads (common.h, MJLAB_COPY_BATCH)
+      float v[CPB];
+#pragma unroll
+      for (int u = 0; u < CPB; ++u) {
+        const int k = k0 + 64 * u, e = 3 * g0 + k, g = e / 3, c = e - 3 * g;
+        v[u] = 0.f;
+        if (k < 3 * nl) v[u] = g < ng0 ? gxw[e] - (c == 0 ? org[0] : c == 1 ? org[1] : org[2]) : gxr[e];
+      }
+#pragma unroll
+      for (int u = 0; u < CPB; ++u) { const int k = k0 + 64 * u; if (k < 3 * nl) s_gx[k] = v[u]; }
     }
   }
   global_to_lds(s_gm, d.geom_xmat + ((size_t)w * ng + g0) * 9, 9 * nl, lane);
-  for (int l = lane; l < nl; l += 64) {
-    const int g = g0 + l;
-    ((int*)s_gc)[8 * l] = m.geom_type[g];
-    for (int k = 0; k < 3; ++k) s_gc[8 * l + 1 + k] = gsize[3 * g + k];
-    s_gc[8 * l + 4] = rbound[g];
-    s_gc[8 * l + 5] = gmargin[g];
-    s_gc[8 * l + 6] = ggap[g];
+  for (int l0 = lane; l0 < nl; l0 += 128) {  // two geoms per lane and trip: their 14 loads in flight together
+    int gt[2];
+    float gc[2][6];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int l = l0 + 64 * u, g = g0 + (l < nl ? l : 0);
+      gt[u] = m.geom_type[g];
+      for (int k = 0; k < 3; ++k) gc[u][k] = gsize[3 * g + k];
+      gc[u][3] = rbound[g]; gc[u][4] = gmargin[g]; gc[u][5] = ggap[g];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int l = l0 + 64 * u;
+      if (l < nl) {
+        ((int*)s_gc)[8 * l] = gt[u];
+        for (int k = 0; k < 6; ++k) s_gc[8 * l + 1 + k] = gc[u][k];
+      }
+    }
   }
   __syncthreads();
   PROF_MARK(0);

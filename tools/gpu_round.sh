@@ -15,7 +15,7 @@ fi
 timeout 600 python bench.py --scene $SCENE > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/status.txt
 tail -1 $OUT/bench.log > $OUT/bench.json
 if [ -z "$QUICK" ]; then
-  BCMD="python $R/bench.py --scene $SCENE --steps 40 --warmup 10 --no-cpu-baseline --no-full-env"  # (the full-env leg is ~25 k small torch launches: minutes under --pmc)
+  BCMD="python $R/bench.py --scene $SCENE --steps 40 --warmup 10 --no-cpu-baseline --no-full-env --no-latency-bound"  # (the quarter-size launches of roofline.latency would mix into the kernel's average)  # (the full-env leg is ~25 k small torch launches: minutes under --pmc)
   (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- $BCMD > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/status.txt
   for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 150 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o pmc -- $BCMD > $R/$OUT/pmc_$C.log 2>&1); echo "pmc $C rc=$?" | tee -a $OUT/status.txt
