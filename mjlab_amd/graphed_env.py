@@ -42,6 +42,7 @@ import torch
 
 SUPPORTED_RESET_EVENTS = ("reset_root_state_uniform", "reset_joints_by_scale")
 SUPPORTED_INTERVAL_EVENTS = ("push_by_setting_velocity",)
+SUPPORTED_COMMANDS = ("UniformVelocityCommand", "MotionCommand")
 _AXES = ("x", "y", "z", "roll", "pitch", "yaw")
 
 
@@ -50,9 +51,9 @@ def _range_tensors(rng: dict, device) -> tuple[torch.Tensor, torch.Tensor]:
   return r[:, 0].to(device), r[:, 1].to(device)
 
 
-def _state_tensors(obj: Any, n: int, seen: set, out: list, depth: int = 0, path: str = "", dev_type: str | None = None) -> None:
-  """(owner, attribute | key, tensor) for every torch tensor with leading dimension n reachable from `obj` through attributes,
-  dicts and lists of objects defined in the reference's packages."""
+def _state_tensors(obj: Any, n: int | None, seen: set, out: list, depth: int = 0, path: str = "", dev_type: str | None = None) -> None:
+  """(owner, attribute | key, tensor) for every torch tensor with leading dimension n (n = None: of any shape) reachable from
+  `obj` through attributes, dicts and lists of objects defined in the reference's packages."""
   if depth > 6 or id(obj) in seen:
     return
   seen.add(id(obj))
@@ -65,7 +66,7 @@ def _state_tensors(obj: Any, n: int, seen: set, out: list, depth: int = 0, path:
     items = [(obj, k, v) for k, v in vars(obj).items()]
   for owner, key, v in items:
     if isinstance(v, torch.Tensor):
-      if v.dim() >= 1 and v.shape[0] == n and (dev_type is None or v.device.type == dev_type):
+      if (n is None or (v.dim() >= 1 and v.shape[0] == n)) and (dev_type is None or v.device.type == dev_type):
         out.append((owner, key, v, f"{path}.{key}"))
     elif isinstance(key, str) and key in ("_env", "env", "cfg", "scene", "sim", "_asset", "robot", "_entities"):
       continue  # back references / configuration / the physics: not manager state
@@ -105,7 +106,7 @@ class GraphedRlEnv:
     if any(ev._mode_class_term_cfgs.get(m) for m in ("reset", "interval")):
       raise NotImplementedError("class-based reset / interval event terms are not supported by GraphedRlEnv")
     for name in env.command_manager.active_terms:
-      if type(env.command_manager.get_term(name)).__name__ != "UniformVelocityCommand":
+      if type(env.command_manager.get_term(name)).__name__ not in SUPPORTED_COMMANDS:
         raise NotImplementedError(f"command term '{name}' ({type(env.command_manager.get_term(name)).__name__}) has no mask-based restatement")
     if getattr(env.curriculum_manager, "active_terms", None):
       raise NotImplementedError("curriculum terms are not supported by GraphedRlEnv")
@@ -131,6 +132,32 @@ class GraphedRlEnv:
         self._reset_terms.append((fn, {"position_range": p["position_range"], "velocity_range": p["velocity_range"], "joint_ids": ids}))
     for index, cfg in enumerate(ev._mode_term_cfgs.get("interval", [])):
       self._interval_terms.append((index, cfg.interval_range_s, _range_tensors(cfg.params["velocity_range"], dev)))
+    self._command_ranges = {}
+    for name in self.env.command_manager.active_terms:
+      term = self.env.command_manager.get_term(name)
+      if type(term).__name__ == "MotionCommand":
+        self._command_ranges[id(term)] = (_range_tensors(term.cfg.pose_range, dev), _range_tensors(term.cfg.velocity_range, dev))
+        self._patch_body_index_lists(term)
+
+  @staticmethod
+  def _patch_body_index_lists(term: Any) -> None:
+    """The tracking task's reward and termination functions index with ``_get_body_indexes(command, names)`` -- a Python list
+    built at every call (tasks/tracking/mdp/rewards.py:19-26), i.e. an upload per call inside the term function itself.  The
+    helper is replaced, in the two modules that bind it, by one that returns the same indices as a cached device tensor."""
+    import mjlab.tasks.tracking.mdp.rewards as rw
+    import mjlab.tasks.tracking.mdp.terminations as tm
+
+    orig = getattr(rw._get_body_indexes, "_mjlab_amd_orig", rw._get_body_indexes)
+    cache: dict = {}
+
+    def cached(command, body_names):
+      key = (id(command), None if body_names is None else tuple(body_names))
+      if key not in cache:
+        cache[key] = torch.tensor(orig(command, body_names), dtype=torch.long, device=command.device)
+      return cache[key]
+
+    cached._mjlab_amd_orig = orig
+    rw._get_body_indexes = tm._get_body_indexes = cached
 
   def _upload_index_lists(self) -> None:
     """Index lists in the terms' ``SceneEntityCfg`` parameters (``joint_ids = [0, 1, ...]``, resolved by the managers at
@@ -219,8 +246,9 @@ class GraphedRlEnv:
   # get their new value copied into the original tensor and are bound back to it.
   def _snapshot_bindings(self) -> list:
     env, out = self.env, []
-    for mgr in (env.action_manager, env.reward_manager, env.termination_manager, env.command_manager, env.observation_manager, env.event_manager):
+    for mgr in (env.action_manager, env.reward_manager, env.termination_manager, env.observation_manager, env.event_manager):
       _state_tensors(mgr, self.n, set(), out)
+    _state_tensors(env.command_manager, None, set(), out)  # command terms also carry global state (the tracking task's sampler)
     return out
 
   def _restore_bindings(self, before: list) -> None:
@@ -239,12 +267,7 @@ class GraphedRlEnv:
     env, m1 = self.env, mask[:, None]
     cnt = mask.sum().clamp(min=1).to(torch.float32)
     log: dict = {}
-    # scene.reset -> Entity.clear_state (entity/data.py:171-181)
-    d, ix = self._robot.data.data, self._robot.indexing
-    keep = (~mask).to(torch.float32)
-    d.qfrc_applied[:, ix.free_joint_v_adr] = d.qfrc_applied[:, ix.free_joint_v_adr] * keep[:, None]
-    d.xfrc_applied[:, ix.body_ids] = d.xfrc_applied[:, ix.body_ids] * keep[:, None, None]
-    d.ctrl[:, ix.ctrl_ids] = d.ctrl[:, ix.ctrl_ids] * keep[:, None]
+    self._clear_state(self._robot, mask)  # scene.reset -> Entity.reset -> clear_state
     # reset-mode events (managers/event_manager.py:139-148 with min_step_count 0)
     step_count = env._sim_step_counter // env.cfg.decimation  # (baked in at capture; read by nothing the supported terms use)
     for index, (fn, prm) in enumerate(self._reset_terms):
@@ -277,6 +300,15 @@ class GraphedRlEnv:
       log["Episode_Termination/" + key] = (dones & mask).sum()
     env.extras["log"] = log
     env.episode_length_buf.masked_fill_(mask, 0)
+
+  @staticmethod
+  def _clear_state(robot: Any, mask: torch.Tensor) -> None:
+    """EntityData.clear_state (entity/data.py:171-181) for the environments of `mask`."""
+    d, ix = robot.data.data, robot.indexing
+    keep = (~mask).to(torch.float32)
+    d.qfrc_applied[:, ix.free_joint_v_adr] = d.qfrc_applied[:, ix.free_joint_v_adr] * keep[:, None]
+    d.xfrc_applied[:, ix.body_ids] = d.xfrc_applied[:, ix.body_ids] * keep[:, None, None]
+    d.ctrl[:, ix.ctrl_ids] = d.ctrl[:, ix.ctrl_ids] * keep[:, None]
 
   def _masked_class_reset(self, func: Any, mask: torch.Tensor) -> None:
     """A class-based term's own ``reset()`` run on ALL environments, kept only where `mask` is set."""
@@ -324,11 +356,26 @@ class GraphedRlEnv:
 
   # --------------------------------------------------------------------------------------------------------------- commands
   def _command_resample(self, term: Any, mask: torch.Tensor) -> None:
-    """CommandTerm._resample (managers/command_manager.py:62-66) + UniformVelocityCommand._resample_command
-    (tasks/velocity/mdp/velocity_command.py:64-90) for the environments of `mask`."""
+    """CommandTerm._resample (managers/command_manager.py:62-66) for the environments of `mask`, then the term's own
+    ``_resample_command`` in its mask-based form."""
+    lo, hi = term.cfg.resampling_time_range
+    term.time_left.copy_(torch.where(mask, torch.rand(self.n, device=self.device) * (hi - lo) + lo, term.time_left))
+    getattr(self, "_resample_" + type(term).__name__)(term, mask)
+    term.command_counter += mask.to(term.command_counter.dtype)
+
+  def _command_compute(self) -> None:
+    """CommandManager.compute -> CommandTerm.compute (managers/command_manager.py:55-60)."""
+    for name in self.env.command_manager.active_terms:
+      term = self.env.command_manager.get_term(name)
+      term._update_metrics()  # the reference's own
+      term.time_left -= self.dt
+      self._command_resample(term, term.time_left <= 0.0)
+      getattr(self, "_update_" + type(term).__name__)(term)
+
+  # -- UniformVelocityCommand (tasks/velocity/mdp/velocity_command.py:64-102)
+  def _resample_UniformVelocityCommand(self, term: Any, mask: torch.Tensor) -> None:
     cfg, n, dev = term.cfg, self.n, self.device
     u = lambda lo, hi: torch.rand(n, device=dev) * (hi - lo) + lo  # noqa: E731
-    term.time_left.copy_(torch.where(mask, u(*cfg.resampling_time_range), term.time_left))
     v = term.vel_command_b
     v[:, 0] = torch.where(mask, u(*cfg.ranges.lin_vel_x), v[:, 0])
     v[:, 1] = torch.where(mask, u(*cfg.ranges.lin_vel_y), v[:, 1])
@@ -349,24 +396,78 @@ class GraphedRlEnv:
       vel = torch.cat([rm.quat_apply(rd.root_link_quat_w, lin_b), ang_b], dim=-1)
       d.qpos[:, ix.free_joint_q_adr] = torch.where(im[:, None], state, d.qpos[:, ix.free_joint_q_adr])
       d.qvel[:, ix.free_joint_v_adr] = torch.where(im[:, None], vel, d.qvel[:, ix.free_joint_v_adr])
-    term.command_counter += mask.to(term.command_counter.dtype)
 
-  def _command_compute(self) -> None:
-    """CommandManager.compute -> CommandTerm.compute (managers/command_manager.py:55-60) + UniformVelocityCommand._update_command
-    (tasks/velocity/mdp/velocity_command.py:92-102)."""
+  def _update_UniformVelocityCommand(self, term: Any) -> None:
+    rm, cfg, v = self._m, term.cfg, term.vel_command_b
+    if cfg.heading_command:
+      err = rm.wrap_to_pi(term.heading_target - term.robot.data.heading_w)
+      yaw = torch.clip(cfg.heading_control_stiffness * err, min=cfg.ranges.ang_vel_z[0], max=cfg.ranges.ang_vel_z[1])
+      v[:, 2] = torch.where(term.is_heading_env, yaw, v[:, 2])
+    v.masked_fill_(term.is_standing_env[:, None], 0.0)
+
+  # -- MotionCommand (tasks/tracking/mdp/commands.py:255-392)
+  def _resample_MotionCommand(self, term: Any, mask: torch.Tensor) -> None:
+    """``_adaptive_sampling`` + ``_resample_command`` (:255-363).  The reference runs them only when the id list is non-empty; here
+    the sampler's global state and metrics keep their values unless `mask` has an entry (``any`` on the device)."""
+    rm, cfg, n, dev = self._m, term.cfg, self.n, self.device
+    anyone = mask.any()
+    total = term.motion.time_step_total
+    if cfg.disable_adaptive_sampling:
+      term.time_steps.masked_fill_(mask, 0)
+    else:
+      failed = self.env.termination_manager.terminated & mask
+      bins = torch.clamp((term.time_steps * term.bin_count) // max(total, 1), 0, term.bin_count - 1)
+      counts = torch.zeros(term.bin_count, device=dev).scatter_add_(0, bins, failed.to(torch.float32))  # (:258-265: bincount of the failed envs' bins)
+      term._current_bin_failed.copy_(torch.where(failed.any(), counts, term._current_bin_failed))
+      p = term.bin_failed_count + cfg.adaptive_uniform_ratio / float(term.bin_count)
+      p = torch.nn.functional.pad(p.unsqueeze(0).unsqueeze(0), (0, cfg.adaptive_kernel_size - 1), mode="replicate")
+      p = torch.nn.functional.conv1d(p, term.kernel.view(1, 1, -1)).view(-1)
+      p = p / p.sum()
+      # torch.multinomial(p, n, replacement=True) by inverse CDF (the same distribution, no host round trip)
+      sampled = torch.searchsorted(torch.cumsum(p, 0), torch.rand(n, device=dev)).clamp_(max=term.bin_count - 1)
+      t_new = ((sampled + torch.rand(n, device=dev)) / term.bin_count * (total - 1)).long()
+      term.time_steps.copy_(torch.where(mask, t_new, term.time_steps))
+      H = -(p * (p + 1e-12).log()).sum() / math.log(term.bin_count)
+      pmax, imax = p.max(dim=0)
+      for key, val in (("sampling_entropy", H), ("sampling_top1_prob", pmax), ("sampling_top1_bin", imax.float() / term.bin_count)):
+        term.metrics[key].copy_(torch.where(anyone, val.expand(n), term.metrics[key]))
+    # the motion frame of every env + noise, written where `mask` is set (:299-363)
+    m1 = mask[:, None]
+    (plo, phi), (vlo, vhi) = self._command_ranges[id(term)]
+    rs = rm.sample_uniform(plo, phi, (n, 6), device=dev)
+    root_pos = term.body_pos_w[:, 0] + rs[:, 0:3]
+    root_ori = rm.quat_mul(rm.quat_from_euler_xyz(rs[:, 3], rs[:, 4], rs[:, 5]), term.body_quat_w[:, 0])
+    rs = rm.sample_uniform(vlo, vhi, (n, 6), device=dev)
+    root_lin_vel = term.body_lin_vel_w[:, 0] + rs[:, :3]
+    root_ang_vel = term.body_ang_vel_w[:, 0] + rs[:, 3:]
+    joint_pos = term.joint_pos.clone()
+    joint_vel = term.joint_vel
+    joint_pos += rm.sample_uniform(cfg.joint_position_range[0], cfg.joint_position_range[1], joint_pos.shape, dev)
+    lim = term.robot.data.soft_joint_pos_limits
+    joint_pos = torch.clip(joint_pos, lim[:, :, 0], lim[:, :, 1])
+    d, ix = term.robot.data.data, term.robot.indexing
+    d.qpos[:, ix.joint_q_adr] = torch.where(m1, joint_pos, d.qpos[:, ix.joint_q_adr])
+    d.qvel[:, ix.joint_v_adr] = torch.where(m1, joint_vel, d.qvel[:, ix.joint_v_adr])
+    d.qpos[:, ix.free_joint_q_adr] = torch.where(m1, torch.cat([root_pos, root_ori], dim=-1), d.qpos[:, ix.free_joint_q_adr])
+    d.qvel[:, ix.free_joint_v_adr] = torch.where(m1, torch.cat([root_lin_vel, rm.quat_apply_inverse(root_ori, root_ang_vel)], dim=-1), d.qvel[:, ix.free_joint_v_adr])
+    self._clear_state(term.robot, mask)
+
+  def _update_MotionCommand(self, term: Any) -> None:
+    """``_update_command`` (:365-392)."""
     rm = self._m
-    for name in self.env.command_manager.active_terms:
-      term = self.env.command_manager.get_term(name)
-      cfg = term.cfg
-      term._update_metrics()  # the reference's own
-      term.time_left -= self.dt
-      self._command_resample(term, term.time_left <= 0.0)
-      v = term.vel_command_b
-      if cfg.heading_command:
-        err = rm.wrap_to_pi(term.heading_target - term.robot.data.heading_w)
-        yaw = torch.clip(cfg.heading_control_stiffness * err, min=cfg.ranges.ang_vel_z[0], max=cfg.ranges.ang_vel_z[1])
-        v[:, 2] = torch.where(term.is_heading_env, yaw, v[:, 2])
-      v.masked_fill_(term.is_standing_env[:, None], 0.0)
+    term.time_steps += 1
+    self._resample_MotionCommand(term, term.time_steps >= term.motion.time_step_total)
+    nb = len(term.cfg.body_names)
+    anchor_pos = term.anchor_pos_w[:, None, :].repeat(1, nb, 1)
+    anchor_quat = term.anchor_quat_w[:, None, :].repeat(1, nb, 1)
+    delta_pos = term.robot_anchor_pos_w[:, None, :].repeat(1, nb, 1)
+    robot_quat = term.robot_anchor_quat_w[:, None, :].repeat(1, nb, 1)
+    delta_pos[..., 2] = anchor_pos[..., 2]
+    delta_ori = rm.yaw_quat(rm.quat_mul(robot_quat, rm.quat_inv(anchor_quat)))
+    term.body_quat_relative_w = rm.quat_mul(delta_ori, term.body_quat_w)
+    term.body_pos_relative_w = delta_pos + rm.quat_apply(delta_ori, term.body_pos_w - anchor_pos)
+    term.bin_failed_count = term.cfg.adaptive_alpha * term._current_bin_failed + (1 - term.cfg.adaptive_alpha) * term.bin_failed_count
+    term._current_bin_failed.zero_()
 
   # ---------------------------------------------------------------------------------------------------------------- interval
   def _interval_events(self) -> None:

@@ -46,8 +46,9 @@ def _sync(a, b) -> None:
   n = a.num_envs
   sa, sb = [], []
   for ma, mb in zip(_managers(a), _managers(b), strict=True):
-    _state_tensors(ma, n, set(), sa)
-    _state_tensors(mb, n, set(), sb)
+    any_shape = ma is a.command_manager  # command terms also carry global state (the tracking task's sampler)
+    _state_tensors(ma, None if any_shape else n, set(), sa)
+    _state_tensors(mb, None if any_shape else n, set(), sb)
   assert [p for *_, p in sa] == [p for *_, p in sb], "the two environments do not hold the same state tensors"
   for (_, _, ta, _), (_, _, tb, _) in zip(sa, sb, strict=True):
     tb.copy_(ta)
@@ -135,5 +136,76 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
       assert dv.max() > 0, "two independent pushes came out identical"
     stats["resets"] += int(reset.sum()); stats["resamples"] += int((resample & ~reset).sum()); stats["pushes"] += int(push.sum())
     stats["quiet_env_steps"] += int(quiet.sum()); stats["forward_steps"] += int(reset.any())
+  stats["graph"] = g.graph is not None
+  return stats
+
+
+def run_tracking(make_env, device: str, num_envs: int = 32, steps: int = 40, capture: bool = True) -> dict:
+  """The same teacher-forced comparison for ``Mjlab-Tracking-Flat-Unitree-G1`` (``MotionCommand``: resets to motion phases drawn by
+  the adaptive sampler, resampling when a motion ends, the sampler's global failure statistics)."""
+
+  def edit(cfg):
+    for group in ("policy", "critic"):
+      getattr(cfg.observations, group).enable_corruption = False
+    cfg.events.push_robot.interval_range_s = (0.1, 0.4)
+
+  torch.manual_seed(0)
+  a = make_env(num_envs, device, edit)
+  b = make_env(num_envs, device, edit)
+  a.reset()
+  b.reset()
+  g = GraphedRlEnv(b, capture=capture)
+  gen = torch.Generator(device=device)
+  gen.manual_seed(5)
+  cmd_a, cmd_b = a.command_manager.get_term("motion"), b.command_manager.get_term("motion")
+  ev = a.event_manager
+  total = cmd_a.motion.time_step_total
+  stats = {"resets": 0, "ended": 0, "pushes": 0, "quiet_env_steps": 0}
+  dt = a.step_dt
+  for k in range(steps):
+    _sync(a, b)
+    if k % 7 == 3:  # some motions run out: resample in _update_command without a reset
+      cmd_a.time_steps[: num_envs // 8] = total - 2
+      cmd_b.time_steps[: num_envs // 8] = total - 2
+    action = (torch.rand((num_envs, 29), device=device, generator=gen) * 2 - 1) * 0.3
+    ended = (cmd_a.time_steps + 1) >= total
+    push = (ev._interval_term_time_left[0] - dt) < 1e-6
+    obs_a, rew_a, term_a, to_a, _ = a.step(action.clone())
+    obs_b, rew_b, term_b, to_b, _ = g.step(action.clone())
+    if device != "cpu":
+      torch.cuda.synchronize()
+    assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b), k
+    assert torch.equal(rew_a, rew_b), (k, (rew_a - rew_b).abs().max())
+    reset = term_a | to_a
+    quiet = ~(reset | ended | push)
+    for grp in obs_a:
+      assert torch.equal(obs_a[grp][quiet], obs_b[grp][quiet]), (k, grp, (obs_a[grp][quiet] - obs_b[grp][quiet]).abs().max())
+    for f in ("qpos", "qvel", "ctrl", "xpos", "cvel"):
+      assert torch.equal(getattr(a.sim.data, f)[quiet], getattr(b.sim.data, f)[quiet]), (k, f)
+    assert torch.equal(cmd_a.time_steps[quiet], cmd_b.time_steps[quiet])
+    assert torch.equal(cmd_a.body_pos_relative_w[quiet], cmd_b.body_pos_relative_w[quiet]) and torch.equal(cmd_a.body_quat_relative_w[quiet], cmd_b.body_quat_relative_w[quiet])
+    assert torch.equal(cmd_a.bin_failed_count, cmd_b.bin_failed_count), k  # the sampler's global statistics: no randomness in them
+    assert torch.equal(a.episode_length_buf, b.episode_length_buf)
+    # ---- resampled environments: a motion frame plus the cfg's noise (MotionCommand._resample_command), on both sides
+    rs = reset | ended
+    if rs.any():
+      for env, cm in ((a, cmd_a), (b, cmd_b)):
+        t = cm.time_steps[rs]
+        assert bool((t >= 0).all()) and bool((t < total).all())
+        q, v = env.sim.data.qpos[rs], env.sim.data.qvel[rs]
+        # the command advanced by one frame after the resample only for resets (reset -> compute -> time_steps += 1); compare with both
+        for off in (0, 1):
+          tt = (t - off).clamp(min=0)
+          jdev = (q[:, 7:] - cm.motion.joint_pos[tt]).abs().amax(dim=1)
+          ok = jdev <= 0.1 + 1e-5 if off == 0 else ok | (jdev <= 0.1 + 1e-5)
+        assert bool(ok.all()), jdev.max()
+        pr = cm.cfg.pose_range
+        root = cm.motion._body_pos_w[(t - 1).clamp(min=0), cm.body_indexes[0]] + env.scene.env_origins[rs]
+        root0 = cm.motion._body_pos_w[t, cm.body_indexes[0]] + env.scene.env_origins[rs]
+        dz = torch.minimum((q[:, 2] - root[:, 2]).abs(), (q[:, 2] - root0[:, 2]).abs())
+        pushed_now = push[rs]
+        assert bool((dz <= pr["z"][1] + 1e-5).all()), dz.max()
+        assert bool((env.episode_length_buf[reset] == 0).all())
+    stats["resets"] += int(reset.sum()); stats["ended"] += int((ended & ~reset).sum()); stats["pushes"] += int(push.sum()); stats["quiet_env_steps"] += int(quiet.sum())
   stats["graph"] = g.graph is not None
   return stats

@@ -104,3 +104,32 @@ def test_registered_g1_tracking_task_runs_over_the_hip_simulation(tmp_path):
   assert res["finite"] and res["resets"] > 0 and res["obs"] == {"policy": [256, 160], "critic": [256, 286]}
   assert res["overflow"] == {"nconmax": 0, "njmax": 0, "terrain_candidates": 0} and 0.0 < res["zmin"] and res["zmax"] < 1.3 and res["phase_max"] < 500
   print(f"reference G1 tracking task over mjlab_amd.Simulation: 60 env steps x 256 envs, {res['resets']} resets, mean reward {res['mean_reward']:.4f}")
+
+
+_TRACKING_GRAPHED = """
+import json, sys
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env, _graphed_check
+from _motion_fixture import write_full_motion
+write_full_motion({motion!r})
+def make(n, device, edit):
+  def both(cfg):
+    cfg.commands.motion.motion_file = {motion!r}
+    edit(cfg)
+  return reference_env.make_env("Mjlab-Tracking-Flat-Unitree-G1", num_envs=n, device=device, seed=7, cfg_edit=both)
+print("RESULT " + json.dumps(_graphed_check.run_tracking(make, "cuda:0", num_envs=128, steps=40, capture=True)))
+"""
+
+
+def test_graphed_tracking_env_matches_the_reference_env(tmp_path):
+  """The tracking task's whole control step as one hipGraph (``MotionCommand`` restated mask based: adaptive phase sampling by inverse
+  CDF, resampling when a motion ends) against the reference's eager ``env.step``, teacher-forced, on the MI355X."""
+  import json
+  import subprocess
+
+  code = _TRACKING_GRAPHED.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"), motion=str(tmp_path / "motion.npz"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print("graphed tracking env vs reference env:", st)
+  assert st["graph"] and st["resets"] >= 128 and st["ended"] >= 32 and st["pushes"] >= 64 and st["quiet_env_steps"] >= 2000

@@ -40,3 +40,33 @@ def test_unsupported_terms_are_refused_loudly():
   env = reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=4, device="cpu", sim_cls=OracleSimulation, cfg_edit=edit)
   with pytest.raises(NotImplementedError, match="push_robot"):
     GraphedRlEnv(env, capture=False)
+
+
+_TRACKING = """
+import json, sys
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env, _graphed_check
+from _motion_fixture import write_full_motion
+from _oracle_simulation import OracleSimulation
+write_full_motion({motion!r})
+def make(n, device, edit):
+  def both(cfg):
+    cfg.commands.motion.motion_file = {motion!r}
+    edit(cfg)
+  return reference_env.make_env("Mjlab-Tracking-Flat-Unitree-G1", num_envs=n, device=device, sim_cls=OracleSimulation, seed=7, cfg_edit=both)
+print("RESULT " + json.dumps(_graphed_check.run_tracking(make, "cpu", num_envs=32, steps=40, capture=False)))
+"""
+
+
+def test_mask_based_control_step_of_the_tracking_task(tmp_path):
+  """The second task north_star names: ``MotionCommand`` (adaptive sampling of the reset phase, resampling when a motion ends,
+  body-relative targets) behind GraphedRlEnv, against the reference's own step.  Own process (the tracking task's configs)."""
+  import json
+  import subprocess
+
+  code = _TRACKING.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"), motion=str(tmp_path / "motion.npz"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print(st)
+  assert st["resets"] >= 32 and st["ended"] >= 8 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400
