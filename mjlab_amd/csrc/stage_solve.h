@@ -801,6 +801,13 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           c.s_jar[r] = nw;
         }
         const bool any_changed = __ballot(changed) != 0ull;
+#ifdef MJLAB_PROFILE  // how many rows switch zone per Newton iteration (slots 1 and 4 carry no phase): would rank-1 updates of the factor pay?
+        {
+          const int nch = __popcll(__ballot(changed));
+          prof_acc_[1] += (float)nch;
+          if (nch > 0 && nch <= 3) prof_acc_[4] += 1.f;
+        }
+#endif
         __syncthreads();
         const float oldcost = cost;
 #ifndef MJLAB_NO_LSDIFF_COST

@@ -159,6 +159,9 @@ def run_tracking(make_env, device: str, num_envs: int = 32, steps: int = 40, cap
   gen.manual_seed(5)
   cmd_a, cmd_b = a.command_manager.get_term("motion"), b.command_manager.get_term("motion")
   ev = a.event_manager
+  # MotionCommand._update_metrics creates two of its metric entries on its first call: one step on each side, so that both hold them
+  a.step(torch.zeros((num_envs, 29), device=device))
+  g.step(torch.zeros((num_envs, 29), device=device))
   total = cmd_a.motion.time_step_total
   stats = {"resets": 0, "ended": 0, "pushes": 0, "quiet_env_steps": 0}
   dt = a.step_dt

@@ -126,14 +126,14 @@ def load(scene):
 # fp32 oracle after 4 substeps under the grid line search (measured x 3; velocities carry the solver's qacc noise x 4 dt)
 ATOL_CPU = {"base_lin_vel": 2e-6, "base_ang_vel": 2e-6, "projected_gravity": 1e-6, "joint_pos": 1e-6, "joint_vel": 1e-5, "actions": 0.0, "command": 0.0,
             "motion_anchor_pos_b": 1e-6, "motion_anchor_ori_b": 1e-6, "body_pos": 2e-6, "body_ori": 2e-6}
-ATOL_GPU = {"base_lin_vel": 2e-4, "base_ang_vel": 1e-3, "projected_gravity": 2e-5, "joint_pos": 1e-4, "joint_vel": 5e-3, "actions": 0.0, "command": 0.0,
+ATOL_GPU = {"base_lin_vel": 2e-4, "base_ang_vel": 1e-3, "projected_gravity": 2e-5, "joint_pos": 2e-5, "joint_vel": 5e-3, "actions": 0.0, "command": 0.0,
             "motion_anchor_pos_b": 2e-5, "motion_anchor_ori_b": 2e-5, "body_pos": 2e-5, "body_ori": 5e-5}
 _MARGIN: dict = {}
 
 
 # GPU: the share of (world, step) rows that must lie entirely within 1 x / WORST x a term's bound, and the sanity cap on the rest
 # (worlds whose solve parted under the grid search: see state_tol in the GPU test)
-WORST, ROWS_1X, ROWS_WORST, SANITY = 20.0, 0.92, 0.985, 5.0e4  # measured r04_v7: 1 x >= 0.9375 (body_ori, 320 rows) .. 1.0; 20 x >= 0.9938
+WORST, ROWS_1X, ROWS_WORST, SANITY = 3.0, 0.99, 1.0, 3.0  # measured r04_v11: every row within 1 x but 1 of 320 (joint_vel, tracking: 1.08 x)
 
 
 def compare_terms(meta, z, k, dv, atol, tag, stats):
@@ -341,13 +341,11 @@ def test_hip_path_reproduces_the_reference_environment(scene):
     s.torch.cuda.synchronize()
     return Derived.from_readback(s.rb)
 
-  # per-world relative error of the 4-substep state over the 1280 / 320 replayed world-steps: (median, p90, p99, max).  Two fp32
-  # implementations under the grid line search part wherever they pick different candidates in a late Newton iteration (parity gate,
-  # GRID literals for ONE step: worst world qpos 2e-4, qvel 1e-2); over 4 substeps the worst worlds -- robots standing on 28 foot
-  # contacts (112 rows), reset poses with interpenetrating feet on the tracking task -- reach qpos 1.6e-3, qvel 8.4e-3 (r04_v5).  The
-  # One world of the tracking recording (a reset pose with interpenetrating feet: parity gate, TRACKING literals) parts by 0.5 in
-  # qvel over the 4 substeps.  The contract is the distribution: median at fp32 rounding, p90 at north_star's 1e-5 (qvel: x h^-1 ~
-  # 1e-3), p99 bounded, and at most 0.5 % of the world-steps beyond the outlier line (qpos 1e-3, qvel 3e-2)
-  n = _replay(scene, _HipReplay, derive, ATOL_GPU, "gpu", {"qpos": (5e-6, 1e-5, 3e-4, 1e-3, 0.005), "qvel": (5e-5, 1e-3, 1e-2, 3e-2, 0.005)})
+  # per-world relative error of the 4-substep state over the 1280 / 320 replayed world-steps: (median, p90, p99, outlier line, share
+  # beyond it).  Measured (r04_v11, recordings made over the fp32 oracle whose grid search compares candidates by cost differences
+  # like the kernel: oracle/Makefile): qpos median 6.5e-8 / p90 2.3e-7 / p99 1.0e-5 / max 2.8e-5; qvel 1.7e-6 / 4.7e-6 / 3.6e-4 /
+  # 8.5e-4 -- north_star's 1e-5 on the state at the p99, on the driver's box, against the reference environment's own run.  (Recorded
+  # over the LITERAL fp32 grid search the same replay showed qpos p90 1.2e-5, max 5e-3: that search's 1e-4 floor in qacc)
+  n = _replay(scene, _HipReplay, derive, ATOL_GPU, "gpu", {"qpos": (5e-7, 1e-6, 3e-5, 1e-4, 0.0), "qvel": (5e-6, 1.5e-5, 1e-3, 3e-3, 0.0)})
   meta, _ = load(scene)
   assert n == meta["num_steps"] * len(meta["obs_terms"]["critic"])

@@ -32,14 +32,18 @@ for _ in range(nstep):
 torch.cuda.synchronize()
 pall = sim.data.profile.cpu().numpy().astype(np.float64) / nstep
 p = pall[:, :16]
-tot = p[:, :10].sum(axis=1) + p[:, 12] + p[:, 13]
+tot = p[:, [0, 2, 3, 5, 6, 7, 8, 9, 12, 13]].sum(axis=1)
 print(f"mean cycles per world-step in k_solve_integrate: {tot.mean():.0f}  (p50 {np.percentile(tot,50):.0f}, p90 {np.percentile(tot,90):.0f}, max {tot.max():.0f})")
 for i, n in enumerate(NAMES):
+  if i in (1, 4):
+    continue  # (re-used as counters: see below)
   if i < 10 or i in (12, 13):
     print(f"  {n:28s} {p[:, i].mean():10.0f} cycles  {100*p[:, i].mean()/tot.mean():5.1f}%")
   else:
     print(f"  {n:28s} {p[:, i].mean():10.2f}")
 print("nefc mean", sim.data.nefc.float().mean().item(), "niter mean", sim.data.solver_niter.float().mean().item())
+print(f"rows that switch zone per world-step: {p[:, 1].mean():.2f} (per line search {p[:, 1].mean() / max(p[:, 11].mean(), 1e-9):.2f}); "
+      f"iterations whose active set changed by 1..3 rows: {p[:, 4].mean():.2f} of {p[:, 14].mean() - 2:.2f} refactorizations per world-step")
 # the kernel ends with its slowest wave: same breakdown for the slowest 2% of worlds
 slow = np.argsort(tot)[-max(1, len(tot) // 50):]
 print(f"slowest 2% of worlds: mean cycles {tot[slow].mean():.0f}; nefc {sim.data.nefc.cpu().numpy().ravel()[slow].mean():.1f}; niter {sim.data.solver_niter.cpu().numpy().ravel()[slow].mean():.2f}")
