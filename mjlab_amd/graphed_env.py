@@ -28,9 +28,11 @@ a static buffer and replays the graph.  What the graph holds:
   (tests/test_gpu_reference_env.py::test_graphed_env_matches_the_reference_env).
 
 ``sim.forward()`` after the resets runs on all worlds exactly when some environment reset, like the reference (:129-132), decided
-on the device (``mask.any()`` broadcast into the forward mask).  A term the restatements do not know (another event function,
-another command class, curriculum terms, observation history) raises NotImplementedError at construction -- nothing is silently
-skipped.  ``extras["log"]`` holds 0-dim device tensors (the reference's floats would need a host sync per step).
+on the device (``mask.any()`` broadcast into the forward mask).  Commands: ``UniformVelocityCommand`` (velocity tasks) and
+``MotionCommand`` (tracking task: adaptive phase sampling by inverse CDF instead of ``torch.multinomial`` + ``bincount``, the sampler's
+global failure statistics kept on the device); curriculum: ``commands_vel`` (its rule -- first reset after a step threshold -- evaluated
+on the device, the command ranges in device tensors).  A term the restatements do not know (another event function, another command
+class, another curriculum term, observation history) raises NotImplementedError at construction -- nothing is silently skipped.  ``extras["log"]`` holds 0-dim device tensors (the reference's floats would need a host sync per step).
 """
 
 from __future__ import annotations
@@ -43,6 +45,13 @@ import torch
 SUPPORTED_RESET_EVENTS = ("reset_root_state_uniform", "reset_joints_by_scale")
 SUPPORTED_INTERVAL_EVENTS = ("push_by_setting_velocity",)
 SUPPORTED_COMMANDS = ("UniformVelocityCommand", "MotionCommand")
+# curriculum terms with a mask-based restatement: tasks/velocity/mdp/curriculums.py:60-74 commands_vel (widens the command's velocity
+# ranges once the step counter has passed a stage).  The reference evaluates it inside _reset_idx -- i.e. in the first step AFTER the
+# threshold in which some environment resets, and before that step's command resampling -- by assigning Python floats to the command
+# cfg.  Here the ranges the captured kernels read live in device tensors and the same rule runs on the device (step counter on the
+# device, ``mask.any()``), so the switch happens in exactly the reference's step and the graph is not captured again; the host cfg is
+# refreshed for readers of ``cfg.ranges`` by the same rule evaluated on the host counter (without the reset condition).
+SUPPORTED_CURRICULA = ("commands_vel",)
 _AXES = ("x", "y", "z", "roll", "pitch", "yaw")
 
 
@@ -108,8 +117,9 @@ class GraphedRlEnv:
     for name in env.command_manager.active_terms:
       if type(env.command_manager.get_term(name)).__name__ not in SUPPORTED_COMMANDS:
         raise NotImplementedError(f"command term '{name}' ({type(env.command_manager.get_term(name)).__name__}) has no mask-based restatement")
-    if getattr(env.curriculum_manager, "active_terms", None):
-      raise NotImplementedError("curriculum terms are not supported by GraphedRlEnv")
+    for name, cfg in zip(getattr(env.curriculum_manager, "active_terms", []), getattr(env.curriculum_manager, "_term_cfgs", []), strict=False):
+      if getattr(cfg.func, "__name__", "") not in SUPPORTED_CURRICULA:
+        raise NotImplementedError(f"curriculum term '{name}' ({getattr(cfg.func, '__name__', cfg.func)}) is not supported by GraphedRlEnv")
     om = env.observation_manager
     if any(om._group_obs_term_history_buffer[g] for g in om._group_obs_term_history_buffer) or any(om._group_obs_class_term_cfgs[g] for g in om._group_obs_class_term_cfgs):
       raise NotImplementedError("observation history buffers / class-based observation terms are not supported by GraphedRlEnv")
@@ -132,9 +142,19 @@ class GraphedRlEnv:
         self._reset_terms.append((fn, {"position_range": p["position_range"], "velocity_range": p["velocity_range"], "joint_ids": ids}))
     for index, cfg in enumerate(ev._mode_term_cfgs.get("interval", [])):
       self._interval_terms.append((index, cfg.interval_range_s, _range_tensors(cfg.params["velocity_range"], dev)))
+    self._stage_ranges = {}
+    cm = self.env.curriculum_manager
+    for name, cfg in zip(getattr(cm, "active_terms", []), getattr(cm, "_term_cfgs", []), strict=False):
+      for k, stage in enumerate(cfg.params["velocity_stages"]):
+        self._stage_ranges[(name, k)] = torch.tensor(stage["range"], dtype=torch.float32, device=dev)
     self._command_ranges = {}
+    self._step_counter = torch.full((), int(self.env.common_step_counter), dtype=torch.long, device=dev)  # env.common_step_counter on the device
     for name in self.env.command_manager.active_terms:
       term = self.env.command_manager.get_term(name)
+      if type(term).__name__ == "UniformVelocityCommand":  # ranges as device tensors [lo, hi]: a curriculum may change them inside the graph
+        rg = term.cfg.ranges
+        self._command_ranges[id(term)] = {k: torch.tensor(getattr(rg, k), dtype=torch.float32, device=dev)
+                                          for k in ("lin_vel_x", "lin_vel_y", "ang_vel_z", "heading") if getattr(rg, k, None) is not None}
       if type(term).__name__ == "MotionCommand":
         self._command_ranges[id(term)] = (_range_tensors(term.cfg.pose_range, dev), _range_tensors(term.cfg.velocity_range, dev))
         self._patch_body_index_lists(term)
@@ -213,6 +233,12 @@ class GraphedRlEnv:
       self._body()
     env._sim_step_counter += env.cfg.decimation
     env.common_step_counter += 1
+    cm = env.curriculum_manager  # host copy of the command ranges for readers of cfg.ranges (the graph reads the device tensors)
+    for cfg in getattr(cm, "_term_cfgs", []):
+      for stage in cfg.params["velocity_stages"]:
+        if env.common_step_counter > stage["step"]:
+          rg = env.command_manager.get_term(cfg.params["command_name"]).cfg.ranges
+          rg.lin_vel_x = rg.ang_vel_z = stage["range"]
     if env.common_step_counter % 16 == 0 and hasattr(env.sim, "update_priority_thresholds"):
       env.sim.update_priority_thresholds()  # scheduling hint of the physics kernels (not part of the graph: it reads quantiles)
     return env.obs_buf, env.reward_buf, env.reset_terminated, env.reset_time_outs, env.extras
@@ -228,6 +254,7 @@ class GraphedRlEnv:
     env.sim.step(env.cfg.decimation)
     env.scene.update(dt=env.physics_dt)
     env.episode_length_buf += 1
+    self._step_counter += 1  # (:117 common_step_counter, for the curriculum terms)
     env.reset_buf = env.termination_manager.compute()
     env.reset_terminated = env.termination_manager.terminated
     env.reset_time_outs = env.termination_manager.time_outs
@@ -267,6 +294,7 @@ class GraphedRlEnv:
     env, m1 = self.env, mask[:, None]
     cnt = mask.sum().clamp(min=1).to(torch.float32)
     log: dict = {}
+    self._curricula(mask.any())  # curriculum_manager.compute(env_ids) comes first (:215), and only when some environment resets
     self._clear_state(self._robot, mask)  # scene.reset -> Entity.reset -> clear_state
     # reset-mode events (managers/event_manager.py:139-148 with min_step_count 0)
     step_count = env._sim_step_counter // env.cfg.decimation  # (baked in at capture; read by nothing the supported terms use)
@@ -300,6 +328,19 @@ class GraphedRlEnv:
       log["Episode_Termination/" + key] = (dones & mask).sum()
     env.extras["log"] = log
     env.episode_length_buf.masked_fill_(mask, 0)
+
+  def _curricula(self, any_reset: torch.Tensor) -> None:
+    """CurriculumManager.compute (managers/curriculum_manager.py:97-102) for ``commands_vel`` (tasks/velocity/mdp/curriculums.py:60-74)."""
+    cm = self.env.curriculum_manager
+    for name, cfg in zip(getattr(cm, "active_terms", []), getattr(cm, "_term_cfgs", []), strict=False):
+      term = self.env.command_manager.get_term(cfg.params["command_name"])
+      rg = self._command_ranges[id(term)]
+      for k, stage in enumerate(cfg.params["velocity_stages"]):
+        on = any_reset & (self._step_counter > int(stage["step"]))
+        new = self._stage_ranges[(name, k)]
+        rg["lin_vel_x"].copy_(torch.where(on, new, rg["lin_vel_x"]))
+        rg["ang_vel_z"].copy_(torch.where(on, new, rg["ang_vel_z"]))
+      cm._curriculum_state[name] = rg["lin_vel_x"][1:2]
 
   @staticmethod
   def _clear_state(robot: Any, mask: torch.Tensor) -> None:
@@ -374,14 +415,15 @@ class GraphedRlEnv:
 
   # -- UniformVelocityCommand (tasks/velocity/mdp/velocity_command.py:64-102)
   def _resample_UniformVelocityCommand(self, term: Any, mask: torch.Tensor) -> None:
-    cfg, n, dev = term.cfg, self.n, self.device
+    cfg, n, dev, rg = term.cfg, self.n, self.device, self._command_ranges[id(term)]
     u = lambda lo, hi: torch.rand(n, device=dev) * (hi - lo) + lo  # noqa: E731
+    ur = lambda r: torch.rand(n, device=dev) * (r[1] - r[0]) + r[0]  # noqa: E731  (range on the device: a curriculum may move it)
     v = term.vel_command_b
-    v[:, 0] = torch.where(mask, u(*cfg.ranges.lin_vel_x), v[:, 0])
-    v[:, 1] = torch.where(mask, u(*cfg.ranges.lin_vel_y), v[:, 1])
-    v[:, 2] = torch.where(mask, u(*cfg.ranges.ang_vel_z), v[:, 2])
+    v[:, 0] = torch.where(mask, ur(rg["lin_vel_x"]), v[:, 0])
+    v[:, 1] = torch.where(mask, ur(rg["lin_vel_y"]), v[:, 1])
+    v[:, 2] = torch.where(mask, ur(rg["ang_vel_z"]), v[:, 2])
     if cfg.heading_command:
-      term.heading_target.copy_(torch.where(mask, u(*cfg.ranges.heading), term.heading_target))
+      term.heading_target.copy_(torch.where(mask, ur(rg["heading"]), term.heading_target))
       term.is_heading_env.copy_(torch.where(mask, u(0.0, 1.0) <= cfg.rel_heading_envs, term.is_heading_env))
     term.is_standing_env.copy_(torch.where(mask, u(0.0, 1.0) <= cfg.rel_standing_envs, term.is_standing_env))
     if cfg.init_velocity_prob > 0.0:
@@ -401,7 +443,8 @@ class GraphedRlEnv:
     rm, cfg, v = self._m, term.cfg, term.vel_command_b
     if cfg.heading_command:
       err = rm.wrap_to_pi(term.heading_target - term.robot.data.heading_w)
-      yaw = torch.clip(cfg.heading_control_stiffness * err, min=cfg.ranges.ang_vel_z[0], max=cfg.ranges.ang_vel_z[1])
+      az = self._command_ranges[id(term)]["ang_vel_z"]
+      yaw = torch.clip(cfg.heading_control_stiffness * err, min=az[0], max=az[1])
       v[:, 2] = torch.where(term.is_heading_env, yaw, v[:, 2])
     v.masked_fill_(term.is_standing_env[:, None], 0.0)
 

@@ -73,9 +73,10 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
   reset_cfg = next(c for c in ev._mode_term_cfgs["reset"] if c.func.__name__ == "reset_root_state_uniform")
   stats = {"resets": 0, "resamples": 0, "pushes": 0, "quiet_env_steps": 0, "forward_steps": 0}
   dt = a.step_dt
+  na = sum(a.action_manager.action_term_dim)
   for k in range(steps):
     _sync(a, b)
-    action = torch.rand((num_envs, 29), device=device, generator=gen) * 2 - 1
+    action = torch.rand((num_envs, na), device=device, generator=gen) * 2 - 1
     if k > 20:
       action[: num_envs // 8] *= 6.0  # a few robots flail and fall: fell_over terminations besides the time-outs
     # which envs will draw random numbers in this step (a function of the synced pre-step state)

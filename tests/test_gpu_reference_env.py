@@ -133,3 +133,40 @@ def test_graphed_tracking_env_matches_the_reference_env(tmp_path):
   st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
   print("graphed tracking env vs reference env:", st)
   assert st["graph"] and st["resets"] >= 32 and st["ended"] >= 32 and st["pushes"] >= 64 and st["quiet_env_steps"] >= 2000  # measured: 71 / 108 / 339 / 4618
+
+
+_GO1_GRAPHED = """
+import json, sys
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env, _graphed_check
+import mjlab_amd.graphed_env as ge
+ncap = [0]
+orig = ge.GraphedRlEnv.capture
+def counting(self, warmup=2):
+  ncap[0] += 1
+  return orig(self, warmup)
+ge.GraphedRlEnv.capture = counting
+def make(n, device, edit):
+  def both(cfg):
+    edit(cfg)
+    cfg.curriculum.command_vel.params["velocity_stages"] = [dict(step=30, range=(-3.0, 3.0))]
+  return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-Go1", num_envs=n, device=device, seed=11, cfg_edit=both)
+st = _graphed_check.run(make, "cuda:0", num_envs=128, steps=60, capture=True)
+st["captures"] = ncap[0]
+print("RESULT " + json.dumps(st))
+"""
+
+
+def test_graphed_go1_env_with_its_curriculum(tmp_path):
+  """The Go1 velocity task (BASELINE config 2's robot) as one hipGraph, its ``commands_vel`` curriculum switching the command ranges
+  after step 30 INSIDE the graph (ranges in device tensors, the reference's rule -- first reset after the threshold -- evaluated on
+  the device): captured once, and the comparison with the reference's eager step holds bit for bit across the switch."""
+  import json
+  import subprocess
+
+  code = _GO1_GRAPHED.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print("graphed Go1 env vs reference env:", st)
+  assert st["graph"] and st["captures"] == 1 and st["resets"] >= 64 and st["pushes"] >= 64 and st["quiet_env_steps"] >= 2000

@@ -70,3 +70,32 @@ def test_mask_based_control_step_of_the_tracking_task(tmp_path):
   st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
   print(st)
   assert st["resets"] >= 8 and st["ended"] >= 8 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400
+
+
+_GO1 = """
+import json, sys
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env, _graphed_check
+from _oracle_simulation import OracleSimulation
+def make(n, device, edit):
+  def both(cfg):
+    edit(cfg)
+    cfg.curriculum.command_vel.params["velocity_stages"] = [dict(step=30, range=(-3.0, 3.0))]  # the stage switches inside the run
+  return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-Go1", num_envs=n, device=device, sim_cls=OracleSimulation, seed=11, cfg_edit=both)
+st = _graphed_check.run(make, "cpu", num_envs=16, steps=60, capture=False)
+print("RESULT " + json.dumps(st))
+"""
+
+
+def test_go1_task_with_its_host_side_curriculum():
+  """``Mjlab-Velocity-Flat-Unitree-Go1`` keeps the ``commands_vel`` curriculum (widens the command ranges at the first reset after a
+  step threshold): GraphedRlEnv keeps the ranges in device tensors and applies the same rule on the device -- bit for bit across the
+  switch at step 30."""
+  import json
+  import subprocess
+
+  code = _GO1.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  assert st["resets"] >= 16 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400
