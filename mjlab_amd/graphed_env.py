@@ -211,18 +211,38 @@ class GraphedRlEnv:
   # ---------------------------------------------------------------------------------------------------------------- capture
   def capture(self, warmup: int = 2) -> None:
     """Warm-up passes on a side stream (allocator, lazy initialisation inside the reference's properties), then the capture."""
+    saved = self._save_state()  # the warm-up passes are real steps (with a zero action): the environment gets its state back
     s = torch.cuda.Stream(device=self.device)
     s.wait_stream(torch.cuda.current_stream(self.device))
     with torch.cuda.stream(s):
       for _ in range(warmup):
         self._body()
     torch.cuda.current_stream(self.device).wait_stream(s)
+    for t, c in saved:
+      t.copy_(c)
     torch.cuda.synchronize(self.device)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
       self._body()
     self.graph = g
     self._out = (self.env.obs_buf, self.env.reward_buf, self.env.reset_terminated, self.env.reset_time_outs)
+
+  def _save_state(self) -> list:
+    """(tensor, clone) of everything a control step mutates: mjData, the managers' and terms' buffers, the counters."""
+    env, found = self.env, []
+    for mgr in (env.action_manager, env.reward_manager, env.termination_manager, env.observation_manager, env.event_manager):
+      _state_tensors(mgr, self.n, set(), found)
+    _state_tensors(env.command_manager, None, set(), found)
+    tensors = [t for *_, t, _ in found] + list(env.sim._data.values()) + [env.episode_length_buf, self._step_counter]
+    tensors += [t for rg in self._command_ranges.values() if isinstance(rg, dict) for t in rg.values()]
+    seen, out = set(), []
+    for t in tensors:
+      if any(st == 0 and sz > 1 for st, sz in zip(t.stride(), t.shape)):
+        continue  # a broadcast view of a shared constant (default joint state, model fields): nothing writes through it
+      if t.data_ptr() not in seen and t.numel() > 0:
+        seen.add(t.data_ptr())
+        out.append((t, t.clone()))
+    return out
 
   def step(self, action: torch.Tensor):
     env = self.env
