@@ -137,6 +137,61 @@ def _quat_apply_inverse(q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
   return v - q[..., 0:1] * t + torch.cross(xyz, t, dim=-1)
 
 
+def motion_reset_tables(m: Model, motion: dict, motion_reset: dict | None, decimation: int, n: int, dev) -> dict:
+  """Device tables and parameters of the tracking task's reset (reference tasks/tracking/mdp/commands.py:30-65 MotionLoader,
+  :107 the adaptive sampler's one-second bins, tracking_env_cfg.py:56-76 the cfg's noise ranges): what ``motion_reset_rows`` and the
+  control kernel (``mjlab_motion_reset_t``) read."""
+  cfg = dict(TRACKING_TASK_EVENTS["g1"]["motion_reset"], **(motion_reset or {}))
+  tab = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=dev) for k, v in motion.items() if k != "fps"}
+  nframe = int(tab["joint_pos"].shape[0])
+  hinge = [j for j in range(m.njnt) if m.jnt_type[j] != JNT_FREE]
+  rng_ = np.asarray(m.jnt_range, dtype=np.float64)[hinge]
+  mean, half = 0.5 * (rng_[:, 0] + rng_[:, 1]), 0.5 * (rng_[:, 1] - rng_[:, 0]) * cfg["soft_joint_pos_limit_factor"]
+  limited = np.asarray(m.jnt_limited)[hinge].astype(bool)
+  soft_lo = torch.tensor(np.where(limited, mean - half, -np.inf), dtype=torch.float32, device=dev)
+  soft_hi = torch.tensor(np.where(limited, mean + half, np.inf), dtype=torch.float32, device=dev)
+  six = ("x", "y", "z", "roll", "pitch", "yaw")
+  pr = torch.tensor([cfg["pose_range"].get(k, (0.0, 0.0)) for k in six], dtype=torch.float32, device=dev)
+  vr = torch.tensor([cfg["velocity_range"].get(k, (0.0, 0.0)) for k in six], dtype=torch.float32, device=dev)
+  # bins of one second like the reference's adaptive sampler (commands.py:107); nothing has failed yet: uniform over the bins
+  return {"tab": tab, "nframe": nframe, "bins": int(nframe // (1.0 / (m.opt.timestep * decimation))) + 1, "soft_lo": soft_lo, "soft_hi": soft_hi,
+          "pose_range": pr, "velocity_range": vr, "joint_range": cfg["joint_position_range"], "dz": float(cfg["anchor_dz"]), "dup": float(cfg["anchor_dup"]),
+          "time_steps": torch.zeros((n,), dtype=torch.int32, device=dev), "rnd": torch.zeros((n, 14 + m.nq - 7), device=dev),
+          "reset_qpos": torch.zeros((n, m.nq), device=dev), "reset_qvel": torch.zeros((n, m.nv), device=dev), "term_ref": torch.zeros((n, 2), device=dev)}
+
+
+def motion_reset_rows(mo: dict, env_origins: torch.Tensor | None) -> torch.Tensor:
+  """Refresh, for EVERY world, the state its reset would write now (reference MotionCommand._resample_command,
+  tasks/tracking/mdp/commands.py:299-363: a motion frame of a freshly sampled phase + the cfg's noise, through
+  write_joint_state_to_sim / write_root_state_to_sim) and the termination reference of its current phase; returns the
+  sampled phases.  Plain device ops, no host sync: which worlds take their row is decided by the reset itself.  The control
+  kernel computes the same rows per resetting world (bit for bit: tests/test_gpu_fullsize.py); this function is checked element
+  by element against the reference's own ``_resample_command`` fed the same uniforms (tests/test_reference_env.py)."""
+  tab, T = mo["tab"], mo["nframe"]
+  u = mo["rnd"]  # refreshed by the caller: the same uniforms the control kernel reads (mjlab_motion_reset_t.rnd)
+  bins = torch.clamp((u[:, 0] * mo["bins"]).long(), max=mo["bins"] - 1)
+  t_new = ((bins.float() + u[:, 1]) / mo["bins"] * (T - 1)).long()
+  pose = mo["pose_range"][:, 0] + (mo["pose_range"][:, 1] - mo["pose_range"][:, 0]) * u[:, 2:8]
+  vel = mo["velocity_range"][:, 0] + (mo["velocity_range"][:, 1] - mo["velocity_range"][:, 0]) * u[:, 8:14]
+  root_pos = tab["body_pos_w"][t_new, 0] + pose[:, 0:3]
+  if env_origins is not None:
+    root_pos = root_pos + env_origins
+  root_ori = _quat_mul(_quat_from_euler_xyz(pose[:, 3], pose[:, 4], pose[:, 5]), tab["body_quat_w"][t_new, 0])
+  lin = tab["body_lin_vel_w"][t_new, 0] + vel[:, 0:3]
+  ang = _quat_apply_inverse(root_ori, tab["body_ang_vel_w"][t_new, 0] + vel[:, 3:6])
+  lo_j, hi_j = mo["joint_range"]
+  jp = torch.minimum(torch.maximum(tab["joint_pos"][t_new] + lo_j + (hi_j - lo_j) * u[:, 14:], mo["soft_lo"]), mo["soft_hi"])
+  torch.cat([root_pos, root_ori, jp], dim=1, out=mo["reset_qpos"])
+  torch.cat([lin, ang, tab["joint_vel"][t_new]], dim=1, out=mo["reset_qvel"])
+  t_cur = torch.clamp(mo["time_steps"].long(), max=T - 1)
+  q = tab["body_quat_w"][t_cur, 0]
+  z = tab["body_pos_w"][t_cur, 0, 2]
+  if env_origins is not None:
+    z = z + env_origins[:, 2]
+  torch.stack([z, 1.0 - 2.0 * (q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2])], dim=1, out=mo["term_ref"])
+  return t_new
+
+
 class PhysicsRollout:
   def __init__(self, sim: Simulation, action_scale: np.ndarray | float = 0.25, decimation: int = 4,
                episode_length_s: float = 20.0, min_height: float = 0.3, seed: int = 42, key: int = 0,
@@ -226,23 +281,9 @@ class PhysicsRollout:
     if motion is not None:
       if not self.has_free:
         raise ValueError("motion resets need a floating base")
+      self.motion = motion_reset_tables(m, motion, motion_reset, decimation, n, dev)
+      tab, nframe, soft_lo, soft_hi, pr, vr = (self.motion[k] for k in ("tab", "nframe", "soft_lo", "soft_hi", "pose_range", "velocity_range"))
       cfg = dict(TRACKING_TASK_EVENTS["g1"]["motion_reset"], **(motion_reset or {}))
-      tab = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=dev) for k, v in motion.items() if k != "fps"}
-      nframe = int(tab["joint_pos"].shape[0])
-      hinge = [j for j in range(m.njnt) if m.jnt_type[j] != JNT_FREE]
-      rng_ = np.asarray(m.jnt_range, dtype=np.float64)[hinge]
-      mean, half = 0.5 * (rng_[:, 0] + rng_[:, 1]), 0.5 * (rng_[:, 1] - rng_[:, 0]) * cfg["soft_joint_pos_limit_factor"]
-      limited = np.asarray(m.jnt_limited)[hinge].astype(bool)
-      soft_lo = torch.tensor(np.where(limited, mean - half, -np.inf), dtype=torch.float32, device=dev)
-      soft_hi = torch.tensor(np.where(limited, mean + half, np.inf), dtype=torch.float32, device=dev)
-      six = ("x", "y", "z", "roll", "pitch", "yaw")
-      pr = torch.tensor([cfg["pose_range"].get(k, (0.0, 0.0)) for k in six], dtype=torch.float32, device=dev)
-      vr = torch.tensor([cfg["velocity_range"].get(k, (0.0, 0.0)) for k in six], dtype=torch.float32, device=dev)
-      # bins of one second like the reference's adaptive sampler (commands.py:107); nothing has failed yet: uniform over the bins
-      self.motion = {"tab": tab, "nframe": nframe, "bins": int(nframe // (1.0 / (m.opt.timestep * decimation))) + 1, "soft_lo": soft_lo, "soft_hi": soft_hi,
-                     "pose_range": pr, "velocity_range": vr, "joint_range": cfg["joint_position_range"], "dz": float(cfg["anchor_dz"]), "dup": float(cfg["anchor_dup"]),
-                     "time_steps": torch.zeros((n,), dtype=torch.int32, device=dev), "rnd": torch.zeros((n, 14 + m.nq - 7), device=dev),
-                     "reset_qpos": torch.zeros((n, m.nq), device=dev), "reset_qvel": torch.zeros((n, m.nv), device=dev), "term_ref": torch.zeros((n, 2), device=dev)}
       if not (control_kernel or not fused_reset):
         raise ValueError("motion resets run in the control kernel or in the torch reset chain (fused_reset=False)")
       # the control kernel does all of this per resetting world itself (mjlab_motion_reset_t): tables and parameters, once
@@ -301,34 +342,7 @@ class PhysicsRollout:
     return q
 
   def _motion_rows(self) -> torch.Tensor:
-    """Refresh, for EVERY world, the state its reset would write now (reference MotionCommand._resample_command,
-    tasks/tracking/mdp/commands.py:299-363: a motion frame of a freshly sampled phase + the cfg's noise, through
-    write_joint_state_to_sim / write_root_state_to_sim) and the termination reference of its current phase; returns the
-    sampled phases.  Plain device ops, no host sync: which worlds take their row is decided by the reset itself."""
-    mo = self.motion
-    tab, T = mo["tab"], mo["nframe"]
-    u = mo["rnd"]  # refreshed by the caller: the same uniforms the control kernel reads (mjlab_motion_reset_t.rnd)
-    bins = torch.clamp((u[:, 0] * mo["bins"]).long(), max=mo["bins"] - 1)
-    t_new = ((bins.float() + u[:, 1]) / mo["bins"] * (T - 1)).long()
-    pose = mo["pose_range"][:, 0] + (mo["pose_range"][:, 1] - mo["pose_range"][:, 0]) * u[:, 2:8]
-    vel = mo["velocity_range"][:, 0] + (mo["velocity_range"][:, 1] - mo["velocity_range"][:, 0]) * u[:, 8:14]
-    root_pos = tab["body_pos_w"][t_new, 0] + pose[:, 0:3]
-    if self.env_origins is not None:
-      root_pos = root_pos + self.env_origins
-    root_ori = _quat_mul(_quat_from_euler_xyz(pose[:, 3], pose[:, 4], pose[:, 5]), tab["body_quat_w"][t_new, 0])
-    lin = tab["body_lin_vel_w"][t_new, 0] + vel[:, 0:3]
-    ang = _quat_apply_inverse(root_ori, tab["body_ang_vel_w"][t_new, 0] + vel[:, 3:6])
-    lo_j, hi_j = mo["joint_range"]
-    jp = torch.minimum(torch.maximum(tab["joint_pos"][t_new] + lo_j + (hi_j - lo_j) * u[:, 14:], mo["soft_lo"]), mo["soft_hi"])
-    torch.cat([root_pos, root_ori, jp], dim=1, out=mo["reset_qpos"])
-    torch.cat([lin, ang, tab["joint_vel"][t_new]], dim=1, out=mo["reset_qvel"])
-    t_cur = torch.clamp(mo["time_steps"].long(), max=T - 1)
-    q = tab["body_quat_w"][t_cur, 0]
-    z = tab["body_pos_w"][t_cur, 0, 2]
-    if self.env_origins is not None:
-      z = z + self.env_origins[:, 2]
-    torch.stack([z, 1.0 - 2.0 * (q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2])], dim=1, out=mo["term_ref"])
-    return t_new
+    return motion_reset_rows(self.motion, self.env_origins)
 
   def reset_all(self) -> None:
     d = self.sim.data

@@ -184,3 +184,69 @@ def test_tracking_task_constructs_and_steps(tmp_path):
   # the in-kernel restatement (mjlab_motion_reset_t)
   jdev, xy, z, v = res["reset"]
   assert jdev <= 0.1 + 1e-5 and xy <= 0.05 + 1e-5 and z <= 0.01 + 1e-5 and 0.05 < v <= 0.5 + 1e-5, res["reset"]
+
+
+_RESET_ROWS = """
+import json, sys
+import numpy as np
+import torch
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env
+from _motion_fixture import write_full_motion
+from _oracle_simulation import OracleSimulation
+from mjlab_amd import robots
+from mjlab_amd.rollout import TRACKING_TASK_EVENTS, motion_reset_rows, motion_reset_tables, synthetic_motion
+write_full_motion({motion!r})
+def edit(cfg):
+  cfg.commands.motion.motion_file = {motion!r}
+n = 64
+env = reference_env.make_env("Mjlab-Tracking-Flat-Unitree-G1", num_envs=n, device="cpu", sim_cls=OracleSimulation, cfg_edit=edit)
+env.reset()
+cmd = env.command_manager.get_term("motion")
+model = robots.load_model("g1_tracking_flat")
+mo = motion_reset_tables(model, synthetic_motion(model), TRACKING_TASK_EVENTS["g1"]["motion_reset"], 4, n, "cpu")
+assert mo["bins"] == cmd.bin_count and mo["nframe"] == cmd.motion.time_step_total
+gen = torch.Generator().manual_seed(5)
+u = torch.rand((n, 14 + model.nq - 7), generator=gen)
+mo["rnd"].copy_(u)
+# ---- the reference's own _resample_command, its random draws replaced by the SAME uniforms, in its call order:
+#   _adaptive_sampling: torch.multinomial(p, n) -> the bin (uniform bins while nothing has failed), sample_uniform(0, 1, (n,)) -> the phase in the bin
+#   _resample_command:  sample_uniform(pose ranges, (n, 6)), sample_uniform(velocity ranges, (n, 6)), sample_uniform(joint range, (n, nj))
+import mjlab.tasks.tracking.mdp.commands as C
+queue = [u[:, 1], u[:, 2:8], u[:, 8:14], u[:, 14:]]
+def fed(lower, upper, size, device=None):
+  x = queue.pop(0)
+  assert tuple(x.shape) == tuple(size if not isinstance(size, int) else (size,)), (x.shape, size)
+  return lower + (upper - lower) * x
+C.sample_uniform = fed
+real_multinomial = torch.multinomial
+torch.multinomial = lambda p, k, replacement=True: torch.clamp((u[:, 0] * cmd.bin_count).long(), max=cmd.bin_count - 1)
+try:
+  cmd._resample_command(torch.arange(n))
+finally:
+  torch.multinomial = real_multinomial
+assert not queue
+t_new = motion_reset_rows(mo, env.scene.env_origins)
+d = env.sim.data
+dq = (d.qpos - mo["reset_qpos"]).abs()
+dv = (d.qvel - mo["reset_qvel"]).abs()
+print("RESULT " + json.dumps({{"t_equal": bool(torch.equal(cmd.time_steps, t_new)), "qpos": float(dq.max()), "qvel": float(dv.max()),
+      "root_quat": float(dq[:, 3:7].max()), "clipped": int((mo["reset_qpos"][:, 7:] == mo["soft_lo"]).sum() + (mo["reset_qpos"][:, 7:] == mo["soft_hi"]).sum()),
+      "t_spread": int(t_new.max() - t_new.min())}}))
+"""
+
+
+def test_tracking_reset_rows_equal_the_reference_resample_command_on_the_same_uniforms(tmp_path):
+  """``mjlab_amd.rollout.motion_reset_rows`` -- the rows the control kernel's in-kernel tracking reset reproduces bit
+  for bit (tests/test_gpu_fullsize.py) -- against the reference's OWN ``MotionCommand._resample_command`` (tasks/tracking/mdp/
+  commands.py:255-363) with its random draws replaced by the same uniforms: sampled phases equal, every qpos / qvel entry to float
+  rounding.  Own process (the tracking task's configs; torch.multinomial is patched)."""
+  import json
+  import subprocess
+
+  code = _RESET_ROWS.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"), motion=str(tmp_path / "motion.npz"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  res = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  assert res["t_equal"] and res["t_spread"] > 100
+  assert res["qpos"] <= 2e-6 and res["qvel"] <= 2e-6, res  # float32 rounding of the same arithmetic in a different association
