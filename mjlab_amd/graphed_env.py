@@ -96,7 +96,7 @@ class GraphedRlEnv:
     self._prepare_events()
     self._upload_index_lists()
     self.graph: torch.cuda.CUDAGraph | None = None
-    self._keep: list = []
+    self._ep_len = env.episode_length_buf  # the tensor the captured kernels address (see step())
     env.sim.use_graph = False  # the launches are captured here, once, for the whole control step
     if capture:
       self.capture(warmup)
@@ -244,8 +244,27 @@ class GraphedRlEnv:
         out.append((t, t.clone()))
     return out
 
+  # ---- gym-style wrapper surface: ``RslRlVecEnvWrapper(GraphedRlEnv(env))`` (reference rl/vecenv_wrapper.py:11-113) steps through
+  # the graph; everything else (spaces, managers, reset(), close(), cfg ...) is the wrapped environment's
+  @property
+  def unwrapped(self) -> Any:
+    return self.env
+
+  def __getattr__(self, name: str) -> Any:
+    if name.startswith("__") or name == "env":
+      raise AttributeError(name)
+    return getattr(self.env, name)
+
+  def reset(self, **kw: Any):
+    return self.env.reset(**kw)  # the reference's own (eager) reset of all environments
+
   def step(self, action: torch.Tensor):
     env = self.env
+    if env.episode_length_buf is not self._ep_len:
+      # a caller REPLACED the buffer (rsl_rl's init_at_random_ep_len assigns a new tensor through the wrapper's setter,
+      # rl/vecenv_wrapper.py:63-65): the graph addresses the original one -- take the values over and bind it back
+      self._ep_len.copy_(env.episode_length_buf)
+      env.episode_length_buf = self._ep_len
     self._action_in.copy_(action)
     if self.graph is not None:
       self.graph.replay()

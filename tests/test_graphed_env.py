@@ -28,6 +28,25 @@ def test_mask_based_control_step_equals_the_reference_step():
   assert st["resets"] >= 32 and st["pushes"] >= 32 and st["resamples"] >= 1 and st["quiet_env_steps"] >= 500 and 0 < st["forward_steps"] < 70
 
 
+def test_wrapper_surface_and_replaced_episode_length_buffer():
+  """GraphedRlEnv stands where the reference's RslRlVecEnvWrapper expects an environment (``unwrapped``, attribute delegation), and
+  a caller that REPLACES ``episode_length_buf`` (the wrapper's setter, as rsl_rl's init_at_random_ep_len does) does not detach the
+  step from it."""
+  import torch
+  from _oracle_simulation import OracleSimulation
+
+  from mjlab_amd.graphed_env import GraphedRlEnv
+
+  env = reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=8, device="cpu", sim_cls=OracleSimulation, seed=3)
+  g = GraphedRlEnv(env, capture=False)
+  assert g.unwrapped is env and g.num_envs == 8 and g.max_episode_length == env.max_episode_length and g.action_manager is env.action_manager
+  g.reset()
+  buf = env.episode_length_buf
+  env.episode_length_buf = torch.full((8,), 7, dtype=buf.dtype)  # what `wrapper.episode_length_buf = ...` does
+  g.step(torch.zeros(8, 29))
+  assert env.episode_length_buf is buf and bool((buf == 8).all())
+
+
 def test_unsupported_terms_are_refused_loudly():
   """A term without a mask-based restatement must raise at construction, not be skipped."""
   from _oracle_simulation import OracleSimulation
