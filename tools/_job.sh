@@ -1,4 +1,3 @@
-T=gpurun_out/r04_v16; mkdir -p $T
+T=gpurun_out/r04_v17; mkdir -p $T
 timeout 90 python -c "import torch; x = torch.ones(1024, device='cuda'); print('gpu ok', float((x * 2).sum()))" || exit 9
-NOSMOKE=1 bash tools/ab_bench.sh --no-full-env --no-latency-bound --scene g1_tracking_flat 2>&1 | tee $T/ab_round3_vs_round4_tracking.txt
-NOSMOKE=1 bash tools/ab_bench.sh --no-full-env --no-latency-bound 2>&1 | tee $T/ab_round3_vs_round4_velocity.txt
+NOSMOKE=1 bash tools/ab_bench.sh --no-full-env --no-latency-bound --scene g1_tracking_flat 2>&1 | tee $T/ab_tracking_knobs.txt
