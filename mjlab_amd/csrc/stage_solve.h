@@ -507,6 +507,14 @@ __device__ __forceinline__ float grad_noise(float ulps, float scale, bool own, f
   return ulps * MJLAB_GNOISE * 5.9604645e-8f * scale * sqrtf(wave_sum(t * t));
 }
 
+// Experiment switch (round 4): a floor under the improvement test.  An fp32 engine that forms the improvement as the difference of
+// two cost totals (the reference's rule, taken literally) cannot see an improvement below a few ulps of the cost and ends the
+// iteration there by accident; since the grid search hands over the improvement as a sum of differences (below) this kernel sees
+// it exactly and keeps iterating down to `tolerance`.  MJLAB_INOISE > 0 stops at MJLAB_INOISE ulps of the cost instead.
+#ifndef MJLAB_INOISE
+#define MJLAB_INOISE 0.f
+#endif
+#define IMPROVEMENT_FLOOR fmaxf(tol, c.noise_ulps * (MJLAB_INOISE) * 5.9604645e-8f * scale * fabsf(cost))
 #ifndef MJLAB_NO_LSDIFF_COST
 #define IMPROVEMENT ((m.opt.flags & MJLAB_OPT_LS_PARALLEL) ? -scale * ls_diff : scale * (oldcost - cost))
 #else
@@ -839,7 +847,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = IMPROVEMENT;
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
-          finished = improvement < tol || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
+          finished = improvement < IMPROVEMENT_FLOOR || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
           if (!finished) {
             __syncthreads();
             hessian_store<NVP, BIG>(c, htile);
@@ -854,7 +862,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           rhs = own ? Ma - qs - fc : 0.f;
           const float improvement = IMPROVEMENT;
           const float gradient = scale * sqrtf(wave_sum(rhs * rhs));
-          finished = improvement < tol || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
+          finished = improvement < IMPROVEMENT_FLOOR || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
           need_factor = false;
         }
         PROF_MARK(7);
