@@ -566,6 +566,3 @@ class GraphedRlEnv:
       vel_w = torch.cat([vel_w[:, :3], rm.quat_apply_inverse(robot.data.root_link_quat_w, vel_w[:, 3:])], dim=-1)
       d.qvel[:, ix.free_joint_v_adr] = torch.where(trig[:, None], vel_w, d.qvel[:, ix.free_joint_v_adr])
 
-
-def max_episode_steps(env: Any) -> int:
-  return int(math.ceil(env.max_episode_length_s / env.step_dt))
