@@ -55,6 +55,16 @@ SUPPORTED_CURRICULA = ("commands_vel",)
 _AXES = ("x", "y", "z", "roll", "pitch", "yaw")
 
 
+def _as_slice(idx: Any) -> Any:
+  """An index tensor that is a contiguous ascending range -> the equivalent slice (a view: in-place updates need no gather / scatter
+  pair); anything else is returned as it is."""
+  if isinstance(idx, torch.Tensor) and idx.dim() == 1 and idx.numel() > 0:
+    v = idx.tolist()  # (construction time, outside any capture)
+    if v == list(range(v[0], v[0] + len(v))):
+      return slice(v[0], v[0] + len(v))
+  return idx
+
+
 def _range_tensors(rng: dict, device) -> tuple[torch.Tensor, torch.Tensor]:
   r = torch.tensor([rng.get(k, (0.0, 0.0)) for k in _AXES], dtype=torch.float32)
   return r[:, 0].to(device), r[:, 1].to(device)
@@ -83,14 +93,48 @@ def _state_tensors(obj: Any, n: int | None, seen: set, out: list, depth: int = 0
       _state_tensors(v, n, seen, out, depth + 1, f"{path}.{key}", dev_type)
 
 
+class _CachedEntityData:
+  """Stands where ``entity.data`` stood (reference entity/entity.py:184-186): every ``EntityData`` PROPERTY is computed once per phase
+  of the control step and handed out again until ``invalidate()`` -- the reference re-derives e.g. ``root_link_lin_vel_b`` from
+  ``xpos / subtree_com / cvel / xquat`` (6-8 small kernels) in every term that reads it: both observation groups, the rewards, the
+  command metrics.  The same tensors, fewer launches; the terms only read them (the managers clone what they keep).  Writers and
+  plain attributes go straight through."""
+
+  def __init__(self, inner: Any) -> None:
+    object.__setattr__(self, "_inner", inner)
+    object.__setattr__(self, "_cache", {})
+    object.__setattr__(self, "_props", {k for k in dir(type(inner)) if isinstance(getattr(type(inner), k, None), property)})
+
+  def __getattr__(self, name: str) -> Any:
+    inner = object.__getattribute__(self, "_inner")
+    if name in object.__getattribute__(self, "_props"):
+      cache = object.__getattribute__(self, "_cache")
+      if name not in cache:
+        cache[name] = getattr(inner, name)
+      return cache[name]
+    return getattr(inner, name)
+
+  def __setattr__(self, name: str, value: Any) -> None:
+    setattr(object.__getattribute__(self, "_inner"), name, value)
+
+  def invalidate(self) -> None:
+    object.__getattribute__(self, "_cache").clear()
+
+
 class GraphedRlEnv:
-  def __init__(self, env: Any, capture: bool = True, warmup: int = 2) -> None:
+  def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True) -> None:
     from mjlab.third_party.isaaclab.isaaclab.utils import math as rmath  # the reference's own helpers (pure torch)
 
     self.env, self._m = env, rmath
     self.n, self.device = env.num_envs, env.device
     self.dt = float(env.step_dt)
     self._robot = env.scene["robot"]
+    self._data_caches = []
+    if cache_entity_data:
+      for ent in env.scene.entities.values():
+        if not isinstance(ent._data, _CachedEntityData):
+          ent._data = _CachedEntityData(ent._data)
+        self._data_caches.append(ent._data)
     self._action_in = torch.zeros((self.n, sum(env.action_manager.action_term_dim)), device=self.device)
     self._check_supported()
     self._prepare_events()
@@ -139,7 +183,9 @@ class GraphedRlEnv:
       else:
         ids = p["asset_cfg"].joint_ids
         ids = slice(None) if isinstance(ids, slice) else torch.as_tensor(ids, device=dev, dtype=torch.long)
-        self._reset_terms.append((fn, {"position_range": p["position_range"], "velocity_range": p["velocity_range"], "joint_ids": ids}))
+        rix = self._robot.indexing
+        self._reset_terms.append((fn, {"position_range": p["position_range"], "velocity_range": p["velocity_range"], "joint_ids": ids,
+                                       "qa": rix.joint_q_adr[ids], "va": rix.joint_v_adr[ids]}))
     for index, cfg in enumerate(ev._mode_term_cfgs.get("interval", [])):
       self._interval_terms.append((index, cfg.interval_range_s, _range_tensors(cfg.params["velocity_range"], dev)))
     self._stage_ranges = {}
@@ -283,14 +329,20 @@ class GraphedRlEnv:
     return env.obs_buf, env.reward_buf, env.reset_terminated, env.reset_time_outs, env.extras
 
   # ------------------------------------------------------------------------------------------------------------------- body
+  def _invalidate(self) -> None:
+    for c in self._data_caches:
+      c.invalidate()
+
   def _body(self) -> None:
-    """reference envs/manager_based_rl_env.py:106-147, in its order."""
+    """reference envs/manager_based_rl_env.py:106-147, in its order.  The EntityData cache is dropped wherever mjData changes."""
     env = self.env
     before = self._snapshot_bindings()
+    self._invalidate()
     env.action_manager.process_action(self._action_in)
     env.action_manager.apply_action()  # the same ctrl before each of the substeps (:109-113)
     env.scene.write_data_to_sim()
     env.sim.step(env.cfg.decimation)
+    self._invalidate()
     env.scene.update(dt=env.physics_dt)
     env.episode_length_buf += 1
     self._step_counter += 1  # (:117 common_step_counter, for the curriculum terms)
@@ -300,10 +352,13 @@ class GraphedRlEnv:
     env.reward_buf = env.reward_manager.compute(dt=self.dt)
     mask = env.reset_buf
     self._masked_reset(mask)
+    self._invalidate()
     env.scene.write_data_to_sim()
     env.sim.forward(env_mask=mask.any().expand(self.n))  # all worlds iff some environment reset (:129-132)
+    self._invalidate()
     self._command_compute()
     self._interval_events()
+    self._invalidate()
     env.obs_buf = env.observation_manager.compute(update_history=True)
     self._restore_bindings(before)
 
@@ -349,22 +404,32 @@ class GraphedRlEnv:
       term._raw_actions.masked_fill_(m1, 0.0)
     # reward manager (managers/reward_manager.py:60-74)
     rm = env.reward_manager
-    for key, sums in rm._episode_sums.items():
-      log["Episode_Reward/" + key] = (sums * mask).sum() / cnt / env.max_episode_length_s
-      sums.masked_fill_(mask, 0.0)
+    keepf = (~mask).to(torch.float32)
+    keys, sums = list(rm._episode_sums), list(rm._episode_sums.values())
+    if sums:  # all terms in one stacked reduction and one multi-tensor update instead of five launches per term
+      vals = (torch.stack(sums, dim=1) * mask[:, None]).sum(dim=0) / cnt / env.max_episode_length_s
+      for k, key in enumerate(keys):
+        log["Episode_Reward/" + key] = vals[k]
+      torch._foreach_mul_(sums, [keepf] * len(sums))
     for cfg in rm._class_term_cfgs:
       self._masked_class_reset(cfg.func, mask)
     # command manager (managers/command_manager.py:44-53)
     for name in env.command_manager.active_terms:
       term = env.command_manager.get_term(name)
-      for metric, value in term.metrics.items():
-        log[f"Metrics/{name}/{metric}"] = (value * mask).sum() / cnt
-        value.masked_fill_(mask, 0.0)
+      mkeys, mvals = list(term.metrics), list(term.metrics.values())
+      if mvals:
+        vals = (torch.stack(mvals, dim=1) * mask[:, None]).sum(dim=0) / cnt
+        for k, metric in enumerate(mkeys):
+          log[f"Metrics/{name}/{metric}"] = vals[k]
+        torch._foreach_mul_(mvals, [keepf] * len(mvals))
       term.command_counter.masked_fill_(mask, 0)
       self._command_resample(term, mask)
     # termination manager (managers/termination_manager.py:73-85)
-    for key, dones in env.termination_manager._term_dones.items():
-      log["Episode_Termination/" + key] = (dones & mask).sum()
+    tkeys, tdones = list(env.termination_manager._term_dones), list(env.termination_manager._term_dones.values())
+    if tdones:
+      counts = (torch.stack(tdones, dim=1) & mask[:, None]).sum(dim=0)
+      for k, key in enumerate(tkeys):
+        log["Episode_Termination/" + key] = counts[k]
     env.extras["log"] = log
     env.episode_length_buf.masked_fill_(mask, 0)
 
@@ -381,14 +446,36 @@ class GraphedRlEnv:
         rg["ang_vel_z"].copy_(torch.where(on, new, rg["ang_vel_z"]))
       cm._curriculum_state[name] = rg["lin_vel_x"][1:2]
 
-  @staticmethod
-  def _clear_state(robot: Any, mask: torch.Tensor) -> None:
+  def _clear_state(self, robot: Any, mask: torch.Tensor) -> None:
     """EntityData.clear_state (entity/data.py:171-181) for the environments of `mask`."""
-    d, ix = robot.data.data, robot.indexing
+    d = robot.data.data
+    fv, bi, ci = self._index_slices(robot)
     keep = (~mask).to(torch.float32)
-    d.qfrc_applied[:, ix.free_joint_v_adr] = d.qfrc_applied[:, ix.free_joint_v_adr] * keep[:, None]
-    d.xfrc_applied[:, ix.body_ids] = d.xfrc_applied[:, ix.body_ids] * keep[:, None, None]
-    d.ctrl[:, ix.ctrl_ids] = d.ctrl[:, ix.ctrl_ids] * keep[:, None]
+    for arr, idx, k in ((d.qfrc_applied, fv, keep[:, None]), (d.xfrc_applied, bi, keep[:, None, None]), (d.ctrl, ci, keep[:, None])):
+      if isinstance(idx, slice):
+        arr[:, idx].mul_(k)  # a view: one kernel
+      else:
+        arr[:, idx] = arr[:, idx] * k
+
+  def _put(self, arr: torch.Tensor, idx: Any, m1: torch.Tensor, new: torch.Tensor) -> None:
+    """arr[:, idx] = where(m1, new, arr[:, idx]); contiguous index ranges are addressed as views (no gather / scatter)."""
+    key = id(idx)
+    cache = self.__dict__.setdefault("_slice_of", {})
+    if key not in cache:
+      cache[key] = (_as_slice(idx), idx)  # (the index object is kept alive with its slice)
+    sl = cache[key][0]
+    if isinstance(sl, slice):
+      view = arr[:, sl]
+      view.copy_(torch.where(m1, new, view))
+    else:
+      arr[:, idx] = torch.where(m1, new, arr[:, idx])
+
+  def _index_slices(self, robot: Any) -> tuple:
+    cache = self.__dict__.setdefault("_slices", {})
+    if id(robot) not in cache:
+      ix = robot.indexing
+      cache[id(robot)] = (_as_slice(ix.free_joint_v_adr), _as_slice(ix.body_ids), _as_slice(ix.ctrl_ids))
+    return cache[id(robot)]
 
   def _masked_class_reset(self, func: Any, mask: torch.Tensor) -> None:
     """A class-based term's own ``reset()`` run on ALL environments, kept only where `mask` is set."""
@@ -417,10 +504,10 @@ class GraphedRlEnv:
     velocities = root[:, 7:13] + rm.sample_uniform(vel[0], vel[1], (self.n, 6), device=self.device)
     velocities = torch.cat([velocities[:, :3], rm.quat_apply_inverse(orientations, velocities[:, 3:])], dim=-1)
     m1 = mask[:, None]
-    d.qpos[:, ix.free_joint_q_adr] = torch.where(m1, torch.cat([positions, orientations], dim=-1), d.qpos[:, ix.free_joint_q_adr])
-    d.qvel[:, ix.free_joint_v_adr] = torch.where(m1, velocities, d.qvel[:, ix.free_joint_v_adr])
+    self._put(d.qpos, ix.free_joint_q_adr, m1, torch.cat([positions, orientations], dim=-1))
+    self._put(d.qvel, ix.free_joint_v_adr, m1, velocities)
 
-  def _reset_joints_by_scale(self, mask: torch.Tensor, position_range, velocity_range, joint_ids) -> None:
+  def _reset_joints_by_scale(self, mask: torch.Tensor, position_range, velocity_range, joint_ids, qa, va) -> None:
     """envs/mdp/events.py:94-124."""
     rm, robot = self._m, self._robot
     d, ix = robot.data.data, robot.indexing
@@ -430,9 +517,9 @@ class GraphedRlEnv:
     jv *= rm.sample_uniform(*velocity_range, jv.shape, self.device)
     lim = robot.data.soft_joint_pos_limits[:, joint_ids]
     jp = jp.clamp_(lim[..., 0], lim[..., 1])
-    qa, va, m1 = ix.joint_q_adr[joint_ids], ix.joint_v_adr[joint_ids], mask[:, None]
-    d.qpos[:, qa] = torch.where(m1, jp, d.qpos[:, qa])
-    d.qvel[:, va] = torch.where(m1, jv, d.qvel[:, va])
+    m1 = mask[:, None]
+    self._put(d.qpos, qa, m1, jp)
+    self._put(d.qvel, va, m1, jv)
 
   # --------------------------------------------------------------------------------------------------------------- commands
   def _command_resample(self, term: Any, mask: torch.Tensor) -> None:
@@ -475,8 +562,8 @@ class GraphedRlEnv:
       ang_b[:, 2] = v[:, 2]
       state = torch.cat([rd.root_link_pos_w, rd.root_link_quat_w], dim=-1)
       vel = torch.cat([rm.quat_apply(rd.root_link_quat_w, lin_b), ang_b], dim=-1)
-      d.qpos[:, ix.free_joint_q_adr] = torch.where(im[:, None], state, d.qpos[:, ix.free_joint_q_adr])
-      d.qvel[:, ix.free_joint_v_adr] = torch.where(im[:, None], vel, d.qvel[:, ix.free_joint_v_adr])
+      self._put(d.qpos, ix.free_joint_q_adr, im[:, None], state)
+      self._put(d.qvel, ix.free_joint_v_adr, im[:, None], vel)
 
   def _update_UniformVelocityCommand(self, term: Any) -> None:
     rm, cfg, v = self._m, term.cfg, term.vel_command_b
@@ -528,10 +615,10 @@ class GraphedRlEnv:
     lim = term.robot.data.soft_joint_pos_limits
     joint_pos = torch.clip(joint_pos, lim[:, :, 0], lim[:, :, 1])
     d, ix = term.robot.data.data, term.robot.indexing
-    d.qpos[:, ix.joint_q_adr] = torch.where(m1, joint_pos, d.qpos[:, ix.joint_q_adr])
-    d.qvel[:, ix.joint_v_adr] = torch.where(m1, joint_vel, d.qvel[:, ix.joint_v_adr])
-    d.qpos[:, ix.free_joint_q_adr] = torch.where(m1, torch.cat([root_pos, root_ori], dim=-1), d.qpos[:, ix.free_joint_q_adr])
-    d.qvel[:, ix.free_joint_v_adr] = torch.where(m1, torch.cat([root_lin_vel, rm.quat_apply_inverse(root_ori, root_ang_vel)], dim=-1), d.qvel[:, ix.free_joint_v_adr])
+    self._put(d.qpos, ix.joint_q_adr, m1, joint_pos)
+    self._put(d.qvel, ix.joint_v_adr, m1, joint_vel)
+    self._put(d.qpos, ix.free_joint_q_adr, m1, torch.cat([root_pos, root_ori], dim=-1))
+    self._put(d.qvel, ix.free_joint_v_adr, m1, torch.cat([root_lin_vel, rm.quat_apply_inverse(root_ori, root_ang_vel)], dim=-1))
     self._clear_state(term.robot, mask)
 
   def _update_MotionCommand(self, term: Any) -> None:
@@ -564,5 +651,5 @@ class GraphedRlEnv:
       time_left.copy_(torch.where(trig, torch.rand(self.n, device=self.device) * (hi - lo) + lo, time_left))
       vel_w = robot.data.root_link_vel_w + rm.sample_uniform(vlo, vhi, (self.n, 6), device=self.device)
       vel_w = torch.cat([vel_w[:, :3], rm.quat_apply_inverse(robot.data.root_link_quat_w, vel_w[:, 3:])], dim=-1)
-      d.qvel[:, ix.free_joint_v_adr] = torch.where(trig[:, None], vel_w, d.qvel[:, ix.free_joint_v_adr])
+      self._put(d.qvel, ix.free_joint_v_adr, trig[:, None], vel_w)
 
