@@ -542,16 +542,18 @@ class GraphedRlEnv:
   # -- UniformVelocityCommand (tasks/velocity/mdp/velocity_command.py:64-102)
   def _resample_UniformVelocityCommand(self, term: Any, mask: torch.Tensor) -> None:
     cfg, n, dev, rg = term.cfg, self.n, self.device, self._command_ranges[id(term)]
-    u = lambda lo, hi: torch.rand(n, device=dev) * (hi - lo) + lo  # noqa: E731
-    ur = lambda r: torch.rand(n, device=dev) * (r[1] - r[0]) + r[0]  # noqa: E731  (range on the device: a curriculum may move it)
+    # all of the term's draws of this call as ONE (7, n) block of uniforms, scaled by the stacked ranges in two launches
+    lo = torch.stack([rg["lin_vel_x"][0], rg["lin_vel_y"][0], rg["ang_vel_z"][0], rg.get("heading", rg["ang_vel_z"])[0]])
+    hi = torch.stack([rg["lin_vel_x"][1], rg["lin_vel_y"][1], rg["ang_vel_z"][1], rg.get("heading", rg["ang_vel_z"])[1]])
+    U = torch.rand((7, n), device=dev)
+    R = U[:4] * (hi - lo)[:, None] + lo[:, None]
+    u = lambda lo_, hi_: U[6] * (hi_ - lo_) + lo_  # noqa: E731  (only the rarely enabled init-velocity branch)
     v = term.vel_command_b
-    v[:, 0] = torch.where(mask, ur(rg["lin_vel_x"]), v[:, 0])
-    v[:, 1] = torch.where(mask, ur(rg["lin_vel_y"]), v[:, 1])
-    v[:, 2] = torch.where(mask, ur(rg["ang_vel_z"]), v[:, 2])
+    v.copy_(torch.where(mask[:, None], R[:3].T, v))
     if cfg.heading_command:
-      term.heading_target.copy_(torch.where(mask, ur(rg["heading"]), term.heading_target))
-      term.is_heading_env.copy_(torch.where(mask, u(0.0, 1.0) <= cfg.rel_heading_envs, term.is_heading_env))
-    term.is_standing_env.copy_(torch.where(mask, u(0.0, 1.0) <= cfg.rel_standing_envs, term.is_standing_env))
+      term.heading_target.copy_(torch.where(mask, R[3], term.heading_target))
+      term.is_heading_env.copy_(torch.where(mask, U[4] <= cfg.rel_heading_envs, term.is_heading_env))
+    term.is_standing_env.copy_(torch.where(mask, U[5] <= cfg.rel_standing_envs, term.is_standing_env))
     if cfg.init_velocity_prob > 0.0:
       rm, rd = self._m, term.robot.data
       d, ix = rd.data, term.robot.indexing
