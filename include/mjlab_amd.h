@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MJLAB_ABI_VERSION 2 /* 2: the round-3 struct layouts (option: ls_parallel_min_step; sizes: nstaticsite; control: motion, read-back) */
+#define MJLAB_ABI_VERSION 3 /* 2: the round-3 struct layouts (option: ls_parallel_min_step; sizes: nstaticsite; control: motion, read-back); 3: + the environment terms */
 
 /* stage bits for mjlab_forward_stages (testing / profiling of single stages) */
 enum {
@@ -227,6 +227,64 @@ typedef struct mjlab_control {
 int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, void* stream);
 int mjlab_sizeof_control(void); /* sizeof(mjlab_control_t), for bindings that mirror the struct */
 int mjlab_sizeof_motion_reset(void); /* sizeof(mjlab_motion_reset_t) */
+
+/* Extension: ENVIRONMENT TERMS -- the reference's event and command terms that write mjData, in
+ * mask-based form, one launch per term.  The reference runs each on a variable-length id list (`reset_buf.nonzero()`,
+ * `(time_left <= 0).nonzero()`: a host round trip, which a hipGraph cannot hold) as 20-90 small torch kernels; here every world
+ * is evaluated by one thread and `mask` (nworld bytes, torch.bool) decides which rows are written, with the reference's
+ * arithmetic operation by operation (its helpers third_party/isaaclab/isaaclab/utils/math.py: sample_uniform :1354,
+ * quat_from_euler_xyz :269, quat_mul :521, quat_apply_inverse :645, wrap_to_pi :96; no fma contraction).  Uniforms in [0, 1)
+ * come in from the caller: row w of U (leading dimension ldu floats) holds world w's draws, so a world's result depends on its
+ * own row only.  All pointers are device pointers; ranges are device arrays so that a curriculum may change them between
+ * replays of a captured graph.  Used by mjlab_amd/graphed_env.py; the torch restatements there compute the same from the same U.
+ *
+ * reset_root_state_uniform (envs/mdp/events.py:42-91): U row = 6 pose draws, 6 velocity draws; pose_range / velocity_range =
+ * (2, 6) [lo row, hi row] over x y z roll pitch yaw; default_root_state rows of 13 with leading dimension ld_root (0 = one
+ * shared row); writes qpos[w][q_adr .. +7) and qvel[w][v_adr .. +6) (angular part rotated into the body frame). */
+int mjlab_event_reset_root_state_uniform(float* qpos, int nq, int q_adr, float* qvel, int nv, int v_adr, int nworld,
+                                         const unsigned char* mask, const float* default_root_state, int ld_root,
+                                         const float* env_origins, const float* U, int ldu, const float* pose_range,
+                                         const float* velocity_range, void* stream);
+/* reset_joints_by_scale (envs/mdp/events.py:94-124) for nj selected joints: joint_ids[j] (NULL = j) indexes the entity-local
+ * default_joint_pos / default_joint_vel (leading dimensions ld_*; 0 = shared row) and soft_joint_pos_limits (rows of 2 per
+ * joint, leading dimension ld_lim); q_adr[j] / v_adr[j] are the qpos / qvel addresses of the selected joints; U row = nj
+ * position draws then nj velocity draws; ranges = device [pos_lo, pos_hi, vel_lo, vel_hi]. */
+int mjlab_event_reset_joints_by_scale(float* qpos, int nq, float* qvel, int nv, int nworld, const unsigned char* mask, int nj,
+                                      const int* joint_ids, const int* q_adr, const int* v_adr, const float* default_joint_pos,
+                                      int ld_jpos, const float* default_joint_vel, int ld_jvel, const float* soft_joint_pos_limits,
+                                      int ld_lim, const float* U, int ldu, const float* ranges, void* stream);
+/* The interval event push_by_setting_velocity (envs/mdp/events.py:127-143) under the event manager's per-env timer
+ * (managers/event_manager.py:116-138): time_left[w] -= dt; where it drops below 1e-6 a new interval is drawn from
+ * interval_range (device [lo, hi]) and qvel[w][v_adr .. +6) = root_link_vel_w[w] + U(velocity_range), the angular part rotated
+ * by the inverse of root_link_quat_w[w].  root_link_vel_w / root_link_quat_w are the tensors the reference's EntityData
+ * properties return (entity/data.py:213-236; leading dimensions ld_vel, ld_quat) -- unlike mjlab_interval_push, which reads
+ * qvel and qpos.  U row = 6 velocity draws, 1 interval draw. */
+int mjlab_event_push_by_setting_velocity(float* qvel, int nv, int v_adr, int nworld, float* time_left, float dt,
+                                         const float* interval_range, const float* root_link_vel_w, int ld_vel,
+                                         const float* root_link_quat_w, int ld_quat, const float* U, int ldu,
+                                         const float* velocity_range, void* stream);
+/* UniformVelocityCommand (tasks/velocity/mdp/velocity_command.py:64-102) inside CommandTerm.reset / compute
+ * (managers/command_manager.py:44-66).  mask != NULL -- reset(): the worlds of the mask draw a new command
+ * (time_left, vel_command_b, heading_target, is_heading_env, is_standing_env; command_counter += 1).  mask == NULL --
+ * compute(dt): time_left -= dt, the worlds with time_left <= 0 draw a new command, then _update_command on every world
+ * (heading control from heading_w, zero command for standing envs).  U row = [time_left, lin_vel_x, lin_vel_y, ang_vel_z,
+ * heading, is_heading, is_standing, (unused)].  The init-velocity branch (init_velocity_prob > 0) is not covered. */
+typedef struct mjlab_velocity_command {
+  int nworld, ldu, ld_heading, heading_command;
+  const unsigned char* mask;      /* NULL = compute() */
+  const float* U;
+  const float* ranges;            /* device (4, 2): lin_vel_x, lin_vel_y, ang_vel_z, heading rows of [lo, hi] */
+  const float* heading_w;         /* EntityData.heading_w (compute() with heading_command only) */
+  float* time_left;               /* (nworld) */
+  float* vel_command_b;           /* (nworld, 3) */
+  float* heading_target;          /* (nworld) */
+  unsigned char* is_heading_env;  /* (nworld) torch.bool */
+  unsigned char* is_standing_env; /* (nworld) torch.bool */
+  long long* command_counter;     /* (nworld) torch.long */
+  float dt, resampling_lo, resampling_hi, rel_heading_envs, rel_standing_envs, heading_control_stiffness;
+} mjlab_velocity_command_t;
+int mjlab_command_uniform_velocity(const mjlab_velocity_command_t* c, void* stream);
+int mjlab_sizeof_velocity_command(void);
 
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);

@@ -1,0 +1,189 @@
+// env_terms.h -- MASK-BASED forms of the reference's event and command terms that touch mjData (include/mjlab_amd.h,
+// "environment terms").  The reference runs each of them on a variable-length id list (`reset_buf.nonzero()`,
+// `(time_left <= 0).nonzero()`), 20-90 small torch kernels per term and call; here one launch per term, one thread per
+// world (per world and joint for the joint reset), every world evaluated and the mask deciding which rows are written:
+// no host round trip, so the launches sit inside the hipGraph of the whole control step (mjlab_amd/graphed_env.py).
+// The arithmetic follows the reference's helper functions operation by operation (no contraction into fma), so that a
+// world gets the values the reference's chain of torch kernels would give it for the same uniforms.
+#pragma once
+#ifdef MJLAB_MAIN_TU
+
+namespace env_terms {
+
+struct Quat { float w, x, y, z; };
+
+// third_party/isaaclab/isaaclab/utils/math.py:269-295
+__device__ __forceinline__ Quat quat_from_euler_xyz(const float roll, const float pitch, const float yaw) {
+#pragma clang fp contract(off)
+  const float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f);
+  const float cr = cosf(roll * 0.5f), sr = sinf(roll * 0.5f);
+  const float cp = cosf(pitch * 0.5f), sp = sinf(pitch * 0.5f);
+  Quat q;
+  q.w = cy * cr * cp + sy * sr * sp;
+  q.x = cy * sr * cp - sy * cr * sp;
+  q.y = cy * cr * sp + sy * sr * cp;
+  q.z = sy * cr * cp - cy * sr * sp;
+  return q;
+}
+
+// math.py:521-555 (the 8-multiplication form, in its order)
+__device__ __forceinline__ Quat quat_mul(const Quat a, const Quat b) {
+#pragma clang fp contract(off)
+  const float ww = (a.z + a.x) * (b.x + b.y);
+  const float yy = (a.w - a.y) * (b.w + b.z);
+  const float zz = (a.w + a.y) * (b.w - b.z);
+  const float xx = ww + yy + zz;
+  const float qq = 0.5f * (xx + (a.z - a.x) * (b.x - b.y));
+  Quat q;
+  q.w = qq - ww + (a.z - a.y) * (b.y - b.z);
+  q.x = qq - xx + (a.x + a.w) * (b.x + b.w);
+  q.y = qq - yy + (a.w - a.x) * (b.y + b.z);
+  q.z = qq - zz + (a.z + a.y) * (b.w - b.x);
+  return q;
+}
+
+__device__ __forceinline__ void cross3(float* o, const float* a, const float* b) {
+#pragma clang fp contract(off)
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// math.py:645-664: vec - w * t + xyz x t, t = 2 (xyz x vec)
+__device__ __forceinline__ void quat_apply_inverse(float* o, const Quat q, const float* v) {
+#pragma clang fp contract(off)
+  const float xyz[3] = {q.x, q.y, q.z};
+  float t[3], c[3];
+  cross3(t, xyz, v);
+  for (int k = 0; k < 3; ++k) t[k] = t[k] * 2.f;
+  cross3(c, xyz, t);
+  for (int k = 0; k < 3; ++k) o[k] = (v[k] - q.w * t[k]) + c[k];
+}
+
+// math.py:96-117 (torch.remainder: the result takes the sign of the divisor)
+__device__ __forceinline__ float wrap_to_pi(const float a) {
+#pragma clang fp contract(off)
+  const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
+  float m = fmodf(a + pi, two_pi);
+  if (m != 0.f && m < 0.f) m = m + two_pi;
+  return (m == 0.f && a > 0.f) ? pi : m - pi;
+}
+
+__device__ __forceinline__ float uniform(const float u, const float lo, const float hi) {  // math.py:1354-1373
+#pragma clang fp contract(off)
+  return u * (hi - lo) + lo;
+}
+
+}  // namespace env_terms
+
+// envs/mdp/events.py:42-91 reset_root_state_uniform
+__global__ __launch_bounds__(256) void k_event_reset_root_state_uniform(float* qpos, const int nq, const int q_adr, float* qvel, const int nv,
+                                                                        const int v_adr, const int nworld, const unsigned char* mask,
+                                                                        const float* root, const int ld_root, const float* org, const float* U,
+                                                                        const int ldu, const float* pose, const float* vel) {
+#pragma clang fp contract(off)
+  using namespace env_terms;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= nworld || !mask[w]) return;
+  const float* u = U + (size_t)w * ldu;
+  const float* r = root + (size_t)w * ld_root;
+  float rs[6], vs[6];
+  for (int k = 0; k < 6; ++k) {
+    rs[k] = uniform(u[k], pose[k], pose[6 + k]);
+    vs[k] = r[7 + k] + uniform(u[6 + k], vel[k], vel[6 + k]);
+  }
+  float* qp = qpos + (size_t)w * nq + q_adr;
+  float* qv = qvel + (size_t)w * nv + v_adr;
+  for (int k = 0; k < 3; ++k) qp[k] = (r[k] + rs[k]) + org[3 * w + k];
+  const Quat q = quat_mul(Quat{r[3], r[4], r[5], r[6]}, quat_from_euler_xyz(rs[3], rs[4], rs[5]));
+  qp[3] = q.w, qp[4] = q.x, qp[5] = q.y, qp[6] = q.z;
+  float ang[3];
+  quat_apply_inverse(ang, q, vs + 3);  // (entity.write_root_link_velocity_to_sim stores the body-frame angular velocity)
+  for (int k = 0; k < 3; ++k) qv[k] = vs[k], qv[3 + k] = ang[k];
+}
+
+// envs/mdp/events.py:94-124 reset_joints_by_scale; one thread per (world, selected joint)
+__global__ __launch_bounds__(256) void k_event_reset_joints_by_scale(float* qpos, const int nq, float* qvel, const int nv, const int nworld,
+                                                                     const unsigned char* mask, const int nj, const int* joint_ids,
+                                                                     const int* q_adr, const int* v_adr, const float* jpos, const int ld_jpos,
+                                                                     const float* jvel, const int ld_jvel, const float* lim, const int ld_lim,
+                                                                     const float* U, const int ldu, const float* ranges) {
+#pragma clang fp contract(off)
+  using namespace env_terms;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int w = i / nj, j = i - w * nj;
+  if (w >= nworld || !mask[w]) return;
+  const int id = joint_ids ? joint_ids[j] : j;
+  const float* u = U + (size_t)w * ldu;
+  float p = jpos[(size_t)w * ld_jpos + id] * uniform(u[j], ranges[0], ranges[1]);
+  const float v = jvel[(size_t)w * ld_jvel + id] * uniform(u[nj + j], ranges[2], ranges[3]);
+  const float* l = lim + (size_t)w * ld_lim + 2 * id;
+  p = fminf(fmaxf(p, l[0]), l[1]);
+  qpos[(size_t)w * nq + q_adr[j]] = p;
+  qvel[(size_t)w * nv + v_adr[j]] = v;
+}
+
+// EventManager.apply(mode="interval") (managers/event_manager.py:116-138) + envs/mdp/events.py:127-143 push_by_setting_velocity
+__global__ __launch_bounds__(256) void k_event_push_by_setting_velocity(float* qvel, const int nv, const int v_adr, const int nworld, float* time_left,
+                                                                        const float dt, const float* interval, const float* vel_w, const int ld_vel,
+                                                                        const float* quat_w, const int ld_quat, const float* U, const int ldu,
+                                                                        const float* range) {
+#pragma clang fp contract(off)
+  using namespace env_terms;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= nworld) return;
+  const float* u = U + (size_t)w * ldu;
+  float t = time_left[w] - dt;
+  if (t < 1e-6f) {
+    t = uniform(u[6], interval[0], interval[1]);
+    const float* vw = vel_w + (size_t)w * ld_vel;
+    const float* qw = quat_w + (size_t)w * ld_quat;
+    float v[6], ang[3];
+    for (int k = 0; k < 6; ++k) v[k] = vw[k] + uniform(u[k], range[k], range[6 + k]);
+    quat_apply_inverse(ang, Quat{qw[0], qw[1], qw[2], qw[3]}, v + 3);
+    float* qv = qvel + (size_t)w * nv + v_adr;
+    for (int k = 0; k < 3; ++k) qv[k] = v[k], qv[3 + k] = ang[k];
+  }
+  time_left[w] = t;
+}
+
+// CommandTerm.reset / compute / _resample (managers/command_manager.py:44-66) around UniformVelocityCommand's _resample_command and
+// _update_command (tasks/velocity/mdp/velocity_command.py:64-102, without the init-velocity branch)
+__global__ __launch_bounds__(256) void k_command_uniform_velocity(const mjlab_velocity_command_t c) {
+#pragma clang fp contract(off)
+  using namespace env_terms;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= c.nworld) return;
+  float t = c.time_left[w];
+  bool m;
+  if (c.mask) m = c.mask[w] != 0;
+  else {
+    t = t - c.dt;
+    m = t <= 0.f;
+  }
+  float* v = c.vel_command_b + 3 * (size_t)w;
+  if (m) {
+    const float* u = c.U + (size_t)w * c.ldu;
+    const float* rg = c.ranges;  // rows lin_vel_x, lin_vel_y, ang_vel_z, heading: [lo, hi]
+    t = uniform(u[0], c.resampling_lo, c.resampling_hi);
+    v[0] = uniform(u[1], rg[0], rg[1]);
+    v[1] = uniform(u[2], rg[2], rg[3]);
+    v[2] = uniform(u[3], rg[4], rg[5]);
+    if (c.heading_command) {
+      c.heading_target[w] = uniform(u[4], rg[6], rg[7]);
+      c.is_heading_env[w] = u[5] <= c.rel_heading_envs;
+    }
+    c.is_standing_env[w] = u[6] <= c.rel_standing_envs;
+    c.command_counter[w] += 1;
+  }
+  c.time_left[w] = t;
+  if (!c.mask) {  // compute(): _update_command on every world
+    if (c.heading_command && c.is_heading_env[w]) {
+      const float err = wrap_to_pi(c.heading_target[w] - c.heading_w[(size_t)w * c.ld_heading]);
+      v[2] = fminf(fmaxf(c.heading_control_stiffness * err, c.ranges[4]), c.ranges[5]);
+    }
+    if (c.is_standing_env[w]) v[0] = v[1] = v[2] = 0.f;
+  }
+}
+
+#endif  // MJLAB_MAIN_TU

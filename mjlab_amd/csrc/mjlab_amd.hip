@@ -5,6 +5,7 @@
 #define MJLAB_MAIN_TU
 #include "kernels.h"
 #include "nvp_launch.h"
+#include "env_terms.h"
 
 // ====================================================================================
 // C ABI
@@ -27,6 +28,7 @@ int mjlab_sizeof_option(void) { return (int)sizeof(mjlab_option_t); }
 int mjlab_sizeof_sizes(void) { return (int)sizeof(mjlab_sizes_t); }
 int mjlab_sizeof_control(void) { return (int)sizeof(mjlab_control_t); }
 int mjlab_sizeof_motion_reset(void) { return (int)sizeof(mjlab_motion_reset_t); }
+int mjlab_sizeof_velocity_command(void) { return (int)sizeof(mjlab_velocity_command_t); }
 
 // the solve kernel's LDS block: the primal solvers' layout, or the dual solver's where that one is configured
 static int solve_stage_lds_floats(const mjlab_model_t* m) {
@@ -185,6 +187,49 @@ int mjlab_interval_push(const mjlab_model_t* m, const mjlab_data_t* d, float* ti
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, "k_interval_push launch failed");
   return 0;
+}
+
+// ---- environment terms (env_terms.h)
+static int launched(const char* what) {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail((int)e, what);
+}
+int mjlab_event_reset_root_state_uniform(float* qpos, int nq, int q_adr, float* qvel, int nv, int v_adr, int nworld, const unsigned char* mask,
+                                         const float* default_root_state, int ld_root, const float* env_origins, const float* U, int ldu,
+                                         const float* pose_range, const float* velocity_range, void* stream) {
+  if (!qpos || !qvel || !mask || !default_root_state || !env_origins || !U || !pose_range || !velocity_range) return fail(-22, "reset_root_state_uniform: null argument");
+  if (nworld < 1 || q_adr < 0 || q_adr + 7 > nq || v_adr < 0 || v_adr + 6 > nv || ldu < 12) return fail(-22, "reset_root_state_uniform: bad sizes");
+  hipLaunchKernelGGL(k_event_reset_root_state_uniform, dim3((nworld + 255) / 256), dim3(256), 0, (hipStream_t)stream, qpos, nq, q_adr, qvel, nv, v_adr,
+                     nworld, mask, default_root_state, ld_root, env_origins, U, ldu, pose_range, velocity_range);
+  return launched("k_event_reset_root_state_uniform launch failed");
+}
+int mjlab_event_reset_joints_by_scale(float* qpos, int nq, float* qvel, int nv, int nworld, const unsigned char* mask, int nj, const int* joint_ids,
+                                      const int* q_adr, const int* v_adr, const float* default_joint_pos, int ld_jpos, const float* default_joint_vel,
+                                      int ld_jvel, const float* soft_joint_pos_limits, int ld_lim, const float* U, int ldu, const float* ranges,
+                                      void* stream) {
+  if (!qpos || !qvel || !mask || !q_adr || !v_adr || !default_joint_pos || !default_joint_vel || !soft_joint_pos_limits || !U || !ranges)
+    return fail(-22, "reset_joints_by_scale: null argument");
+  if (nworld < 1 || nj < 1 || ldu < 2 * nj) return fail(-22, "reset_joints_by_scale: bad sizes");
+  const long long total = (long long)nworld * nj;
+  hipLaunchKernelGGL(k_event_reset_joints_by_scale, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qpos, nq, qvel, nv, nworld, mask,
+                     nj, joint_ids, q_adr, v_adr, default_joint_pos, ld_jpos, default_joint_vel, ld_jvel, soft_joint_pos_limits, ld_lim, U, ldu, ranges);
+  return launched("k_event_reset_joints_by_scale launch failed");
+}
+int mjlab_event_push_by_setting_velocity(float* qvel, int nv, int v_adr, int nworld, float* time_left, float dt, const float* interval_range,
+                                         const float* root_link_vel_w, int ld_vel, const float* root_link_quat_w, int ld_quat, const float* U, int ldu,
+                                         const float* velocity_range, void* stream) {
+  if (!qvel || !time_left || !interval_range || !root_link_vel_w || !root_link_quat_w || !U || !velocity_range) return fail(-22, "push_by_setting_velocity: null argument");
+  if (nworld < 1 || v_adr < 0 || v_adr + 6 > nv || ldu < 7) return fail(-22, "push_by_setting_velocity: bad sizes");
+  hipLaunchKernelGGL(k_event_push_by_setting_velocity, dim3((nworld + 255) / 256), dim3(256), 0, (hipStream_t)stream, qvel, nv, v_adr, nworld, time_left, dt,
+                     interval_range, root_link_vel_w, ld_vel, root_link_quat_w, ld_quat, U, ldu, velocity_range);
+  return launched("k_event_push_by_setting_velocity launch failed");
+}
+int mjlab_command_uniform_velocity(const mjlab_velocity_command_t* c, void* stream) {
+  if (!c || !c->U || !c->ranges || !c->time_left || !c->vel_command_b || !c->is_standing_env || !c->command_counter) return fail(-22, "command_uniform_velocity: null argument");
+  if (c->heading_command && (!c->heading_target || !c->is_heading_env || (!c->mask && !c->heading_w))) return fail(-22, "command_uniform_velocity: heading arguments missing");
+  if (c->nworld < 1 || c->ldu < 7) return fail(-22, "command_uniform_velocity: bad sizes");
+  hipLaunchKernelGGL(k_command_uniform_velocity, dim3((c->nworld + 255) / 256), dim3(256), 0, (hipStream_t)stream, *c);
+  return launched("k_command_uniform_velocity launch failed");
 }
 
 int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, void* stream) {

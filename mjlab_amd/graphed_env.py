@@ -42,6 +42,8 @@ from typing import Any
 
 import torch
 
+from . import env_terms
+
 SUPPORTED_RESET_EVENTS = ("reset_root_state_uniform", "reset_joints_by_scale")
 SUPPORTED_INTERVAL_EVENTS = ("push_by_setting_velocity",)
 SUPPORTED_COMMANDS = ("UniformVelocityCommand", "MotionCommand")
@@ -53,6 +55,9 @@ SUPPORTED_COMMANDS = ("UniformVelocityCommand", "MotionCommand")
 # refreshed for readers of ``cfg.ranges`` by the same rule evaluated on the host counter (without the reset condition).
 SUPPORTED_CURRICULA = ("commands_vel",)
 _AXES = ("x", "y", "z", "roll", "pitch", "yaw")
+# the mjData arrays the command update and the interval events may write (command terms: write_root_state / write_joint_state /
+# clear_state of the tracking task's resample; push_by_setting_velocity: qvel)
+_LATE_WRITES = frozenset(("qpos", "qvel", "qfrc_applied", "xfrc_applied", "ctrl"))
 
 
 def _as_slice(idx: Any) -> Any:
@@ -93,40 +98,70 @@ def _state_tensors(obj: Any, n: int | None, seen: set, out: list, depth: int = 0
       _state_tensors(v, n, seen, out, depth + 1, f"{path}.{key}", dev_type)
 
 
+class _ReadRecorder:
+  """Stands where ``EntityData.data`` stood: hands every field of the simulation's data bridge through and notes its name."""
+
+  def __init__(self, inner: Any) -> None:
+    object.__setattr__(self, "_inner", inner)
+    object.__setattr__(self, "reads", set())
+
+  def __getattr__(self, name: str) -> Any:
+    object.__getattribute__(self, "reads").add(name)
+    return getattr(object.__getattribute__(self, "_inner"), name)
+
+  def __setattr__(self, name: str, value: Any) -> None:
+    setattr(object.__getattribute__(self, "_inner"), name, value)
+
+
 class _CachedEntityData:
   """Stands where ``entity.data`` stood (reference entity/entity.py:184-186): every ``EntityData`` PROPERTY is computed once per phase
   of the control step and handed out again until ``invalidate()`` -- the reference re-derives e.g. ``root_link_lin_vel_b`` from
   ``xpos / subtree_com / cvel / xquat`` (6-8 small kernels) in every term that reads it: both observation groups, the rewards, the
   command metrics.  The same tensors, fewer launches; the terms only read them (the managers clone what they keep).  Writers and
-  plain attributes go straight through."""
+  plain attributes go straight through.  Each entry remembers which mjData arrays its evaluation read, so that a phase that wrote
+  only some arrays (the push: ``qvel``) drops only the entries that depend on them."""
 
   def __init__(self, inner: Any) -> None:
     object.__setattr__(self, "_inner", inner)
     object.__setattr__(self, "_cache", {})
     object.__setattr__(self, "_props", {k for k in dir(type(inner)) if isinstance(getattr(type(inner), k, None), property)})
+    if not isinstance(inner.data, _ReadRecorder):
+      inner.data = _ReadRecorder(inner.data)
 
   def __getattr__(self, name: str) -> Any:
     inner = object.__getattribute__(self, "_inner")
     if name in object.__getattribute__(self, "_props"):
       cache = object.__getattribute__(self, "_cache")
       if name not in cache:
-        cache[name] = getattr(inner, name)
-      return cache[name]
+        reads = inner.data.reads
+        reads.clear()
+        value = getattr(inner, name)
+        cache[name] = (value, frozenset(reads))
+      return cache[name][0]
     return getattr(inner, name)
 
   def __setattr__(self, name: str, value: Any) -> None:
     setattr(object.__getattribute__(self, "_inner"), name, value)
 
-  def invalidate(self) -> None:
-    object.__getattribute__(self, "_cache").clear()
+  def invalidate(self, written: frozenset | None = None) -> None:
+    """written = None: every mjData array may have changed; else only the named ones."""
+    cache = object.__getattribute__(self, "_cache")
+    if written is None:
+      cache.clear()
+    else:
+      for name in [k for k, (_, reads) in cache.items() if reads & written]:
+        del cache[name]
 
 
 class GraphedRlEnv:
-  def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True) -> None:
+  def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None) -> None:
     from mjlab.third_party.isaaclab.isaaclab.utils import math as rmath  # the reference's own helpers (pure torch)
 
     self.env, self._m = env, rmath
     self.n, self.device = env.num_envs, env.device
+    # the event / command terms as one HIP launch each (mjlab_amd/env_terms.py) wherever the environment lives on the GPU; the
+    # torch restatements below compute the same from the same uniforms (CPU runs over the oracle; fused_terms=False: A/B on the GPU)
+    self._fused = torch.device(self.device).type == "cuda" if fused_terms is None else bool(fused_terms)
     self.dt = float(env.step_dt)
     self._robot = env.scene["robot"]
     self._data_caches = []
@@ -176,18 +211,34 @@ class GraphedRlEnv:
     """Everything the event restatements need that the reference builds per call with ``torch.tensor(..., device=)``."""
     ev, dev = self.env.event_manager, self.device
     self._reset_terms, self._interval_terms = [], []
-    for cfg in ev._mode_term_cfgs.get("reset", []):
+    # every uniform number of one control step comes from ONE block U (n, ncol), drawn once per step: a term's draws are the
+    # columns `_ucols[key]` of its world's row (layouts: include/mjlab_amd.h, "environment terms")
+    self._ucols: dict = {}
+    ncol = 0
+
+    def cols(key: Any, width: int) -> None:
+      nonlocal ncol
+      self._ucols[key] = (ncol, ncol + width)
+      ncol += width
+
+    rix = self._robot.indexing
+    for index, cfg in enumerate(ev._mode_term_cfgs.get("reset", [])):
       p, fn = cfg.params, cfg.func.__name__
       if fn == "reset_root_state_uniform":
-        self._reset_terms.append((fn, {"pose": _range_tensors(p["pose_range"], dev), "vel": _range_tensors(p["velocity_range"], dev)}))
+        cols(("reset", index), 12)
+        self._reset_terms.append((fn, {"pose": torch.stack(_range_tensors(p["pose_range"], dev)), "vel": torch.stack(_range_tensors(p["velocity_range"], dev))}))
       else:
         ids = p["asset_cfg"].joint_ids
         ids = slice(None) if isinstance(ids, slice) else torch.as_tensor(ids, device=dev, dtype=torch.long)
-        rix = self._robot.indexing
-        self._reset_terms.append((fn, {"position_range": p["position_range"], "velocity_range": p["velocity_range"], "joint_ids": ids,
-                                       "qa": rix.joint_q_adr[ids], "va": rix.joint_v_adr[ids]}))
+        qa, va = rix.joint_q_adr[ids], rix.joint_v_adr[ids]
+        cols(("reset", index), 2 * qa.numel())
+        self._reset_terms.append((fn, {"position_range": p["position_range"], "velocity_range": p["velocity_range"], "joint_ids": ids, "qa": qa, "va": va,
+                                       "dev": (None if isinstance(ids, slice) else ids.to(torch.int32), qa.to(torch.int32).contiguous(), va.to(torch.int32).contiguous(),
+                                               torch.tensor([*p["position_range"], *p["velocity_range"]], dtype=torch.float32, device=dev))}))
     for index, cfg in enumerate(ev._mode_term_cfgs.get("interval", [])):
-      self._interval_terms.append((index, cfg.interval_range_s, _range_tensors(cfg.params["velocity_range"], dev)))
+      cols(("interval", index), 7)
+      self._interval_terms.append((index, cfg.interval_range_s, torch.stack(_range_tensors(cfg.params["velocity_range"], dev)),
+                                   torch.tensor(cfg.interval_range_s, dtype=torch.float32, device=dev)))
     self._stage_ranges = {}
     cm = self.env.curriculum_manager
     for name, cfg in zip(getattr(cm, "active_terms", []), getattr(cm, "_term_cfgs", []), strict=False):
@@ -197,13 +248,26 @@ class GraphedRlEnv:
     self._step_counter = torch.full((), int(self.env.common_step_counter), dtype=torch.long, device=dev)  # env.common_step_counter on the device
     for name in self.env.command_manager.active_terms:
       term = self.env.command_manager.get_term(name)
+      cols(("command", name, "reset"), 8)
+      cols(("command", name, "compute"), 8)
       if type(term).__name__ == "UniformVelocityCommand":  # ranges as device tensors [lo, hi]: a curriculum may change them inside the graph
         rg = term.cfg.ranges
-        self._command_ranges[id(term)] = {k: torch.tensor(getattr(rg, k), dtype=torch.float32, device=dev)
-                                          for k in ("lin_vel_x", "lin_vel_y", "ang_vel_z", "heading") if getattr(rg, k, None) is not None}
+        table = torch.zeros((4, 2), dtype=torch.float32, device=dev)  # rows lin_vel_x, lin_vel_y, ang_vel_z, heading (the fused term reads it whole)
+        views = {"table": table}
+        for k, key in enumerate(("lin_vel_x", "lin_vel_y", "ang_vel_z", "heading")):
+          if getattr(rg, key, None) is not None:
+            table[k] = torch.tensor(getattr(rg, key), dtype=torch.float32, device=dev)
+            views[key] = table[k]
+        self._command_ranges[id(term)] = views
       if type(term).__name__ == "MotionCommand":
         self._command_ranges[id(term)] = (_range_tensors(term.cfg.pose_range, dev), _range_tensors(term.cfg.velocity_range, dev))
         self._patch_body_index_lists(term)
+    self._ncol = max(ncol, 1)
+    self._U = torch.zeros((self.n, self._ncol), device=dev)
+
+  def _Uof(self, key: Any) -> torch.Tensor:
+    a, b = self._ucols[key]
+    return self._U[:, a:b]
 
   @staticmethod
   def _patch_body_index_lists(term: Any) -> None:
@@ -329,9 +393,9 @@ class GraphedRlEnv:
     return env.obs_buf, env.reward_buf, env.reset_terminated, env.reset_time_outs, env.extras
 
   # ------------------------------------------------------------------------------------------------------------------- body
-  def _invalidate(self) -> None:
+  def _invalidate(self, written: frozenset | None = None) -> None:
     for c in self._data_caches:
-      c.invalidate()
+      c.invalidate(written)
 
   def _body(self) -> None:
     """reference envs/manager_based_rl_env.py:106-147, in its order.  The EntityData cache is dropped wherever mjData changes."""
@@ -351,6 +415,7 @@ class GraphedRlEnv:
     env.reset_time_outs = env.termination_manager.time_outs
     env.reward_buf = env.reward_manager.compute(dt=self.dt)
     mask = env.reset_buf
+    self._U = torch.rand((self.n, self._ncol), device=self.device)  # this step's uniforms for every mask-based term (one launch)
     self._masked_reset(mask)
     self._invalidate()
     env.scene.write_data_to_sim()
@@ -358,7 +423,7 @@ class GraphedRlEnv:
     self._invalidate()
     self._command_compute()
     self._interval_events()
-    self._invalidate()
+    self._invalidate(_LATE_WRITES)  # (no forward() follows: xpos / xquat / cvel and what the terms derived from them still stand)
     env.obs_buf = env.observation_manager.compute(update_history=True)
     self._restore_bindings(before)
 
@@ -395,7 +460,7 @@ class GraphedRlEnv:
     for index, (fn, prm) in enumerate(self._reset_terms):
       env.event_manager._reset_term_last_triggered_step_id[index].masked_fill_(mask, step_count)
       env.event_manager._reset_term_last_triggered_once[index].masked_fill_(mask, True)
-      getattr(self, "_" + fn)(mask, **prm)
+      getattr(self, "_" + fn)(mask, self._Uof(("reset", index)), **prm)
     # observation manager: nothing stateful (checked at construction).  action manager (managers/action_manager.py:101-110):
     am = env.action_manager
     am._prev_action.masked_fill_(m1, 0.0)
@@ -423,7 +488,7 @@ class GraphedRlEnv:
           log[f"Metrics/{name}/{metric}"] = vals[k]
         torch._foreach_mul_(mvals, [keepf] * len(mvals))
       term.command_counter.masked_fill_(mask, 0)
-      self._command_resample(term, mask)
+      self._command_resample(term, mask, self._Uof(("command", name, "reset")))
     # termination manager (managers/termination_manager.py:73-85)
     tkeys, tdones = list(env.termination_manager._term_dones), list(env.termination_manager._term_dones.values())
     if tdones:
@@ -449,7 +514,7 @@ class GraphedRlEnv:
   def _clear_state(self, robot: Any, mask: torch.Tensor) -> None:
     """EntityData.clear_state (entity/data.py:171-181) for the environments of `mask`."""
     d = robot.data.data
-    fv, bi, ci = self._index_slices(robot)
+    fv, bi, ci, _ = self._index_slices(robot)
     keep = (~mask).to(torch.float32)
     for arr, idx, k in ((d.qfrc_applied, fv, keep[:, None]), (d.xfrc_applied, bi, keep[:, None, None]), (d.ctrl, ci, keep[:, None])):
       if isinstance(idx, slice):
@@ -474,7 +539,9 @@ class GraphedRlEnv:
     cache = self.__dict__.setdefault("_slices", {})
     if id(robot) not in cache:
       ix = robot.indexing
-      cache[id(robot)] = (_as_slice(ix.free_joint_v_adr), _as_slice(ix.body_ids), _as_slice(ix.ctrl_ids))
+      fq, fv = ix.free_joint_q_adr, ix.free_joint_v_adr
+      root = (int(fq[0]), int(fv[0])) if len(fq) == 7 and len(fv) == 6 else None  # (construction time) where the floating base starts
+      cache[id(robot)] = (_as_slice(ix.free_joint_v_adr), _as_slice(ix.body_ids), _as_slice(ix.ctrl_ids), root)
     return cache[id(robot)]
 
   def _masked_class_reset(self, func: Any, mask: torch.Tensor) -> None:
@@ -493,28 +560,37 @@ class GraphedRlEnv:
         else:
           setattr(owner, key, t)
 
-  def _reset_root_state_uniform(self, mask: torch.Tensor, pose, vel) -> None:
-    """envs/mdp/events.py:42-91."""
+  def _reset_root_state_uniform(self, mask: torch.Tensor, U: torch.Tensor, pose, vel) -> None:
+    """envs/mdp/events.py:42-91.  U: (n, 12) uniforms; pose / vel: (2, 6) [lo; hi]."""
     env, rm, robot = self.env, self._m, self._robot
     d, ix = robot.data.data, robot.indexing
     root = robot.data.default_root_state
-    rs = rm.sample_uniform(pose[0], pose[1], (self.n, 6), device=self.device)
+    if self._fused:
+      fq, fv = self._index_slices(robot)[3]
+      env_terms.reset_root_state_uniform(d.qpos, d.qvel, fq, fv, mask, root, env.scene.env_origins, U, pose, vel)
+      return
+    rs = U[:, 0:6] * (pose[1] - pose[0]) + pose[0]  # sample_uniform (math.py:1354-1373) on this step's uniforms
     positions = root[:, 0:3] + rs[:, 0:3] + env.scene.env_origins
     orientations = rm.quat_mul(root[:, 3:7], rm.quat_from_euler_xyz(rs[:, 3], rs[:, 4], rs[:, 5]))
-    velocities = root[:, 7:13] + rm.sample_uniform(vel[0], vel[1], (self.n, 6), device=self.device)
+    velocities = root[:, 7:13] + (U[:, 6:12] * (vel[1] - vel[0]) + vel[0])
     velocities = torch.cat([velocities[:, :3], rm.quat_apply_inverse(orientations, velocities[:, 3:])], dim=-1)
     m1 = mask[:, None]
     self._put(d.qpos, ix.free_joint_q_adr, m1, torch.cat([positions, orientations], dim=-1))
     self._put(d.qvel, ix.free_joint_v_adr, m1, velocities)
 
-  def _reset_joints_by_scale(self, mask: torch.Tensor, position_range, velocity_range, joint_ids, qa, va) -> None:
-    """envs/mdp/events.py:94-124."""
-    rm, robot = self._m, self._robot
-    d, ix = robot.data.data, robot.indexing
+  def _reset_joints_by_scale(self, mask: torch.Tensor, U: torch.Tensor, position_range, velocity_range, joint_ids, qa, va, dev) -> None:
+    """envs/mdp/events.py:94-124.  U: (n, 2 nj) uniforms, positions then velocities."""
+    robot = self._robot
+    d, nj = robot.data.data, qa.numel()
+    if self._fused:
+      ids32, qa32, va32, ranges = dev
+      env_terms.reset_joints_by_scale(d.qpos, d.qvel, mask, ids32, qa32, va32, robot.data.default_joint_pos, robot.data.default_joint_vel,
+                                      robot.data.soft_joint_pos_limits, U, ranges)
+      return
     jp = robot.data.default_joint_pos[:, joint_ids].clone()
     jv = robot.data.default_joint_vel[:, joint_ids].clone()
-    jp *= rm.sample_uniform(*position_range, jp.shape, self.device)
-    jv *= rm.sample_uniform(*velocity_range, jv.shape, self.device)
+    jp *= U[:, :nj] * (position_range[1] - position_range[0]) + position_range[0]
+    jv *= U[:, nj:] * (velocity_range[1] - velocity_range[0]) + velocity_range[0]
     lim = robot.data.soft_joint_pos_limits[:, joint_ids]
     jp = jp.clamp_(lim[..., 0], lim[..., 1])
     m1 = mask[:, None]
@@ -522,12 +598,18 @@ class GraphedRlEnv:
     self._put(d.qvel, va, m1, jv)
 
   # --------------------------------------------------------------------------------------------------------------- commands
-  def _command_resample(self, term: Any, mask: torch.Tensor) -> None:
+  def _fused_command(self, term: Any) -> bool:
+    return self._fused and type(term).__name__ == "UniformVelocityCommand" and term.cfg.init_velocity_prob <= 0.0
+
+  def _command_resample(self, term: Any, mask: torch.Tensor, U: torch.Tensor) -> None:
     """CommandTerm._resample (managers/command_manager.py:62-66) for the environments of `mask`, then the term's own
-    ``_resample_command`` in its mask-based form."""
+    ``_resample_command`` in its mask-based form.  U: (n, 8) uniforms, column 0 for ``time_left``."""
+    if self._fused_command(term):
+      env_terms.command_uniform_velocity(term, mask, U, self._command_ranges[id(term)]["table"], self.dt)
+      return
     lo, hi = term.cfg.resampling_time_range
-    term.time_left.copy_(torch.where(mask, torch.rand(self.n, device=self.device) * (hi - lo) + lo, term.time_left))
-    getattr(self, "_resample_" + type(term).__name__)(term, mask)
+    term.time_left.copy_(torch.where(mask, U[:, 0] * (hi - lo) + lo, term.time_left))
+    getattr(self, "_resample_" + type(term).__name__)(term, mask, U)
     term.command_counter += mask.to(term.command_counter.dtype)
 
   def _command_compute(self) -> None:
@@ -535,29 +617,30 @@ class GraphedRlEnv:
     for name in self.env.command_manager.active_terms:
       term = self.env.command_manager.get_term(name)
       term._update_metrics()  # the reference's own
+      U = self._Uof(("command", name, "compute"))
+      if self._fused_command(term):  # time_left -= dt, resampling where it ran out, _update_command: one launch
+        env_terms.command_uniform_velocity(term, None, U, self._command_ranges[id(term)]["table"], self.dt)
+        continue
       term.time_left -= self.dt
-      self._command_resample(term, term.time_left <= 0.0)
+      self._command_resample(term, term.time_left <= 0.0, U)
       getattr(self, "_update_" + type(term).__name__)(term)
 
   # -- UniformVelocityCommand (tasks/velocity/mdp/velocity_command.py:64-102)
-  def _resample_UniformVelocityCommand(self, term: Any, mask: torch.Tensor) -> None:
-    cfg, n, dev, rg = term.cfg, self.n, self.device, self._command_ranges[id(term)]
-    # all of the term's draws of this call as ONE (7, n) block of uniforms, scaled by the stacked ranges in two launches
-    lo = torch.stack([rg["lin_vel_x"][0], rg["lin_vel_y"][0], rg["ang_vel_z"][0], rg.get("heading", rg["ang_vel_z"])[0]])
-    hi = torch.stack([rg["lin_vel_x"][1], rg["lin_vel_y"][1], rg["ang_vel_z"][1], rg.get("heading", rg["ang_vel_z"])[1]])
-    U = torch.rand((7, n), device=dev)
-    R = U[:4] * (hi - lo)[:, None] + lo[:, None]
-    u = lambda lo_, hi_: U[6] * (hi_ - lo_) + lo_  # noqa: E731  (only the rarely enabled init-velocity branch)
+  def _resample_UniformVelocityCommand(self, term: Any, mask: torch.Tensor, U: torch.Tensor) -> None:
+    """U columns: [time_left, lin_vel_x, lin_vel_y, ang_vel_z, heading, is_heading, is_standing, init_velocity]."""
+    cfg, table = term.cfg, self._command_ranges[id(term)]["table"]
+    lo, hi = table[:, 0], table[:, 1]
+    R = U[:, 1:5] * (hi - lo) + lo  # the four ranged draws scaled by the stacked ranges in two launches
     v = term.vel_command_b
-    v.copy_(torch.where(mask[:, None], R[:3].T, v))
+    v.copy_(torch.where(mask[:, None], R[:, :3], v))
     if cfg.heading_command:
-      term.heading_target.copy_(torch.where(mask, R[3], term.heading_target))
-      term.is_heading_env.copy_(torch.where(mask, U[4] <= cfg.rel_heading_envs, term.is_heading_env))
-    term.is_standing_env.copy_(torch.where(mask, U[5] <= cfg.rel_standing_envs, term.is_standing_env))
+      term.heading_target.copy_(torch.where(mask, R[:, 3], term.heading_target))
+      term.is_heading_env.copy_(torch.where(mask, U[:, 5] <= cfg.rel_heading_envs, term.is_heading_env))
+    term.is_standing_env.copy_(torch.where(mask, U[:, 6] <= cfg.rel_standing_envs, term.is_standing_env))
     if cfg.init_velocity_prob > 0.0:
       rm, rd = self._m, term.robot.data
       d, ix = rd.data, term.robot.indexing
-      im = mask & (u(0.0, 1.0) < cfg.init_velocity_prob)
+      im = mask & (U[:, 7] < cfg.init_velocity_prob)
       lin_b = rd.root_link_lin_vel_b.clone()
       lin_b[:, :2] = v[:, :2]
       ang_b = rd.root_link_ang_vel_b.clone()
@@ -577,7 +660,7 @@ class GraphedRlEnv:
     v.masked_fill_(term.is_standing_env[:, None], 0.0)
 
   # -- MotionCommand (tasks/tracking/mdp/commands.py:255-392)
-  def _resample_MotionCommand(self, term: Any, mask: torch.Tensor) -> None:
+  def _resample_MotionCommand(self, term: Any, mask: torch.Tensor, U: torch.Tensor | None = None) -> None:
     """``_adaptive_sampling`` + ``_resample_command`` (:255-363).  The reference runs them only when the id list is non-empty; here
     the sampler's global state and metrics keep their values unless `mask` has an entry (``any`` on the device)."""
     rm, cfg, n, dev = self._m, term.cfg, self.n, self.device
@@ -646,12 +729,17 @@ class GraphedRlEnv:
     (envs/mdp/events.py:127-143)."""
     rm, robot, ev = self._m, self._robot, self.env.event_manager
     d, ix = robot.data.data, robot.indexing
-    for index, (lo, hi), (vlo, vhi) in self._interval_terms:
+    for index, (lo, hi), vel, interval in self._interval_terms:
       time_left = ev._interval_term_time_left[index]
+      U = self._Uof(("interval", index))  # (n, 7): six velocity draws, the next interval
+      if self._fused:
+        env_terms.push_by_setting_velocity(d.qvel, self._index_slices(robot)[3][1], time_left, self.dt, interval, robot.data.root_link_vel_w,
+                                           robot.data.root_link_quat_w, U, vel)
+        continue
       time_left -= self.dt
       trig = time_left < 1e-6
-      time_left.copy_(torch.where(trig, torch.rand(self.n, device=self.device) * (hi - lo) + lo, time_left))
-      vel_w = robot.data.root_link_vel_w + rm.sample_uniform(vlo, vhi, (self.n, 6), device=self.device)
+      time_left.copy_(torch.where(trig, U[:, 6] * (hi - lo) + lo, time_left))
+      vel_w = robot.data.root_link_vel_w + (U[:, :6] * (vel[1] - vel[0]) + vel[0])
       vel_w = torch.cat([vel_w[:, :3], rm.quat_apply_inverse(robot.data.root_link_quat_w, vel_w[:, 3:])], dim=-1)
       self._put(d.qvel, ix.free_joint_v_adr, trig[:, None], vel_w)
 

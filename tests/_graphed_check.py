@@ -141,6 +141,62 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
   return stats
 
 
+def run_fused_vs_torch(make_env, device: str, num_envs: int = 256, steps: int = 60, edit=_edit, noise: bool = True) -> dict:
+  """The event / command terms as HIP launches (``fused_terms=True``, mjlab_amd/env_terms.py) against their torch restatements
+  (``fused_terms=False``) inside two captured environments of the same task: both consume the same block of uniforms per step
+  (the same seed is set before each replay), so EVERY environment -- the ones that reset, resample or get pushed included --
+  must agree: decisions bit for bit, values to rounding (the torch chain's jit-scripted helpers may contract into fma)."""
+
+  def both(cfg):
+    edit(cfg)
+    if noise:
+      for group in ("policy", "critic"):
+        getattr(cfg.observations, group).enable_corruption = True  # (the noise draws follow the block in the generator's stream)
+
+  torch.manual_seed(0)
+  a = make_env(num_envs, device, both)
+  b = make_env(num_envs, device, both)
+  a.reset()
+  b.reset()
+  ga, gb = GraphedRlEnv(a, fused_terms=True), GraphedRlEnv(b, fused_terms=False)
+  gen = torch.Generator(device=device)
+  gen.manual_seed(9)
+  na = sum(a.action_manager.action_term_dim)
+  worst = {"obs": 0.0, "qpos": 0.0, "qvel": 0.0, "command": 0.0, "time_left": 0.0}
+  stats = {"resets": 0, "pushes": 0, "resamples": 0}
+  for k in range(steps):
+    _sync(a, b)
+    action = torch.rand((num_envs, na), device=device, generator=gen) * 2 - 1
+    if k > 20:
+      action[: num_envs // 8] *= 6.0
+    push = (a.event_manager._interval_term_time_left[0] - a.step_dt) < 1e-6
+    outs = []
+    for g in (ga, gb):
+      torch.manual_seed(1000 + k)
+      outs.append(g.step(action.clone()))
+    torch.cuda.synchronize()
+    (obs_a, rew_a, term_a, to_a, _), (obs_b, rew_b, term_b, to_b, _) = outs
+    assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b) and torch.equal(rew_a, rew_b), k
+    for grp in obs_a:
+      worst["obs"] = max(worst["obs"], float((obs_a[grp] - obs_b[grp]).abs().max()))
+    for f in ("qpos", "qvel"):
+      worst[f] = max(worst[f], float((getattr(a.sim.data, f) - getattr(b.sim.data, f)).abs().max()))
+    for name in a.command_manager.active_terms:
+      ta, tb = a.command_manager.get_term(name), b.command_manager.get_term(name)
+      worst["command"] = max(worst["command"], float((ta.command - tb.command).abs().max()))
+      worst["time_left"] = max(worst["time_left"], float((ta.time_left - tb.time_left).abs().max()))
+      assert torch.equal(ta.command_counter, tb.command_counter), k
+      for flag in ("is_heading_env", "is_standing_env"):
+        if hasattr(ta, flag):
+          assert torch.equal(getattr(ta, flag), getattr(tb, flag)), (k, flag)
+    assert torch.equal(a.episode_length_buf, b.episode_length_buf)
+    for ia, ib in zip(a.event_manager._interval_term_time_left, b.event_manager._interval_term_time_left, strict=True):
+      worst["time_left"] = max(worst["time_left"], float((ia - ib).abs().max()))
+    stats["resets"] += int((term_a | to_a).sum()); stats["pushes"] += int(push.sum())
+  stats["worst"] = worst
+  return stats
+
+
 def run_tracking(make_env, device: str, num_envs: int = 32, steps: int = 40, capture: bool = True) -> dict:
   """The same teacher-forced comparison for ``Mjlab-Tracking-Flat-Unitree-G1`` (``MotionCommand``: resets to motion phases drawn by
   the adaptive sampler, resampling when a motion ends, the sampler's global failure statistics)."""

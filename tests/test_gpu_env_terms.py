@@ -1,0 +1,261 @@
+"""The ENVIRONMENT TERMS of include/mjlab_amd.h (mjlab_amd/env_terms.py: one HIP launch per event / command term, mask based)
+against the formulas of the reference's terms written out in torch fp64 here -- reference envs/mdp/events.py:42-143,
+tasks/velocity/mdp/velocity_command.py:64-102, managers/command_manager.py:44-66, managers/event_manager.py:116-138 and the
+helpers third_party/isaaclab/isaaclab/utils/math.py:96 / :269 / :521 / :645 / :1354.  Needs no reference tree (the comparison
+with the reference's own functions inside the captured environment step: tests/test_gpu_reference_env.py).
+
+Tolerance: 2e-6 absolute on quantities of magnitude <= ~4 (fp32 kernels against fp64 formulas); rows outside the mask, and
+decisions (booleans, counters, timers that did not run out), bit for bit."""
+
+import math
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+N = 777  # (not a multiple of the block size)
+
+
+def _dev():
+  return torch.device("cuda:0")
+
+
+def quat_from_euler_xyz(r, p, y):
+  cy, sy, cr, sr, cp, sp = torch.cos(y / 2), torch.sin(y / 2), torch.cos(r / 2), torch.sin(r / 2), torch.cos(p / 2), torch.sin(p / 2)
+  return torch.stack([cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp], -1)
+
+
+def quat_mul(a, b):
+  w1, x1, y1, z1 = a.unbind(-1)
+  w2, x2, y2, z2 = b.unbind(-1)
+  return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                      w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)  # fmt: skip
+
+
+def quat_apply_inverse(q, v):
+  xyz = q[..., 1:]
+  t = torch.cross(xyz, v, dim=-1) * 2
+  return v - q[..., 0:1] * t + torch.cross(xyz, t, dim=-1)
+
+
+def wrap_to_pi(a):
+  w = (a + math.pi) % (2 * math.pi)
+  return torch.where((w == 0) & (a > 0), torch.full_like(a, math.pi), w - math.pi)
+
+
+def _unit_quats(n, g):
+  q = torch.randn((n, 4), generator=g, dtype=torch.float64)
+  return q / q.norm(dim=-1, keepdim=True)
+
+
+def _setup(seed, nq=36, nv=35):
+  g = torch.Generator().manual_seed(seed)
+  qpos = torch.randn((N, nq), generator=g)
+  qvel = torch.randn((N, nv), generator=g)
+  mask = torch.rand(N, generator=g) < 0.3
+  return g, qpos, qvel, mask
+
+
+@pytest.mark.parametrize("shared_root", [True, False])
+def test_reset_root_state_uniform(shared_root):
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g, qpos, qvel, mask = _setup(1)
+  root = torch.cat([torch.randn((N, 3), generator=g, dtype=torch.float64), _unit_quats(N, g), torch.randn((N, 6), generator=g, dtype=torch.float64) * 0.3], -1)
+  if shared_root:
+    root = root[:1].expand(N, 13)
+  org = torch.randn((N, 3), generator=g, dtype=torch.float64) * 5
+  U = torch.rand((N, 20), generator=g)  # a wider block: the term reads columns 3..15 of its row
+  pose = torch.tensor([[-0.5, -0.5, 0.0, -0.2, -0.1, -3.14], [0.5, 0.5, 0.1, 0.2, 0.1, 3.14]])
+  vel = torch.tensor([[-0.5, -0.4, -0.3, -0.2, -0.1, -0.6], [0.5, 0.4, 0.3, 0.2, 0.1, 0.6]])
+  q_adr, v_adr = 0, 0
+  dq, dv, du = qpos.to(dev), qvel.to(dev), U.to(dev)
+  root32 = root.float().to(dev) if not shared_root else root[:1].float().to(dev).expand(N, 13)
+  env_terms.reset_root_state_uniform(dq, dv, q_adr, v_adr, mask.to(dev), root32, org.float().to(dev), du[:, 3:15], pose.to(dev), vel.to(dev))
+  torch.cuda.synchronize()
+  # reference formulas on the fp32-rounded inputs, in fp64
+  r64, o64, u = root32.cpu().double(), org.float().double(), U[:, 3:15].double()
+  rs = u[:, :6] * (pose[1] - pose[0]).double() + pose[0].double()
+  pos = r64[:, 0:3] + rs[:, 0:3] + o64
+  ori = quat_mul(r64[:, 3:7], quat_from_euler_xyz(rs[:, 3], rs[:, 4], rs[:, 5]))
+  v = r64[:, 7:13] + u[:, 6:] * (vel[1] - vel[0]).double() + vel[0].double()
+  v = torch.cat([v[:, :3], quat_apply_inverse(ori, v[:, 3:])], -1)
+  want_q, want_v = qpos.clone().double(), qvel.clone().double()
+  want_q[mask, 0:7] = torch.cat([pos, ori], -1)[mask]
+  want_v[mask, 0:6] = v[mask]
+  got_q, got_v = dq.cpu(), dv.cpu()
+  assert torch.equal(got_q[~mask], qpos[~mask]) and torch.equal(got_v[~mask], qvel[~mask])
+  assert torch.equal(got_q[:, 7:], qpos[:, 7:]) and torch.equal(got_v[:, 6:], qvel[:, 6:])
+  assert (got_q.double() - want_q).abs().max() <= 5 * TOL, (got_q.double() - want_q).abs().max()  # (positions up to ~20 m)
+  assert (got_v.double() - want_v).abs().max() <= TOL
+  assert mask.sum() > 100
+
+
+@pytest.mark.parametrize("subset", [False, True])
+def test_reset_joints_by_scale(subset):
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g, qpos, qvel, mask = _setup(2)
+  nj_all = 29
+  ids = torch.tensor([0, 3, 4, 11, 28]) if subset else None
+  sel = ids if subset else torch.arange(nj_all)
+  nj = len(sel)
+  jpos = (torch.randn((1, nj_all), generator=g)).expand(N, nj_all)  # the reference's defaults: one row shared by all envs
+  jvel = torch.randn((N, nj_all), generator=g)
+  lim = torch.stack([jpos[0] - torch.rand(nj_all, generator=g), jpos[0] + torch.rand(nj_all, generator=g)], -1)[None].expand(N, nj_all, 2)
+  U = torch.rand((N, 2 * nj + 3), generator=g)
+  ranges = torch.tensor([0.5, 1.5, -1.0, 1.0])
+  qa, va = 7 + sel, 6 + sel
+  dq, dv = qpos.to(dev), qvel.to(dev)
+  env_terms.reset_joints_by_scale(dq, dv, mask.to(dev), None if ids is None else ids.to(dev, torch.int32), qa.to(dev, torch.int32), va.to(dev, torch.int32),
+                                  jpos[:1].to(dev).expand(N, nj_all), jvel.to(dev), lim[:1].to(dev).expand(N, nj_all, 2), U.to(dev)[:, 1 : 1 + 2 * nj], ranges.to(dev))
+  torch.cuda.synchronize()
+  u = U[:, 1 : 1 + 2 * nj].double()
+  p = jpos[:, sel].double() * (u[:, :nj] * (ranges[1] - ranges[0]).double() + ranges[0].double())
+  p = torch.minimum(torch.maximum(p, lim[:, sel, 0].double()), lim[:, sel, 1].double())
+  v = jvel[:, sel].double() * (u[:, nj:] * (ranges[3] - ranges[2]).double() + ranges[2].double())
+  want_q, want_v = qpos.clone().double(), qvel.clone().double()
+  rows = mask.nonzero().flatten()
+  want_q[rows[:, None], qa[None, :]] = p[mask]
+  want_v[rows[:, None], va[None, :]] = v[mask]
+  got_q, got_v = dq.cpu(), dv.cpu()
+  assert torch.equal(got_q[~mask], qpos[~mask]) and torch.equal(got_v[~mask], qvel[~mask])
+  others = torch.ones(36, dtype=torch.bool)
+  others[qa] = False
+  assert torch.equal(got_q[:, others], qpos[:, others])
+  assert (got_q.double() - want_q).abs().max() <= TOL and (got_v.double() - want_v).abs().max() <= TOL
+  clipped = ((p == lim[:, sel, 0].double()) | (p == lim[:, sel, 1].double()))[mask].sum()
+  assert clipped > 0  # the soft limits acted somewhere
+
+
+def test_push_by_setting_velocity():
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g, _, qvel, _ = _setup(3)
+  time_left = torch.rand(N, generator=g) * 0.1  # dt 0.02: about a fifth of the worlds trigger
+  dt = 0.02
+  interval = torch.tensor([1.0, 3.0])
+  vel_w = torch.randn((N, 6), generator=g)
+  xquat = _unit_quats(N * 3, g).float().view(N, 3, 4)  # root_link_quat_w is a strided view of xquat in the reference
+  U = torch.rand((N, 9), generator=g)
+  rng = torch.tensor([[-0.5, -0.5, 0.0, -0.1, -0.2, -0.3], [0.5, 0.5, 0.2, 0.1, 0.2, 0.3]])
+  dv, dt_left = qvel.to(dev), time_left.to(dev)
+  env_terms.push_by_setting_velocity(dv, 0, dt_left, dt, interval.to(dev), vel_w.to(dev), xquat.to(dev)[:, 1], U.to(dev)[:, 2:9], rng.to(dev))
+  torch.cuda.synchronize()
+  t32 = time_left - torch.tensor(dt, dtype=torch.float32)
+  trig = t32 < 1e-6
+  u = U[:, 2:9].double()
+  v = vel_w.double() + u[:, :6] * (rng[1] - rng[0]).double() + rng[0].double()
+  v = torch.cat([v[:, :3], quat_apply_inverse(xquat[:, 1].double(), v[:, 3:])], -1)
+  want_v = qvel.clone().double()
+  want_v[trig, 0:6] = v[trig]
+  want_t = torch.where(trig, u[:, 6] * 2.0 + 1.0, t32.double())
+  got_v, got_t = dv.cpu(), dt_left.cpu()
+  assert 50 < trig.sum() < N - 50
+  assert torch.equal(got_v[~trig], qvel[~trig]) and torch.equal(got_t[~trig], t32[~trig])
+  assert (got_v.double() - want_v).abs().max() <= TOL and (got_t.double() - want_t).abs().max() <= TOL
+
+
+def _command_term(g, dev, heading_command=True):
+  cfg = types.SimpleNamespace(init_velocity_prob=0.0, heading_command=heading_command, resampling_time_range=(3.0, 8.0), rel_heading_envs=0.7,
+                              rel_standing_envs=0.2, heading_control_stiffness=0.5)
+  heading_w = (torch.rand((N, 2), generator=g) * 8 - 4).to(dev)
+  t = types.SimpleNamespace(cfg=cfg, num_envs=N, time_left=(torch.rand(N, generator=g) * 0.1).to(dev), vel_command_b=torch.randn((N, 3), generator=g).to(dev),
+                            heading_target=(torch.rand(N, generator=g) * 6.28 - 3.14).to(dev), is_heading_env=(torch.rand(N, generator=g) < 0.5).to(dev),
+                            is_standing_env=(torch.rand(N, generator=g) < 0.3).to(dev), command_counter=torch.randint(0, 5, (N,), generator=g).to(dev),
+                            robot=types.SimpleNamespace(data=types.SimpleNamespace(heading_w=heading_w[:, 1])))
+  return t
+
+
+def _snapshot(t):
+  return {k: getattr(t, k).cpu().clone() for k in ("time_left", "vel_command_b", "heading_target", "is_heading_env", "is_standing_env", "command_counter")}
+
+
+def _resampled(s0, m, u, ranges, cfg):
+  """The reference's _resample + _resample_command for the rows of m, fp64."""
+  out = {k: (v.double() if v.dtype == torch.float32 else v.clone()) for k, v in s0.items()}
+  lo, hi = ranges[:, 0].double(), ranges[:, 1].double()
+  out["time_left"][m] = (u[:, 0] * (cfg.resampling_time_range[1] - cfg.resampling_time_range[0]) + cfg.resampling_time_range[0])[m]
+  out["vel_command_b"][m] = (u[:, 1:4] * (hi[:3] - lo[:3]) + lo[:3])[m]
+  if cfg.heading_command:
+    out["heading_target"][m] = (u[:, 4] * (hi[3] - lo[3]) + lo[3])[m]
+    out["is_heading_env"][m] = (u[:, 5].float() <= cfg.rel_heading_envs)[m]
+  out["is_standing_env"][m] = (u[:, 6].float() <= torch.tensor(cfg.rel_standing_envs, dtype=torch.float32))[m]
+  out["command_counter"][m] += 1
+  return out
+
+
+def _check(got, want, m, s0):
+  for k in ("is_heading_env", "is_standing_env", "command_counter"):
+    assert torch.equal(got[k], want[k]), k
+  for k in ("time_left", "vel_command_b", "heading_target"):
+    assert (got[k].double() - want[k]).abs().max() <= TOL, (k, (got[k].double() - want[k]).abs().max())
+
+
+@pytest.mark.parametrize("heading_command", [True, False])
+def test_command_uniform_velocity_reset(heading_command):
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(4)
+  t = _command_term(g, dev, heading_command)
+  s0 = _snapshot(t)
+  mask = torch.rand(N, generator=g) < 0.4
+  U = torch.rand((N, 8), generator=g)
+  ranges = torch.tensor([[-1.0, 1.0], [-0.5, 0.5], [-0.7, 0.7], [-3.14, 3.14]])
+  env_terms.command_uniform_velocity(t, mask.to(dev), U.to(dev), ranges.to(dev), 0.02)
+  torch.cuda.synchronize()
+  got = _snapshot(t)
+  want = _resampled(s0, mask, U.double(), ranges, t.cfg)
+  _check(got, want, mask, s0)
+  for k, v in s0.items():  # rows outside the mask: untouched, bit for bit
+    assert torch.equal(got[k][~mask], v[~mask]), k
+
+
+@pytest.mark.parametrize("heading_command", [True, False])
+def test_command_uniform_velocity_compute(heading_command):
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(5)
+  t = _command_term(g, dev, heading_command)
+  s0 = _snapshot(t)
+  U = torch.rand((N, 8), generator=g)
+  ranges = torch.tensor([[-1.0, 1.0], [-0.5, 0.5], [-0.7, 0.7], [-3.14, 3.14]])
+  dt = 0.02
+  env_terms.command_uniform_velocity(t, None, U.to(dev), ranges.to(dev), dt)
+  torch.cuda.synchronize()
+  got = _snapshot(t)
+  t32 = s0["time_left"] - torch.tensor(dt, dtype=torch.float32)
+  m = t32 <= 0
+  assert 50 < m.sum() < N - 50
+  s1 = dict(s0)
+  s1["time_left"] = t32
+  want = _resampled(s1, m, U.double(), ranges, t.cfg)
+  # _update_command (velocity_command.py:89-102) on every row
+  if heading_command:
+    hw = t.robot.data.heading_w.cpu().double()
+    err = wrap_to_pi(want["heading_target"].double() - hw)
+    yaw = torch.clamp(0.5 * err, ranges[2, 0].double(), ranges[2, 1].double())
+    want["vel_command_b"][:, 2] = torch.where(want["is_heading_env"], yaw, want["vel_command_b"][:, 2])
+  want["vel_command_b"][want["is_standing_env"]] = 0.0
+  _check(got, want, m, s0)
+  assert torch.equal(got["time_left"][~m], t32[~m])
+
+
+def test_terms_refuse_what_they_cannot_address():
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g, qpos, qvel, mask = _setup(6)
+  with pytest.raises(TypeError):
+    env_terms.reset_root_state_uniform(qpos.to(dev).double(), qvel.to(dev), 0, 0, mask.to(dev), torch.zeros((N, 13), device=dev), torch.zeros((N, 3), device=dev),
+                                       torch.zeros((N, 12), device=dev), torch.zeros((2, 6), device=dev), torch.zeros((2, 6), device=dev))
+  with pytest.raises(RuntimeError, match="bad sizes"):
+    env_terms.reset_root_state_uniform(qpos.to(dev), qvel.to(dev), 33, 0, mask.to(dev), torch.zeros((N, 13), device=dev), torch.zeros((N, 3), device=dev),
+                                       torch.zeros((N, 12), device=dev), torch.zeros((2, 6), device=dev), torch.zeros((2, 6), device=dev))

@@ -68,6 +68,22 @@ def test_graphed_env_matches_the_reference_env():
   assert st["graph"] and st["resets"] >= 256 and st["pushes"] >= 256 and st["resamples"] >= 8 and st["quiet_env_steps"] >= 4000 and 0 < st["forward_steps"] < 70
 
 
+def test_fused_environment_terms_equal_their_torch_restatements():
+  """mjlab_amd/env_terms.py (one HIP launch per event / command term) inside the captured step against the torch restatements of
+  the same terms, on the same uniforms, for EVERY environment -- resets, command resampling and pushes included."""
+  sys.path.insert(0, str(ROOT / "tests"))
+  import _graphed_check
+
+  def make(n, device, edit):
+    return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=n, device=device, seed=11, cfg_edit=edit)
+
+  st = _graphed_check.run_fused_vs_torch(make, "cuda:0", num_envs=256, steps=60)
+  print("fused environment terms vs torch restatements:", st)
+  w = st["worst"]
+  assert st["resets"] >= 200 and st["pushes"] >= 200
+  assert w["qpos"] <= 2e-6 and w["qvel"] <= 1e-5 and w["command"] <= 1e-6 and w["time_left"] <= 1e-6 and w["obs"] <= 1e-5, w
+
+
 _TRACKING_GPU = """
 import json, sys
 import torch
