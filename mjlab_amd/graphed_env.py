@@ -22,6 +22,9 @@ a static buffer and replays the graph.  What the graph holds:
     ``CommandTerm.reset / compute / _resample`` (managers/command_manager.py:44-66) and ``UniformVelocityCommand``'s
     ``_resample_command`` / ``_update_command`` (tasks/velocity/mdp/velocity_command.py:64-102)
     ``EventManager.apply(mode="interval")`` (managers/event_manager.py:116-138)
+  On the GPU the four terms that write mjData -- the two reset events, the push, ``UniformVelocityCommand`` -- are ONE HIP launch each
+  (mjlab_amd/env_terms.py, include/mjlab_amd.h "environment terms"); all uniforms of a step come from one block drawn once, which
+  the torch restatements (CPU runs over the oracle; ``fused_terms=False``) consume the same way.  Either way
   with the same arithmetic in the same order per environment (the reference's own quaternion / sampling helpers are called);
   what differs is which random numbers an environment draws (every environment draws, the mask selects), so environments that
   reset, resample or get pushed in a step match the reference IN DISTRIBUTION, all others bit for bit

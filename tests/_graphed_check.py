@@ -163,13 +163,14 @@ def run_fused_vs_torch(make_env, device: str, num_envs: int = 256, steps: int = 
   gen.manual_seed(9)
   na = sum(a.action_manager.action_term_dim)
   worst = {"obs": 0.0, "qpos": 0.0, "qvel": 0.0, "command": 0.0, "time_left": 0.0}
-  stats = {"resets": 0, "pushes": 0, "resamples": 0}
+  stats = {"resets": 0, "pushes": 0, "resamples": 0}  # (resamples: commands that ran out inside an episode)
   for k in range(steps):
     _sync(a, b)
     action = torch.rand((num_envs, na), device=device, generator=gen) * 2 - 1
     if k > 20:
       action[: num_envs // 8] *= 6.0
     push = (a.event_manager._interval_term_time_left[0] - a.step_dt) < 1e-6
+    stats["resamples"] += sum(int(((a.command_manager.get_term(nm).time_left - a.step_dt) <= 0.0).sum()) for nm in a.command_manager.active_terms)
     outs = []
     for g in (ga, gb):
       torch.manual_seed(1000 + k)
