@@ -56,7 +56,10 @@ SUPPORTED_COMMANDS = ("UniformVelocityCommand", "MotionCommand")
 # cfg.  Here the ranges the captured kernels read live in device tensors and the same rule runs on the device (step counter on the
 # device, ``mask.any()``), so the switch happens in exactly the reference's step and the graph is not captured again; the host cfg is
 # refreshed for readers of ``cfg.ranges`` by the same rule evaluated on the host counter (without the reset condition).
-SUPPORTED_CURRICULA = ("commands_vel",)
+SUPPORTED_CURRICULA = ("commands_vel", "terrain_levels_vel")
+# terrain_levels_vel (tasks/velocity/mdp/curriculums.py:18-52 + terrains/terrain_importer.py:186-201): environments that reset move up
+# / down a terrain level by the distance they walked; mask based here (every environment evaluated, the reset mask selects; the
+# random level of an environment that walks off the hardest row comes from the step's block of uniforms instead of randint_like).
 _AXES = ("x", "y", "z", "roll", "pitch", "yaw")
 # the mjData arrays the command update and the interval events may write (command terms: write_root_state / write_joint_state /
 # clear_state of the tracking task's resample; push_by_setting_velocity: qvel)
@@ -245,6 +248,9 @@ class GraphedRlEnv:
     self._stage_ranges = {}
     cm = self.env.curriculum_manager
     for name, cfg in zip(getattr(cm, "active_terms", []), getattr(cm, "_term_cfgs", []), strict=False):
+      if cfg.func.__name__ == "terrain_levels_vel":
+        cols(("curriculum", name), 1)
+        continue
       for k, stage in enumerate(cfg.params["velocity_stages"]):
         self._stage_ranges[(name, k)] = torch.tensor(stage["range"], dtype=torch.float32, device=dev)
     self._command_ranges = {}
@@ -348,6 +354,9 @@ class GraphedRlEnv:
     _state_tensors(env.command_manager, None, set(), found)
     tensors = [t for *_, t, _ in found] + list(env.sim._data.values()) + [env.episode_length_buf, self._step_counter]
     tensors += [t for rg in self._command_ranges.values() if isinstance(rg, dict) for t in rg.values()]
+    terrain = getattr(env.scene, "terrain", None)
+    if terrain is not None and getattr(terrain, "terrain_origins", None) is not None:
+      tensors += [terrain.terrain_levels, terrain.env_origins]  # (the terrain curriculum moves them)
     seen, out = set(), []
     for t in tensors:
       if any(st == 0 and sz > 1 for st, sz in zip(t.stride(), t.shape)):
@@ -387,7 +396,7 @@ class GraphedRlEnv:
     env.common_step_counter += 1
     cm = env.curriculum_manager  # host copy of the command ranges for readers of cfg.ranges (the graph reads the device tensors)
     for cfg in getattr(cm, "_term_cfgs", []):
-      for stage in cfg.params["velocity_stages"]:
+      for stage in cfg.params.get("velocity_stages", ()):
         if env.common_step_counter > stage["step"]:
           rg = env.command_manager.get_term(cfg.params["command_name"]).cfg.ranges
           rg.lin_vel_x = rg.ang_vel_z = stage["range"]
@@ -456,7 +465,7 @@ class GraphedRlEnv:
     env, m1 = self.env, mask[:, None]
     cnt = mask.sum().clamp(min=1).to(torch.float32)
     log: dict = {}
-    self._curricula(mask.any())  # curriculum_manager.compute(env_ids) comes first (:215), and only when some environment resets
+    self._curricula(mask)  # curriculum_manager.compute(env_ids) comes first (:215), and only when some environment resets
     self._clear_state(self._robot, mask)  # scene.reset -> Entity.reset -> clear_state
     # reset-mode events (managers/event_manager.py:139-148 with min_step_count 0)
     step_count = env._sim_step_counter // env.cfg.decimation  # (baked in at capture; read by nothing the supported terms use)
@@ -498,13 +507,21 @@ class GraphedRlEnv:
       counts = (torch.stack(tdones, dim=1) & mask[:, None]).sum(dim=0)
       for k, key in enumerate(tkeys):
         log["Episode_Termination/" + key] = counts[k]
+    for cname, state in getattr(env.curriculum_manager, "_curriculum_state", {}).items():  # CurriculumManager.reset (managers/curriculum_manager.py:70-85)
+      if isinstance(state, torch.Tensor):
+        log["Curriculum/" + cname] = state.reshape(-1)[0] if state.numel() == 1 else state
     env.extras["log"] = log
     env.episode_length_buf.masked_fill_(mask, 0)
 
-  def _curricula(self, any_reset: torch.Tensor) -> None:
-    """CurriculumManager.compute (managers/curriculum_manager.py:97-102) for ``commands_vel`` (tasks/velocity/mdp/curriculums.py:60-74)."""
+  def _curricula(self, mask: torch.Tensor) -> None:
+    """CurriculumManager.compute (managers/curriculum_manager.py:97-102) for ``commands_vel`` (tasks/velocity/mdp/curriculums.py:60-74)
+    and ``terrain_levels_vel`` (:18-52)."""
     cm = self.env.curriculum_manager
+    any_reset = mask.any()
     for name, cfg in zip(getattr(cm, "active_terms", []), getattr(cm, "_term_cfgs", []), strict=False):
+      if cfg.func.__name__ == "terrain_levels_vel":
+        cm._curriculum_state[name] = self._terrain_levels_vel(mask, self._Uof(("curriculum", name))[:, 0], **cfg.params)
+        continue
       term = self.env.command_manager.get_term(cfg.params["command_name"])
       rg = self._command_ranges[id(term)]
       for k, stage in enumerate(cfg.params["velocity_stages"]):
@@ -513,6 +530,23 @@ class GraphedRlEnv:
         rg["lin_vel_x"].copy_(torch.where(on, new, rg["lin_vel_x"]))
         rg["ang_vel_z"].copy_(torch.where(on, new, rg["ang_vel_z"]))
       cm._curriculum_state[name] = rg["lin_vel_x"][1:2]
+
+  def _terrain_levels_vel(self, mask: torch.Tensor, u: torch.Tensor, command_name: str, asset_cfg: Any = None) -> torch.Tensor:
+    env = self.env
+    asset = env.scene[asset_cfg.name] if asset_cfg is not None else self._robot
+    terrain = env.scene.terrain
+    command = env.command_manager.get_command(command_name)
+    distance = torch.norm(asset.data.root_link_pos_w[:, :2] - env.scene.env_origins[:, :2], dim=1)
+    move_up = distance > terrain.cfg.terrain_generator.size[0] / 2
+    move_down = distance < torch.norm(command[:, :2], dim=1) * env.max_episode_length_s * 0.5
+    move_down = move_down * ~move_up
+    if terrain.terrain_origins is not None:  # TerrainImporter.update_env_origins (terrains/terrain_importer.py:186-201)
+      lv = terrain.terrain_levels + (1 * move_up - 1 * move_down)
+      rnd = (u * terrain.max_terrain_level).to(lv.dtype).clamp_(max=terrain.max_terrain_level - 1)  # randint_like(levels, max_terrain_level)
+      lv = torch.where(lv >= terrain.max_terrain_level, rnd, torch.clip(lv, 0))
+      terrain.terrain_levels.copy_(torch.where(mask, lv, terrain.terrain_levels))
+      terrain.env_origins.copy_(torch.where(mask[:, None], terrain.terrain_origins[terrain.terrain_levels, terrain.terrain_types], terrain.env_origins))
+    return torch.mean(terrain.terrain_levels.float())
 
   def _clear_state(self, robot: Any, mask: torch.Tensor) -> None:
     """EntityData.clear_state (entity/data.py:171-181) for the environments of `mask`."""

@@ -173,6 +173,7 @@ class SpecGeom:
   body: "SpecBody | None" = None
   mass: float | None = None  # overrides density when given (MJCF geom/mass)
   density: float = 1000.0
+  material: str | None = None  # (rendering only; the terrain generator reads it back: terrains/terrain_generator.py:215)
 
 
 @dataclass
@@ -214,6 +215,7 @@ class SpecBody:
     g = SpecGeom(name, int(type), sz, np.array(pos, dtype=np.float64), np.array(quat, dtype=np.float64), body=self, **keep)
     if rgba is not None:
       g.rgba = np.array(rgba, dtype=np.float64)
+    g.material = material
     self.geoms.append(g)
     return g
 

@@ -54,12 +54,19 @@ def _sync(a, b) -> None:
     tb.copy_(ta)
   b.episode_length_buf.copy_(a.episode_length_buf)
   b._sim_step_counter, b.common_step_counter = a._sim_step_counter, a.common_step_counter
+  ta, tb = getattr(a.scene, "terrain", None), getattr(b.scene, "terrain", None)
+  if ta is not None and getattr(ta, "terrain_origins", None) is not None:  # the terrain curriculum's state
+    tb.terrain_levels.copy_(ta.terrain_levels)
+    tb.env_origins.copy_(ta.env_origins)
 
 
-def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: bool = True) -> dict:
+def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: bool = True, post_make=None) -> dict:
   torch.manual_seed(0)
   a = make_env(num_envs, device, _edit)
   b = make_env(num_envs, device, _edit)
+  if post_make is not None:
+    post_make(a)
+    post_make(b)
   a.reset()
   b.reset()
   g = GraphedRlEnv(b, capture=capture)
@@ -82,6 +89,8 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
     # which envs will draw random numbers in this step (a function of the synced pre-step state)
     resample = (cmd_a.time_left - dt) <= 0.0
     push = (ev._interval_term_time_left[0] - dt) < 1e-6
+    terr = a.scene.terrain if getattr(getattr(a.scene, "terrain", None), "terrain_origins", None) is not None else None
+    levels_before = terr.terrain_levels.clone() if terr is not None else None
     obs_a, rew_a, term_a, to_a, _ = a.step(action.clone())
     obs_b, rew_b, term_b, to_b, _ = g.step(action.clone())
     if device != "cpu":
@@ -89,6 +98,16 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
     assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b), k
     assert torch.equal(rew_a, rew_b), (k, (rew_a - rew_b).abs().max())
     reset = term_a | to_a
+    if terr is not None:  # the terrain curriculum (terrain_levels_vel): the same moves; a random level only past the hardest row
+      tb = b.scene.terrain
+      drew = reset & (levels_before + 1 >= terr.max_terrain_level)
+      assert torch.equal(terr.terrain_levels[~drew], tb.terrain_levels[~drew]), k
+      assert torch.equal(terr.env_origins[~drew], tb.env_origins[~drew]), k
+      for t in (terr, tb):
+        assert bool((t.terrain_levels >= 0).all()) and bool((t.terrain_levels < t.max_terrain_level).all())
+        assert torch.equal(t.env_origins, t.terrain_origins[t.terrain_levels, t.terrain_types])
+      stats["level_moves"] = stats.get("level_moves", 0) + int((terr.terrain_levels != levels_before).sum())
+      stats["level_draws"] = stats.get("level_draws", 0) + int((drew & (terr.terrain_levels != levels_before + 1)).sum())
     noisy = reset | resample | push
     quiet = ~noisy
     for grp in obs_a:

@@ -186,3 +186,46 @@ def test_graphed_go1_env_with_its_curriculum(tmp_path):
   st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
   print("graphed Go1 env vs reference env:", st)
   assert st["graph"] and st["captures"] == 1 and st["resets"] >= 64 and st["pushes"] >= 64 and st["quiet_env_steps"] >= 2000
+
+
+_ROUGH_GRAPHED = """
+import json, sys
+import torch
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env, _graphed_check
+def make(n, device, edit):
+  return reference_env.make_env("Mjlab-Velocity-Rough-Unitree-G1", num_envs=n, device=device, seed=11, cfg_edit=edit)
+def post(env):
+  t = env.scene.terrain
+  g = t.cfg.terrain_generator
+  g.size = (0.6, g.size[1])  # "walked far enough" after 0.3 m: the 30-step episodes of the check move up as well as down
+  t.terrain_levels[:16] = t.max_terrain_level - 1  # moving up from the hardest row draws a random row
+  t.env_origins[:] = t.terrain_origins[t.terrain_levels, t.terrain_types]
+st = _graphed_check.run(make, "cuda:0", num_envs=128, steps=70, capture=True, post_make=post)
+env = make(256, "cuda:0", None)
+env.reset()
+z = []
+for k in range(60):
+  out = env.step(torch.rand((256, 29), device="cuda:0") * 2 - 1)
+  z.append(bool(torch.isfinite(out[1]).all()))
+st["eager_finite"] = all(z)
+st["overflow"] = env.sim.overflow_report()
+st["ngeom"] = int(env.sim.mj_model.ngeom)
+print("RESULT " + json.dumps(st))
+"""
+
+
+def test_graphed_rough_env_with_its_terrain_curriculum(tmp_path):
+  """``Mjlab-Velocity-Rough-Unitree-G1`` -- the terrain the reference's own generator builds (box stairs, 10 x 20 sub-terrains) through
+  the MjSpec shim, over the HIP simulation -- as one hipGraph with the ``terrain_levels_vel`` curriculum mask based: the same level moves
+  and spawn origins as the reference's eager step (tests/_graphed_check.py)."""
+  import json
+  import subprocess
+
+  code = _ROUGH_GRAPHED.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print("graphed rough G1 env vs reference env:", st)
+  assert st["graph"] and st["resets"] >= 128 and st["pushes"] >= 128 and st["quiet_env_steps"] >= 2000 and st["level_moves"] >= 64 and st["level_draws"] >= 1
+  assert st["eager_finite"] and st["overflow"] == {"nconmax": 0, "njmax": 0, "terrain_candidates": 0}, st

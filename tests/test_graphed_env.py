@@ -118,3 +118,36 @@ def test_go1_task_with_its_host_side_curriculum():
   assert r.returncode == 0, r.stderr[-3000:]
   st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
   assert st["resets"] >= 16 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400
+
+
+_ROUGH = """
+import json, sys
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env, _graphed_check
+from _oracle_simulation import OracleSimulation
+def make(n, device, edit):
+  return reference_env.make_env("Mjlab-Velocity-Rough-Unitree-G1", num_envs=n, device=device, sim_cls=OracleSimulation, seed=11, cfg_edit=edit)
+def post(env):
+  # "walked far enough" after 0.3 m instead of half a sub-terrain (4 m), so that the 30-step episodes of the check move up as well as
+  # down (the curriculum reads the size at every call)
+  t = env.scene.terrain
+  g = t.cfg.terrain_generator
+  g.size = (0.6, g.size[1])
+  t.terrain_levels[:4] = t.max_terrain_level - 1  # four environments start on the hardest row: moving up from there draws a random row
+  t.env_origins[:] = t.terrain_origins[t.terrain_levels, t.terrain_types]
+st = _graphed_check.run(make, "cpu", num_envs=16, steps=70, capture=False, post_make=post)
+print("RESULT " + json.dumps(st))
+"""
+
+
+def test_rough_task_with_its_terrain_curriculum():
+  """``Mjlab-Velocity-Rough-Unitree-G1``: the reference's terrain generator (box stairs, 10 x 20 sub-terrains) through the MjSpec shim,
+  and the ``terrain_levels_vel`` curriculum mask based -- the same level moves and spawn origins as the reference's eager step."""
+  import json
+  import subprocess
+
+  code = _ROUGH.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  assert st["resets"] >= 16 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400 and st["level_moves"] >= 8 and st["level_draws"] >= 1, st
