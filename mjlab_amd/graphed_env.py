@@ -105,14 +105,17 @@ def _state_tensors(obj: Any, n: int | None, seen: set, out: list, depth: int = 0
 
 
 class _ReadRecorder:
-  """Stands where ``EntityData.data`` stood: hands every field of the simulation's data bridge through and notes its name."""
+  """Stands where ``EntityData.data`` stood: hands every field of the simulation's data bridge through and notes its name in the
+  read set of the property evaluation in progress (`stack`: nested evaluations)."""
 
   def __init__(self, inner: Any) -> None:
     object.__setattr__(self, "_inner", inner)
-    object.__setattr__(self, "reads", set())
+    object.__setattr__(self, "stack", [])
 
   def __getattr__(self, name: str) -> Any:
-    object.__getattribute__(self, "reads").add(name)
+    stack = object.__getattribute__(self, "stack")
+    if stack:
+      stack[-1].add(name)
     return getattr(object.__getattribute__(self, "_inner"), name)
 
   def __setattr__(self, name: str, value: Any) -> None:
@@ -124,27 +127,37 @@ class _CachedEntityData:
   of the control step and handed out again until ``invalidate()`` -- the reference re-derives e.g. ``root_link_lin_vel_b`` from
   ``xpos / subtree_com / cvel / xquat`` (6-8 small kernels) in every term that reads it: both observation groups, the rewards, the
   command metrics.  The same tensors, fewer launches; the terms only read them (the managers clone what they keep).  Writers and
-  plain attributes go straight through.  Each entry remembers which mjData arrays its evaluation read, so that a phase that wrote
-  only some arrays (the push: ``qvel``) drops only the entries that depend on them."""
+  plain attributes go straight through.  A property is evaluated with this object as its ``self`` (the reference's own getter,
+  ``type(inner).<name>.fget``), so the properties it builds on -- ``root_link_vel_w`` under both ``root_link_lin_vel_b`` and
+  ``root_link_ang_vel_b``, ``root_link_pose_w`` under five of them -- are shared as well.  Each entry remembers which mjData arrays
+  its evaluation read (its own and its building blocks'), so that a phase that wrote only some arrays (the push: ``qvel``) drops
+  only the entries that depend on them."""
 
   def __init__(self, inner: Any) -> None:
     object.__setattr__(self, "_inner", inner)
     object.__setattr__(self, "_cache", {})
-    object.__setattr__(self, "_props", {k for k in dir(type(inner)) if isinstance(getattr(type(inner), k, None), property)})
+    object.__setattr__(self, "_props", {k: getattr(type(inner), k).fget for k in dir(type(inner)) if isinstance(getattr(type(inner), k, None), property)})
     if not isinstance(inner.data, _ReadRecorder):
       inner.data = _ReadRecorder(inner.data)
 
   def __getattr__(self, name: str) -> Any:
     inner = object.__getattribute__(self, "_inner")
-    if name in object.__getattribute__(self, "_props"):
-      cache = object.__getattribute__(self, "_cache")
-      if name not in cache:
-        reads = inner.data.reads
-        reads.clear()
-        value = getattr(inner, name)
-        cache[name] = (value, frozenset(reads))
-      return cache[name][0]
-    return getattr(inner, name)
+    getter = object.__getattribute__(self, "_props").get(name)
+    if getter is None:
+      return getattr(inner, name)
+    cache = object.__getattribute__(self, "_cache")
+    stack = inner.data.stack
+    if name not in cache:
+      stack.append(set())
+      try:
+        value = getter(self)
+      finally:
+        reads = frozenset(stack.pop())
+      cache[name] = (value, reads)
+    value, reads = cache[name]
+    if stack:
+      stack[-1].update(reads)  # a building block's reads are its user's reads
+    return value
 
   def __setattr__(self, name: str, value: Any) -> None:
     setattr(object.__getattribute__(self, "_inner"), name, value)
