@@ -30,7 +30,7 @@ sys.path.insert(0, str(ROOT / "tools"))
 sys.path.insert(0, str(ROOT / "tests"))
 
 GOLD = ROOT / "tests" / "golden"
-SCENES = ("g1_velocity_flat", "g1_tracking_flat")
+SCENES = ("g1_velocity_flat", "g1_tracking_flat", "g1_velocity_rough")
 
 
 # ------------------------------------------------------------------------------------------------ quaternion helpers (w, x, y, z)
@@ -134,6 +134,9 @@ _MARGIN: dict = {}
 # GPU: the share of (world, step) rows that must lie entirely within 1 x / WORST x a term's bound, and the sanity cap on the rest
 # (worlds whose solve parted under the grid search: see state_tol in the GPU test)
 WORST, ROWS_1X, ROWS_WORST, SANITY = 3.0, 0.99, 1.0, 3.0  # measured r04_v11: every row within 1 x but 1 of 320 (joint_vel, tracking: 1.08 x)
+# the rough scene: a foot on a stair edge gains or loses a contact row between two fp32 engines now and then, and that world's step
+# differs at the 1e-4 level (the parity gate's "deep / capped" class); such rows are bounded in number and size
+ROUGH = {"rows_worst": 0.995, "sanity": float("inf")}  # measured r04_v27: 4 of 1280 world-steps beyond 3 x (joint_pos), the worst at 1.9e-2 rad
 
 
 def compare_terms(meta, z, k, dv, atol, tag, stats):
@@ -150,7 +153,8 @@ def compare_terms(meta, z, k, dv, atol, tag, stats):
     _MARGIN[key] = max(_MARGIN.get(key, 0.0), float(err.max()))
     st = stats.setdefault(name, [0, 0, 0.0, 0])
     st[0] += int((ratio <= 1.0).sum()); st[1] += len(ratio); st[2] = max(st[2], float(ratio.max())); st[3] += int((ratio <= WORST).sum())
-    assert ratio.max() <= (1.0 if tag == "cpu" else SANITY), (meta["scene"], k, name, float(err.max()), atol[name], float(ratio.max()))
+    sanity = ROUGH["sanity"] if meta["scene"].endswith("rough") else SANITY
+    assert ratio.max() <= (1.0 if tag == "cpu" else sanity), (meta["scene"], k, name, float(err.max()), atol[name], float(ratio.max()))
   return len(ref)
 
 
@@ -202,7 +206,7 @@ def _replay(scene, make_sim, derive, atol, tag, state_tol):
       state_err[f].append(err)
       assert np.isfinite(a).all(), (scene, k, f)
     done = z["terminated"][k] | z["time_out"][k]
-    if scene == "g1_velocity_flat":
+    if scene.startswith("g1_velocity"):
       # the task's terminations from the replayed state (velocity_env_cfg.py:219-223): fell_over = tilt beyond 70 degrees
       # (envs/mdp/terminations.py bad_orientation: acos(-projected_gravity_z) > limit), time_out = episode length
       g = derive(sim).gravity_b
@@ -222,7 +226,7 @@ def _replay(scene, make_sim, derive, atol, tag, state_tol):
   for name, (ok, tot, worst, okw) in stats.items():
     _MARGIN[(tag, scene, name + f" rows within 1x / {WORST:.0f}x bound, worst ratio")] = (ok / tot, okw / tot, worst)
     if tag != "cpu":  # (world, step) rows whose every element is within the term's bound
-      assert ok >= ROWS_1X * tot and okw >= ROWS_WORST * tot, (scene, name, ok, okw, tot, worst)
+      assert ok >= ROWS_1X * tot and okw >= (ROUGH["rows_worst"] if scene.endswith("rough") else ROWS_WORST) * tot, (scene, name, ok, okw, tot, worst)
   for f, errs in state_err.items():
     e = np.concatenate(errs)
     q = tuple(float(x) for x in (np.median(e), np.percentile(e, 90), np.percentile(e, 99)))
@@ -346,6 +350,10 @@ def test_hip_path_reproduces_the_reference_environment(scene):
   # like the kernel: oracle/Makefile): qpos median 6.5e-8 / p90 2.3e-7 / p99 1.0e-5 / max 2.8e-5; qvel 1.7e-6 / 4.7e-6 / 3.6e-4 /
   # 8.5e-4 -- north_star's 1e-5 on the state at the p99, on the driver's box, against the reference environment's own run.  (Recorded
   # over the LITERAL fp32 grid search the same replay showed qpos p90 1.2e-5, max 5e-3: that search's 1e-4 floor in qacc)
-  n = _replay(scene, _HipReplay, derive, ATOL_GPU, "gpu", {"qpos": (5e-7, 1e-6, 3e-5, 1e-4, 0.0), "qvel": (5e-6, 1.5e-5, 1e-3, 3e-3, 0.0)})
+  tol = {"qpos": (5e-7, 1e-6, 3e-5, 1e-4, 0.0), "qvel": (5e-6, 1.5e-5, 1e-3, 3e-3, 0.0)}
+  if scene.endswith("rough"):  # (see ROUGH above)
+    # measured r04_v27: qpos median 1.7e-8 / p90 4.3e-8 / p99 1.4e-7 / max 3.2e-4; qvel 6.4e-6 / 2.1e-5 / 7.3e-5, one world-step of 1280 at 0.74
+    tol = {"qpos": (1e-7, 2e-7, 1e-6, 1e-3, 0.0), "qvel": (2e-5, 6e-5, 3e-4, 3e-2, 0.003)}
+  n = _replay(scene, _HipReplay, derive, ATOL_GPU, "gpu", tol)
   meta, _ = load(scene)
   assert n == meta["num_steps"] * len(meta["obs_terms"]["critic"])

@@ -41,11 +41,14 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tools"))
 sys.path.insert(0, str(ROOT / "tests"))
 
-TASKS = {"g1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-G1", "g1_tracking_flat": "Mjlab-Tracking-Flat-Unitree-G1"}
+TASKS = {"g1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-G1", "g1_tracking_flat": "Mjlab-Tracking-Flat-Unitree-G1",
+         # beyond north_star's two: the rough variant -- the terrain the reference's own generator builds (10 x 20 sub-terrains of box
+         # stairs, 3632 geoms) under the seed mjlab_amd.robots uses for its scene of the same name, and the terrain curriculum
+         "g1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-G1"}
 NUM_ENVS, SEED = 16, 42
 # control steps: the tracking task resets within the first step (below); the velocity task needs ~50 steps of random actions before
 # robots fall (fell_over) and the first interval pushes (every U(1, 3) s = 50..150 steps) fire
-NUM_STEPS = {"g1_velocity_flat": 80, "g1_tracking_flat": 20}
+NUM_STEPS = {"g1_velocity_flat": 80, "g1_tracking_flat": 20, "g1_velocity_rough": 80}
 DR_FIELDS = ("geom_friction", "body_ipos", "qpos0")
 
 
@@ -63,6 +66,10 @@ def record(scene: str, num_envs: int = NUM_ENVS, num_steps: int | None = None, s
   def edit(cfg):
     for group in ("policy", "critic"):
       getattr(cfg.observations, group).enable_corruption = False  # observation noise off: the terms themselves are compared
+    if scene == "g1_velocity_rough":
+      from mjlab_amd import robots
+
+      cfg.scene.terrain.terrain_generator.seed = robots.ROUGH_TERRAIN_SEED
     if scene == "g1_tracking_flat":
       from _motion_fixture import write_full_motion
 
@@ -72,6 +79,12 @@ def record(scene: str, num_envs: int = NUM_ENVS, num_steps: int | None = None, s
   env = reference_env.make_env(task, num_envs=num_envs, device="cpu", sim_cls=OracleSimulation, seed=seed, cfg_edit=edit)
   sim, robot = env.sim, env.scene["robot"]
   d = sim.data
+  if scene == "g1_velocity_rough":  # the consumer rebuilds the model with mjlab_amd.robots.load_model(scene): it must be this one
+    from mjlab_amd import robots
+
+    own = robots.load_model(scene)
+    for f in ("geom_pos", "geom_size", "geom_quat", "geom_type", "geom_bodyid", "geom_friction", "geom_priority", "body_pos", "body_mass"):
+      assert np.array_equal(np.asarray(getattr(env.sim.mj_model, f)), np.asarray(getattr(own, f))), f
   snap = lambda *names: {n: getattr(d, n).detach().clone().numpy() for n in names}  # noqa: E731
   steps: list[dict] = []
   cur: dict = {}
@@ -108,8 +121,11 @@ def record(scene: str, num_envs: int = NUM_ENVS, num_steps: int | None = None, s
                forward_ran=np.array(sim.forward_calls - fwd0))
     for g, o in obs.items():
       cur["obs_" + g] = o.clone().numpy()
-    if scene == "g1_velocity_flat":
+    if scene.startswith("g1_velocity"):
       cur["command"] = env.command_manager.get_command("twist").clone().numpy()
+      if scene == "g1_velocity_rough":
+        cur["terrain_levels"] = env.scene.terrain.terrain_levels.clone().numpy()
+        cur["env_origins_step"] = env.scene.env_origins.clone().numpy()
     else:
       cmd = env.command_manager.get_term("motion")
       cur.update(command=cmd.command.clone().numpy(), time_steps=cmd.time_steps.clone().numpy(), anchor_pos_w=cmd.anchor_pos_w.clone().numpy(),
