@@ -473,7 +473,8 @@ def main() -> None:
     # (tools/reference_env.py: MJLAB_REFERENCE_SRC / gpurun_ref staged by tools/stage_reference.sh); the driver's box has none.
     full_env, full_env_note, full_env_graphed, full_env_graphed_note = None, None, None, None
     task = {"g1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-G1", "go1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-Go1",
-            "g1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-G1", "go1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-Go1"}.get(args.scene)
+            "g1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-G1", "go1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-Go1",
+            "g1_tracking_flat": "Mjlab-Tracking-Flat-Unitree-G1"}.get(args.scene)
     if not args.no_full_env and info.world_size == 1 and task is not None:
       sys.path.insert(0, str(ROOT / "tools"))
       import reference_env
@@ -482,7 +483,20 @@ def main() -> None:
         full_env_note = "not measured: the reference's source is not on this machine (tools/stage_reference.sh stages it for one gpurun call)"
       else:
         try:
-          env = reference_env.make_env(task, num_envs=args.envs_per_gpu, device=dev, seed=args.seed)
+          cfg_edit = None
+          if tracking:  # the task needs a motion file (none ships with the reference): the synthetic 10 s motion of the physics line, every
+            # body's pose from this package's forward kinematics (mjlab_amd.rollout.write_motion_npz)
+            import tempfile
+
+            from mjlab_amd.rollout import write_motion_npz
+
+            motion_path = str(Path(tempfile.mkdtemp()) / "motion.npz")
+            write_motion_npz(motion_path, model, dev)
+
+            def cfg_edit(cfg, _p=motion_path):
+              cfg.commands.motion.motion_file = _p
+
+          env = reference_env.make_env(task, num_envs=args.envs_per_gpu, device=dev, seed=args.seed, cfg_edit=cfg_edit)
           na = sum(env.action_manager.action_term_dim)
           gen = torch.Generator(device=dev)
           gen.manual_seed(args.seed)

@@ -286,6 +286,35 @@ typedef struct mjlab_velocity_command {
 int mjlab_command_uniform_velocity(const mjlab_velocity_command_t* c, void* stream);
 int mjlab_sizeof_velocity_command(void);
 
+/* MotionCommand of the tracking task (tasks/tracking/mdp/commands.py:68-392) -- the two parts of it that are per-world arithmetic;
+ * the adaptive phase sampler (:255-297: statistics over all environments) stays with the caller.  The motion tables are the tensors
+ * MotionLoader holds (:28-65), whole (all bodies of the file; body_indexes picks the tracked ones, the first of which is the
+ * floating base). */
+typedef struct mjlab_motion_tables {
+  const float* joint_pos;      /* (nframe, nj) */
+  const float* joint_vel;      /* (nframe, nj) */
+  const float* body_pos_w;     /* (nframe, nbody_m, 3) */
+  const float* body_quat_w;    /* (nframe, nbody_m, 4) w x y z */
+  const float* body_lin_vel_w; /* (nframe, nbody_m, 3) */
+  const float* body_ang_vel_w; /* (nframe, nbody_m, 3) */
+  const int* body_indexes;     /* (nb) tracked body -> index on the tables' body axis */
+  int nframe, nj, nbody_m, nb;
+} mjlab_motion_tables_t;
+/* _resample_command (:305-363) for the worlds of `mask`, at the phase time_steps[w] already drawn: root pose / velocity of the motion
+ * frame + U(pose_range) / U(velocity_range) (device (2, 6) each), joints + U(joint_lo, joint_hi) clipped to the soft limits, written to
+ * qpos / qvel.  U row (>= 12 + nj): 6 pose draws, 6 velocity draws, nj joint draws.  clear_state stays with the caller. */
+int mjlab_command_motion_write(const mjlab_motion_tables_t* tab, float* qpos, int nq, int q_adr, float* qvel, int nv, int v_adr,
+                               const int* joint_q_adr, const int* joint_v_adr, int nworld, const unsigned char* mask,
+                               const long long* time_steps, const float* env_origins, const float* soft_joint_pos_limits, int ld_lim,
+                               const float* U, int ldu, const float* pose_range, const float* velocity_range, float joint_lo,
+                               float joint_hi, void* stream);
+/* _update_command's body_pos_relative_w / body_quat_relative_w (:371-392) for every world and tracked body; xpos / xquat are mjData's
+ * (nworld, nbody, 3 / 4), anchor_body_id the anchor's body id there, anchor_index its place among the tracked bodies. */
+int mjlab_command_motion_relative(const mjlab_motion_tables_t* tab, int nworld, const long long* time_steps, const float* env_origins,
+                                  const float* xpos, const float* xquat, int nbody, int anchor_body_id, int anchor_index,
+                                  float* body_pos_relative_w, float* body_quat_relative_w, void* stream);
+int mjlab_sizeof_motion_tables(void);
+
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);
 

@@ -186,4 +186,99 @@ __global__ __launch_bounds__(256) void k_command_uniform_velocity(const mjlab_ve
   }
 }
 
+// math.py:623-642: vec + w * t + xyz x t, t = 2 (xyz x vec)
+namespace env_terms {
+__device__ __forceinline__ void quat_apply(float* o, const Quat q, const float* v) {
+#pragma clang fp contract(off)
+  const float xyz[3] = {q.x, q.y, q.z};
+  float t[3], c[3];
+  cross3(t, xyz, v);
+  for (int k = 0; k < 3; ++k) t[k] = t[k] * 2.f;
+  cross3(c, xyz, t);
+  for (int k = 0; k < 3; ++k) o[k] = (v[k] + q.w * t[k]) + c[k];
+}
+}  // namespace env_terms
+
+// MotionCommand._resample_command after the phase has been drawn (tasks/tracking/mdp/commands.py:305-363): the motion frame of the
+// world's time step plus the cfg's noise, written to the floating base and the joints.  U row: [.. 3 unused by this kernel (time_left,
+// bin, within-bin) .., 6 pose, 6 velocity, nj joint draws] -- the caller passes the row pointer at the pose draws.
+__global__ __launch_bounds__(256) void k_command_motion_write(const mjlab_motion_tables_t tab, float* qpos, const int nq, const int q_adr, float* qvel,
+                                                              const int nv, const int v_adr, const int* joint_q_adr, const int* joint_v_adr,
+                                                              const int nworld, const unsigned char* mask, const long long* time_steps,
+                                                              const float* org, const float* lim, const int ld_lim, const float* U, const int ldu,
+                                                              const float* pose, const float* vel, const float joint_lo, const float joint_hi) {
+#pragma clang fp contract(off)
+  using namespace env_terms;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= nworld || !mask[w]) return;
+  const long long t = time_steps[w];
+  const size_t fb = (size_t)t * tab.nbody_m + tab.body_indexes[0];  // the first tracked body = the floating base
+  const float* u = U + (size_t)w * ldu;
+  float rs[6], vs[6];
+  for (int k = 0; k < 6; ++k) {
+    rs[k] = uniform(u[k], pose[k], pose[6 + k]);
+    vs[k] = uniform(u[6 + k], vel[k], vel[6 + k]);
+  }
+  float* qp = qpos + (size_t)w * nq;
+  float* qv = qvel + (size_t)w * nv;
+  for (int k = 0; k < 3; ++k) qp[q_adr + k] = (tab.body_pos_w[3 * fb + k] + org[3 * w + k]) + rs[k];
+  const float* bq = tab.body_quat_w + 4 * fb;
+  const Quat q = quat_mul(quat_from_euler_xyz(rs[3], rs[4], rs[5]), Quat{bq[0], bq[1], bq[2], bq[3]});
+  qp[q_adr + 3] = q.w, qp[q_adr + 4] = q.x, qp[q_adr + 5] = q.y, qp[q_adr + 6] = q.z;
+  float ang_w[3], ang[3];
+  for (int k = 0; k < 3; ++k) {
+    qv[v_adr + k] = tab.body_lin_vel_w[3 * fb + k] + vs[k];
+    ang_w[k] = tab.body_ang_vel_w[3 * fb + k] + vs[3 + k];
+  }
+  quat_apply_inverse(ang, q, ang_w);
+  for (int k = 0; k < 3; ++k) qv[v_adr + 3 + k] = ang[k];
+  const float* l = lim + (size_t)w * ld_lim;
+  for (int j = 0; j < tab.nj; ++j) {
+    float p = tab.joint_pos[(size_t)t * tab.nj + j] + uniform(u[12 + j], joint_lo, joint_hi);
+    p = fminf(fmaxf(p, l[2 * j]), l[2 * j + 1]);
+    qp[joint_q_adr[j]] = p;
+    qv[joint_v_adr[j]] = tab.joint_vel[(size_t)t * tab.nj + j];
+  }
+}
+
+// MotionCommand._update_command's relative body poses (commands.py:371-392): the motion's bodies moved to the robot's anchor in x, y and
+// yaw.  One thread per (world, tracked body).
+__global__ __launch_bounds__(256) void k_command_motion_relative(const mjlab_motion_tables_t tab, const int nworld, const long long* time_steps,
+                                                                 const float* org, const float* xpos, const float* xquat, const int nbody,
+                                                                 const int anchor_body_id, const int anchor_index, float* out_pos, float* out_quat) {
+#pragma clang fp contract(off)
+  using namespace env_terms;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int w = i / tab.nb, b = i - w * tab.nb;
+  if (w >= nworld) return;
+  const long long t = time_steps[w];
+  const size_t fa = (size_t)t * tab.nbody_m + tab.body_indexes[anchor_index], fb = (size_t)t * tab.nbody_m + tab.body_indexes[b];
+  float apos[3], bpos[3];
+  for (int k = 0; k < 3; ++k) {
+    apos[k] = tab.body_pos_w[3 * fa + k] + org[3 * w + k];
+    bpos[k] = tab.body_pos_w[3 * fb + k] + org[3 * w + k];
+  }
+  const float* aq = tab.body_quat_w + 4 * fa;
+  const float* rp = xpos + ((size_t)w * nbody + anchor_body_id) * 3;
+  const float* rq = xquat + ((size_t)w * nbody + anchor_body_id) * 4;
+  // quat_inv (math.py:255-266): conjugate / clamp(sum of squares, 1e-9)
+  const float n2 = fmaxf(((aq[0] * aq[0] + aq[1] * aq[1]) + aq[2] * aq[2]) + aq[3] * aq[3], 1e-9f);
+  const Quat inv{aq[0] / n2, -aq[1] / n2, -aq[2] / n2, -aq[3] / n2};
+  const Quat d = quat_mul(Quat{rq[0], rq[1], rq[2], rq[3]}, inv);
+  // yaw_quat (math.py:560-582)
+  const float yaw = atan2f(2.f * (d.w * d.z + d.x * d.y), 1.f - 2.f * (d.y * d.y + d.z * d.z));
+  float cw = cosf(yaw / 2.f), sz = sinf(yaw / 2.f);
+  const float nrm = fmaxf(sqrtf(((cw * cw + 0.f) + 0.f) + sz * sz), 1e-9f);
+  const Quat dq{cw / nrm, 0.f / nrm, 0.f / nrm, sz / nrm};
+  const float* bq = tab.body_quat_w + 4 * fb;
+  const Quat oq = quat_mul(dq, Quat{bq[0], bq[1], bq[2], bq[3]});
+  float* oQ = out_quat + ((size_t)w * tab.nb + b) * 4;
+  oQ[0] = oq.w, oQ[1] = oq.x, oQ[2] = oq.y, oQ[3] = oq.z;
+  float rel[3], rot[3];
+  for (int k = 0; k < 3; ++k) rel[k] = bpos[k] - apos[k];
+  quat_apply(rot, dq, rel);
+  float* oP = out_pos + ((size_t)w * tab.nb + b) * 3;
+  oP[0] = rp[0] + rot[0], oP[1] = rp[1] + rot[1], oP[2] = apos[2] + rot[2];
+}
+
 #endif  // MJLAB_MAIN_TU

@@ -232,6 +232,38 @@ int mjlab_command_uniform_velocity(const mjlab_velocity_command_t* c, void* stre
   return launched("k_command_uniform_velocity launch failed");
 }
 
+static int check_tables(const mjlab_motion_tables_t* t, const char* who) {
+  if (!t || !t->joint_pos || !t->joint_vel || !t->body_pos_w || !t->body_quat_w || !t->body_lin_vel_w || !t->body_ang_vel_w || !t->body_indexes) return fail(-22, who);
+  if (t->nframe < 1 || t->nj < 0 || t->nbody_m < 1 || t->nb < 1) return fail(-22, who);
+  return 0;
+}
+int mjlab_command_motion_write(const mjlab_motion_tables_t* tab, float* qpos, int nq, int q_adr, float* qvel, int nv, int v_adr, const int* joint_q_adr,
+                               const int* joint_v_adr, int nworld, const unsigned char* mask, const long long* time_steps, const float* env_origins,
+                               const float* soft_joint_pos_limits, int ld_lim, const float* U, int ldu, const float* pose_range, const float* velocity_range,
+                               float joint_lo, float joint_hi, void* stream) {
+  int rc = check_tables(tab, "command_motion_write: bad motion tables");
+  if (rc) return rc;
+  if (!qpos || !qvel || !joint_q_adr || !joint_v_adr || !mask || !time_steps || !env_origins || !soft_joint_pos_limits || !U || !pose_range || !velocity_range)
+    return fail(-22, "command_motion_write: null argument");
+  if (nworld < 1 || q_adr < 0 || q_adr + 7 > nq || v_adr < 0 || v_adr + 6 > nv || ldu < 12 + tab->nj) return fail(-22, "command_motion_write: bad sizes");
+  hipLaunchKernelGGL(k_command_motion_write, dim3((nworld + 255) / 256), dim3(256), 0, (hipStream_t)stream, *tab, qpos, nq, q_adr, qvel, nv, v_adr, joint_q_adr,
+                     joint_v_adr, nworld, mask, time_steps, env_origins, soft_joint_pos_limits, ld_lim, U, ldu, pose_range, velocity_range, joint_lo, joint_hi);
+  return launched("k_command_motion_write launch failed");
+}
+int mjlab_command_motion_relative(const mjlab_motion_tables_t* tab, int nworld, const long long* time_steps, const float* env_origins, const float* xpos,
+                                  const float* xquat, int nbody, int anchor_body_id, int anchor_index, float* body_pos_relative_w, float* body_quat_relative_w,
+                                  void* stream) {
+  int rc = check_tables(tab, "command_motion_relative: bad motion tables");
+  if (rc) return rc;
+  if (!time_steps || !env_origins || !xpos || !xquat || !body_pos_relative_w || !body_quat_relative_w) return fail(-22, "command_motion_relative: null argument");
+  if (nworld < 1 || anchor_body_id < 0 || anchor_body_id >= nbody || anchor_index < 0 || anchor_index >= tab->nb) return fail(-22, "command_motion_relative: bad sizes");
+  const long long total = (long long)nworld * tab->nb;
+  hipLaunchKernelGGL(k_command_motion_relative, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *tab, nworld, time_steps, env_origins, xpos,
+                     xquat, nbody, anchor_body_id, anchor_index, body_pos_relative_w, body_quat_relative_w);
+  return launched("k_command_motion_relative launch failed");
+}
+int mjlab_sizeof_motion_tables(void) { return (int)sizeof(mjlab_motion_tables_t); }
+
 int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, void* stream) {
   int rc = check_model(m);
   if (rc) return rc;

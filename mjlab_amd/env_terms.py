@@ -113,3 +113,46 @@ def command_uniform_velocity(term, mask: torch.Tensor | None, U: torch.Tensor, r
   c.rel_heading_envs, c.rel_standing_envs = cfg.rel_heading_envs, cfg.rel_standing_envs
   c.heading_control_stiffness = cfg.heading_control_stiffness
   native.check(native.lib().mjlab_command_uniform_velocity(ctypes.byref(c), _stream(U)), "mjlab_command_uniform_velocity")
+
+
+class MotionTables(ctypes.Structure):  # mjlab_motion_tables_t
+  _fields_ = [("joint_pos", _vp), ("joint_vel", _vp), ("body_pos_w", _vp), ("body_quat_w", _vp), ("body_lin_vel_w", _vp), ("body_ang_vel_w", _vp),
+              ("body_indexes", _vp), ("nframe", ctypes.c_int), ("nj", ctypes.c_int), ("nbody_m", ctypes.c_int), ("nb", ctypes.c_int)]  # fmt: skip
+
+
+def motion_tables(term) -> tuple:
+  """(MotionTables, keep-alive) for the reference's MotionCommand `term`: the whole tables its MotionLoader holds
+  (tasks/tracking/mdp/commands.py:28-50) and the tracked bodies' indices as int32."""
+  mo = term.motion
+  idx = mo._body_indexes.to(torch.int32).contiguous()
+  t = MotionTables()
+  t.joint_pos, t.joint_vel = _dense(mo.joint_pos, "joint_pos", torch.float32).data_ptr(), _dense(mo.joint_vel, "joint_vel", torch.float32).data_ptr()
+  t.body_pos_w = _dense(mo._body_pos_w, "body_pos_w", torch.float32).data_ptr()
+  t.body_quat_w = _dense(mo._body_quat_w, "body_quat_w", torch.float32).data_ptr()
+  t.body_lin_vel_w = _dense(mo._body_lin_vel_w, "body_lin_vel_w", torch.float32).data_ptr()
+  t.body_ang_vel_w = _dense(mo._body_ang_vel_w, "body_ang_vel_w", torch.float32).data_ptr()
+  t.body_indexes = idx.data_ptr()
+  t.nframe, t.nj, t.nbody_m, t.nb = mo.joint_pos.shape[0], mo.joint_pos.shape[1], mo._body_pos_w.shape[1], idx.numel()
+  return t, (idx,)
+
+
+def command_motion_write(tab: MotionTables, qpos: torch.Tensor, qvel: torch.Tensor, q_adr: int, v_adr: int, joint_q_adr: torch.Tensor, joint_v_adr: torch.Tensor,
+                         mask: torch.Tensor, time_steps: torch.Tensor, env_origins: torch.Tensor, soft_joint_pos_limits: torch.Tensor, U: torch.Tensor,
+                         pose_range: torch.Tensor, velocity_range: torch.Tensor, joint_range: tuple) -> None:
+  """MotionCommand._resample_command's state write for the worlds of `mask` (U: (nworld, >= 12 + nj): pose, velocity, joint draws)."""
+  native.check(native.lib().mjlab_command_motion_write(
+    ctypes.byref(tab), _dense(qpos, "qpos", torch.float32).data_ptr(), qpos.shape[1], q_adr, _dense(qvel, "qvel", torch.float32).data_ptr(), qvel.shape[1], v_adr,
+    _dense(joint_q_adr, "joint_q_adr", torch.int32).data_ptr(), _dense(joint_v_adr, "joint_v_adr", torch.int32).data_ptr(), qpos.shape[0],
+    _dense(mask, "mask", torch.bool).data_ptr(), _dense(time_steps, "time_steps", torch.long).data_ptr(), _dense(env_origins, "env_origins", torch.float32).data_ptr(),
+    _f32(soft_joint_pos_limits, "soft_joint_pos_limits").data_ptr(), _ld(soft_joint_pos_limits), _f32(U, "U").data_ptr(), U.stride(0),
+    _dense(pose_range, "pose_range", torch.float32).data_ptr(), _dense(velocity_range, "velocity_range", torch.float32).data_ptr(),
+    float(joint_range[0]), float(joint_range[1]), _stream(qpos)), "mjlab_command_motion_write")  # fmt: skip
+
+
+def command_motion_relative(tab: MotionTables, time_steps: torch.Tensor, env_origins: torch.Tensor, xpos: torch.Tensor, xquat: torch.Tensor, anchor_body_id: int,
+                            anchor_index: int, body_pos_relative_w: torch.Tensor, body_quat_relative_w: torch.Tensor) -> None:
+  native.check(native.lib().mjlab_command_motion_relative(
+    ctypes.byref(tab), xpos.shape[0], _dense(time_steps, "time_steps", torch.long).data_ptr(), _dense(env_origins, "env_origins", torch.float32).data_ptr(),
+    _dense(xpos, "xpos", torch.float32).data_ptr(), _dense(xquat, "xquat", torch.float32).data_ptr(), xpos.shape[1], anchor_body_id, anchor_index,
+    _dense(body_pos_relative_w, "body_pos_relative_w", torch.float32).data_ptr(), _dense(body_quat_relative_w, "body_quat_relative_w", torch.float32).data_ptr(),
+    _stream(xpos)), "mjlab_command_motion_relative")  # fmt: skip

@@ -172,8 +172,35 @@ class _CachedEntityData:
         del cache[name]
 
 
+def _cache_properties(obj: Any) -> Any:
+  """Gives `obj` a subclass of its own class (same name) whose read-only properties are evaluated once and handed out again until the
+  returned ``invalidate()`` is called.  For the tracking task's ``MotionCommand`` (reference tasks/tracking/mdp/commands.py:128-215:
+  ``body_pos_w``, ``anchor_quat_w``, ``robot_body_pos_w`` ... are properties that gather from the motion tables / ``EntityData`` at
+  EVERY access, and the task's rewards, terminations, metrics and observations read them ~200 times per step) and its
+  ``MotionLoader`` (:51-65: a gather of the whole motion per access).  The same tensors, fewer launches; readers do not write them."""
+  cls = type(obj)
+  cache: dict = {}
+  ns: dict = {}
+
+  def make(name: str, fget: Any) -> property:
+    def get(self: Any) -> Any:
+      if name not in cache:
+        cache[name] = fget(self)
+      return cache[name]
+
+    return property(get)
+
+  for name in dir(cls):
+    attr = getattr(cls, name, None)
+    if isinstance(attr, property) and attr.fset is None:
+      ns[name] = make(name, attr.fget)
+  obj.__class__ = type(cls.__name__, (cls,), ns)
+  return cache.clear
+
+
 class GraphedRlEnv:
-  def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None) -> None:
+  def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None,
+               fused_relative_poses: bool = False) -> None:
     from mjlab.third_party.isaaclab.isaaclab.utils import math as rmath  # the reference's own helpers (pure torch)
 
     self.env, self._m = env, rmath
@@ -181,9 +208,15 @@ class GraphedRlEnv:
     # the event / command terms as one HIP launch each (mjlab_amd/env_terms.py) wherever the environment lives on the GPU; the
     # torch restatements below compute the same from the same uniforms (CPU runs over the oracle; fused_terms=False: A/B on the GPU)
     self._fused = torch.device(self.device).type == "cuda" if fused_terms is None else bool(fused_terms)
+    # MotionCommand's relative body poses feed the rewards and observations of EVERY environment in every step; the HIP launch agrees
+    # with the reference's jit-fused chain to 1 ulp, not bit for bit (tests/test_gpu_reference_env.py), so it is opt-in: the default
+    # keeps "rewards and quiet observations bit for bit with the eager reference step"
+    self._fused_relative = bool(fused_relative_poses) and self._fused
     self.dt = float(env.step_dt)
     self._robot = env.scene["robot"]
     self._data_caches = []
+    self._term_caches: list = []  # invalidate() of the command terms whose properties are cached (dropped with the EntityData caches)
+    self._cache_entity_data = cache_entity_data
     if cache_entity_data:
       for ent in env.scene.entities.values():
         if not isinstance(ent._data, _CachedEntityData):
@@ -193,6 +226,9 @@ class GraphedRlEnv:
     self._check_supported()
     self._prepare_events()
     self._upload_index_lists()
+    self._obs_memo: dict = {}
+    self._obs_memo_on = False
+    self._share_observation_terms()
     self.graph: torch.cuda.CUDAGraph | None = None
     self._ep_len = env.episode_length_buf  # the tensor the captured kernels address (see step())
     env.sim.use_graph = False  # the launches are captured here, once, for the whole control step
@@ -267,11 +303,15 @@ class GraphedRlEnv:
       for k, stage in enumerate(cfg.params["velocity_stages"]):
         self._stage_ranges[(name, k)] = torch.tensor(stage["range"], dtype=torch.float32, device=dev)
     self._command_ranges = {}
+    self._motion_dev: dict = {}  # MotionCommand: (tables, keep-alive, joint q / v addresses as int32, the anchor's global body id)
     self._step_counter = torch.full((), int(self.env.common_step_counter), dtype=torch.long, device=dev)  # env.common_step_counter on the device
     for name in self.env.command_manager.active_terms:
       term = self.env.command_manager.get_term(name)
-      cols(("command", name, "reset"), 8)
-      cols(("command", name, "compute"), 8)
+      # UniformVelocityCommand: 8 draws per call; MotionCommand: [time_left, bin, within-bin, 6 pose, 6 velocity, nj joints], and a third
+      # call per step (the motions that ran out, in _update_command)
+      width = 8 if type(term).__name__ != "MotionCommand" else 15 + term.motion.joint_pos.shape[1]
+      for phase in ("reset", "compute") + (("update",) if type(term).__name__ == "MotionCommand" else ()):
+        cols(("command", name, phase), width)
       if type(term).__name__ == "UniformVelocityCommand":  # ranges as device tensors [lo, hi]: a curriculum may change them inside the graph
         rg = term.cfg.ranges
         table = torch.zeros((4, 2), dtype=torch.float32, device=dev)  # rows lin_vel_x, lin_vel_y, ang_vel_z, heading (the fused term reads it whole)
@@ -282,8 +322,16 @@ class GraphedRlEnv:
             views[key] = table[k]
         self._command_ranges[id(term)] = views
       if type(term).__name__ == "MotionCommand":
-        self._command_ranges[id(term)] = (_range_tensors(term.cfg.pose_range, dev), _range_tensors(term.cfg.velocity_range, dev))
+        self._command_ranges[id(term)] = (torch.stack(_range_tensors(term.cfg.pose_range, dev)), torch.stack(_range_tensors(term.cfg.velocity_range, dev)))
         self._patch_body_index_lists(term)
+        if self._fused:
+          rix = term.robot.indexing
+          self._motion_dev[id(term)] = (*env_terms.motion_tables(term), rix.joint_q_adr.to(torch.int32).contiguous(), rix.joint_v_adr.to(torch.int32).contiguous(),
+                                        int(rix.body_ids[term.robot_anchor_body_index]))
+        if self._cache_entity_data and not getattr(term, "_mjlab_amd_cached", False):
+          _cache_properties(term.motion)  # (the tables and body_indexes never change: kept for good)
+          self._term_caches.append(_cache_properties(term))
+          term._mjlab_amd_cached = True
     self._ncol = max(ncol, 1)
     self._U = torch.zeros((self.n, self._ncol), device=dev)
 
@@ -339,6 +387,51 @@ class GraphedRlEnv:
 
     for mgr in (env.reward_manager, env.termination_manager, env.observation_manager, env.command_manager, env.action_manager, env.event_manager):
       visit(mgr)
+
+  def _share_observation_terms(self) -> None:
+    """The reference computes every observation term once PER GROUP (managers/observation_manager.py:160-162) -- for the shipped tasks
+    the ``critic`` group repeats all of ``policy``'s terms -- and clones the result before it adds noise, clips or scales.  A term
+    function called again within one ``compute()`` with the same parameters returns the tensor of its first call: the same values,
+    half the launches (the tracking task's terms are ~250 launches per group).  Only plain functions whose parameters can be compared
+    by value take part; anything else is called as before."""
+    om = self.env.observation_manager
+    memo = self._obs_memo
+
+    def freeze(v: Any) -> Any:
+      if v is None or isinstance(v, (bool, int, float, str)):
+        return v
+      if isinstance(v, slice):
+        return ("slice", v.start, v.stop, v.step)
+      if isinstance(v, torch.Tensor):
+        return ("tensor", tuple(v.shape), tuple(v.reshape(-1).tolist())) if v.numel() <= 256 else ("tensor-id", id(v))
+      if isinstance(v, (list, tuple)):
+        return tuple(freeze(x) for x in v)
+      if isinstance(v, dict):
+        return tuple(sorted((k, freeze(x)) for k, x in v.items()))
+      if type(v).__name__ == "SceneEntityCfg":
+        return ("SceneEntityCfg",) + tuple(sorted((k, freeze(x)) for k, x in vars(v).items()))
+      raise TypeError(type(v))
+
+    for cfgs in om._group_obs_term_cfgs.values():
+      for cfg in cfgs:
+        func = cfg.func
+        if not callable(func) or not hasattr(func, "__name__") or hasattr(func, "_mjlab_amd_shared"):
+          continue
+        try:
+          key = (func.__module__, func.__name__, freeze(cfg.params))
+        except TypeError:
+          continue
+
+        def shared(env: Any, _func=func, _key=key, **params: Any) -> torch.Tensor:
+          if not self._obs_memo_on:  # outside the captured step (the eager env.reset(), a caller's own compute()): as the reference
+            return _func(env, **params)
+          if _key not in memo:
+            memo[_key] = _func(env, **params)
+          return memo[_key]
+
+        shared._mjlab_amd_shared = func
+        shared.__name__ = func.__name__
+        cfg.func = shared
 
   # ---------------------------------------------------------------------------------------------------------------- capture
   def capture(self, warmup: int = 2) -> None:
@@ -421,6 +514,12 @@ class GraphedRlEnv:
   def _invalidate(self, written: frozenset | None = None) -> None:
     for c in self._data_caches:
       c.invalidate(written)
+    for clear in self._term_caches:  # (a command term's properties read EntityData and its own time_steps: dropped at every boundary)
+      clear()
+
+  def _terms_changed(self) -> None:
+    for clear in self._term_caches:
+      clear()
 
   def _body(self) -> None:
     """reference envs/manager_based_rl_env.py:106-147, in its order.  The EntityData cache is dropped wherever mjData changes."""
@@ -449,7 +548,13 @@ class GraphedRlEnv:
     self._command_compute()
     self._interval_events()
     self._invalidate(_LATE_WRITES)  # (no forward() follows: xpos / xquat / cvel and what the terms derived from them still stand)
-    env.obs_buf = env.observation_manager.compute(update_history=True)
+    self._obs_memo.clear()
+    self._obs_memo_on = True
+    try:
+      env.obs_buf = env.observation_manager.compute(update_history=True)
+    finally:
+      self._obs_memo_on = False
+      self._obs_memo.clear()  # (nothing outlives the step)
     self._restore_bindings(before)
 
   # State the reference carries by REBINDING an attribute to a new tensor (``self.x = torch.where(...)``) would be lost between
@@ -673,7 +778,10 @@ class GraphedRlEnv:
         continue
       term.time_left -= self.dt
       self._command_resample(term, term.time_left <= 0.0, U)
-      getattr(self, "_update_" + type(term).__name__)(term)
+      if type(term).__name__ == "MotionCommand":
+        self._update_MotionCommand(term, self._Uof(("command", name, "update")))
+      else:
+        getattr(self, "_update_" + type(term).__name__)(term)
 
   # -- UniformVelocityCommand (tasks/velocity/mdp/velocity_command.py:64-102)
   def _resample_UniformVelocityCommand(self, term: Any, mask: torch.Tensor, U: torch.Tensor) -> None:
@@ -710,7 +818,7 @@ class GraphedRlEnv:
     v.masked_fill_(term.is_standing_env[:, None], 0.0)
 
   # -- MotionCommand (tasks/tracking/mdp/commands.py:255-392)
-  def _resample_MotionCommand(self, term: Any, mask: torch.Tensor, U: torch.Tensor | None = None) -> None:
+  def _resample_MotionCommand(self, term: Any, mask: torch.Tensor, U: torch.Tensor) -> None:
     """``_adaptive_sampling`` + ``_resample_command`` (:255-363).  The reference runs them only when the id list is non-empty; here
     the sampler's global state and metrics keep their values unless `mask` has an entry (``any`` on the device)."""
     rm, cfg, n, dev = self._m, term.cfg, self.n, self.device
@@ -718,6 +826,7 @@ class GraphedRlEnv:
     total = term.motion.time_step_total
     if cfg.disable_adaptive_sampling:
       term.time_steps.masked_fill_(mask, 0)
+      self._terms_changed()
     else:
       failed = self.env.termination_manager.terminated & mask
       bins = torch.clamp((term.time_steps * term.bin_count) // max(total, 1), 0, term.bin_count - 1)
@@ -728,25 +837,35 @@ class GraphedRlEnv:
       p = torch.nn.functional.conv1d(p, term.kernel.view(1, 1, -1)).view(-1)
       p = p / p.sum()
       # torch.multinomial(p, n, replacement=True) by inverse CDF (the same distribution, no host round trip)
-      sampled = torch.searchsorted(torch.cumsum(p, 0), torch.rand(n, device=dev)).clamp_(max=term.bin_count - 1)
-      t_new = ((sampled + torch.rand(n, device=dev)) / term.bin_count * (total - 1)).long()
+      sampled = torch.searchsorted(torch.cumsum(p, 0), U[:, 1].contiguous()).clamp_(max=term.bin_count - 1)
+      t_new = ((sampled + U[:, 2]) / term.bin_count * (total - 1)).long()
       term.time_steps.copy_(torch.where(mask, t_new, term.time_steps))
+      self._terms_changed()
       H = -(p * (p + 1e-12).log()).sum() / math.log(term.bin_count)
       pmax, imax = p.max(dim=0)
       for key, val in (("sampling_entropy", H), ("sampling_top1_prob", pmax), ("sampling_top1_bin", imax.float() / term.bin_count)):
         term.metrics[key].copy_(torch.where(anyone, val.expand(n), term.metrics[key]))
-    # the motion frame of every env + noise, written where `mask` is set (:299-363)
+    # the motion frame of every env + noise, written where `mask` is set (:299-363); U columns 3.. : 6 pose, 6 velocity, nj joint draws
+    pose, vel = self._command_ranges[id(term)]
+    if self._fused:
+      tab, _, qa32, va32, _ = self._motion_dev[id(term)]
+      d = term.robot.data.data
+      fq, fv = self._index_slices(term.robot)[3]
+      env_terms.command_motion_write(tab, d.qpos, d.qvel, fq, fv, qa32, va32, mask, term.time_steps, self.env.scene.env_origins,
+                                     term.robot.data.soft_joint_pos_limits, U[:, 3:], pose, vel, cfg.joint_position_range)
+      self._clear_state(term.robot, mask)
+      return
     m1 = mask[:, None]
-    (plo, phi), (vlo, vhi) = self._command_ranges[id(term)]
-    rs = rm.sample_uniform(plo, phi, (n, 6), device=dev)
+    rs = U[:, 3:9] * (pose[1] - pose[0]) + pose[0]
     root_pos = term.body_pos_w[:, 0] + rs[:, 0:3]
     root_ori = rm.quat_mul(rm.quat_from_euler_xyz(rs[:, 3], rs[:, 4], rs[:, 5]), term.body_quat_w[:, 0])
-    rs = rm.sample_uniform(vlo, vhi, (n, 6), device=dev)
+    rs = U[:, 9:15] * (vel[1] - vel[0]) + vel[0]
     root_lin_vel = term.body_lin_vel_w[:, 0] + rs[:, :3]
     root_ang_vel = term.body_ang_vel_w[:, 0] + rs[:, 3:]
     joint_pos = term.joint_pos.clone()
     joint_vel = term.joint_vel
-    joint_pos += rm.sample_uniform(cfg.joint_position_range[0], cfg.joint_position_range[1], joint_pos.shape, dev)
+    jlo, jhi = cfg.joint_position_range
+    joint_pos += U[:, 15:] * (jhi - jlo) + jlo
     lim = term.robot.data.soft_joint_pos_limits
     joint_pos = torch.clip(joint_pos, lim[:, :, 0], lim[:, :, 1])
     d, ix = term.robot.data.data, term.robot.indexing
@@ -756,11 +875,20 @@ class GraphedRlEnv:
     self._put(d.qvel, ix.free_joint_v_adr, m1, torch.cat([root_lin_vel, rm.quat_apply_inverse(root_ori, root_ang_vel)], dim=-1))
     self._clear_state(term.robot, mask)
 
-  def _update_MotionCommand(self, term: Any) -> None:
+  def _update_MotionCommand(self, term: Any, U: torch.Tensor) -> None:
     """``_update_command`` (:365-392)."""
     rm = self._m
     term.time_steps += 1
-    self._resample_MotionCommand(term, term.time_steps >= term.motion.time_step_total)
+    self._terms_changed()
+    self._resample_MotionCommand(term, term.time_steps >= term.motion.time_step_total, U)
+    if self._fused_relative:
+      tab, _, _, _, anchor_gid = self._motion_dev[id(term)]
+      d = term.robot.data.data
+      env_terms.command_motion_relative(tab, term.time_steps, self.env.scene.env_origins, d.xpos, d.xquat, anchor_gid, term.motion_anchor_body_index,
+                                        term.body_pos_relative_w, term.body_quat_relative_w)
+      term.bin_failed_count = term.cfg.adaptive_alpha * term._current_bin_failed + (1 - term.cfg.adaptive_alpha) * term.bin_failed_count
+      term._current_bin_failed.zero_()
+      return
     nb = len(term.cfg.body_names)
     anchor_pos = term.anchor_pos_w[:, None, :].repeat(1, nb, 1)
     anchor_quat = term.anchor_quat_w[:, None, :].repeat(1, nb, 1)

@@ -108,6 +108,8 @@ def lib() -> ctypes.CDLL:
   L.mjlab_event_reset_joints_by_scale.argtypes = [vp, ci, vp, ci, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp]
   L.mjlab_event_push_by_setting_velocity.argtypes = [vp, ci, ci, ci, vp, cf, vp, vp, ci, vp, ci, vp, ci, vp, vp]
   L.mjlab_command_uniform_velocity.argtypes = [vp, vp]
+  L.mjlab_command_motion_write.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, cf, cf, vp]
+  L.mjlab_command_motion_relative.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
   L.mjlab_control_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
   L.mjlab_forward_stages.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
   L.mjlab_tile_field.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -117,12 +119,13 @@ def lib() -> ctypes.CDLL:
     raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.mjlab_abi_version()}, this package speaks {ABI_VERSION}; rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
   # the two host structs and the control-step structs are mirrored by hand in ctypes (_abi.Option / _abi.Sizes, rollout._Control /
   # _MotionReset): a library built from other headers would be driven with shifted fields -- refuse it here instead
-  from .env_terms import VelocityCommand
+  from .env_terms import MotionTables, VelocityCommand
   from .rollout import _Control as Control, _MotionReset as MotionReset  # (imported here: rollout imports this module)
 
   for what, mine, theirs in (("mjlab_option_t", ctypes.sizeof(_abi.Option), L.mjlab_sizeof_option()), ("mjlab_sizes_t", ctypes.sizeof(_abi.Sizes), L.mjlab_sizeof_sizes()),
                              ("mjlab_control_t", ctypes.sizeof(Control), L.mjlab_sizeof_control()), ("mjlab_motion_reset_t", ctypes.sizeof(MotionReset), L.mjlab_sizeof_motion_reset()),
-                             ("mjlab_velocity_command_t", ctypes.sizeof(VelocityCommand), L.mjlab_sizeof_velocity_command())):
+                             ("mjlab_velocity_command_t", ctypes.sizeof(VelocityCommand), L.mjlab_sizeof_velocity_command()),
+                             ("mjlab_motion_tables_t", ctypes.sizeof(MotionTables), L.mjlab_sizeof_motion_tables())):
     if mine != theirs:
       raise NativeLibraryError(f"{LIB_PATH}: sizeof({what}) is {theirs} in the library, {mine} in the Python mirror; rebuild the library")
   _LIB = L
@@ -131,7 +134,7 @@ def lib() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = (
   "mjlab_abi_version", "mjlab_last_error", "mjlab_model_layout", "mjlab_data_layout", "mjlab_sizeof_model",
-  "mjlab_sizeof_data", "mjlab_sizeof_option", "mjlab_sizeof_sizes", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_sizeof_motion_reset", "mjlab_event_reset_root_state_uniform", "mjlab_event_reset_joints_by_scale", "mjlab_event_push_by_setting_velocity", "mjlab_command_uniform_velocity", "mjlab_sizeof_velocity_command", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest",
+  "mjlab_sizeof_data", "mjlab_sizeof_option", "mjlab_sizeof_sizes", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_sizeof_motion_reset", "mjlab_event_reset_root_state_uniform", "mjlab_event_reset_joints_by_scale", "mjlab_event_push_by_setting_velocity", "mjlab_command_uniform_velocity", "mjlab_sizeof_velocity_command", "mjlab_command_motion_write", "mjlab_command_motion_relative", "mjlab_sizeof_motion_tables", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest",
 )  # fmt: skip
 
 

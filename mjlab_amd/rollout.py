@@ -118,6 +118,34 @@ def synthetic_motion(model: Model, nframe: int = 500, fps: float = 50.0, amplitu
           "body_quat_w": quat.astype(np.float32), "body_lin_vel_w": z.astype(np.float32), "body_ang_vel_w": z.astype(np.float32), "fps": np.float32(fps)}
 
 
+def write_motion_npz(path: str, model: Model, device: str = "cuda:0", motion: dict | None = None) -> tuple:
+  """A complete ``motion.npz`` for the tracking task's ``MotionLoader`` (reference tasks/tracking/mdp/commands.py:30-65; keys and shapes
+  of scripts/csv_to_npz.py:298-309): the joint trajectory and root pose of `motion` (default: ``synthetic_motion``) with the pose and
+  velocity of EVERY robot body, from this package's forward kinematics -- one world per frame through ``Simulation.forward()`` (what
+  the reference's converter does with one ``mj_forward`` per frame).  Returns the shape of ``body_pos_w``."""
+  from .sim import Simulation, SimulationCfg
+
+  mo = synthetic_motion(model) if motion is None else motion
+  nframe = mo["joint_pos"].shape[0]
+  sim = Simulation(nframe, SimulationCfg(njmax=250, use_graph=False), model, device)
+  d = sim.data
+  dev = d.qpos.device
+  d.qpos[:, 0:3] = torch.from_numpy(mo["body_pos_w"][:, 0]).to(dev)
+  d.qpos[:, 3:7] = torch.from_numpy(mo["body_quat_w"][:, 0]).to(dev)
+  d.qpos[:, 7:] = torch.from_numpy(mo["joint_pos"]).to(dev)
+  d.qvel[:] = 0.0
+  d.qvel[:, 6:] = torch.from_numpy(mo["joint_vel"]).to(dev)
+  sim.forward()
+  root = int(model.jnt_bodyid[0])
+  pos, quat, cv = d.xpos[:, root:].double(), d.xquat[:, root:].double(), d.cvel[:, root:].double()  # the robot's bodies (world and terrain come first)
+  sub = d.subtree_com[:, root].double()[:, None, :]
+  lin = cv[..., 3:] - torch.cross(cv[..., :3], (sub - pos).expand_as(pos), dim=-1)  # body-origin velocity from the com-based spatial velocity (entity/data.py:20-31)
+  f32 = lambda t: t.float().cpu().numpy()  # noqa: E731
+  np.savez(path, fps=np.array([float(mo.get("fps", 50.0))]), joint_pos=mo["joint_pos"], joint_vel=mo["joint_vel"], body_pos_w=f32(pos), body_quat_w=f32(quat),
+           body_lin_vel_w=f32(lin), body_ang_vel_w=f32(cv[..., :3]))
+  return tuple(pos.shape)
+
+
 def _quat_from_euler_xyz(r: torch.Tensor, p: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
   """(w, x, y, z) of roll-pitch-yaw, the convention of the reference's quat_from_euler_xyz (isaaclab utils/math.py)."""
   cr, sr, cp, sp, cy, sy = torch.cos(r * 0.5), torch.sin(r * 0.5), torch.cos(p * 0.5), torch.sin(p * 0.5), torch.cos(y * 0.5), torch.sin(y * 0.5)

@@ -217,6 +217,55 @@ def run_fused_vs_torch(make_env, device: str, num_envs: int = 256, steps: int = 
   return stats
 
 
+def run_fused_vs_torch_tracking(make_env, device: str, num_envs: int = 128, steps: int = 40) -> dict:
+  """``run_fused_vs_torch`` for ``Mjlab-Tracking-Flat-Unitree-G1``: MotionCommand's state write and relative body poses as HIP launches
+  against their torch restatements, on the same uniforms, every environment compared."""
+
+  def edit(cfg):
+    cfg.events.push_robot.interval_range_s = (0.1, 0.4)
+
+  torch.manual_seed(0)
+  a = make_env(num_envs, device, edit)
+  b = make_env(num_envs, device, edit)
+  a.reset()
+  b.reset()
+  ga, gb = GraphedRlEnv(a, fused_terms=True, fused_relative_poses=True), GraphedRlEnv(b, fused_terms=False)
+  gen = torch.Generator(device=device)
+  gen.manual_seed(9)
+  ca, cb = a.command_manager.get_term("motion"), b.command_manager.get_term("motion")
+  for g in (ga, gb):
+    torch.manual_seed(999)
+    g.step(torch.zeros((num_envs, 29), device=device))  # (MotionCommand._update_metrics creates two of its metric entries on its first call)
+  total = ca.motion.time_step_total
+  worst = {"obs": 0.0, "qpos": 0.0, "qvel": 0.0, "body_pos_relative_w": 0.0, "body_quat_relative_w": 0.0, "reward": 0.0}
+  stats = {"resets": 0, "ended": 0}
+  for k in range(steps):
+    _sync(a, b)
+    if k % 7 == 3:
+      ca.time_steps[: num_envs // 8] = total - 2
+      cb.time_steps[: num_envs // 8] = total - 2
+    action = (torch.rand((num_envs, 29), device=device, generator=gen) * 2 - 1) * 0.3
+    stats["ended"] += int(((ca.time_steps + 1) >= total).sum())
+    outs = []
+    for g in (ga, gb):
+      torch.manual_seed(1000 + k)
+      outs.append(g.step(action.clone()))
+    torch.cuda.synchronize()
+    (obs_a, rew_a, term_a, to_a, _), (obs_b, rew_b, term_b, to_b, _) = outs
+    assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b), k
+    assert torch.equal(ca.time_steps, cb.time_steps) and torch.equal(ca.bin_failed_count, cb.bin_failed_count), k
+    worst["reward"] = max(worst["reward"], float((rew_a - rew_b).abs().max()))
+    for grp in obs_a:
+      worst["obs"] = max(worst["obs"], float((obs_a[grp] - obs_b[grp]).abs().max()))
+    for f in ("qpos", "qvel"):
+      worst[f] = max(worst[f], float((getattr(a.sim.data, f) - getattr(b.sim.data, f)).abs().max()))
+    for f in ("body_pos_relative_w", "body_quat_relative_w"):
+      worst[f] = max(worst[f], float((getattr(ca, f) - getattr(cb, f)).abs().max()))
+    stats["resets"] += int((term_a | to_a).sum())
+  stats["worst"] = worst
+  return stats
+
+
 def run_tracking(make_env, device: str, num_envs: int = 32, steps: int = 40, capture: bool = True) -> dict:
   """The same teacher-forced comparison for ``Mjlab-Tracking-Flat-Unitree-G1`` (``MotionCommand``: resets to motion phases drawn by
   the adaptive sampler, resampling when a motion ends, the sampler's global failure statistics)."""

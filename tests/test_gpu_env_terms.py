@@ -259,3 +259,121 @@ def test_terms_refuse_what_they_cannot_address():
   with pytest.raises(RuntimeError, match="bad sizes"):
     env_terms.reset_root_state_uniform(qpos.to(dev), qvel.to(dev), 33, 0, mask.to(dev), torch.zeros((N, 13), device=dev), torch.zeros((N, 3), device=dev),
                                        torch.zeros((N, 12), device=dev), torch.zeros((2, 6), device=dev), torch.zeros((2, 6), device=dev))
+
+
+def test_motion_file_from_the_hip_forward_kinematics_equals_the_oracle(tmp_path):
+  """mjlab_amd.rollout.write_motion_npz (one world per frame through Simulation.forward) against the same file built from the CPU
+  oracle's kinematics (tests/_motion_fixture.py): keys, shapes, and every body's pose / velocity to fp32 rounding."""
+  import sys
+  from pathlib import Path
+
+  import numpy as np
+
+  sys.path.insert(0, str(Path(__file__).resolve().parent))
+  from _motion_fixture import write_full_motion
+
+  from mjlab_amd import robots
+  from mjlab_amd.rollout import write_motion_npz
+
+  model = robots.load_model("g1_tracking_flat")
+  shape = write_motion_npz(str(tmp_path / "hip.npz"), model, "cuda:0")
+  assert tuple(write_full_motion(str(tmp_path / "oracle.npz"))) == shape
+  a, b = np.load(tmp_path / "hip.npz"), np.load(tmp_path / "oracle.npz")
+  assert sorted(a.files) == sorted(b.files)
+  for k in a.files:
+    assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, k
+    assert np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() <= 5e-6, (k, np.abs(a[k] - b[k]).max())
+
+
+# ---------------------------------------------------------------------------------------------------- MotionCommand (tracking task)
+def quat_apply(q, v):
+  xyz = q[..., 1:]
+  t = torch.cross(xyz, v, dim=-1) * 2
+  return v + q[..., 0:1] * t + torch.cross(xyz, t, dim=-1)
+
+
+def _motion_term(g, dev, nframe=40, nbody_m=9, nj=29):
+  """Synthetic motion tables shaped like the reference's MotionLoader holds them (tasks/tracking/mdp/commands.py:28-50)."""
+  idx = torch.tensor([0, 3, 4, 7, 8])  # tracked bodies on the tables' body axis; the first is the floating base
+  mo = types.SimpleNamespace(joint_pos=torch.randn((nframe, nj), generator=g).to(dev), joint_vel=torch.randn((nframe, nj), generator=g).to(dev),
+                             _body_pos_w=torch.randn((nframe, nbody_m, 3), generator=g).to(dev), _body_quat_w=_unit_quats(nframe * nbody_m, g).float().view(nframe, nbody_m, 4).to(dev),
+                             _body_lin_vel_w=torch.randn((nframe, nbody_m, 3), generator=g).to(dev), _body_ang_vel_w=torch.randn((nframe, nbody_m, 3), generator=g).to(dev),
+                             _body_indexes=idx.to(dev))
+  return types.SimpleNamespace(motion=mo), idx
+
+
+def test_command_motion_write():
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g, qpos, qvel, mask = _setup(7)
+  term, idx = _motion_term(g, dev)
+  mo, nj = term.motion, 29
+  tab, keep = env_terms.motion_tables(term)
+  ts = torch.randint(0, 40, (N,), generator=g)
+  org = torch.randn((N, 3), generator=g) * 3
+  lim = torch.stack([-0.8 - torch.rand(nj, generator=g), 0.8 + torch.rand(nj, generator=g)], -1)[None].expand(N, nj, 2)
+  U = torch.rand((N, 15 + nj), generator=g)
+  pose = torch.tensor([[-0.05, -0.05, -0.01, -0.1, -0.1, -0.2], [0.05, 0.05, 0.01, 0.1, 0.1, 0.2]])
+  vel = torch.tensor([[-0.5, -0.5, -0.2, -0.52, -0.52, -0.78], [0.5, 0.5, 0.2, 0.52, 0.52, 0.78]])
+  jr = (-0.1, 0.1)
+  qa, va = 7 + torch.arange(nj), 6 + torch.arange(nj)
+  dq, dv = qpos.to(dev), qvel.to(dev)
+  env_terms.command_motion_write(tab, dq, dv, 0, 0, qa.to(dev, torch.int32), va.to(dev, torch.int32), mask.to(dev), ts.to(dev), org.to(dev),
+                                 lim[:1].to(dev).expand(N, nj, 2), U.to(dev)[:, 3:], pose.to(dev), vel.to(dev), jr)
+  torch.cuda.synchronize()
+  # MotionCommand._resample_command (:305-363) in fp64 on the same inputs
+  u = U[:, 3:].double()
+  b0 = int(idx[0])
+  rs = u[:, :6] * (pose[1] - pose[0]).double() + pose[0].double()
+  root_pos = mo._body_pos_w.cpu().double()[ts, b0] + org.double() + rs[:, :3]
+  root_ori = quat_mul(quat_from_euler_xyz(rs[:, 3], rs[:, 4], rs[:, 5]), mo._body_quat_w.cpu().double()[ts, b0])
+  rv = u[:, 6:12] * (vel[1] - vel[0]).double() + vel[0].double()
+  lin = mo._body_lin_vel_w.cpu().double()[ts, b0] + rv[:, :3]
+  ang = quat_apply_inverse(root_ori, mo._body_ang_vel_w.cpu().double()[ts, b0] + rv[:, 3:])
+  jp = mo.joint_pos.cpu().double()[ts] + (u[:, 12:] * (jr[1] - jr[0]) + jr[0])
+  jp = torch.minimum(torch.maximum(jp, lim[..., 0].double()), lim[..., 1].double())
+  want_q, want_v = qpos.clone().double(), qvel.clone().double()
+  want_q[mask] = torch.cat([root_pos, root_ori, jp], -1)[mask]
+  want_v[mask] = torch.cat([lin, ang, mo.joint_vel.cpu().double()[ts]], -1)[mask]
+  got_q, got_v = dq.cpu(), dv.cpu()
+  assert torch.equal(got_q[~mask], qpos[~mask]) and torch.equal(got_v[~mask], qvel[~mask])
+  assert (got_q.double() - want_q).abs().max() <= 3 * TOL and (got_v.double() - want_v).abs().max() <= 3 * TOL
+  assert ((jp == lim[..., 0].double()) | (jp == lim[..., 1].double()))[mask].sum() > 0  # the soft limits acted somewhere
+  del keep
+
+
+def test_command_motion_relative():
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(8)
+  term, idx = _motion_term(g, dev)
+  mo, nb, nbody = term.motion, len(idx), 12
+  tab, keep = env_terms.motion_tables(term)
+  ts = torch.randint(0, 40, (N,), generator=g)
+  org = torch.randn((N, 3), generator=g) * 3
+  xpos = torch.randn((N, nbody, 3), generator=g)
+  xquat = _unit_quats(N * nbody, g).float().view(N, nbody, 4)
+  anchor_gid, anchor_index = 5, 2
+  out_p, out_q = torch.zeros((N, nb, 3), device=dev), torch.zeros((N, nb, 4), device=dev)
+  env_terms.command_motion_relative(tab, ts.to(dev), org.to(dev), xpos.to(dev), xquat.to(dev), anchor_gid, anchor_index, out_p, out_q)
+  torch.cuda.synchronize()
+  # MotionCommand._update_command (:371-392) in fp64
+  bp = mo._body_pos_w.cpu().double()[ts][:, idx] + org.double()[:, None, :]
+  bq = mo._body_quat_w.cpu().double()[ts][:, idx]
+  apos, aquat = bp[:, anchor_index], bq[:, anchor_index]
+  rp, rq = xpos.double()[:, anchor_gid], xquat.double()[:, anchor_gid]
+  inv = torch.cat([aquat[:, :1], -aquat[:, 1:]], -1) / aquat.pow(2).sum(-1, keepdim=True).clamp(min=1e-9)
+  d = quat_mul(rq, inv)
+  yaw = torch.atan2(2 * (d[:, 0] * d[:, 3] + d[:, 1] * d[:, 2]), 1 - 2 * (d[:, 2] ** 2 + d[:, 3] ** 2))
+  dq = torch.stack([torch.cos(yaw / 2), torch.zeros_like(yaw), torch.zeros_like(yaw), torch.sin(yaw / 2)], -1)
+  dq = dq / dq.norm(dim=-1, keepdim=True)
+  dqr = dq[:, None, :].expand(N, nb, 4)
+  want_q = quat_mul(dqr, bq)
+  delta = rp.clone()
+  delta[:, 2] = apos[:, 2]
+  want_p = delta[:, None, :] + quat_apply(dqr, bp - apos[:, None, :])
+  assert (out_q.cpu().double() - want_q).abs().max() <= TOL, (out_q.cpu().double() - want_q).abs().max()
+  assert (out_p.cpu().double() - want_p).abs().max() <= 5 * TOL, (out_p.cpu().double() - want_p).abs().max()
+  del keep

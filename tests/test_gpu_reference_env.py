@@ -229,3 +229,34 @@ def test_graphed_rough_env_with_its_terrain_curriculum(tmp_path):
   print("graphed rough G1 env vs reference env:", st)
   assert st["graph"] and st["resets"] >= 128 and st["pushes"] >= 128 and st["quiet_env_steps"] >= 2000 and st["level_moves"] >= 64 and st["level_draws"] >= 1
   assert st["eager_finite"] and st["overflow"] == {"nconmax": 0, "njmax": 0, "terrain_candidates": 0}, st
+
+
+_TRACKING_FUSED = """
+import json, sys
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env, _graphed_check
+from _motion_fixture import write_full_motion
+write_full_motion({motion!r})
+def make(n, device, edit):
+  def both(cfg):
+    cfg.commands.motion.motion_file = {motion!r}
+    edit(cfg)
+  return reference_env.make_env("Mjlab-Tracking-Flat-Unitree-G1", num_envs=n, device=device, seed=7, cfg_edit=both)
+print("RESULT " + json.dumps(_graphed_check.run_fused_vs_torch_tracking(make, "cuda:0", num_envs=128, steps=40)))
+"""
+
+
+def test_fused_motion_command_equals_its_torch_restatement(tmp_path):
+  """MotionCommand's state write and relative body poses as HIP launches (mjlab_amd/env_terms.py) inside the captured tracking step
+  against the torch restatements on the same uniforms: every environment, resets and ended motions included."""
+  import json
+  import subprocess
+
+  code = _TRACKING_FUSED.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"), motion=str(tmp_path / "motion.npz"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print("fused MotionCommand vs torch restatement:", st)
+  w = st["worst"]
+  assert st["resets"] >= 32 and st["ended"] >= 32
+  assert w["qpos"] <= 2e-6 and w["qvel"] <= 1e-5 and w["body_pos_relative_w"] <= 2e-6 and w["body_quat_relative_w"] <= 1e-6 and w["obs"] <= 1e-4 and w["reward"] <= 1e-5, w
