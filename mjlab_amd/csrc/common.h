@@ -481,6 +481,76 @@ struct CholRL {
   }
 };
 
+// MJLAB_CHOL_LOOKAHEAD: the same sweep with the dependence between consecutive columns cut down to its last term.  Column J + 1
+// needs Lu[J+1][0 .. J]; all but the last entry were final a whole column earlier, so their products (the bulk of the column) are
+// accumulated while column J's pivot chain (readlane, clamp, reciprocal, scale) is still in flight, from LDS reads issued before that
+// chain; the last entry, Lu[J+1][J] = t[J+1][J] / d[J], is formed as a wave-uniform value from a v_readlane of lane J+1's t and
+// the reciprocal -- no LDS write -> read round trip sits between two columns any more.  Products and sums are the ones of
+// CholSweep in the same order per partial sum (the last term of a column was the last subtraction of its chain there too), so the
+// factor is bit-identical.
+template <int NVP, int CB>
+struct CholSweepLA {
+  static constexpr int LD = CholCfg<NVP>::LD;
+  template <int R, int K0, int LIM>
+  static __device__ __forceinline__ void load_batch(lds_f32* A, float (&dst)[CB]) {
+#pragma unroll
+    for (int q = 0; q < CB / 4; ++q) {
+      if (K0 + 4 * q < LIM) {
+        const f32x4 v = *(lds_f32x4*)(A + R * LD + K0 + 4 * q);
+        dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+      }
+    }
+  }
+  // the products k < LIM of column C (row C of Lu against this lane's t), batch BI; `cur` holds batch BI, `nxt` receives batch BI + 1
+  template <int C, int LIM, int BI>
+  static __device__ __forceinline__ void bulk(const float (&a)[NVP], f32x2& acc, float (&cur)[CB], float (&nxt)[CB], lds_f32* A) {
+    constexpr int NBL = (LIM + CB - 1) / CB, K0 = BI * CB;
+    if constexpr (BI < NBL) {
+      if constexpr (BI + 1 < NBL) load_batch<C, K0 + CB, LIM>(A, nxt);
+#pragma unroll
+      for (int k = 0; k < CB; k += 2) {
+        if (K0 + k + 1 < LIM) {
+          const f32x2 av = {a[K0 + k], a[K0 + k + 1]};
+          const f32x2 sv = {cur[k], cur[k + 1]};
+          acc -= av * sv;
+        } else if (K0 + k < LIM) {
+          acc.x -= a[K0 + k] * cur[k];  // (LIM odd: the even-indexed product of the pair whose odd one is the column's last term)
+        }
+      }
+      CHOL_SCHED_BARRIER();
+      bulk<C, LIM, BI + 1>(a, acc, nxt, cur, A);
+    }
+  }
+  // column J: `acc` holds a[J] minus the products k < J - 1, `e` = Lu[J][J-1] (wave-uniform)
+  template <int J>
+  static __device__ __forceinline__ void col(float (&a)[NVP], f32x2 acc, const float e, float (&cur)[CB], float (&oth)[CB], lds_f32* A, lds_f32* row,
+                                             lds_f32* s_invd, int rowid) {
+    if constexpr (J >= 1) {
+      if constexpr ((J - 1) & 1) acc.y -= a[J - 1] * e;
+      else acc.x -= a[J - 1] * e;
+    }
+    const float t = acc.x + acc.y;
+    // next column's row, entries k < J (final since the end of column J - 1), requested ahead of the pivot chain
+    if constexpr (J + 1 < NVP && J >= 1) load_batch<J + 1, 0, J>(A, cur);
+    const float tj = lane_bcast(t, J);
+    float tn = 0.f;
+    if constexpr (J + 1 < NVP) tn = lane_bcast(t, J + 1);
+    const float djj = __builtin_amdgcn_fmed3f(tj, MINVAL, 3.0e38f);
+    const float invd = __builtin_amdgcn_rcpf(djj);
+    a[J] = t;
+    const float lu = rowid > J ? t * invd : 0.f;
+    row[J] = lu;
+    s_invd[J] = invd;
+    if constexpr (J + 1 < NVP) {
+      const float en = tn * invd;  // = lane J+1's lu
+      f32x2 accn = (f32x2){a[J + 1], 0.f};
+      CHOL_SCHED_BARRIER();
+      bulk<J + 1, J, 0>(a, accn, cur, oth, A);
+      col<J + 1>(a, accn, en, cur, oth, A, row, s_invd, rowid);
+    }
+  }
+};
+
 template <int NVP, bool FWD = false>
 __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int lane, float* fwd = nullptr) {
   constexpr int LD = CholCfg<NVP>::LD;
@@ -511,7 +581,11 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
   // row j+1 is requested before column j is written; its one missing entry Lu[j+1][j] is
   // patched in from lane j+1's register.
   float bufA[MJLAB_CB], bufB[MJLAB_CB];
+#ifdef MJLAB_CHOL_LOOKAHEAD
+  CholSweepLA<NVP, MJLAB_CB>::template col<0>(a, (f32x2){a[0], 0.f}, 0.f, bufA, bufB, A, row, s_invd, rowid);
+#else
   CholSweep<NVP, MJLAB_CB>::template col<0>(a, bufA, bufB, A, row, s_invd, rowid);
+#endif
 #endif
 }
 // Solves Lu D Lu^T x = b with the factor in LDS (as left by chol_factor); lane i owns
