@@ -72,7 +72,8 @@ KB(kb_lseval) {
 }
 KB(kb_lspar) {  // the whole parallel (grid) line search: 20 candidates priced in one trip over the rows
   SMEM; SolveCtx<N> c = make_ctx(a, smem);
-  a.out[threadIdx.x] = line_search_parallel<N, false>(c, c.quad_gauss[1], a.nact) + c.quad_gauss[0] + c.s_jar[threadIdx.x];
+  float bd = 0.f;
+  a.out[threadIdx.x] = line_search_parallel<N, false>(c, c.quad_gauss[1], a.nact, &bd) + bd + c.quad_gauss[0] + c.s_jar[threadIdx.x];
 }
 KB(kb_loadM) {
   SMEM; SolveCtx<N> c = make_ctx(a, smem);
