@@ -315,6 +315,13 @@ int mjlab_command_motion_relative(const mjlab_motion_tables_t* tab, int nworld, 
                                   float* body_pos_relative_w, float* body_quat_relative_w, void* stream);
 int mjlab_sizeof_motion_tables(void);
 
+/* RewardManager.compute's accumulation loop (managers/reward_manager.py:77-89) as one launch: `values` (k, nworld) holds the raw
+ * outputs of the k terms with non-zero weight, in term order; per world and term value = raw * weights[i] * dt,
+ * reward += value, episode_sums[i][w] += value, step_reward[w][columns[i]] = value / dt (step_reward is (nworld, nterm); the
+ * columns of zero-weight terms are the caller's).  weights / columns / episode_sums are device arrays of k entries. */
+int mjlab_reward_accumulate(const float* values, const float* weights, const int* columns, int k, int nworld, float dt, float* reward,
+                            float* const* episode_sums, float* step_reward, int nterm, void* stream);
+
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);
 

@@ -281,4 +281,24 @@ __global__ __launch_bounds__(256) void k_command_motion_relative(const mjlab_mot
   oP[0] = rp[0] + rot[0], oP[1] = rp[1] + rot[1], oP[2] = apos[2] + rot[2];
 }
 
+// RewardManager.compute's accumulation (managers/reward_manager.py:77-89) for the k active terms whose raw values are the rows of
+// `values` (k, n): value = raw * weight * dt; reward += value (in term order); episode_sum[term] += value; step_reward[:, column] =
+// value / dt (as torch computes it: value * (1 / dt)).  Elementwise IEEE operations in the reference's order: the same bits as its 6 launches per term.
+__global__ __launch_bounds__(256) void k_reward_accumulate(const float* values, const float* weights, const int* columns, const int k, const int n,
+                                                           const float dt, float* reward, float* const* episode_sums, float* step_reward,
+                                                           const int nterm) {
+#pragma clang fp contract(off)
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n) return;
+  float r = 0.f;
+  const float inv_dt = __fdiv_rn(1.f, dt);  // torch divides by a host scalar as a multiplication by its float32 reciprocal
+  for (int i = 0; i < k; ++i) {
+    const float v = (values[(size_t)i * n + w] * weights[i]) * dt;
+    r = r + v;
+    episode_sums[i][w] = episode_sums[i][w] + v;
+    step_reward[(size_t)w * nterm + columns[i]] = v * inv_dt;
+  }
+  reward[w] = r;
+}
+
 #endif  // MJLAB_MAIN_TU

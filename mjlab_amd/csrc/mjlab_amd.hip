@@ -263,6 +263,14 @@ int mjlab_command_motion_relative(const mjlab_motion_tables_t* tab, int nworld, 
   return launched("k_command_motion_relative launch failed");
 }
 int mjlab_sizeof_motion_tables(void) { return (int)sizeof(mjlab_motion_tables_t); }
+int mjlab_reward_accumulate(const float* values, const float* weights, const int* columns, int k, int nworld, float dt, float* reward,
+                            float* const* episode_sums, float* step_reward, int nterm, void* stream) {
+  if (!values || !weights || !columns || !reward || !episode_sums || !step_reward) return fail(-22, "reward_accumulate: null argument");
+  if (k < 1 || nworld < 1 || nterm < k) return fail(-22, "reward_accumulate: bad sizes");
+  hipLaunchKernelGGL(k_reward_accumulate, dim3((nworld + 255) / 256), dim3(256), 0, (hipStream_t)stream, values, weights, columns, k, nworld, dt, reward,
+                     episode_sums, step_reward, nterm);
+  return launched("k_reward_accumulate launch failed");
+}
 
 int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, void* stream) {
   int rc = check_model(m);

@@ -156,3 +156,34 @@ def command_motion_relative(tab: MotionTables, time_steps: torch.Tensor, env_ori
     _dense(xpos, "xpos", torch.float32).data_ptr(), _dense(xquat, "xquat", torch.float32).data_ptr(), xpos.shape[1], anchor_body_id, anchor_index,
     _dense(body_pos_relative_w, "body_pos_relative_w", torch.float32).data_ptr(), _dense(body_quat_relative_w, "body_quat_relative_w", torch.float32).data_ptr(),
     _stream(xpos)), "mjlab_command_motion_relative")  # fmt: skip
+
+
+class RewardAccumulator:
+  """RewardManager.compute's accumulation loop (reference managers/reward_manager.py:77-89) as one launch for a given reward
+  manager: the device tables (weights, step_reward columns, the episode-sum buffers' addresses) are built once."""
+
+  def __init__(self, manager) -> None:
+    self.manager = manager
+    self.active = [(i, name, cfg) for i, (name, cfg) in enumerate(zip(manager._term_names, manager._term_cfgs, strict=True)) if cfg.weight != 0.0]
+    self.idle = [i for i, cfg in enumerate(manager._term_cfgs) if cfg.weight == 0.0]
+    dev = manager._reward_buf.device
+    self.weights = torch.tensor([float(cfg.weight) for _, _, cfg in self.active], dtype=torch.float32, device=dev)
+    self.columns = torch.tensor([i for i, _, _ in self.active], dtype=torch.int32, device=dev)
+    self.sums = [_dense(manager._episode_sums[name], "episode_sums", torch.float32) for _, name, _ in self.active]
+    self.sum_ptrs = torch.tensor([t.data_ptr() for t in self.sums], dtype=torch.int64, device=dev)
+
+  def compute(self, dt: float) -> torch.Tensor:
+    m = self.manager
+    for i in self.idle:
+      m._step_reward[:, i] = 0.0
+    if not self.active:
+      m._reward_buf[:] = 0.0
+      return m._reward_buf
+    values = torch.stack([cfg.func(m._env, **cfg.params) for _, _, cfg in self.active], dim=0)  # (k, n): one launch for the k raw outputs
+    if any(m._episode_sums[name] is not t for (_, name, _), t in zip(self.active, self.sums, strict=True)):
+      raise RuntimeError("RewardAccumulator: an episode-sum buffer of the reward manager was replaced")
+    native.check(native.lib().mjlab_reward_accumulate(
+      _dense(values, "values", torch.float32).data_ptr(), self.weights.data_ptr(), self.columns.data_ptr(), len(self.active), values.shape[1], float(dt),
+      _dense(m._reward_buf, "reward_buf", torch.float32).data_ptr(), self.sum_ptrs.data_ptr(), _dense(m._step_reward, "step_reward", torch.float32).data_ptr(),
+      m._step_reward.shape[1], _stream(values)), "mjlab_reward_accumulate")  # fmt: skip
+    return m._reward_buf

@@ -226,6 +226,8 @@ class GraphedRlEnv:
     self._check_supported()
     self._prepare_events()
     self._upload_index_lists()
+    # RewardManager.compute's accumulation (6 launches per term) as one launch; the term functions are the reference's (GPU only)
+    self._reward = env_terms.RewardAccumulator(env.reward_manager) if self._fused else None
     self._obs_memo: dict = {}
     self._obs_memo_on = False
     self._share_observation_terms()
@@ -537,7 +539,7 @@ class GraphedRlEnv:
     env.reset_buf = env.termination_manager.compute()
     env.reset_terminated = env.termination_manager.terminated
     env.reset_time_outs = env.termination_manager.time_outs
-    env.reward_buf = env.reward_manager.compute(dt=self.dt)
+    env.reward_buf = self._reward.compute(self.dt) if self._reward is not None else env.reward_manager.compute(dt=self.dt)
     mask = env.reset_buf
     self._U = torch.rand((self.n, self._ncol), device=self.device)  # this step's uniforms for every mask-based term (one launch)
     self._masked_reset(mask)

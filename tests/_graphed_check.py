@@ -60,6 +60,14 @@ def _sync(a, b) -> None:
     tb.env_origins.copy_(ta.env_origins)
 
 
+def _same_reward_state(a, b, k) -> None:
+  """RewardManager's per-term bookkeeping (managers/reward_manager.py:84-88): episode sums and the per-step term values, bit for bit."""
+  ra, rb = a.reward_manager, b.reward_manager
+  assert torch.equal(ra._step_reward, rb._step_reward), (k, (ra._step_reward - rb._step_reward).abs().max())
+  for name in ra._episode_sums:
+    assert torch.equal(ra._episode_sums[name], rb._episode_sums[name]), (k, name)
+
+
 def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: bool = True, post_make=None) -> dict:
   torch.manual_seed(0)
   a = make_env(num_envs, device, _edit)
@@ -97,6 +105,7 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
       torch.cuda.synchronize()
     assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b), k
     assert torch.equal(rew_a, rew_b), (k, (rew_a - rew_b).abs().max())
+    _same_reward_state(a, b, k)
     reset = term_a | to_a
     if terr is not None:  # the terrain curriculum (terrain_levels_vel): the same moves; a random level only past the hardest row
       tb = b.scene.terrain
@@ -305,6 +314,7 @@ def run_tracking(make_env, device: str, num_envs: int = 32, steps: int = 40, cap
       torch.cuda.synchronize()
     assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b), k
     assert torch.equal(rew_a, rew_b), (k, (rew_a - rew_b).abs().max())
+    _same_reward_state(a, b, k)
     reset = term_a | to_a
     quiet = ~(reset | ended | push)
     for grp in obs_a:

@@ -377,3 +377,41 @@ def test_command_motion_relative():
   assert (out_q.cpu().double() - want_q).abs().max() <= TOL, (out_q.cpu().double() - want_q).abs().max()
   assert (out_p.cpu().double() - want_p).abs().max() <= 5 * TOL, (out_p.cpu().double() - want_p).abs().max()
   del keep
+
+
+def test_reward_accumulate_equals_the_managers_loop_bit_for_bit():
+  """mjlab_reward_accumulate against the reference loop's torch operations (managers/reward_manager.py:77-89) on the same raw term
+  values: reward, episode sums and per-step term values, bitwise."""
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(11)
+  names = ["a", "b", "zero", "c", "d"]
+  weights = [1.0, -0.1, 0.0, 2.5, -1.0e-3]
+  raws = [torch.randn(N, generator=g).to(dev) * s for s in (1.0, 30.0, 1.0, 1e-3, 500.0)]
+  dt = 0.02
+
+  def manager():
+    cfgs = [types.SimpleNamespace(weight=w, params={}, func=(lambda env, _r=r: _r)) for w, r in zip(weights, raws, strict=True)]
+    return types.SimpleNamespace(_term_names=list(names), _term_cfgs=cfgs, _env=None, _reward_buf=torch.full((N,), 7.0, device=dev),
+                                 _episode_sums={n: torch.randn(N, generator=g).to(dev) for n in names}, _step_reward=torch.full((N, len(names)), 3.0, device=dev))
+
+  m1, m2 = manager(), manager()
+  for n in names:
+    m2._episode_sums[n].copy_(m1._episode_sums[n])
+  out = env_terms.RewardAccumulator(m1).compute(dt)
+  # the reference's loop, operation by operation
+  m2._reward_buf[:] = 0.0
+  for i, (n, cfg) in enumerate(zip(m2._term_names, m2._term_cfgs, strict=True)):
+    if cfg.weight == 0.0:
+      m2._step_reward[:, i] = 0.0
+      continue
+    value = cfg.func(None) * cfg.weight * dt
+    m2._reward_buf += value
+    m2._episode_sums[n] += value
+    m2._step_reward[:, i] = value / dt
+  torch.cuda.synchronize()
+  assert out is m1._reward_buf and torch.equal(m1._reward_buf, m2._reward_buf)
+  assert torch.equal(m1._step_reward, m2._step_reward)
+  for n in names:
+    assert torch.equal(m1._episode_sums[n], m2._episode_sums[n]), n
