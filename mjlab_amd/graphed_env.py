@@ -8,9 +8,15 @@ a static buffer and replays the graph.  What the graph holds:
 
   reference code, captured as it is (pure torch, no host round trip):
     ``ActionManager.process_action`` / ``apply_action``        (reference envs/manager_based_rl_env.py:107-111)
-    ``TerminationManager.compute``, ``RewardManager.compute``   (:121-126; every term function of the task's cfg)
-    ``ObservationManager.compute``                              (:140; every term, noise model, concatenation)
-    ``CommandTerm._update_metrics``, every ``EntityData`` property the terms read
+    ``TerminationManager.compute``                              (:121-123)
+    EVERY TERM FUNCTION of the task's cfg: rewards, terminations, observations, ``CommandTerm._update_metrics``, and every
+    ``EntityData`` property they read
+  the two manager loops around those term functions, restated with the same arithmetic in fewer launches:
+    ``RewardManager.compute`` (managers/reward_manager.py:77-89): the raw term values stacked, then weight, dt, reward, episode
+      sums and per-step term values in ONE launch (``mjlab_reward_accumulate``: bit for bit, tests/test_gpu_env_terms.py; GPU only,
+      the reference's own loop elsewhere)
+    ``ObservationManager.compute`` (managers/observation_manager.py:144-188): a group = one concatenation of the raw term outputs (+
+      one noise block; ``_observation_compute``); groups with clip / scale / history / other noise models: the reference's own
   this package's physics:
     ``Simulation.step(decimation)`` -- one launch for the 4 substeps (the action is constant across them; bit-identical to
     the reference's 4 x [apply_action, sim.step()]), ``Simulation.forward(env_mask)``
@@ -334,6 +340,25 @@ class GraphedRlEnv:
           _cache_properties(term.motion)  # (the tables and body_indexes never change: kept for good)
           self._term_caches.append(_cache_properties(term))
           term._mjlab_amd_cached = True
+    # observation groups assembled in a handful of launches (see _observation_compute): per group the noise bounds of every column
+    self._obs_plan: dict = {}
+    om = self.env.observation_manager
+    for group, cfgs in om._group_obs_term_cfgs.items():
+      dims = om._group_obs_term_dim[group]
+      plain = om._group_obs_concatenate.get(group, False) and om._group_obs_concatenate_dim.get(group, -1) in (-1, 1) and all(len(d) == 1 for d in dims)
+      lo, hi = [], []
+      for cfg, d in zip(cfgs, dims, strict=True):
+        nz = cfg.noise
+        uniform_add = type(nz).__name__ == "UniformNoiseCfg" and nz.operation == "add" and isinstance(nz.n_min, (int, float)) and isinstance(nz.n_max, (int, float))
+        plain = plain and (nz is None or uniform_add) and not cfg.clip and cfg.scale is None and cfg.history_length == 0
+        lo += [float(nz.n_min) if uniform_add else 0.0] * int(d[0] if d else 0)
+        hi += [float(nz.n_max) if uniform_add else 0.0] * int(d[0] if d else 0)
+      if plain:
+        noisy = any(a != b for a, b in zip(lo, hi, strict=True))
+        if noisy:
+          cols(("obs", group), len(lo))
+        lo_t, hi_t = torch.tensor(lo, dtype=torch.float32, device=dev), torch.tensor(hi, dtype=torch.float32, device=dev)
+        self._obs_plan[group] = (noisy, hi_t - lo_t, lo_t)
     self._ncol = max(ncol, 1)
     self._U = torch.zeros((self.n, self._ncol), device=dev)
 
@@ -519,6 +544,27 @@ class GraphedRlEnv:
     for clear in self._term_caches:  # (a command term's properties read EntityData and its own time_steps: dropped at every boundary)
       clear()
 
+  def _observation_compute(self) -> dict:
+    """ObservationManager.compute (managers/observation_manager.py:144-188).  A group of plain terms -- 2-D outputs concatenated along
+    the last dimension, no clip / scale / history, noise none or ``UniformNoiseCfg(operation="add")`` with scalar bounds: every group of
+    the shipped tasks -- is assembled as ONE concatenation of the raw term outputs plus, if the group is corrupted, ONE noise block
+    ``U * (n_max - n_min) + n_min`` with per-column bounds from the step's uniforms (the reference: clone + rand_like + mul + add +
+    add per term, then the concatenation).  Without noise the values are the reference's bit for bit; with noise the same
+    distribution from different draws.  Any other group goes through the reference's own ``compute_group``."""
+    env = self.env
+    om = env.observation_manager
+    out: dict = {}
+    for group in om._group_obs_term_names:
+      plan = self._obs_plan.get(group)
+      if plan is None:
+        out[group] = om.compute_group(group, True)
+        continue
+      noisy, width, lo = plan
+      raw = torch.cat([cfg.func(env, **cfg.params) for cfg in om._group_obs_term_cfgs[group]], dim=-1)
+      out[group] = raw + (self._Uof(("obs", group)) * width + lo) if noisy else raw
+    om._obs_buffer = out
+    return out
+
   def _terms_changed(self) -> None:
     for clear in self._term_caches:
       clear()
@@ -553,7 +599,7 @@ class GraphedRlEnv:
     self._obs_memo.clear()
     self._obs_memo_on = True
     try:
-      env.obs_buf = env.observation_manager.compute(update_history=True)
+      env.obs_buf = self._observation_compute()
     finally:
       self._obs_memo_on = False
       self._obs_memo.clear()  # (nothing outlives the step)

@@ -177,9 +177,9 @@ def run_fused_vs_torch(make_env, device: str, num_envs: int = 256, steps: int = 
 
   def both(cfg):
     edit(cfg)
-    if noise:
-      for group in ("policy", "critic"):
-        getattr(cfg.observations, group).enable_corruption = True  # (the noise draws follow the block in the generator's stream)
+    if noise:  # the policy group corrupted as the task ships it, the critic group clean (tasks/velocity/velocity_env_cfg.py:118-126)
+      cfg.observations.policy.enable_corruption = True
+      cfg.observations.critic.enable_corruption = False
 
   torch.manual_seed(0)
   a = make_env(num_envs, device, both)
@@ -208,6 +208,22 @@ def run_fused_vs_torch(make_env, device: str, num_envs: int = 256, steps: int = 
     assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b) and torch.equal(rew_a, rew_b), k
     for grp in obs_a:
       worst["obs"] = max(worst["obs"], float((obs_a[grp] - obs_b[grp]).abs().max()))
+    if noise and "critic" in obs_a and obs_a["critic"].shape == obs_a["policy"].shape:
+      # the policy group is the critic group plus UniformNoiseCfg noise (tasks/velocity/velocity_env_cfg.py:88-116): inside its bounds,
+      # centred, and using the whole width of each term's interval
+      om = a.observation_manager
+      diff, c0 = obs_a["policy"] - obs_a["critic"], 0
+      for cfg, dim in zip(om._group_obs_term_cfgs["policy"], om._group_obs_term_dim["policy"], strict=True):
+        d = diff[:, c0 : c0 + dim[0]]
+        c0 += dim[0]
+        if cfg.noise is None:
+          assert float(d.abs().max()) == 0.0
+          continue
+        lo, hi = float(cfg.noise.n_min), float(cfg.noise.n_max)
+        tol = 1e-6 * max(1.0, float(obs_a["critic"].abs().max()))
+        assert float(d.min()) >= lo - tol and float(d.max()) <= hi + tol, (k, lo, hi, float(d.min()), float(d.max()))
+        assert float(d.max()) - float(d.min()) > 0.8 * (hi - lo) and abs(float(d.mean())) < 0.1 * (hi - lo), (k, lo, hi, float(d.mean()))
+      stats["noise_checks"] = stats.get("noise_checks", 0) + 1
     for f in ("qpos", "qvel"):
       worst[f] = max(worst[f], float((getattr(a.sim.data, f) - getattr(b.sim.data, f)).abs().max()))
     for name in a.command_manager.active_terms:
