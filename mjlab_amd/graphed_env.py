@@ -254,6 +254,9 @@ class GraphedRlEnv:
           or (mode == "interval" and fn in SUPPORTED_INTERVAL_EVENTS and not cfg.is_global_time)
         if not ok:
           raise NotImplementedError(f"event '{name}' ({mode}: {fn}) has no mask-based restatement in GraphedRlEnv")
+        asset = cfg.params.get("asset_cfg") if mode in ("reset", "interval") else None
+        if asset is not None and env.scene[asset.name] is not self._robot:
+          raise NotImplementedError(f"event '{name}' acts on entity '{asset.name}': the mask-based events address the entity 'robot' only")
     if any(ev._mode_class_term_cfgs.get(m) for m in ("reset", "interval")):
       raise NotImplementedError("class-based reset / interval event terms are not supported by GraphedRlEnv")
     for name in env.command_manager.active_terms:
