@@ -314,12 +314,19 @@ class GraphedRlEnv:
       for k, stage in enumerate(cfg.params["velocity_stages"]):
         self._stage_ranges[(name, k)] = torch.tensor(stage["range"], dtype=torch.float32, device=dev)
     self._command_ranges = {}
+    # a command whose resampling time exceeds the episode length (the tracking task: 1e9 s) never runs out between two resets: the
+    # timed resample of CommandTerm.compute is then a no-op for every environment and is not issued (checked on the timers as they
+    # stand: an environment that was never reset keeps the full path)
+    self._never_times_out: dict = {}
+    self._sampler_cache: dict = {}  # MotionCommand: the adaptive sampler's distribution, the same for every resample of one step
     self._motion_dev: dict = {}  # MotionCommand: (tables, keep-alive, joint q / v addresses as int32, the anchor's global body id)
     self._step_counter = torch.full((), int(self.env.common_step_counter), dtype=torch.long, device=dev)  # env.common_step_counter on the device
     for name in self.env.command_manager.active_terms:
       term = self.env.command_manager.get_term(name)
       # UniformVelocityCommand: 8 draws per call; MotionCommand: [time_left, bin, within-bin, 6 pose, 6 velocity, nj joints], and a third
       # call per step (the motions that ran out, in _update_command)
+      horizon = float(self.env.max_episode_length_s) + 2.0 * self.dt
+      self._never_times_out[id(term)] = float(term.cfg.resampling_time_range[0]) > horizon and bool((term.time_left > horizon).all())
       width = 8 if type(term).__name__ != "MotionCommand" else 15 + term.motion.joint_pos.shape[1]
       for phase in ("reset", "compute") + (("update",) if type(term).__name__ == "MotionCommand" else ()):
         cols(("command", name, phase), width)
@@ -599,6 +606,7 @@ class GraphedRlEnv:
     self._command_compute()
     self._interval_events()
     self._invalidate(_LATE_WRITES)  # (no forward() follows: xpos / xquat / cvel and what the terms derived from them still stand)
+    self._sampler_cache.clear()
     self._obs_memo.clear()
     self._obs_memo_on = True
     try:
@@ -828,7 +836,8 @@ class GraphedRlEnv:
         env_terms.command_uniform_velocity(term, None, U, self._command_ranges[id(term)]["table"], self.dt)
         continue
       term.time_left -= self.dt
-      self._command_resample(term, term.time_left <= 0.0, U)
+      if not self._never_times_out.get(id(term), False):
+        self._command_resample(term, term.time_left <= 0.0, U)
       if type(term).__name__ == "MotionCommand":
         self._update_MotionCommand(term, self._Uof(("command", name, "update")))
       else:
@@ -883,19 +892,22 @@ class GraphedRlEnv:
       bins = torch.clamp((term.time_steps * term.bin_count) // max(total, 1), 0, term.bin_count - 1)
       counts = torch.zeros(term.bin_count, device=dev).scatter_add_(0, bins, failed.to(torch.float32))  # (:258-265: bincount of the failed envs' bins)
       term._current_bin_failed.copy_(torch.where(failed.any(), counts, term._current_bin_failed))
-      p = term.bin_failed_count + cfg.adaptive_uniform_ratio / float(term.bin_count)
-      p = torch.nn.functional.pad(p.unsqueeze(0).unsqueeze(0), (0, cfg.adaptive_kernel_size - 1), mode="replicate")
-      p = torch.nn.functional.conv1d(p, term.kernel.view(1, 1, -1)).view(-1)
-      p = p / p.sum()
+      if id(term) not in self._sampler_cache:  # bin_failed_count changes once per step, after the last resample (_update_command's end)
+        p = term.bin_failed_count + cfg.adaptive_uniform_ratio / float(term.bin_count)
+        p = torch.nn.functional.pad(p.unsqueeze(0).unsqueeze(0), (0, cfg.adaptive_kernel_size - 1), mode="replicate")
+        p = torch.nn.functional.conv1d(p, term.kernel.view(1, 1, -1)).view(-1)
+        p = p / p.sum()
+        H = -(p * (p + 1e-12).log()).sum() / math.log(term.bin_count)
+        pmax, imax = p.max(dim=0)
+        self._sampler_cache[id(term)] = (torch.cumsum(p, 0), H.expand(n), pmax.expand(n), (imax.float() / term.bin_count).expand(n))
+      cdf, H, pmax, top = self._sampler_cache[id(term)]
       # torch.multinomial(p, n, replacement=True) by inverse CDF (the same distribution, no host round trip)
-      sampled = torch.searchsorted(torch.cumsum(p, 0), U[:, 1].contiguous()).clamp_(max=term.bin_count - 1)
+      sampled = torch.searchsorted(cdf, U[:, 1].contiguous()).clamp_(max=term.bin_count - 1)
       t_new = ((sampled + U[:, 2]) / term.bin_count * (total - 1)).long()
       term.time_steps.copy_(torch.where(mask, t_new, term.time_steps))
       self._terms_changed()
-      H = -(p * (p + 1e-12).log()).sum() / math.log(term.bin_count)
-      pmax, imax = p.max(dim=0)
-      for key, val in (("sampling_entropy", H), ("sampling_top1_prob", pmax), ("sampling_top1_bin", imax.float() / term.bin_count)):
-        term.metrics[key].copy_(torch.where(anyone, val.expand(n), term.metrics[key]))
+      for key, val in (("sampling_entropy", H), ("sampling_top1_prob", pmax), ("sampling_top1_bin", top)):
+        term.metrics[key].copy_(torch.where(anyone, val, term.metrics[key]))
     # the motion frame of every env + noise, written where `mask` is set (:299-363); U columns 3.. : 6 pose, 6 velocity, nj joint draws
     pose, vel = self._command_ranges[id(term)]
     if self._fused:
