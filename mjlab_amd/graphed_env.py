@@ -143,13 +143,18 @@ class _CachedEntityData:
     object.__setattr__(self, "_inner", inner)
     object.__setattr__(self, "_cache", {})
     object.__setattr__(self, "_props", {k: getattr(type(inner), k).fget for k in dir(type(inner)) if isinstance(getattr(type(inner), k, None), property)})
+    object.__setattr__(self, "_active", [False])  # caching happens inside GraphedRlEnv's step body only (activate()); outside: a plain pass-through
     if not isinstance(inner.data, _ReadRecorder):
       inner.data = _ReadRecorder(inner.data)
+
+  def activate(self, on: bool) -> None:
+    object.__getattribute__(self, "_active")[0] = bool(on)
+    object.__getattribute__(self, "_cache").clear()
 
   def __getattr__(self, name: str) -> Any:
     inner = object.__getattribute__(self, "_inner")
     getter = object.__getattribute__(self, "_props").get(name)
-    if getter is None:
+    if getter is None or not object.__getattribute__(self, "_active")[0]:
       return getattr(inner, name)
     cache = object.__getattribute__(self, "_cache")
     stack = inner.data.stack
@@ -178,7 +183,7 @@ class _CachedEntityData:
         del cache[name]
 
 
-def _cache_properties(obj: Any) -> Any:
+def _cache_properties(obj: Any, active: list | None = None) -> Any:
   """Gives `obj` a subclass of its own class (same name) whose read-only properties are evaluated once and handed out again until the
   returned ``invalidate()`` is called.  For the tracking task's ``MotionCommand`` (reference tasks/tracking/mdp/commands.py:128-215:
   ``body_pos_w``, ``anchor_quat_w``, ``robot_body_pos_w`` ... are properties that gather from the motion tables / ``EntityData`` at
@@ -187,9 +192,12 @@ def _cache_properties(obj: Any) -> Any:
   cls = type(obj)
   cache: dict = {}
   ns: dict = {}
+  active = [False] if active is None else active  # (a shared switch: the owner turns caching on for the duration of its step body)
 
   def make(name: str, fget: Any) -> property:
     def get(self: Any) -> Any:
+      if not active[0]:
+        return fget(self)
       if name not in cache:
         cache[name] = fget(self)
       return cache[name]
@@ -222,6 +230,7 @@ class GraphedRlEnv:
     self._robot = env.scene["robot"]
     self._data_caches = []
     self._term_caches: list = []  # invalidate() of the command terms whose properties are cached (dropped with the EntityData caches)
+    self._caching = [False]  # the property caches work inside _body() only: the eager env.reset() / a caller's own reads see the reference's objects
     self._cache_entity_data = cache_entity_data
     if cache_entity_data:
       for ent in env.scene.entities.values():
@@ -347,8 +356,8 @@ class GraphedRlEnv:
           self._motion_dev[id(term)] = (*env_terms.motion_tables(term), rix.joint_q_adr.to(torch.int32).contiguous(), rix.joint_v_adr.to(torch.int32).contiguous(),
                                         int(rix.body_ids[term.robot_anchor_body_index]))
         if self._cache_entity_data and not getattr(term, "_mjlab_amd_cached", False):
-          _cache_properties(term.motion)  # (the tables and body_indexes never change: kept for good)
-          self._term_caches.append(_cache_properties(term))
+          _cache_properties(term.motion, [True])  # (the tables and body_indexes never change: kept for good, inside and outside the step)
+          self._term_caches.append(_cache_properties(term, self._caching))
           term._mjlab_amd_cached = True
     # observation groups assembled in a handful of launches (see _observation_compute): per group the noise bounds of every column
     self._obs_plan: dict = {}
@@ -580,6 +589,21 @@ class GraphedRlEnv:
       clear()
 
   def _body(self) -> None:
+    """One control step with the property caches switched on for its duration (outside it -- the eager ``env.reset()``, a caller
+    reading ``robot.data`` -- the reference's objects behave as the reference's)."""
+    self._caching[0] = True
+    for c in self._data_caches:
+      c.activate(True)
+    try:
+      self._step_body()
+    finally:
+      self._caching[0] = False
+      for c in self._data_caches:
+        c.activate(False)
+      for clear in self._term_caches:
+        clear()
+
+  def _step_body(self) -> None:
     """reference envs/manager_based_rl_env.py:106-147, in its order.  The EntityData cache is dropped wherever mjData changes."""
     env = self.env
     before = self._snapshot_bindings()

@@ -45,6 +45,21 @@ def test_wrapper_surface_and_replaced_episode_length_buffer():
   env.episode_length_buf = torch.full((8,), 7, dtype=buf.dtype)  # what `wrapper.episode_length_buf = ...` does
   g.step(torch.zeros(8, 29))
   assert env.episode_length_buf is buf and bool((buf == 8).all())
+  # the property caches live inside the step body only: an eager reset() between steps (the reference's own code, reading
+  # robot.data.* through the cache's proxy) sees the state it has just written, not tensors of the last step
+  for _ in range(3):
+    g.step(torch.rand(8, 29) * 2 - 1)
+  robot = env.scene["robot"]
+  before = robot.data.root_link_pos_w.clone()
+  obs, _ = g.reset()
+  root = int(robot.indexing.root_body_id)
+  assert torch.equal(robot.data.root_link_pos_w, env.sim.data.xpos[:, root]) and not torch.equal(robot.data.root_link_pos_w, before)
+  fresh = env.observation_manager.compute()
+  for grp in obs:
+    if grp == "critic":  # (the policy group draws new noise at every call)
+      assert torch.equal(obs[grp], fresh[grp]), grp
+  jp = robot.data.joint_pos - robot.data.default_joint_pos
+  assert torch.equal(obs["critic"][:, 9 : 9 + 29], jp)  # base_lin_vel 3, base_ang_vel 3, projected_gravity 3, then joint_pos
 
 
 def test_unsupported_terms_are_refused_loudly():
