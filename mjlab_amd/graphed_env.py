@@ -214,7 +214,7 @@ def _cache_properties(obj: Any, active: list | None = None) -> Any:
 
 class GraphedRlEnv:
   def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None,
-               fused_relative_poses: bool = False) -> None:
+               fused_relative_poses: bool = False, forward: str = "reference") -> None:
     from mjlab.third_party.isaaclab.isaaclab.utils import math as rmath  # the reference's own helpers (pure torch)
 
     self.env, self._m = env, rmath
@@ -226,6 +226,13 @@ class GraphedRlEnv:
     # with the reference's jit-fused chain to 1 ulp, not bit for bit (tests/test_gpu_reference_env.py), so it is opt-in: the default
     # keeps "rewards and quiet observations bit for bit with the eager reference step"
     self._fused_relative = bool(fused_relative_poses) and self._fused
+    # forward="reference": sim.forward() on ALL worlds whenever some environment reset, as the reference does (:129-132) -- with 4096
+    # envs that is practically every step; "reset_worlds" (SURVEY 8f row 2): only the worlds that reset are recomputed, the others
+    # keep the derived quantities of their last physics step, as they do in the reference in a step without resets.  Opt-in: the
+    # observations of non-reset worlds then differ from the reference's in steps where somebody else reset.
+    if forward not in ("reference", "reset_worlds"):
+      raise ValueError(f"forward must be 'reference' or 'reset_worlds', not {forward!r}")
+    self._forward_all = forward == "reference"
     self.dt = float(env.step_dt)
     self._robot = env.scene["robot"]
     self._data_caches = []
@@ -625,7 +632,7 @@ class GraphedRlEnv:
     self._masked_reset(mask)
     self._invalidate()
     env.scene.write_data_to_sim()
-    env.sim.forward(env_mask=mask.any().expand(self.n))  # all worlds iff some environment reset (:129-132)
+    env.sim.forward(env_mask=mask.any().expand(self.n) if self._forward_all else mask)  # all worlds iff some environment reset (:129-132), or the reset worlds only
     self._invalidate()
     self._command_compute()
     self._interval_events()

@@ -76,14 +76,21 @@ class OracleSimulation:
     pass
 
   def forward(self, env_mask=None) -> None:
-    """``env_mask`` as in mjlab_amd.Simulation.forward (extension): here all-or-nothing, which is what its callers pass."""
+    """``env_mask`` as in mjlab_amd.Simulation.forward (extension): only the marked worlds are recomputed (the others keep every
+    array: the oracle forwards all worlds, the unmarked rows are put back)."""
+    keep = None
     if env_mask is not None:
       m = torch.as_tensor(env_mask).bool()
-      assert bool(m.all()) or not bool(m.any()), "the CPU stand-in recomputes all worlds or none"
       if not bool(m.any()):
         return
+      if not bool(m.all()):
+        rows = (~m).nonzero().flatten()
+        keep = [(t, rows, t[rows].clone()) for t in self._data.values() if t.dim() >= 1 and t.shape[0] == m.numel()]
     self.forward_calls += 1
     self.ora.forward(nthread=self.nthread)
+    if keep is not None:
+      for t, rows, old in keep:
+        t[rows] = old
 
   def step(self, nsubstep: int = 1) -> None:
     self.step_calls += nsubstep

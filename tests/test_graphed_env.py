@@ -166,3 +166,52 @@ def test_rough_task_with_its_terrain_curriculum():
   assert r.returncode == 0, r.stderr[-3000:]
   st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
   assert st["resets"] >= 16 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400 and st["level_moves"] >= 8 and st["level_draws"] >= 1, st
+
+
+def test_forward_on_the_reset_worlds_only_is_the_reference_on_those_worlds_and_the_last_step_on_the_others():
+  """``GraphedRlEnv(forward="reset_worlds")`` (opt-in): in a step where some environment resets, the worlds that reset
+  hold what the reference's all-worlds ``forward()`` gives them, the others what the physics step left (what the reference shows in a
+  step without resets); state, rewards and terminations are the reference's in every world."""
+  import torch
+  from _oracle_simulation import OracleSimulation
+
+  from mjlab_amd.graphed_env import GraphedRlEnv
+
+  def edit(cfg):
+    for group in ("policy", "critic"):
+      getattr(cfg.observations, group).enable_corruption = False
+    cfg.episode_length_s = 0.2  # time-outs after 10 control steps
+
+  def make():
+    env = reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=8, device="cpu", sim_cls=OracleSimulation, seed=5, cfg_edit=edit)
+    env.reset()
+    return env
+
+  torch.manual_seed(0)
+  a, b = make(), make()
+  ga, gb = GraphedRlEnv(a, capture=False), GraphedRlEnv(b, capture=False, forward="reset_worlds")
+  with pytest.raises(ValueError):
+    GraphedRlEnv(b, capture=False, forward="sometimes")
+  a.episode_length_buf[:4] = 5  # half of the environments time out five steps before the others
+  b.episode_length_buf[:4] = 5
+  seen = 0
+  import _graphed_check
+
+  for k in range(12):
+    _graphed_check._sync(a, b)  # (teacher forced: the reference's all-worlds forward() also refreshes qacc_warmstart of the worlds that did not reset)
+    act = torch.rand(8, 29) * 2 - 1
+    torch.manual_seed(100 + k)
+    oa, ra, ta, toa, _ = ga.step(act.clone())
+    torch.manual_seed(100 + k)
+    ob, rb, tb, tob, _ = gb.step(act.clone())
+    assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(toa, tob)
+    assert torch.equal(a.sim.data.qpos, b.sim.data.qpos) and torch.equal(a.sim.data.qvel, b.sim.data.qvel)
+    reset = ta | toa
+    if reset.any() and not reset.all():
+      seen += 1
+      assert torch.equal(a.sim.data.xpos[reset], b.sim.data.xpos[reset]) and torch.equal(oa["critic"][reset], ob["critic"][reset])
+      quiet = ~reset
+      assert not torch.equal(a.sim.data.xpos[quiet], b.sim.data.xpos[quiet])  # the reference moved them to the post-step pose
+    elif not reset.any():
+      assert torch.equal(a.sim.data.xpos, b.sim.data.xpos) and torch.equal(oa["critic"], ob["critic"])
+  assert seen >= 1
