@@ -415,3 +415,29 @@ def test_reward_accumulate_equals_the_managers_loop_bit_for_bit():
   assert torch.equal(m1._step_reward, m2._step_reward)
   for n in names:
     assert torch.equal(m1._episode_sums[n], m2._episode_sums[n]), n
+
+
+@pytest.mark.parametrize("fill", [False, True])
+def test_masks_that_select_nobody_or_everybody(fill):
+  """All-false mask: nothing is written; all-true mask: every row is written (reset events and the velocity command)."""
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g, qpos, qvel, _ = _setup(12)
+  mask = torch.full((N,), fill, dtype=torch.bool, device=dev)
+  dq, dv = qpos.to(dev), qvel.to(dev)
+  root = torch.cat([torch.zeros(1, 3), torch.tensor([[1.0, 0, 0, 0]]), torch.zeros(1, 6)], -1).to(dev).expand(N, 13)
+  U = torch.rand((N, 12 + 58), generator=g).to(dev)
+  env_terms.reset_root_state_uniform(dq, dv, 0, 0, mask, root, torch.zeros((N, 3), device=dev), U[:, :12],
+                                     torch.tensor([[-0.5] * 6, [0.5] * 6], device=dev), torch.tensor([[-0.1] * 6, [0.1] * 6], device=dev))
+  qa, va = (7 + torch.arange(29)).to(dev, torch.int32), (6 + torch.arange(29)).to(dev, torch.int32)
+  env_terms.reset_joints_by_scale(dq, dv, mask, None, qa, va, torch.ones((1, 29), device=dev).expand(N, 29), torch.ones((1, 29), device=dev).expand(N, 29),
+                                  torch.tensor([-10.0, 10.0], device=dev).repeat(29).view(1, 29, 2).expand(N, 29, 2), U[:, 12:], torch.tensor([0.5, 1.5, -1.0, 1.0], device=dev))
+  torch.cuda.synchronize()
+  if not fill:
+    assert torch.equal(dq.cpu(), qpos) and torch.equal(dv.cpu(), qvel)
+  else:
+    got = dq.cpu()
+    assert bool((got[:, 0:3].abs() <= 0.5).all()) and bool(((got[:, 3:7].norm(dim=1) - 1).abs() < 1e-5).all())
+    assert bool((got[:, 7:] >= 0.5).all()) and bool((got[:, 7:] <= 1.5).all()) and bool((dv.cpu()[:, 6:].abs() <= 1.0).all())
+    assert not torch.equal(got, qpos)
