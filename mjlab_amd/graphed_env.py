@@ -213,6 +213,15 @@ def _cache_properties(obj: Any, active: list | None = None) -> Any:
 
 
 class GraphedRlEnv:
+  """See the module docstring.  Options (all keep the wrapped environment object usable; outside ``step()`` it behaves as the reference's):
+
+    capture               False: the same step body runs eagerly (CPU runs over the oracle; debugging)
+    cache_entity_data     property caches for ``EntityData`` / command terms and shared observation terms inside the step body
+    fused_terms           None: HIP launches for the event / command / reward-accumulation terms on the GPU, torch restatements elsewhere
+    fused_relative_poses  opt-in (tracking): ``MotionCommand``'s relative body poses from one launch -- 1 ulp from the reference's chain
+    forward               "reference": ``sim.forward()`` on all worlds whenever some environment reset; "reset_worlds" (opt-in): only those
+  """
+
   def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None,
                fused_relative_poses: bool = False, forward: str = "reference") -> None:
     from mjlab.third_party.isaaclab.isaaclab.utils import math as rmath  # the reference's own helpers (pure torch)
