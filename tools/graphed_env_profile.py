@@ -1,5 +1,6 @@
 """Kernel census of one GraphedRlEnv control step (GPU box, reference staged): run under `rocprofv3 --kernel-trace --stats`.
-  python tools/graphed_env_profile.py [num_envs] [steps] [task]     (task: a registered task id; default the G1 velocity-flat task)"""
+  python tools/graphed_env_profile.py [num_envs] [steps] [task] [random]     (task: a registered task id; default the G1 velocity-flat
+  task; "random": a random policy instead of zero actions; many steps = a soak run: finiteness, overflow and memory are reported)"""
 import sys
 import tempfile
 import time
@@ -36,8 +37,16 @@ for _ in range(10):
   g.step(a)
 torch.cuda.synchronize()
 t = time.perf_counter()
+rnd = len(sys.argv) > 4 and sys.argv[4] == "random"
+gen = torch.Generator(device="cuda:0")
+gen.manual_seed(0)
 for _ in range(steps):
-  g.step(a)
+  g.step(2.0 * torch.rand(a.shape, device="cuda:0", generator=gen) - 1.0 if rnd else a)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / steps
+obs = g.step(a)[0]
+torch.cuda.synchronize()
+finite = all(bool(torch.isfinite(o).all()) for o in obs.values()) and bool(torch.isfinite(env.sim.data.qpos).all()) and bool(torch.isfinite(env.sim.data.qvel).all())
+print(f"SOAK {steps + 11} steps: observations and state finite: {finite}; episode length min / max {int(env.episode_length_buf.min())} / {int(env.episode_length_buf.max())}; "
+      f"overflow {env.sim.overflow_report()}; allocated {torch.cuda.memory_allocated() / 2**20:.0f} MiB")
 print(f"GRAPHED {task} {n} envs: {dt * 1e3:.3f} ms per step, {n / dt:.0f} env-steps/s, graph nodes replayed per step: see the kernel trace / {steps + 10 + 3} bodies")
