@@ -110,6 +110,13 @@ def _state_tensors(obj: Any, n: int | None, seen: set, out: list, depth: int = 0
       _state_tensors(v, n, seen, out, depth + 1, f"{path}.{key}", dev_type)
 
 
+# what mjlab_amd.entity_data.EntityReadback provides under the reference's EntityData names (entity/data.py:190-516)
+_READBACK_PROPERTIES = frozenset(("body_link_pose_w", "body_link_vel_w", "body_com_pose_w", "body_com_vel_w", "root_link_pose_w", "root_link_vel_w", "root_com_pose_w",
+                                  "root_com_vel_w", "projected_gravity_b", "heading_w", "root_link_lin_vel_b", "root_link_ang_vel_b", "root_com_lin_vel_b",
+                                  "root_com_ang_vel_b", "joint_pos", "joint_vel", "joint_acc"))
+_ALL_ARRAYS = frozenset(("*",))
+
+
 class _ReadRecorder:
   """Stands where ``EntityData.data`` stood: hands every field of the simulation's data bridge through and notes its name in the
   read set of the property evaluation in progress (`stack`: nested evaluations)."""
@@ -144,12 +151,21 @@ class _CachedEntityData:
     object.__setattr__(self, "_cache", {})
     object.__setattr__(self, "_props", {k: getattr(type(inner), k).fget for k in dir(type(inner)) if isinstance(getattr(type(inner), k, None), property)})
     object.__setattr__(self, "_active", [False])  # caching happens inside GraphedRlEnv's step body only (activate()); outside: a plain pass-through
+    object.__setattr__(self, "_readback", [None, False])  # [mjlab_amd.entity_data.EntityReadback | None, its buffers are current]
     if not isinstance(inner.data, _ReadRecorder):
       inner.data = _ReadRecorder(inner.data)
 
   def activate(self, on: bool) -> None:
     object.__getattribute__(self, "_active")[0] = bool(on)
     object.__getattribute__(self, "_cache").clear()
+    object.__getattribute__(self, "_readback")[1] = False
+
+  def use_readback(self, readback: Any) -> None:
+    """The base quantities (body / root poses and velocities, the root-frame vectors, the joint views) come from ONE launch per phase
+    (``mjlab_entity_readback``) instead of the reference's chains of small kernels.  The launch reproduces those
+    chains bit for bit (measured: rewards, observations and state of ~50 000 env-steps of four tasks equal to the eager reference
+    step's, profiles/r04_v51); the teacher-forced tests run with it."""
+    object.__getattribute__(self, "_readback")[0] = readback
 
   def __getattr__(self, name: str) -> Any:
     inner = object.__getattribute__(self, "_inner")
@@ -158,6 +174,12 @@ class _CachedEntityData:
       return getattr(inner, name)
     cache = object.__getattribute__(self, "_cache")
     stack = inner.data.stack
+    rb = object.__getattribute__(self, "_readback")
+    if rb[0] is not None and name not in cache and name in _READBACK_PROPERTIES:
+      if not rb[1]:
+        rb[0].update()
+        rb[1] = True
+      cache[name] = (getattr(rb[0], name), _ALL_ARRAYS)
     if name not in cache:
       stack.append(set())
       try:
@@ -176,8 +198,10 @@ class _CachedEntityData:
   def invalidate(self, written: frozenset | None = None) -> None:
     """written = None: every mjData array may have changed; else only the named ones."""
     cache = object.__getattribute__(self, "_cache")
-    if written is None:
+    rb = object.__getattribute__(self, "_readback")
+    if written is None or rb[0] is not None:  # (the read-back refreshes everything at once: any write makes it stale)
       cache.clear()
+      rb[1] = False
     else:
       for name in [k for k, (_, reads) in cache.items() if reads & written]:
         del cache[name]
@@ -220,10 +244,12 @@ class GraphedRlEnv:
     fused_terms           None: HIP launches for the event / command / reward-accumulation terms on the GPU, torch restatements elsewhere
     fused_relative_poses  opt-in (tracking): ``MotionCommand``'s relative body poses from one launch -- 1 ulp from the reference's chain
     forward               "reference": ``sim.forward()`` on all worlds whenever some environment reset; "reset_worlds" (opt-in): only those
+    fused_entity_data     None: on the GPU ``EntityData``'s base quantities come from one ``mjlab_entity_readback`` launch per phase (bit for bit
+                          the reference's chains); False: the reference's own chains
   """
 
   def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None,
-               fused_relative_poses: bool = False, forward: str = "reference") -> None:
+               fused_relative_poses: bool = False, forward: str = "reference", fused_entity_data: bool | None = None) -> None:
     from mjlab.third_party.isaaclab.isaaclab.utils import math as rmath  # the reference's own helpers (pure torch)
 
     self.env, self._m = env, rmath
@@ -253,6 +279,17 @@ class GraphedRlEnv:
         if not isinstance(ent._data, _CachedEntityData):
           ent._data = _CachedEntityData(ent._data)
         self._data_caches.append(ent._data)
+    # EntityData's base quantities from ONE mjlab_entity_readback launch per phase instead of the reference's chains
+    # of small kernels: on the GPU, when every entity is a floating-base articulated robot (what the read-back covers).  The launch
+    # gives the reference's values BIT FOR BIT (the teacher-forced tests against the eager reference run with it; asserted per task)
+    able = cache_entity_data and torch.device(self.device).type == "cuda" and all(not e.is_fixed_base and e.is_articulated for e in env.scene.entities.values())
+    if fused_entity_data and not able:
+      raise ValueError("fused_entity_data needs cache_entity_data=True, an environment on the GPU and floating-base articulated entities")
+    if able and fused_entity_data is not False:
+      from .entity_data import EntityReadback
+
+      for ent in env.scene.entities.values():
+        ent._data.use_readback(EntityReadback(env.sim, root_body=int(ent.indexing.root_body_id)))
     self._action_in = torch.zeros((self.n, sum(env.action_manager.action_term_dim)), device=self.device)
     self._check_supported()
     self._prepare_events()

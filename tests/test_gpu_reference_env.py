@@ -84,6 +84,24 @@ def test_fused_environment_terms_equal_their_torch_restatements():
   assert w["qpos"] <= 2e-6 and w["qvel"] <= 1e-5 and w["command"] <= 1e-6 and w["time_left"] <= 1e-6 and w["obs"] <= 1e-5, w
 
 
+def test_entity_data_from_the_fused_read_back_equals_the_reference_chains():
+  """SURVEY 8f row 1 inside the reference's own environment: every ``EntityData`` base quantity of a phase from ONE
+  ``mjlab_entity_readback`` launch (GraphedRlEnv's default on the GPU) against the reference's own chains of small kernels
+  (``fused_entity_data=False`` on the other side, which also keeps the torch restatements of the terms): teacher-forced, terminations,
+  rewards and observations equal bit for bit, state to the push term's 1 ulp."""
+  sys.path.insert(0, str(ROOT / "tests"))
+  import _graphed_check
+
+  def make(n, device, edit):
+    return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=n, device=device, seed=11, cfg_edit=edit)
+
+  st = _graphed_check.run_fused_vs_torch(make, "cuda:0", num_envs=256, steps=60, a_kwargs={"fused_entity_data": True}, b_kwargs={"fused_entity_data": False})
+  print("EntityData from the fused read-back vs the reference's chains:", st)
+  w = st["worst"]
+  assert st["resets"] >= 200 and st["pushes"] >= 200
+  assert w["qpos"] == 0.0 and w["qvel"] <= 1e-5 and w["command"] == 0.0 and w["obs"] == 0.0, w
+
+
 _TRACKING_GPU = """
 import json, sys
 import torch

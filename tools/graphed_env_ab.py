@@ -29,7 +29,8 @@ if "Tracking" in task:
     cfg.commands.motion.motion_file = path
 
 VARIANTS = {"torch restatements": dict(fused_terms=False), "fused terms (default)": dict(), "fused terms + relative poses": dict(fused_relative_poses=True),
-            "no EntityData / term caches": dict(cache_entity_data=False), "forward() on the reset worlds only": dict(forward="reset_worlds")}
+            "no EntityData / term caches": dict(cache_entity_data=False), "forward() on the reset worlds only": dict(forward="reset_worlds"),
+            "EntityData by the reference's own chains": dict(fused_entity_data=False)}
 envs = {}
 for name, kw in VARIANTS.items():
   if "relative" in name and "Tracking" not in task:
