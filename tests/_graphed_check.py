@@ -60,6 +60,25 @@ def _sync(a, b) -> None:
     tb.env_origins.copy_(ta.env_origins)
 
 
+def _same_logs(a, b, k, reset) -> None:
+  """``extras["log"]`` of a step in which some environment reset (reference envs/manager_based_rl_env.py:214-249: the managers' reset()
+  logging -- episode reward sums, command metrics, termination counts, curriculum state -- as Python floats; GraphedRlEnv: 0-dim device
+  tensors): the same keys, the same numbers to float rounding."""
+  if not bool(reset.any()):
+    return
+  la, lb = a.extras["log"], b.extras["log"]
+  missing = [key for key in la if key not in lb]
+  assert not missing, (k, missing)
+  for key, va in la.items():
+    va = float(va.item() if isinstance(va, torch.Tensor) else va)
+    vb = float(lb[key].float().mean().item() if isinstance(lb[key], torch.Tensor) else lb[key])
+    if key == "Curriculum/terrain_levels":  # (an environment leaving the hardest row draws a random one: each side logs the mean of ITS levels)
+      for env, v in ((a, va), (b, vb)):
+        assert abs(v - float(env.scene.terrain.terrain_levels.float().mean())) <= 1e-6, (k, key, v)
+      continue
+    assert abs(va - vb) <= 1e-5 * (1.0 + abs(va)), (k, key, va, vb)
+
+
 def _same_reward_state(a, b, k) -> None:
   """RewardManager's per-term bookkeeping (managers/reward_manager.py:84-88): episode sums and the per-step term values, bit for bit."""
   ra, rb = a.reward_manager, b.reward_manager
@@ -107,6 +126,7 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
     assert torch.equal(rew_a, rew_b), (k, (rew_a - rew_b).abs().max())
     _same_reward_state(a, b, k)
     reset = term_a | to_a
+    _same_logs(a, b, k, reset)
     if terr is not None:  # the terrain curriculum (terrain_levels_vel): the same moves; a random level only past the hardest row
       tb = b.scene.terrain
       drew = reset & (levels_before + 1 >= terr.max_terrain_level)
@@ -338,6 +358,7 @@ def run_tracking(make_env, device: str, num_envs: int = 32, steps: int = 40, cap
     assert torch.equal(rew_a, rew_b), (k, (rew_a - rew_b).abs().max())
     _same_reward_state(a, b, k)
     reset = term_a | to_a
+    _same_logs(a, b, k, reset)
     quiet = ~(reset | ended | push)
     for grp in obs_a:
       assert torch.equal(obs_a[grp][quiet], obs_b[grp][quiet]), (k, grp, (obs_a[grp][quiet] - obs_b[grp][quiet]).abs().max())
