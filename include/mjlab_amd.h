@@ -322,6 +322,17 @@ int mjlab_sizeof_motion_tables(void);
 int mjlab_reward_accumulate(const float* values, const float* weights, const int* columns, int k, int nworld, float dt, float* reward,
                             float* const* episode_sums, float* step_reward, int nterm, void* stream);
 
+/* The managers' reset() bookkeeping and logging for the worlds of a mask (envs/manager_based_rl_env.py:214-249 calls
+ * managers/{action,reward,command,event,termination}_manager.py reset(); entity/data.py:169-178 clear_state), each as one launch:
+ * mjlab_masked_fill_rows -- row w (row_bytes bytes at ptr + w * row_stride_bytes) of every entry is filled with `pattern`
+ *   (elements of 1, 4 or 8 bytes) where mask[w] is set;
+ * mjlab_masked_sums -- out[i] = sum over the masked worlds of vector i (nworld floats, or nworld bools counted as 0 / 1),
+ *   out[k] = the number of masked worlds.  `entries` are DEVICE arrays. */
+typedef struct mjlab_fill_entry { void* ptr; long long pattern; int row_stride_bytes, row_bytes, elem_bytes, pad_; } mjlab_fill_entry_t;
+typedef struct mjlab_sum_entry { const void* ptr; int is_bool, pad_; } mjlab_sum_entry_t;
+int mjlab_masked_fill_rows(const mjlab_fill_entry_t* entries, int nentries, const unsigned char* mask, int nworld, void* stream);
+int mjlab_masked_sums(const mjlab_sum_entry_t* entries, int k, const unsigned char* mask, int nworld, float* out, void* stream);
+
 /* Runs only the selected stages once (bit mask of MJLAB_STAGE_*), in pipeline order. */
 int mjlab_forward_stages(const mjlab_model_t* m, const mjlab_data_t* d, int stages, void* stream);
 

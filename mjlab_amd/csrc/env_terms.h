@@ -301,4 +301,41 @@ __global__ __launch_bounds__(256) void k_reward_accumulate(const float* values, 
   reward[w] = r;
 }
 
+// The managers' reset() bookkeeping (managers/{action,reward,command,event}_manager.py reset(), envs/manager_based_rl_env.py:246,
+// entity/data.py:169-178 clear_state): `row_bytes` bytes of row w of every listed buffer are filled with the entry's pattern where
+// mask[w] is set -- one launch for the ~20 masked fills of a step.  One 64-lane block per world.
+__global__ __launch_bounds__(64) void k_masked_fill_rows(const mjlab_fill_entry_t* e, const int ne, const unsigned char* mask, const int nworld) {
+  const int w = blockIdx.x;
+  if (w >= nworld || !mask[w]) return;
+  for (int i = 0; i < ne; ++i) {
+    char* row = (char*)e[i].ptr + (size_t)w * e[i].row_stride_bytes;
+    const int eb = e[i].elem_bytes, nel = e[i].row_bytes / eb;
+    for (int k = threadIdx.x; k < nel; k += 64) {
+      if (eb == 4) ((int*)row)[k] = (int)e[i].pattern;
+      else if (eb == 8) ((long long*)row)[k] = e[i].pattern;
+      else row[k] = (char)e[i].pattern;
+    }
+  }
+}
+
+// The managers' reset() logging (reward_manager.py:67-71, command_manager.py:46-49, termination_manager.py:79-83): out[i] = the sum
+// over the worlds of the mask of vector i (float, or bool counted as 0 / 1), out[k] = the number of worlds in the mask.  One block per
+// vector; fp32 accumulation in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void k_masked_sums(const mjlab_sum_entry_t* e, const int k, const unsigned char* mask, const int nworld, float* out) {
+  __shared__ float part[256];
+  const int i = blockIdx.x;
+  float acc = 0.f;
+  for (int w = threadIdx.x; w < nworld; w += 256) {
+    if (!mask[w]) continue;
+    acc += i == k ? 1.f : (e[i].is_bool ? (float)(((const unsigned char*)e[i].ptr)[w] != 0) : ((const float*)e[i].ptr)[w]);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[i] = part[0];
+}
+
 #endif  // MJLAB_MAIN_TU

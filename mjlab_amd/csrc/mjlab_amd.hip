@@ -263,6 +263,18 @@ int mjlab_command_motion_relative(const mjlab_motion_tables_t* tab, int nworld, 
   return launched("k_command_motion_relative launch failed");
 }
 int mjlab_sizeof_motion_tables(void) { return (int)sizeof(mjlab_motion_tables_t); }
+int mjlab_masked_fill_rows(const mjlab_fill_entry_t* entries, int nentries, const unsigned char* mask, int nworld, void* stream) {
+  if (!entries || !mask) return fail(-22, "masked_fill_rows: null argument");
+  if (nentries < 1 || nworld < 1) return fail(-22, "masked_fill_rows: bad sizes");
+  hipLaunchKernelGGL(k_masked_fill_rows, dim3(nworld), dim3(64), 0, (hipStream_t)stream, entries, nentries, mask, nworld);
+  return launched("k_masked_fill_rows launch failed");
+}
+int mjlab_masked_sums(const mjlab_sum_entry_t* entries, int k, const unsigned char* mask, int nworld, float* out, void* stream) {
+  if (!mask || !out || (k > 0 && !entries)) return fail(-22, "masked_sums: null argument");
+  if (k < 0 || nworld < 1) return fail(-22, "masked_sums: bad sizes");
+  hipLaunchKernelGGL(k_masked_sums, dim3(k + 1), dim3(256), 0, (hipStream_t)stream, entries, k, mask, nworld, out);
+  return launched("k_masked_sums launch failed");
+}
 int mjlab_reward_accumulate(const float* values, const float* weights, const int* columns, int k, int nworld, float dt, float* reward,
                             float* const* episode_sums, float* step_reward, int nterm, void* stream) {
   if (!values || !weights || !columns || !reward || !episode_sums || !step_reward) return fail(-22, "reward_accumulate: null argument");

@@ -187,3 +187,66 @@ class RewardAccumulator:
       _dense(m._reward_buf, "reward_buf", torch.float32).data_ptr(), self.sum_ptrs.data_ptr(), _dense(m._step_reward, "step_reward", torch.float32).data_ptr(),
       m._step_reward.shape[1], _stream(values)), "mjlab_reward_accumulate")  # fmt: skip
     return m._reward_buf
+
+
+class _FillEntry(ctypes.Structure):  # mjlab_fill_entry_t
+  _fields_ = [("ptr", _vp), ("pattern", ctypes.c_longlong), ("row_stride_bytes", ctypes.c_int), ("row_bytes", ctypes.c_int), ("elem_bytes", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+class _SumEntry(ctypes.Structure):  # mjlab_sum_entry_t
+  _fields_ = [("ptr", _vp), ("is_bool", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+def _upload(entries: list, device) -> torch.Tensor:
+  raw = b"".join(bytes(e) for e in entries)
+  return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+class MaskedFill:
+  """One launch for a list of masked row fills (``buf[mask] = value`` / ``buf[mask, a:b] = value`` of the managers' reset()).  Built
+  once from (tensor, value) pairs -- views with a contiguous row are fine; the tensors are kept alive and must not be replaced."""
+
+  def __init__(self, items: list) -> None:
+    import struct
+
+    entries, self.keep = [], []
+    for t, value in items:
+      if not t.is_cuda or (t.dim() > 1 and not t[0].is_contiguous()):
+        raise TypeError(f"MaskedFill: a device tensor with contiguous rows is needed (shape {tuple(t.shape)}, strides {t.stride()})")
+      eb = t.element_size()
+      if eb not in (1, 4, 8):
+        raise TypeError(f"MaskedFill: element size {eb}")
+      if t.dtype.is_floating_point:
+        pattern = struct.unpack("<q", struct.pack("<d", float(value)))[0] if eb == 8 else struct.unpack("<i", struct.pack("<f", float(value)))[0]
+      else:
+        pattern = int(value)
+      row = int(t[0].numel()) if t.dim() > 1 else 1
+      entries.append(_FillEntry(t.data_ptr(), pattern, int(t.stride(0)) * eb, row * eb, eb, 0))
+      self.keep.append(t)
+    self.n = items[0][0].shape[0]
+    self.table = _upload(entries, items[0][0].device)
+    self.count = len(entries)
+
+  def __call__(self, mask: torch.Tensor) -> None:
+    native.check(native.lib().mjlab_masked_fill_rows(self.table.data_ptr(), self.count, _dense(mask, "mask", torch.bool).data_ptr(), self.n, _stream(mask)),
+                 "mjlab_masked_fill_rows")
+
+
+class MaskedSums:
+  """One launch for the masked sums the managers' reset() logs: ``out[i] = vectors[i][mask].sum()`` (bools counted), ``out[-1] =
+  mask.sum()``.  The vectors (float32 or bool, shape (n,)) are kept alive and must not be replaced."""
+
+  def __init__(self, vectors: list) -> None:
+    self.keep = [_dense(v, "vector", v.dtype) for v in vectors]
+    for v in vectors:
+      if v.dtype not in (torch.float32, torch.bool) or v.dim() != 1:
+        raise TypeError(f"MaskedSums: float32 or bool vectors, got {v.dtype} {tuple(v.shape)}")
+    dev = vectors[0].device
+    self.n, self.k = vectors[0].shape[0], len(vectors)
+    self.table = _upload([_SumEntry(v.data_ptr(), int(v.dtype == torch.bool), 0) for v in vectors], dev)
+    self.out = torch.zeros(self.k + 1, dtype=torch.float32, device=dev)
+
+  def __call__(self, mask: torch.Tensor) -> torch.Tensor:
+    native.check(native.lib().mjlab_masked_sums(self.table.data_ptr(), self.k, _dense(mask, "mask", torch.bool).data_ptr(), self.n, self.out.data_ptr(), _stream(mask)),
+                 "mjlab_masked_sums")
+    return self.out

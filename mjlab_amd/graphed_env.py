@@ -296,11 +296,12 @@ class GraphedRlEnv:
     self._upload_index_lists()
     # RewardManager.compute's accumulation (6 launches per term) as one launch; the term functions are the reference's (GPU only)
     self._reward = env_terms.RewardAccumulator(env.reward_manager) if self._fused else None
+    self._ep_len = env.episode_length_buf  # the tensor the captured kernels address (see step())
+    self._book = self._prepare_bookkeeping() if self._fused else None
     self._obs_memo: dict = {}
     self._obs_memo_on = False
     self._share_observation_terms()
     self.graph: torch.cuda.CUDAGraph | None = None
-    self._ep_len = env.episode_length_buf  # the tensor the captured kernels address (see step())
     env.sim.use_graph = False  # the launches are captured here, once, for the whole control step
     if capture:
       self.capture(warmup)
@@ -714,8 +715,87 @@ class GraphedRlEnv:
           setattr(owner, key, old)
 
   # ------------------------------------------------------------------------------------------------------------------ reset
+  def _prepare_bookkeeping(self) -> Any:
+    """The masked fills and masked sums of ``_reset_idx`` over buffers that live for the whole run (updated in place by the reference),
+    as ONE launch each (env_terms.MaskedFill / MaskedSums).  Command terms whose metric tensors are rebound at every update (the
+    tracking task's MotionCommand, tasks/tracking/mdp/commands.py:216-253) keep the torch path for their metrics."""
+    env = self.env
+    d = self._robot.data.data
+    fv, bi, ci, _ = self._index_slices(self._robot)
+    fills: list = []
+    whole_clear = all(isinstance(x, slice) for x in (fv, bi, ci))
+    if whole_clear:  # EntityData.clear_state (entity/data.py:169-178)
+      fills += [(d.qfrc_applied[:, fv], 0.0), (d.xfrc_applied[:, bi], 0.0), (d.ctrl[:, ci], 0.0)]
+    ev = env.event_manager
+    step_count = env._sim_step_counter // env.cfg.decimation
+    for index in range(len(self._reset_terms)):  # EventManager bookkeeping of reset-mode terms (managers/event_manager.py:139-148)
+      fills += [(ev._reset_term_last_triggered_step_id[index], step_count), (ev._reset_term_last_triggered_once[index], 1)]
+    am = env.action_manager  # managers/action_manager.py:101-110
+    fills += [(am._prev_action, 0.0), (am._action, 0.0)] + [(t._raw_actions, 0.0) for t in am._terms.values()]
+    rm = env.reward_manager  # managers/reward_manager.py:60-74
+    rkeys = list(rm._episode_sums)
+    fills += [(rm._episode_sums[k], 0.0) for k in rkeys]
+    vectors = [rm._episode_sums[k] for k in rkeys]
+    mkeys: list = []
+    for name in env.command_manager.active_terms:  # managers/command_manager.py:44-53
+      term = env.command_manager.get_term(name)
+      fills.append((term.command_counter, 0))
+      if type(term).__name__ == "UniformVelocityCommand":  # (metrics updated in place: velocity_command.py:49-62)
+        for key in term.metrics:
+          mkeys.append((name, key))
+          fills.append((term.metrics[key], 0.0))
+          vectors.append(term.metrics[key])
+    tm = env.termination_manager  # managers/termination_manager.py:73-85
+    tkeys = list(tm._term_dones)
+    vectors += [tm._term_dones[k] for k in tkeys]
+    fills.append((self._ep_len if hasattr(self, "_ep_len") else env.episode_length_buf, 0))  # envs/manager_based_rl_env.py:246
+    return env_terms.MaskedFill(fills), env_terms.MaskedSums(vectors), rkeys, mkeys, tkeys, whole_clear
+
+  def _masked_reset_fused(self, mask: torch.Tensor) -> None:
+    """``_masked_reset`` with the managers' bookkeeping as two launches: every masked sum the reset logs first (nothing below changes
+    the summed buffers), then every masked fill, then the terms that draw."""
+    env = self.env
+    fill, sums, rkeys, mkeys, tkeys, whole_clear = self._book
+    log: dict = {}
+    self._curricula(mask)
+    out = sums(mask)
+    cnt = out[-1].clamp(min=1.0)
+    kr, km = len(rkeys), len(mkeys)
+    r = out[:kr] / cnt / env.max_episode_length_s
+    m = out[kr : kr + km] / cnt
+    for k, key in enumerate(rkeys):
+      log["Episode_Reward/" + key] = r[k]
+    for k, (name, key) in enumerate(mkeys):
+      log[f"Metrics/{name}/{key}"] = m[k]
+    for k, key in enumerate(tkeys):
+      log["Episode_Termination/" + key] = out[kr + km + k]
+    if not whole_clear:
+      self._clear_state(self._robot, mask)
+    fill(mask)
+    for index, (fn, prm) in enumerate(self._reset_terms):
+      getattr(self, "_" + fn)(mask, self._Uof(("reset", index)), **prm)
+    for cfg in env.reward_manager._class_term_cfgs:
+      self._masked_class_reset(cfg.func, mask)
+    for name in env.command_manager.active_terms:
+      term = env.command_manager.get_term(name)
+      if type(term).__name__ != "UniformVelocityCommand":
+        mk, mvals = list(term.metrics), list(term.metrics.values())
+        if mvals:
+          vals = (torch.stack(mvals, dim=1) * mask[:, None]).sum(dim=0) / cnt
+          for k, metric in enumerate(mk):
+            log[f"Metrics/{name}/{metric}"] = vals[k]
+          torch._foreach_mul_(mvals, [(~mask).to(torch.float32)] * len(mvals))
+      self._command_resample(term, mask, self._Uof(("command", name, "reset")))
+    for cname, state in getattr(env.curriculum_manager, "_curriculum_state", {}).items():
+      if isinstance(state, torch.Tensor):
+        log["Curriculum/" + cname] = state.reshape(-1)[0] if state.numel() == 1 else state
+    env.extras["log"] = log
+
   def _masked_reset(self, mask: torch.Tensor) -> None:
     """``_reset_idx`` (:214-249) for the environments of `mask`, in its order."""
+    if self._book is not None:
+      self._masked_reset_fused(mask)
+      return
     env, m1 = self.env, mask[:, None]
     cnt = mask.sum().clamp(min=1).to(torch.float32)
     log: dict = {}

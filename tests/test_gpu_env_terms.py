@@ -441,3 +441,41 @@ def test_masks_that_select_nobody_or_everybody(fill):
     assert bool((got[:, 0:3].abs() <= 0.5).all()) and bool(((got[:, 3:7].norm(dim=1) - 1).abs() < 1e-5).all())
     assert bool((got[:, 7:] >= 0.5).all()) and bool((got[:, 7:] <= 1.5).all()) and bool((dv.cpu()[:, 6:].abs() <= 1.0).all())
     assert not torch.equal(got, qpos)
+
+
+def test_masked_fill_rows_and_masked_sums():
+  """env_terms.MaskedFill / MaskedSums (the managers' reset() bookkeeping and logging as one launch each) against the torch operations
+  they replace: fills bit for bit (float / int64 / bool buffers, whole rows and column ranges), sums to fp32 summation order."""
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(13)
+  mask = (torch.rand(N, generator=g) < 0.3).to(dev)
+  a = torch.randn((N, 29), generator=g).to(dev)
+  b = torch.randn((N, 32, 6), generator=g).to(dev)
+  c = torch.randn((N, 35), generator=g).to(dev)
+  cnt = torch.randint(0, 9, (N,), generator=g).to(dev)
+  flag = torch.zeros(N, dtype=torch.bool, device=dev)
+  v = torch.randn(N, generator=g).to(dev)
+  want = [t.clone() for t in (a, b, c, cnt, flag, v)]
+  fill = env_terms.MaskedFill([(a, 0.0), (b[:, 2:32], 0.0), (c[:, 0:6], 0.0), (cnt, 7), (flag, 1), (v, -1.5)])
+  fill(mask)
+  torch.cuda.synchronize()
+  want[0][mask] = 0.0
+  want[1][mask, 2:32] = 0.0
+  want[2][mask, 0:6] = 0.0
+  want[3][mask] = 7
+  want[4][mask] = True
+  want[5][mask] = -1.5
+  for got, w in zip((a, b, c, cnt, flag, v), want, strict=True):
+    assert torch.equal(got, w)
+  x = [torch.randn(N, generator=g).to(dev) * s for s in (1.0, 100.0, 1e-3)]
+  done = (torch.rand(N, generator=g) < 0.5).to(dev)
+  sums = env_terms.MaskedSums([*x, done])
+  out = sums(mask).cpu().double()
+  ref = [float(t[mask].double().sum()) for t in x] + [float((done & mask).sum()), float(mask.sum())]
+  for got, r in zip(out.tolist(), ref, strict=True):
+    assert abs(got - r) <= 2e-6 * max(1.0, abs(r)) * 30, (got, r)
+  assert out[-1] == float(mask.sum()) and out[-2] == float((done & mask).sum())  # counts are exact
+  none = torch.zeros(N, dtype=torch.bool, device=dev)
+  assert float(sums(none).abs().max()) == 0.0
