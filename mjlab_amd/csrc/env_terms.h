@@ -319,23 +319,17 @@ __global__ __launch_bounds__(64) void k_masked_fill_rows(const mjlab_fill_entry_
 }
 
 // The managers' reset() logging (reward_manager.py:67-71, command_manager.py:46-49, termination_manager.py:79-83): out[i] = the sum
-// over the worlds of the mask of vector i (float, or bool counted as 0 / 1), out[k] = the number of worlds in the mask.  One block per
+// over the worlds of the mask of vector i (float, or bool counted as 0 / 1), out[k] = the number of worlds in the mask.  One wave per
 // vector; fp32 accumulation in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void k_masked_sums(const mjlab_sum_entry_t* e, const int k, const unsigned char* mask, const int nworld, float* out) {
-  __shared__ float part[256];
+__global__ __launch_bounds__(64) void k_masked_sums(const mjlab_sum_entry_t* e, const int k, const unsigned char* mask, const int nworld, float* out) {
   const int i = blockIdx.x;
   float acc = 0.f;
-  for (int w = threadIdx.x; w < nworld; w += 256) {
+  for (int w = threadIdx.x; w < nworld; w += 64) {
     if (!mask[w]) continue;
     acc += i == k ? 1.f : (e[i].is_bool ? (float)(((const unsigned char*)e[i].ptr)[w] != 0) : ((const float*)e[i].ptr)[w]);
   }
-  part[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[i] = part[0];
+  acc = wave_sum(acc);  // (DPP reduction: no LDS)
+  if (threadIdx.x == 0) out[i] = acc;
 }
 
 #endif  // MJLAB_MAIN_TU
