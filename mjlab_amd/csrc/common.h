@@ -149,6 +149,38 @@ __device__ __forceinline__ void global_to_lds(float* dst, const float* src, int 
   }
 }
 
+// ---- global -> LDS without registers (round 5): gfx950's LDS-DMA load (`global_load_lds_dword`: each lane names its own global
+// address, the data lands at a wave-uniform LDS base + 4 * lane).  No destination VGPR means every trip of a copy can be in flight
+// at once whatever the kernel's register allocation looks like -- the one way to batch the copies of the fused control kernel, which
+// sits on the 128-register cap (MJLAB_COPY_BATCH above buys the same overlap with registers and loses it again to spills).  The
+// compiler counts these loads (vmcnt) and waits before the first LDS access that follows; copies only: results are bit-identical.
+// MJLAB_GLDS bit 0: the solve stage's load of M; bit 1: the other stages' prologue copies.
+#ifndef MJLAB_GLDS
+#define MJLAB_GLDS 3
+#endif
+typedef __attribute__((address_space(1))) const void* glds_src_t;
+typedef __attribute__((address_space(3))) void* glds_dst_t;
+__device__ __forceinline__ void glds_to_lds(float* dst, const float* src, int n, int lane) {
+  lane = launder(lane);
+  for (int k0 = 0; k0 < n; k0 += 64)
+    if (k0 + lane < n) __builtin_amdgcn_global_load_lds((glds_src_t)(src + k0 + lane), (glds_dst_t)(dst + k0), 4, 0, 0);
+}
+// lower triangle of a dense row-major n x n matrix in global memory -> packed lower triangle in LDS (element (i, j), j <= i, at
+// i (i + 1) / 2 + j): lane k of a trip fetches the element whose packed index is k0 + k.  (i, j) from the packed index by a square
+// root (exact for these sizes after one correction either way).
+__device__ __forceinline__ void glds_dense_to_packed(float* packed, const float* src, int n, int lane) {
+  lane = launder(lane);
+  const int total = (n * (n + 1)) >> 1;
+  for (int k0 = 0; k0 < total; k0 += 64) {
+    const int k = k0 + lane;
+    int i = (int)((sqrtf((float)(8 * k + 1)) - 1.f) * 0.5f);
+    if (((i + 1) * (i + 2)) >> 1 <= k) ++i;
+    if ((i * (i + 1)) >> 1 > k) --i;
+    const int j = k - ((i * (i + 1)) >> 1);
+    if (k < total) __builtin_amdgcn_global_load_lds((glds_src_t)(src + i * n + j), (glds_dst_t)(packed + k0), 4, 0, 0);
+  }
+}
+
 // Dense n x n matrix copies between row-major global memory (leading dimension n) and LDS
 // (leading dimension ld); lanes walk consecutive global elements.  (i, j) of element k advance by 64 per step:
 // j += 64 mod n, i += 64 div n, one conditional carry -- no division and no data-dependent loop inside the batches.

@@ -573,8 +573,17 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
     if (BIG) {
       dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
     } else {
+#if MJLAB_GLDS & 1
+      // every trip of the load in flight at once, straight into the packed copy (common.h: glds_dense_to_packed); the dense
+      // lower triangle the factorization reads is laid out from that copy on chip
+      glds_dense_to_packed(c.s_M, c.M, nv, lane);
+      for (int k = ((nv * (nv + 1)) >> 1) + lane; k < NVP * (NVP + 1) / 2; k += 64) c.s_M[k] = 0.f;
+      __syncthreads();
+      packed_to_lds(c.s_H, c.s_M, nv, ld, lane);
+#else
       dense_global_to_lds_packed(c.s_H, c.s_M, c.M, nv, ld, lane);
       for (int k = ((nv * (nv + 1)) >> 1) + lane; k < NVP * (NVP + 1) / 2; k += 64) c.s_M[k] = 0.f;
+#endif
     }
     chol_pad_rows<NVP>(c.s_H, nv, lane);
     chol_pad_diag<NVP>(c.s_H, nv, lane);

@@ -272,6 +272,7 @@ class GraphedRlEnv:
     self._robot = env.scene["robot"]
     self._data_caches = []
     self._term_caches: list = []  # invalidate() of the command terms whose properties are cached (dropped with the EntityData caches)
+    self._log_vec, self._log_keys, self._log_pub = None, None, {}  # extras["log"]: see _publish_log
     self._caching = [False]  # the property caches work inside _body() only: the eager env.reset() / a caller's own reads see the reference's objects
     self._cache_entity_data = cache_entity_data
     if cache_entity_data:
@@ -550,7 +551,10 @@ class GraphedRlEnv:
     with torch.cuda.graph(g):
       self._body()
     self.graph = g
-    self._out = (self.env.obs_buf, self.env.reward_buf, self.env.reset_terminated, self.env.reset_time_outs)
+    # what a replay rewrites: the tensors bound at capture time.  step() binds the environment's attributes back to them after
+    # every replay -- the reference's reset() REBINDS obs_buf (envs/manager_based_rl_env.py:95-101) and _reset_idx rebinds
+    # extras["log"], after which the environment's attributes would no longer name the tensors the graph writes
+    self._out = (self.env.obs_buf, self.env.reward_buf, self.env.reset_terminated, self.env.reset_time_outs, self.env.reset_buf)
 
   def _save_state(self) -> list:
     """(tensor, clone) of everything a control step mutates: mjData, the managers' and terms' buffers, the counters."""
@@ -596,6 +600,9 @@ class GraphedRlEnv:
     self._action_in.copy_(action)
     if self.graph is not None:
       self.graph.replay()
+      env.obs_buf, env.reward_buf, env.reset_terminated, env.reset_time_outs, env.reset_buf = self._out
+      env.observation_manager._obs_buffer = env.obs_buf
+      env.extras["log"] = self._log_pub
     else:
       self._body()
     env._sim_step_counter += env.cfg.decimation
@@ -789,7 +796,26 @@ class GraphedRlEnv:
     for cname, state in getattr(env.curriculum_manager, "_curriculum_state", {}).items():
       if isinstance(state, torch.Tensor):
         log["Curriculum/" + cname] = state.reshape(-1)[0] if state.numel() == 1 else state
-    env.extras["log"] = log
+    self._publish_log(log, mask)
+
+  def _publish_log(self, log: dict, mask: torch.Tensor) -> None:
+    """``extras["log"]`` as the reference leaves it: ``_reset_idx`` -- and with it the managers' reset() logging -- runs only in a
+    step in which some environment reset (envs/manager_based_rl_env.py:121-127), so between two such steps the dict keeps the
+    numbers of the last one.  Here the masked sums are evaluated every step (a capture cannot skip them); the scalars go through
+    ONE ``where(any reset, new, previous)`` into a persistent vector, and ``extras["log"]`` is a persistent dict of 0-dim views
+    of it (the same objects across replays and resets; counts are float32 like everything else in the vector)."""
+    keys = [k for k, v in log.items() if v.dim() == 0]
+    new = torch.stack([log[k].to(torch.float32) for k in keys]) if keys else None
+    if self._log_vec is None or self._log_keys != keys:
+      self._log_keys = keys
+      self._log_vec = new.clone() if new is not None else None
+      self._log_pub = {k: self._log_vec[i] for i, k in enumerate(keys)}
+    elif new is not None:
+      torch.where(mask.any(), new, self._log_vec, out=self._log_vec)
+    for k, v in log.items():  # (non-scalar curriculum state: passed through as it is)
+      if v.dim() != 0:
+        self._log_pub[k] = v
+    self.env.extras["log"] = self._log_pub
 
   def _masked_reset(self, mask: torch.Tensor) -> None:
     """``_reset_idx`` (:214-249) for the environments of `mask`, in its order."""
@@ -844,7 +870,7 @@ class GraphedRlEnv:
     for cname, state in getattr(env.curriculum_manager, "_curriculum_state", {}).items():  # CurriculumManager.reset (managers/curriculum_manager.py:70-85)
       if isinstance(state, torch.Tensor):
         log["Curriculum/" + cname] = state.reshape(-1)[0] if state.numel() == 1 else state
-    env.extras["log"] = log
+    self._publish_log(log, mask)
     env.episode_length_buf.masked_fill_(mask, 0)
 
   def _curricula(self, mask: torch.Tensor) -> None:

@@ -87,7 +87,11 @@ def _same_reward_state(a, b, k) -> None:
     assert torch.equal(ra._episode_sums[name], rb._episode_sums[name]), (k, name)
 
 
-def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: bool = True, post_make=None, g_kwargs: dict | None = None) -> dict:
+def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: bool = True, post_make=None, g_kwargs: dict | None = None,
+        reset_at: int | None = None) -> dict:
+  """``reset_at``: before that step both environments are reset through their public ``reset()`` (the reference's eager reset of all
+  environments -- what ``RslRlVecEnvWrapper.__init__`` does AFTER the graph was captured): the reference rebinds ``obs_buf`` and
+  ``extras["log"]`` there, and the replays that follow must still hand out the tensors they write."""
   torch.manual_seed(0)
   a = make_env(num_envs, device, _edit)
   b = make_env(num_envs, device, _edit)
@@ -108,7 +112,12 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
   stats = {"resets": 0, "resamples": 0, "pushes": 0, "quiet_env_steps": 0, "forward_steps": 0}
   dt = a.step_dt
   na = sum(a.action_manager.action_term_dim)
+  prev_log: dict = {}
   for k in range(steps):
+    if reset_at is not None and k == reset_at:
+      a.reset()
+      g.reset()
+      stats["public_resets"] = stats.get("public_resets", 0) + 1
     _sync(a, b)
     action = torch.rand((num_envs, na), device=device, generator=gen) * 2 - 1
     if k > 20:
@@ -127,6 +136,12 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
     _same_reward_state(a, b, k)
     reset = term_a | to_a
     _same_logs(a, b, k, reset)
+    # a step without resets leaves extras["log"] as the last step with resets wrote it (the reference runs _reset_idx only then)
+    cur_log = {key: float(v.float().mean().item()) for key, v in b.extras["log"].items() if isinstance(v, torch.Tensor)}
+    if not bool(reset.any()) and prev_log and not (reset_at is not None and k == reset_at):
+      assert cur_log == prev_log, (k, {key: (cur_log[key], prev_log.get(key)) for key in cur_log if cur_log[key] != prev_log.get(key)})
+      stats["steps_with_a_kept_log"] = stats.get("steps_with_a_kept_log", 0) + 1
+    prev_log = cur_log
     if terr is not None:  # the terrain curriculum (terrain_levels_vel): the same moves; a random level only past the hardest row
       tb = b.scene.terrain
       drew = reset & (levels_before + 1 >= terr.max_terrain_level)

@@ -63,7 +63,7 @@ def test_graphed_env_matches_the_reference_env():
   def make(n, device, edit):
     return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=n, device=device, seed=11, cfg_edit=edit)
 
-  st = _graphed_check.run(make, "cuda:0", num_envs=256, steps=70, capture=True)
+  st = _graphed_check.run(make, "cuda:0", num_envs=256, steps=70, capture=True, reset_at=30)
   print("graphed env vs reference env:", st)
   assert st["graph"] and st["resets"] >= 256 and st["pushes"] >= 256 and st["resamples"] >= 8 and st["quiet_env_steps"] >= 4000 and 0 < st["forward_steps"] < 70
 

@@ -23,7 +23,7 @@ def test_mask_based_control_step_equals_the_reference_step():
   def make(n, device, edit):
     return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=n, device=device, sim_cls=OracleSimulation, seed=11, cfg_edit=edit)
 
-  st = _graphed_check.run(make, "cpu", num_envs=32, steps=70, capture=False)
+  st = _graphed_check.run(make, "cpu", num_envs=32, steps=70, capture=False, reset_at=30)
   print(st)
   assert st["resets"] >= 32 and st["pushes"] >= 32 and st["resamples"] >= 1 and st["quiet_env_steps"] >= 500 and 0 < st["forward_steps"] < 70
 
