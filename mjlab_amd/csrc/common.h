@@ -666,6 +666,278 @@ __device__ CHOL_INLINE float chol_solve_back(const float* L_, const float* s_inv
   for (int k = NVP - 1; k >= 0; --k) b = fmaf(-at[k], lane_bcast(b, k), b);
   return b;
 }
+// ------------------------------------------------------------------------------------
+// REGISTER-RESIDENT BLOCKED LDL^T ON MFMA TILES (round 5; lane-level model: tools/chol_mfma_model.py, which this code follows
+// operation by operation).  The left-looking sweep above spends its time waiting: every batch of a column's dot product needs an
+// LDS broadcast of the factor's row (2.7 exposed round trips per column, 9.4 k cycles per 36 x 36 factorization on one wave per SIMD,
+// profiles/r04_v3/latency_table.md), and the Hessian it factors was laid out in LDS from MFMA accumulators just before.  Here the
+// matrix never leaves those accumulators.  The symmetric matrix is held as UPPER block tiles U(Jb, I), Jb <= I, in the C / D layout
+// of v_mfma_f32_16x16x4_f32:
+//     U(Jb, I)[reg r][lane l] = A[16 Jb + 4 kk + r][16 I + j],   kk = l >> 4, j = l & 15
+// so ONE REGISTER r of tile row Jb holds four matrix rows {16 Jb + 4 kk + r}, one per 16-lane group -- which is exactly the shape of
+// an MFMA A / B operand (K index = lane group).  The columns of a 16-column block are eliminated in that order: panel r = columns
+// c(kk) = 16 Jb + 4 kk + r, kk = 0..3, for r = 0..3 (a fixed permutation inside every block; the substitutions walk the same order), and
+// a panel's rows are operands AS THEY LIE -- no transposition, no LDS round trip:
+//   1. the panel's 4 x 4 diagonal block: 10 v_readlane, a wave-uniform LDL^T of it (4 reciprocals: the only sequential chain) and
+//      the inverse of its unit factor;
+//   2. W = panel x Linv^T: one MFMA per tile of the block row (A operand: Linv on rows 0, 4, 8, 12; the result's register 0 is W in
+//      operand layout), masked to the rows eliminated later, L = W / D;
+//   3. L goes to LDS as columns of the factor (for the substitutions; nothing waits for it);
+//   4. the trailing update U(J', I) -= W(J') L(I)^T: one MFMA per tile (6 for the G1's first block row, then 3, then none).
+// A last block of 4 real columns (NVP 20, 36) is one uniform 4 x 4 factorization.  Same LDL^T, no square roots, the same pivot clamp;
+// sums are formed in a different order than in the sweep above, so results differ in the last bits (parity gate: DESIGN.md section 4).
+// Factor storage (what chol_solve_tiles reads): C[c][i] = Lu[i][c], column-major with leading dimension LD, natural indices, exactly
+// zero unless column c is eliminated before row i.
+// ------------------------------------------------------------------------------------
+#ifndef MJLAB_CHOL_TILES
+#define MJLAB_CHOL_TILES 1
+#endif
+#ifndef MJLAB_CHOL_PANEL
+#define MJLAB_CHOL_PANEL 0  // 0: panel x Linv^T as an MFMA (default), 1: substitution after three permlane swaps (experiment)
+#endif
+template <int NVP>
+struct CholT {
+  static constexpr int NB = CholCfg<NVP>::NB, NT = NB * (NB + 1) / 2, LD = CholCfg<NVP>::LD;
+  static constexpr bool SMALL_LAST = NVP - 16 * (NB - 1) == 4;  // the last block is one 4 x 4 block (lane group 0, registers 0..3)
+  __host__ __device__ static constexpr int tix(int jb, int i) { return i * (i + 1) / 2 + jb; }  // tile (jb, i), jb <= i
+  // the s-th column (< NVP) in elimination order
+  __host__ __device__ static constexpr int order(int s) {
+    int n = 0;
+    for (int jb = 0; jb < NB; ++jb) {
+      if (SMALL_LAST && jb == NB - 1) {
+        for (int r = 0; r < 4; ++r) { if (n == s) return 16 * jb + r; ++n; }
+        continue;
+      }
+      for (int r = 0; r < 4; ++r)
+        for (int kk = 0; kk < 4; ++kk) {
+          const int c = 16 * jb + 4 * kk + r;
+          if (c < NVP) { if (n == s) return c; ++n; }
+        }
+    }
+    return -1;
+  }
+};
+__device__ __forceinline__ float chol_pivot(float x) { return __builtin_amdgcn_fmed3f(x, MINVAL, 3.0e38f); }
+
+// tiles (+)= M: the packed lower triangle in LDS (zero-padded to NVP; stage_solve) or, GLOBAL, the dense row-major matrix in global
+// memory; identity beyond nv.  ADD = false overwrites the tiles.  Branch-free: every load is issued by every lane (index clamped into
+// the array), the bounds are selects, and off-diagonal tiles address through one per-lane base per block column plus an immediate.
+template <int NVP, bool GLOBAL, bool ADD>
+__device__ __forceinline__ void tiles_add_M(f32x4 (&T)[CholT<NVP>::NT], const float* sM_, const float* Mg, int nv, int lane) {
+  using K = CholT<NVP>;
+  const lds_f32* sM = (const lds_f32*)sM_;
+  asm volatile("" : "+v"(lane));
+  const int kk = lane >> 4, j = lane & 15;
+#pragma unroll
+  for (int i = 0; i < K::NB; ++i) {
+    const bool colin = 16 * i + 16 <= NVP || j < NVP - 16 * i;  // column 16 i + j exists in the padded matrix
+    const int col = colin ? 16 * i + j : 0;
+#pragma unroll
+    for (int jb = 0; jb <= i; ++jb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool rowin = 16 * jb + 16 <= NVP || 4 * kk + r < NVP - 16 * jb;
+        const int row = rowin ? 16 * jb + 4 * kk + r : 0;
+        int hi = col, lo = row;  // off-diagonal tiles lie above the diagonal: column > row
+        if (i == jb) { hi = row > col ? row : col; lo = row > col ? col : row; }
+        float v;
+        if (GLOBAL) { const bool in = hi < nv; v = Mg[in ? hi * nv + lo : 0]; v = in ? v : 0.f; }
+        else v = sM[((hi * (hi + 1)) >> 1) + lo];
+        if (!(16 * i + 16 <= NVP)) v = colin ? v : 0.f;
+        if (!(16 * jb + 16 <= NVP)) v = rowin ? v : 0.f;
+        if (i == jb) v = (j == 4 * kk + r && 16 * jb + j >= nv) ? 1.f : v;  // identity beyond nv
+        if (ADD) T[K::tix(jb, i)][r] += v; else T[K::tix(jb, i)][r] = v;
+      }
+    }
+  }
+}
+// Ends the tiles' live range: every register is "written" by an empty asm statement (no instruction), so that the allocator does not
+// keep 6 tiles alive around the solver loop on the paths where they are not refilled (the factor site is one place in a state
+// machine; path-insensitive liveness would carry them from one visit to the next).
+#ifndef MJLAB_TILES_KILL
+#define MJLAB_TILES_KILL 1
+#endif
+template <int NT>
+__device__ __forceinline__ void tiles_kill(f32x4 (&T)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#if MJLAB_TILES_KILL == 2
+    T[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#elif MJLAB_TILES_KILL == 1
+    asm volatile("" : "=v"(T[t]));
+#endif
+  }
+}
+// tiles += diag(s[dof]) for dofs < nv (s in LDS: friction-loss curvature, the integrator's h * damping)
+template <int NVP>
+__device__ __forceinline__ void tiles_add_diag(f32x4 (&T)[CholT<NVP>::NT], const float* s_, int nv, int lane) {
+  using K = CholT<NVP>;
+  const lds_f32* s = (const lds_f32*)s_;
+  asm volatile("" : "+v"(lane));
+  const int kk = lane >> 4, j = lane & 15;
+#pragma unroll
+  for (int jb = 0; jb < K::NB; ++jb) {
+    const int dof = 16 * jb + j;
+    float v = s[dof < NVP ? dof : 0];
+    v = dof < nv ? v : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[K::tix(jb, jb)][r] += (j == 4 * kk + r) ? v : 0.f;
+  }
+}
+
+template <int NVP>
+__device__ CHOL_INLINE void chol_factor_tiles(f32x4 (&T)[CholT<NVP>::NT], float* C_, float* s_invd_, int lane) {
+  using K = CholT<NVP>;
+  constexpr int NB = K::NB, LD = K::LD;
+  lds_f32* C = (lds_f32*)C_;
+  lds_f32* s_invd = (lds_f32*)s_invd_;
+  asm volatile("" : "+v"(lane));  // (per-lane predicates below: formed here, not hoisted out of the caller's solver loop)
+  const int kk = lane >> 4, j = lane & 15, jr = j & 3, jq = j >> 2;
+  lds_f32* cl = C + 4 * kk * LD + j;  // column 4 kk (+ 16 jb + r), row j (+ 16 i) of the factor
+#pragma unroll
+  for (int jb = 0; jb < NB; ++jb) {
+    if (K::SMALL_LAST && jb == NB - 1) {
+      // ---- the last 4 columns 16 jb + r: a[r][r'] = U(jb, jb)[reg r][lane r']
+      const f32x4 t = T[K::tix(jb, jb)];
+      const float a00 = lane_bcast(t[0], 0), a10 = lane_bcast(t[1], 0), a11 = lane_bcast(t[1], 1), a20 = lane_bcast(t[2], 0), a21 = lane_bcast(t[2], 1),
+                  a22 = lane_bcast(t[2], 2), a30 = lane_bcast(t[3], 0), a31 = lane_bcast(t[3], 1), a32 = lane_bcast(t[3], 2), a33 = lane_bcast(t[3], 3);
+      const float d0 = chol_pivot(a00), i0 = __builtin_amdgcn_rcpf(d0);
+      const float l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+      const float d1 = chol_pivot(a11 - l10 * a10), i1 = __builtin_amdgcn_rcpf(d1);
+      const float t21 = a21 - l20 * a10, l21 = t21 * i1, t31 = a31 - l30 * a10, l31 = t31 * i1;
+      const float d2 = chol_pivot(a22 - l20 * a20 - l21 * t21), i2 = __builtin_amdgcn_rcpf(d2);
+      const float t32 = a32 - l30 * a20 - l31 * t21, l32 = t32 * i2;
+      const float d3 = chol_pivot(a33 - l30 * a30 - l31 * t31 - l32 * t32), i3 = __builtin_amdgcn_rcpf(d3);
+      const int b0 = 16 * jb;
+      if (lane < NVP) {
+        C[(b0 + 0) * LD + lane] = lane == b0 + 1 ? l10 : lane == b0 + 2 ? l20 : lane == b0 + 3 ? l30 : 0.f;
+        C[(b0 + 1) * LD + lane] = lane == b0 + 2 ? l21 : lane == b0 + 3 ? l31 : 0.f;
+        C[(b0 + 2) * LD + lane] = lane == b0 + 3 ? l32 : 0.f;
+        C[(b0 + 3) * LD + lane] = 0.f;
+      }
+      if (lane < 4) s_invd[b0 + lane] = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : i3;
+      continue;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // ---- 1. diagonal block of the panel: a[kk][kk'] = U(jb, jb)[reg r][lane 16 kk + 4 kk' + r]; uniform LDL^T and inverse factor
+      const float s = T[K::tix(jb, jb)][r];
+      const float a00 = lane_bcast(s, r), a10 = lane_bcast(s, 16 + r), a11 = lane_bcast(s, 20 + r), a20 = lane_bcast(s, 32 + r), a21 = lane_bcast(s, 36 + r),
+                  a22 = lane_bcast(s, 40 + r), a30 = lane_bcast(s, 48 + r), a31 = lane_bcast(s, 52 + r), a32 = lane_bcast(s, 56 + r), a33 = lane_bcast(s, 60 + r);
+      const float d0 = chol_pivot(a00), i0 = __builtin_amdgcn_rcpf(d0);
+      const float l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+      const float d1 = chol_pivot(a11 - l10 * a10), i1 = __builtin_amdgcn_rcpf(d1);
+      const float t21 = a21 - l20 * a10, l21 = t21 * i1, t31 = a31 - l30 * a10, l31 = t31 * i1;
+      const float d2 = chol_pivot(a22 - l20 * a20 - l21 * t21), i2 = __builtin_amdgcn_rcpf(d2);
+      const float t32 = a32 - l30 * a20 - l31 * t21, l32 = t32 * i2;
+      const float d3 = chol_pivot(a33 - l30 * a30 - l31 * t31 - l32 * t32), i3 = __builtin_amdgcn_rcpf(d3);
+      const float invl = kk == 0 ? i0 : kk == 1 ? i1 : kk == 2 ? i2 : i3;
+      const bool below = jr > r || (jr == r && jq > kk);  // rows of the panel's own block that are eliminated later
+      float Wm[NB], Lm[NB];
+#if MJLAB_CHOL_PANEL == 1
+      // ---- 2 (experiment, MEASURED SLOWER: profiles/r05_v5). the panel's rows through the block's unit factor by substitution: every
+      // lane gets the four panel entries of its row -- the values of lane column j in the four 16-lane groups, by one
+      // v_permlane16_swap and two v_permlane32_swap -- forms w_0..w_3 with the uniform factor entries and keeps its own group's
+#pragma unroll
+      for (int i = jb; i < NB; ++i) {
+        const unsigned xv = __float_as_uint(T[K::tix(jb, i)][r]);
+        const auto pq = __builtin_amdgcn_permlane16_swap(xv, xv, false, false);  // [x0 x0 x2 x2], [x1 x1 x3 x3] (rows of 16 lanes)
+        const auto e = __builtin_amdgcn_permlane32_swap(pq[0], pq[0], false, false);  // [x0 x0 x0 x0], [x2 x2 x2 x2]
+        const auto o = __builtin_amdgcn_permlane32_swap(pq[1], pq[1], false, false);  // [x1 x1 x1 x1], [x3 x3 x3 x3]
+        const float b0 = __uint_as_float(e[0]), b1 = __uint_as_float(o[0]), b2 = __uint_as_float(e[1]), b3 = __uint_as_float(o[1]);
+        const float w1 = b1 - b0 * l10;
+        const float w2 = (b2 - b0 * l20) - w1 * l21;
+        const float w3 = ((b3 - b0 * l30) - w1 * l31) - w2 * l32;
+        const float W = kk == 0 ? b0 : kk == 1 ? w1 : kk == 2 ? w2 : w3;
+        Wm[i] = (i > jb || below) ? W : 0.f;
+        Lm[i] = Wm[i] * invl;
+      }
+#else
+      // ---- 2. W = panel x Linv^T, Linv = inverse of the block's unit factor (uniform, 6 multiply-adds): ONE MFMA per tile of the block
+      // row.  A operand: row 4 q of a 16 x 4 matrix = Linv[q][:] (lanes 0 4 8 12 | 20 24 28 | 40 44 | 60), B operand: the panel's
+      // register as it lies; register 0 of the result is W in operand layout (lane (g, j): row 16 i + j, column c(g)).  Masked to the
+      // rows eliminated later; L = W / D
+      const float m10 = -l10, m21 = -l21, m32 = -l32;
+      const float m20 = -(l20 + l21 * m10), m31 = -(l31 + l32 * m21), m30 = -(l30 + l31 * m10 + l32 * m20);
+      float G = j == 4 * kk ? 1.f : 0.f;  // unit diagonal: lanes 0, 20, 40, 60
+      G = lane == 4 ? m10 : G; G = lane == 24 ? m21 : G; G = lane == 8 ? m20 : G;  // (in the order the entries become available)
+      G = lane == 44 ? m32 : G; G = lane == 28 ? m31 : G; G = lane == 12 ? m30 : G;
+#pragma unroll
+      for (int i = jb; i < NB; ++i) {
+        const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x4f32(G, T[K::tix(jb, i)][r], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        Wm[i] = (i > jb || below) ? o[0] : 0.f;
+        Lm[i] = Wm[i] * invl;
+      }
+#endif
+      // ---- 3. columns c(kk) = 16 jb + 4 kk + r of the factor, every row (zero in the blocks above)
+      const bool colok = 16 * jb + 4 * kk + r < NVP;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        if (16 * i < NVP) {
+          const float v = i >= jb ? Lm[i < jb ? jb : i] : 0.f;
+          if (colok && (16 * i + 16 <= NVP || j < NVP - 16 * i)) cl[(16 * jb + r) * LD + 16 * i] = v;
+        }
+      }
+      if (colok && j == 0) s_invd[16 * jb + 4 * kk + r] = invl;
+      // ---- 4. trailing update of every tile that still holds entries to be eliminated (this block's own row first: the next panel)
+#pragma unroll
+      for (int jp = jb; jp < NB; ++jp) {
+        if (jp == jb && r == 3) continue;
+        const float nw = -Wm[jp];
+#pragma unroll
+        for (int i = jp; i < NB; ++i) T[K::tix(jp, i)] = __builtin_amdgcn_mfma_f32_16x16x4f32(nw, Lm[i], T[K::tix(jp, i)], 0, 0, 0);
+      }
+    }
+  }
+}
+// Solves A x = b with the factor as chol_factor_tiles left it; lane i owns b_i / x_i (lanes >= n must pass 0).
+template <int NVP>
+struct CholSolveT {
+  using K = CholT<NVP>;
+  template <int S>
+  static __device__ __forceinline__ void fwd(const float (&a)[NVP], float& b) {
+    if constexpr (S < NVP) {
+      constexpr int c = K::order(S);
+      b = fmaf(-a[c], lane_bcast(b, c), b);  // a[c] = Lu[i][c]: zero unless c is eliminated before i
+      fwd<S + 1>(a, b);
+    }
+  }
+  template <int S>
+  static __device__ __forceinline__ void bwd(const float (&at)[NVP], float& b) {
+    if constexpr (S >= 0) {
+      constexpr int c = K::order(S);
+      b = fmaf(-at[c], lane_bcast(b, c), b);  // at[c] = Lu[c][i]: zero unless c is eliminated after i
+      bwd<S - 1>(at, b);
+    }
+  }
+};
+template <int NVP>
+__device__ CHOL_INLINE float chol_solve_tiles(const float* C_, const float* s_invd_, int lane, float b) {
+  constexpr int LD = CholT<NVP>::LD;
+  const lds_f32* C = (const lds_f32*)C_;
+  const lds_f32* s_invd = (const lds_f32*)s_invd_;
+  const int li = lane < NVP ? lane : NVP - 1;
+  const float invd = s_invd[li];
+  {
+    float a[NVP];
+#pragma unroll
+    for (int c = 0; c < NVP; ++c) a[c] = C[c * LD + li];  // row li of Lu, one column at a time (unit stride across lanes)
+    CholSolveT<NVP>::template fwd<0>(a, b);
+  }
+  b *= invd;
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float at[NVP];
+#pragma unroll
+    for (int q = 0; q < NVP / 4; ++q) {
+      const f32x4 v = *(const lds_f32x4*)(C + li * LD + 4 * q);  // column li of Lu = row li of C
+      at[4 * q] = v.x; at[4 * q + 1] = v.y; at[4 * q + 2] = v.z; at[4 * q + 3] = v.w;
+    }
+    CholSolveT<NVP>::template bwd<NVP - 1>(at, b);
+  }
+  return b;
+}
+
 // y_i = sum_j M[i][j] v_j with M symmetric, dense row-major in GLOBAL memory (ld = n) -- worlds with more rows than
 // fit in LDS next to a packed copy of M (stage_solve's BIG instantiation) read M this way;
 // lane i owns v_i and y_i.  Row j is read coalesced (M[j][i] = M[i][j]), v_j comes from

@@ -39,10 +39,12 @@ def test_g1_kernels_are_cdna4_code(kernels):
   assert all(k in names for k in ("k_solve_integrate", "k_substep", "k_control_step"))
   for name, md in g1.items():
     ins = md["insts"]
-    assert ins.get("mfma", 0) >= 24, (name, ins)      # J^T D J: 6 lower 16 x 16 tiles x 4 row groups per block
+    # J^T D J (6 upper 16 x 16 tiles x 4 row groups per block) and, since round 5, the LDL^T of the Hessian taken apart in those
+    # tiles (51 MFMAs per factor site: common.h, chol_factor_tiles)
+    assert ins.get("mfma", 0) >= 24 + 2 * 51, (name, ins)
     assert ins.get("dpp", 0) >= 200, (name, ins)      # wave / row reductions without LDS
-    assert ins.get("pk_fma", 0) >= 300, (name, ins)   # the register-resident LDL^T sweep
+    assert ins.get("pk_fma", 0) >= 100, (name, ins)   # packed fp32 multiply-adds (the LDS-broadcast sweep of round 2-4 had 300 more: PGS keeps it)
     assert ins.get("setprio", 0) >= 4, (name, ins)    # wave issue priority by the world's constraint rows
     assert md["private_segment_fixed_size"] <= 256, (name, md)
   ctrl = next(md for n, md in g1.items() if "k_control_step" in n)
-  assert ctrl["vgpr_count"] == 128 and ctrl["vgpr_spill_count"] <= 48, ctrl
+  assert ctrl["vgpr_count"] == 128 and ctrl["vgpr_spill_count"] <= 24, ctrl  # (16 since the tiles are factored where they lie; 39-41 before)

