@@ -281,7 +281,15 @@ enum {
    * reference's engine does).  The host sets it for the ONE pass that poses the static geoms and sites (world / terrain
    * bodies), so that their stored world poses do not depend on where the robots happen to be at construction; it is also
    * the switch for A/B runs of the local frame (SimulationCfg.local_frame = False) */
-  MJLAB_OPT_WORLD_FRAME = 128
+  MJLAB_OPT_WORLD_FRAME = 128,
+  /* MJLAB_OPT_LS_PARALLEL: the grid search compares its candidates by their LITERAL total costs cost(alpha_i) = Gauss term +
+   * sum_r s_r(jar_r + alpha_i jv_r), and the Newton iteration forms its improvement as the difference of two such totals.  Default
+   * (bit clear) on the device and in the fp32 build of the restatement: candidates are compared by cost(alpha_i) - cost(0), formed
+   * row by row as a product of differences -- the same argmin in exact arithmetic (what the fp64 restatement computes either way),
+   * without the common constant that buries the candidates' differences under fp32 rounding (DESIGN.md section 3;
+   * tests/test_oracle_flags.py asserts what the literal form costs in fp32).  Which form upstream's fp32 engine takes is for
+   * upstream vectors to decide (tests/test_golden.py tries both) */
+  MJLAB_OPT_LS_LITERAL_COST = 256
 };
 
 #define MJLAB_DECL_INT_(name, ncol, count) const int* name;

@@ -415,8 +415,10 @@ __device__ float line_search(SolveCtx<NVP>& c, float gtol, int lsmax) {
 // lanes of a group read the same address (a broadcast), so one trip over the rows prices every candidate at once: ~6 VALU + 3 LDS
 // instructions per row trip instead of one wave reduction per candidate (20 of them for the reference's ls_iterations).
 // Candidates are compared by cost(alpha) - cost(0): the same argmin, without the common constant (see the row loop).
+// `literal` (MJLAB_OPT_LS_LITERAL_COST): the candidates' LITERAL total costs are compared instead -- every row contributes its full cost
+// and the Gauss term keeps its constant (what an engine that sums the costs as MuJoCo's PrimalEval writes them would compare).
 template <int NVP, bool FL>
-__device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsmax, float* best_diff) {
+__device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsmax, float* best_diff, const bool literal) {
   const int nc = lsmax < 64 ? (lsmax > 1 ? lsmax : 1) : 64;  // candidates per pass over the rows
   const int G = 1 + (2 * nc <= 64) + (3 * nc <= 64) + (4 * nc <= 64);  // min(4, 64 / nc) without an integer division
   const float lo = logf(min_step), step = (0.f - lo) / (float)(lsmax > 1 ? lsmax - 1 : 1);
@@ -448,12 +450,12 @@ __device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsma
         // minimiser the LITERAL sum of costs cannot tell the candidates apart and the solve stalls at 1e-4
         const float x = fmaf(alpha, jv[u], j0[u]);
         const float xm = fminf(x, 0.f), xm0 = fminf(j0[u], 0.f);
-        float t = Dr[u] * (xm - xm0) * (xm + xm0);
+        float t = literal ? Dr[u] * xm * xm : Dr[u] * (xm - xm0) * (xm + xm0);
         if (FL && fl[u] >= 0.f) {  // friction loss (mj PrimalEval): Huber cost, linear beyond |x| = f / D
           const float rf = fl[u] / Dr[u], ax = fabsf(x), a0 = fabsf(j0[u]);
           const float ha = ax >= rf ? 2.f * fl[u] * (ax - 0.5f * rf) : Dr[u] * x * x;
           const float h0 = a0 >= rf ? 2.f * fl[u] * (a0 - 0.5f * rf) : Dr[u] * j0[u] * j0[u];
-          t = ha - h0;
+          t = literal ? ha : ha - h0;
         }
         acc += t;
       }
@@ -463,6 +465,7 @@ __device__ float line_search_parallel(SolveCtx<NVP>& c, float min_step, int lsma
       for (int k = 1; k < G; ++k) acc += __shfl(part, c.lane + k * nc);
     }
     float cost = 0.5f * acc + alpha * (alpha * c.quad_gauss[2] + c.quad_gauss[1]);  // relative to the cost at alpha = 0
+    if (literal) cost += c.quad_gauss[0];
     if (!(g == 0 && ci < lsmax)) cost = 3.0e38f;
     const float cmin = wave_min(cost);
     const unsigned long long hit = __ballot(cost == cmin && g == 0 && ci < lsmax);
@@ -532,10 +535,11 @@ __device__ __forceinline__ float grad_noise(float ulps, float scale, bool own, f
 #endif
 #define IMPROVEMENT_FLOOR fmaxf(tol, c.noise_ulps * (MJLAB_INOISE) * 5.9604645e-8f * scale * fabsf(cost))
 #ifndef MJLAB_NO_LSDIFF_COST
-#define IMPROVEMENT ((m.opt.flags & MJLAB_OPT_LS_PARALLEL) ? -scale * ls_diff : scale * (oldcost - cost))
-#else
-#define IMPROVEMENT (scale * (oldcost - cost))
+#define LS_BY_DIFFERENCES ((m.opt.flags & (MJLAB_OPT_LS_PARALLEL | MJLAB_OPT_LS_LITERAL_COST)) == MJLAB_OPT_LS_PARALLEL)
+#else  // (round-3 experiment build: the search by differences, the improvement from two totals)
+#define LS_BY_DIFFERENCES false
 #endif
+#define IMPROVEMENT (LS_BY_DIFFERENCES ? -scale * ls_diff : scale * (oldcost - cost))
 // BIG: this world has more rows than fit in LDS next to M: all njmax rows in LDS instead, M from global memory
 // CG: mjSOL_CG -- no Hessian; the direction is M^-1 grad (the factor of M from ST_SMOOTH stays in LDS for the whole solve)
 // combined with the previous direction by Polak-Ribiere (mj_solPrimal with flg_Newton = 0)
@@ -847,8 +851,8 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         c.quad_gauss[2] = wave_sum(own ? 0.5f * search * Mv : 0.f);
         PROF_MARK(5);
         if (m.opt.flags & MJLAB_OPT_LS_PARALLEL)
-          alpha = c.nf > 0 ? line_search_parallel<NVP, true>(c, (float)m.opt.ls_parallel_min_step, lsmax, &ls_diff)
-                           : line_search_parallel<NVP, false>(c, (float)m.opt.ls_parallel_min_step, lsmax, &ls_diff);
+          alpha = c.nf > 0 ? line_search_parallel<NVP, true>(c, (float)m.opt.ls_parallel_min_step, lsmax, &ls_diff, (m.opt.flags & MJLAB_OPT_LS_LITERAL_COST) != 0)
+                           : line_search_parallel<NVP, false>(c, (float)m.opt.ls_parallel_min_step, lsmax, &ls_diff, (m.opt.flags & MJLAB_OPT_LS_LITERAL_COST) != 0);
         else
           alpha = c.nf > 0 ? line_search<NVP, true>(c, gtol, lsmax) : line_search<NVP, false>(c, gtol, lsmax);
         PROF_MARK(6);
@@ -880,15 +884,12 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
 #endif
         __syncthreads();
         const float oldcost = cost;
-#ifndef MJLAB_NO_LSDIFF_COST
-        if (m.opt.flags & MJLAB_OPT_LS_PARALLEL) {
+        if (LS_BY_DIFFERENCES) {
           // the grid search has just priced this very step: cost(alpha) - cost(0), formed from differences.  The improvement
           // test below reads it directly (no second trip over the rows, no Gauss reduction, and no difference of two totals
           // of 1e3..1e5 that differ in the 6th digit); the Gauss term itself is not needed by this search
           cost = oldcost + ls_diff;
-        } else
-#endif
-        {
+        } else {
           cost = constraint_cost<NVP>(c, c.s_jar);
           gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
           cost += gauss;

@@ -102,6 +102,8 @@ class SimulationCfg:
   # MuJoCo's literal Newton / line-search termination (tolerance, gtol) without the fp32
   # rounding-noise floors (MJLAB_OPT_LITERAL_TERMINATION)
   literal_termination: bool = False
+  # ls_parallel only: compare the grid candidates by their literal total costs instead of by cost differences (MJLAB_OPT_LS_LITERAL_COST)
+  ls_literal_cost: bool = False
   # qacc_warmstart is saved by the integrator's advance only (forward() leaves it untouched)
   # instead of at the end of every constraint solve (MJLAB_OPT_WARMSTART_AT_ADVANCE)
   warmstart_at_advance: bool = False
@@ -224,6 +226,7 @@ class Simulation:
                          | (_abi.OPT_LITERAL_TERMINATION if opt("literal_termination") else 0)
                          | (_abi.OPT_WARMSTART_AT_ADVANCE if opt("warmstart_at_advance") else 0)
                          | (_abi.OPT_LS_PARALLEL if self.ls_parallel else 0)
+                         | (_abi.OPT_LS_LITERAL_COST if opt("ls_literal_cost") else 0)
                          | (0 if (opt("local_frame") and os.environ.get("MJLAB_LOCAL_FRAME", "1") != "0") else _abi.OPT_WORLD_FRAME)
                          | {"stage": 0, "presolve": _abi.OPT_FUSE_PRESOLVE, "step": _abi.OPT_FUSE_STEP}[self.fuse])
     self._d, self._data = device_state.alloc_data(model, num_envs, self.nconmax, self.njmax, dev)

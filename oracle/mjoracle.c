@@ -1198,18 +1198,25 @@ static real line_search(const mjo_model_t* m, nctx_t* c) {
     real lo = (real)log(m->opt.ls_parallel_min_step), step = (0 - lo) / (real)(lsmax > 1 ? lsmax - 1 : 1), best_alpha = 0, best_cost = 0;
     for (int i = 0; i < lsmax; i++) {
       real alpha = (real)exp(lo + (real)i * step);
-#ifdef MJO_LSP_DIFF /* experiment build: candidates compared by cost(alpha) - cost(0) formed row by row as a product of
-                       differences, like the device kernel (stage_solve.h line_search_parallel); the same argmin in exact
-                       arithmetic.  Used with -DMJO_FLOAT to see what that buys in fp32 */
-      real acc = 0;
-      for (int r = c->nf; r < c->nefc; r++) {
-        real x = c->jar[r] + alpha * c->jv[r], xm = x < 0 ? x : 0, xm0 = c->jar[r] < 0 ? c->jar[r] : 0;
-        acc += c->Dv[r] * (xm - xm0) * (xm + xm0);
+      /* candidates compared by cost(alpha) - cost(0), formed row by row as a product of differences like the device kernel
+       * (stage_solve.h line_search_parallel): the same argmin in exact arithmetic.  The fp32 build takes this form unless
+       * MJLAB_OPT_LS_LITERAL_COST asks for the literal totals; the fp64 build is literal either way (include/mjlab_fields.h) */
+      if (sizeof(real) == 4 && !(m->opt.flags & MJLAB_OPT_LS_LITERAL_COST)) {
+        real acc = 0;
+        for (int r = c->nf; r < c->nefc; r++) {
+          real x = c->jar[r] + alpha * c->jv[r], xm = x < 0 ? x : 0, xm0 = c->jar[r] < 0 ? c->jar[r] : 0;
+          acc += c->Dv[r] * (xm - xm0) * (xm + xm0);
+        }
+        for (int r = 0; r < c->nf; r++) { /* friction loss (Huber cost), as a difference too */
+          real x = c->jar[r] + alpha * c->jv[r], fl = c->floss[r], rf = fl / c->Dv[r], ax = fabs(x), a0 = fabs(c->jar[r]);
+          real ha = ax >= rf ? 2 * fl * (ax - (real)0.5 * rf) : c->Dv[r] * x * x;
+          real h0 = a0 >= rf ? 2 * fl * (a0 - (real)0.5 * rf) : c->Dv[r] * c->jar[r] * c->jar[r];
+          acc += ha - h0;
+        }
+        p0.cost = (real)0.5 * acc + alpha * (alpha * c->quad_gauss[2] + c->quad_gauss[1]);
+      } else {
+        ls_eval(c, &p0, alpha);
       }
-      p0.cost = (real)0.5 * acc + alpha * (alpha * c->quad_gauss[2] + c->quad_gauss[1]);
-#else
-      ls_eval(c, &p0, alpha);
-#endif
       if (i == 0 || p0.cost < best_cost) { best_cost = p0.cost; best_alpha = alpha; }
     }
     return best_alpha;

@@ -136,7 +136,10 @@ _MARGIN: dict = {}
 WORST, ROWS_1X, ROWS_WORST, SANITY = 3.0, 0.99, 1.0, 3.0  # measured r04_v11: every row within 1 x but 1 of 320 (joint_vel, tracking: 1.08 x)
 # the rough scene: a foot on a stair edge gains or loses a contact row between two fp32 engines now and then, and that world's step
 # differs at the 1e-4 level (the parity gate's "deep / capped" class); such rows are bounded in number and size
-ROUGH = {"rows_worst": 0.995, "sanity": float("inf")}  # measured r04_v27: 4 of 1280 world-steps beyond 3 x (joint_pos), the worst at 1.9e-2 rad
+# (measured r04_v27 and r05_v10: 3-4 of 1280 world-steps beyond 3 x, the worst at 1.9e-2 rad in joint_pos (820 x its bound) and 3.8 rad/s
+# in joint_vel (760 x): one 20 ms control step with / without one foot contact's force.  The cap on such rows is that event's size
+# x 3.5 -- 0.06 rad, 15 rad/s --, not infinity: VERDICT round 4, item 3d)
+ROUGH = {"rows_worst": 0.995, "sanity": 3000.0}
 
 
 def compare_terms(meta, z, k, dv, atol, tag, stats):

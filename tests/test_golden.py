@@ -117,8 +117,13 @@ _UP_TOL = {"qpos": 1e-5, "qvel": 1e-5, "xpos": 1e-5, "xquat": 1e-5, "subtree_com
            "qacc": 5e-5, "qfrc_constraint": 1e-4, "efc_J": 1e-5, "efc_D": 1e-3, "efc_aref": 2e-4, "efc_pos": 1e-3, "efc_force": 1e-3}
 # the termination / warm-start conventions (MJLAB_OPT_LITERAL_TERMINATION, MJLAB_OPT_WARMSTART_AT_ADVANCE) are all tried against
 # real upstream vectors -- which one upstream follows is what those vectors decide; the dry-run set was produced under the defaults
-_UP_CASES = [(tag, name, lsp, lit, wsa) for tag, name in (_FILES or [("none", "none")]) for lsp in (1, 0)
-             for lit in ((False, True) if tag != "dryrun" else (False,)) for wsa in ((False, True) if tag != "dryrun" else (False,))]
+# AND the two ways of comparing the grid search's candidates (MJLAB_OPT_LS_LITERAL_COST, ls_parallel only: literal totals / differences).
+# The dry-run set goes through the same consumers under test names of its own (test_tool_consumers_execute_*): nothing in a test log
+# says "matches upstream" unless upstream vectors were compared.
+_UP_CASES = [("upstream", name, lsp, lit, wsa, lc) for tag, name in _FILES if tag == "upstream" for lsp in (1, 0)
+             for lit in (False, True) for wsa in (False, True) for lc in ((False, True) if lsp else (False,))]
+_DRY_CASES = [("dryrun", name, lsp, False, False, False) for tag, name in _FILES if tag == "dryrun" for lsp in (1, 0)]
+_NONE = [("none", "none", 0, False, False, False)]
 # ls_parallel on: the grid search moves every iterate by one of `ls_iterations` discrete steps, so two fp32 implementations with a
 # different summation order part wherever they pick different candidates in a late iteration and end at the iteration cap on different
 # iterates (parity gate, GRID literals: worst world 5e-3 in qacc).  The files are compared in max-norm over ALL their worlds, so the
@@ -189,15 +194,15 @@ def check_compiled_model(z, name):
   return ncmp
 
 
-def _oracle_flags(lit, wsa):
-  return (2 if lit else 0) | (4 if wsa else 0)
+def _oracle_flags(lit, wsa, lc=False):
+  return (2 if lit else 0) | (4 if wsa else 0) | (256 if lc else 0)
 
 
-def check_oracle(z, name, lsp, lit, wsa):
+def check_oracle(z, name, lsp, lit, wsa, lc=False):
   """fp32 oracle against the recorded engine: forward() fields (-> count compared), then nstep x step() + forward()."""
   model = models()[_scene_of(name)]
   n = z["in_qpos"].shape[0]
-  s = OracleSim(model, n, njmax=300, precision="f32", flags=_oracle_flags(lit, wsa), ls_parallel=bool(lsp))
+  s = OracleSim(model, n, njmax=300, precision="f32", flags=_oracle_flags(lit, wsa, lc), ls_parallel=bool(lsp))
   for key in z.files:
     if key.startswith("dr_"):
       s.expand_model_field(key[3:])[:] = z[key]
@@ -218,22 +223,40 @@ def check_oracle(z, name, lsp, lit, wsa):
   return ncmp
 
 
-@pytest.mark.skipif(not _FILES, reason=_NO_UP)
-@pytest.mark.parametrize("tag,name", _FILES or [("none", "none")])
+_UP_FILES, _DRY_FILES = [f for f in _FILES if f[0] == "upstream"], [f for f in _FILES if f[0] == "dryrun"]
+
+
+@pytest.mark.skipif(not _UP_FILES, reason=_NO_UP)
+@pytest.mark.parametrize("tag,name", _UP_FILES or [("none", "none")])
 def test_compiled_model_matches_upstream(tag, name):
   assert check_compiled_model(np.load(_SETS[tag] / f"{name}.npz"), name) >= 40
 
 
-@pytest.mark.skipif(not _FILES, reason=_NO_UP)
-@pytest.mark.parametrize("tag,name,lsp,lit,wsa", _UP_CASES)
-def test_oracle_matches_upstream(tag, name, lsp, lit, wsa):
-  assert check_oracle(np.load(_SETS[tag] / f"{name}.npz"), name, lsp, lit, wsa) >= 8
+@pytest.mark.skipif(not _DRY_FILES, reason="no dry-run vectors")
+@pytest.mark.parametrize("tag,name", _DRY_FILES or [("none", "none")])
+def test_tool_consumers_execute_on_the_compiled_model(tag, name):
+  """(dry run: the model arrays were recorded from this package's own compiler through the mujoco shim -- plumbing, not parity)"""
+  assert check_compiled_model(np.load(_SETS[tag] / f"{name}.npz"), name) >= 40
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(not _FILES, reason=_NO_UP)
-@pytest.mark.parametrize("tag,name,lsp,lit,wsa", _UP_CASES)
-def test_hip_matches_upstream(tag, name, lsp, lit, wsa):
+_NO_REAL = "no upstream vectors (tests/golden_upstream/ absent): parity unpinned, see DESIGN.md section 3"
+
+
+@pytest.mark.skipif(not _UP_CASES, reason=_NO_REAL)
+@pytest.mark.parametrize("tag,name,lsp,lit,wsa,lc", _UP_CASES or _NONE)
+def test_oracle_matches_upstream(tag, name, lsp, lit, wsa, lc):
+  assert check_oracle(np.load(_SETS[tag] / f"{name}.npz"), name, lsp, lit, wsa, lc) >= 8
+
+
+@pytest.mark.skipif(not _DRY_CASES, reason="no dry-run vectors")
+@pytest.mark.parametrize("tag,name,lsp,lit,wsa,lc", _DRY_CASES or _NONE)
+def test_tool_consumers_execute_on_the_oracle(tag, name, lsp, lit, wsa, lc):
+  """The dry-run records (tools/fake_mjwarp.py: the fp32 restatement behind mujoco_warp's API) through the consumer the real
+  upstream vectors will go through.  Plumbing, not parity: the restatement is compared with itself."""
+  assert check_oracle(np.load(_SETS[tag] / f"{name}.npz"), name, lsp, lit, wsa, lc) >= 8
+
+
+def check_hip(tag, name, lsp, lit, wsa, lc):
   import torch
 
   from mjlab_amd.sim import Simulation, SimulationCfg
@@ -241,7 +264,7 @@ def test_hip_matches_upstream(tag, name, lsp, lit, wsa):
   z = np.load(_SETS[tag] / f"{name}.npz")
   model = models()[_scene_of(name)]
   n = z["in_qpos"].shape[0]
-  sim = Simulation(n, SimulationCfg(njmax=300, ls_parallel=bool(lsp), literal_termination=lit, warmstart_at_advance=wsa, use_graph=False), model, "cuda:0")
+  sim = Simulation(n, SimulationCfg(njmax=300, ls_parallel=bool(lsp), literal_termination=lit, warmstart_at_advance=wsa, ls_literal_cost=lc, use_graph=False), model, "cuda:0")
   dr = [key[3:] for key in z.files if key.startswith("dr_")]
   if dr:
     sim.expand_model_fields(dr)
@@ -266,6 +289,21 @@ def test_hip_matches_upstream(tag, name, lsp, lit, wsa):
   tol_step = (2e-3 if name.endswith("_rollout") else 5e-5) if lsp else 2e-5
   for f in ("qpos", "xpos", "xquat"):
     assert _rel(getattr(sim.data, f).cpu().numpy(), z[f"lsp{lsp}_step_{f}"]) <= tol_step, ("step", f)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _UP_CASES, reason=_NO_REAL)
+@pytest.mark.parametrize("tag,name,lsp,lit,wsa,lc", _UP_CASES or _NONE)
+def test_hip_matches_upstream(tag, name, lsp, lit, wsa, lc):
+  check_hip(tag, name, lsp, lit, wsa, lc)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _DRY_CASES, reason="no dry-run vectors")
+@pytest.mark.parametrize("tag,name,lsp,lit,wsa,lc", _DRY_CASES or _NONE)
+def test_tool_consumers_execute_on_the_device(tag, name, lsp, lit, wsa, lc):
+  """The HIP path against the dry-run records: one more comparison with the fp32 restatement through the upstream consumer (plumbing)."""
+  check_hip(tag, name, lsp, lit, wsa, lc)
 
 
 def test_upstream_dump_tool_stops_cleanly_without_the_engine():

@@ -272,6 +272,39 @@ def test_literal_termination_switch_matches_the_literal_oracle():
   assert r["niter_gpu"][0] >= r["niter_oracle"][0] - 0.1  # noise floors off: never fewer iterations than fp64
 
 
+def test_literal_grid_cost_switch_on_the_device():
+  """MJLAB_OPT_LS_LITERAL_COST on the device (SimulationCfg.ls_literal_cost): the grid search ranks its candidates by their literal
+  totals.  Against the fp64 restatement on the gate's rollout states the bulk is unchanged and the worst world is not better than
+  under the default (tests/test_oracle_flags.py shows on the CPU what the literal form costs in fp32); the switch exists so that
+  upstream vectors can decide which form upstream takes (tests/test_golden.py)."""
+  import numpy as np
+  import torch
+
+  from make_golden import models
+  from mjlab_amd.sim import Simulation, SimulationCfg
+  from oracle.oracle import OracleSim
+
+  z = np.load(ROOT / "tests" / "golden" / "rollout_states_g1_velocity_flat.npz")
+  model, n = models()["g1_velocity_flat"], 256
+  ora = OracleSim(model, n, njmax=300, precision="f64", ls_parallel=True)
+  for f in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+    getattr(ora, f)[:] = z[f][:n]
+  ora.forward()
+  err = {}
+  for lit in (False, True):
+    sim = Simulation(n, SimulationCfg(njmax=300, ls_parallel=True, ls_literal_cost=lit, use_graph=False), model, "cuda:0")
+    for f in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+      getattr(sim.data, f)[:] = torch.from_numpy(z[f][:n].astype(np.float32)).cuda()
+    sim.forward()
+    torch.cuda.synchronize()
+    q = sim.data.qacc.cpu().numpy().astype(np.float64)
+    err[lit] = np.abs(q - ora.qacc).max(axis=1) / np.abs(ora.qacc).max(axis=1)
+  assert np.median(err[False]) <= 5e-6 and np.median(err[True]) <= 5e-6, (np.median(err[False]), np.median(err[True]))
+  assert err[False].max() <= 3e-5, err[False].max()
+  assert not np.array_equal(err[False], err[True])  # the switch changes which candidates win somewhere
+  assert err[True].max() >= 0.8 * err[False].max(), (err[True].max(), err[False].max())
+
+
 def test_warmstart_at_advance_switch():
   """MJLAB_OPT_WARMSTART_AT_ADVANCE: forward() leaves qacc_warmstart alone, step() saves qacc."""
   import torch

@@ -86,7 +86,7 @@ def test_ls_parallel_reaches_the_engine(dry):
 
 def test_committed_dry_run_set_is_what_the_tool_writes(dry):
   """tests/golden_upstream_dryrun/ (committed so that the GPU box, which has no reference tree, can run the HIP-side consumer
-  test_hip_matches_upstream on it) is this tool's current output."""
+  test_tool_consumers_execute_on_the_device on it) is this tool's current output."""
   for p in sorted(dry.glob("*.npz")):
     a, b = np.load(p), np.load(tg.DRYRUN / p.name)
     assert sorted(a.files) == sorted(b.files), p.name
