@@ -86,6 +86,58 @@ def cpu_baseline(scene: str, seed: int) -> dict:
   }
 
 
+def sharded_full_env(args, info, dev, model, tracking):
+  """env-steps/s of the reference's own environment, one GraphedRlEnv per rank, with the learner exchange on the timed path
+  (GraphedRlEnv.step_sharded).  Returns (value over all ranks, note); (None, reason) where the reference's source is absent."""
+  import torch
+
+  from mjlab_amd import dist as mdist
+
+  sys.path.insert(0, str(ROOT / "tools"))
+  import reference_env
+
+  task = {"g1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-G1", "go1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-Go1",
+          "g1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-G1", "go1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-Go1",
+          "g1_tracking_flat": "Mjlab-Tracking-Flat-Unitree-G1"}.get(args.scene)
+  have = torch.tensor([0.0 if (task is None or reference_env.locate_reference() is None) else 1.0])
+  if mdist.max_over_ranks(1.0 - float(have), dev) > 0.0:  # (agreed on by every rank: nobody waits in a collective for a rank that skipped)
+    return None, "not measured: the reference's source is not on every rank's machine (tools/stage_reference.sh stages it)"
+  from mjlab_amd.graphed_env import GraphedRlEnv
+
+  cfg_edit = None
+  if tracking:
+    import tempfile
+
+    from mjlab_amd.rollout import write_motion_npz
+
+    motion_path = str(Path(tempfile.mkdtemp()) / "motion.npz")
+    write_motion_npz(motion_path, model, dev)
+
+    def cfg_edit(cfg, _p=motion_path):
+      cfg.commands.motion.motion_file = _p
+
+  env = reference_env.make_env(task, num_envs=args.envs_per_gpu, device=dev, seed=mdist.seed_for_rank(args.seed, info), cfg_edit=cfg_edit)
+  env.reset()
+  genv = GraphedRlEnv(env, shard=info)
+  na = sum(env.action_manager.action_term_dim)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(args.seed)
+  n = max(50, min(args.steps, 200))
+  for k in range(20 + n):
+    if k == 20:
+      mdist.barrier()
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+    a_all = 2.0 * torch.rand((info.global_envs, na), device=dev, generator=gen) - 1.0 if info.rank == 0 else None
+    genv.step_sharded(a_all)
+  torch.cuda.synchronize()
+  mdist.barrier()
+  t = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+  return info.global_envs * n / t, (f"{task}: GraphedRlEnv(env, shard) per rank x{info.world_size}, {n} timed steps after 20; per step: action scatter, the captured control step "
+                                    f"({'two graphs around the all-reduce of the reset flag' if genv.graph_b is not None else 'one graph'}), all-reduce of the log sums"
+                                    f"{' and the failure histogram' if tracking else ''}, gather of the observation groups + reward + dones to rank 0")
+
+
 def main() -> None:
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -413,6 +465,16 @@ def main() -> None:
     if dom_ms is None:
       dom_ms, dom_name = solve_ms, "k_solve_integrate"
 
+  # ---- N > 1: the FULL environment sharded (reference env per rank behind GraphedRlEnv(env, shard=info): the tracking histogram and
+  # the reset logging all-reduced, actions scattered from / observation groups + reward + dones gathered to the learner); every
+  # rank takes part, rank 0 reports.  Only where the reference's source is staged (like value_full_env).
+  full_env_sharded, full_env_sharded_note = None, None
+  if not args.no_full_env and (info.world_size > 1 or mdist._FORCE):
+    try:
+      full_env_sharded, full_env_sharded_note = sharded_full_env(args, info, dev, model, tracking)
+    except Exception as e:  # noqa: BLE001
+      full_env_sharded_note = f"failed: {type(e).__name__}: {e}"
+
   if info.rank == 0:
     n_env = args.envs_per_gpu * info.world_size
     value = n_env * args.steps / elapsed
@@ -575,6 +637,8 @@ def main() -> None:
       "value_full_env_note": full_env_note,
       "value_full_env_graphed": full_env_graphed,
       "value_full_env_graphed_note": full_env_graphed_note,
+      "value_full_env_sharded": full_env_sharded,
+      "value_full_env_sharded_note": full_env_sharded_note,
       "std_over_5": float(np.std(chunk_rates)) if nchunk == 5 else None,
       "chunk_values": chunk_rates,
       "per_rank_ms_per_step": rank_ms,

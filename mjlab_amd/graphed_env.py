@@ -249,11 +249,26 @@ class GraphedRlEnv:
   """
 
   def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None,
-               fused_relative_poses: bool = False, forward: str = "reference", fused_entity_data: bool | None = None) -> None:
+               fused_relative_poses: bool = False, forward: str = "reference", fused_entity_data: bool | None = None,
+               shard: Any = None, replicate_rng: bool = False) -> None:
+    """``shard`` (mjlab_amd.dist.ShardInfo): this environment is rank ``shard.rank``'s slice of a batch of ``shard.global_envs``
+    environments (worlds are independent, one process per GPU).  The control step itself needs nothing from the other
+    ranks; what the reference computes over the WHOLE batch is exchanged by ``_exchange()`` right after the step -- outside the
+    captured graph, on the stream the replay ran on: the tracking task's failure histogram (all-reduce, sum) before the sampler's
+    update, the reset logging's sums and counts (all-reduce, sum) before their division.  ``step_sharded()`` adds north_star's
+    learner exchange: actions scattered from the learner, observation groups + reward + dones gathered to it.
+    ``replicate_rng``: draw the step's uniforms for the global batch on every rank and keep this rank's rows (tests: a sharded run then
+    equals the single-process run of the concatenated batch draw for draw; production ranks seed their own generators)."""
     from mjlab.third_party.isaaclab.isaaclab.utils import math as rmath  # the reference's own helpers (pure torch)
 
     self.env, self._m = env, rmath
     self.n, self.device = env.num_envs, env.device
+    self.shard, self._replicate_rng = shard, bool(replicate_rng)
+    self._sharded = shard is not None and shard.world_size > 1
+    if shard is not None and shard.envs_per_rank != env.num_envs:
+      raise ValueError(f"shard.envs_per_rank = {shard.envs_per_rank}, the environment holds {env.num_envs}")
+    self._any_reset = torch.zeros((), device=self.device)  # "some environment reset in this step" (of the global batch after _exchange_any)
+    self._bin_calls: dict = {}  # sharded MotionCommand: per resample call of a step, this rank's failure histogram + an "any" flag
     # the event / command terms as one HIP launch each (mjlab_amd/env_terms.py) wherever the environment lives on the GPU; the
     # torch restatements below compute the same from the same uniforms (CPU runs over the oracle; fused_terms=False: A/B on the GPU)
     self._fused = torch.device(self.device).type == "cuda" if fused_terms is None else bool(fused_terms)
@@ -303,6 +318,7 @@ class GraphedRlEnv:
     self._obs_memo_on = False
     self._share_observation_terms()
     self.graph: torch.cuda.CUDAGraph | None = None
+    self.graph_b: torch.cuda.CUDAGraph | None = None  # sharded: the second half of the step (after the mid-step exchange)
     env.sim.use_graph = False  # the launches are captured here, once, for the whole control step
     if capture:
       self.capture(warmup)
@@ -548,8 +564,16 @@ class GraphedRlEnv:
       t.copy_(c)
     torch.cuda.synchronize(self.device)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-      self._body()
+    self.graph_b = None
+    if self._sharded and self._forward_all:  # two halves around the one mid-step exchange (see _step_body_b)
+      with torch.cuda.graph(g):
+        self._run_cached(self._step_body_a)
+      self.graph_b = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(self.graph_b):
+        self._run_cached(self._step_body_b)
+    else:
+      with torch.cuda.graph(g):
+        self._body()
     self.graph = g
     # what a replay rewrites: the tensors bound at capture time.  step() binds the environment's attributes back to them after
     # every replay -- the reference's reset() REBINDS obs_buf (envs/manager_based_rl_env.py:95-101) and _reset_idx rebinds
@@ -600,11 +624,16 @@ class GraphedRlEnv:
     self._action_in.copy_(action)
     if self.graph is not None:
       self.graph.replay()
+      if self.graph_b is not None:
+        self._exchange_any()
+        self.graph_b.replay()
       env.obs_buf, env.reward_buf, env.reset_terminated, env.reset_time_outs, env.reset_buf = self._out
       env.observation_manager._obs_buffer = env.obs_buf
       env.extras["log"] = self._log_pub
     else:
       self._body()
+    if self._sharded:
+      self._exchange()
     env._sim_step_counter += env.cfg.decimation
     env.common_step_counter += 1
     cm = env.curriculum_manager  # host copy of the command ranges for readers of cfg.ranges (the graph reads the device tensors)
@@ -616,6 +645,65 @@ class GraphedRlEnv:
     if env.common_step_counter % 16 == 0 and hasattr(env.sim, "update_priority_thresholds"):
       env.sim.update_priority_thresholds()  # scheduling hint of the physics kernels (not part of the graph: it reads quantiles)
     return env.obs_buf, env.reward_buf, env.reset_terminated, env.reset_time_outs, env.extras
+
+  # ---------------------------------------------------------------------------------------------------------------- sharding
+  def _all_reduce_sum(self, t: torch.Tensor) -> None:
+    import torch.distributed as tdist
+
+    if t.is_cuda and tdist.get_backend() == "gloo":  # testing path: several ranks on one GPU, staged through the host
+      h = t.cpu()
+      tdist.all_reduce(h, op=tdist.ReduceOp.SUM)
+      t.copy_(h)
+    else:
+      tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+
+  def _exchange_any(self) -> None:
+    if self._sharded and self._forward_all:
+      self._all_reduce_sum(self._any_reset.view(1))
+
+  def _exchange(self) -> None:
+    """What the reference computes over the whole batch, made global after this rank's step.  Two small all-reduces per
+    control step (the tracking task: + one), enqueued on the stream the step ran on; every rank ends with the same sampler state
+    and the same log numbers as a single process stepping the concatenated batch."""
+    env = self.env
+    for name in env.command_manager.active_terms:
+      term = env.command_manager.get_term(name)
+      buf = self._bin_calls.get(id(term))
+      if buf is None:
+        continue
+      self._all_reduce_sum(buf)  # per resample call of the step: [histogram of the failed environments' bins, how many ranks had any]
+      cur = term._current_bin_failed
+      for c in range(buf.shape[0]):  # commands.py:258-265: a call with failures REPLACES the histogram, one without leaves it
+        cur.copy_(torch.where(buf[c, -1] > 0, buf[c, :-1], cur))
+      term.bin_failed_count.copy_(term.cfg.adaptive_alpha * cur + (1 - term.cfg.adaptive_alpha) * term.bin_failed_count)
+      cur.zero_()
+      buf.zero_()
+    if self._log_vec is not None and self._log_keys:
+      self._all_reduce_sum(self._log_raw)
+      self._finish_log(self._log_raw, getattr(self, "_log_first", False))
+      self._log_first = False
+
+  def step_sharded(self, actions_global: torch.Tensor | None, learner: int = 0, to_all: bool = False):
+    """One control step of the sharded batch with north_star's learner exchange (mjlab_amd/dist.py): the learner's actions for ALL
+    environments -- ``(shard.global_envs, action_dim)`` on rank `learner`, None elsewhere -- are scattered, every rank steps its
+    slice, and ONE fused row block [observation groups | reward | terminated | time_outs] per environment is gathered back to the
+    learner (``to_all``: to every rank).  Returns ``(local, gathered)``: this rank's ``step()`` result and, on the learner, the
+    global ``(obs dict, reward, terminated, time_outs)`` in rank order (None elsewhere)."""
+    from . import dist as mdist
+
+    info = self.shard if self.shard is not None else mdist.ShardInfo(0, 1, 0, self.n)
+    adim = self._action_in.shape[1]
+    mine = mdist.scatter_actions(info, actions_global, adim, self.device, src=learner)
+    obs, rew, term, tout, extras = self.step(mine)
+    groups = list(obs)
+    widths = [obs[g].shape[1] for g in groups]
+    rows = torch.cat([obs[g] for g in groups] + [rew[:, None], term[:, None].to(rew.dtype), tout[:, None].to(rew.dtype)], dim=1)
+    got = mdist.gather_rollout(info, rows, dst=learner, to_all=to_all)
+    gathered = None
+    if got is not None:
+      parts = torch.split(got, widths + [1, 1, 1], dim=1)
+      gathered = ({g: parts[i] for i, g in enumerate(groups)}, parts[-3][:, 0], parts[-2][:, 0] > 0.5, parts[-1][:, 0] > 0.5)
+    return (obs, rew, term, tout, extras), gathered
 
   # ------------------------------------------------------------------------------------------------------------------- body
   def _invalidate(self, written: frozenset | None = None) -> None:
@@ -652,11 +740,14 @@ class GraphedRlEnv:
   def _body(self) -> None:
     """One control step with the property caches switched on for its duration (outside it -- the eager ``env.reset()``, a caller
     reading ``robot.data`` -- the reference's objects behave as the reference's)."""
+    self._run_cached(self._step_body)
+
+  def _run_cached(self, fn: Any) -> None:
     self._caching[0] = True
     for c in self._data_caches:
       c.activate(True)
     try:
-      self._step_body()
+      fn()
     finally:
       self._caching[0] = False
       for c in self._data_caches:
@@ -666,8 +757,14 @@ class GraphedRlEnv:
 
   def _step_body(self) -> None:
     """reference envs/manager_based_rl_env.py:106-147, in its order.  The EntityData cache is dropped wherever mjData changes."""
+    self._step_body_a()
+    self._exchange_any()
+    self._step_body_b()
+
+  def _step_body_a(self) -> None:
+    """The first half: action, physics, terminations, rewards, resets."""
     env = self.env
-    before = self._snapshot_bindings()
+    self._before = self._snapshot_bindings()
     self._invalidate()
     env.action_manager.process_action(self._action_in)
     env.action_manager.apply_action()  # the same ctrl before each of the substeps (:109-113)
@@ -682,11 +779,23 @@ class GraphedRlEnv:
     env.reset_time_outs = env.termination_manager.time_outs
     env.reward_buf = self._reward.compute(self.dt) if self._reward is not None else env.reward_manager.compute(dt=self.dt)
     mask = env.reset_buf
-    self._U = torch.rand((self.n, self._ncol), device=self.device)  # this step's uniforms for every mask-based term (one launch)
+    if self._replicate_rng and self.shard is not None:  # the global batch's draws, this rank's rows
+      self._U = torch.rand((self.shard.global_envs, self._ncol), device=self.device)[self.shard.env_slice]
+    else:
+      self._U = torch.rand((self.n, self._ncol), device=self.device)  # this step's uniforms for every mask-based term (one launch)
+    self._bin_call = 0
     self._masked_reset(mask)
     self._invalidate()
     env.scene.write_data_to_sim()
-    env.sim.forward(env_mask=mask.any().expand(self.n) if self._forward_all else mask)  # all worlds iff some environment reset (:129-132), or the reset worlds only
+    self._any_reset.copy_(mask.any().to(torch.float32))
+
+  def _step_body_b(self) -> None:
+    """The second half: forward(), commands, interval events, observations.  Sharded with the reference's rule "forward() on ALL
+    worlds iff SOME environment reset" (:129-132): "some" is over the global batch, so ``_exchange_any()`` -- one 4-byte all-reduce
+    between the two halves (two captured graphs, then) -- makes the flag global first."""
+    env = self.env
+    mask = env.reset_buf
+    env.sim.forward(env_mask=(self._any_reset > 0).expand(self.n) if self._forward_all else mask)  # all worlds iff some environment reset (:129-132), or the reset worlds only
     self._invalidate()
     self._command_compute()
     self._interval_events()
@@ -699,7 +808,7 @@ class GraphedRlEnv:
     finally:
       self._obs_memo_on = False
       self._obs_memo.clear()  # (nothing outlives the step)
-    self._restore_bindings(before)
+    self._restore_bindings(self._before)
 
   # State the reference carries by REBINDING an attribute to a new tensor (``self.x = torch.where(...)``) would be lost between
   # replays (the captured kernels read the tensor the attribute pointed to at capture time): after the body such attributes
@@ -765,17 +874,14 @@ class GraphedRlEnv:
     fill, sums, rkeys, mkeys, tkeys, whole_clear = self._book
     log: dict = {}
     self._curricula(mask)
-    out = sums(mask)
-    cnt = out[-1].clamp(min=1.0)
+    out = sums(mask)  # (the masked sums and, last, the number of environments that reset: _publish_log divides)
     kr, km = len(rkeys), len(mkeys)
-    r = out[:kr] / cnt / env.max_episode_length_s
-    m = out[kr : kr + km] / cnt
     for k, key in enumerate(rkeys):
-      log["Episode_Reward/" + key] = r[k]
+      log["Episode_Reward/" + key] = (out[k], "sum_len")
     for k, (name, key) in enumerate(mkeys):
-      log[f"Metrics/{name}/{key}"] = m[k]
+      log[f"Metrics/{name}/{key}"] = (out[kr + k], "sum")
     for k, key in enumerate(tkeys):
-      log["Episode_Termination/" + key] = out[kr + km + k]
+      log["Episode_Termination/" + key] = (out[kr + km + k], "count")
     if not whole_clear:
       self._clear_state(self._robot, mask)
     fill(mask)
@@ -788,34 +894,61 @@ class GraphedRlEnv:
       if type(term).__name__ != "UniformVelocityCommand":
         mk, mvals = list(term.metrics), list(term.metrics.values())
         if mvals:
-          vals = (torch.stack(mvals, dim=1) * mask[:, None]).sum(dim=0) / cnt
+          vals = (torch.stack(mvals, dim=1) * mask[:, None]).sum(dim=0)
           for k, metric in enumerate(mk):
-            log[f"Metrics/{name}/{metric}"] = vals[k]
+            log[f"Metrics/{name}/{metric}"] = (vals[k], "sum")
           torch._foreach_mul_(mvals, [(~mask).to(torch.float32)] * len(mvals))
       self._command_resample(term, mask, self._Uof(("command", name, "reset")))
     for cname, state in getattr(env.curriculum_manager, "_curriculum_state", {}).items():
       if isinstance(state, torch.Tensor):
-        log["Curriculum/" + cname] = state.reshape(-1)[0] if state.numel() == 1 else state
+        log["Curriculum/" + cname] = (state.reshape(-1)[0] if state.numel() == 1 else state, "state")
     self._publish_log(log, mask)
 
   def _publish_log(self, log: dict, mask: torch.Tensor) -> None:
-    """``extras["log"]`` as the reference leaves it: ``_reset_idx`` -- and with it the managers' reset() logging -- runs only in a
-    step in which some environment reset (envs/manager_based_rl_env.py:121-127), so between two such steps the dict keeps the
-    numbers of the last one.  Here the masked sums are evaluated every step (a capture cannot skip them); the scalars go through
-    ONE ``where(any reset, new, previous)`` into a persistent vector, and ``extras["log"]`` is a persistent dict of 0-dim views
-    of it (the same objects across replays and resets; counts are float32 like everything else in the vector)."""
-    keys = [k for k, v in log.items() if v.dim() == 0]
-    new = torch.stack([log[k].to(torch.float32) for k in keys]) if keys else None
+    """``extras["log"]`` as the reference leaves it.  `log`: key -> (value, kind) with the RAW masked sums of this step: kind "sum_len"
+    (episode reward sums: / resets / max_episode_length_s, managers/reward_manager.py:65-70), "sum" (command metrics: / resets,
+    managers/command_manager.py:128-134), "count" (terminations per term), "state" (curriculum state).
+
+    * ``_reset_idx`` -- and with it the managers' reset() logging -- runs only in a step in which some environment reset
+      (envs/manager_based_rl_env.py:121-127), so between two such steps the dict keeps the numbers of the last one.  Here the masked
+      sums are evaluated every step (a capture cannot skip them); the scalars go through ONE ``where(any reset, new, previous)`` into
+      a persistent vector, and ``extras["log"]`` is a persistent dict of 0-dim views of it (the same objects across replays and
+      resets; counts are float32 like everything else in the vector).
+    * SHARDED (``shard.world_size > 1``): the raw sums and the reset count of this rank are parked in a persistent vector
+      and ``_exchange()`` -- after the replay, outside the graph -- all-reduces them (sum) before the division, so every rank logs
+      the numbers of the GLOBAL batch: mean over all ranks' reset environments, total termination counts, mean curriculum state."""
+    keys = [k for k, (v, _) in log.items() if v.dim() == 0]
+    raw = torch.stack([log[k][0].to(torch.float32) for k in keys] + [mask.sum().to(torch.float32)])
     if self._log_vec is None or self._log_keys != keys:
+      world = float(self.shard.world_size) if self.shard is not None else 1.0
+      kinds = [log[k][1] for k in keys]
       self._log_keys = keys
-      self._log_vec = new.clone() if new is not None else None
+      self._log_div = torch.tensor([kd in ("sum_len", "sum") for kd in kinds], device=self.device)
+      self._log_scale = torch.tensor([1.0 / float(self.env.max_episode_length_s) if kd == "sum_len" else (1.0 / world if kd == "state" else 1.0) for kd in kinds],
+                                     device=self.device)
+      self._log_vec = torch.zeros(len(keys), device=self.device)
+      self._log_raw = torch.zeros(len(keys) + 1, device=self.device)
       self._log_pub = {k: self._log_vec[i] for i, k in enumerate(keys)}
-    elif new is not None:
-      torch.where(mask.any(), new, self._log_vec, out=self._log_vec)
-    for k, v in log.items():  # (non-scalar curriculum state: passed through as it is)
+      first = True
+    else:
+      first = False
+    if self._sharded:
+      self._log_raw.copy_(raw)  # finished by _exchange() after the all-reduce
+      self._log_first = first or getattr(self, "_log_first", False)
+    else:
+      self._finish_log(raw, first)
+    for k, (v, _) in log.items():  # (non-scalar curriculum state: passed through as it is)
       if v.dim() != 0:
         self._log_pub[k] = v
     self.env.extras["log"] = self._log_pub
+
+  def _finish_log(self, raw: torch.Tensor, first: bool) -> None:
+    cnt = raw[-1]
+    new = torch.where(self._log_div, raw[:-1] / cnt.clamp(min=1.0), raw[:-1]) * self._log_scale
+    if first:
+      self._log_vec.copy_(new)
+    else:
+      torch.where(cnt > 0, new, self._log_vec, out=self._log_vec)
 
   def _masked_reset(self, mask: torch.Tensor) -> None:
     """``_reset_idx`` (:214-249) for the environments of `mask`, in its order."""
@@ -823,7 +956,6 @@ class GraphedRlEnv:
       self._masked_reset_fused(mask)
       return
     env, m1 = self.env, mask[:, None]
-    cnt = mask.sum().clamp(min=1).to(torch.float32)
     log: dict = {}
     self._curricula(mask)  # curriculum_manager.compute(env_ids) comes first (:215), and only when some environment resets
     self._clear_state(self._robot, mask)  # scene.reset -> Entity.reset -> clear_state
@@ -844,9 +976,9 @@ class GraphedRlEnv:
     keepf = (~mask).to(torch.float32)
     keys, sums = list(rm._episode_sums), list(rm._episode_sums.values())
     if sums:  # all terms in one stacked reduction and one multi-tensor update instead of five launches per term
-      vals = (torch.stack(sums, dim=1) * mask[:, None]).sum(dim=0) / cnt / env.max_episode_length_s
+      vals = (torch.stack(sums, dim=1) * mask[:, None]).sum(dim=0)
       for k, key in enumerate(keys):
-        log["Episode_Reward/" + key] = vals[k]
+        log["Episode_Reward/" + key] = (vals[k], "sum_len")
       torch._foreach_mul_(sums, [keepf] * len(sums))
     for cfg in rm._class_term_cfgs:
       self._masked_class_reset(cfg.func, mask)
@@ -855,9 +987,9 @@ class GraphedRlEnv:
       term = env.command_manager.get_term(name)
       mkeys, mvals = list(term.metrics), list(term.metrics.values())
       if mvals:
-        vals = (torch.stack(mvals, dim=1) * mask[:, None]).sum(dim=0) / cnt
+        vals = (torch.stack(mvals, dim=1) * mask[:, None]).sum(dim=0)
         for k, metric in enumerate(mkeys):
-          log[f"Metrics/{name}/{metric}"] = vals[k]
+          log[f"Metrics/{name}/{metric}"] = (vals[k], "sum")
         torch._foreach_mul_(mvals, [keepf] * len(mvals))
       term.command_counter.masked_fill_(mask, 0)
       self._command_resample(term, mask, self._Uof(("command", name, "reset")))
@@ -866,10 +998,10 @@ class GraphedRlEnv:
     if tdones:
       counts = (torch.stack(tdones, dim=1) & mask[:, None]).sum(dim=0)
       for k, key in enumerate(tkeys):
-        log["Episode_Termination/" + key] = counts[k]
+        log["Episode_Termination/" + key] = (counts[k], "count")
     for cname, state in getattr(env.curriculum_manager, "_curriculum_state", {}).items():  # CurriculumManager.reset (managers/curriculum_manager.py:70-85)
       if isinstance(state, torch.Tensor):
-        log["Curriculum/" + cname] = state.reshape(-1)[0] if state.numel() == 1 else state
+        log["Curriculum/" + cname] = (state.reshape(-1)[0] if state.numel() == 1 else state, "state")
     self._publish_log(log, mask)
     env.episode_length_buf.masked_fill_(mask, 0)
 
@@ -1074,7 +1206,18 @@ class GraphedRlEnv:
       failed = self.env.termination_manager.terminated & mask
       bins = torch.clamp((term.time_steps * term.bin_count) // max(total, 1), 0, term.bin_count - 1)
       counts = torch.zeros(term.bin_count, device=dev).scatter_add_(0, bins, failed.to(torch.float32))  # (:258-265: bincount of the failed envs' bins)
-      term._current_bin_failed.copy_(torch.where(failed.any(), counts, term._current_bin_failed))
+      if self._sharded:  # parked for _exchange(): the histogram is the global batch's (all-reduce) before the sampler's update reads it
+        buf = self._bin_calls.get(id(term))
+        if buf is None or buf.shape[0] <= self._bin_call:
+          old_buf = buf
+          buf = self._bin_calls[id(term)] = torch.zeros((self._bin_call + 1, term.bin_count + 1), device=dev)
+          if old_buf is not None:
+            buf[: old_buf.shape[0]] = old_buf
+        buf[self._bin_call, : term.bin_count] = counts
+        buf[self._bin_call, term.bin_count] = failed.any().to(torch.float32)
+        self._bin_call += 1
+      else:
+        term._current_bin_failed.copy_(torch.where(failed.any(), counts, term._current_bin_failed))
       if id(term) not in self._sampler_cache:  # bin_failed_count changes once per step, after the last resample (_update_command's end)
         p = term.bin_failed_count + cfg.adaptive_uniform_ratio / float(term.bin_count)
         p = torch.nn.functional.pad(p.unsqueeze(0).unsqueeze(0), (0, cfg.adaptive_kernel_size - 1), mode="replicate")
@@ -1132,8 +1275,7 @@ class GraphedRlEnv:
       d = term.robot.data.data
       env_terms.command_motion_relative(tab, term.time_steps, self.env.scene.env_origins, d.xpos, d.xquat, anchor_gid, term.motion_anchor_body_index,
                                         term.body_pos_relative_w, term.body_quat_relative_w)
-      term.bin_failed_count = term.cfg.adaptive_alpha * term._current_bin_failed + (1 - term.cfg.adaptive_alpha) * term.bin_failed_count
-      term._current_bin_failed.zero_()
+      self._sampler_update(term)
       return
     nb = len(term.cfg.body_names)
     anchor_pos = term.anchor_pos_w[:, None, :].repeat(1, nb, 1)
@@ -1144,6 +1286,14 @@ class GraphedRlEnv:
     delta_ori = rm.yaw_quat(rm.quat_mul(robot_quat, rm.quat_inv(anchor_quat)))
     term.body_quat_relative_w = rm.quat_mul(delta_ori, term.body_quat_w)
     term.body_pos_relative_w = delta_pos + rm.quat_apply(delta_ori, term.body_pos_w - anchor_pos)
+    self._sampler_update(term)
+
+  def _sampler_update(self, term: Any) -> None:
+    """The end of ``_update_command`` (tasks/tracking/mdp/commands.py:389-392): the failure statistics take this step's histogram in.
+    Sharded: deferred to ``_exchange()`` -- nothing between here and the end of the step reads ``bin_failed_count``, and the
+    histogram has to be the global batch's first."""
+    if self._sharded and not term.cfg.disable_adaptive_sampling:
+      return
     term.bin_failed_count = term.cfg.adaptive_alpha * term._current_bin_failed + (1 - term.cfg.adaptive_alpha) * term.bin_failed_count
     term._current_bin_failed.zero_()
 

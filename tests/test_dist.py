@@ -161,3 +161,27 @@ def test_single_rank_passthrough():
   rows = torch.arange(10.0).view(5, 2)
   assert mdist.gather_rollout(info, rows) is rows
   assert mdist.seed_for_rank(42, mdist.ShardInfo(3, 8, 3, 5)) == 45
+
+
+def test_sharded_tracking_environment_equals_the_single_process_batch(tmp_path):
+  """The FULL environment sharded: two gloo ranks, each with its slice of the reference's
+  tracking task behind ``GraphedRlEnv(env, shard=...)`` over the oracle, against the single process' batch -- see
+  tests/_sharded_env_worker.py for what is compared after each of the 30 control steps."""
+  import json
+  import subprocess
+
+  if not (ROOT.parent / "reference").exists():
+    import pytest
+
+    pytest.skip("needs the reference tree (the environment classes are the reference's own)")
+  port = str(29911 + os.getpid() % 200)
+  motion, out = str(tmp_path / "motion.npz"), str(tmp_path / "stats.json")
+  procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "_sharded_env_worker.py"), str(r), "2", port, motion, out], cwd=str(ROOT),
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+  outs = [p.communicate(timeout=1500) for p in procs]
+  for p, (so, se) in zip(procs, outs):
+    assert p.returncode == 0, se[-4000:]
+  st = json.loads(Path(out).read_text())
+  print(st)
+  # the run must have exercised what the exchange is for: failures feeding the sampler, on one rank only in some steps
+  assert st["failed"] >= 4 and st["resets"] >= 4 and st["ended"] >= 4 and st["bin_failed_mass"] > 0 and st["steps_with_global_failures_on_one_rank_only"] >= 1, st
