@@ -393,7 +393,7 @@ struct CholSweep {
   }
   // batch BI of column J: request the next batch (same row, or first batch of row J+1) into
   // `nxt`, feed `cur` to the FMAs, recurse with the buffers swapped
-  // MJLAB_CHOL_ACC pairs of accumulators (default 2 = four partial sums): the products of a column's dot product go round-robin into
+  // MJLAB_CHOL_ACC pairs of accumulators (default 1 = two partial sums; 2 measured equal): the products of a column's dot product go round-robin into
   // independent v_pk_fma_f32 chains, so the dependent chain of a column is J / (2 ACC) multiply-adds long instead of J / 2
   template <int J, int BI>
   static __device__ __forceinline__ void batches(const float (&a)[NVP], f32x2 (&acc)[MJLAB_CHOL_ACC], float (&cur)[CB], float (&nxt)[CB], lds_f32* A) {

@@ -167,10 +167,25 @@ class RewardAccumulator:
     self.active = [(i, name, cfg) for i, (name, cfg) in enumerate(zip(manager._term_names, manager._term_cfgs, strict=True)) if cfg.weight != 0.0]
     self.idle = [i for i, cfg in enumerate(manager._term_cfgs) if cfg.weight == 0.0]
     dev = manager._reward_buf.device
-    self.weights = torch.tensor([float(cfg.weight) for _, _, cfg in self.active], dtype=torch.float32, device=dev)
+    self._host_weights = [float(cfg.weight) for _, _, cfg in self.active]
+    self.weights = torch.tensor(self._host_weights, dtype=torch.float32, device=dev)
     self.columns = torch.tensor([i for i, _, _ in self.active], dtype=torch.int32, device=dev)
     self.sums = [_dense(manager._episode_sums[name], "episode_sums", torch.float32) for _, name, _ in self.active]
     self.sum_ptrs = torch.tensor([t.data_ptr() for t in self.sums], dtype=torch.int64, device=dev)
+
+  def refresh_weights(self) -> None:
+    """The reference reads ``term_cfg.weight`` on every ``compute()`` (managers/reward_manager.py:82-86); here the weights sit in a
+    device table a captured graph reads.  Called on the host once per control step (GraphedRlEnv.step, outside the graph): a weight
+    that changed since the table was built -- a user's curriculum -- is uploaded (the next replay uses it); a term that crossed
+    between zero and non-zero changes WHICH terms are evaluated, which a captured graph cannot follow: that raises."""
+    cfgs = self.manager._term_cfgs
+    if [i for i, cfg in enumerate(cfgs) if cfg.weight == 0.0] != self.idle:
+      raise RuntimeError("RewardAccumulator: a reward term's weight crossed between zero and non-zero after the accumulator was built; "
+                         "build a new GraphedRlEnv (the set of evaluated terms is part of the captured step)")
+    now = [float(cfg.weight) for _, _, cfg in self.active]
+    if now != self._host_weights:
+      self._host_weights = now
+      self.weights.copy_(torch.tensor(now, dtype=torch.float32), non_blocking=False)
 
   def compute(self, dt: float) -> torch.Tensor:
     m = self.manager

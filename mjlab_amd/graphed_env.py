@@ -622,6 +622,8 @@ class GraphedRlEnv:
       self._ep_len.copy_(env.episode_length_buf)
       env.episode_length_buf = self._ep_len
     self._action_in.copy_(action)
+    if self._reward is not None:
+      self._reward.refresh_weights()  # (host side: the reference reads cfg.weight at every compute())
     if self.graph is not None:
       self.graph.replay()
       if self.graph_b is not None:

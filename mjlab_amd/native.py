@@ -42,6 +42,25 @@ def build(force: bool = False, verbose: bool = False, out: Path | None = None, d
   hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
   objdir = CSRC / "build" / (out.stem + ("_" + "_".join(defines) if defines else ""))
   objdir.mkdir(parents=True, exist_ok=True)
+  # One builder at a time per output (torchrun: every rank may find the library stale at once -- ADVICE round 4): an exclusive
+  # file lock around compile + link, the link goes to a temporary name and is moved into place atomically, and a rank that waited
+  # for the lock finds the finished library and returns.
+  import fcntl
+
+  lock = open(objdir / ".build.lock", "w")
+  fcntl.flock(lock, fcntl.LOCK_EX)
+  try:
+    if out.exists() and not force and not defines and out.stat().st_mtime >= newest_src:
+      return out
+    return _build_locked(out, objdir, hipcc, verbose, defines, jobs, only_size)
+  finally:
+    fcntl.flock(lock, fcntl.LOCK_UN)
+    lock.close()
+
+
+def _build_locked(out: Path, objdir: Path, hipcc: str, verbose: bool, defines: tuple[str, ...], jobs: int | None, only_size: int | None) -> Path:
+  from concurrent.futures import ThreadPoolExecutor
+
   dflags = [f"-D{x}" for x in defines] + ([f"-DMJLAB_NVP_ONLY={only_size}"] if only_size else [])
   dflags += os.environ.get("MJLAB_HIPCC_EXTRA", "").split()  # compiler-flag experiments
   sizes = (only_size,) if only_size else NVP_SIZES  # only_size: an experiment library for models of one padded size (A/B runs)
@@ -58,10 +77,12 @@ def build(force: bool = False, verbose: bool = False, out: Path | None = None, d
 
   with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 4)) as pool:
     list(pool.map(compile_one, units))
-  cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(u[1]) for u in units]]
+  tmp = out.with_name(out.name + f".tmp{os.getpid()}")
+  cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp), *[str(u[1]) for u in units]]
   if verbose:
     print(" ".join(cmd), flush=True)
   subprocess.run(cmd, check=True)
+  os.replace(tmp, out)  # (a process that has the old library mapped keeps its inode; nobody ever sees a half-written file)
   return out
 
 
