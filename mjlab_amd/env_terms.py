@@ -158,6 +158,16 @@ def command_motion_relative(tab: MotionTables, time_steps: torch.Tensor, env_ori
     _stream(xpos)), "mjlab_command_motion_relative")  # fmt: skip
 
 
+def reward_accumulate(values: torch.Tensor, weights: torch.Tensor, columns: torch.Tensor, dt: float, reward_buf: torch.Tensor, sum_ptrs: torch.Tensor,
+                      step_reward: torch.Tensor) -> None:
+  """The mjlab_reward_accumulate launch on plain tensors: `values` (k, n) raw term outputs, `weights` (k) float32, `columns` (k) int32,
+  `sum_ptrs` (k) int64 device addresses of the episode-sum vectors (n float32 each)."""
+  native.check(native.lib().mjlab_reward_accumulate(
+    _dense(values, "values", torch.float32).data_ptr(), weights.data_ptr(), columns.data_ptr(), int(values.shape[0]), values.shape[1], float(dt),
+    _dense(reward_buf, "reward_buf", torch.float32).data_ptr(), sum_ptrs.data_ptr(), _dense(step_reward, "step_reward", torch.float32).data_ptr(),
+    step_reward.shape[1], _stream(values)), "mjlab_reward_accumulate")  # fmt: skip
+
+
 class RewardAccumulator:
   """RewardManager.compute's accumulation loop (reference managers/reward_manager.py:77-89) as one launch for a given reward
   manager: the device tables (weights, step_reward columns, the episode-sum buffers' addresses) are built once."""
@@ -197,10 +207,7 @@ class RewardAccumulator:
     values = torch.stack([cfg.func(m._env, **cfg.params) for _, _, cfg in self.active], dim=0)  # (k, n): one launch for the k raw outputs
     if any(m._episode_sums[name] is not t for (_, name, _), t in zip(self.active, self.sums, strict=True)):
       raise RuntimeError("RewardAccumulator: an episode-sum buffer of the reward manager was replaced")
-    native.check(native.lib().mjlab_reward_accumulate(
-      _dense(values, "values", torch.float32).data_ptr(), self.weights.data_ptr(), self.columns.data_ptr(), len(self.active), values.shape[1], float(dt),
-      _dense(m._reward_buf, "reward_buf", torch.float32).data_ptr(), self.sum_ptrs.data_ptr(), _dense(m._step_reward, "step_reward", torch.float32).data_ptr(),
-      m._step_reward.shape[1], _stream(values)), "mjlab_reward_accumulate")  # fmt: skip
+    reward_accumulate(values, self.weights, self.columns, dt, m._reward_buf, self.sum_ptrs, m._step_reward)
     return m._reward_buf
 
 

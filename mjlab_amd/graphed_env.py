@@ -51,7 +51,7 @@ from typing import Any
 
 import torch
 
-from . import env_terms
+from . import env_core, env_terms
 
 SUPPORTED_RESET_EVENTS = ("reset_root_state_uniform", "reset_joints_by_scale")
 SUPPORTED_INTERVAL_EVENTS = ("push_by_setting_velocity",)
@@ -236,6 +236,44 @@ def _cache_properties(obj: Any, active: list | None = None) -> Any:
   return cache.clear
 
 
+def bookkeeping_plan(env: Any, robot: Any, slices: tuple, n_reset_terms: int, ep_len: torch.Tensor) -> tuple:
+  """What ``_reset_idx`` fills and sums, read off the reference's environment object: ``(fills, vectors, rkeys, mkeys, tkeys,
+  whole_clear)`` with ``fills`` = (name, tensor, value) and ``vectors`` = (name, tensor) in the order env_core.ResetBookkeeping
+  expects.  (A function of its own so that tools/make_graphed_golden.py can enumerate the SAME buffers of the eager reference
+  environment it records.)"""
+  d = robot.data.data
+  fv, bi, ci, _ = slices
+  fills: list = []
+  whole_clear = all(isinstance(x, slice) for x in (fv, bi, ci))
+  if whole_clear:  # EntityData.clear_state (entity/data.py:169-178)
+    fills += [("qfrc_applied", d.qfrc_applied[:, fv], 0.0), ("xfrc_applied", d.xfrc_applied[:, bi], 0.0), ("ctrl", d.ctrl[:, ci], 0.0)]
+  ev = env.event_manager
+  step_count = env._sim_step_counter // env.cfg.decimation
+  for index in range(n_reset_terms):  # EventManager bookkeeping of reset-mode terms (managers/event_manager.py:139-148)
+    fills += [(f"event.last_triggered_step_id.{index}", ev._reset_term_last_triggered_step_id[index], step_count),
+              (f"event.last_triggered_once.{index}", ev._reset_term_last_triggered_once[index], 1)]
+  am = env.action_manager  # managers/action_manager.py:101-110
+  fills += [("action.prev_action", am._prev_action, 0.0), ("action.action", am._action, 0.0)] + [(f"action.raw.{k}", t._raw_actions, 0.0) for k, t in am._terms.items()]
+  rm = env.reward_manager  # managers/reward_manager.py:60-74
+  rkeys = list(rm._episode_sums)
+  fills += [(f"reward.episode_sums.{k}", rm._episode_sums[k], 0.0) for k in rkeys]
+  vectors = [(f"reward.episode_sums.{k}", rm._episode_sums[k]) for k in rkeys]
+  mkeys: list = []
+  for name in env.command_manager.active_terms:  # managers/command_manager.py:44-53
+    term = env.command_manager.get_term(name)
+    fills.append((f"command.{name}.command_counter", term.command_counter, 0))
+    if type(term).__name__ == "UniformVelocityCommand":  # (metrics updated in place: velocity_command.py:49-62)
+      for key in term.metrics:
+        mkeys.append((name, key))
+        fills.append((f"command.{name}.metrics.{key}", term.metrics[key], 0.0))
+        vectors.append((f"command.{name}.metrics.{key}", term.metrics[key]))
+  tm = env.termination_manager  # managers/termination_manager.py:73-85
+  tkeys = list(tm._term_dones)
+  vectors += [(f"termination.term_dones.{k}", tm._term_dones[k]) for k in tkeys]
+  fills.append(("episode_length_buf", ep_len, 0))  # envs/manager_based_rl_env.py:246
+  return fills, vectors, rkeys, mkeys, tkeys, whole_clear
+
+
 class GraphedRlEnv:
   """See the module docstring.  Options (all keep the wrapped environment object usable; outside ``step()`` it behaves as the reference's):
 
@@ -287,7 +325,7 @@ class GraphedRlEnv:
     self._robot = env.scene["robot"]
     self._data_caches = []
     self._term_caches: list = []  # invalidate() of the command terms whose properties are cached (dropped with the EntityData caches)
-    self._log_vec, self._log_keys, self._log_pub = None, None, {}  # extras["log"]: see _publish_log
+    self._logbook = env_core.LogBook(env.max_episode_length_s, self.device, world=shard.world_size if shard is not None else 1)  # extras["log"]
     self._caching = [False]  # the property caches work inside _body() only: the eager env.reset() / a caller's own reads see the reference's objects
     self._cache_entity_data = cache_entity_data
     if cache_entity_data:
@@ -313,7 +351,7 @@ class GraphedRlEnv:
     # RewardManager.compute's accumulation (6 launches per term) as one launch; the term functions are the reference's (GPU only)
     self._reward = env_terms.RewardAccumulator(env.reward_manager) if self._fused else None
     self._ep_len = env.episode_length_buf  # the tensor the captured kernels address (see step())
-    self._book = self._prepare_bookkeeping() if self._fused else None
+    self._book = self._prepare_bookkeeping()
     self._obs_memo: dict = {}
     self._obs_memo_on = False
     self._share_observation_terms()
@@ -631,7 +669,7 @@ class GraphedRlEnv:
         self.graph_b.replay()
       env.obs_buf, env.reward_buf, env.reset_terminated, env.reset_time_outs, env.reset_buf = self._out
       env.observation_manager._obs_buffer = env.obs_buf
-      env.extras["log"] = self._log_pub
+      env.extras["log"] = self._logbook.pub
     else:
       self._body()
     if self._sharded:
@@ -680,10 +718,10 @@ class GraphedRlEnv:
       term.bin_failed_count.copy_(term.cfg.adaptive_alpha * cur + (1 - term.cfg.adaptive_alpha) * term.bin_failed_count)
       cur.zero_()
       buf.zero_()
-    if self._log_vec is not None and self._log_keys:
-      self._all_reduce_sum(self._log_raw)
-      self._finish_log(self._log_raw, getattr(self, "_log_first", False))
-      self._log_first = False
+    lb = self._logbook
+    if lb.raw is not None and lb.keys:
+      self._all_reduce_sum(lb.raw)
+      lb.finish(lb.raw, lb.first)
 
   def step_sharded(self, actions_global: torch.Tensor | None, learner: int = 0, to_all: bool = False):
     """One control step of the sharded batch with north_star's learner exchange (mjlab_amd/dist.py): the learner's actions for ALL
@@ -730,8 +768,8 @@ class GraphedRlEnv:
         out[group] = om.compute_group(group, True)
         continue
       noisy, width, lo = plan
-      raw = torch.cat([cfg.func(env, **cfg.params) for cfg in om._group_obs_term_cfgs[group]], dim=-1)
-      out[group] = raw + (self._Uof(("obs", group)) * width + lo) if noisy else raw
+      out[group] = env_core.assemble_observation([cfg.func(env, **cfg.params) for cfg in om._group_obs_term_cfgs[group]], noisy, width, lo,
+                                                 self._Uof(("obs", group)) if noisy else None)
     om._obs_buffer = out
     return out
 
@@ -835,58 +873,24 @@ class GraphedRlEnv:
   # ------------------------------------------------------------------------------------------------------------------ reset
   def _prepare_bookkeeping(self) -> Any:
     """The masked fills and masked sums of ``_reset_idx`` over buffers that live for the whole run (updated in place by the reference),
-    as ONE launch each (env_terms.MaskedFill / MaskedSums).  Command terms whose metric tensors are rebound at every update (the
-    tracking task's MotionCommand, tasks/tracking/mdp/commands.py:216-253) keep the torch path for their metrics."""
-    env = self.env
-    d = self._robot.data.data
-    fv, bi, ci, _ = self._index_slices(self._robot)
-    fills: list = []
-    whole_clear = all(isinstance(x, slice) for x in (fv, bi, ci))
-    if whole_clear:  # EntityData.clear_state (entity/data.py:169-178)
-      fills += [(d.qfrc_applied[:, fv], 0.0), (d.xfrc_applied[:, bi], 0.0), (d.ctrl[:, ci], 0.0)]
-    ev = env.event_manager
-    step_count = env._sim_step_counter // env.cfg.decimation
-    for index in range(len(self._reset_terms)):  # EventManager bookkeeping of reset-mode terms (managers/event_manager.py:139-148)
-      fills += [(ev._reset_term_last_triggered_step_id[index], step_count), (ev._reset_term_last_triggered_once[index], 1)]
-    am = env.action_manager  # managers/action_manager.py:101-110
-    fills += [(am._prev_action, 0.0), (am._action, 0.0)] + [(t._raw_actions, 0.0) for t in am._terms.values()]
-    rm = env.reward_manager  # managers/reward_manager.py:60-74
-    rkeys = list(rm._episode_sums)
-    fills += [(rm._episode_sums[k], 0.0) for k in rkeys]
-    vectors = [rm._episode_sums[k] for k in rkeys]
-    mkeys: list = []
-    for name in env.command_manager.active_terms:  # managers/command_manager.py:44-53
-      term = env.command_manager.get_term(name)
-      fills.append((term.command_counter, 0))
-      if type(term).__name__ == "UniformVelocityCommand":  # (metrics updated in place: velocity_command.py:49-62)
-        for key in term.metrics:
-          mkeys.append((name, key))
-          fills.append((term.metrics[key], 0.0))
-          vectors.append(term.metrics[key])
-    tm = env.termination_manager  # managers/termination_manager.py:73-85
-    tkeys = list(tm._term_dones)
-    vectors += [tm._term_dones[k] for k in tkeys]
-    fills.append((self._ep_len if hasattr(self, "_ep_len") else env.episode_length_buf, 0))  # envs/manager_based_rl_env.py:246
-    return env_terms.MaskedFill(fills), env_terms.MaskedSums(vectors), rkeys, mkeys, tkeys, whole_clear
+    as ONE launch each on the GPU (env_terms.MaskedFill / MaskedSums) or as their torch twins (env_core.py).  Command terms whose metric tensors
+    are rebound at every update (the tracking task's MotionCommand, tasks/tracking/mdp/commands.py:216-253) keep the torch path for their metrics."""
+    fills, vectors, rkeys, mkeys, tkeys, whole_clear = bookkeeping_plan(self.env, self._robot, self._index_slices(self._robot), len(self._reset_terms),
+                                                                        self._ep_len if hasattr(self, "_ep_len") else self.env.episode_length_buf)
+    return env_core.ResetBookkeeping([(t, v) for _, t, v in fills], [t for _, t in vectors], rkeys, mkeys, tkeys, fused=self._fused), whole_clear
 
-  def _masked_reset_fused(self, mask: torch.Tensor) -> None:
-    """``_masked_reset`` with the managers' bookkeeping as two launches: every masked sum the reset logs first (nothing below changes
-    the summed buffers), then every masked fill, then the terms that draw."""
+  def _masked_reset(self, mask: torch.Tensor) -> None:
+    """``_reset_idx`` (:214-249) for the environments of `mask`: the managers' bookkeeping first -- every masked sum the reset logs
+    (nothing below changes the summed buffers), then every masked fill (env_core.ResetBookkeeping: two HIP launches on the GPU, the
+    torch twins otherwise) -- then the terms that draw."""
     env = self.env
-    fill, sums, rkeys, mkeys, tkeys, whole_clear = self._book
-    log: dict = {}
-    self._curricula(mask)
-    out = sums(mask)  # (the masked sums and, last, the number of environments that reset: _publish_log divides)
-    kr, km = len(rkeys), len(mkeys)
-    for k, key in enumerate(rkeys):
-      log["Episode_Reward/" + key] = (out[k], "sum_len")
-    for k, (name, key) in enumerate(mkeys):
-      log[f"Metrics/{name}/{key}"] = (out[kr + k], "sum")
-    for k, key in enumerate(tkeys):
-      log["Episode_Termination/" + key] = (out[kr + km + k], "count")
+    book, whole_clear = self._book
+    self._curricula(mask)  # curriculum_manager.compute(env_ids) comes first (:215), and only when some environment resets
+    out = book.sums(mask)  # (the masked sums and, last, the number of environments that reset: the log book divides)
+    log = book.log_entries(out)
     if not whole_clear:
       self._clear_state(self._robot, mask)
-    fill(mask)
+    book.fill(mask)
     for index, (fn, prm) in enumerate(self._reset_terms):
       getattr(self, "_" + fn)(mask, self._Uof(("reset", index)), **prm)
     for cfg in env.reward_manager._class_term_cfgs:
@@ -907,105 +911,8 @@ class GraphedRlEnv:
     self._publish_log(log, mask)
 
   def _publish_log(self, log: dict, mask: torch.Tensor) -> None:
-    """``extras["log"]`` as the reference leaves it.  `log`: key -> (value, kind) with the RAW masked sums of this step: kind "sum_len"
-    (episode reward sums: / resets / max_episode_length_s, managers/reward_manager.py:65-70), "sum" (command metrics: / resets,
-    managers/command_manager.py:128-134), "count" (terminations per term), "state" (curriculum state).
-
-    * ``_reset_idx`` -- and with it the managers' reset() logging -- runs only in a step in which some environment reset
-      (envs/manager_based_rl_env.py:121-127), so between two such steps the dict keeps the numbers of the last one.  Here the masked
-      sums are evaluated every step (a capture cannot skip them); the scalars go through ONE ``where(any reset, new, previous)`` into
-      a persistent vector, and ``extras["log"]`` is a persistent dict of 0-dim views of it (the same objects across replays and
-      resets; counts are float32 like everything else in the vector).
-    * SHARDED (``shard.world_size > 1``): the raw sums and the reset count of this rank are parked in a persistent vector
-      and ``_exchange()`` -- after the replay, outside the graph -- all-reduces them (sum) before the division, so every rank logs
-      the numbers of the GLOBAL batch: mean over all ranks' reset environments, total termination counts, mean curriculum state."""
-    keys = [k for k, (v, _) in log.items() if v.dim() == 0]
-    raw = torch.stack([log[k][0].to(torch.float32) for k in keys] + [mask.sum().to(torch.float32)])
-    if self._log_vec is None or self._log_keys != keys:
-      world = float(self.shard.world_size) if self.shard is not None else 1.0
-      kinds = [log[k][1] for k in keys]
-      self._log_keys = keys
-      self._log_div = torch.tensor([kd in ("sum_len", "sum") for kd in kinds], device=self.device)
-      self._log_scale = torch.tensor([1.0 / float(self.env.max_episode_length_s) if kd == "sum_len" else (1.0 / world if kd == "state" else 1.0) for kd in kinds],
-                                     device=self.device)
-      self._log_vec = torch.zeros(len(keys), device=self.device)
-      self._log_raw = torch.zeros(len(keys) + 1, device=self.device)
-      self._log_pub = {k: self._log_vec[i] for i, k in enumerate(keys)}
-      first = True
-    else:
-      first = False
-    if self._sharded:
-      self._log_raw.copy_(raw)  # finished by _exchange() after the all-reduce
-      self._log_first = first or getattr(self, "_log_first", False)
-    else:
-      self._finish_log(raw, first)
-    for k, (v, _) in log.items():  # (non-scalar curriculum state: passed through as it is)
-      if v.dim() != 0:
-        self._log_pub[k] = v
-    self.env.extras["log"] = self._log_pub
-
-  def _finish_log(self, raw: torch.Tensor, first: bool) -> None:
-    cnt = raw[-1]
-    new = torch.where(self._log_div, raw[:-1] / cnt.clamp(min=1.0), raw[:-1]) * self._log_scale
-    if first:
-      self._log_vec.copy_(new)
-    else:
-      torch.where(cnt > 0, new, self._log_vec, out=self._log_vec)
-
-  def _masked_reset(self, mask: torch.Tensor) -> None:
-    """``_reset_idx`` (:214-249) for the environments of `mask`, in its order."""
-    if self._book is not None:
-      self._masked_reset_fused(mask)
-      return
-    env, m1 = self.env, mask[:, None]
-    log: dict = {}
-    self._curricula(mask)  # curriculum_manager.compute(env_ids) comes first (:215), and only when some environment resets
-    self._clear_state(self._robot, mask)  # scene.reset -> Entity.reset -> clear_state
-    # reset-mode events (managers/event_manager.py:139-148 with min_step_count 0)
-    step_count = env._sim_step_counter // env.cfg.decimation  # (baked in at capture; read by nothing the supported terms use)
-    for index, (fn, prm) in enumerate(self._reset_terms):
-      env.event_manager._reset_term_last_triggered_step_id[index].masked_fill_(mask, step_count)
-      env.event_manager._reset_term_last_triggered_once[index].masked_fill_(mask, True)
-      getattr(self, "_" + fn)(mask, self._Uof(("reset", index)), **prm)
-    # observation manager: nothing stateful (checked at construction).  action manager (managers/action_manager.py:101-110):
-    am = env.action_manager
-    am._prev_action.masked_fill_(m1, 0.0)
-    am._action.masked_fill_(m1, 0.0)
-    for term in am._terms.values():
-      term._raw_actions.masked_fill_(m1, 0.0)
-    # reward manager (managers/reward_manager.py:60-74)
-    rm = env.reward_manager
-    keepf = (~mask).to(torch.float32)
-    keys, sums = list(rm._episode_sums), list(rm._episode_sums.values())
-    if sums:  # all terms in one stacked reduction and one multi-tensor update instead of five launches per term
-      vals = (torch.stack(sums, dim=1) * mask[:, None]).sum(dim=0)
-      for k, key in enumerate(keys):
-        log["Episode_Reward/" + key] = (vals[k], "sum_len")
-      torch._foreach_mul_(sums, [keepf] * len(sums))
-    for cfg in rm._class_term_cfgs:
-      self._masked_class_reset(cfg.func, mask)
-    # command manager (managers/command_manager.py:44-53)
-    for name in env.command_manager.active_terms:
-      term = env.command_manager.get_term(name)
-      mkeys, mvals = list(term.metrics), list(term.metrics.values())
-      if mvals:
-        vals = (torch.stack(mvals, dim=1) * mask[:, None]).sum(dim=0)
-        for k, metric in enumerate(mkeys):
-          log[f"Metrics/{name}/{metric}"] = (vals[k], "sum")
-        torch._foreach_mul_(mvals, [keepf] * len(mvals))
-      term.command_counter.masked_fill_(mask, 0)
-      self._command_resample(term, mask, self._Uof(("command", name, "reset")))
-    # termination manager (managers/termination_manager.py:73-85)
-    tkeys, tdones = list(env.termination_manager._term_dones), list(env.termination_manager._term_dones.values())
-    if tdones:
-      counts = (torch.stack(tdones, dim=1) & mask[:, None]).sum(dim=0)
-      for k, key in enumerate(tkeys):
-        log["Episode_Termination/" + key] = (counts[k], "count")
-    for cname, state in getattr(env.curriculum_manager, "_curriculum_state", {}).items():  # CurriculumManager.reset (managers/curriculum_manager.py:70-85)
-      if isinstance(state, torch.Tensor):
-        log["Curriculum/" + cname] = (state.reshape(-1)[0] if state.numel() == 1 else state, "state")
-    self._publish_log(log, mask)
-    env.episode_length_buf.masked_fill_(mask, 0)
+    """``extras["log"]`` through the log book (env_core.LogBook: kept between steps with resets; sharded: finished by _exchange())."""
+    self.env.extras["log"] = self._logbook.publish(log, mask)
 
   def _curricula(self, mask: torch.Tensor) -> None:
     """CurriculumManager.compute (managers/curriculum_manager.py:97-102) for ``commands_vel`` (tasks/velocity/mdp/curriculums.py:60-74)
@@ -1186,13 +1093,11 @@ class GraphedRlEnv:
       self._put(d.qvel, ix.free_joint_v_adr, im[:, None], vel)
 
   def _update_UniformVelocityCommand(self, term: Any) -> None:
-    rm, cfg, v = self._m, term.cfg, term.vel_command_b
-    if cfg.heading_command:
-      err = rm.wrap_to_pi(term.heading_target - term.robot.data.heading_w)
-      az = self._command_ranges[id(term)]["ang_vel_z"]
-      yaw = torch.clip(cfg.heading_control_stiffness * err, min=az[0], max=az[1])
-      v[:, 2] = torch.where(term.is_heading_env, yaw, v[:, 2])
-    v.masked_fill_(term.is_standing_env[:, None], 0.0)
+    cfg = term.cfg
+    env_core.update_uniform_velocity(term.vel_command_b, term.heading_target if cfg.heading_command else None,
+                                     term.robot.data.heading_w if cfg.heading_command else None, term.is_heading_env if cfg.heading_command else None,
+                                     term.is_standing_env, bool(cfg.heading_command), cfg.heading_control_stiffness,
+                                     self._command_ranges[id(term)]["ang_vel_z"], self._m.wrap_to_pi)
 
   # -- MotionCommand (tasks/tracking/mdp/commands.py:255-392)
   def _resample_MotionCommand(self, term: Any, mask: torch.Tensor, U: torch.Tensor) -> None:
