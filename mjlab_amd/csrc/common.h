@@ -692,6 +692,18 @@ __device__ CHOL_INLINE float chol_solve_back(const float* L_, const float* s_inv
 #ifndef MJLAB_CHOL_TILES
 #define MJLAB_CHOL_TILES 1
 #endif
+// Per padded size (measured, profiles/r05_v14/nvp_sweep.txt: chain models with 75-230 rows per world, 4096 worlds, us per physics step,
+// tiles | sweep): NVP 8: 109 | 106, 20: 706 | 703, 32: 595 | 664, 36: 754 | 793, 40: 1247 | 962, 48: 1870 | 1885, 64: 3108 | 3230;
+// Go1 (NVP 20, few rows): 7.94 | 8.34 M env-steps/s.  The tile factorization pays where the blocks are full (32, 48, 64) or the
+// remainder is one 4 x 4 block (36); with 8 real columns in the last block (40) its four half-empty panels cost more than they save, and
+// below two blocks the column sweep's few short columns are cheaper than the panels' uniform 4 x 4 chains.  MJLAB_CHOL_TILES_MIN overrides
+// (8: tiles everywhere, 99: nowhere) for A/B builds.
+#ifndef MJLAB_CHOL_TILES_MIN
+#define MJLAB_CHOL_TILES_MIN 0
+#endif
+__host__ __device__ constexpr bool chol_use_tiles(int nvp) {
+  return MJLAB_CHOL_TILES && (MJLAB_CHOL_TILES_MIN ? nvp >= MJLAB_CHOL_TILES_MIN : (nvp == 32 || nvp == 36 || nvp == 48 || nvp == 64));
+}
 #ifndef MJLAB_CHOL_PANEL
 #define MJLAB_CHOL_PANEL 0  // 0: panel x Linv^T as an MFMA (default), 1: substitution after three permlane swaps (experiment)
 #endif

@@ -210,11 +210,12 @@ __device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&a
 #ifndef MJLAB_NO_HSKIP
             if (nz[I] && nz[Jb])
 #endif
-#if MJLAB_CHOL_TILES  // UPPER tiles U(Jb, I) = H[16 Jb + ..][16 I + ..] (the layout chol_factor_tiles eliminates in, common.h)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[Jb], x[u][I], acc[t], 0, 0, 0);
-#else
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[u][Jb], acc[t], 0, 0, 0);
-#endif
+            {
+              if constexpr (chol_use_tiles(NVP))  // UPPER tiles U(Jb, I) = H[16 Jb + ..][16 I + ..] (the layout chol_factor_tiles eliminates in, common.h)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[Jb], x[u][I], acc[t], 0, 0, 0);
+              else
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[u][Jb], acc[t], 0, 0, 0);
+            }
             ++t;
           }
       }
@@ -493,7 +494,6 @@ __device__ __forceinline__ float constraint_cost(const SolveCtx<NVP>& c, const f
   return wave_sum(cost);
 }
 
-#if MJLAB_CHOL_TILES
 // H = M + J^T D J (+ friction-loss curvature) in the tiles hessian_accum filled, factored where they lie (common.h, chol_factor_tiles):
 // the Hessian never exists in LDS.  The factor replaces the previous one in s_H; the caller has synchronised since the last solve.
 template <int NVP, bool BIG>
@@ -503,7 +503,6 @@ __device__ __forceinline__ void newton_factor(const SolveCtx<NVP>& c, f32x4 (&ht
   chol_factor_tiles<NVP>(htile, c.s_H, c.s_invd, lane);
   __syncthreads();
 }
-#endif
 
 // The kernel is written as a small state machine around ONE factor + substitution site:
 //   ST_SMOOTH     s_H = M,            rhs = qfrc_smooth          -> qacc_smooth
@@ -547,6 +546,7 @@ template <int NVP, bool BIG, bool CG>
 __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, const int w, const int lane, const int do_solve, const int do_integrate, const int flags,
                                                  float* smem) {
   constexpr int NB = CholCfg<NVP>::NB, ld = CholCfg<NVP>::LD;
+  constexpr bool TILES = chol_use_tiles(NVP);  // the matrices are factored as MFMA accumulator tiles (common.h); else: the LDS-broadcast column sweep
   const int nv = m.size.nv, nq = m.size.nq, nu = m.size.nu, nj = m.size.njnt, njm = m.size.njmax;
   SolveCtx<NVP> c;
   c.s_H = smem;
@@ -590,13 +590,13 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
 
   if (do_solve) {
     // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
-#if MJLAB_CHOL_TILES
+    if constexpr (TILES) {
     if (!BIG) {
       glds_dense_to_packed(c.s_M, c.M, nv, lane);
       for (int k = ((nv * (nv + 1)) >> 1) + lane; k < NVP * (NVP + 1) / 2; k += 64) c.s_M[k] = 0.f;
       __syncthreads();
     }
-#else
+    } else {
     if (BIG) {
       dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
     } else {
@@ -614,7 +614,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
     }
     chol_pad_rows<NVP>(c.s_H, nv, lane);
     chol_pad_diag<NVP>(c.s_H, nv, lane);
-#endif  // MJLAB_CHOL_TILES
+    }  // !TILES
     rhs = qs;
     state = ST_SMOOTH;
     PROF_MARK(0);
@@ -655,17 +655,17 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
       state = ST_INTEGRATE;
       if (__ballot(need)) {
         __syncthreads();
-#if MJLAB_CHOL_TILES
-        s_vec[lane] = own ? h * diag : 0.f;  // added to the diagonal where the tiles of M are built (the factor site below)
-        __syncthreads();
-#else
-        if (do_solve && !BIG) packed_to_lds(c.s_H, c.s_M, nv, ld, lane);  // M is still on chip
-        else dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
-        chol_pad_rows<NVP>(c.s_H, nv, lane);
-        chol_pad_diag<NVP>(c.s_H, nv, lane);
-        __syncthreads();
-        if (own) c.s_H[lane * ld + lane] += h * diag;
-#endif
+        if constexpr (TILES) {
+          s_vec[lane] = own ? h * diag : 0.f;  // added to the diagonal where the tiles of M are built (the factor site below)
+          __syncthreads();
+        } else {
+          if (do_solve && !BIG) packed_to_lds(c.s_H, c.s_M, nv, ld, lane);  // M is still on chip
+          else dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
+          chol_pad_rows<NVP>(c.s_H, nv, lane);
+          chol_pad_diag<NVP>(c.s_H, nv, lane);
+          __syncthreads();
+          if (own) c.s_H[lane * ld + lane] += h * diag;
+        }
         rhs = own ? qs + fc : 0.f;
         need_factor = true;
       } else {
@@ -689,7 +689,8 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
       }
       PROF_MARK(13);
       PROF_COUNT(15);
-#elif MJLAB_CHOL_TILES
+#else
+      if constexpr (TILES) {
       if (need_factor) {
         // The two factorizations of M per pass (ST_SMOOTH: M, ST_INTEGRATE: M + h diag): the matrix goes from the packed copy on
         // chip (or, BIG / integrate-only passes, from global memory) straight into MFMA accumulator tiles and is taken apart
@@ -709,7 +710,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
       x = chol_solve_tiles<NVP>(c.s_H, c.s_invd, lane, rhs);
       PROF_MARK(13);
       PROF_COUNT(15);
-#else
+      } else {
       if (need_factor) {
         __syncthreads();
         chol_factor<NVP>(c.s_H, c.s_invd, nv, lane);
@@ -720,6 +721,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
       x = chol_solve<NVP>(c.s_H, c.s_invd, lane, rhs);
       PROF_MARK(13);
       PROF_COUNT(15);
+      }
 #endif
     }
 
@@ -808,17 +810,17 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           if (c.nf > 0) fc += friction_rows<NVP>(c);
           rhs = own ? Ma - qs - fc : 0.f;
           if (!CG) {
-#if MJLAB_CHOL_TILES
-            newton_factor<NVP, BIG>(c, htile, nv, lane);
-#else
-            hessian_store<NVP, BIG>(c, htile);
-            if (c.nf > 0) hessian_friction_diag<NVP>(c);
-            chol_pad_diag<NVP>(c.s_H, nv, lane);
-#endif
+            if constexpr (TILES) {
+              newton_factor<NVP, BIG>(c, htile, nv, lane);
+            } else {
+              hessian_store<NVP, BIG>(c, htile);
+              if (c.nf > 0) hessian_friction_diag<NVP>(c);
+              chol_pad_diag<NVP>(c.s_H, nv, lane);
+            }
           }
         }
         PROF_MARK(3);
-        need_factor = !CG && !MJLAB_CHOL_TILES;  // CG: the factor of M is what the gradient goes through; tiles: factored above
+        need_factor = !CG && !TILES;  // CG: the factor of M is what the gradient goes through; tiles: factored above
         state = ST_NEWTON;
       }
     } else {
@@ -913,18 +915,18 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           finished = improvement < IMPROVEMENT_FLOOR || gradient < tol || gradient < grad_noise(c.noise_ulps, scale, own, Ma, qs, fc) || iter >= maxiter;
           if (!finished) {
             __syncthreads();
-#if MJLAB_CHOL_TILES
-            PROF_MARK(7);
-            newton_factor<NVP, BIG>(c, htile, nv, lane);
-            PROF_MARK(12);
-            PROF_COUNT(14);
-#else
-            hessian_store<NVP, BIG>(c, htile);
-            if (c.nf > 0) hessian_friction_diag<NVP>(c);
-            chol_pad_diag<NVP>(c.s_H, nv, lane);
-#endif
+            if constexpr (TILES) {
+              PROF_MARK(7);
+              newton_factor<NVP, BIG>(c, htile, nv, lane);
+              PROF_MARK(12);
+              PROF_COUNT(14);
+            } else {
+              hessian_store<NVP, BIG>(c, htile);
+              if (c.nf > 0) hessian_friction_diag<NVP>(c);
+              chol_pad_diag<NVP>(c.s_H, nv, lane);
+            }
           }
-          need_factor = !MJLAB_CHOL_TILES;
+          need_factor = !TILES;
         } else {  // same active set -> same H -> the factor in LDS is still valid
           f32x4 unused[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, false>(c, unused, s_act, nact);
