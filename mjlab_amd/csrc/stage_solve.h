@@ -156,6 +156,109 @@ __device__ __forceinline__ int build_active_list(const SolveCtx<NVP>& c, int* s_
   }
   return nact;
 }
+// `am`: the active set of rows 0..63 / 64..127 as bit masks (what the low-rank correction of the factor compares, below).
+template <int NVP>
+__device__ __forceinline__ int build_active_list(const SolveCtx<NVP>& c, int* s_act, unsigned long long (&am)[2]) {
+  int nact = 0;
+  am[0] = am[1] = 0ull;
+  for (int r0 = 0; r0 < c.nefc; r0 += 64) {
+    const int r = r0 + c.lane;
+    const bool act = r < c.nefc && r >= c.nf && c.s_jar[r] < 0.f;  // friction-loss rows: friction_rows() below
+    const unsigned long long mask = __ballot(act);
+    if (act) s_act[nact + __popcll(mask & ((1ull << c.lane) - 1ull))] = r;
+    nact += __popcll(mask);
+    if (r0 == 0) am[0] = mask;
+    if (r0 == 64) am[1] = mask;
+  }
+  return nact;
+}
+
+// ---- LOW-RANK CORRECTION OF THE FACTOR (round 5, MJLAB_SMW).  A Newton iteration that moves 1..3 rows across their zone boundary changes
+// the Hessian by that many rank-1 terms, H_new = H_fact + sum_q s_q u_q u_q^T (u_q = row q of J, s_q = +D_q for a row that became
+// active, -D_q for one that left): 1.7 of the 4.2 refactorizations per world-step are of that kind (profiles/r04_v12).  Instead of a
+// new Hessian pass and a new factorization (~1 600 VALU instructions + 75 MFMAs) the factor in LDS is KEPT and the Newton direction
+// comes from the Sherman-Morrison-Woodbury identity
+//     H_new^-1 g = x0 - Z (S^-1 + U^T Z)^-1 U^T x0,     x0 = H_fact^-1 g,  Z = H_fact^-1 U
+// i.e. one substitution per changed row when the set of changed rows changes (Z goes to LDS: the friction-loss scratch, idle in worlds
+// without such rows), and per iteration <= 3 dot products, a 3 x 3 solve with wave-uniform numbers and <= 3 multiply-adds.  The
+// correction set is the difference between the CURRENT active set and the one the factor was built for (bit masks of rows 0..127), so
+// small changes accumulate until more than 3 rows differ -- then, or when the 3 x 3 system is ill-conditioned, the Hessian is rebuilt
+// and refactored as before.  Exact in exact arithmetic; in fp32 another rounding of the same direction.
+// MEASURED (profiles/r05_v17), NOT THE DEFAULT: 1.4 of the 5.2 counted factorizations per world-step go away (2.2 iterations run on a
+// corrected factor) and 4096 worlds step 1.4 % faster (3.451 -> 3.501 M env-steps/s), but the corrected directions are noisier -- a row
+// that becomes ACTIVE is stiff (D ~ 1e3..1e5), the uncorrected x0 is large along it and the correction subtracts it again -- so the
+// solver needs 3 % more Newton iterations (3.93 -> 4.05; the parity gate's bound on the iteration count against the restatement trips on the
+// tracking scene) for the same medians and p99.  A factor UPDATE (mju_cholUpdate's recurrence) would not cancel like that, but on this
+// storage it is a 36-step sweep of ~12 instructions + 2 LDS accesses per column and row: no cheaper than the panels for 2-3 rows.
+#ifndef MJLAB_SMW
+#define MJLAB_SMW 0
+#endif
+struct SmwState {
+  unsigned long long fact[2];  // active set the factor in LDS belongs to
+  unsigned long long diff[2];  // rows whose activity differs from it (the correction set); 0 = none
+  int n;                       // number of correction rows (0..3)
+  int row[3];
+  float ki[6];                 // inverse of K = S^-1 + U^T Z (symmetric: 00 01 02 11 12 22), padded with identity rows.  (Parked in LDS instead
+                               // -- six fewer values live around the Newton loop -- the kernel allocates WORSE: 47 spilled VGPRs against 27.)
+};
+// Z_q = H_fact^-1 u_q and K^-1 for the rows of `diff`; returns false when K is too ill-conditioned to trust (caller refactors).
+template <int NVP>
+__device__ __forceinline__ bool smw_setup(const SolveCtx<NVP>& c, SmwState& sw, const unsigned long long (&now)[2], const unsigned long long (&diff)[2], int nd,
+                                          float* s_z) {
+  unsigned long long lo = diff[0], hi = diff[1];
+  float u[3], z[3], si[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    u[q] = 0.f; z[q] = 0.f; si[q] = 1.f; sw.row[q] = 0;
+    if (q < nd) {
+      int r;
+      if (lo) { r = (int)__builtin_ctzll(lo); lo &= lo - 1ull; }
+      else { r = 64 + (int)__builtin_ctzll(hi); hi &= hi - 1ull; }
+      const bool added = r < 64 ? ((now[0] >> r) & 1ull) != 0ull : ((now[1] >> (r - 64)) & 1ull) != 0ull;
+      const float Dr = c.s_D[r];
+      si[q] = added ? 1.f / Dr : -1.f / Dr;
+      sw.row[q] = r;
+      u[q] = c.lane < c.nv ? c.J[(size_t)r * c.nv + launder(c.lane)] : 0.f;
+      z[q] = chol_solve_tiles<NVP>(c.s_H, c.s_invd, c.lane, u[q]);
+      if (c.lane < NVP) s_z[q * NVP + c.lane] = z[q];
+    }
+  }
+  // K = S^-1 + U^T Z (symmetric), identity where q >= nd
+  const float k00 = si[0] + wave_sum(u[0] * z[0]);
+  float k01 = 0.f, k11 = 1.f, k02 = 0.f, k12 = 0.f, k22 = 1.f;
+  if (nd > 1) { k01 = wave_sum(u[0] * z[1]); k11 = si[1] + wave_sum(u[1] * z[1]); }
+  if (nd > 2) { k02 = wave_sum(u[0] * z[2]); k12 = wave_sum(u[1] * z[2]); k22 = si[2] + wave_sum(u[2] * z[2]); }
+  // inverse by cofactors; the determinant against the product of the diagonal tells how far K is from singular
+  const float c00 = k11 * k22 - k12 * k12, c01 = k02 * k12 - k01 * k22, c02 = k01 * k12 - k02 * k11;
+  const float det = k00 * c00 + k01 * c01 + k02 * c02;
+  const float scale = fabsf(k00 * k11 * k22);
+  if (!(fabsf(det) > 1e-4f * scale) || !(scale > 0.f)) return false;
+  const float id = 1.f / det;
+  sw.ki[0] = c00 * id; sw.ki[1] = c01 * id; sw.ki[2] = c02 * id;
+  sw.ki[3] = (k00 * k22 - k02 * k02) * id; sw.ki[4] = (k01 * k02 - k00 * k12) * id; sw.ki[5] = (k00 * k11 - k01 * k01) * id;
+  sw.diff[0] = diff[0]; sw.diff[1] = diff[1]; sw.n = nd;
+  return true;
+}
+// x0 = H_fact^-1 g  ->  H_new^-1 g
+template <int NVP>
+__device__ __forceinline__ float smw_apply(const SolveCtx<NVP>& c, const SmwState& sw, const float* s_z, float x0) {
+  float t[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (q < sw.n) {
+      const float uq = c.lane < c.nv ? c.J[(size_t)sw.row[q] * c.nv + launder(c.lane)] : 0.f;
+      t[q] = wave_sum(uq * x0);
+    }
+  const float c0 = sw.ki[0] * t[0] + sw.ki[1] * t[1] + sw.ki[2] * t[2];
+  const float c1 = sw.ki[1] * t[0] + sw.ki[3] * t[1] + sw.ki[4] * t[2];
+  const float c2 = sw.ki[2] * t[0] + sw.ki[4] * t[1] + sw.ki[5] * t[2];
+  const int li = c.lane < NVP ? c.lane : NVP - 1;
+  float x = x0;
+  if (sw.n > 0) x -= c0 * s_z[li];
+  if (sw.n > 1) x -= c1 * s_z[NVP + li];
+  if (sw.n > 2) x -= c2 * s_z[2 * NVP + li];
+  return x;
+}
 
 template <int NVP, bool WITH_H>
 __device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2], const int* s_act, int nact) {
@@ -586,6 +689,12 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
   float cg_search = 0.f, cg_grad = 0.f, cg_Mgrad = 0.f;  // CG: the previous direction, gradient and M^-1 gradient
   int iter = 0, state;
   bool need_factor = true;
+  // low-rank correction of the Newton factor (above): tile factorization, worlds whose rows fit the masks, no friction-loss rows
+#if MJLAB_SMW
+  constexpr bool SMW = TILES && !BIG && !CG;
+  SmwState sw;
+  sw.fact[0] = sw.fact[1] = sw.diff[0] = sw.diff[1] = 0ull; sw.n = 0;
+#endif
   PROF_INIT();
 
   if (do_solve) {
@@ -708,6 +817,11 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         PROF_COUNT(14);
       }
       x = chol_solve_tiles<NVP>(c.s_H, c.s_invd, lane, rhs);
+#if MJLAB_SMW
+      if constexpr (SMW) {
+        if (state == ST_NEWTON && sw.n > 0) x = smw_apply<NVP>(c, sw, c.s_fl, x);
+      }
+#endif
       PROF_MARK(13);
       PROF_COUNT(15);
       } else {
@@ -803,7 +917,13 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         {
           __syncthreads();
           int* s_act = (int*)c.s_jv;
+#if MJLAB_SMW
+          unsigned long long am[2];
+          const int nact = build_active_list<NVP>(c, s_act, am);
+          sw.fact[0] = am[0]; sw.fact[1] = am[1]; sw.n = 0;
+#else
           const int nact = build_active_list<NVP>(c, s_act);
+#endif
           __syncthreads();
           f32x4 htile[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, !CG>(c, htile, s_act, nact);
@@ -877,13 +997,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           c.s_jar[r] = nw;
         }
         const bool any_changed = __ballot(changed) != 0ull;
-#ifdef MJLAB_PROFILE  // how many rows switch zone per Newton iteration (slots 1 and 4 carry no phase): would rank-1 updates of the factor pay?
-        {
-          const int nch = __popcll(__ballot(changed));
-          prof_acc_[1] += (float)nch;
-          if (nch > 0 && nch <= 3) prof_acc_[4] += 1.f;
-        }
-#endif
+
         __syncthreads();
         const float oldcost = cost;
         if (LS_BY_DIFFERENCES) {
@@ -903,9 +1017,44 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         // out so that the 24 tile registers are live only inside the branch that needs them.)
         iter++;
         int* s_act = (int*)c.s_jv;  // J search is dead until the next line search
+#if !MJLAB_SMW
         const int nact = build_active_list<NVP>(c, s_act);
         __syncthreads();
-        if (!CG && any_changed) {
+        const bool refactor = !CG && any_changed;
+#else
+        unsigned long long am[2];
+        const int nact = build_active_list<NVP>(c, s_act, am);
+        __syncthreads();
+        bool refactor = !CG && any_changed;
+        if constexpr (SMW) {
+          if (c.nf == 0 && nefc <= 128) {
+            // the factor in LDS belongs to the active set sw.fact: 0 rows differ -> it is this Hessian's; 1..3 -> kept and corrected;
+            // more (or an ill-conditioned correction) -> rebuilt
+            const unsigned long long df[2] = {am[0] ^ sw.fact[0], am[1] ^ sw.fact[1]};
+            const int nd = __popcll(df[0]) + __popcll(df[1]);
+            refactor = false;
+            if (nd == 0) {
+              sw.n = 0;
+            } else if (nd <= 3) {
+              if (!(sw.n == nd && sw.diff[0] == df[0] && sw.diff[1] == df[1])) {
+                __syncthreads();
+                if (!smw_setup<NVP>(c, sw, am, df, nd, c.s_fl)) refactor = true;
+                __syncthreads();
+#ifdef MJLAB_PROFILE  // (slots 1 and 4 carry no phase: corrections set up / iterations that ran on a corrected factor)
+                prof_acc_[4] += 1.f;
+#endif
+              }
+#ifdef MJLAB_PROFILE
+              if (!refactor) prof_acc_[1] += 1.f;
+#endif
+            } else {
+              refactor = true;
+            }
+            if (refactor) { sw.fact[0] = am[0]; sw.fact[1] = am[1]; sw.n = 0; }
+          }
+        }
+#endif
+        if (refactor) {
           f32x4 htile[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, true>(c, htile, s_act, nact);
           if (c.nf > 0) fc += friction_rows<NVP>(c);

@@ -42,8 +42,8 @@ for i, n in enumerate(NAMES):
   else:
     print(f"  {n:28s} {p[:, i].mean():10.2f}")
 print("nefc mean", sim.data.nefc.float().mean().item(), "niter mean", sim.data.solver_niter.float().mean().item())
-print(f"rows that switch zone per world-step: {p[:, 1].mean():.2f} (per line search {p[:, 1].mean() / max(p[:, 11].mean(), 1e-9):.2f}); "
-      f"iterations whose active set changed by 1..3 rows: {p[:, 4].mean():.2f} of {p[:, 14].mean() - 2:.2f} refactorizations per world-step")
+print(f"low-rank corrections per world-step (MJLAB_SMW): {p[:, 1].mean():.2f} iterations ran on a corrected factor ({p[:, 4].mean():.2f} set-ups), "
+      f"{p[:, 14].mean():.2f} factorizations counted at the M / Newton sites, {p[:, 11].mean():.2f} line searches")
 # the kernel ends with its slowest wave: same breakdown for the slowest 2% of worlds
 slow = np.argsort(tot)[-max(1, len(tot) // 50):]
 print(f"slowest 2% of worlds: mean cycles {tot[slow].mean():.0f}; nefc {sim.data.nefc.cpu().numpy().ravel()[slow].mean():.1f}; niter {sim.data.solver_niter.cpu().numpy().ravel()[slow].mean():.2f}")
