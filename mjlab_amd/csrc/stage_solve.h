@@ -184,12 +184,14 @@ __device__ __forceinline__ int build_active_list(const SolveCtx<NVP>& c, int* s_
 // correction set is the difference between the CURRENT active set and the one the factor was built for (bit masks of rows 0..127), so
 // small changes accumulate until more than 3 rows differ -- then, or when the 3 x 3 system is ill-conditioned, the Hessian is rebuilt
 // and refactored as before.  Exact in exact arithmetic; in fp32 another rounding of the same direction.
-// MEASURED (profiles/r05_v17), NOT THE DEFAULT: 1.4 of the 5.2 counted factorizations per world-step go away (2.2 iterations run on a
-// corrected factor) and 4096 worlds step 1.4 % faster (3.451 -> 3.501 M env-steps/s), but the corrected directions are noisier -- a row
-// that becomes ACTIVE is stiff (D ~ 1e3..1e5), the uncorrected x0 is large along it and the correction subtracts it again -- so the
-// solver needs 3 % more Newton iterations (3.93 -> 4.05; the parity gate's bound on the iteration count against the restatement trips on the
-// tracking scene) for the same medians and p99.  A factor UPDATE (mju_cholUpdate's recurrence) would not cancel like that, but on this
-// storage it is a 36-step sweep of ~12 instructions + 2 LDS accesses per column and row: no cheaper than the panels for 2-3 rows.
+// MEASURED (profiles/r05_v17, r05_v18), NOT THE DEFAULT: 1.4 of the 5.2 counted factorizations per world-step go away (2.2 iterations run
+// on a corrected factor), but the corrected directions are noisier -- a row that becomes ACTIVE is stiff (D ~ 1e3..1e5), the
+// uncorrected x0 is large along it and the correction subtracts it again -- so the solver needs 2.7-3 % more Newton iterations (4.68 ->
+// 4.80 in the bench rollout; the parity gate's bound on the iteration count trips on the tracking scene), the kernel allocates 27
+// spilled VGPRs instead of 16, and against the default build 4096 worlds step at the same rate (3.395 against 3.397 M env-steps/s; the
+// +1.4 % of the first A/B was against a base build that the new code paths had perturbed).  MJLAB_SMW=2 corrects REMOVED rows only
+// (no cancellation: iterations unchanged, 4.69) and is 0.6 % slower.  A factor UPDATE (mju_cholUpdate's recurrence) would not cancel,
+// but on this storage it is a 36-step sweep of ~12 instructions + 2 LDS accesses per column and row: no cheaper than the panels.
 #ifndef MJLAB_SMW
 #define MJLAB_SMW 0
 #endif
@@ -1035,7 +1037,11 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
             refactor = false;
             if (nd == 0) {
               sw.n = 0;
+#if MJLAB_SMW == 2  // removals only: a row that LEFT the active set is corrected without cancellation (x0 is small along it, the correction adds)
+            } else if (nd <= 3 && (df[0] & am[0]) == 0ull && (df[1] & am[1]) == 0ull) {
+#else
             } else if (nd <= 3) {
+#endif
               if (!(sw.n == nd && sw.diff[0] == df[0] && sw.diff[1] == df[1])) {
                 __syncthreads();
                 if (!smw_setup<NVP>(c, sw, am, df, nd, c.s_fl)) refactor = true;
