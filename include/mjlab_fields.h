@@ -202,7 +202,10 @@ enum { MJLAB_OBJ_BODY = 1, MJLAB_OBJ_XBODY = 2, MJLAB_OBJ_GEOM = 5, MJLAB_OBJ_SI
 enum { MJLAB_INT_EULER = 0, MJLAB_INT_IMPLICITFAST = 3 };
 enum { MJLAB_SOL_PGS = 0, MJLAB_SOL_CG = 1, MJLAB_SOL_NEWTON = 2 };
 /* mjtConstraint (reference typings/mujoco/_enums.pyi:1029): values of efc_type */
-enum { MJLAB_EFC_FRICTION_DOF = 1, MJLAB_EFC_LIMIT = 3, MJLAB_EFC_CONTACT_FRICTIONLESS = 5, MJLAB_EFC_CONTACT_PYRAMIDAL = 6 };
+enum { MJLAB_EFC_FRICTION_DOF = 1, MJLAB_EFC_LIMIT = 3, MJLAB_EFC_CONTACT_FRICTIONLESS = 5, MJLAB_EFC_CONTACT_PYRAMIDAL = 6,
+       MJLAB_EFC_CONTACT_ELLIPTIC = 7 /* rows [normal, tangent 1, tangent 2] of a condim-3 contact under mjlab_option_t.cone = MJLAB_CONE_ELLIPTIC */ };
+/* mjtCone: values of mjlab_option_t.cone */
+enum { MJLAB_CONE_PYRAMIDAL = 0, MJLAB_CONE_ELLIPTIC = 1 };
 
 /* Sizes shared by model and data (host struct, passed by pointer). */
 typedef struct mjlab_sizes {

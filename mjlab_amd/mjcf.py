@@ -450,6 +450,10 @@ class _MjcfParser:
         o.ls_iterations = int(opt.get("ls_iterations"))
       if opt.get("tolerance"):
         o.tolerance = float(opt.get("tolerance"))
+      if opt.get("cone"):
+        o.cone = {"pyramidal": CONE_PYRAMIDAL, "elliptic": CONE_ELLIPTIC}[opt.get("cone")]
+      if opt.get("impratio"):
+        o.impratio = float(opt.get("impratio"))
     wb = root.find("worldbody")
     if wb is not None:
       self._parse_body_children(wb, self.spec.world, None)

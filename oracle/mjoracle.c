@@ -870,7 +870,8 @@ static void make_constraint(const mjo_model_t* m, mjo_data_t* d, int w) {
     real dist = D(contact_dist, ncm)[c], inc = D(contact_includemargin, ncm)[c];
     (d->contact_efc_address + (size_t)w * ncm)[c] = -1;
     if (dist >= inc) continue;
-    int nrow = dim == 1 ? 1 : 2 * (dim - 1);
+    const int elliptic = m->opt.cone == MJLAB_CONE_ELLIPTIC;
+    int nrow = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
     if (nefc + nrow > njm) { d->overflow[w] |= MJLAB_OVF_NJMAX; continue; }
     int g1 = (d->contact_geom + (size_t)w * 2 * ncm)[2 * c], g2 = (d->contact_geom + (size_t)w * 2 * ncm)[2 * c + 1];
     int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
@@ -902,6 +903,26 @@ static void make_constraint(const mjo_model_t* m, mjo_data_t* d, int w) {
       memcpy(J + (size_t)nefc * nv, jf[0], sizeof(real) * nv);
       finish_row(m, d, w, nefc, dist, inc, solref, solimp, tran, MJLAB_EFC_CONTACT_FRICTIONLESS, c);
       nefc++;
+    } else if (elliptic) {
+      /* ELLIPTIC cone (mj_instantiateContact + mj_makeImpedance, restated from MuJoCo's documented model; UNVERIFIED like the rest):
+       * dim rows = the contact-frame components of the relative acceleration [normal, tangent 1, tangent 2]; only the normal row has
+       * a position (dist) and margin, the friction rows are pure velocity constraints (pos = margin = 0: aref = -b * vel).  The normal
+       * row's regulariser R comes from the impedance as for every row; the friction rows get R_1 = R_0 / impratio and
+       * R_j = R_1 friction[0]^2 / friction[j-1]^2, and the cone's friction coefficient in the regularised problem is
+       * mu = friction[0] sqrt(R_1 / R_0) = friction[0] / sqrt(impratio) (the solver below reads it the same way). */
+      int first = nefc;
+      for (int k = 0; k < dim; k++) {
+        memcpy(J + (size_t)nefc * nv, jf[k], sizeof(real) * nv);
+        finish_row(m, d, w, nefc, k == 0 ? dist : 0, k == 0 ? inc : 0, solref, solimp, tran, MJLAB_EFC_CONTACT_ELLIPTIC, c);
+        nefc++;
+      }
+      real R0 = 1 / D(efc_D, njm)[first], ir = (real)m->opt.impratio;
+      real R1 = R0 / (ir > MINVAL ? ir : MINVAL);
+      for (int k = 1; k < dim; k++) {
+        real Rk = R1 * fri[0] * fri[0] / (fri[k - 1] * fri[k - 1]);
+        if (Rk < MINVAL) Rk = MINVAL;
+        D(efc_D, njm)[first + k] = 1 / Rk;
+      }
     } else {
       int first = nefc;
       for (int k = 1; k < dim; k++) {
@@ -1042,7 +1063,13 @@ typedef struct {
   const real *J, *Dv, *aref, *floss, *M, *qfrc_smooth, *qacc_smooth;
   real *qacc, *Ma, *jar, *grad, *search, *Mv, *jv, *force, *qfrc_constraint, *H;
   real quad_gauss[3], cost, gauss;
+  /* elliptic cones: row r with type[r] == MJLAB_EFC_CONTACT_ELLIPTIC that is the FIRST row of its contact (r == cadr[id[r]]) starts a
+   * group of 3 rows [normal, tangent 1, tangent 2]; fri = contact_friction (5 per contact), impratio from the options */
+  const int *type, *id, *cadr;
+  const real* fri;
+  real impratio;
 } nctx_t;
+static inline int cone_start(const nctx_t* c, int r) { return c->type && c->type[r] == MJLAB_EFC_CONTACT_ELLIPTIC && c->cadr[c->id[r]] == r; }
 
 typedef struct { real alpha, cost, d0, d1; } lspnt_t;
 
@@ -1062,18 +1089,67 @@ static inline int row_cost(const nctx_t* c, int r, real x, real* cost, real* for
   *force = 0; *cost = 0; return 0;
 }
 
+/* One elliptic contact (condim 3) at residuals x[3] = (J qacc - aref) of its rows [normal, t1, t2] (mj_constraintUpdate, elliptic branch,
+ * restated from the cone's definition).  With mu = friction[0] / sqrt(impratio), U = (mu x0, f1 x1, f2 x2), N = U0, T = |(U1, U2)|:
+ *   top zone     N >= mu T (or T = 0, N >= 0): satisfied, cost 0, force 0;
+ *   bottom zone  mu N + T <= 0 (or T = 0, N < 0): every row quadratic, cost = 0.5 sum_k D_k x_k^2, force_k = -D_k x_k;
+ *   middle zone  otherwise: cost = 0.5 Dm (N - mu T)^2 with Dm = D_0 / (mu^2 (1 + mu^2)); force = -d cost / d x.
+ * The three pieces join continuously (the friction rows' D_k = D_0 friction[0]^2 / (mu^2 friction[k-1]^2) is what makes them).
+ * H (optional): the 3 x 3 Hessian d^2 cost / d x^2 (row-major).  Returns the zone: 0 top, 1 bottom, 2 middle. */
+static int cone_eval(const nctx_t* c, int r, const real* x, real* cost, real* force, real* H) {
+  const real* fr = c->fri + 5 * c->id[r];
+  real mu = fr[0] / (real)sqrt(c->impratio > MINVAL ? c->impratio : MINVAL);
+  real f[3] = {mu, fr[0], fr[1]};
+  real U[3] = {x[0] * f[0], x[1] * f[1], x[2] * f[2]};
+  real N = U[0], T = (real)sqrt(U[1] * U[1] + U[2] * U[2]);
+  if (H) memset(H, 0, 9 * sizeof(real));
+  if (N >= mu * T || (T <= 0 && N >= 0)) {
+    *cost = 0; force[0] = force[1] = force[2] = 0;
+    return 0;
+  }
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    *cost = 0;
+    for (int k = 0; k < 3; k++) {
+      real Dk = c->Dv[r + k];
+      *cost += (real)0.5 * Dk * x[k] * x[k];
+      force[k] = -Dk * x[k];
+      if (H) H[4 * k] = Dk;
+    }
+    return 1;
+  }
+  real Dm = c->Dv[r] / (mu * mu * (1 + mu * mu)), phi = N - mu * T;
+  *cost = (real)0.5 * Dm * phi * phi;
+  /* g = d phi / d x = (mu, -mu f1 U1 / T, -mu f2 U2 / T) */
+  real g[3] = {mu, -mu * f[1] * U[1] / T, -mu * f[2] * U[2] / T};
+  for (int k = 0; k < 3; k++) force[k] = -Dm * phi * g[k];
+  if (H) {
+    /* d^2 cost = Dm (g g^T + phi d^2 phi), d^2 phi = -mu d^2 T, d^2 T_jk = f_j f_k (delta_jk / T - U_j U_k / T^3), j, k >= 1 */
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        real h = g[a] * g[b];
+        if (a >= 1 && b >= 1) h += phi * (-mu) * f[a] * f[b] * ((a == b ? 1 / T : 0) - U[a] * U[b] / (T * T * T));
+        H[3 * a + b] = Dm * h;
+      }
+  }
+  return 2;
+}
+
 static void update_constraint(nctx_t* c) {
   int nv = c->nv;
   real cost = 0;
   memset(c->qfrc_constraint, 0, sizeof(real) * nv);
   for (int r = 0; r < c->nefc; r++) {
     real rc;
-    row_cost(c, r, c->jar[r], &rc, &c->force[r]);
+    int nr = 1;
+    if (cone_start(c, r)) { cone_eval(c, r, c->jar + r, &rc, c->force + r, NULL); nr = 3; }
+    else row_cost(c, r, c->jar[r], &rc, &c->force[r]);
     cost += rc;
-    if (c->force[r] != 0) {
-      const real* row = c->J + (size_t)r * nv;
-      for (int i = 0; i < nv; i++) c->qfrc_constraint[i] += row[i] * c->force[r];
-    }
+    for (int k = 0; k < nr; k++)
+      if (c->force[r + k] != 0) {
+        const real* row = c->J + (size_t)(r + k) * nv;
+        for (int i = 0; i < nv; i++) c->qfrc_constraint[i] += row[i] * c->force[r + k];
+      }
+    r += nr - 1;
   }
   real gauss = 0;
   for (int i = 0; i < nv; i++) gauss += (real)0.5 * (c->Ma[i] - c->qfrc_smooth[i]) * (c->qacc[i] - c->qacc_smooth[i]);
@@ -1092,6 +1168,23 @@ static void update_gradient(nctx_t* c) {
   memcpy(c->H, c->M, sizeof(real) * nv * nv);
   for (int r = 0; r < c->nefc; r++) {
     real rc, rfo;
+    if (cone_start(c, r)) { /* H += Jc^T Hc Jc with the cone's 3 x 3 Hessian (diagonal D in the bottom zone, dense in the middle zone) */
+      real fo[3], Hc[9];
+      if (cone_eval(c, r, c->jar + r, &rc, fo, Hc)) {
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) {
+            if (Hc[3 * a + b] == 0) continue;
+            const real *ra = c->J + (size_t)(r + a) * nv, *rb = c->J + (size_t)(r + b) * nv;
+            for (int i = 0; i < nv; i++) {
+              if (ra[i] == 0) continue;
+              real t = Hc[3 * a + b] * ra[i];
+              for (int j = 0; j <= i; j++) c->H[i * nv + j] += t * rb[j];
+            }
+          }
+      }
+      r += 2;
+      continue;
+    }
     if (!row_cost(c, r, c->jar[r], &rc, &rfo)) continue;
     const real* row = c->J + (size_t)r * nv;
     real Dr = c->Dv[r];
@@ -1117,6 +1210,18 @@ static void ls_eval(nctx_t* c, lspnt_t* p, real alpha) {
   real cost = alpha * alpha * c->quad_gauss[2] + alpha * c->quad_gauss[1] + c->quad_gauss[0];
   real d0 = 2 * alpha * c->quad_gauss[2] + c->quad_gauss[1], d1 = 2 * c->quad_gauss[2];
   for (int r = 0; r < c->nefc; r++) {
+    if (cone_start(c, r)) { /* cost, slope -force . jv and curvature jv^T Hc jv of the cone along the direction */
+      real x[3], fo[3], Hc[9], rc;
+      for (int k = 0; k < 3; k++) x[k] = c->jar[r + k] + alpha * c->jv[r + k];
+      cone_eval(c, r, x, &rc, fo, Hc);
+      cost += rc;
+      for (int a = 0; a < 3; a++) {
+        d0 -= fo[a] * c->jv[r + a];
+        for (int b = 0; b < 3; b++) d1 += c->jv[r + a] * Hc[3 * a + b] * c->jv[r + b];
+      }
+      r += 2;
+      continue;
+    }
     real x = c->jar[r] + alpha * c->jv[r];
     if (r < c->nf) { /* friction loss: linear outside |x| < R f (mj PrimalEval) */
       real f = c->floss[r], rf = f / c->Dv[r];
@@ -1204,6 +1309,15 @@ static real line_search(const mjo_model_t* m, nctx_t* c) {
       if (sizeof(real) == 4 && !(m->opt.flags & MJLAB_OPT_LS_LITERAL_COST)) {
         real acc = 0;
         for (int r = c->nf; r < c->nefc; r++) {
+          if (cone_start(c, r)) { /* (no product-of-differences form for a cone: the difference of its two costs) */
+            real x[3], fo[3], ca, c0;
+            for (int k = 0; k < 3; k++) x[k] = c->jar[r + k] + alpha * c->jv[r + k];
+            cone_eval(c, r, x, &ca, fo, NULL);
+            cone_eval(c, r, c->jar + r, &c0, fo, NULL);
+            acc += 2 * (ca - c0);
+            r += 2;
+            continue;
+          }
           real x = c->jar[r] + alpha * c->jv[r], xm = x < 0 ? x : 0, xm0 = c->jar[r] < 0 ? c->jar[r] : 0;
           acc += c->Dv[r] * (xm - xm0) * (xm + xm0);
         }
@@ -1260,12 +1374,17 @@ static real constraint_cost_at(nctx_t* c, const real* qacc, int with_gauss) {
   int nv = c->nv;
   real cost = 0;
   for (int r = 0; r < c->nefc; r++) {
-    const real* row = c->J + (size_t)r * nv;
-    real x = -c->aref[r];
-    for (int i = 0; i < nv; i++) x += row[i] * qacc[i];
-    real rc, rfo;
-    row_cost(c, r, x, &rc, &rfo);
+    int nr = cone_start(c, r) ? 3 : 1;
+    real x[3], rc, fo[3];
+    for (int k = 0; k < nr; k++) {
+      const real* row = c->J + (size_t)(r + k) * nv;
+      x[k] = -c->aref[r + k];
+      for (int i = 0; i < nv; i++) x[k] += row[i] * qacc[i];
+    }
+    if (nr == 3) cone_eval(c, r, x, &rc, fo, NULL);
+    else row_cost(c, r, x[0], &rc, fo);
     cost += rc;
+    r += nr - 1;
   }
   if (with_gauss)
     for (int i = 0; i < nv; i++) {
@@ -1369,6 +1488,11 @@ static void solve(const mjo_model_t* m, mjo_data_t* d, int w) {
   c.J = D(efc_J, njm * nv); c.Dv = D(efc_D, njm); c.aref = D(efc_aref, njm); c.floss = D(efc_frictionloss, njm); c.M = D(qM, nv * nv);
   c.qfrc_smooth = D(qfrc_smooth, nv); c.qacc_smooth = qas; c.qacc = qacc; c.force = force;
   c.qfrc_constraint = D(qfrc_constraint, nv);
+  c.type = m->opt.cone == MJLAB_CONE_ELLIPTIC ? d->efc_type + (size_t)w * njm : NULL;
+  c.id = d->efc_id + (size_t)w * njm;
+  c.cadr = d->contact_efc_address + (size_t)w * s->nconmax;
+  c.fri = D(contact_friction, 5 * s->nconmax);
+  c.impratio = (real)m->opt.impratio;
   c.cg = m->opt.solver == MJLAB_SOL_CG;
   c.L = D(qLD, nv * nv);
   real* buf = (real*)calloc((size_t)8 * nv + 2 * nefc + (size_t)nv * nv, sizeof(real));

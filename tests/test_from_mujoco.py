@@ -65,7 +65,8 @@ def test_enum_ids_match_the_pinned_mujoco_build():
   hdr = (Path(__file__).resolve().parents[1] / "include" / "mjlab_fields.h").read_text()
   efc = {k: int(v) for k, v in re.findall(r"MJLAB_EFC_(\w+) = (\d+)", hdr)}
   assert efc == {"FRICTION_DOF": e["mjCNSTR_FRICTION_DOF"], "LIMIT": e["mjCNSTR_LIMIT_JOINT"],
-                 "CONTACT_FRICTIONLESS": e["mjCNSTR_CONTACT_FRICTIONLESS"], "CONTACT_PYRAMIDAL": e["mjCNSTR_CONTACT_PYRAMIDAL"]}
+                 "CONTACT_FRICTIONLESS": e["mjCNSTR_CONTACT_FRICTIONLESS"], "CONTACT_PYRAMIDAL": e["mjCNSTR_CONTACT_PYRAMIDAL"],
+                 "CONTACT_ELLIPTIC": e["mjCNSTR_CONTACT_ELLIPTIC"]}
   # the actuator checks of from_mujoco assume these
   assert (e["mjTRN_JOINT"], e["mjGAIN_FIXED"], e["mjBIAS_NONE"], e["mjBIAS_AFFINE"], e["mjDYN_NONE"]) == (0, 0, 0, 1, 0)
 

@@ -1,0 +1,203 @@
+"""Elliptic friction cones in the CPU restatement (oracle/mjoracle.c; VERDICT round 4, item 6: "oracle first").  mjlab's SimulationCfg
+accepts ``cone="elliptic"`` (reference sim/sim.py:49,52); no registered task uses it.  Like everything else in the restatement the
+cone model -- rows [normal, tangent 1, tangent 2] per condim-3 contact, friction rows regularised with R_0 / impratio, mu =
+friction / sqrt(impratio), the three zones of the dual cone -- is restated from MuJoCo's documentation and UNPINNED; what is checked
+here does not depend on that recollection being right in every constant: Coulomb's law on an incline, the optimality conditions of
+the convex problem the rows define, and membership of the contact forces in the cone."""
+
+import numpy as np
+import pytest
+
+from mjlab_amd import robots
+from mjlab_amd.mjcf import CONE_ELLIPTIC, CONE_PYRAMIDAL, INT_IMPLICITFAST, Spec
+from oracle.oracle import OracleSim
+
+G = 9.81
+
+
+SLAB_XML = """<mujoco model="slab_on_plane">
+  <compiler angle="radian"/>
+  <option timestep="0.002"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 0.01" friction="{mu} 0.005 0.0001"/>
+    <body name="box" pos="0 0 0.02">
+      <inertial pos="0 0 0" mass="2" diaginertia="0.027 0.027 0.053"/>
+      <freejoint name="root"/>
+      <geom name="box_geom" type="box" size="0.2 0.2 0.02" friction="{mu} 0.005 0.0001"/>
+    </body>
+  </worldbody>
+</mujoco>"""
+
+
+def _box(mu: float, gravity, cone=CONE_ELLIPTIC, impratio: float = 1.0):
+  """a 2 kg slab (0.4 x 0.4 x 0.04: the friction torque about its low centre of mass does not rock it) on the plane"""
+  spec = Spec.from_string(SLAB_XML.format(mu=mu))
+  spec.option.integrator = INT_IMPLICITFAST
+  spec.option.cone = cone
+  spec.option.impratio = impratio
+  spec.option.gravity = tuple(gravity)
+  spec.option.iterations, spec.option.ls_iterations, spec.option.tolerance = 50, 50, 1e-10
+  return spec.compile()
+
+
+def _tilt(theta, phi=0.0):
+  """gravity of a plane tilted by theta, downhill direction at azimuth phi in the plane"""
+  return (G * np.sin(theta) * np.cos(phi), G * np.sin(theta) * np.sin(phi), -G * np.cos(theta))
+
+
+def _slide_acceleration(model, settle=100, measure=500):
+  """mean acceleration over a one-second window.  (The soft contact couples normal force to sliding speed -- the friction rows'
+  reference acceleration is -b v_t -- so a sliding body hops a little in either cone model; over a window the normal impulse is the
+  weight's, and the friction impulse mu times it as long as every contact force sits ON the cone while sliding.)"""
+  s = OracleSim(model)
+  s.step(settle)
+  v0, t0 = s.qvel[0, :3].copy(), float(s.time[0, 0])
+  on_cone = []
+  for _ in range(measure):
+    s.step(1)
+    n = int(s.nefc[0, 0])
+    if n and (s.efc_type[0, :n] == 7).all():
+      f = s.efc_force[0, :n].reshape(-1, 3)
+      live = f[:, 0] > 1e-6
+      on_cone.append(np.hypot(f[live, 1], f[live, 2]) / f[live, 0])
+  return (s.qvel[0, :3] - v0) / (float(s.time[0, 0]) - t0), s, (np.concatenate(on_cone) if on_cone else np.zeros(0))
+
+
+def test_elliptic_rows_per_contact():
+  s = OracleSim(_box(0.5, _tilt(0.0)))
+  s.step(300)
+  ncon, nefc = int(s.ncon[0, 0]), int(s.nefc[0, 0])
+  assert ncon == 4 and nefc == 12  # 3 rows per condim-3 contact (pyramidal: 4)
+  assert (s.efc_type[0, :nefc] == 7).all()
+  D = s.efc_D[0, :nefc].reshape(4, 3)
+  assert np.allclose(D[:, 1], D[:, 0]) and np.allclose(D[:, 2], D[:, 0])  # impratio 1, isotropic friction: R_1 = R_2 = R_0
+  f = s.efc_force[0, :nefc].reshape(4, 3)
+  assert f[:, 0].sum() == pytest.approx(2 * G, rel=1e-5)  # resting: the normal forces carry the weight
+  assert np.abs(f[:, 1:]).max() < 1e-6 * f[:, 0].sum()
+  s4 = OracleSim(_box(0.5, _tilt(0.0), impratio=4.0))
+  s4.step(10)
+  D4 = s4.efc_D[0, :12].reshape(4, 3)
+  assert np.allclose(D4[:, 1], 4 * D4[:, 0])  # R_friction = R_normal / impratio
+
+
+@pytest.mark.parametrize("phi", (0.0, np.pi / 4, 1.1))
+def test_coulomb_friction_on_an_incline(phi):
+  """mu = 0.5.  Below the friction angle (tan theta = 0.3) the slab stays (up to the soft constraint's creep); above it (tan theta = 0.8)
+  it slides downhill with a = g (sin theta - mu cos theta) ALONG the slope, whatever the slope's direction in the contact frame, and
+  with no acceleration across it -- the property of the elliptic cone that the pyramid lacks (next test)."""
+  mu = 0.5
+  a, s, _ = _slide_acceleration(_box(mu, _tilt(np.arctan(0.3), phi)))
+  assert np.abs(a).max() < 0.02 * G and np.abs(s.qvel[0, :3]).max() < 0.02
+  th = np.arctan(0.8)
+  a, s, ratio = _slide_acceleration(_box(mu, _tilt(th, phi)))
+  want = G * (np.sin(th) - mu * np.cos(th))
+  along = a[0] * np.cos(phi) + a[1] * np.sin(phi)
+  across = -a[0] * np.sin(phi) + a[1] * np.cos(phi)
+  assert ratio.size > 200 and np.allclose(ratio, mu, rtol=2e-3)  # sliding: |f_t| = mu f_n in every live contact of every step
+  assert along == pytest.approx(want, rel=0.06), (along, want)
+  assert abs(across) < 0.01 * want and abs(a[2]) < 0.03 * G
+
+
+def test_the_pyramid_is_anisotropic_where_the_ellipse_is_not():
+  """MuJoCo's pyramid spans |f_1| + |f_2| <= mu f_n in the contact frame: full friction along a frame axis, mu / sqrt(2) on the diagonal
+  (the slab accelerates faster there), and a force that is not antiparallel to the sliding velocity in between (it drifts across the slope)."""
+  mu, th = 0.5, np.arctan(0.8)
+  want = G * (np.sin(th) - mu * np.cos(th))
+  diag = G * (np.sin(th) - mu / np.sqrt(2) * np.cos(th))
+  for cone, phi, lo, hi, drift in ((CONE_PYRAMIDAL, 0.0, 0.94, 1.06, 0.01), (CONE_PYRAMIDAL, np.pi / 4, 0.94 * diag / want, 1.06 * diag / want, 0.01),
+                                   (CONE_PYRAMIDAL, 1.1, 1.15, 1.6, None), (CONE_ELLIPTIC, 1.1, 0.94, 1.06, 0.01)):
+    a, _, _ = _slide_acceleration(_box(mu, _tilt(th, phi), cone))
+    along = (a[0] * np.cos(phi) + a[1] * np.sin(phi)) / want
+    across = (-a[0] * np.sin(phi) + a[1] * np.cos(phi)) / want
+    assert lo < along < hi, (cone, phi, along)
+    assert (abs(across) < drift) if drift else (abs(across) > 0.2), (cone, phi, across)
+
+
+def test_solution_is_the_minimiser_and_forces_lie_in_the_cone():
+  """Optimality of the solve with cones in the mix (G1: 14 condim-3 foot capsules): M qacc - qfrc_smooth - J^T f = 0 with f the
+  reported efc_force, every contact force inside its friction cone (f_n >= 0, |f_t| <= mu f_n), and an independent quasi-Newton
+  minimiser of the SAME cost -- cones evaluated in numpy from their definition -- lands on the same accelerations."""
+  from scipy.optimize import minimize
+
+  model = robots.load_model("g1_velocity_flat")
+  model.opt.cone = CONE_ELLIPTIC
+  model.opt.iterations, model.opt.ls_iterations, model.opt.tolerance = 100, 50, 1e-12
+  s = OracleSim(model, 1)
+  rng = np.random.default_rng(4)
+  q0 = model.key_qpos[0].copy()
+  q0[2] -= 0.006
+  q0[7:] += rng.normal(0, 0.05, model.nq - 7)
+  s.qpos[0], s.qvel[0] = q0, rng.normal(0, 0.3, model.nv)
+  s.ctrl[0] = q0[7:] + rng.normal(0, 0.1, model.nu)
+  s.forward()
+  nv, nefc = model.nv, int(s.nefc[0, 0])
+  M = s.qM[0].reshape(nv, nv)
+  J = s.efc_J[0].reshape(-1, nv)[:nefc]
+  D, aref, a0, typ = s.efc_D[0, :nefc], s.efc_aref[0, :nefc], s.qacc_smooth[0], s.efc_type[0, :nefc]
+  f = s.efc_force[0, :nefc]
+  res = M @ s.qacc[0] - s.qfrc_smooth[0] - J.T @ f
+  assert np.abs(res).max() <= 1e-6 * np.abs(s.qfrc_smooth[0]).max()
+  ell = np.flatnonzero(typ == 7)  # contiguous, three rows per contact
+  assert ell.size % 3 == 0 and (np.diff(ell) == 1).all()
+  cones = [int(r) for r in ell[::3]]
+  assert len(cones) >= 4
+  mus = []
+  for r in cones:
+    cid = int(s.efc_id[0, r])
+    mu = float(s.contact_friction[0, cid, 0])
+    mus.append(mu)
+    assert f[r] >= -1e-9 and np.hypot(f[r + 1], f[r + 2]) <= mu * f[r] * (1 + 1e-6) + 1e-9, (r, f[r : r + 3])
+  scalar = [r for r in range(nefc) if typ[r] != 7]
+
+  def cone_cost(x, D3, mu):
+    U = np.array([mu * x[0], mu * x[1], mu * x[2]])  # isotropic friction, impratio 1: f = (mu, mu, mu)
+    N, T = U[0], np.hypot(U[1], U[2])
+    if N >= mu * T or (T <= 0 and N >= 0):
+      return 0.0, np.zeros(3)
+    if mu * N + T <= 0 or (T <= 0 and N < 0):
+      return 0.5 * np.sum(D3 * x * x), D3 * x
+    Dm, phi = D3[0] / (mu * mu * (1 + mu * mu)), N - mu * T
+    g = np.array([mu, -mu * mu * U[1] / T, -mu * mu * U[2] / T])
+    return 0.5 * Dm * phi * phi, Dm * phi * g
+
+  def cost(a):
+    jar = J @ a - aref
+    da = a - a0
+    c, grad = 0.5 * da @ M @ da, M @ da
+    js = np.minimum(jar[scalar], 0.0)
+    c += 0.5 * np.sum(D[scalar] * js * js)
+    grad = grad + J[scalar].T @ (D[scalar] * js)
+    for r, mu in zip(cones, mus):
+      cc, gg = cone_cost(jar[r : r + 3], D[r : r + 3], mu)
+      c += cc
+      grad = grad + J[r : r + 3].T @ gg
+    return c, grad
+
+  zones = [0 if cone_cost(J[r : r + 3] @ s.qacc[0] - aref[r : r + 3], D[r : r + 3], mu)[0] == 0.0 else 1 for r, mu in zip(cones, mus)]
+  assert 0 < sum(zones)  # (some contacts push)
+  ref = minimize(cost, a0, jac=True, method="BFGS", options={"gtol": 1e-9, "maxiter": 8000}).x
+  got = s.qacc[0]
+  assert cost(got)[0] <= cost(ref)[0] * (1 + 1e-9) + 1e-9
+  assert np.abs(got - ref).max() / max(1.0, np.abs(ref).max()) < 1e-5
+
+
+def test_grid_line_search_and_fp32_build_agree_with_the_exact_fp64_solve():
+  model = robots.load_model("g1_velocity_flat")
+  model.opt.cone = CONE_ELLIPTIC
+  rng = np.random.default_rng(5)
+  n = 8
+  qpos = np.tile(model.key_qpos[0], (n, 1))
+  qpos[:, 7:] += rng.normal(0, 0.05, (n, model.nq - 7))
+  qpos[:, 2] -= 0.01
+  qvel = rng.normal(0, 0.2, (n, model.nv))
+  out = {}
+  for prec, lsp in (("f64", False), ("f64", True), ("f32", True)):
+    s = OracleSim(model, n, precision=prec, ls_parallel=lsp)
+    s.qpos[:], s.qvel[:], s.ctrl[:] = qpos, qvel, qpos[:, 7:]
+    s.forward()
+    out[(prec, lsp)] = s.qacc.astype(np.float64).copy()
+    assert (s.nefc.ravel() >= 12).all()
+  ref = out[("f64", False)]
+  sc = np.abs(ref).max(axis=1)
+  assert (np.abs(out[("f64", True)] - ref).max(axis=1) / sc).max() < 1e-6
+  assert (np.abs(out[("f32", True)] - ref).max(axis=1) / sc).max() < 2e-4
