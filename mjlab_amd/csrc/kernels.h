@@ -85,6 +85,7 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #include "stage_constraint.h"  // stage 4: limits + contacts -> efc rows, contact sensors
 #include "stage_solve.h"  // stages 5+6: Newton solver and integration
 #include "stage_pgs.h"  // the dual PGS solver (one kernel per stage only)
+#include "stage_cone.h"  // the Newton solver with elliptic friction cones (one kernel per stage only)
 #include "extras.h"  // fused entity read-back, masked reset, field tiling, self-test
 
 // ====================================================================================

@@ -33,7 +33,8 @@ int mjlab_sizeof_velocity_command(void) { return (int)sizeof(mjlab_velocity_comm
 // the solve kernel's LDS block: the primal solvers' layout, or the dual solver's where that one is configured
 static int solve_stage_lds_floats(const mjlab_model_t* m) {
   const int a = solve_lds_floats(m->size), b = m->opt.solver == MJLAB_SOL_PGS ? pgs_lds_floats(m->size) : 0;
-  return a > b ? a : b;
+  const int c = m->opt.cone == MJLAB_CONE_ELLIPTIC ? cone_lds_floats(m->size) : 0;
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 int mjlab_lds_bytes(const mjlab_model_t* m, int stage) {
   switch (stage) {
@@ -54,7 +55,9 @@ static int check_model(const mjlab_model_t* m) {
   if (s.nbody < 1 || s.nbody > 64) return fail(-13, "nbody must be in [1, 64] (one body per lane in the kinematics sweep)");
   if (s.njmax < 1 || s.nconmax < 1) return fail(-4, "njmax and nconmax must be >= 1");
   if (s.ngeom > 65535) return fail(-19, "ngeom must be < 65536 (geom pairs are packed into one word)");
-  if (m->opt.cone != 0) return fail(-5, "only the pyramidal friction cone is implemented");
+  if (m->opt.cone != MJLAB_CONE_PYRAMIDAL && m->opt.cone != MJLAB_CONE_ELLIPTIC) return fail(-5, "opt.cone must be MJLAB_CONE_PYRAMIDAL or MJLAB_CONE_ELLIPTIC");
+  if (m->opt.cone == MJLAB_CONE_ELLIPTIC && (m->opt.solver != MJLAB_SOL_NEWTON || (m->opt.flags & (MJLAB_OPT_FUSE_PRESOLVE | MJLAB_OPT_FUSE_STEP))))
+    return fail(-5, "MJLAB_CONE_ELLIPTIC runs with MJLAB_SOL_NEWTON and one kernel per stage only (clear MJLAB_OPT_FUSE_PRESOLVE / MJLAB_OPT_FUSE_STEP)");
   if (m->opt.integrator != MJLAB_INT_EULER && m->opt.integrator != MJLAB_INT_IMPLICITFAST)
     return fail(-6, "integrator must be Euler or implicitfast");
   if (m->opt.solver != MJLAB_SOL_CG && m->opt.solver != MJLAB_SOL_NEWTON && m->opt.solver != MJLAB_SOL_PGS)
@@ -76,6 +79,12 @@ static int check_model(const mjlab_model_t* m) {
 static int launch_solve(const mjlab_model_t* m, const mjlab_data_t* d, int do_solve, int do_integrate, int flags, hipStream_t st) {
   const NvpLaunch* L = nvp_launch(solve_nvp(m->size.nv));
   if (!L) return fail(-3, "nv must be in [1, 64]");
+  if (do_solve && m->opt.cone == MJLAB_CONE_ELLIPTIC) {  // the cone solver's own kernel, then the integrator with the solve switched off
+    hipError_t e = L->cone(m, d, flags, 4 * solve_stage_lds_floats(m), st);
+    if (e != hipSuccess) return fail((int)e, "k_solve_cone launch failed");
+    if (!do_integrate) return 0;
+    do_solve = 0;
+  }
   hipError_t e = L->solve(m, d, do_solve, do_integrate, flags, 4 * solve_stage_lds_floats(m), st);
   if (e != hipSuccess) return fail((int)e, "k_solve_integrate launch failed");
   return 0;
@@ -111,7 +120,10 @@ static int forward_stages_impl(const mjlab_model_t* m, const mjlab_data_t* d, in
   if (stages & MJLAB_STAGE_POSITION) LAUNCH(k_position, position_lds_floats(m->size), *m, *d, flags);
   if (stages & MJLAB_STAGE_COLLISION) LAUNCH(k_collision, collision_lds_floats(m->size), *m, *d, flags);
   if (stages & MJLAB_STAGE_VELOCITY) LAUNCH(k_velocity, velocity_lds_floats(m->size), *m, *d, flags);
-  if (stages & MJLAB_STAGE_CONSTRAINT) LAUNCH(k_constraint, constraint_lds_floats(m->size), *m, *d, flags);
+  if (stages & MJLAB_STAGE_CONSTRAINT) {
+    if (m->opt.cone == MJLAB_CONE_ELLIPTIC) LAUNCH(k_constraint_cone, constraint_lds_floats(m->size), *m, *d, flags);
+    else LAUNCH(k_constraint, constraint_lds_floats(m->size), *m, *d, flags);
+  }
   if (stages & (MJLAB_STAGE_SOLVE | MJLAB_STAGE_INTEGRATE)) {
     rc = launch_solve(m, d, (stages & MJLAB_STAGE_SOLVE) != 0, (stages & MJLAB_STAGE_INTEGRATE) != 0, flags, st);
     if (rc) return rc;
@@ -289,6 +301,7 @@ int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjla
   if (rc) return rc;
   if (!c || c->nsubstep < 0) return fail(-20, "control_step: bad argument");
   if (m->opt.solver == MJLAB_SOL_PGS) return fail(-20, "control_step: the control kernel carries the primal solvers only (MJLAB_SOL_PGS: separate calls)");
+  if (m->opt.cone == MJLAB_CONE_ELLIPTIC) return fail(-20, "control_step: the control kernel carries the pyramidal cone only (MJLAB_CONE_ELLIPTIC: separate calls)");
   if (c->action && (!c->action_offset || !c->action_scale)) return fail(-20, "control_step: action without offset / scale");
   if (c->key_qpos && (!c->rnd3 || !c->episode_length || !c->reset_mask)) return fail(-15, "control_step: reset arguments missing");
   if ((c->reset_qpos != nullptr) != (c->reset_qvel != nullptr)) return fail(-15, "control_step: reset_qpos and reset_qvel come together");

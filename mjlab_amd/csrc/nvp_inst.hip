@@ -1,6 +1,6 @@
 // nvp_inst.hip -- the kernels that are templates of the padded dof count, instantiated for ONE size and ONE half:
 // compiled with -DMJLAB_NVP=<8|16|20|24|32|36|40|48|64> -DMJLAB_NVP_PART=<0|1> (mjlab_amd/native.py).
-//   part 0: k_solve_integrate<NVP>, k_substep<NVP, false> (forward());   part 1: k_substep<NVP, true>, k_control_step<NVP>
+//   part 0: k_solve_integrate<NVP>, k_substep<NVP, false> (forward()), k_solve_cone<NVP>;   part 1: k_substep<NVP, true>, k_control_step<NVP>
 #if !defined(MJLAB_NVP) || !defined(MJLAB_NVP_PART)
 #error "compile with -DMJLAB_NVP=<padded dof count> -DMJLAB_NVP_PART=<0|1>"
 #endif
@@ -19,6 +19,10 @@ hipError_t NVP_CAT_(mjlab_nvp_solve_, MJLAB_NVP)(const mjlab_model_t* m, const m
 hipError_t NVP_CAT_(mjlab_nvp_forward_, MJLAB_NVP)(const mjlab_model_t* m, const mjlab_data_t* d, int flags, int nsub, int lds_bytes, hipStream_t st) {
   (void)nsub;
   hipLaunchKernelGGL((k_substep<MJLAB_NVP, false>), dim3(m->size.nworld), dim3(64), (size_t)lds_bytes, st, *m, *d, flags, 1);
+  return hipGetLastError();
+}
+hipError_t NVP_CAT_(mjlab_nvp_cone_, MJLAB_NVP)(const mjlab_model_t* m, const mjlab_data_t* d, int flags, int lds_bytes, hipStream_t st) {
+  hipLaunchKernelGGL(k_solve_cone<MJLAB_NVP>, dim3(m->size.nworld), dim3(64), (size_t)lds_bytes, st, *m, *d, flags);
   return hipGetLastError();
 }
 #else

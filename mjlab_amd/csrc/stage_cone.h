@@ -1,0 +1,443 @@
+// stage_cone.h -- the Newton solver with ELLIPTIC friction cones (mjlab_option_t.cone = MJLAB_CONE_ELLIPTIC), one kernel per stage only.
+// Part of kernels.h (included there, after stage_pgs.h, by every translation unit of the library); not a stand-alone header.
+#pragma once
+
+// ====================================================================================
+// mj_solPrimal (Newton) where a condim-3 contact is ONE three-row block [normal, tangent 1, tangent 2] whose cost is the distance to the
+// dual friction cone instead of three scalar rows (MujocoCfg.cone = "elliptic", reference sim/sim.py:49,52; no registered task
+// configures it).  The cone model is restated from MuJoCo's documentation (mj_constraintUpdate's elliptic branch) and UNPINNED; the CPU
+// restatement the parity tests compare against is itself held to Coulomb's law, the optimality conditions and cone membership:
+//   x = (J qacc - aref) of the block, mu = friction[0] / sqrt(impratio), U = (mu x0, f1 x1, f2 x2), N = U0, T = |(U1, U2)|
+//   top zone     N >= mu T: cost 0;      bottom zone  mu N + T <= 0: 0.5 sum_k D_k x_k^2;
+//   middle zone  0.5 Dm (N - mu T)^2, Dm = D_0 / (mu^2 (1 + mu^2)), whose Hessian is the sum of two rank-one terms
+//                Dm g g^T + (Dm (mu T - N) mu / T) q q^T,  g = d(N - mu T) / dx,  q = (0, -f1 U2 / T, f2 U1 / T):
+//                the block enters H = M + J^T (...) J as two virtual rows g^T Jc and q^T Jc.
+// Like the dual solver (stage_pgs.h) this is here because the configuration names it, as a plain wave-per-world kernel next to the
+// optimised pyramid path, which it leaves untouched: rows evaluated one per lane from LDS, the Hessian accumulated row by row in
+// registers (lane i owns row i of H), factored by the LDS column sweep (common.h chol_factor), both line searches of the primal path
+// (the exact one and mujoco_warp's grid).  The fused launch structures and the control kernel carry the pyramid only (check_model).
+// LDS: H / its factor | 1 / D_i of the factor | per row: jar, J search, D, force, aux (friction loss | cone: mu, f1, f2), role.
+// ====================================================================================
+__host__ __device__ inline int cone_lds_floats(const mjlab_sizes_t& s) {
+  const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
+  return nvp * ld + nvp + 6 * s.njmax;
+}
+
+enum { CONE_ROLE_ROW = 0, CONE_ROLE_START = 1, CONE_ROLE_MEMBER = 2 };
+
+struct ConeCtx {
+  const float* J;
+  float *s_jar, *s_jv, *s_D, *s_force, *s_aux;
+  int* s_role;
+  int nv, nefc, nf, lane;
+  float quad_gauss[3];
+  int ls_iter;
+};
+
+// one cone at residuals x: zone (0 top, 1 bottom, 2 middle), cost, force = -d cost / dx, and for the middle zone the two rank-one
+// terms of the Hessian (Da g g^T + Db q q^T).  D = the three rows' efc_D, fr = (mu, friction[0], friction[1]).
+__device__ __forceinline__ int cone_block(const float (&x)[3], const float (&D)[3], const float (&fr)[3], float& cost, float (&force)[3], float (&g)[3],
+                                          float (&q)[3], float& Da, float& Db) {
+  const float mu = fr[0];
+  const float U0 = x[0] * mu, U1 = x[1] * fr[1], U2 = x[2] * fr[2];
+  const float N = U0, T = sqrtf(U1 * U1 + U2 * U2);
+  cost = 0.f; force[0] = force[1] = force[2] = 0.f;
+  if (N >= mu * T || (T <= 0.f && N >= 0.f)) return 0;
+  if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
+    for (int k = 0; k < 3; ++k) { cost += 0.5f * D[k] * x[k] * x[k]; force[k] = -D[k] * x[k]; }
+    return 1;
+  }
+  const float Dm = D[0] / (mu * mu * (1.f + mu * mu)), phi = N - mu * T, it = 1.f / T;
+  cost = 0.5f * Dm * phi * phi;
+  g[0] = mu; g[1] = -mu * fr[1] * U1 * it; g[2] = -mu * fr[2] * U2 * it;
+  for (int k = 0; k < 3; ++k) force[k] = -Dm * phi * g[k];
+  q[0] = 0.f; q[1] = -fr[1] * U2 * it; q[2] = fr[2] * U1 * it;
+  Da = Dm; Db = Dm * (-phi) * mu * it;
+  return 2;
+}
+
+// cost / force of the scalar row r at residual x (mj_constraintUpdate); returns true in the quadratic zone
+__device__ __forceinline__ bool cone_scalar_row(const ConeCtx& c, int r, float x, float& cost, float& force) {
+  const float Dr = c.s_D[r];
+  if (r < c.nf) {
+    const float f = c.s_aux[r], rf = f / Dr;
+    if (x <= -rf) { force = f; cost = f * (-0.5f * rf - x); return false; }
+    if (x >= rf) { force = -f; cost = f * (-0.5f * rf + x); return false; }
+    force = -Dr * x; cost = 0.5f * Dr * x * x; return true;
+  }
+  if (x < 0.f) { force = -Dr * x; cost = 0.5f * Dr * x * x; return true; }
+  force = 0.f; cost = 0.f; return false;
+}
+
+// sum of the rows' costs at residuals xs[] (LDS); WRITE: the forces go to s_force
+template <bool WRITE>
+__device__ __forceinline__ float cone_rows_cost(const ConeCtx& c, const float* xs) {
+  float cost = 0.f;
+  for (int r = c.lane; r < c.nefc; r += 64) {
+    const int role = c.s_role[r];
+    if (role == CONE_ROLE_MEMBER) continue;
+    if (role == CONE_ROLE_START) {
+      const float x[3] = {xs[r], xs[r + 1], xs[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
+      float rc, fo[3], g[3], q[3], Da, Db;
+      cone_block(x, D, fr, rc, fo, g, q, Da, Db);
+      cost += rc;
+      if (WRITE) { c.s_force[r] = fo[0]; c.s_force[r + 1] = fo[1]; c.s_force[r + 2] = fo[2]; }
+    } else {
+      float rc, fo;
+      cone_scalar_row(c, r, xs[r], rc, fo);
+      cost += rc;
+      if (WRITE) c.s_force[r] = fo;
+    }
+  }
+  return wave_sum(cost);
+}
+
+// cost, slope and curvature along the search direction at step alpha (mj PrimalEval)
+__device__ __forceinline__ void cone_ls_eval(ConeCtx& c, LsPnt* p, float alpha) {
+  float cost = 0.f, d0 = 0.f, d1 = 0.f;
+  for (int r = c.lane; r < c.nefc; r += 64) {
+    const int role = c.s_role[r];
+    if (role == CONE_ROLE_MEMBER) continue;
+    if (role == CONE_ROLE_START) {
+      const float jv[3] = {c.s_jv[r], c.s_jv[r + 1], c.s_jv[r + 2]};
+      const float x[3] = {fmaf(alpha, jv[0], c.s_jar[r]), fmaf(alpha, jv[1], c.s_jar[r + 1]), fmaf(alpha, jv[2], c.s_jar[r + 2])};
+      const float D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
+      float rc, fo[3], g[3], q[3], Da, Db;
+      const int zone = cone_block(x, D, fr, rc, fo, g, q, Da, Db);
+      cost += rc;
+      d0 -= fo[0] * jv[0] + fo[1] * jv[1] + fo[2] * jv[2];
+      if (zone == 1) d1 += D[0] * jv[0] * jv[0] + D[1] * jv[1] * jv[1] + D[2] * jv[2] * jv[2];
+      else if (zone == 2) {
+        const float gj = g[0] * jv[0] + g[1] * jv[1] + g[2] * jv[2], qj = q[1] * jv[1] + q[2] * jv[2];
+        d1 += Da * gj * gj + Db * qj * qj;
+      }
+      continue;
+    }
+    const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r], x = fmaf(alpha, jv, j0);
+    if (r < c.nf) {
+      const float f = c.s_aux[r], rf = f / Dr;
+      if (x <= -rf) { cost += f * (-0.5f * rf - j0) - alpha * f * jv; d0 -= f * jv; continue; }
+      if (x >= rf) { cost += f * (-0.5f * rf + j0) + alpha * f * jv; d0 += f * jv; continue; }
+    }
+    if (x < 0.f || r < c.nf) {
+      const float q0 = 0.5f * Dr * j0 * j0, q1 = Dr * j0 * jv, q2 = 0.5f * Dr * jv * jv;
+      cost += alpha * alpha * q2 + alpha * q1 + q0;
+      d0 += 2.f * alpha * q2 + q1;
+      d1 += 2.f * q2;
+    }
+  }
+  cost = wave_sum(cost) + alpha * alpha * c.quad_gauss[2] + alpha * c.quad_gauss[1] + c.quad_gauss[0];
+  d0 = wave_sum(d0) + 2.f * alpha * c.quad_gauss[2] + c.quad_gauss[1];
+  d1 = wave_sum(d1) + 2.f * c.quad_gauss[2];
+  if (d1 <= 0.f) d1 = MINVAL;
+  p->alpha = alpha; p->cost = cost; p->d0 = d0; p->d1 = d1;
+  c.ls_iter++;
+}
+
+// cost(alpha) - cost(0) formed row by row as differences (the grid search's default comparison; stage_solve.h line_search_parallel)
+__device__ __forceinline__ float cone_ls_diff(const ConeCtx& c, float alpha) {
+  float acc = 0.f;
+  for (int r = c.lane; r < c.nefc; r += 64) {
+    const int role = c.s_role[r];
+    if (role == CONE_ROLE_MEMBER) continue;
+    if (role == CONE_ROLE_START) {
+      const float x0[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]};
+      const float x[3] = {fmaf(alpha, c.s_jv[r], x0[0]), fmaf(alpha, c.s_jv[r + 1], x0[1]), fmaf(alpha, c.s_jv[r + 2], x0[2])};
+      const float D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
+      float ca, cb, fo[3], g[3], q[3], Da, Db;
+      cone_block(x, D, fr, ca, fo, g, q, Da, Db);
+      cone_block(x0, D, fr, cb, fo, g, q, Da, Db);
+      acc += 2.f * (ca - cb);
+      continue;
+    }
+    const float j0 = c.s_jar[r], Dr = c.s_D[r], x = fmaf(alpha, c.s_jv[r], j0);
+    if (r < c.nf) {
+      const float fl = c.s_aux[r], rf = fl / Dr, ax = fabsf(x), a0 = fabsf(j0);
+      const float ha = ax >= rf ? 2.f * fl * (ax - 0.5f * rf) : Dr * x * x;
+      const float h0 = a0 >= rf ? 2.f * fl * (a0 - 0.5f * rf) : Dr * j0 * j0;
+      acc += ha - h0;
+    } else {
+      const float xm = fminf(x, 0.f), xm0 = fminf(j0, 0.f);
+      acc += Dr * (xm - xm0) * (xm + xm0);
+    }
+  }
+  return 0.5f * wave_sum(acc) + alpha * (alpha * c.quad_gauss[2] + c.quad_gauss[1]);
+}
+
+__device__ __forceinline__ int cone_update_bracket(ConeCtx& c, LsPnt* p, const LsPnt* cand, LsPnt* pnext) {
+  int flag = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (p->d0 < 0.f && cand[i].d0 < 0.f && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
+    else if (p->d0 > 0.f && cand[i].d0 > 0.f && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
+  }
+  if (flag) cone_ls_eval(c, pnext, p->alpha - p->d0 / p->d1);
+  return flag;
+}
+
+// MuJoCo's exact search (mj_solPrimal's PrimalSearch), all values wave-uniform
+__device__ float cone_line_search(ConeCtx& c, float gtol, float dn1, float dn2, int lsmax) {
+#define CONE_LS_TOL(a_) fmaxf(gtol, dn1 + fabsf(a_) * dn2)
+  LsPnt p0, p1, p2, pmid, p1next, p2next;
+  cone_ls_eval(c, &p0, 0.f);
+  cone_ls_eval(c, &p1, p0.alpha - p0.d0 / p0.d1);
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabsf(p1.d0) < CONE_LS_TOL(p1.alpha)) return p1.alpha;
+  const float dir = p1.d0 < 0.f ? 1.f : -1.f;
+  bool p2update = false;
+  p2 = p1;
+  while (p1.d0 * dir <= -CONE_LS_TOL(p1.alpha) && c.ls_iter < lsmax) {
+    p2 = p1;
+    p2update = true;
+    cone_ls_eval(c, &p1, p1.alpha - p1.d0 / p1.d1);
+    if (fabsf(p1.d0) < CONE_LS_TOL(p1.alpha)) return p1.alpha;
+  }
+  if (c.ls_iter >= lsmax || !p2update) return p1.alpha;
+  p2next = p1;
+  cone_ls_eval(c, &p1next, p1.alpha - p1.d0 / p1.d1);
+  while (c.ls_iter < lsmax) {
+    cone_ls_eval(c, &pmid, 0.5f * (p1.alpha + p2.alpha));
+    const LsPnt cand[3] = {p1next, p2next, pmid};
+    float bestcost = 0.f;
+    int best = -1;
+    for (int i = 0; i < 3; ++i)
+      if (fabsf(cand[i].d0) < CONE_LS_TOL(cand[i].alpha) && (best == -1 || cand[i].cost < bestcost)) { bestcost = cand[i].cost; best = i; }
+    if (best >= 0) return cand[best].alpha;
+    const int b1 = cone_update_bracket(c, &p1, cand, &p1next);
+    const int b2 = cone_update_bracket(c, &p2, cand, &p2next);
+    if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : 0.f;
+  }
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0.f;
+#undef CONE_LS_TOL
+}
+
+// y_i = sum_j M[i][j] x_j, lane i owning x_i / y_i (M dense row-major in global memory; read a few times per iteration)
+template <int NVP>
+__device__ __forceinline__ float cone_mul_M(const float* M, int nv, int lane, float x) {
+  float y = 0.f;
+  const float* row = M + (size_t)(lane < nv ? lane : 0) * nv;
+#pragma unroll
+  for (int j = 0; j < NVP; ++j) {
+    const float xj = lane_bcast(x, j);
+    if (j < nv) y = fmaf(row[j], xj, y);
+  }
+  return lane < nv ? y : 0.f;
+}
+
+// h (lane i: row i of H) += Dv * a_i * a_j
+template <int NVP>
+__device__ __forceinline__ void cone_rank1(float (&h)[NVP], float a, float Dv) {
+  const float t = Dv * a;
+#pragma unroll
+  for (int j = 0; j < NVP; ++j) h[j] = fmaf(t, lane_bcast(a, j), h[j]);
+}
+
+template <int NVP>
+__device__ void stage_solve_cone(const Model& m, const Data& d, const int w, const int lane, float* smem) {
+  constexpr int ld = CholCfg<NVP>::LD;
+  const int nv = m.size.nv, njm = m.size.njmax, ncm = m.size.nconmax;
+  float* s_H = smem;
+  float* s_invd = s_H + NVP * ld;
+  ConeCtx c;
+  c.s_jar = s_invd + NVP;
+  c.s_jv = c.s_jar + njm;
+  c.s_D = c.s_jv + njm;
+  c.s_force = c.s_D + njm;
+  c.s_aux = c.s_force + njm;
+  c.s_role = (int*)(c.s_aux + njm);
+  const bool own = lane < nv;
+  const size_t wv = (size_t)w * nv + lane, wr = (size_t)w * njm;
+  const float* J = d.efc_J + wr * nv;
+  const float* M = d.qM + (size_t)w * nv * nv;
+  const int nefc = d.nefc[w];
+  c.J = J; c.nv = nv; c.nefc = nefc; c.lane = lane;
+  c.nf = (m.opt.flags & MJLAB_OPT_FRICTIONLOSS) ? d.nf[w] : 0;
+  const float qs = own ? d.qfrc_smooth[wv] : 0.f;
+  const bool ws_at_advance = (m.opt.flags & MJLAB_OPT_WARMSTART_AT_ADVANCE) != 0;
+  // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
+  dense_global_to_lds(s_H, M, nv, ld, lane, true);
+  chol_pad_rows<NVP>(s_H, nv, lane);
+  chol_pad_diag<NVP>(s_H, nv, lane);
+  __syncthreads();
+  chol_factor<NVP>(s_H, s_invd, nv, lane);
+  __syncthreads();
+  const float qas = chol_solve<NVP>(s_H, s_invd, lane, qs);
+  if (own) d.qacc_smooth[wv] = qas;
+  if (nefc == 0) {
+    if (own) {
+      d.qacc[wv] = qas;
+      d.qfrc_constraint[wv] = 0.f;
+      if (!ws_at_advance) d.qacc_warmstart[wv] = qas;
+    }
+    if (lane == 0) d.solver_niter[w] = 0;
+    return;
+  }
+  // ---- per row: D, role, aux
+  const float impratio = (float)m.opt.impratio;
+  const float mu_scale = 1.f / sqrtf(impratio > MINVAL ? impratio : MINVAL);
+  for (int r = lane; r < nefc; r += 64) {
+    c.s_D[r] = d.efc_D[wr + r];
+    int role = CONE_ROLE_ROW;
+    float aux = r < c.nf ? d.efc_frictionloss[wr + r] : 0.f;
+    if (d.efc_type[wr + r] == MJLAB_EFC_CONTACT_ELLIPTIC) {
+      const int cid = d.efc_id[wr + r], k = r - d.contact_efc_address[(size_t)w * ncm + cid];
+      const float* fri = d.contact_friction + 5 * ((size_t)w * ncm + cid);
+      role = k == 0 ? CONE_ROLE_START : CONE_ROLE_MEMBER;
+      aux = k == 0 ? fri[0] * mu_scale : fri[k - 1];
+    }
+    c.s_role[r] = role;
+    c.s_aux[r] = aux;
+  }
+  // ---- warm start: the better of qacc_warmstart and qacc_smooth (mj_fwdConstraint)
+  const float ws = own ? d.qacc_warmstart[wv] : 0.f;
+  for (int r = 0; r < nefc; ++r) {
+    const float jr = own ? J[(size_t)r * nv + lane] : 0.f, ar = d.efc_aref[wr + r];
+    const float xw = wave_sum(jr * ws) - ar, xs = wave_sum(jr * qas) - ar;
+    if (lane == 0) { c.s_jar[r] = xw; c.s_jv[r] = xs; }
+  }
+  __syncthreads();
+  float Ma = cone_mul_M<NVP>(M, nv, lane, ws);
+  const float cw = cone_rows_cost<false>(c, c.s_jar) + wave_sum(own ? 0.5f * (Ma - qs) * (ws - qas) : 0.f);
+  const float cs = cone_rows_cost<false>(c, c.s_jv);
+  float qacc = ws;
+  if (cw > cs) {
+    qacc = qas;
+    Ma = cone_mul_M<NVP>(M, nv, lane, qas);
+    __syncthreads();
+    for (int r = lane; r < nefc; r += 64) c.s_jar[r] = c.s_jv[r];
+  }
+  __syncthreads();
+  const float nvf = (float)(nv > 1 ? nv : 1), mi = (float)m.opt.meaninertia;
+  const float scale = 1.f / (mi * nvf), tol = (float)m.opt.tolerance, lstol = (float)m.opt.ls_tolerance;
+  const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
+  const float ulp4 = (m.opt.flags & MJLAB_OPT_LITERAL_TERMINATION) ? 0.f : 4.f * 5.9604645e-8f;
+  // constraint update: forces, cost, J^T f
+  float cost, gauss, fc;
+  auto update = [&]() {
+    const float rows = cone_rows_cost<true>(c, c.s_jar);
+    __syncthreads();
+    float acc = 0.f;
+    for (int r = 0; r < nefc; ++r) {
+      const float f = c.s_force[r];
+      if (f != 0.f) acc = fmaf(own ? J[(size_t)r * nv + lane] : 0.f, f, acc);
+    }
+    fc = acc;
+    gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
+    cost = rows + gauss;
+  };
+  update();
+  int iter = 0;
+  while (iter < maxiter) {
+    // ---- H = M + sum over the quadratic rows and cones, factored; search = -H^-1 grad
+    const float grad = own ? Ma - qs - fc : 0.f;
+    {
+      float h[NVP];
+      const float* mrow = M + (size_t)(own ? lane : 0) * nv;
+#pragma unroll
+      for (int j = 0; j < NVP; ++j) h[j] = (own && j < nv) ? mrow[j] : 0.f;
+      for (int r = 0; r < nefc; ++r) {
+        const int role = c.s_role[r];  // wave-uniform
+        if (role == CONE_ROLE_MEMBER) continue;
+        if (role == CONE_ROLE_START) {
+          const float x[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
+          float rc, fo[3], g[3], q[3], Da, Db;
+          const int zone = cone_block(x, D, fr, rc, fo, g, q, Da, Db);
+          if (zone == 0) continue;
+          const float j0 = own ? J[(size_t)r * nv + lane] : 0.f, j1 = own ? J[(size_t)(r + 1) * nv + lane] : 0.f, j2 = own ? J[(size_t)(r + 2) * nv + lane] : 0.f;
+          if (zone == 1) {
+            cone_rank1<NVP>(h, j0, D[0]);
+            cone_rank1<NVP>(h, j1, D[1]);
+            cone_rank1<NVP>(h, j2, D[2]);
+          } else {
+            cone_rank1<NVP>(h, g[0] * j0 + g[1] * j1 + g[2] * j2, Da);
+            cone_rank1<NVP>(h, q[1] * j1 + q[2] * j2, Db);
+          }
+          continue;
+        }
+        float rc, fo;
+        if (!cone_scalar_row(c, r, c.s_jar[r], rc, fo)) continue;
+        cone_rank1<NVP>(h, own ? J[(size_t)r * nv + lane] : 0.f, c.s_D[r]);
+      }
+      __syncthreads();
+      if (lane < NVP) {
+#pragma unroll
+        for (int j = 0; j < NVP; ++j) s_H[lane * ld + j] = own ? h[j] : (j == lane ? 1.f : 0.f);
+      }
+      __syncthreads();
+    }
+    chol_factor<NVP>(s_H, s_invd, nv, lane);
+    __syncthreads();
+    const float search = -chol_solve<NVP>(s_H, s_invd, lane, grad);
+    // ---- line search
+    const float snorm = sqrtf(wave_sum(search * search));
+    if (snorm < MINVAL) break;
+    const float Mv = cone_mul_M<NVP>(M, nv, lane, search);
+    __syncthreads();
+    for (int r = 0; r < nefc; ++r) {
+      const float t = wave_sum((own ? J[(size_t)r * nv + lane] : 0.f) * search);
+      if (lane == 0) c.s_jv[r] = t;
+    }
+    __syncthreads();
+    c.quad_gauss[0] = gauss;
+    c.quad_gauss[1] = wave_sum(search * (Ma - qs));
+    c.quad_gauss[2] = wave_sum(0.5f * search * Mv);
+    c.ls_iter = 0;
+    float alpha;
+    if (m.opt.flags & MJLAB_OPT_LS_PARALLEL) {
+      const float lo = logf((float)m.opt.ls_parallel_min_step), step = (0.f - lo) / (float)(lsmax > 1 ? lsmax - 1 : 1);
+      const bool literal = (m.opt.flags & MJLAB_OPT_LS_LITERAL_COST) != 0;
+      float best_cost = 0.f;
+      alpha = 0.f;
+      for (int i = 0; i < lsmax; ++i) {
+        const float a = expf(lo + (float)i * step);
+        float cc;
+        if (literal) { LsPnt p; cone_ls_eval(c, &p, a); cc = p.cost; }
+        else cc = cone_ls_diff(c, a);
+        if (i == 0 || cc < best_cost) { best_cost = cc; alpha = a; }
+      }
+    } else {
+      float a1 = 0.f, a2 = 0.f;
+      for (int r = lane; r < nefc; r += 64) {
+        const float dj = c.s_D[r] * c.s_jv[r];
+        a1 += fabsf(dj * c.s_jar[r]); a2 += fabsf(0.5f * dj * c.s_jv[r]);
+      }
+      const float dn1 = ulp4 * (wave_sum(a1) + fabsf(c.quad_gauss[1])), dn2 = 2.f * ulp4 * (wave_sum(a2) + fabsf(c.quad_gauss[2]));
+      alpha = cone_line_search(c, tol * lstol * snorm * (mi * nvf), dn1, dn2, lsmax);
+    }
+    if (alpha == 0.f) break;
+    qacc += alpha * search;
+    Ma += alpha * Mv;
+    __syncthreads();
+    for (int r = lane; r < nefc; r += 64) c.s_jar[r] = fmaf(alpha, c.s_jv[r], c.s_jar[r]);
+    __syncthreads();
+    const float oldcost = cost;
+    update();
+    const float gnew = own ? Ma - qs - fc : 0.f;
+    const float tn = own ? fabsf(Ma) + fabsf(qs) + fabsf(fc) : 0.f;
+    const float improvement = scale * (oldcost - cost), gradient = scale * sqrtf(wave_sum(gnew * gnew));
+    const float noise = ulp4 * scale * sqrtf(wave_sum(tn * tn));
+    ++iter;
+    if (improvement < tol || gradient < tol || gradient < noise) break;
+  }
+  // ---- publish
+  __syncthreads();
+  for (int r = lane; r < nefc; r += 64) d.efc_force[wr + r] = c.s_force[r];
+  if (own) {
+    d.qacc[wv] = qacc;
+    d.qfrc_constraint[wv] = fc;
+    if (!ws_at_advance) d.qacc_warmstart[wv] = qacc;
+  }
+  if (lane == 0) d.solver_niter[w] = iter;
+}
+
+// the solve of a world with elliptic cones; the integrator follows as k_solve_integrate<NVP> with the solve switched off (like the dual
+// solver).  A kernel of its own so that the pyramid path's kernels carry none of its registers or scratch; 2 waves per SIMD (a row of H
+// per lane in registers next to the factor's).
+template <int NVP>
+__global__ __launch_bounds__(64, 2) void k_solve_cone(const Model m, const Data d, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  stage_solve_cone<NVP>(m, d, w, lane, smem);
+}

@@ -62,6 +62,12 @@ __host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) {
   return s.nconmax + 2 * constraint_nlim(s) + CC_NROWS * 64;
 }
 
+// ELL: mjlab_option_t.cone == MJLAB_CONE_ELLIPTIC -- a condim-3 contact gives 3 rows [normal, tangent 1, tangent 2] (the contact-frame
+// components of the relative acceleration) instead of the pyramid's 4 edges; only the normal row has a position and a margin, the friction
+// rows are velocity rows (aref = -b v); R_0 from the impedance and the translational weight, R_k = R_0 / impratio * friction[0]^2 /
+// friction[k-1]^2 (mj_instantiateContact / mj_makeImpedance).  A separate instantiation reached through k_constraint_cone only: the fused
+// kernels carry the pyramid (check_model).
+template <bool ELL = false>
 __device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, const int w, const int lane, const int flags, float* smem) {
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ncm = m.size.nconmax, njm = m.size.njmax;
   const int nlim = constraint_nlim(m.size);
@@ -199,7 +205,7 @@ __device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, 
         bb = -solref[1] / fmaxf(dmax, MINVAL);
       }
       float Dc;
-      if (dim == 1) {
+      if (dim == 1 || ELL) {
         Dc = 1.f / fmaxf((1.f - imp) / imp * tran, MINVAL);
       } else {
         const float Rfirst = fmaxf((1.f - imp) / imp * (tran + mu0 * mu0 * tran), MINVAL);
@@ -213,7 +219,7 @@ __device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, 
       s_cc[CC_DIST * 64 + lane] = dist;
       s_cc[CC_INC * 64 + lane] = inc;
       ((int*)s_cc)[CC_DIM * 64 + lane] = dim;
-      if (dist < inc) nrow = dim == 1 ? 1 : 2 * (dim - 1);
+      if (dist < inc) nrow = dim == 1 ? 1 : (ELL ? dim : 2 * (dim - 1));
     }
     // efc addresses: contacts take rows in order; one that does not fit is dropped
     int total;
@@ -275,6 +281,21 @@ __device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, 
           d.efc_pos[wr + adr_i] = dist; d.efc_margin[wr + adr_i] = inc; d.efc_D[wr + adr_i] = Dc;
           d.efc_aref[wr + adr_i] = -bb * v0 - kip;
           d.efc_type[wr + adr_i] = MJLAB_EFC_CONTACT_FRICTIONLESS; d.efc_id[wr + adr_i] = cid;
+        }
+      } else if constexpr (ELL) {
+        const float v1 = wave_sum(jf[1] * qv), v2 = wave_sum(jf[2] * qv);
+        const float mu0 = s_cc[CC_MU * 64 + i], mu1 = s_cc[(CC_MU + 1) * 64 + i];
+        for (int r = 0; r < 3; ++r)
+          if (lane < nv) J[(size_t)(adr_i + r) * nv + lane] = jf[r];
+        if (lane < 3) {  // lanes = rows of this contact for the scalar row fields
+          const float ir = (float)m.opt.impratio;
+          const float R1 = (1.f / Dc) / (ir > MINVAL ? ir : MINVAL);
+          const float fk = lane == 2 ? mu1 : mu0;
+          const size_t rr = wr + adr_i + lane;
+          d.efc_pos[rr] = lane == 0 ? dist : 0.f; d.efc_margin[rr] = lane == 0 ? inc : 0.f;
+          d.efc_D[rr] = lane == 0 ? Dc : 1.f / fmaxf(R1 * mu0 * mu0 / (fk * fk), MINVAL);
+          d.efc_aref[rr] = lane == 0 ? -bb * v0 - kip : -bb * (lane == 1 ? v1 : v2);
+          d.efc_type[rr] = MJLAB_EFC_CONTACT_ELLIPTIC; d.efc_id[rr] = cid;
         }
       } else {
         const float v1 = wave_sum(jf[1] * qv), v2 = wave_sum(jf[2] * qv);
@@ -339,5 +360,12 @@ __global__ __launch_bounds__(64, 4) void k_constraint(const Model m, const Data 
   if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
   if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
   stage_constraint(m, d, w, lane, flags, smem);
+}
+__global__ __launch_bounds__(64, 4) void k_constraint_cone(const Model m, const Data d, const int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if ((flags & FLAG_MASK) && !d.world_mask[w]) return;
+  if ((flags & FLAG_FOLD) && d.fold_reuse[w]) return;
+  stage_constraint<true>(m, d, w, lane, flags, smem);
 }
 #endif  // MJLAB_MAIN_TU

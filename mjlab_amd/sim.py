@@ -119,8 +119,10 @@ def check_supported(model: Model) -> None:
   configurations use."""
   if model.opt.solver not in (SOL_NEWTON, SOL_CG, SOL_PGS):
     raise NotImplementedError("opt.solver must be Newton, CG or PGS")
-  if model.opt.cone != CONE_PYRAMIDAL:
-    raise NotImplementedError("only the pyramidal cone is implemented")
+  if model.opt.cone not in (CONE_PYRAMIDAL, CONE_ELLIPTIC):
+    raise NotImplementedError("opt.cone must be pyramidal or elliptic")
+  if model.opt.cone == CONE_ELLIPTIC and model.opt.solver != SOL_NEWTON:
+    raise NotImplementedError("the elliptic cone is implemented for the Newton solver only (pyramidal: Newton, CG, PGS)")
   if model.opt.integrator not in (INT_EULER, INT_IMPLICITFAST):
     raise NotImplementedError("integrator must be 'euler' or 'implicitfast'")
   if model.nv > 64:
@@ -220,7 +222,8 @@ class Simulation:
     ext = SimulationCfg()
     opt = lambda name: getattr(cfg, name, getattr(ext, name))  # noqa: E731
     # the dual solver (MujocoCfg.solver = "pgs") exists as a stage kernel only: the fused launch structures carry the primal solvers
-    self.fuse = "stage" if model.opt.solver == SOL_PGS else opt("fuse")
+    # ... and so do elliptic friction cones (MujocoCfg.cone = "elliptic": csrc/stage_cone.h)
+    self.fuse = "stage" if (model.opt.solver == SOL_PGS or model.opt.cone == CONE_ELLIPTIC) else opt("fuse")
     self._m.opt.ls_parallel_min_step = float(opt("ls_parallel_min_step"))
     self._m.opt.flags = ((self._m.opt.flags & _abi.OPT_FRICTIONLOSS) | (_abi.OPT_FOLD_FORWARD if opt("fold_forward") else 0)
                          | (_abi.OPT_LITERAL_TERMINATION if opt("literal_termination") else 0)

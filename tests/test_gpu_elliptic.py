@@ -1,0 +1,175 @@
+"""Elliptic friction cones on the device (csrc/stage_cone.h + the ELL instantiation of the constraint stage):
+MujocoCfg(cone="elliptic") (reference sim/sim.py:49,52) as stage kernels, against the CPU restatement (oracle/mjoracle.c), which
+tests/test_oracle_elliptic.py holds to Coulomb's law, the optimality conditions and cone membership.  The cone model is restated from
+MuJoCo's documentation and UNPINNED on both sides; Newton only (the dual solver and CG keep the pyramid), fused launches excluded."""
+
+import copy
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
+
+from make_golden import golden_inputs, models  # noqa: E402
+
+from oracle.oracle import OracleSim  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+  import torch
+
+  torch.cuda.synchronize()
+  return t.cpu().numpy()
+
+
+def _per_world(a, b):
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  return np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-6)
+
+
+@pytest.mark.parametrize("lsp", [False, True], ids=["exact_ls", "grid_ls"])
+@pytest.mark.parametrize("name", ["mixed", "go1_velocity_flat", "g1_velocity_flat"])
+def test_elliptic_forward_and_rollout_track_the_restatement(name, lsp):
+  import torch
+
+  from mjlab_amd import _abi, mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = copy.deepcopy(models()[name])
+  model.opt.cone = mjcf.CONE_ELLIPTIC
+  model.opt.impratio = 2.0 if name == "mixed" else 1.0
+  flags = 0
+  if name == "go1_velocity_flat":  # friction-loss rows next to the cones
+    model.dof_frictionloss = np.asarray(model.dof_frictionloss, dtype=np.float64).copy()
+    model.dof_frictionloss[6:] = 0.2
+    flags = _abi.OPT_FRICTIONLOSS
+  nworld, nv = 16, model.nv
+  qpos, qvel, ctrl = golden_inputs(model, nworld, 43)
+  sim = Simulation(nworld, SimulationCfg(njmax=300, use_graph=False, ls_parallel=lsp), model, "cuda:0")
+  assert sim.fuse == "stage"
+  ora = OracleSim(model, nworld, njmax=300, precision="f64", flags=flags, ls_parallel=lsp)
+  for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+    getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+    getattr(ora, f)[:] = v.astype(np.float32)
+  sim.data.qacc_warmstart.zero_()  # (the constructor's forward() left its own solution there)
+  sim.forward()
+  ora.forward(nthread=8)
+  # ---- the rows: three per condim-3 contact, friction rows without position, R_k from impratio
+  assert np.array_equal(_np(sim.data.ncon).ravel(), ora.ncon.ravel())
+  assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
+  nefc = ora.nefc.ravel()
+  assert nefc.max() >= 12
+  with_cones = 0
+  tg, ig = _np(sim.data.efc_type), _np(sim.data.efc_id)
+  for w in range(nworld):
+    n = int(nefc[w])
+    if n == 0:
+      continue
+    assert np.array_equal(tg[w, :n], ora.efc_type[w, :n]) and np.array_equal(ig[w, :n], ora.efc_id[w, :n])
+    with_cones += (tg[w, :n] == 7).sum() >= 3
+    Jg = _np(sim.data.efc_J)[w].reshape(-1, nv)[:n]
+    assert np.abs(Jg - ora.efc_J[w].reshape(-1, nv)[:n]).max() < 2e-6 * max(1.0, np.abs(Jg).max())
+    for f, tol in (("efc_D", 1e-3), ("efc_aref", 1e-3), ("efc_pos", 1e-4), ("efc_margin", 1e-6)):
+      a, b = _np(getattr(sim.data, f))[w, :n], getattr(ora, f)[w, :n]
+      assert np.abs(a - b).max() <= tol * max(1e-6, np.abs(b).max()), (f, w)
+  assert with_cones >= nworld // 2
+  # ---- the solve
+  qa, fo = _np(sim.data.qacc), _np(sim.data.efc_force)
+  err = _per_world(qa, ora.qacc)
+  fric = _np(sim.data.contact_friction).reshape(nworld, -1, 5)
+  mu_scale = 1.0 / np.sqrt(model.opt.impratio)
+  kkt, incone = [], 0
+  for w in range(nworld):
+    n = int(nefc[w])
+    if n == 0:
+      continue
+    Jw = _np(sim.data.efc_J)[w].reshape(-1, nv)[:n].astype(np.float64)
+    Mw = _np(sim.data.qM)[w].reshape(nv, nv).astype(np.float64)
+    res = Mw @ qa[w] - _np(sim.data.qfrc_smooth)[w] - Jw.T @ fo[w, :n]
+    kkt.append(np.abs(res).max() / max(1.0, np.abs(_np(sim.data.qfrc_smooth)[w]).max()))
+    assert np.abs(_np(sim.data.qfrc_constraint)[w] - Jw.T @ fo[w, :n]).max() < 1e-4 * max(1.0, np.abs(fo[w, :n]).max())
+    ell = np.flatnonzero(tg[w, :n] == 7)
+    for r in ell[::3]:
+      f0, f1, f2 = fo[w, r : r + 3]
+      fr = fric[w, ig[w, r]]
+      # inside the friction cone of the regularised problem: (f1 / friction1)^2 + (f2 / friction2)^2 <= (f0 / mu)^2 ... in force space
+      # |f_t| <= friction * f_n with mu = friction / sqrt(impratio) scaling the normal axis of the dual cone
+      assert f0 >= -1e-5
+      assert np.hypot(f1 / fr[0], f2 / fr[1]) <= f0 * (1 + 1e-3) + 1e-4 * max(1.0, abs(f0)), (w, r, f0, f1, f2)
+      incone += f0 > 1e-3
+  assert incone >= nworld // 2  # (contacts that push)
+  print(f"\n{name} lsp={lsp}: elliptic qacc device vs restatement median {np.median(err):.2e} max {err.max():.2e}; stationarity residual max {max(kkt):.2e}; "
+        f"iterations device {_np(sim.data.solver_niter).mean():.1f} restatement {ora.solver_niter.mean():.1f}; mu scale {mu_scale:.3f}")
+  # measured (profiles/r05_v20_elliptic.txt): exact search median <= 2.3e-6, max <= 2.1e-5; grid search median <= 2.7e-6, max <= 9.8e-5
+  assert np.median(err) < 1e-5 and err.max() < (4e-4 if lsp else 8e-5), err
+  assert max(kkt) < (2e-2 if lsp else 5e-5)  # (the grid search stops where no candidate step improves: stationary to the grid only)
+  # ---- a short rollout (stage launches: constraint-cone, solve-cone, integrate)
+  for _ in range(10):
+    sim.step()
+  ora.step(10, nthread=8)
+  assert np.isfinite(_np(sim.data.qpos)).all()
+  perr = _per_world(_np(sim.data.qpos), ora.qpos)
+  print(f"{name} lsp={lsp}: qpos after 10 steps median {np.median(perr):.2e} max {perr.max():.2e}")
+  assert (np.median(perr) < 1.5e-5 and perr.max() < 8e-5) if lsp else (np.median(perr) < 1e-6 and perr.max() < 3e-6)  # measured: 3.5e-6 / 1.7e-5 | 1.6e-7 / 6.9e-7
+
+
+def test_elliptic_slab_slides_by_coulombs_law_on_the_device():
+  """The same physics check the restatement passes (tests/test_oracle_elliptic.py), on the device: a slab on a 38.7 degree incline
+  (tan = 0.8, mu = 0.5) whose downhill direction is NOT a contact-frame axis accelerates at g (sin - mu cos) along the slope and
+  not across it, with every live contact force on its cone."""
+  import torch
+
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  sys.path.insert(0, str(ROOT / "tests"))
+  from test_oracle_elliptic import G, _box, _tilt
+
+  mu, th, phi = 0.5, np.arctan(0.8), 1.1
+  model = _box(mu, _tilt(th, phi))
+  sim = Simulation(4, SimulationCfg(use_graph=False, ls_parallel=False), model, "cuda:0")
+  for _ in range(100):
+    sim.step()
+  v0, t0 = _np(sim.data.qvel)[:, :3].copy(), 100 * model.opt.timestep
+  ratios = []
+  for _ in range(500):
+    sim.step()
+    n = int(_np(sim.data.nefc)[0].ravel()[0])
+    if n:
+      f = _np(sim.data.efc_force)[0, :n].reshape(-1, 3)
+      live = f[:, 0] > 1e-6
+      ratios.append(np.hypot(f[live, 1], f[live, 2]) / f[live, 0])
+  a = (_np(sim.data.qvel)[:, :3] - v0) / (500 * model.opt.timestep)
+  want = G * (np.sin(th) - mu * np.cos(th))
+  along = a[:, 0] * np.cos(phi) + a[:, 1] * np.sin(phi)
+  across = -a[:, 0] * np.sin(phi) + a[:, 1] * np.cos(phi)
+  ratios = np.concatenate(ratios)
+  print(f"\nslab: along / want {along / want}, across / want {across / want}, |f_t| / f_n in [{ratios.min():.4f}, {ratios.max():.4f}] over {ratios.size} contact-steps")
+  assert ratios.size > 200 and np.allclose(ratios, mu, rtol=5e-3)
+  assert np.allclose(along, want, rtol=0.06) and (np.abs(across) < 0.02 * want).all()
+  assert t0 > 0
+
+
+def test_elliptic_is_refused_where_it_is_not_carried():
+  """The fused launches, the control kernel and the other solvers carry the pyramid only: asked for elliptic cones they say so."""
+  from mjlab_amd import _abi, mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg, check_supported
+
+  model = copy.deepcopy(models()["g1_velocity_flat"])
+  model.opt.cone = mjcf.CONE_ELLIPTIC
+  sim = Simulation(4, SimulationCfg(njmax=300, use_graph=False, fuse="step"), model, "cuda:0")
+  assert sim.fuse == "stage"  # (the configuration's "step" gives way, as it does for the dual solver)
+  sim._m.opt.flags |= _abi.OPT_FUSE_STEP
+  with pytest.raises(RuntimeError, match="ELLIPTIC"):
+    sim.forward()
+  sim._m.opt.flags &= ~_abi.OPT_FUSE_STEP
+  sim.forward()
+  cg = copy.deepcopy(model)
+  cg.opt.solver = mjcf.SOL_CG
+  with pytest.raises(NotImplementedError, match="elliptic"):
+    check_supported(cg)

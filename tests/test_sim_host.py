@@ -16,6 +16,9 @@ def test_supported_models_pass():
   pgs = copy.deepcopy(robots.load_model("go1_velocity_flat"))
   pgs.opt.solver = 0  # mjSOL_PGS: the dual solver exists since round 3 (one kernel per stage: stage_pgs.h)
   check_supported(pgs)
+  ell = copy.deepcopy(robots.load_model("g1_velocity_flat"))
+  ell.opt.cone = 1  # mjCONE_ELLIPTIC: since round 5, Newton only, one kernel per stage (stage_cone.h)
+  check_supported(ell)
   for m in (robots.box_model(), robots.mixed_model(), robots.pendulum_model()):
     check_supported(m)
 
@@ -24,7 +27,8 @@ def test_supported_models_pass():
   "mutate, match",
   [
     (lambda m: setattr(m.opt, "solver", 3), "solver"),
-    (lambda m: setattr(m.opt, "cone", 1), "pyramidal"),
+    (lambda m: setattr(m.opt, "cone", 2), "cone"),
+    (lambda m: (setattr(m.opt, "cone", 1), setattr(m.opt, "solver", 1)), "elliptic"),
     (lambda m: m.jnt_type.__setitem__(2, 1), "ball"),
     (lambda m: m.geom_condim.__setitem__(slice(None), 4), "condim"),
     (lambda m: m.sensor_intprm.__setitem__((0, 0), 3), "found"),
