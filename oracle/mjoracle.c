@@ -1094,7 +1094,7 @@ static inline int row_cost(const nctx_t* c, int r, real x, real* cost, real* for
  *   top zone     N >= mu T (or T = 0, N >= 0): satisfied, cost 0, force 0;
  *   bottom zone  mu N + T <= 0 (or T = 0, N < 0): every row quadratic, cost = 0.5 sum_k D_k x_k^2, force_k = -D_k x_k;
  *   middle zone  otherwise: cost = 0.5 Dm (N - mu T)^2 with Dm = D_0 / (mu^2 (1 + mu^2)); force = -d cost / d x.
- * The three pieces join continuously (the friction rows' D_k = D_0 friction[0]^2 / (mu^2 friction[k-1]^2) is what makes them).
+ * The three pieces join continuously (the friction rows' D_k = D_0 friction[k-1]^2 / mu^2 -- R_k = R_0 / impratio * friction[0]^2 / friction[k-1]^2 -- is what makes them).
  * H (optional): the 3 x 3 Hessian d^2 cost / d x^2 (row-major).  Returns the zone: 0 top, 1 bottom, 2 middle. */
 static int cone_eval(const nctx_t* c, int r, const real* x, real* cost, real* force, real* H) {
   const real* fr = c->fri + 5 * c->id[r];
