@@ -16,11 +16,12 @@
 // optimised pyramid path, which it leaves untouched: rows evaluated one per lane from LDS, the Hessian accumulated row by row in
 // registers (lane i owns row i of H), factored by the LDS column sweep (common.h chol_factor), both line searches of the primal path
 // (the exact one and mujoco_warp's grid).  The fused launch structures and the control kernel carry the pyramid only (check_model).
-// LDS: H / its factor | 1 / D_i of the factor | per row: jar, J search, D, force, aux (friction loss | cone: mu, f1, f2), role.
+// LDS: H / its factor | M (dense, both triangles) | 1 / D_i of the factor | per row: jar, J search, D, force, aux (friction loss | cone: mu, f1, f2), role | one trip's rows of J.
 // ====================================================================================
+#define CONE_U 8  // rows of J per trip (their loads in flight together)
 __host__ __device__ inline int cone_lds_floats(const mjlab_sizes_t& s) {
   const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
-  return nvp * ld + nvp + 6 * s.njmax;
+  return 2 * nvp * ld + nvp + 6 * s.njmax + (CONE_U + 2) * 64;
 }
 
 enum { CONE_ROLE_ROW = 0, CONE_ROLE_START = 1, CONE_ROLE_MEMBER = 2 };
@@ -134,11 +135,12 @@ __device__ __forceinline__ void cone_ls_eval(ConeCtx& c, LsPnt* p, float alpha) 
   c.ls_iter++;
 }
 
-// cost(alpha) - cost(0) formed row by row as differences (the grid search's default comparison; stage_solve.h line_search_parallel)
-__device__ __forceinline__ float cone_ls_diff(const ConeCtx& c, float alpha) {
+// the grid search's price of step alpha, evaluated by ONE lane over all rows (lanes = candidates; every LDS read is a broadcast):
+// cost(alpha) - cost(0) formed row by row as differences (stage_solve.h line_search_parallel), or -- literal -- the total cost
+__device__ __forceinline__ float cone_cost_at(const ConeCtx& c, float alpha, bool literal) {
   float acc = 0.f;
-  for (int r = c.lane; r < c.nefc; r += 64) {
-    const int role = c.s_role[r];
+  for (int r = 0; r < c.nefc; ++r) {
+    const int role = c.s_role[r];  // wave-uniform
     if (role == CONE_ROLE_MEMBER) continue;
     if (role == CONE_ROLE_START) {
       const float x0[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]};
@@ -147,7 +149,7 @@ __device__ __forceinline__ float cone_ls_diff(const ConeCtx& c, float alpha) {
       float ca, cb, fo[3], g[3], q[3], Da, Db;
       cone_block(x, D, fr, ca, fo, g, q, Da, Db);
       cone_block(x0, D, fr, cb, fo, g, q, Da, Db);
-      acc += 2.f * (ca - cb);
+      acc += literal ? 2.f * ca : 2.f * (ca - cb);
       continue;
     }
     const float j0 = c.s_jar[r], Dr = c.s_D[r], x = fmaf(alpha, c.s_jv[r], j0);
@@ -155,13 +157,14 @@ __device__ __forceinline__ float cone_ls_diff(const ConeCtx& c, float alpha) {
       const float fl = c.s_aux[r], rf = fl / Dr, ax = fabsf(x), a0 = fabsf(j0);
       const float ha = ax >= rf ? 2.f * fl * (ax - 0.5f * rf) : Dr * x * x;
       const float h0 = a0 >= rf ? 2.f * fl * (a0 - 0.5f * rf) : Dr * j0 * j0;
-      acc += ha - h0;
+      acc += literal ? ha : ha - h0;
     } else {
       const float xm = fminf(x, 0.f), xm0 = fminf(j0, 0.f);
-      acc += Dr * (xm - xm0) * (xm + xm0);
+      acc += literal ? Dr * xm * xm : Dr * (xm - xm0) * (xm + xm0);
     }
   }
-  return 0.5f * wave_sum(acc) + alpha * (alpha * c.quad_gauss[2] + c.quad_gauss[1]);
+  const float cost = 0.5f * acc + alpha * (alpha * c.quad_gauss[2] + c.quad_gauss[1]);
+  return literal ? cost + c.quad_gauss[0] : cost;
 }
 
 __device__ __forceinline__ int cone_update_bracket(ConeCtx& c, LsPnt* p, const LsPnt* cand, LsPnt* pnext) {
@@ -212,17 +215,26 @@ __device__ float cone_line_search(ConeCtx& c, float gtol, float dn1, float dn2, 
 #undef CONE_LS_TOL
 }
 
-// y_i = sum_j M[i][j] x_j, lane i owning x_i / y_i (M dense row-major in global memory; read a few times per iteration)
+// y_i = sum_j M[i][j] x_j, lane i owning x_i / y_i; M dense in LDS (both triangles, zero beyond nv)
 template <int NVP>
-__device__ __forceinline__ float cone_mul_M(const float* M, int nv, int lane, float x) {
+__device__ __forceinline__ float cone_mul_M(const float* s_M, int lane, float x) {
+  constexpr int ld = CholCfg<NVP>::LD;
+  const lds_f32* row = (const lds_f32*)s_M + (lane < NVP ? lane : 0) * ld;
   float y = 0.f;
-  const float* row = M + (size_t)(lane < nv ? lane : 0) * nv;
 #pragma unroll
-  for (int j = 0; j < NVP; ++j) {
-    const float xj = lane_bcast(x, j);
-    if (j < nv) y = fmaf(row[j], xj, y);
+  for (int c4 = 0; c4 < NVP / 4; ++c4) {
+    const f32x4 v = *(const lds_f32x4*)(row + 4 * c4);
+    y = fmaf(v.x, lane_bcast(x, 4 * c4), y); y = fmaf(v.y, lane_bcast(x, 4 * c4 + 1), y);
+    y = fmaf(v.z, lane_bcast(x, 4 * c4 + 2), y); y = fmaf(v.w, lane_bcast(x, 4 * c4 + 3), y);
   }
-  return lane < nv ? y : 0.f;
+  return lane < NVP ? y : 0.f;
+}
+
+// this lane's entries of rows r0 .. r0 + N - 1 of J, every load in flight at once (a row per trip would pay a global round trip per row)
+template <int N>
+__device__ __forceinline__ void cone_load_rows(const float* J, int r0, int nefc, int nv, int lane, float (&jr)[N]) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) jr[u] = (lane < nv && r0 + u < nefc) ? J[(size_t)(r0 + u) * nv + lane] : 0.f;
 }
 
 // h (lane i: row i of H) += Dv * a_i * a_j
@@ -238,7 +250,8 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   constexpr int ld = CholCfg<NVP>::LD;
   const int nv = m.size.nv, njm = m.size.njmax, ncm = m.size.nconmax;
   float* s_H = smem;
-  float* s_invd = s_H + NVP * ld;
+  float* s_M = s_H + NVP * ld;
+  float* s_invd = s_M + NVP * ld;
   ConeCtx c;
   c.s_jar = s_invd + NVP;
   c.s_jv = c.s_jar + njm;
@@ -246,6 +259,7 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   c.s_force = c.s_D + njm;
   c.s_aux = c.s_force + njm;
   c.s_role = (int*)(c.s_aux + njm);
+  float* s_Jc = (float*)(c.s_role + njm);  // staging of CONE_U + 2 rows of J, [row][lane]
   const bool own = lane < nv;
   const size_t wv = (size_t)w * nv + lane, wr = (size_t)w * njm;
   const float* J = d.efc_J + wr * nv;
@@ -255,8 +269,12 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   c.nf = (m.opt.flags & MJLAB_OPT_FRICTIONLOSS) ? d.nf[w] : 0;
   const float qs = own ? d.qfrc_smooth[wv] : 0.f;
   const bool ws_at_advance = (m.opt.flags & MJLAB_OPT_WARMSTART_AT_ADVANCE) != 0;
-  // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
+  PROF_INIT();
+  // M: the lower triangle for the factor, a full dense copy (zero beyond nv) for the products; mj_factorM + qacc_smooth = M^-1 qfrc_smooth
+  for (int k = lane; k < NVP * ld; k += 64) s_M[k] = 0.f;
+  __syncthreads();
   dense_global_to_lds(s_H, M, nv, ld, lane, true);
+  dense_global_to_lds(s_M, M, nv, ld, lane, false);
   chol_pad_rows<NVP>(s_H, nv, lane);
   chol_pad_diag<NVP>(s_H, nv, lane);
   __syncthreads();
@@ -264,6 +282,7 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   __syncthreads();
   const float qas = chol_solve<NVP>(s_H, s_invd, lane, qs);
   if (own) d.qacc_smooth[wv] = qas;
+  PROF_MARK(0);
   if (nefc == 0) {
     if (own) {
       d.qacc[wv] = qas;
@@ -273,11 +292,12 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     if (lane == 0) d.solver_niter[w] = 0;
     return;
   }
-  // ---- per row: D, role, aux
+  // ---- per row: D, role, aux; aref parked in the force array until the first constraint update
   const float impratio = (float)m.opt.impratio;
   const float mu_scale = 1.f / sqrtf(impratio > MINVAL ? impratio : MINVAL);
   for (int r = lane; r < nefc; r += 64) {
     c.s_D[r] = d.efc_D[wr + r];
+    c.s_force[r] = d.efc_aref[wr + r];
     int role = CONE_ROLE_ROW;
     float aux = r < c.nf ? d.efc_frictionloss[wr + r] : 0.f;
     if (d.efc_type[wr + r] == MJLAB_EFC_CONTACT_ELLIPTIC) {
@@ -289,21 +309,28 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     c.s_role[r] = role;
     c.s_aux[r] = aux;
   }
+  __syncthreads();
   // ---- warm start: the better of qacc_warmstart and qacc_smooth (mj_fwdConstraint)
   const float ws = own ? d.qacc_warmstart[wv] : 0.f;
-  for (int r = 0; r < nefc; ++r) {
-    const float jr = own ? J[(size_t)r * nv + lane] : 0.f, ar = d.efc_aref[wr + r];
-    const float xw = wave_sum(jr * ws) - ar, xs = wave_sum(jr * qas) - ar;
-    if (lane == 0) { c.s_jar[r] = xw; c.s_jv[r] = xs; }
+  for (int r0 = 0; r0 < nefc; r0 += CONE_U) {
+    float jr[CONE_U];
+    cone_load_rows<CONE_U>(J, r0, nefc, nv, lane, jr);
+#pragma unroll
+    for (int u = 0; u < CONE_U; ++u) {
+      if (r0 + u >= nefc) break;
+      const float ar = c.s_force[r0 + u];
+      const float xw = wave_sum(jr[u] * ws) - ar, xs = wave_sum(jr[u] * qas) - ar;
+      if (lane == 0) { c.s_jar[r0 + u] = xw; c.s_jv[r0 + u] = xs; }
+    }
   }
   __syncthreads();
-  float Ma = cone_mul_M<NVP>(M, nv, lane, ws);
+  float Ma = cone_mul_M<NVP>(s_M, lane, ws);
   const float cw = cone_rows_cost<false>(c, c.s_jar) + wave_sum(own ? 0.5f * (Ma - qs) * (ws - qas) : 0.f);
   const float cs = cone_rows_cost<false>(c, c.s_jv);
   float qacc = ws;
   if (cw > cs) {
     qacc = qas;
-    Ma = cone_mul_M<NVP>(M, nv, lane, qas);
+    Ma = cone_mul_M<NVP>(s_M, lane, qas);
     __syncthreads();
     for (int r = lane; r < nefc; r += 64) c.s_jar[r] = c.s_jv[r];
   }
@@ -318,83 +345,121 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     const float rows = cone_rows_cost<true>(c, c.s_jar);
     __syncthreads();
     float acc = 0.f;
-    for (int r = 0; r < nefc; ++r) {
-      const float f = c.s_force[r];
-      if (f != 0.f) acc = fmaf(own ? J[(size_t)r * nv + lane] : 0.f, f, acc);
+    for (int r0 = 0; r0 < nefc; r0 += CONE_U) {
+      float jr[CONE_U];
+      cone_load_rows<CONE_U>(J, r0, nefc, nv, lane, jr);
+#pragma unroll
+      for (int u = 0; u < CONE_U; ++u)
+        if (r0 + u < nefc) acc = fmaf(jr[u], c.s_force[r0 + u], acc);
     }
     fc = acc;
     gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
     cost = rows + gauss;
   };
+  PROF_MARK(1);
   update();
+  PROF_MARK(2);
   int iter = 0;
   while (iter < maxiter) {
     // ---- H = M + sum over the quadratic rows and cones, factored; search = -H^-1 grad
     const float grad = own ? Ma - qs - fc : 0.f;
     {
       float h[NVP];
-      const float* mrow = M + (size_t)(own ? lane : 0) * nv;
+      {
+        const lds_f32* mrow = (const lds_f32*)s_M + (lane < NVP ? lane : 0) * ld;
 #pragma unroll
-      for (int j = 0; j < NVP; ++j) h[j] = (own && j < nv) ? mrow[j] : 0.f;
-      for (int r = 0; r < nefc; ++r) {
-        const int role = c.s_role[r];  // wave-uniform
-        if (role == CONE_ROLE_MEMBER) continue;
-        if (role == CONE_ROLE_START) {
-          const float x[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
-          float rc, fo[3], g[3], q[3], Da, Db;
-          const int zone = cone_block(x, D, fr, rc, fo, g, q, Da, Db);
-          if (zone == 0) continue;
-          const float j0 = own ? J[(size_t)r * nv + lane] : 0.f, j1 = own ? J[(size_t)(r + 1) * nv + lane] : 0.f, j2 = own ? J[(size_t)(r + 2) * nv + lane] : 0.f;
-          if (zone == 1) {
-            cone_rank1<NVP>(h, j0, D[0]);
-            cone_rank1<NVP>(h, j1, D[1]);
-            cone_rank1<NVP>(h, j2, D[2]);
-          } else {
-            cone_rank1<NVP>(h, g[0] * j0 + g[1] * j1 + g[2] * j2, Da);
-            cone_rank1<NVP>(h, q[1] * j1 + q[2] * j2, Db);
-          }
-          continue;
+        for (int c4 = 0; c4 < NVP / 4; ++c4) {
+          const f32x4 v = *(const lds_f32x4*)(mrow + 4 * c4);
+          h[4 * c4] = v.x; h[4 * c4 + 1] = v.y; h[4 * c4 + 2] = v.z; h[4 * c4 + 3] = v.w;
         }
-        float rc, fo;
-        if (!cone_scalar_row(c, r, c.s_jar[r], rc, fo)) continue;
-        cone_rank1<NVP>(h, own ? J[(size_t)r * nv + lane] : 0.f, c.s_D[r]);
       }
+      for (int r0 = 0; r0 < nefc; r0 += CONE_U) {
+        {  // this trip's rows (+ 2: a cone that starts in this trip may end in the next one's rows) through LDS: the loads in flight together,
+           // the row loop below ONE copy of the zone logic (unrolled over the trip it is 40 inlined rank-one updates and spills h)
+          float jr[CONE_U + 2];
+          cone_load_rows<CONE_U + 2>(J, r0, nefc, nv, lane, jr);
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < CONE_U + 2; ++u) s_Jc[u * 64 + lane] = jr[u];
+          __syncthreads();
+        }
+#pragma unroll 1
+        for (int u = 0; u < CONE_U; ++u) {
+          const int r = r0 + u;
+          if (r >= nefc) break;
+          const int role = c.s_role[r];  // wave-uniform
+          if (role == CONE_ROLE_MEMBER) continue;
+          const float j0 = s_Jc[u * 64 + lane];
+          if (role == CONE_ROLE_START) {
+            const float x[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
+            float rc, fo[3], g[3], q[3], Da, Db;
+            const int zone = cone_block(x, D, fr, rc, fo, g, q, Da, Db);
+            if (zone == 0) continue;
+            const float j1 = s_Jc[(u + 1) * 64 + lane], j2 = s_Jc[(u + 2) * 64 + lane];
+            // three updates either way: the rows' own in the bottom zone; g^T Jc, q^T Jc (and nothing) in the middle zone
+            const bool mid = zone == 2;
+            cone_rank1<NVP>(h, mid ? g[0] * j0 + g[1] * j1 + g[2] * j2 : j0, mid ? Da : D[0]);
+            cone_rank1<NVP>(h, mid ? q[1] * j1 + q[2] * j2 : j1, mid ? Db : D[1]);
+            if (!mid) cone_rank1<NVP>(h, j2, D[2]);
+            continue;
+          }
+          float rc, fo;
+          if (cone_scalar_row(c, r, c.s_jar[r], rc, fo)) cone_rank1<NVP>(h, j0, c.s_D[r]);
+        }
+      }
+      PROF_MARK(3);
       __syncthreads();
       if (lane < NVP) {
 #pragma unroll
-        for (int j = 0; j < NVP; ++j) s_H[lane * ld + j] = own ? h[j] : (j == lane ? 1.f : 0.f);
+        for (int c4 = 0; c4 < NVP / 4; ++c4) {
+          f32x4 v = {h[4 * c4], h[4 * c4 + 1], h[4 * c4 + 2], h[4 * c4 + 3]};
+          if (!own) { v.x = 4 * c4 == lane ? 1.f : 0.f; v.y = 4 * c4 + 1 == lane ? 1.f : 0.f; v.z = 4 * c4 + 2 == lane ? 1.f : 0.f; v.w = 4 * c4 + 3 == lane ? 1.f : 0.f; }
+          *(lds_f32x4*)((lds_f32*)s_H + lane * ld + 4 * c4) = v;
+        }
       }
       __syncthreads();
     }
     chol_factor<NVP>(s_H, s_invd, nv, lane);
     __syncthreads();
     const float search = -chol_solve<NVP>(s_H, s_invd, lane, grad);
+    PROF_MARK(4);
     // ---- line search
     const float snorm = sqrtf(wave_sum(search * search));
     if (snorm < MINVAL) break;
-    const float Mv = cone_mul_M<NVP>(M, nv, lane, search);
+    const float Mv = cone_mul_M<NVP>(s_M, lane, search);
     __syncthreads();
-    for (int r = 0; r < nefc; ++r) {
-      const float t = wave_sum((own ? J[(size_t)r * nv + lane] : 0.f) * search);
-      if (lane == 0) c.s_jv[r] = t;
+    for (int r0 = 0; r0 < nefc; r0 += CONE_U) {
+      float jr[CONE_U];
+      cone_load_rows<CONE_U>(J, r0, nefc, nv, lane, jr);
+#pragma unroll
+      for (int u = 0; u < CONE_U; ++u) {
+        if (r0 + u >= nefc) break;
+        const float t = wave_sum(jr[u] * search);
+        if (lane == 0) c.s_jv[r0 + u] = t;
+      }
     }
     __syncthreads();
     c.quad_gauss[0] = gauss;
     c.quad_gauss[1] = wave_sum(search * (Ma - qs));
     c.quad_gauss[2] = wave_sum(0.5f * search * Mv);
     c.ls_iter = 0;
+    PROF_MARK(5);
     float alpha;
     if (m.opt.flags & MJLAB_OPT_LS_PARALLEL) {
+      // mujoco_warp's grid: ls_iterations log-spaced steps in [ls_parallel_min_step, 1], lanes = candidates, lowest cost wins, the first one on ties
       const float lo = logf((float)m.opt.ls_parallel_min_step), step = (0.f - lo) / (float)(lsmax > 1 ? lsmax - 1 : 1);
       const bool literal = (m.opt.flags & MJLAB_OPT_LS_LITERAL_COST) != 0;
       float best_cost = 0.f;
+      bool have = false;
       alpha = 0.f;
-      for (int i = 0; i < lsmax; ++i) {
-        const float a = expf(lo + (float)i * step);
-        float cc;
-        if (literal) { LsPnt p; cone_ls_eval(c, &p, a); cc = p.cost; }
-        else cc = cone_ls_diff(c, a);
-        if (i == 0 || cc < best_cost) { best_cost = cc; alpha = a; }
+      for (int c0 = 0; c0 < lsmax; c0 += 64) {
+        const int ci = c0 + lane;
+        const float a = expf(lo + (float)ci * step);
+        float cc = cone_cost_at(c, a, literal);
+        if (ci >= lsmax) cc = 3.0e38f;
+        const float cmin = wave_min(cc);
+        const unsigned long long hit = __ballot(cc == cmin && ci < lsmax);
+        if (hit && (!have || cmin < best_cost)) { best_cost = cmin; alpha = lane_bcast_dyn(a, (int)__builtin_ctzll(hit)); have = true; }
       }
     } else {
       float a1 = 0.f, a2 = 0.f;
@@ -405,6 +470,7 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
       const float dn1 = ulp4 * (wave_sum(a1) + fabsf(c.quad_gauss[1])), dn2 = 2.f * ulp4 * (wave_sum(a2) + fabsf(c.quad_gauss[2]));
       alpha = cone_line_search(c, tol * lstol * snorm * (mi * nvf), dn1, dn2, lsmax);
     }
+    PROF_MARK(6);
     if (alpha == 0.f) break;
     qacc += alpha * search;
     Ma += alpha * Mv;
@@ -418,6 +484,8 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     const float improvement = scale * (oldcost - cost), gradient = scale * sqrtf(wave_sum(gnew * gnew));
     const float noise = ulp4 * scale * sqrtf(wave_sum(tn * tn));
     ++iter;
+    PROF_MARK(7);
+    PROF_COUNT(8);
     if (improvement < tol || gradient < tol || gradient < noise) break;
   }
   // ---- publish
@@ -429,6 +497,7 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     if (!ws_at_advance) d.qacc_warmstart[wv] = qacc;
   }
   if (lane == 0) d.solver_niter[w] = iter;
+  PROF_FLUSH(d.profile + (size_t)w * 64 + 48);  // (slots 48..63: the constraint stage's block uses its first four only)
 }
 
 // the solve of a world with elliptic cones; the integrator follows as k_solve_integrate<NVP> with the solve switched off (like the dual

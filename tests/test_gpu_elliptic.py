@@ -132,7 +132,7 @@ def test_elliptic_slab_slides_by_coulombs_law_on_the_device():
 
   mu, th, phi = 0.5, np.arctan(0.8), 1.1
   model = _box(mu, _tilt(th, phi))
-  sim = Simulation(4, SimulationCfg(use_graph=False, ls_parallel=False), model, "cuda:0")
+  sim = Simulation(4, SimulationCfg(ls_parallel=False), model, "cuda:0")  # (use_graph default: the stage launches inside a captured step)
   for _ in range(100):
     sim.step()
   v0, t0 = _np(sim.data.qvel)[:, :3].copy(), 100 * model.opt.timestep
