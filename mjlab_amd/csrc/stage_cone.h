@@ -12,16 +12,20 @@
 //   middle zone  0.5 Dm (N - mu T)^2, Dm = D_0 / (mu^2 (1 + mu^2)), whose Hessian is the sum of two rank-one terms
 //                Dm g g^T + (Dm (mu T - N) mu / T) q q^T,  g = d(N - mu T) / dx,  q = (0, -f1 U2 / T, f2 U1 / T):
 //                the block enters H = M + J^T (...) J as two virtual rows g^T Jc and q^T Jc.
-// Like the dual solver (stage_pgs.h) this is here because the configuration names it, as a plain wave-per-world kernel next to the
-// optimised pyramid path, which it leaves untouched: rows evaluated one per lane from LDS, the Hessian accumulated row by row in
-// registers (lane i owns row i of H), factored by the LDS column sweep (common.h chol_factor), both line searches of the primal path
-// (the exact one and mujoco_warp's grid).  The fused launch structures and the control kernel carry the pyramid only (check_model).
-// LDS: H / its factor | M (dense, both triangles) | 1 / D_i of the factor | per row: jar, J search, D, force, aux (friction loss | cone: mu, f1, f2), role | one trip's rows of J.
+// Like the dual solver (stage_pgs.h) this is here because the configuration names it, as a wave-per-world kernel next to the
+// optimised pyramid path, which it leaves untouched.  Rows are evaluated one per lane from LDS; what they contribute to J^T f and to
+// H is written down as a list of VIRTUAL rows (base row, three coefficients, weight D, force f: a quadratic scalar row is (r; 1 0 0;
+// D_r; -D_r x_r), a friction-loss row in its linear zone has D = 0, a cone gives its three rows in the bottom zone and g^T Jc, q^T Jc in
+// the middle zone, nothing in the top zone), and ONE pass over that list forms J^T f and the 16 x 16 tiles of J^T D J on the matrix
+// cores (v_mfma_f32_16x16x4_f32, four virtual rows per instruction, the loads of 16 virtual rows in flight together).  The factor is
+// the LDS column sweep (common.h chol_factor); both line searches of the primal path (the exact one and mujoco_warp's grid).  The
+// fused launch structures and the control kernel carry the pyramid only (check_model).
+// LDS: H / its factor | M (dense, both triangles) | 1 / D_i of the factor | per row: jar, J search, D, force, aux (friction loss | cone: mu, f1, f2), role, virtual-row force.
 // ====================================================================================
-#define CONE_U 8  // rows of J per trip (their loads in flight together)
 __host__ __device__ inline int cone_lds_floats(const mjlab_sizes_t& s) {
   const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
-  return 2 * nvp * ld + nvp + 6 * s.njmax + (CONE_U + 2) * 64;
+  // (the virtual rows' coefficients and weights -- 4 njmax floats -- live in the dead factor's block where they fit)
+  return 2 * nvp * ld + nvp + 7 * s.njmax + (nvp * ld >= 4 * s.njmax ? 0 : 4 * s.njmax);
 }
 
 enum { CONE_ROLE_ROW = 0, CONE_ROLE_START = 1, CONE_ROLE_MEMBER = 2 };
@@ -30,6 +34,8 @@ struct ConeCtx {
   const float* J;
   float *s_jar, *s_jv, *s_D, *s_force, *s_aux;
   int* s_role;
+  int* s_vr;                              // virtual rows: base row ...
+  float *s_vc0, *s_vc1, *s_vc2, *s_vD, *s_vf;  // ... coefficients of rows r, r + 1, r + 2, weight, force
   int nv, nefc, nf, lane;
   float quad_gauss[3];
   int ls_iter;
@@ -135,21 +141,20 @@ __device__ __forceinline__ void cone_ls_eval(ConeCtx& c, LsPnt* p, float alpha) 
   c.ls_iter++;
 }
 
-// the grid search's price of step alpha, evaluated by ONE lane over all rows (lanes = candidates; every LDS read is a broadcast):
-// cost(alpha) - cost(0) formed row by row as differences (stage_solve.h line_search_parallel), or -- literal -- the total cost
-__device__ __forceinline__ float cone_cost_at(const ConeCtx& c, float alpha, bool literal) {
+// the grid search's price of step alpha over the rows g, g + G, g + 2 G, ... (lanes = candidates x G row groups; every LDS read is a
+// broadcast within a group): cost(alpha) - cost(0) formed row by row as differences (stage_solve.h line_search_parallel), or -- literal --
+// the cost itself (times two, without the Gauss term).  s_c0 = the cones' costs at alpha = 0.
+__device__ __forceinline__ float cone_cost_at(const ConeCtx& c, float alpha, bool literal, int g, int G, const float* s_c0) {
   float acc = 0.f;
-  for (int r = 0; r < c.nefc; ++r) {
-    const int role = c.s_role[r];  // wave-uniform
+  for (int r = g; r < c.nefc; r += G) {
+    const int role = c.s_role[r];
     if (role == CONE_ROLE_MEMBER) continue;
     if (role == CONE_ROLE_START) {
-      const float x0[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]};
-      const float x[3] = {fmaf(alpha, c.s_jv[r], x0[0]), fmaf(alpha, c.s_jv[r + 1], x0[1]), fmaf(alpha, c.s_jv[r + 2], x0[2])};
+      const float x[3] = {fmaf(alpha, c.s_jv[r], c.s_jar[r]), fmaf(alpha, c.s_jv[r + 1], c.s_jar[r + 1]), fmaf(alpha, c.s_jv[r + 2], c.s_jar[r + 2])};
       const float D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
-      float ca, cb, fo[3], g[3], q[3], Da, Db;
-      cone_block(x, D, fr, ca, fo, g, q, Da, Db);
-      cone_block(x0, D, fr, cb, fo, g, q, Da, Db);
-      acc += literal ? 2.f * ca : 2.f * (ca - cb);
+      float ca, fo[3], gg[3], q[3], Da, Db;
+      cone_block(x, D, fr, ca, fo, gg, q, Da, Db);
+      acc += literal ? 2.f * ca : 2.f * (ca - s_c0[r]);
       continue;
     }
     const float j0 = c.s_jar[r], Dr = c.s_D[r], x = fmaf(alpha, c.s_jv[r], j0);
@@ -163,8 +168,7 @@ __device__ __forceinline__ float cone_cost_at(const ConeCtx& c, float alpha, boo
       acc += literal ? Dr * xm * xm : Dr * (xm - xm0) * (xm + xm0);
     }
   }
-  const float cost = 0.5f * acc + alpha * (alpha * c.quad_gauss[2] + c.quad_gauss[1]);
-  return literal ? cost + c.quad_gauss[0] : cost;
+  return acc;
 }
 
 __device__ __forceinline__ int cone_update_bracket(ConeCtx& c, LsPnt* p, const LsPnt* cand, LsPnt* pnext) {
@@ -230,19 +234,138 @@ __device__ __forceinline__ float cone_mul_M(const float* s_M, int lane, float x)
   return lane < NVP ? y : 0.f;
 }
 
-// this lane's entries of rows r0 .. r0 + N - 1 of J, every load in flight at once (a row per trip would pay a global round trip per row)
-template <int N>
-__device__ __forceinline__ void cone_load_rows(const float* J, int r0, int nefc, int nv, int lane, float (&jr)[N]) {
+// Constraint update at the residuals s_jar (lanes = rows): forces to s_force, the virtual-row list (header), the rows' cost.
+__device__ __forceinline__ float cone_update_rows(const ConeCtx& c, int* nvirt) {
+  float cost = 0.f;
+  int base = 0;
+  for (int r0 = 0; r0 < c.nefc; r0 += 64) {  // wave-uniform trips
+    const int r = r0 + c.lane;
+    int n = 0;
+    float e0[3] = {0.f, 0.f, 0.f}, e1[3] = {0.f, 0.f, 0.f}, e2[3] = {0.f, 0.f, 0.f}, eD[3] = {0.f, 0.f, 0.f}, ef[3] = {0.f, 0.f, 0.f};
+    if (r < c.nefc) {
+      const int role = c.s_role[r];
+      if (role == CONE_ROLE_START) {
+        const float x[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
+        float rc, fo[3], g[3], q[3], Da, Db;
+        const int zone = cone_block(x, D, fr, rc, fo, g, q, Da, Db);
+        cost += rc;
+        c.s_force[r] = fo[0]; c.s_force[r + 1] = fo[1]; c.s_force[r + 2] = fo[2];
+        if (zone == 1) {
+          n = 3;
+          e0[0] = 1.f; e1[1] = 1.f; e2[2] = 1.f;
 #pragma unroll
-  for (int u = 0; u < N; ++u) jr[u] = (lane < nv && r0 + u < nefc) ? J[(size_t)(r0 + u) * nv + lane] : 0.f;
+          for (int k = 0; k < 3; ++k) { eD[k] = D[k]; ef[k] = fo[k]; }
+        } else if (zone == 2) {
+          n = 2;
+          e0[0] = g[0]; e1[0] = g[1]; e2[0] = g[2]; eD[0] = Da; ef[0] = fo[0] / fr[0];  // (-Dm phi: force_0 = -Dm phi mu)
+          e1[1] = q[1]; e2[1] = q[2]; eD[1] = Db;
+        }
+      } else if (role == CONE_ROLE_ROW) {
+        float rc, fo;
+        const bool quad = cone_scalar_row(c, r, c.s_jar[r], rc, fo);
+        cost += rc;
+        c.s_force[r] = fo;
+        if (fo != 0.f || quad) { n = 1; e0[0] = 1.f; eD[0] = quad ? c.s_D[r] : 0.f; ef[0] = fo; }
+      }
+    }
+    int total;
+    const int off = base + wave_excl_scan(n, c.lane, &total);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)  // (static indices: the entries stay in registers)
+      if (k < n) { c.s_vr[off + k] = r; c.s_vc0[off + k] = e0[k]; c.s_vc1[off + k] = e1[k]; c.s_vc2[off + k] = e2[k]; c.s_vD[off + k] = eD[k]; c.s_vf[off + k] = ef[k]; }
+    base += total;
+  }
+  *nvirt = base;
+  return wave_sum(cost);
 }
 
-// h (lane i: row i of H) += Dv * a_i * a_j
+// ONE pass over the virtual rows: this lane's (dof's) J^T f, and H = M + sum_k D_k a_k a_k^T laid out in LDS (lower triangle) for the factor.
+// Lanes form 4 virtual rows x 16 columns; the tiles live in registers inside this function only.
 template <int NVP>
-__device__ __forceinline__ void cone_rank1(float (&h)[NVP], float a, float Dv) {
-  const float t = Dv * a;
+__device__ __forceinline__ float cone_accum_store(const ConeCtx& c, int nvirt, float* s_H, const float* s_M) {
+  constexpr int NB = CholCfg<NVP>::NB, NT = NB * (NB + 1) / 2, ld = CholCfg<NVP>::LD;
+  f32x4 acc[NT];
 #pragma unroll
-  for (int j = 0; j < NVP; ++j) h[j] = fmaf(t, lane_bcast(a, j), h[j]);
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float jtf[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) jtf[cb] = 0.f;
+  const int sub = c.lane >> 4, col = launder(c.lane & 15);
+  for (int k0 = 0; k0 < nvirt; k0 += 4 * JU) {
+    float x[JU][NB], dv[JU], fv[JU];
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      const int k = k0 + 4 * u + sub;
+      const bool valid = k < nvirt;
+      const int kk = valid ? k : 0;
+      const int r = c.s_vr[kk];
+      const float c0 = valid ? c.s_vc0[kk] : 0.f, c1 = valid ? c.s_vc1[kk] : 0.f, c2 = valid ? c.s_vc2[kk] : 0.f;
+      dv[u] = valid ? c.s_vD[kk] : 0.f;
+      fv[u] = valid ? c.s_vf[kk] : 0.f;
+      // every load unconditional, from a clamped (always valid) address: per-element conditions would put each load in a branch of its
+      // own and serialise the round trips.  Rows r + 1, r + 2 are fetched for scalar rows too (coefficient 0; the same cache lines mostly)
+      const int ra = valid ? r : 0, rb = min(ra + 1, c.nefc - 1), rc = min(ra + 2, c.nefc - 1);
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        const int cc = 16 * cb + col, ci = min(cc, c.nv - 1);
+        const float j0 = c.J[(size_t)ra * c.nv + ci], j1 = c.J[(size_t)rb * c.nv + ci], j2 = c.J[(size_t)rc * c.nv + ci];
+        x[u][cb] = (valid && cc < c.nv) ? c0 * j0 + c1 * j1 + c2 * j2 : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      float a[NB];
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        jtf[cb] += x[u][cb] * fv[u];
+        a[cb] = dv[u] * x[u][cb];
+      }
+      // (a 16-column block that is all zero in these four rows adds exact zeros: skipped, like the pyramid path's pass)
+      bool nz[NB];
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) nz[cb] = __ballot(x[u][cb] != 0.f) != 0ull;
+      int t = 0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int Jb = 0; Jb <= I; ++Jb) {
+          if (nz[I] && nz[Jb]) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I], x[u][Jb], acc[t], 0, 0, 0);
+          ++t;
+        }
+    }
+  }
+  __syncthreads();
+  {
+    int t = 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int Jb = 0; Jb <= I; ++Jb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
+          if (row < c.nv && cc <= row) s_H[row * ld + cc] = acc[t][k] + s_M[row * ld + cc];
+        }
+        ++t;
+      }
+  }
+  chol_pad_rows<NVP>(s_H, c.nv, c.lane);
+  chol_pad_diag<NVP>(s_H, c.nv, c.lane);
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) { jtf[cb] += __shfl_xor(jtf[cb], 16); jtf[cb] += __shfl_xor(jtf[cb], 32); }
+  return pick16<NB>(jtf, c.lane);
+}
+
+// out[r] = sum_i J[r][i] x_i (and out2 for y) through the pyramid path's pass (stage_solve.h jac_mul: 4 rows x 16 columns per trip of the lanes)
+template <int NVP, bool TWO>
+__device__ __forceinline__ void cone_jac_mul(const ConeCtx& c, float x, float y, float* out, float* out2) {
+  constexpr int NB = CholCfg<NVP>::NB;
+  SolveCtx<NVP> sc;
+  sc.J = c.J; sc.nv = c.nv; sc.nefc = c.nefc; sc.lane = c.lane;
+  float x16[NB], y16[NB];
+  gather16<NB>(x, x16, c.lane);
+  gather16<NB>(TWO ? y : 0.f, y16, c.lane);
+  jac_mul<NVP, TWO>(sc, x16, y16, out, out2);
 }
 
 template <int NVP>
@@ -259,7 +382,14 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   c.s_force = c.s_D + njm;
   c.s_aux = c.s_force + njm;
   c.s_role = (int*)(c.s_aux + njm);
-  float* s_Jc = (float*)(c.s_role + njm);  // staging of CONE_U + 2 rows of J, [row][lane]
+  // the virtual rows live inside one constraint update: their base rows in the J search array (dead between two line searches), their
+  // coefficients and weights in the factor's block (dead until the update lays the next H out there, after its last read of the list)
+  c.s_vf = (float*)(c.s_role + njm);
+  c.s_vr = (int*)c.s_jv;
+  c.s_vc0 = (NVP * ld >= 4 * njm) ? s_H : c.s_vf + njm;
+  c.s_vc1 = c.s_vc0 + njm;
+  c.s_vc2 = c.s_vc1 + njm;
+  c.s_vD = c.s_vc2 + njm;
   const bool own = lane < nv;
   const size_t wv = (size_t)w * nv + lane, wr = (size_t)w * njm;
   const float* J = d.efc_J + wr * nv;
@@ -309,20 +439,11 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     c.s_role[r] = role;
     c.s_aux[r] = aux;
   }
-  __syncthreads();
   // ---- warm start: the better of qacc_warmstart and qacc_smooth (mj_fwdConstraint)
   const float ws = own ? d.qacc_warmstart[wv] : 0.f;
-  for (int r0 = 0; r0 < nefc; r0 += CONE_U) {
-    float jr[CONE_U];
-    cone_load_rows<CONE_U>(J, r0, nefc, nv, lane, jr);
-#pragma unroll
-    for (int u = 0; u < CONE_U; ++u) {
-      if (r0 + u >= nefc) break;
-      const float ar = c.s_force[r0 + u];
-      const float xw = wave_sum(jr[u] * ws) - ar, xs = wave_sum(jr[u] * qas) - ar;
-      if (lane == 0) { c.s_jar[r0 + u] = xw; c.s_jv[r0 + u] = xs; }
-    }
-  }
+  cone_jac_mul<NVP, true>(c, ws, qas, c.s_jar, c.s_jv);
+  __syncthreads();
+  for (int r = lane; r < nefc; r += 64) { const float ar = c.s_force[r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
   __syncthreads();
   float Ma = cone_mul_M<NVP>(s_M, lane, ws);
   const float cw = cone_rows_cost<false>(c, c.s_jar) + wave_sum(own ? 0.5f * (Ma - qs) * (ws - qas) : 0.f);
@@ -339,86 +460,28 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   const float scale = 1.f / (mi * nvf), tol = (float)m.opt.tolerance, lstol = (float)m.opt.ls_tolerance;
   const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
   const float ulp4 = (m.opt.flags & MJLAB_OPT_LITERAL_TERMINATION) ? 0.f : 4.f * 5.9604645e-8f;
-  // constraint update: forces, cost, J^T f
+  PROF_MARK(1);
+  // constraint update: forces, cost, and -- one pass over the virtual rows -- J^T f and H = M + J^T (.) J laid out for the factor
+  // (the previous factor in s_H is dead by then: it is used between two updates only)
   float cost, gauss, fc;
   auto update = [&]() {
-    const float rows = cone_rows_cost<true>(c, c.s_jar);
+    int nvirt;
+    PROF_MARK(9);
+    const float rows = cone_update_rows(c, &nvirt);
     __syncthreads();
-    float acc = 0.f;
-    for (int r0 = 0; r0 < nefc; r0 += CONE_U) {
-      float jr[CONE_U];
-      cone_load_rows<CONE_U>(J, r0, nefc, nv, lane, jr);
-#pragma unroll
-      for (int u = 0; u < CONE_U; ++u)
-        if (r0 + u < nefc) acc = fmaf(jr[u], c.s_force[r0 + u], acc);
-    }
-    fc = acc;
+    PROF_MARK(10);
+    fc = cone_accum_store<NVP>(c, nvirt, s_H, s_M);
     gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
     cost = rows + gauss;
+    __syncthreads();
+    PROF_MARK(11);
   };
-  PROF_MARK(1);
   update();
   PROF_MARK(2);
   int iter = 0;
   while (iter < maxiter) {
-    // ---- H = M + sum over the quadratic rows and cones, factored; search = -H^-1 grad
+    // ---- search = -H^-1 grad
     const float grad = own ? Ma - qs - fc : 0.f;
-    {
-      float h[NVP];
-      {
-        const lds_f32* mrow = (const lds_f32*)s_M + (lane < NVP ? lane : 0) * ld;
-#pragma unroll
-        for (int c4 = 0; c4 < NVP / 4; ++c4) {
-          const f32x4 v = *(const lds_f32x4*)(mrow + 4 * c4);
-          h[4 * c4] = v.x; h[4 * c4 + 1] = v.y; h[4 * c4 + 2] = v.z; h[4 * c4 + 3] = v.w;
-        }
-      }
-      for (int r0 = 0; r0 < nefc; r0 += CONE_U) {
-        {  // this trip's rows (+ 2: a cone that starts in this trip may end in the next one's rows) through LDS: the loads in flight together,
-           // the row loop below ONE copy of the zone logic (unrolled over the trip it is 40 inlined rank-one updates and spills h)
-          float jr[CONE_U + 2];
-          cone_load_rows<CONE_U + 2>(J, r0, nefc, nv, lane, jr);
-          __syncthreads();
-#pragma unroll
-          for (int u = 0; u < CONE_U + 2; ++u) s_Jc[u * 64 + lane] = jr[u];
-          __syncthreads();
-        }
-#pragma unroll 1
-        for (int u = 0; u < CONE_U; ++u) {
-          const int r = r0 + u;
-          if (r >= nefc) break;
-          const int role = c.s_role[r];  // wave-uniform
-          if (role == CONE_ROLE_MEMBER) continue;
-          const float j0 = s_Jc[u * 64 + lane];
-          if (role == CONE_ROLE_START) {
-            const float x[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
-            float rc, fo[3], g[3], q[3], Da, Db;
-            const int zone = cone_block(x, D, fr, rc, fo, g, q, Da, Db);
-            if (zone == 0) continue;
-            const float j1 = s_Jc[(u + 1) * 64 + lane], j2 = s_Jc[(u + 2) * 64 + lane];
-            // three updates either way: the rows' own in the bottom zone; g^T Jc, q^T Jc (and nothing) in the middle zone
-            const bool mid = zone == 2;
-            cone_rank1<NVP>(h, mid ? g[0] * j0 + g[1] * j1 + g[2] * j2 : j0, mid ? Da : D[0]);
-            cone_rank1<NVP>(h, mid ? q[1] * j1 + q[2] * j2 : j1, mid ? Db : D[1]);
-            if (!mid) cone_rank1<NVP>(h, j2, D[2]);
-            continue;
-          }
-          float rc, fo;
-          if (cone_scalar_row(c, r, c.s_jar[r], rc, fo)) cone_rank1<NVP>(h, j0, c.s_D[r]);
-        }
-      }
-      PROF_MARK(3);
-      __syncthreads();
-      if (lane < NVP) {
-#pragma unroll
-        for (int c4 = 0; c4 < NVP / 4; ++c4) {
-          f32x4 v = {h[4 * c4], h[4 * c4 + 1], h[4 * c4 + 2], h[4 * c4 + 3]};
-          if (!own) { v.x = 4 * c4 == lane ? 1.f : 0.f; v.y = 4 * c4 + 1 == lane ? 1.f : 0.f; v.z = 4 * c4 + 2 == lane ? 1.f : 0.f; v.w = 4 * c4 + 3 == lane ? 1.f : 0.f; }
-          *(lds_f32x4*)((lds_f32*)s_H + lane * ld + 4 * c4) = v;
-        }
-      }
-      __syncthreads();
-    }
     chol_factor<NVP>(s_H, s_invd, nv, lane);
     __syncthreads();
     const float search = -chol_solve<NVP>(s_H, s_invd, lane, grad);
@@ -428,16 +491,7 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     if (snorm < MINVAL) break;
     const float Mv = cone_mul_M<NVP>(s_M, lane, search);
     __syncthreads();
-    for (int r0 = 0; r0 < nefc; r0 += CONE_U) {
-      float jr[CONE_U];
-      cone_load_rows<CONE_U>(J, r0, nefc, nv, lane, jr);
-#pragma unroll
-      for (int u = 0; u < CONE_U; ++u) {
-        if (r0 + u >= nefc) break;
-        const float t = wave_sum(jr[u] * search);
-        if (lane == 0) c.s_jv[r0 + u] = t;
-      }
-    }
+    cone_jac_mul<NVP, false>(c, search, 0.f, c.s_jv, nullptr);
     __syncthreads();
     c.quad_gauss[0] = gauss;
     c.quad_gauss[1] = wave_sum(search * (Ma - qs));
@@ -449,16 +503,32 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
       // mujoco_warp's grid: ls_iterations log-spaced steps in [ls_parallel_min_step, 1], lanes = candidates, lowest cost wins, the first one on ties
       const float lo = logf((float)m.opt.ls_parallel_min_step), step = (0.f - lo) / (float)(lsmax > 1 ? lsmax - 1 : 1);
       const bool literal = (m.opt.flags & MJLAB_OPT_LS_LITERAL_COST) != 0;
+      // the cones' costs at alpha = 0, once per search (virtual-row force array: free between two updates)
+      float* s_c0 = c.s_vf;
+      for (int r = lane; r < nefc; r += 64)
+        if (c.s_role[r] == CONE_ROLE_START) {
+          const float x[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
+          float cb, fo[3], gg[3], q[3], Da, Db;
+          cone_block(x, D, fr, cb, fo, gg, q, Da, Db);
+          s_c0[r] = cb;
+        }
+      __syncthreads();
+      const int nc = lsmax < 64 ? (lsmax > 1 ? lsmax : 1) : 64;  // candidates per trip
+      const int G = 1 + (2 * nc <= 64) + (3 * nc <= 64) + (4 * nc <= 64);  // row groups per candidate
+      const int g = (lane >= nc) + (lane >= 2 * nc) + (lane >= 3 * nc) + (lane >= 4 * nc), cnd = lane - g * nc;
       float best_cost = 0.f;
       bool have = false;
       alpha = 0.f;
-      for (int c0 = 0; c0 < lsmax; c0 += 64) {
-        const int ci = c0 + lane;
+      for (int c0 = 0; c0 < lsmax; c0 += nc) {
+        const int ci = c0 + cnd;
         const float a = expf(lo + (float)ci * step);
-        float cc = cone_cost_at(c, a, literal);
-        if (ci >= lsmax) cc = 3.0e38f;
+        float part = g < G ? cone_cost_at(c, a, literal, g, G, s_c0) : 0.f, acc = part;
+        for (int k = 1; k < G; ++k) acc += __shfl(part, lane + k * nc);  // group 0 collects its candidate's row groups
+        float cc = 0.5f * acc + a * (a * c.quad_gauss[2] + c.quad_gauss[1]);
+        if (literal) cc += c.quad_gauss[0];
+        if (!(g == 0 && ci < lsmax)) cc = 3.0e38f;
         const float cmin = wave_min(cc);
-        const unsigned long long hit = __ballot(cc == cmin && ci < lsmax);
+        const unsigned long long hit = __ballot(cc == cmin && g == 0 && ci < lsmax);
         if (hit && (!have || cmin < best_cost)) { best_cost = cmin; alpha = lane_bcast_dyn(a, (int)__builtin_ctzll(hit)); have = true; }
       }
     } else {
@@ -479,6 +549,7 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     __syncthreads();
     const float oldcost = cost;
     update();
+    PROF_MARK(3);
     const float gnew = own ? Ma - qs - fc : 0.f;
     const float tn = own ? fabsf(Ma) + fabsf(qs) + fabsf(fc) : 0.f;
     const float improvement = scale * (oldcost - cost), gradient = scale * sqrtf(wave_sum(gnew * gnew));
