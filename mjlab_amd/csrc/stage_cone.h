@@ -76,25 +76,22 @@ __device__ __forceinline__ bool cone_scalar_row(const ConeCtx& c, int r, float x
   force = 0.f; cost = 0.f; return false;
 }
 
-// sum of the rows' costs at residuals xs[] (LDS); WRITE: the forces go to s_force
-template <bool WRITE>
+// sum of the rows' costs at residuals xs[] (LDS), lanes = rows: the warm start's comparison
 __device__ __forceinline__ float cone_rows_cost(const ConeCtx& c, const float* xs) {
   float cost = 0.f;
   for (int r = c.lane; r < c.nefc; r += 64) {
     const int role = c.s_role[r];
     if (role == CONE_ROLE_MEMBER) continue;
+    float rc;
     if (role == CONE_ROLE_START) {
       const float x[3] = {xs[r], xs[r + 1], xs[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
-      float rc, fo[3], g[3], q[3], Da, Db;
+      float fo[3], g[3], q[3], Da, Db;
       cone_block(x, D, fr, rc, fo, g, q, Da, Db);
-      cost += rc;
-      if (WRITE) { c.s_force[r] = fo[0]; c.s_force[r + 1] = fo[1]; c.s_force[r + 2] = fo[2]; }
     } else {
-      float rc, fo;
+      float fo;
       cone_scalar_row(c, r, xs[r], rc, fo);
-      cost += rc;
-      if (WRITE) c.s_force[r] = fo;
     }
+    cost += rc;
   }
   return wave_sum(cost);
 }
@@ -446,8 +443,8 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   for (int r = lane; r < nefc; r += 64) { const float ar = c.s_force[r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
   __syncthreads();
   float Ma = cone_mul_M<NVP>(s_M, lane, ws);
-  const float cw = cone_rows_cost<false>(c, c.s_jar) + wave_sum(own ? 0.5f * (Ma - qs) * (ws - qas) : 0.f);
-  const float cs = cone_rows_cost<false>(c, c.s_jv);
+  const float cw = cone_rows_cost(c, c.s_jar) + wave_sum(own ? 0.5f * (Ma - qs) * (ws - qas) : 0.f);
+  const float cs = cone_rows_cost(c, c.s_jv);
   float qacc = ws;
   if (cw > cs) {
     qacc = qas;

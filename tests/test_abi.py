@@ -95,3 +95,7 @@ def test_every_bundled_scene_keeps_16_waves_per_cu_in_lds():
     assert all(0 < b <= 10240 for b in lds.values()), (scene, lds)
     if scene.startswith("g1"):
       assert lds["solve"] == 10104, lds
+      # elliptic cones (stage_cone.h): their own kernel and LDS layout -- H, dense M, 7 per-row arrays over all njmax rows: 2 waves per SIMD
+      ms.opt.cone = 1
+      ell = L.mjlab_lds_bytes(ctypes.byref(ms), 16)
+      assert ell == 4 * (2 * 36 * 36 + 36 + 7 * 300) and ell <= 160 * 1024 // 8, ell
