@@ -24,6 +24,9 @@ __host__ __device__ inline int solve_nvp(int nv) {
 #endif
 // everything but the per-row arrays: H / factor, 1 / D, scratch (friction-loss arrays during the solve, 64 floats for the
 // integrator after it), packed M
+#ifndef MJLAB_JSKIP
+#define MJLAB_JSKIP 0  // block-sparse jac_mul (experiment; below)
+#endif
 __host__ __device__ inline int solve_lds_fixed_floats(const mjlab_sizes_t& s) {
   const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
   const int scratch = 4 * nvp > 64 ? 4 * nvp : 64;
@@ -47,9 +50,16 @@ __host__ __device__ inline int solve_lds_rows(const mjlab_sizes_t& s) {
   return rows;
 }
 __host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
-  const int rows = solve_lds_rows(s), all_rows = solve_lds_all_rows_floats(s);
+  const int rows = solve_lds_rows(s);
+#if defined(MJLAB_JSKIP) && MJLAB_JSKIP == 2  // experiment: + one word per 4-row group behind the per-row arrays
+  const int all_rows = solve_lds_all_rows_floats(s) + (s.njmax + 3) / 4;
+  if (rows < 0) return all_rows;
+  const int with_m = solve_lds_fixed_floats(s) + 3 * rows + (rows + 3) / 4;
+#else
+  const int all_rows = solve_lds_all_rows_floats(s);
   if (rows < 0) return all_rows;
   const int with_m = solve_lds_fixed_floats(s) + 3 * rows;
+#endif
   return with_m > all_rows ? with_m : all_rows;
 }
 
@@ -105,8 +115,18 @@ __device__ __forceinline__ float pick16(const float (&v)[NB], int lane) {
 constexpr int JU = MJLAB_JU;  // 4-row groups per unrolled block
 
 // out[r] = sum_i J[r][i] x_i (+ out2 for a second vector); lanes form 4 row groups x 16 columns
+// MJLAB_JSKIP (experiment, default 0): block-sparse pass.  A row touches the dofs of its bodies' chains only, so
+// most 16-column blocks of a 4-row group are all zero.  The warm start's pass (TWO) notes per group which blocks hold anything (a ballot
+// on the values it loads anyway; lane g of `gmask` keeps group g's three bits: no LDS, one register), the passes of the Newton loop load
+// the other blocks only.  Adds exact zeros otherwise: bit-identical.  Measured: profiles/r05_v23/ab_jskip.txt.
 template <int NVP, bool TWO>
-__device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x16)[CholCfg<NVP>::NB], const float (&y16)[CholCfg<NVP>::NB], float* out, float* out2) {
+__device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x16)[CholCfg<NVP>::NB], const float (&y16)[CholCfg<NVP>::NB], float* out, float* out2
+#if MJLAB_JSKIP == 1
+                                        , int& gmask
+#elif MJLAB_JSKIP == 2
+                                        , int* gmask  // LDS, one word per 4-row group
+#endif
+) {
   constexpr int NB = CholCfg<NVP>::NB;
   const int sub = c.lane >> 4, col = launder(c.lane & 15);
   for (int r0 = 0; r0 < c.nefc; r0 += 4 * JU) {
@@ -114,15 +134,39 @@ __device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x1
 #pragma unroll
     for (int u = 0; u < JU; ++u) {
       const int r = r0 + 4 * u + sub;
+#if MJLAB_JSKIP == 1
+      const int gi = (r0 >> 2) + u;  // wave-uniform
+      const int mk = (!TWO && gi < 64) ? __builtin_amdgcn_readlane(gmask, gi) : (1 << NB) - 1;
+#elif MJLAB_JSKIP == 2
+      const int mk = TWO ? (1 << NB) - 1 : __builtin_amdgcn_readfirstlane(gmask[(r0 >> 2) + u]);
+#endif
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
         const int cc = 16 * cb + col;
+#if MJLAB_JSKIP
+        jv[u][cb] = 0.f;
+        if ((mk >> cb) & 1) jv[u][cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
+#else
         jv[u][cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
+#endif
       }
     }
 #pragma unroll
     for (int u = 0; u < JU; ++u) {
       const int r = r0 + 4 * u + sub;
+#if MJLAB_JSKIP
+      if (TWO) {
+        int nzm = 0;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) nzm |= (__ballot(jv[u][cb] != 0.f) != 0ull) ? (1 << cb) : 0;
+        const int gi = (r0 >> 2) + u;
+#if MJLAB_JSKIP == 1
+        gmask = c.lane == gi ? nzm : gmask;
+#else
+        if (c.lane == 0) gmask[gi] = nzm;
+#endif
+      }
+#endif
       float acc = 0.f, acc2 = 0.f;
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
@@ -691,6 +735,11 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
   float cg_search = 0.f, cg_grad = 0.f, cg_Mgrad = 0.f;  // CG: the previous direction, gradient and M^-1 gradient
   int iter = 0, state;
   bool need_factor = true;
+#if MJLAB_JSKIP == 1
+  int jskip_mask = (1 << NB) - 1;  // lane g: the non-zero 16-column blocks of row group g (jac_mul)
+#elif MJLAB_JSKIP == 2
+  int* jskip_mask = (int*)(s_vec + (4 * NVP > 64 ? 4 * NVP : 64) + (BIG ? 0 : NVP * (NVP + 1) / 2));  // (the end of the block: solve_lds_floats)
+#endif
   // low-rank correction of the Newton factor (above): tile factorization, worlds whose rows fit the masks, no friction-loss rows
 #if MJLAB_SMW
   constexpr bool SMW = TILES && !BIG && !CG;
@@ -894,7 +943,11 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           float x16[NB], y16[NB];
           gather16<NB>(ws, x16, lane);
           gather16<NB>(qas, y16, lane);
+#if MJLAB_JSKIP
+          jac_mul<NVP, true>(c, x16, y16, c.s_jar, c.s_jv, jskip_mask);
+#else
           jac_mul<NVP, true>(c, x16, y16, c.s_jar, c.s_jv);
+#endif
         }
         __syncthreads();
         for (int r = launder(lane); r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
@@ -967,7 +1020,11 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           float x16[NB];
           gather16<NB>(search, x16, lane);
           __syncthreads();
+#if MJLAB_JSKIP
+          jac_mul<NVP, false>(c, x16, x16, c.s_jv, c.s_jv, jskip_mask);
+#else
           jac_mul<NVP, false>(c, x16, x16, c.s_jv, c.s_jv);
+#endif
         }
         __syncthreads();
         c.quad_gauss[0] = gauss;
