@@ -23,7 +23,6 @@ reads the XMLs from the reference checkout when it is present).
 
 from __future__ import annotations
 
-import math
 import os
 from dataclasses import dataclass, field
 from pathlib import Path

@@ -135,7 +135,7 @@ def test_elliptic_slab_slides_by_coulombs_law_on_the_device():
   sim = Simulation(4, SimulationCfg(ls_parallel=False), model, "cuda:0")  # (use_graph default: the stage launches inside a captured step)
   for _ in range(100):
     sim.step()
-  v0, t0 = _np(sim.data.qvel)[:, :3].copy(), 100 * model.opt.timestep
+  v0 = _np(sim.data.qvel)[:, :3].copy()
   ratios = []
   for _ in range(500):
     sim.step()
@@ -152,7 +152,6 @@ def test_elliptic_slab_slides_by_coulombs_law_on_the_device():
   print(f"\nslab: along / want {along / want}, across / want {across / want}, |f_t| / f_n in [{ratios.min():.4f}, {ratios.max():.4f}] over {ratios.size} contact-steps")
   assert ratios.size > 200 and np.allclose(ratios, mu, rtol=5e-3)
   assert np.allclose(along, want, rtol=0.06) and (np.abs(across) < 0.02 * want).all()
-  assert t0 > 0
 
 
 def test_elliptic_is_refused_where_it_is_not_carried():
