@@ -178,6 +178,8 @@ def main() -> None:
   ap.add_argument("--no-pipeline", action="store_true",
                   help="N > 1: skip the second view in which each rank's worlds are two half batches whose learner round trips are "
                   "interleaved (mjlab_amd.dist.pingpong_steps; key `pipelined`).  `value` is always the plain synchronous exchange")
+  ap.add_argument("--cone", choices=["pyramidal", "elliptic"], default="pyramidal",
+                  help="friction cone of the compiled model (the tasks configure pyramidal: the headline workload; elliptic = the cone variants of the kernels, an experiment line)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-latency-bound", action="store_true", help="skip the one-wave-per-SIMD launch that measures roofline.latency")
   ap.add_argument("--no-full-env", action="store_true",
@@ -199,6 +201,13 @@ def main() -> None:
   torch.cuda.set_device(mdist.device_index(info))
 
   model = robots.load_model(args.scene)
+  if args.cone == "elliptic":
+    import copy
+
+    from mjlab_amd.mjcf import CONE_ELLIPTIC
+
+    model = copy.deepcopy(model)
+    model.opt.cone = CONE_ELLIPTIC
   sim = Simulation(args.envs_per_gpu, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), use_graph=not args.no_graph, fold_forward=not args.no_fold, fuse=args.fuse, ls_parallel=not args.exact_ls), model, dev)
   scale = g1_action_scale(model) if args.scene.startswith("g1") else go1_action_scale(model)
   robot = "g1" if args.scene.startswith("g1") else "go1"
@@ -389,7 +398,7 @@ def main() -> None:
       # the bracket holds torch.rand (one small launch) + the control-step kernel; the kernel's own
       # duration is what rocprofv3 reports (profiles/<tag>/kernel_stats.csv)
       dom_ms, dom_sub = acc / reps, roll.decimation + 1
-      dom_name = f"k_control_step<{min(x for x in (8, 16, 20, 24, 32, 36, 40, 48, 64) if x >= model.nv)}>"
+      dom_name = f"k_control_step{'_cone' if args.cone == 'elliptic' else ''}<{min(x for x in (8, 16, 20, 24, 32, 36, 40, 48, 64) if x >= model.nv)}>"
     elif args.fuse == "step":
       acc, nl = 0.0, 0
       sim_graph = sim.use_graph
@@ -617,7 +626,7 @@ def main() -> None:
       "config": {
         "workload": f"{args.scene}: {args.envs_per_gpu} envs/GPU, timestep 0.005, decimation 4, Newton 10 it / 20 ls "
         + ("(ls_parallel: mujoco_warp's grid search, the reference's setting)" if sim.ls_parallel else "(exact iterative line search; ls_parallel off)")
-        + ", implicitfast, pyramidal, njmax 300"
+        + f", implicitfast, {args.cone}, njmax 300"
         + ("" if args.no_task_events else ("; task events: DR friction / torso com / joint zero offsets, 6-component pushes, motion-phase resets, anchor height / orientation terminations, 10 s episodes"
                                            if "motion" in events else "; task events: DR friction (per-env geom_friction), pushes, bad_orientation 70 deg termination")),
         "global_envs": n_env,

@@ -246,7 +246,7 @@ typedef struct mjlab_option {
   int iterations;
   int ls_iterations;
   int integrator;
-  int cone; /* MJLAB_CONE_PYRAMIDAL everywhere; MJLAB_CONE_ELLIPTIC: MJLAB_SOL_NEWTON, one kernel per stage only (no MJLAB_OPT_FUSE_*, no mjlab_control_step) */
+  int cone; /* MJLAB_CONE_PYRAMIDAL everywhere; MJLAB_CONE_ELLIPTIC: MJLAB_SOL_NEWTON only; every launch structure but MJLAB_OPT_FUSE_PRESOLVE (kernels of its own) */
   int flags; /* MJLAB_OPT_* bits below */
   int solver; /* mjtSolver: MJLAB_SOL_NEWTON, MJLAB_SOL_CG, or MJLAB_SOL_PGS (the dual solver: only with one kernel per stage, i.e.
                  neither MJLAB_OPT_FUSE_PRESOLVE nor MJLAB_OPT_FUSE_STEP, and not through mjlab_control_step) */

@@ -114,6 +114,7 @@ typedef const __attribute__((address_space(4))) char* kptr_t;
 static_assert(sizeof(Model) % 8 == 0 && alignof(Data) == 8, "kernarg layout assumed by FUSED_ARGS");
 
 // wsel_ = the world this wave works on (blockIdx.x, or mjlab_control_t.world_order[blockIdx.x])
+template <bool ELL = false>  // ELL: the constraint stage's elliptic-cone instantiation (the cone variants of the fused kernels, below)
 __device__ __forceinline__ void fused_presolve(const int wsel_, const int flags, float* smem) {
   bool reuse;
   { FUSED_ARGS; reuse = stage_position(m, d, w, lane, flags, smem); }
@@ -125,7 +126,7 @@ __device__ __forceinline__ void fused_presolve(const int wsel_, const int flags,
   { FUSED_ARGS; stage_velocity(m, d, w, lane, flags, smem); }
   __syncthreads();
   if (!reuse) {
-    { FUSED_ARGS; stage_constraint(m, d, w, lane, flags, smem); }
+    { FUSED_ARGS; stage_constraint<ELL>(m, d, w, lane, flags, smem); }
     __syncthreads();
   }
 }
@@ -217,3 +218,69 @@ __global__ __launch_bounds__(64, MJLAB_WPE) void k_control_step(const Model m_, 
 #endif
 }
 
+// ====================================================================================
+// The cone variants of the fused launches (mjlab_option_t.cone = MJLAB_CONE_ELLIPTIC; stage_cone.h): the same structures with the
+// constraint stage's ELL instantiation and, for the solve, the cone solver followed by the pyramid path's integrator with its solve
+// switched off (the hand-over of qacc / qfrc_constraint through the public arrays, as between any two stages).  Kernels of their own --
+// the bodies are spelled out a second time rather than shared through a template parameter -- so that the pyramid's kernels, the
+// measured path, are the code they were instruction for instruction; 2 waves per SIMD like k_solve_cone.
+// ====================================================================================
+template <int NVP>
+__device__ __forceinline__ void fused_solve_cone(const int wsel_, const bool integrate, const int flags, float* smem) {
+  { FUSED_ARGS; stage_solve_cone<NVP>(m, d, w, lane, smem); }
+  __syncthreads();
+  if (integrate) {
+    { FUSED_ARGS; stage_solve<NVP>(m, d, w, lane, 0, 1, flags, smem); }
+    __syncthreads();
+  }
+}
+template <int NVP, bool INTEGRATE>
+__global__ __launch_bounds__(64, 2) void k_substep_cone(const Model m_, const Data d_, const int flags, const int nsub) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((flags & FLAG_MASK) && !d_.world_mask[blockIdx.x]) return;
+  const int wsel_ = blockIdx.x;
+  for (int s = 0; s < nsub; ++s) {
+    const int f = s == 0 ? flags : (flags & ~FLAG_FOLD);
+    fused_presolve<true>(wsel_, f, smem);
+    fused_solve_cone<NVP>(wsel_, INTEGRATE, f, smem);
+  }
+  if (!INTEGRATE && (flags & FLAG_SNAPSHOT)) { FUSED_ARGS; fold_snapshot(m, d, w, lane); }
+}
+template <int NVP>
+__global__ __launch_bounds__(64, 2) void k_control_step_cone(const Model m_, const Data d_, const mjlab_control_t c, const int fold) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wsel_ = __builtin_amdgcn_readfirstlane(c.world_order ? c.world_order[blockIdx.x] : (int)blockIdx.x);
+  if (c.action) {
+    FUSED_ARGS;
+    const int nu = m.size.nu;
+    for (int a = lane; a < nu; a += 64) d.ctrl[(size_t)w * nu + a] = __fadd_rn(c.action_offset[a], __fmul_rn(c.action_scale[a], c.action[(size_t)w * nu + a]));
+    __syncthreads();
+  }
+  bool reset = false;
+  for (int s = 0; s <= c.nsubstep; ++s) {
+    const bool fwd = s == c.nsubstep;
+    if (fwd) {
+      if (c.key_qpos) {
+        FUSED_ARGS;
+        reset = masked_reset_world(m, d, w, lane, c.key_qpos, c.rnd3, c.episode_length, c.max_len, c.min_height, c.reset_mask, c.env_origins, c.min_up_z,
+                                   c.reset_qpos, c.reset_qvel, c.term_ref, c.term_dz, c.term_dup, c.motion);
+        __syncthreads();
+      }
+      if (!(c.forward_mode == 1 || (c.forward_mode == 2 && reset))) break;
+    }
+    const int f = (s == 0 && fold && !fwd) ? FLAG_FOLD : 0;
+    fused_presolve<true>(wsel_, f, smem);
+    fused_solve_cone<NVP>(wsel_, !fwd, f, smem);
+    if (fwd) { FUSED_ARGS; fold_snapshot(m, d, w, lane); }
+  }
+  if (c.readback_on) {
+    FUSED_ARGS;
+    __syncthreads();
+    entity_readback_world(m, d, c.readback, w, lane);
+  }
+  if (c.push_time_left) {
+    FUSED_ARGS;
+    __syncthreads();
+    if (lane == 0) interval_push_world(m, d, w, c.push_time_left, c.rnd7, c.push_dt, c.push_interval_lo, c.push_interval_hi, c.push_range);
+  }
+}

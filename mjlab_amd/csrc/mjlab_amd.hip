@@ -56,8 +56,8 @@ static int check_model(const mjlab_model_t* m) {
   if (s.njmax < 1 || s.nconmax < 1) return fail(-4, "njmax and nconmax must be >= 1");
   if (s.ngeom > 65535) return fail(-19, "ngeom must be < 65536 (geom pairs are packed into one word)");
   if (m->opt.cone != MJLAB_CONE_PYRAMIDAL && m->opt.cone != MJLAB_CONE_ELLIPTIC) return fail(-5, "opt.cone must be MJLAB_CONE_PYRAMIDAL or MJLAB_CONE_ELLIPTIC");
-  if (m->opt.cone == MJLAB_CONE_ELLIPTIC && (m->opt.solver != MJLAB_SOL_NEWTON || (m->opt.flags & (MJLAB_OPT_FUSE_PRESOLVE | MJLAB_OPT_FUSE_STEP))))
-    return fail(-5, "MJLAB_CONE_ELLIPTIC runs with MJLAB_SOL_NEWTON and one kernel per stage only (clear MJLAB_OPT_FUSE_PRESOLVE / MJLAB_OPT_FUSE_STEP)");
+  if (m->opt.cone == MJLAB_CONE_ELLIPTIC && (m->opt.solver != MJLAB_SOL_NEWTON || (m->opt.flags & MJLAB_OPT_FUSE_PRESOLVE)))
+    return fail(-5, "MJLAB_CONE_ELLIPTIC runs with MJLAB_SOL_NEWTON, one kernel per stage or MJLAB_OPT_FUSE_STEP (no MJLAB_OPT_FUSE_PRESOLVE)");
   if (m->opt.integrator != MJLAB_INT_EULER && m->opt.integrator != MJLAB_INT_IMPLICITFAST)
     return fail(-6, "integrator must be Euler or implicitfast");
   if (m->opt.solver != MJLAB_SOL_CG && m->opt.solver != MJLAB_SOL_NEWTON && m->opt.solver != MJLAB_SOL_PGS)
@@ -95,10 +95,11 @@ static int presolve_lds_floats(const mjlab_sizes_t& s) {
   return max4(position_lds_floats(s), collision_lds_floats(s), velocity_lds_floats(s), constraint_lds_floats(s));
 }
 static int launch_substep(const mjlab_model_t* m, const mjlab_data_t* d, int do_integrate, int flags, int nsub, hipStream_t st) {
-  const int a = presolve_lds_floats(m->size), b = solve_lds_floats(m->size), lds = a > b ? a : b;
+  const int a = presolve_lds_floats(m->size), b = solve_stage_lds_floats(m), lds = a > b ? a : b;
   const NvpLaunch* L = nvp_launch(solve_nvp(m->size.nv));
   if (!L) return fail(-3, "nv must be in [1, 64]");
-  hipError_t e = do_integrate ? L->step(m, d, flags, nsub, 4 * lds, st) : L->forward(m, d, flags, 1, 4 * lds, st);
+  const bool cone = m->opt.cone == MJLAB_CONE_ELLIPTIC;
+  hipError_t e = do_integrate ? (cone ? L->step_cone : L->step)(m, d, flags, nsub, 4 * lds, st) : (cone ? L->forward_cone : L->forward)(m, d, flags, 1, 4 * lds, st);
   if (e != hipSuccess) return fail((int)e, "k_substep launch failed");
   return 0;
 }
@@ -301,7 +302,6 @@ int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjla
   if (rc) return rc;
   if (!c || c->nsubstep < 0) return fail(-20, "control_step: bad argument");
   if (m->opt.solver == MJLAB_SOL_PGS) return fail(-20, "control_step: the control kernel carries the primal solvers only (MJLAB_SOL_PGS: separate calls)");
-  if (m->opt.cone == MJLAB_CONE_ELLIPTIC) return fail(-20, "control_step: the control kernel carries the pyramidal cone only (MJLAB_CONE_ELLIPTIC: separate calls)");
   if (c->action && (!c->action_offset || !c->action_scale)) return fail(-20, "control_step: action without offset / scale");
   if (c->key_qpos && (!c->rnd3 || !c->episode_length || !c->reset_mask)) return fail(-15, "control_step: reset arguments missing");
   if ((c->reset_qpos != nullptr) != (c->reset_qvel != nullptr)) return fail(-15, "control_step: reset_qpos and reset_qvel come together");
@@ -310,11 +310,11 @@ int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjla
   if (c->push_time_left && (!c->rnd7 || m->size.nq < 7 || m->size.nv < 6)) return fail(-17, "control_step: push needs rnd7 and a free root joint");
   if (c->forward_mode < 0 || c->forward_mode > 2) return fail(-20, "control_step: forward_mode must be 0, 1 or 2");
   hipStream_t st = (hipStream_t)stream;
-  const int a = presolve_lds_floats(m->size), b = solve_lds_floats(m->size), lds = a > b ? a : b;
+  const int a = presolve_lds_floats(m->size), b = solve_stage_lds_floats(m), lds = a > b ? a : b;
   const int fold = (m->opt.flags & MJLAB_OPT_FOLD_FORWARD) ? 1 : 0;
   const NvpLaunch* L = nvp_launch(solve_nvp(m->size.nv));
   if (!L) return fail(-3, "nv must be in [1, 64]");
-  hipError_t e = L->control(m, d, c, fold, 4 * lds, st);
+  hipError_t e = (m->opt.cone == MJLAB_CONE_ELLIPTIC ? L->control_cone : L->control)(m, d, c, fold, 4 * lds, st);
   if (e != hipSuccess) return fail((int)e, "k_control_step launch failed");
   return 0;
 }

@@ -1,4 +1,4 @@
-// stage_cone.h -- the Newton solver with ELLIPTIC friction cones (mjlab_option_t.cone = MJLAB_CONE_ELLIPTIC), one kernel per stage only.
+// stage_cone.h -- the Newton solver with ELLIPTIC friction cones (mjlab_option_t.cone = MJLAB_CONE_ELLIPTIC): kernels of their own.
 // Part of kernels.h (included there, after stage_pgs.h, by every translation unit of the library); not a stand-alone header.
 #pragma once
 
@@ -18,8 +18,8 @@
 // D_r; -D_r x_r), a friction-loss row in its linear zone has D = 0, a cone gives its three rows in the bottom zone and g^T Jc, q^T Jc in
 // the middle zone, nothing in the top zone), and ONE pass over that list forms J^T f and the 16 x 16 tiles of J^T D J on the matrix
 // cores (v_mfma_f32_16x16x4_f32, four virtual rows per instruction, the loads of 16 virtual rows in flight together).  The factor is
-// the LDS column sweep (common.h chol_factor); both line searches of the primal path (the exact one and mujoco_warp's grid).  The
-// fused launch structures and the control kernel carry the pyramid only (check_model).
+// the LDS column sweep (common.h chol_factor); both line searches of the primal path (the exact one and mujoco_warp's grid).  Launched
+// as k_solve_cone (one kernel per stage) or inside the cone variants of the fused kernels (kernels.h: k_substep_cone, k_control_step_cone).
 // LDS: H / its factor | M (dense, both triangles) | 1 / D_i of the factor | per row: jar, J search, D, force, aux (friction loss | cone: mu, f1, f2), role, virtual-row force.
 // ====================================================================================
 __host__ __device__ inline int cone_lds_floats(const mjlab_sizes_t& s) {

@@ -65,8 +65,8 @@ __host__ __device__ inline int constraint_lds_floats(const mjlab_sizes_t& s) {
 // ELL: mjlab_option_t.cone == MJLAB_CONE_ELLIPTIC -- a condim-3 contact gives 3 rows [normal, tangent 1, tangent 2] (the contact-frame
 // components of the relative acceleration) instead of the pyramid's 4 edges; only the normal row has a position and a margin, the friction
 // rows are velocity rows (aref = -b v); R_0 from the impedance and the translational weight, R_k = R_0 / impratio * friction[0]^2 /
-// friction[k-1]^2 (mj_instantiateContact / mj_makeImpedance).  A separate instantiation reached through k_constraint_cone only: the fused
-// kernels carry the pyramid (check_model).
+// friction[k-1]^2 (mj_instantiateContact / mj_makeImpedance).  A separate instantiation reached through k_constraint_cone and the cone
+// variants of the fused kernels (kernels.h); the pyramid's kernels instantiate the default.
 template <bool ELL = false>
 __device__ __forceinline__ void stage_constraint(const Model& m, const Data& d, const int w, const int lane, const int flags, float* smem) {
   const int nb = m.size.nbody, nv = m.size.nv, nq = m.size.nq, nj = m.size.njnt, ncm = m.size.nconmax, njm = m.size.njmax;

@@ -65,8 +65,9 @@ def _build_locked(out: Path, objdir: Path, hipcc: str, verbose: bool, defines: t
   dflags += os.environ.get("MJLAB_HIPCC_EXTRA", "").split()  # compiler-flag experiments
   sizes = (only_size,) if only_size else NVP_SIZES  # only_size: an experiment library for models of one padded size (A/B runs)
   units = [(CSRC / "mjlab_amd.hip", objdir / "abi.o", [])] + [
-    (CSRC / "nvp_inst.hip", objdir / f"nvp_{n}_{part}.o", [f"-DMJLAB_NVP={n}", f"-DMJLAB_NVP_PART={part}"]) for n in reversed(sizes) for part in (1, 0)
-  ]  # largest first: the 64-dof instantiations are the critical path
+    (CSRC / "nvp_inst.hip", objdir / f"nvp_{n}_{part}.o", [f"-DMJLAB_NVP={n}", f"-DMJLAB_NVP_PART={part}"]) for n in reversed(sizes) for part in (1, 0, 2)
+  ]  # largest first: the 64-dof instantiations are the critical path; part 2 = the elliptic-cone kernels, a unit of their own so that
+  # the inliner sees the pyramid's kernels (parts 0 and 1: the measured path) among exactly the callers they always had
 
   def compile_one(unit):
     src, obj, extra = unit

@@ -222,8 +222,9 @@ class Simulation:
     ext = SimulationCfg()
     opt = lambda name: getattr(cfg, name, getattr(ext, name))  # noqa: E731
     # the dual solver (MujocoCfg.solver = "pgs") exists as a stage kernel only: the fused launch structures carry the primal solvers
-    # ... and so do elliptic friction cones (MujocoCfg.cone = "elliptic": csrc/stage_cone.h)
-    self.fuse = "stage" if (model.opt.solver == SOL_PGS or model.opt.cone == CONE_ELLIPTIC) else opt("fuse")
+    # ... elliptic friction cones (MujocoCfg.cone = "elliptic": csrc/stage_cone.h) have their own variants of the per-stage and the "step"
+    # structures (and of the control kernel), not of "presolve"
+    self.fuse = "stage" if (model.opt.solver == SOL_PGS or (model.opt.cone == CONE_ELLIPTIC and opt("fuse") == "presolve")) else opt("fuse")
     self._m.opt.ls_parallel_min_step = float(opt("ls_parallel_min_step"))
     self._m.opt.flags = ((self._m.opt.flags & _abi.OPT_FRICTIONLOSS) | (_abi.OPT_FOLD_FORWARD if opt("fold_forward") else 0)
                          | (_abi.OPT_LITERAL_TERMINATION if opt("literal_termination") else 0)

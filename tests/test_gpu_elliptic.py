@@ -1,7 +1,7 @@
 """Elliptic friction cones on the device (csrc/stage_cone.h + the ELL instantiation of the constraint stage):
-MujocoCfg(cone="elliptic") (reference sim/sim.py:49,52) as stage kernels, against the CPU restatement (oracle/mjoracle.c), which
+MujocoCfg(cone="elliptic") (reference sim/sim.py:49,52) as stage kernels and their fused variants, against the CPU restatement (oracle/mjoracle.c), which
 tests/test_oracle_elliptic.py holds to Coulomb's law, the optimality conditions and cone membership.  The cone model is restated from
-MuJoCo's documentation and UNPINNED on both sides; Newton only (the dual solver and CG keep the pyramid), fused launches excluded."""
+MuJoCo's documentation and UNPINNED on both sides; Newton only (the dual solver and CG keep the pyramid)."""
 
 import copy
 import sys
@@ -51,8 +51,7 @@ def test_elliptic_forward_and_rollout_track_the_restatement(name, lsp):
     flags = _abi.OPT_FRICTIONLOSS
   nworld, nv = 16, model.nv
   qpos, qvel, ctrl = golden_inputs(model, nworld, 43)
-  sim = Simulation(nworld, SimulationCfg(njmax=300, use_graph=False, ls_parallel=lsp), model, "cuda:0")
-  assert sim.fuse == "stage"
+  sim = Simulation(nworld, SimulationCfg(njmax=300, use_graph=False, ls_parallel=lsp, fuse="stage"), model, "cuda:0")
   ora = OracleSim(model, nworld, njmax=300, precision="f64", flags=flags, ls_parallel=lsp)
   for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
     getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
@@ -154,19 +153,52 @@ def test_elliptic_slab_slides_by_coulombs_law_on_the_device():
   assert np.allclose(along, want, rtol=0.06) and (np.abs(across) < 0.02 * want).all()
 
 
+def test_elliptic_launch_structures_are_bit_identical():
+  """The cone variants of the fused kernels (kernels.h: k_substep_cone, k_control_step_cone) run the same stage bodies as the one-kernel-
+  per-stage pipeline: every output bit-identical over a rollout with task events, resets, forward() folds and a masked forward -- the
+  pyramid's test of the same name (tests/test_gpu_fullsize.py), with elliptic cones."""
+  import torch
+
+  from mjlab_amd import mjcf, robots
+  from mjlab_amd.rollout import VELOCITY_TASK_EVENTS, PhysicsRollout
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = copy.deepcopy(robots.load_model("g1_velocity_flat"))
+  model.opt.cone = mjcf.CONE_ELLIPTIC
+  fields = ("qpos", "qvel", "qacc", "qacc_warmstart", "qfrc_constraint", "efc_force", "efc_J", "efc_aref", "efc_D", "efc_type", "nefc", "ncon", "xpos", "cvel", "qM",
+            "sensordata", "qfrc_smooth", "contact_pos", "solver_niter")
+  out = {}
+  variants = (("stage", 1), ("step", 1), ("stage", 4), ("step", 4), ("step", 0))  # (launch structure, substeps per call; 0 = one mjlab_control_step launch)
+  for fuse, nsub in variants:
+    s = Simulation(256, SimulationCfg(njmax=300, fuse=fuse), model, "cuda:0")
+    assert s.fuse == fuse
+    roll = PhysicsRollout(s, action_scale=0.25, seed=9, min_height=0.3, substeps_per_call=max(nsub, 1), control_kernel=nsub == 0, **VELOCITY_TASK_EVENTS["g1"])
+    resets = 0
+    for k in range(12):
+      resets += int(roll.step(roll.random_action()).sum())
+    s.forward(torch.arange(256, device="cuda") % 3 == 0)
+    s.step()
+    torch.cuda.synchronize()
+    out[(fuse, nsub)] = {f: getattr(s.data, f).clone() for f in fields}
+    assert bool(torch.isfinite(s.data.qpos).all()) and int((s.data.efc_type == 7).sum()) >= 3 * 256 // 2
+  for v in variants[1:]:
+    for f in fields:
+      assert torch.equal(out[variants[0]][f], out[v][f]), (v, f)
+
+
 def test_elliptic_is_refused_where_it_is_not_carried():
-  """The fused launches, the control kernel and the other solvers carry the pyramid only: asked for elliptic cones they say so."""
+  """The "presolve" launch structure and the other solvers carry the pyramid only: asked for elliptic cones they say so."""
   from mjlab_amd import _abi, mjcf
   from mjlab_amd.sim import Simulation, SimulationCfg, check_supported
 
   model = copy.deepcopy(models()["g1_velocity_flat"])
   model.opt.cone = mjcf.CONE_ELLIPTIC
-  sim = Simulation(4, SimulationCfg(njmax=300, use_graph=False, fuse="step"), model, "cuda:0")
-  assert sim.fuse == "stage"  # (the configuration's "step" gives way, as it does for the dual solver)
-  sim._m.opt.flags |= _abi.OPT_FUSE_STEP
+  sim = Simulation(4, SimulationCfg(njmax=300, use_graph=False, fuse="presolve"), model, "cuda:0")
+  assert sim.fuse == "stage"  # (the configuration's "presolve" gives way, as every fused structure does for the dual solver)
+  sim._m.opt.flags |= _abi.OPT_FUSE_PRESOLVE
   with pytest.raises(RuntimeError, match="ELLIPTIC"):
     sim.forward()
-  sim._m.opt.flags &= ~_abi.OPT_FUSE_STEP
+  sim._m.opt.flags &= ~_abi.OPT_FUSE_PRESOLVE
   sim.forward()
   cg = copy.deepcopy(model)
   cg.opt.solver = mjcf.SOL_CG

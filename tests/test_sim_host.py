@@ -17,7 +17,7 @@ def test_supported_models_pass():
   pgs.opt.solver = 0  # mjSOL_PGS: the dual solver exists since round 3 (one kernel per stage: stage_pgs.h)
   check_supported(pgs)
   ell = copy.deepcopy(robots.load_model("g1_velocity_flat"))
-  ell.opt.cone = 1  # mjCONE_ELLIPTIC: since round 5, Newton only, one kernel per stage (stage_cone.h)
+  ell.opt.cone = 1  # mjCONE_ELLIPTIC: since round 5, Newton only, kernels of its own (stage_cone.h)
   check_supported(ell)
   for m in (robots.box_model(), robots.mixed_model(), robots.pendulum_model()):
     check_supported(m)

@@ -53,7 +53,7 @@ if __name__ == "__main__":
     print(run(mjcf.CONE_ELLIPTIC if sys.argv[1] == "elliptic" else mjcf.CONE_PYRAMIDAL, True, "stage"))
     sys.exit(0)
   print("G1 velocity-flat, 4096 worlds, ms per physics step (mean Newton iterations, mean rows) -- falling robots, golden_inputs seed 5")
-  for name, cone, fuse in (("pyramid, fused step kernel", mjcf.CONE_PYRAMIDAL, "step"), ("pyramid, stage kernels", mjcf.CONE_PYRAMIDAL, "stage"), ("elliptic, stage kernels", mjcf.CONE_ELLIPTIC, "stage")):
+  for name, cone, fuse in (("pyramid, fused step kernel", mjcf.CONE_PYRAMIDAL, "step"), ("pyramid, stage kernels", mjcf.CONE_PYRAMIDAL, "stage"), ("elliptic, stage kernels", mjcf.CONE_ELLIPTIC, "stage"), ("elliptic, fused step kernel", mjcf.CONE_ELLIPTIC, "step")):
     for lsp in (True, False):
       ms, it, rows = run(cone, lsp, fuse)
       print(f"{name:28s} ls_parallel={lsp!s:5s}: {ms:7.3f} ms  ({it:.2f} iterations, {rows:.1f} rows)")
