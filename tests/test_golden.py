@@ -13,7 +13,8 @@ from make_golden import OUT_FIELDS, models  # noqa: E402
 
 from oracle.oracle import OracleSim  # noqa: E402
 
-NAMES = ["g1_velocity_flat", "g1_tracking_flat", "go1_velocity_flat", "g1_velocity_rough", "go1_velocity_rough", "mixed", "box"]
+NAMES = ["g1_velocity_flat", "g1_tracking_flat", "go1_velocity_flat", "g1_velocity_rough", "go1_velocity_rough", "mixed", "box",
+         "g1_velocity_flat_elliptic", "mixed_elliptic"]
 
 
 def _rel(a, b):

@@ -49,13 +49,25 @@ def models():
   out = {n: robots.load_model(n) for n in robots.SCENES}
   out["mixed"] = robots.mixed_model()
   out["box"] = robots.box_model()
+  # elliptic friction cones (MujocoCfg.cone = "elliptic"; round 5): the G1 as the velocity task builds it, and the mixed scene with impratio 2
+  import copy
+
+  from mjlab_amd.mjcf import CONE_ELLIPTIC
+
+  for base, name, impratio in (("g1_velocity_flat", "g1_velocity_flat_elliptic", 1.0), ("mixed", "mixed_elliptic", 2.0)):
+    m = copy.deepcopy(out[base])
+    m.opt.cone, m.opt.impratio = CONE_ELLIPTIC, impratio
+    out[name] = m
   return out
 
 
 def main():
   gold = ROOT / "tests" / "golden"
   gold.mkdir(exist_ok=True)
+  only = sys.argv[1:]  # (names: regenerate these fixtures only)
   for name, model in models().items():
+    if only and name not in only:
+      continue
     nworld, nstep = 4, 5
     qpos, qvel, ctrl = golden_inputs(model, nworld, seed=7)
     s = OracleSim(model, nworld, njmax=300, precision="f64")
