@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64, MJLAB_WPE) void k_control_step(const Model m_, 
 // constraint stage's ELL instantiation and, for the solve, the cone solver followed by the pyramid path's integrator with its solve
 // switched off (the hand-over of qacc / qfrc_constraint through the public arrays, as between any two stages).  Kernels of their own --
 // the bodies are spelled out a second time rather than shared through a template parameter -- so that the pyramid's kernels, the
-// measured path, are the code they were instruction for instruction; 2 waves per SIMD like k_solve_cone.
+// measured path, are the code they were instruction for instruction.
 // ====================================================================================
 template <int NVP>
 __device__ __forceinline__ void fused_solve_cone(const int wsel_, const bool integrate, const int flags, float* smem) {

@@ -20,26 +20,55 @@
 // cores (v_mfma_f32_16x16x4_f32, four virtual rows per instruction, the loads of 16 virtual rows in flight together).  The factor is
 // the LDS column sweep (common.h chol_factor); both line searches of the primal path (the exact one and mujoco_warp's grid).  Launched
 // as k_solve_cone (one kernel per stage) or inside the cone variants of the fused kernels (kernels.h: k_substep_cone, k_control_step_cone).
-// LDS: H / its factor | M (dense, both triangles) | 1 / D_i of the factor | per row: jar, J search, D, force, aux (friction loss | cone: mu, f1, f2), role, virtual-row force.
+//
+// LDS, 10 KB per wave like the pyramid's solve (16 waves per CU: one round for 4096 worlds):
+//   H / its factor | 1 / D_i of the factor | friction loss of the first nf rows | role bits (2 per row) | M packed | jar, J search, D
+// for as many rows as fit (cone_lds_rows: 168 for the G1); a world with more rows runs the layout without M (all njmax rows, M read from
+// global memory: the BIG instantiation, as in stage_solve.h).  A cone's three D slots hold (-D_0, friction_1, friction_2): D_1 = D_0
+// impratio and D_2 = D_1 friction_2^2 / friction_1^2 follow from them (mj_makeImpedance's rule, without its MINVAL clamp), mu =
+// friction_1 / sqrt(impratio).  The virtual rows are written 64 rows at a time (<= 192 per trip) into the factor's block, which is dead
+// between the solve for the search direction and the next H; so are the grid search's cone costs at step 0.
 // ====================================================================================
-__host__ __device__ inline int cone_lds_floats(const mjlab_sizes_t& s) {
+// the factor's block also holds, while the factor is dead, the virtual rows of one 64-row trip (6 arrays of <= 192) or one value per row
+__host__ __device__ constexpr int cone_hblk(int nvp_ld, int njmax) { return nvp_ld > 6 * 192 ? (nvp_ld > njmax ? nvp_ld : njmax) : (6 * 192 > njmax ? 6 * 192 : njmax); }
+__host__ __device__ inline int cone_lds_fixed_floats(const mjlab_sizes_t& s) {  // everything but M and the per-row arrays
   const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
-  // (the virtual rows' coefficients and weights -- 4 njmax floats -- live in the dead factor's block where they fit)
-  return 2 * nvp * ld + nvp + 7 * s.njmax + (nvp * ld >= 4 * s.njmax ? 0 : 4 * s.njmax);
+  return cone_hblk(nvp * ld, s.njmax) + 2 * nvp + (s.njmax + 15) / 16;
+}
+__host__ __device__ inline int cone_lds_rows(const mjlab_sizes_t& s) {  // rows next to M in 10 KB; -1: no such layout (every world without M)
+  const int nvp = solve_nvp(s.nv);
+  int rows = (2560 - cone_lds_fixed_floats(s) - nvp * (nvp + 1) / 2) / 3;
+  rows = rows > 0 ? rows & ~3 : 0;
+  if (rows >= s.njmax) return s.njmax;
+  return rows >= 32 ? rows : -1;
+}
+__host__ __device__ inline int cone_lds_floats(const mjlab_sizes_t& s) {
+  const int nvp = solve_nvp(s.nv), rows = cone_lds_rows(s);
+  const int all = cone_lds_fixed_floats(s) + 3 * s.njmax, with_m = rows < 0 ? 0 : cone_lds_fixed_floats(s) + nvp * (nvp + 1) / 2 + 3 * rows;
+  return all > with_m ? all : with_m;
 }
 
 enum { CONE_ROLE_ROW = 0, CONE_ROLE_START = 1, CONE_ROLE_MEMBER = 2 };
 
 struct ConeCtx {
   const float* J;
-  float *s_jar, *s_jv, *s_D, *s_force, *s_aux;
-  int* s_role;
-  int* s_vr;                              // virtual rows: base row ...
+  float *s_jar, *s_jv, *s_D, *s_fl;
+  const unsigned* s_role;
+  int* s_vr;                                   // virtual rows: base row ...
   float *s_vc0, *s_vc1, *s_vc2, *s_vD, *s_vf;  // ... coefficients of rows r, r + 1, r + 2, weight, force
+  float impratio, mu_scale;                    // (clamped) impratio, 1 / sqrt(impratio)
   int nv, nefc, nf, lane;
   float quad_gauss[3];
   int ls_iter;
 };
+__device__ __forceinline__ int cone_role(const ConeCtx& c, int r) { return (c.s_role[r >> 4] >> (2 * (r & 15))) & 3; }
+// D_k and (mu, friction_1, friction_2) of the cone whose first row is r
+__device__ __forceinline__ void cone_params(const ConeCtx& c, int r, float (&D)[3], float (&fr)[3]) {
+  D[0] = -c.s_D[r]; fr[1] = c.s_D[r + 1]; fr[2] = c.s_D[r + 2];
+  fr[0] = fr[1] * c.mu_scale;
+  D[1] = D[0] * c.impratio;
+  D[2] = D[1] * (fr[2] * fr[2]) / (fr[1] * fr[1]);
+}
 
 // one cone at residuals x: zone (0 top, 1 bottom, 2 middle), cost, force = -d cost / dx, and for the middle zone the two rank-one
 // terms of the Hessian (Da g g^T + Db q q^T).  D = the three rows' efc_D, fr = (mu, friction[0], friction[1]).
@@ -62,12 +91,20 @@ __device__ __forceinline__ int cone_block(const float (&x)[3], const float (&D)[
   Da = Dm; Db = Dm * (-phi) * mu * it;
   return 2;
 }
+// the cone whose first row is r, at residuals xs[r .. r + 2] + alpha dx[r .. r + 2] (dx may be null)
+__device__ __forceinline__ int cone_at(const ConeCtx& c, int r, const float* xs, const float* dx, float alpha, float (&D)[3], float& cost, float (&force)[3],
+                                       float (&g)[3], float (&q)[3], float& Da, float& Db) {
+  float fr[3], x[3];
+  cone_params(c, r, D, fr);
+  for (int k = 0; k < 3; ++k) x[k] = dx ? fmaf(alpha, dx[r + k], xs[r + k]) : xs[r + k];
+  return cone_block(x, D, fr, cost, force, g, q, Da, Db);
+}
 
 // cost / force of the scalar row r at residual x (mj_constraintUpdate); returns true in the quadratic zone
 __device__ __forceinline__ bool cone_scalar_row(const ConeCtx& c, int r, float x, float& cost, float& force) {
   const float Dr = c.s_D[r];
   if (r < c.nf) {
-    const float f = c.s_aux[r], rf = f / Dr;
+    const float f = c.s_fl[r], rf = f / Dr;
     if (x <= -rf) { force = f; cost = f * (-0.5f * rf - x); return false; }
     if (x >= rf) { force = -f; cost = f * (-0.5f * rf + x); return false; }
     force = -Dr * x; cost = 0.5f * Dr * x * x; return true;
@@ -80,13 +117,12 @@ __device__ __forceinline__ bool cone_scalar_row(const ConeCtx& c, int r, float x
 __device__ __forceinline__ float cone_rows_cost(const ConeCtx& c, const float* xs) {
   float cost = 0.f;
   for (int r = c.lane; r < c.nefc; r += 64) {
-    const int role = c.s_role[r];
+    const int role = cone_role(c, r);
     if (role == CONE_ROLE_MEMBER) continue;
     float rc;
     if (role == CONE_ROLE_START) {
-      const float x[3] = {xs[r], xs[r + 1], xs[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
-      float fo[3], g[3], q[3], Da, Db;
-      cone_block(x, D, fr, rc, fo, g, q, Da, Db);
+      float D[3], fo[3], g[3], q[3], Da, Db;
+      cone_at(c, r, xs, nullptr, 0.f, D, rc, fo, g, q, Da, Db);
     } else {
       float fo;
       cone_scalar_row(c, r, xs[r], rc, fo);
@@ -100,14 +136,12 @@ __device__ __forceinline__ float cone_rows_cost(const ConeCtx& c, const float* x
 __device__ __forceinline__ void cone_ls_eval(ConeCtx& c, LsPnt* p, float alpha) {
   float cost = 0.f, d0 = 0.f, d1 = 0.f;
   for (int r = c.lane; r < c.nefc; r += 64) {
-    const int role = c.s_role[r];
+    const int role = cone_role(c, r);
     if (role == CONE_ROLE_MEMBER) continue;
     if (role == CONE_ROLE_START) {
       const float jv[3] = {c.s_jv[r], c.s_jv[r + 1], c.s_jv[r + 2]};
-      const float x[3] = {fmaf(alpha, jv[0], c.s_jar[r]), fmaf(alpha, jv[1], c.s_jar[r + 1]), fmaf(alpha, jv[2], c.s_jar[r + 2])};
-      const float D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
-      float rc, fo[3], g[3], q[3], Da, Db;
-      const int zone = cone_block(x, D, fr, rc, fo, g, q, Da, Db);
+      float D[3], rc, fo[3], g[3], q[3], Da, Db;
+      const int zone = cone_at(c, r, c.s_jar, c.s_jv, alpha, D, rc, fo, g, q, Da, Db);
       cost += rc;
       d0 -= fo[0] * jv[0] + fo[1] * jv[1] + fo[2] * jv[2];
       if (zone == 1) d1 += D[0] * jv[0] * jv[0] + D[1] * jv[1] * jv[1] + D[2] * jv[2] * jv[2];
@@ -119,7 +153,7 @@ __device__ __forceinline__ void cone_ls_eval(ConeCtx& c, LsPnt* p, float alpha) 
     }
     const float j0 = c.s_jar[r], jv = c.s_jv[r], Dr = c.s_D[r], x = fmaf(alpha, jv, j0);
     if (r < c.nf) {
-      const float f = c.s_aux[r], rf = f / Dr;
+      const float f = c.s_fl[r], rf = f / Dr;
       if (x <= -rf) { cost += f * (-0.5f * rf - j0) - alpha * f * jv; d0 -= f * jv; continue; }
       if (x >= rf) { cost += f * (-0.5f * rf + j0) + alpha * f * jv; d0 += f * jv; continue; }
     }
@@ -144,19 +178,17 @@ __device__ __forceinline__ void cone_ls_eval(ConeCtx& c, LsPnt* p, float alpha) 
 __device__ __forceinline__ float cone_cost_at(const ConeCtx& c, float alpha, bool literal, int g, int G, const float* s_c0) {
   float acc = 0.f;
   for (int r = g; r < c.nefc; r += G) {
-    const int role = c.s_role[r];
+    const int role = cone_role(c, r);
     if (role == CONE_ROLE_MEMBER) continue;
     if (role == CONE_ROLE_START) {
-      const float x[3] = {fmaf(alpha, c.s_jv[r], c.s_jar[r]), fmaf(alpha, c.s_jv[r + 1], c.s_jar[r + 1]), fmaf(alpha, c.s_jv[r + 2], c.s_jar[r + 2])};
-      const float D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
-      float ca, fo[3], gg[3], q[3], Da, Db;
-      cone_block(x, D, fr, ca, fo, gg, q, Da, Db);
+      float D[3], ca, fo[3], gg[3], q[3], Da, Db;
+      cone_at(c, r, c.s_jar, c.s_jv, alpha, D, ca, fo, gg, q, Da, Db);
       acc += literal ? 2.f * ca : 2.f * (ca - s_c0[r]);
       continue;
     }
     const float j0 = c.s_jar[r], Dr = c.s_D[r], x = fmaf(alpha, c.s_jv[r], j0);
     if (r < c.nf) {
-      const float fl = c.s_aux[r], rf = fl / Dr, ax = fabsf(x), a0 = fabsf(j0);
+      const float fl = c.s_fl[r], rf = fl / Dr, ax = fabsf(x), a0 = fabsf(j0);
       const float ha = ax >= rf ? 2.f * fl * (ax - 0.5f * rf) : Dr * x * x;
       const float h0 = a0 >= rf ? 2.f * fl * (a0 - 0.5f * rf) : Dr * j0 * j0;
       acc += literal ? ha : ha - h0;
@@ -179,7 +211,7 @@ __device__ __forceinline__ int cone_update_bracket(ConeCtx& c, LsPnt* p, const L
 }
 
 // MuJoCo's exact search (mj_solPrimal's PrimalSearch), all values wave-uniform
-__device__ float cone_line_search(ConeCtx& c, float gtol, float dn1, float dn2, int lsmax) {
+__device__ __forceinline__ float cone_line_search(ConeCtx& c, float gtol, float dn1, float dn2, int lsmax) {
 #define CONE_LS_TOL(a_) fmaxf(gtol, dn1 + fabsf(a_) * dn2)
   LsPnt p0, p1, p2, pmid, p1next, p2next;
   cone_ls_eval(c, &p0, 0.f);
@@ -216,82 +248,55 @@ __device__ float cone_line_search(ConeCtx& c, float gtol, float dn1, float dn2, 
 #undef CONE_LS_TOL
 }
 
-// y_i = sum_j M[i][j] x_j, lane i owning x_i / y_i; M dense in LDS (both triangles, zero beyond nv)
-template <int NVP>
-__device__ __forceinline__ float cone_mul_M(const float* s_M, int lane, float x) {
-  constexpr int ld = CholCfg<NVP>::LD;
-  const lds_f32* row = (const lds_f32*)s_M + (lane < NVP ? lane : 0) * ld;
-  float y = 0.f;
-#pragma unroll
-  for (int c4 = 0; c4 < NVP / 4; ++c4) {
-    const f32x4 v = *(const lds_f32x4*)(row + 4 * c4);
-    y = fmaf(v.x, lane_bcast(x, 4 * c4), y); y = fmaf(v.y, lane_bcast(x, 4 * c4 + 1), y);
-    y = fmaf(v.z, lane_bcast(x, 4 * c4 + 2), y); y = fmaf(v.w, lane_bcast(x, 4 * c4 + 3), y);
-  }
-  return lane < NVP ? y : 0.f;
-}
-
-// Constraint update at the residuals s_jar (lanes = rows): forces to s_force, the virtual-row list (header), the rows' cost.
-__device__ __forceinline__ float cone_update_rows(const ConeCtx& c, int* nvirt) {
+// Constraint update of rows r0 .. r0 + 63 at the residuals s_jar (lanes = rows): their virtual rows (header) into the list, which
+// starts empty; returns this lane's row's cost (the caller sums) and the length of the list.
+__device__ __forceinline__ float cone_update_trip(const ConeCtx& c, int r0, int* nvirt) {
   float cost = 0.f;
-  int base = 0;
-  for (int r0 = 0; r0 < c.nefc; r0 += 64) {  // wave-uniform trips
-    const int r = r0 + c.lane;
-    int n = 0;
-    float e0[3] = {0.f, 0.f, 0.f}, e1[3] = {0.f, 0.f, 0.f}, e2[3] = {0.f, 0.f, 0.f}, eD[3] = {0.f, 0.f, 0.f}, ef[3] = {0.f, 0.f, 0.f};
-    if (r < c.nefc) {
-      const int role = c.s_role[r];
-      if (role == CONE_ROLE_START) {
-        const float x[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
-        float rc, fo[3], g[3], q[3], Da, Db;
-        const int zone = cone_block(x, D, fr, rc, fo, g, q, Da, Db);
-        cost += rc;
-        c.s_force[r] = fo[0]; c.s_force[r + 1] = fo[1]; c.s_force[r + 2] = fo[2];
-        if (zone == 1) {
-          n = 3;
-          e0[0] = 1.f; e1[1] = 1.f; e2[2] = 1.f;
+  const int r = r0 + c.lane;
+  int n = 0;
+  float e0[3] = {0.f, 0.f, 0.f}, e1[3] = {0.f, 0.f, 0.f}, e2[3] = {0.f, 0.f, 0.f}, eD[3] = {0.f, 0.f, 0.f}, ef[3] = {0.f, 0.f, 0.f};
+  if (r < c.nefc) {
+    const int role = cone_role(c, r);
+    if (role == CONE_ROLE_START) {
+      float D[3], fo[3], g[3], q[3], Da, Db;
+      const int zone = cone_at(c, r, c.s_jar, nullptr, 0.f, D, cost, fo, g, q, Da, Db);
+      if (zone == 1) {
+        n = 3;
+        e0[0] = 1.f; e1[1] = 1.f; e2[2] = 1.f;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) { eD[k] = D[k]; ef[k] = fo[k]; }
-        } else if (zone == 2) {
-          n = 2;
-          e0[0] = g[0]; e1[0] = g[1]; e2[0] = g[2]; eD[0] = Da; ef[0] = fo[0] / fr[0];  // (-Dm phi: force_0 = -Dm phi mu)
-          e1[1] = q[1]; e2[1] = q[2]; eD[1] = Db;
-        }
-      } else if (role == CONE_ROLE_ROW) {
-        float rc, fo;
-        const bool quad = cone_scalar_row(c, r, c.s_jar[r], rc, fo);
-        cost += rc;
-        c.s_force[r] = fo;
-        if (fo != 0.f || quad) { n = 1; e0[0] = 1.f; eD[0] = quad ? c.s_D[r] : 0.f; ef[0] = fo; }
+        for (int k = 0; k < 3; ++k) { eD[k] = D[k]; ef[k] = fo[k]; }
+      } else if (zone == 2) {
+        n = 2;
+        e0[0] = g[0]; e1[0] = g[1]; e2[0] = g[2]; eD[0] = Da; ef[0] = fo[0] / g[0];  // (-Dm phi: force_0 = -Dm phi mu, g_0 = mu)
+        e1[1] = q[1]; e2[1] = q[2]; eD[1] = Db;
       }
+    } else if (role == CONE_ROLE_ROW) {
+      float fo;
+      const bool quad = cone_scalar_row(c, r, c.s_jar[r], cost, fo);
+      if (fo != 0.f || quad) { n = 1; e0[0] = 1.f; eD[0] = quad ? c.s_D[r] : 0.f; ef[0] = fo; }
     }
-    int total;
-    const int off = base + wave_excl_scan(n, c.lane, &total);
-#pragma unroll
-    for (int k = 0; k < 3; ++k)  // (static indices: the entries stay in registers)
-      if (k < n) { c.s_vr[off + k] = r; c.s_vc0[off + k] = e0[k]; c.s_vc1[off + k] = e1[k]; c.s_vc2[off + k] = e2[k]; c.s_vD[off + k] = eD[k]; c.s_vf[off + k] = ef[k]; }
-    base += total;
   }
-  *nvirt = base;
-  return wave_sum(cost);
+  int total;
+  const int off = wave_excl_scan(n, c.lane, &total);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)  // (static indices: the entries stay in registers)
+    if (k < n) { c.s_vr[off + k] = r; c.s_vc0[off + k] = e0[k]; c.s_vc1[off + k] = e1[k]; c.s_vc2[off + k] = e2[k]; c.s_vD[off + k] = eD[k]; c.s_vf[off + k] = ef[k]; }
+  *nvirt = total;
+  return cost;
 }
 
-// ONE pass over the virtual rows: this lane's (dof's) J^T f, and H = M + sum_k D_k a_k a_k^T laid out in LDS (lower triangle) for the factor.
-// Lanes form 4 virtual rows x 16 columns; the tiles live in registers inside this function only.
+// The list's share of J^T f (per 16-column block, this lane's column of it) and of the tiles of J^T D J.  Lanes form 4 virtual rows x 16 columns.
+#ifndef CONE_JU
+#define CONE_JU 2  // 4-row groups per trip of the accumulation (three loads per element: 18 in flight per lane)
+#endif
 template <int NVP>
-__device__ __forceinline__ float cone_accum_store(const ConeCtx& c, int nvirt, float* s_H, const float* s_M) {
-  constexpr int NB = CholCfg<NVP>::NB, NT = NB * (NB + 1) / 2, ld = CholCfg<NVP>::LD;
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float jtf[NB];
-#pragma unroll
-  for (int cb = 0; cb < NB; ++cb) jtf[cb] = 0.f;
+__device__ __forceinline__ void cone_accum(const ConeCtx& c, int nvirt, f32x4 (&acc)[CholCfg<NVP>::NB * (CholCfg<NVP>::NB + 1) / 2], float (&jtf)[CholCfg<NVP>::NB]) {
+  constexpr int NB = CholCfg<NVP>::NB;
   const int sub = c.lane >> 4, col = launder(c.lane & 15);
-  for (int k0 = 0; k0 < nvirt; k0 += 4 * JU) {
-    float x[JU][NB], dv[JU], fv[JU];
+  for (int k0 = 0; k0 < nvirt; k0 += 4 * CONE_JU) {
+    float x[CONE_JU][NB], dv[CONE_JU], fv[CONE_JU];
 #pragma unroll
-    for (int u = 0; u < JU; ++u) {
+    for (int u = 0; u < CONE_JU; ++u) {
       const int k = k0 + 4 * u + sub;
       const bool valid = k < nvirt;
       const int kk = valid ? k : 0;
@@ -310,7 +315,7 @@ __device__ __forceinline__ float cone_accum_store(const ConeCtx& c, int nvirt, f
       }
     }
 #pragma unroll
-    for (int u = 0; u < JU; ++u) {
+    for (int u = 0; u < CONE_JU; ++u) {
       float a[NB];
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
@@ -331,26 +336,6 @@ __device__ __forceinline__ float cone_accum_store(const ConeCtx& c, int nvirt, f
         }
     }
   }
-  __syncthreads();
-  {
-    int t = 0;
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int Jb = 0; Jb <= I; ++Jb) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
-          if (row < c.nv && cc <= row) s_H[row * ld + cc] = acc[t][k] + s_M[row * ld + cc];
-        }
-        ++t;
-      }
-  }
-  chol_pad_rows<NVP>(s_H, c.nv, c.lane);
-  chol_pad_diag<NVP>(s_H, c.nv, c.lane);
-#pragma unroll
-  for (int cb = 0; cb < NB; ++cb) { jtf[cb] += __shfl_xor(jtf[cb], 16); jtf[cb] += __shfl_xor(jtf[cb], 32); }
-  return pick16<NB>(jtf, c.lane);
 }
 
 // out[r] = sum_i J[r][i] x_i (and out2 for y) through the pyramid path's pass (stage_solve.h jac_mul: 4 rows x 16 columns per trip of the lanes)
@@ -366,34 +351,31 @@ __device__ __forceinline__ void cone_jac_mul(const ConeCtx& c, float x, float y,
   jac_mul<NVP, true>(sc, x16, y16, out, TWO ? out2 : out, (int*)c.s_vf);  // (masks written, never used: scratch)
 #elif MJLAB_JSKIP == 1
   int all = (1 << NB) - 1;
-  jac_mul<NVP, true>(sc, x16, y16, out, TWO ? out2 : out, all);  // (the block masks are the pyramid path's: every block loaded here)
+  jac_mul<NVP, true>(sc, x16, y16, out, TWO ? out2 : out, all);
 #else
   jac_mul<NVP, TWO>(sc, x16, y16, out, out2);
 #endif
 }
 
-template <int NVP>
-__device__ void stage_solve_cone(const Model& m, const Data& d, const int w, const int lane, float* smem) {
-  constexpr int ld = CholCfg<NVP>::LD;
+// BIG: this world has more rows than fit next to M: all njmax rows in LDS instead, M from global memory
+template <int NVP, bool BIG>
+__device__ __forceinline__ void stage_solve_cone_impl(const Model& m, const Data& d, const int w, const int lane, float* smem) {
+  constexpr int ld = CholCfg<NVP>::LD, NB = CholCfg<NVP>::NB, NT = NB * (NB + 1) / 2;
   const int nv = m.size.nv, njm = m.size.njmax, ncm = m.size.nconmax;
   float* s_H = smem;
-  float* s_M = s_H + NVP * ld;
-  float* s_invd = s_M + NVP * ld;
+  float* s_invd = s_H + cone_hblk(NVP * ld, njm);
   ConeCtx c;
-  c.s_jar = s_invd + NVP;
-  c.s_jv = c.s_jar + njm;
-  c.s_D = c.s_jv + njm;
-  c.s_force = c.s_D + njm;
-  c.s_aux = c.s_force + njm;
-  c.s_role = (int*)(c.s_aux + njm);
-  // the virtual rows live inside one constraint update: their base rows in the J search array (dead between two line searches), their
-  // coefficients and weights in the factor's block (dead until the update lays the next H out there, after its last read of the list)
-  c.s_vf = (float*)(c.s_role + njm);
-  c.s_vr = (int*)c.s_jv;
-  c.s_vc0 = (NVP * ld >= 4 * njm) ? s_H : c.s_vf + njm;
-  c.s_vc1 = c.s_vc0 + njm;
-  c.s_vc2 = c.s_vc1 + njm;
-  c.s_vD = c.s_vc2 + njm;
+  c.s_fl = s_invd + NVP;
+  unsigned* s_role = (unsigned*)(c.s_fl + NVP);
+  c.s_role = s_role;
+  float* s_M = (float*)(s_role + (njm + 15) / 16);  // (!BIG only)
+  const int nrl = BIG ? njm : cone_lds_rows(m.size);
+  c.s_jar = s_M + (BIG ? 0 : NVP * (NVP + 1) / 2);
+  c.s_jv = c.s_jar + nrl;
+  c.s_D = c.s_jv + nrl;
+  // the virtual rows of one 64-row trip live in the factor's block while the factor is dead
+  c.s_vr = (int*)s_H;
+  c.s_vc0 = s_H + 192; c.s_vc1 = s_H + 2 * 192; c.s_vc2 = s_H + 3 * 192; c.s_vD = s_H + 4 * 192; c.s_vf = s_H + 5 * 192;
   const bool own = lane < nv;
   const size_t wv = (size_t)w * nv + lane, wr = (size_t)w * njm;
   const float* J = d.efc_J + wr * nv;
@@ -401,14 +383,21 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   const int nefc = d.nefc[w];
   c.J = J; c.nv = nv; c.nefc = nefc; c.lane = lane;
   c.nf = (m.opt.flags & MJLAB_OPT_FRICTIONLOSS) ? d.nf[w] : 0;
+  const float ir = (float)m.opt.impratio;
+  c.impratio = ir > MINVAL ? ir : MINVAL;
+  c.mu_scale = 1.f / sqrtf(c.impratio);
   const float qs = own ? d.qfrc_smooth[wv] : 0.f;
   const bool ws_at_advance = (m.opt.flags & MJLAB_OPT_WARMSTART_AT_ADVANCE) != 0;
   PROF_INIT();
-  // M: the lower triangle for the factor, a full dense copy (zero beyond nv) for the products; mj_factorM + qacc_smooth = M^-1 qfrc_smooth
-  for (int k = lane; k < NVP * ld; k += 64) s_M[k] = 0.f;
-  __syncthreads();
-  dense_global_to_lds(s_H, M, nv, ld, lane, true);
-  dense_global_to_lds(s_M, M, nv, ld, lane, false);
+  // mj_factorM + qacc_smooth = M^-1 qfrc_smooth
+  if (BIG) {
+    dense_global_to_lds(s_H, M, nv, ld, lane, true);
+  } else {
+    glds_dense_to_packed(s_M, M, nv, lane);
+    for (int k = ((nv * (nv + 1)) >> 1) + lane; k < NVP * (NVP + 1) / 2; k += 64) s_M[k] = 0.f;
+    __syncthreads();
+    packed_to_lds(s_H, s_M, nv, ld, lane);
+  }
   chol_pad_rows<NVP>(s_H, nv, lane);
   chol_pad_diag<NVP>(s_H, nv, lane);
   __syncthreads();
@@ -426,36 +415,44 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     if (lane == 0) d.solver_niter[w] = 0;
     return;
   }
-  // ---- per row: D, role, aux; aref parked in the force array until the first constraint update
-  const float impratio = (float)m.opt.impratio;
-  const float mu_scale = 1.f / sqrtf(impratio > MINVAL ? impratio : MINVAL);
+  // ---- per row: D (a cone's slots: -D_0, friction_1, friction_2), friction loss, role bits (a row's role parked in the J search array,
+  // then 16 rows packed per word by one lane: no atomics)
   for (int r = lane; r < nefc; r += 64) {
-    c.s_D[r] = d.efc_D[wr + r];
-    c.s_force[r] = d.efc_aref[wr + r];
+    float Dr = d.efc_D[wr + r];
     int role = CONE_ROLE_ROW;
-    float aux = r < c.nf ? d.efc_frictionloss[wr + r] : 0.f;
     if (d.efc_type[wr + r] == MJLAB_EFC_CONTACT_ELLIPTIC) {
       const int cid = d.efc_id[wr + r], k = r - d.contact_efc_address[(size_t)w * ncm + cid];
-      const float* fri = d.contact_friction + 5 * ((size_t)w * ncm + cid);
+      Dr = k == 0 ? -Dr : d.contact_friction[5 * ((size_t)w * ncm + cid) + k - 1];
       role = k == 0 ? CONE_ROLE_START : CONE_ROLE_MEMBER;
-      aux = k == 0 ? fri[0] * mu_scale : fri[k - 1];
     }
-    c.s_role[r] = role;
-    c.s_aux[r] = aux;
+    c.s_D[r] = Dr;
+    ((int*)c.s_jv)[r] = role;
+    if (r < c.nf) c.s_fl[r] = d.efc_frictionloss[wr + r];
   }
+  __syncthreads();
+  for (int k = lane; k < (nefc + 15) / 16; k += 64) {
+    unsigned bits = 0u;
+    for (int j = 0; j < 16; ++j) {
+      const int r = 16 * k + j;
+      if (r < nefc) bits |= (unsigned)((const int*)c.s_jv)[r] << (2 * j);
+    }
+    s_role[k] = bits;
+  }
+  __syncthreads();
   // ---- warm start: the better of qacc_warmstart and qacc_smooth (mj_fwdConstraint)
   const float ws = own ? d.qacc_warmstart[wv] : 0.f;
   cone_jac_mul<NVP, true>(c, ws, qas, c.s_jar, c.s_jv);
   __syncthreads();
-  for (int r = lane; r < nefc; r += 64) { const float ar = c.s_force[r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
+  for (int r = lane; r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
   __syncthreads();
-  float Ma = cone_mul_M<NVP>(s_M, lane, ws);
+  auto mul_M = [&](float x) __attribute__((always_inline)) { return BIG ? symm_mul_global<NVP>(M, nv, x, lane) : symm_mul_packed<NVP>(s_M, nv, x, lane); };
+  float Ma = mul_M(ws);
   const float cw = cone_rows_cost(c, c.s_jar) + wave_sum(own ? 0.5f * (Ma - qs) * (ws - qas) : 0.f);
   const float cs = cone_rows_cost(c, c.s_jv);
   float qacc = ws;
   if (cw > cs) {
     qacc = qas;
-    Ma = cone_mul_M<NVP>(s_M, lane, qas);
+    Ma = mul_M(qas);
     __syncthreads();
     for (int r = lane; r < nefc; r += 64) c.s_jar[r] = c.s_jv[r];
   }
@@ -465,20 +462,55 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
   const float ulp4 = (m.opt.flags & MJLAB_OPT_LITERAL_TERMINATION) ? 0.f : 4.f * 5.9604645e-8f;
   PROF_MARK(1);
-  // constraint update: forces, cost, and -- one pass over the virtual rows -- J^T f and H = M + J^T (.) J laid out for the factor
-  // (the previous factor in s_H is dead by then: it is used between two updates only)
+  // constraint update: cost, J^T f, and H = M + J^T (.) J laid out for the factor -- 64 rows at a time: their virtual rows into the
+  // list (the dead factor's block), the list through the matrix cores; the tiles stay in registers until the last trip
   float cost, gauss, fc;
   auto update = [&]() {
-    int nvirt;
-    PROF_MARK(9);
-    const float rows = cone_update_rows(c, &nvirt);
-    __syncthreads();
-    PROF_MARK(10);
-    fc = cone_accum_store<NVP>(c, nvirt, s_H, s_M);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float jtf[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) jtf[cb] = 0.f;
+    float rows = 0.f;
+    if (nefc <= 64) {  // the common case spelled out: no loop around the tiles (carried across a loop they cost register copies)
+      int nvirt;
+      rows = cone_update_trip(c, 0, &nvirt);
+      __syncthreads();
+      cone_accum<NVP>(c, nvirt, acc, jtf);
+      __syncthreads();
+    } else {
+      for (int r0 = 0; r0 < nefc; r0 += 64) {  // wave-uniform
+        int nvirt;
+        rows += cone_update_trip(c, r0, &nvirt);
+        __syncthreads();
+        cone_accum<NVP>(c, nvirt, acc, jtf);
+        __syncthreads();
+      }
+    }
+    {  // H = M + tiles -> LDS (lower triangle), identity beyond nv
+      const int sub = lane >> 4, col = lane & 15;
+      int t = 0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int Jb = 0; Jb <= I; ++Jb) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
+            if (row < nv && cc <= row) s_H[row * ld + cc] = acc[t][k] + (BIG ? M[row * nv + cc] : s_M[((row * (row + 1)) >> 1) + cc]);
+          }
+          ++t;
+        }
+    }
+    chol_pad_rows<NVP>(s_H, nv, lane);
+    chol_pad_diag<NVP>(s_H, nv, lane);
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) { jtf[cb] += __shfl_xor(jtf[cb], 16); jtf[cb] += __shfl_xor(jtf[cb], 32); }
+    fc = pick16<NB>(jtf, lane);
     gauss = wave_sum(own ? 0.5f * (Ma - qs) * (qacc - qas) : 0.f);
-    cost = rows + gauss;
+    cost = wave_sum(rows) + gauss;
     __syncthreads();
-    PROF_MARK(11);
   };
   update();
   PROF_MARK(2);
@@ -493,7 +525,7 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     // ---- line search
     const float snorm = sqrtf(wave_sum(search * search));
     if (snorm < MINVAL) break;
-    const float Mv = cone_mul_M<NVP>(s_M, lane, search);
+    const float Mv = mul_M(search);
     __syncthreads();
     cone_jac_mul<NVP, false>(c, search, 0.f, c.s_jv, nullptr);
     __syncthreads();
@@ -504,16 +536,15 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     PROF_MARK(5);
     float alpha;
     if (m.opt.flags & MJLAB_OPT_LS_PARALLEL) {
-      // mujoco_warp's grid: ls_iterations log-spaced steps in [ls_parallel_min_step, 1], lanes = candidates, lowest cost wins, the first one on ties
+      // mujoco_warp's grid: ls_iterations log-spaced steps in [ls_parallel_min_step, 1], lanes = candidates x row groups, lowest cost wins,
+      // the first one on ties; the cones' costs at alpha = 0 once per search (in the dead factor's block)
       const float lo = logf((float)m.opt.ls_parallel_min_step), step = (0.f - lo) / (float)(lsmax > 1 ? lsmax - 1 : 1);
       const bool literal = (m.opt.flags & MJLAB_OPT_LS_LITERAL_COST) != 0;
-      // the cones' costs at alpha = 0, once per search (virtual-row force array: free between two updates)
-      float* s_c0 = c.s_vf;
+      float* s_c0 = s_H;
       for (int r = lane; r < nefc; r += 64)
-        if (c.s_role[r] == CONE_ROLE_START) {
-          const float x[3] = {c.s_jar[r], c.s_jar[r + 1], c.s_jar[r + 2]}, D[3] = {c.s_D[r], c.s_D[r + 1], c.s_D[r + 2]}, fr[3] = {c.s_aux[r], c.s_aux[r + 1], c.s_aux[r + 2]};
-          float cb, fo[3], gg[3], q[3], Da, Db;
-          cone_block(x, D, fr, cb, fo, gg, q, Da, Db);
+        if (cone_role(c, r) == CONE_ROLE_START) {
+          float D[3], cb, fo[3], gg[3], q[3], Da, Db;
+          cone_at(c, r, c.s_jar, nullptr, 0.f, D, cb, fo, gg, q, Da, Db);
           s_c0[r] = cb;
         }
       __syncthreads();
@@ -535,10 +566,19 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
         const unsigned long long hit = __ballot(cc == cmin && g == 0 && ci < lsmax);
         if (hit && (!have || cmin < best_cost)) { best_cost = cmin; alpha = lane_bcast_dyn(a, (int)__builtin_ctzll(hit)); have = true; }
       }
+      __syncthreads();  // (the update below writes its list over the cone costs)
     } else {
       float a1 = 0.f, a2 = 0.f;
       for (int r = lane; r < nefc; r += 64) {
-        const float dj = c.s_D[r] * c.s_jv[r];
+        const int role = cone_role(c, r);
+        float Dr = c.s_D[r];
+        if (role != CONE_ROLE_ROW) {  // (a cone's D slots hold -D_0, friction_1, friction_2)
+          const int rs = role == CONE_ROLE_START ? r : (cone_role(c, r - 1) == CONE_ROLE_START ? r - 1 : r - 2);
+          float D[3], fr[3];
+          cone_params(c, rs, D, fr);
+          Dr = r == rs ? D[0] : (r == rs + 1 ? D[1] : D[2]);
+        }
+        const float dj = Dr * c.s_jv[r];
         a1 += fabsf(dj * c.s_jar[r]); a2 += fabsf(0.5f * dj * c.s_jv[r]);
       }
       const float dn1 = ulp4 * (wave_sum(a1) + fabsf(c.quad_gauss[1])), dn2 = 2.f * ulp4 * (wave_sum(a2) + fabsf(c.quad_gauss[2]));
@@ -563,9 +603,21 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
     PROF_COUNT(8);
     if (improvement < tol || gradient < tol || gradient < noise) break;
   }
-  // ---- publish
+  // ---- publish (the forces from the residuals once more: no array of them is kept)
   __syncthreads();
-  for (int r = lane; r < nefc; r += 64) d.efc_force[wr + r] = c.s_force[r];
+  for (int r = lane; r < nefc; r += 64) {
+    const int role = cone_role(c, r);
+    if (role == CONE_ROLE_MEMBER) continue;
+    if (role == CONE_ROLE_START) {
+      float D[3], rc, fo[3], g[3], q[3], Da, Db;
+      cone_at(c, r, c.s_jar, nullptr, 0.f, D, rc, fo, g, q, Da, Db);
+      for (int k = 0; k < 3; ++k) d.efc_force[wr + r + k] = fo[k];
+    } else {
+      float rc, fo;
+      cone_scalar_row(c, r, c.s_jar[r], rc, fo);
+      d.efc_force[wr + r] = fo;
+    }
+  }
   if (own) {
     d.qacc[wv] = qacc;
     d.qfrc_constraint[wv] = fc;
@@ -575,11 +627,17 @@ __device__ void stage_solve_cone(const Model& m, const Data& d, const int w, con
   PROF_FLUSH(d.profile + (size_t)w * 64 + 48);  // (slots 48..63: the constraint stage's block uses its first four only)
 }
 
-// the solve of a world with elliptic cones; the integrator follows as k_solve_integrate<NVP> with the solve switched off (like the dual
-// solver).  A kernel of its own so that the pyramid path's kernels carry none of its registers or scratch; 2 waves per SIMD (a row of H
-// per lane in registers next to the factor's).
 template <int NVP>
-__global__ __launch_bounds__(64, 2) void k_solve_cone(const Model m, const Data d, const int flags) {
+__device__ __forceinline__ void stage_solve_cone(const Model& m, const Data& d, const int w, const int lane, float* smem) {
+  const int rows_with_m = cone_lds_rows(m.size);  // wave-uniform; the common instantiation is the one with M in LDS
+  if (rows_with_m < 0 || d.nefc[w] > rows_with_m) stage_solve_cone_impl<NVP, true>(m, d, w, lane, smem);
+  else stage_solve_cone_impl<NVP, false>(m, d, w, lane, smem);
+}
+
+// the solve of a world with elliptic cones; the integrator follows as k_solve_integrate<NVP> with the solve switched off (like the dual
+// solver).  A kernel of its own so that the pyramid path's kernels carry none of its registers or scratch.
+template <int NVP>
+__global__ __launch_bounds__(64, 4) void k_solve_cone(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if ((flags & FLAG_MASK) && !d.world_mask[w]) return;

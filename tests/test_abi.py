@@ -95,7 +95,8 @@ def test_every_bundled_scene_keeps_16_waves_per_cu_in_lds():
     assert all(0 < b <= 10240 for b in lds.values()), (scene, lds)
     if scene.startswith("g1"):
       assert lds["solve"] == 10104, lds
-      # elliptic cones (stage_cone.h): their own kernel and LDS layout -- H, dense M, 7 per-row arrays over all njmax rows: 2 waves per SIMD
+      # elliptic cones (stage_cone.h): their own kernels and LDS layout -- the factor's block, packed M, 168 rows of the three per-row arrays,
+      # role bits: 10 KB per wave like the pyramid's solve
       ms.opt.cone = 1
       ell = L.mjlab_lds_bytes(ctypes.byref(ms), 16)
-      assert ell == 4 * (2 * 36 * 36 + 36 + 7 * 300) and ell <= 160 * 1024 // 8, ell
+      assert ell == 10228 and ell <= 10240, ell

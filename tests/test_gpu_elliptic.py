@@ -186,6 +186,38 @@ def test_elliptic_launch_structures_are_bit_identical():
       assert torch.equal(out[variants[0]][f], out[v][f]), (v, f)
 
 
+def test_elliptic_kernels_of_different_sizes_back_to_back():
+  """Kernels of different padded sizes, launch structures and line searches one after the other in one process (a kernel must not
+  depend on what the previous one left in registers, LDS or scratch: a build of the fused cone kernels at four waves per SIMD passed
+  every test alone and faulted on the 32-dof instantiation right after the 36-dof one -- round 5; they run at two waves per SIMD)."""
+  import gc
+
+  import torch
+
+  from mjlab_amd import mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  base = models()
+  order = ["g1_velocity_flat", "mixed", "go1_velocity_flat", "mixed", "g1_velocity_flat", "box", "mixed"]
+  for rep, (fuse, lsp) in enumerate((("step", False), ("stage", False), ("step", True), ("stage", True))):
+    for name in order:
+      model = copy.deepcopy(base[name])
+      model.opt.cone = mjcf.CONE_ELLIPTIC
+      qpos, qvel, ctrl = golden_inputs(model, 8, 50 + rep)
+      sim = Simulation(8, SimulationCfg(njmax=300, fuse=fuse, ls_parallel=lsp), model, "cuda:0")
+      for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+        getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+      sim.forward()
+      for _ in range(3):
+        sim.step()
+      sim.step(4)
+      sim.forward()
+      torch.cuda.synchronize()
+      assert bool(torch.isfinite(sim.data.qpos).all()) and bool(torch.isfinite(sim.data.qacc).all()), (fuse, lsp, name)
+      del sim
+      gc.collect()
+
+
 def test_elliptic_is_refused_where_it_is_not_carried():
   """The "presolve" launch structure and the other solvers carry the pyramid only: asked for elliptic cones they say so."""
   from mjlab_amd import _abi, mjcf
