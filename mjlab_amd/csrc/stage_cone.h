@@ -635,9 +635,11 @@ __device__ __forceinline__ void stage_solve_cone(const Model& m, const Data& d, 
 }
 
 // the solve of a world with elliptic cones; the integrator follows as k_solve_integrate<NVP> with the solve switched off (like the dual
-// solver).  A kernel of its own so that the pyramid path's kernels carry none of its registers or scratch.
+// solver).  A kernel of its own so that the pyramid path's kernels carry none of its registers or scratch.  Two waves per SIMD: nothing
+// spilled.  (At four -- 128 VGPRs, ~130 spilled -- this kernel ran 7 % faster and passed every test; the FUSED cone kernels with spills
+// faulted when instantiations of different sizes ran back to back, cause not found: none of the cone kernels is built with spills.)
 template <int NVP>
-__global__ __launch_bounds__(64, 4) void k_solve_cone(const Model m, const Data d, const int flags) {
+__global__ __launch_bounds__(64, 2) void k_solve_cone(const Model m, const Data d, const int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int w = blockIdx.x, lane = threadIdx.x;
   if ((flags & FLAG_MASK) && !d.world_mask[w]) return;

@@ -27,8 +27,10 @@ def kernels():
 def test_every_kernel_fits_four_waves_per_simd(kernels):
   assert len(kernels) >= 40  # 9 padded sizes x (solve, forward, step, control step) + the size-independent kernels
   for name, md in kernels.items():
-    if "_cone" in name and "k_constraint_cone" not in name:  # elliptic cones (stage_cone.h, kernels.h): kernels of their own off the measured path, 2 waves per SIMD
-      assert md["vgpr_count"] <= 256 and md["group_segment_fixed_size"] == 0, (name, md)
+    if "_cone" in name and "k_constraint_cone" not in name:  # elliptic cones (stage_cone.h, kernels.h): kernels of their own off the measured path
+      # two waves per SIMD (one for the fused 64-dof instantiations) and NOTHING spilled: fused cone kernels built with spills faulted when
+      # instantiations of different sizes ran back to back (tests/test_gpu_elliptic.py runs that pattern)
+      assert md["group_segment_fixed_size"] == 0 and md["vgpr_spill_count"] == 0, (name, md)
       continue
     assert md["vgpr_count"] <= 128, (name, md)
     assert md["group_segment_fixed_size"] == 0, (name, md)  # LDS is laid out per model at launch (mjlab_lds_bytes)
