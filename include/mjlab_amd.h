@@ -60,6 +60,11 @@ int mjlab_sizeof_sizes(void);
  * decimation loop that calls it 4x per env step is envs/manager_based_rl_env.py:109-114. */
 int mjlab_step(const mjlab_model_t* m, const mjlab_data_t* d, int nsubstep, void* stream);
 
+/* Solver / cone options (mjlab_option_t, include/mjlab_fields.h; reference sim/sim.py:43-82): MJLAB_SOL_NEWTON and MJLAB_SOL_CG with the
+ * pyramidal cone run under every launch structure and in mjlab_control_step; MJLAB_SOL_PGS with one kernel per stage only;
+ * MJLAB_CONE_ELLIPTIC (round 5; MJLAB_SOL_NEWTON only) has kernels of its own for one kernel per stage, MJLAB_OPT_FUSE_STEP and
+ * mjlab_control_step -- not for MJLAB_OPT_FUSE_PRESOLVE.  Anything else is refused with a message (mjlab_last_error). */
+
 /* Contact generation.  Plane / sphere / capsule pairs restate MuJoCo's analytic primitives; sphere-box
  * restates mjc_SphereBox.  Two primitives are NOT upstream-identical (documented rules of this library,
  * mirrored by the test oracle): capsule-box (sphere-box contacts of axis points
