@@ -125,6 +125,9 @@ _UP_CASES = [("upstream", name, lsp, lit, wsa, lc) for tag, name in _FILES if ta
              for lit in (False, True) for wsa in (False, True) for lc in ((False, True) if lsp else (False,))]
 _DRY_CASES = [("dryrun", name, lsp, False, False, False) for tag, name in _FILES if tag == "dryrun" for lsp in (1, 0)]
 _NONE = [("none", "none", 0, False, False, False)]
+# the "ell" records (the same scene with MujocoCfg.cone = "elliptic"; seeded-state files only): what would pin the elliptic path
+_UP_ELL = [c for c in _UP_CASES if not c[1].endswith("_rollout")]
+_DRY_ELL = [c for c in _DRY_CASES if not c[1].endswith("_rollout")]
 # ls_parallel on: the grid search moves every iterate by one of `ls_iterations` discrete steps, so two fp32 implementations with a
 # different summation order part wherever they pick different candidates in a late iteration and end at the iteration cap on different
 # iterates (parity gate, GRID literals: worst world 5e-3 in qacc).  The files are compared in max-norm over ALL their worlds, so the
@@ -199,9 +202,23 @@ def _oracle_flags(lit, wsa, lc=False):
   return (2 if lit else 0) | (4 if wsa else 0) | (256 if lc else 0)
 
 
-def check_oracle(z, name, lsp, lit, wsa, lc=False):
-  """fp32 oracle against the recorded engine: forward() fields (-> count compared), then nstep x step() + forward()."""
+def _model_for(name, ell):
+  """The scene's compiled model; ``ell``: with elliptic friction cones, as the tool's "ell" records were made (MujocoCfg.cone)."""
   model = models()[_scene_of(name)]
+  if ell:
+    import copy
+
+    from mjlab_amd.mjcf import CONE_ELLIPTIC
+
+    model = copy.deepcopy(model)
+    model.opt.cone = CONE_ELLIPTIC
+  return model
+
+
+def check_oracle(z, name, lsp, lit, wsa, lc=False, ell=False):
+  """fp32 oracle against the recorded engine: forward() fields (-> count compared), then nstep x step() + forward()."""
+  model = _model_for(name, ell)
+  pre = ("ell" if ell else "") + f"lsp{lsp}"
   n = z["in_qpos"].shape[0]
   s = OracleSim(model, n, njmax=300, precision="f32", flags=_oracle_flags(lit, wsa, lc), ls_parallel=bool(lsp))
   for key in z.files:
@@ -215,12 +232,12 @@ def check_oracle(z, name, lsp, lit, wsa, lc=False):
 
   load()
   s.forward()
-  ncmp = compare_upstream(z, lambda f: getattr(s, f), f"lsp{lsp}_fwd")
+  ncmp = compare_upstream(z, lambda f: getattr(s, f), pre + "_fwd")
   load()
   s.step(int(z["nstep"]))
   s.forward()
   for f in ("qpos", "xpos", "xquat"):
-    assert _rel(getattr(s, f), z[f"lsp{lsp}_step_{f}"]) <= 2e-5, ("step", f)
+    assert _rel(getattr(s, f), z[f"{pre}_step_{f}"]) <= 2e-5, ("step", f)
   return ncmp
 
 
@@ -257,13 +274,27 @@ def test_tool_consumers_execute_on_the_oracle(tag, name, lsp, lit, wsa, lc):
   assert check_oracle(np.load(_SETS[tag] / f"{name}.npz"), name, lsp, lit, wsa, lc) >= 8
 
 
-def check_hip(tag, name, lsp, lit, wsa, lc):
+@pytest.mark.skipif(not _UP_ELL, reason=_NO_REAL)
+@pytest.mark.parametrize("tag,name,lsp,lit,wsa,lc", _UP_ELL or _NONE)
+def test_oracle_matches_upstream_elliptic(tag, name, lsp, lit, wsa, lc):
+  assert check_oracle(np.load(_SETS[tag] / f"{name}.npz"), name, lsp, lit, wsa, lc, ell=True) >= 8
+
+
+@pytest.mark.skipif(not _DRY_ELL, reason="no dry-run vectors")
+@pytest.mark.parametrize("tag,name,lsp,lit,wsa,lc", _DRY_ELL or _NONE)
+def test_tool_consumers_execute_on_the_oracle_elliptic(tag, name, lsp, lit, wsa, lc):
+  """The "ell" records (the scene compiled with MujocoCfg.cone = "elliptic" through the reference's own edit_spec) through the same consumer."""
+  assert check_oracle(np.load(_SETS[tag] / f"{name}.npz"), name, lsp, lit, wsa, lc, ell=True) >= 8
+
+
+def check_hip(tag, name, lsp, lit, wsa, lc, ell=False):
   import torch
 
   from mjlab_amd.sim import Simulation, SimulationCfg
 
   z = np.load(_SETS[tag] / f"{name}.npz")
-  model = models()[_scene_of(name)]
+  model = _model_for(name, ell)
+  pre = ("ell" if ell else "") + f"lsp{lsp}"
   n = z["in_qpos"].shape[0]
   sim = Simulation(n, SimulationCfg(njmax=300, ls_parallel=bool(lsp), literal_termination=lit, warmstart_at_advance=wsa, ls_literal_cost=lc, use_graph=False), model, "cuda:0")
   dr = [key[3:] for key in z.files if key.startswith("dr_")]
@@ -280,7 +311,7 @@ def check_hip(tag, name, lsp, lit, wsa, lc):
   load()
   sim.forward()
   torch.cuda.synchronize()
-  assert compare_upstream(z, lambda f: getattr(sim.data, f).cpu().numpy(), f"lsp{lsp}_fwd", tol=_UP_TOL_GRID if lsp else _UP_TOL) >= 8
+  assert compare_upstream(z, lambda f: getattr(sim.data, f).cpu().numpy(), pre + "_fwd", tol=_UP_TOL_GRID if lsp else _UP_TOL) >= 8
   load()
   for _ in range(int(z["nstep"])):
     sim.step()
@@ -289,7 +320,7 @@ def check_hip(tag, name, lsp, lit, wsa, lc):
   # robots, worlds at the iteration cap -- the worst of the 16 worlds is 1.8e-4 / 6e-4 after five steps (one step: gate GRID literal 2e-4)
   tol_step = (2e-3 if name.endswith("_rollout") else 5e-5) if lsp else 2e-5
   for f in ("qpos", "xpos", "xquat"):
-    assert _rel(getattr(sim.data, f).cpu().numpy(), z[f"lsp{lsp}_step_{f}"]) <= tol_step, ("step", f)
+    assert _rel(getattr(sim.data, f).cpu().numpy(), z[f"{pre}_step_{f}"]) <= tol_step, ("step", f)
 
 
 @pytest.mark.gpu
@@ -297,6 +328,21 @@ def check_hip(tag, name, lsp, lit, wsa, lc):
 @pytest.mark.parametrize("tag,name,lsp,lit,wsa,lc", _UP_CASES or _NONE)
 def test_hip_matches_upstream(tag, name, lsp, lit, wsa, lc):
   check_hip(tag, name, lsp, lit, wsa, lc)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _UP_ELL, reason=_NO_REAL)
+@pytest.mark.parametrize("tag,name,lsp,lit,wsa,lc", _UP_ELL or _NONE)
+def test_hip_matches_upstream_elliptic(tag, name, lsp, lit, wsa, lc):
+  check_hip(tag, name, lsp, lit, wsa, lc, ell=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _DRY_ELL, reason="no dry-run vectors")
+@pytest.mark.parametrize("tag,name,lsp,lit,wsa,lc", _DRY_ELL or _NONE)
+def test_tool_consumers_execute_on_the_device_elliptic(tag, name, lsp, lit, wsa, lc):
+  """The "ell" records of the dry run (the fp32 restatement with elliptic cones behind the engine's API) against the HIP path: plumbing."""
+  check_hip(tag, name, lsp, lit, wsa, lc, ell=True)
 
 
 @pytest.mark.gpu

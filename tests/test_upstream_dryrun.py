@@ -52,7 +52,11 @@ def test_tool_writes_both_files_of_every_scene(dry):
     zr = np.load(dry / f"{s}_rollout.npz")
     assert zr["in_qpos"].shape[0] == NROLL and "in_qacc_warmstart" in zr.files
     assert any(k.startswith("dr_") for k in zr.files), "per-world model fields of the rollout states missing"
-    for p in ("lsp1", "lsp0"):
+    assert int(z["ell_model_opt_cone"]) == 1  # the elliptic records: MujocoCfg.cone reached the compiled model through the reference's edit_spec
+    assert (z["elllsp0_fwd_nefc"].ravel() <= z["lsp0_fwd_nefc"].ravel()).all()  # 3 rows per condim-3 contact, not 4
+    if s == "g1_velocity_flat":
+      assert (z["elllsp0_fwd_nefc"].ravel() < z["lsp0_fwd_nefc"].ravel()).any()
+    for p in ("lsp1", "lsp0", "elllsp1", "elllsp0"):
       for stage in ("fwd", "step"):
         for f in ("qpos", "qacc", "nefc", "efc_J", "efc_D", "efc_aref", "contact_dist", "qM", "solver_niter"):
           assert f"{p}_{stage}_{f}" in z.files, (s, p, stage, f)

@@ -13,7 +13,8 @@ gap in ONE command on a machine that has them:
 writes tests/golden_upstream_dryrun/ (git-ignored).  tests/test_upstream_dryrun.py does that in CI and feeds the output through
 the very comparison code the upstream tests use, so every line of this tool and of its consumers has executed before the real run.
 
-Per scene it writes two files, each with ``ls_parallel`` on (the reference's setting, sim/sim.py:89,111) AND off:
+Per scene it writes two files, each with ``ls_parallel`` on (the reference's setting, sim/sim.py:89,111) AND off (the seeded-state file also
+with ``MujocoCfg.cone = "elliptic"``: records ``elllsp1_*`` / ``elllsp0_*``, what would pin this repository's elliptic path):
 
   <scene>.npz            the seeded states of tools/make_golden.py (4 worlds), same keys as tests/golden/<scene>.npz
   <scene>_rollout.npz    the ROLLOUT STATES the parity gate uses: tests/golden/rollout_states_<scene>.npz (256 worlds reached
@@ -100,7 +101,7 @@ def record(d, prefix: str, nworld: int, fields) -> dict:
   return rec
 
 
-def run_case(mjwarp, wp, mjm, mjd, cfg, states: dict, dr: dict, ls_parallel: bool, fields) -> dict:
+def run_case(mjwarp, wp, mjm, mjd, cfg, states: dict, dr: dict, ls_parallel: bool, fields, tag: str = "") -> dict:
   nworld = states["qpos"].shape[0]
   m = mjwarp.put_model(mjm)
   m.opt.ls_parallel = ls_parallel  # reference src/mjlab/sim/sim.py:111
@@ -109,7 +110,7 @@ def run_case(mjwarp, wp, mjm, mjd, cfg, states: dict, dr: dict, ls_parallel: boo
     setattr(m, f, wp.array(np.ascontiguousarray(v.astype(np.float32)), dtype=getattr(m, f).dtype))
   for f, v in states.items():
     wp.copy(getattr(d, f), wp.array(np.ascontiguousarray(v.astype(np.float32))))
-  p = "lsp1" if ls_parallel else "lsp0"
+  p = tag + ("lsp1" if ls_parallel else "lsp0")  # tag "ell": the same scene compiled with MujocoCfg.cone = "elliptic"
   mjwarp.forward(m, d)
   rec = record(d, p + "_fwd", nworld, fields)
   for f, v in states.items():  # one step()-chain from the SAME state and warm start (forward() overwrote qacc_warmstart)
@@ -186,6 +187,20 @@ def main() -> None:
     rec.update(marr, nstep=np.array(NSTEP), dry_run=np.array(int(args.dry_run)))
     for lsp in (True, False):
       rec.update(run_case(mjwarp, wp, mjm, mjd, cfg, states, {}, lsp, fields))
+    # ---- (1b) the same scene and states with elliptic friction cones (MujocoCfg.cone, reference sim/sim.py:49,52; no task sets it: this
+    # is what would pin this repository's elliptic path, round 5): records under "elllsp1_*" / "elllsp0_*"
+    import copy
+
+    cfg_e = copy.deepcopy(cfg)  # (the velocity tasks share one module-level SimulationCfg: never edit it in place)
+    cfg_e.sim.mujoco.cone = "elliptic"
+    scene_e = Scene(cfg_e.scene, device=device)
+    cfg_e.sim.mujoco.edit_spec(scene_e.spec)
+    mjm_e = scene_e.compile()
+    mjd_e = mujoco.MjData(mjm_e)
+    mujoco.mj_forward(mjm_e, mjd_e)
+    rec["ell_model_opt_cone"] = np.asarray(mjm_e.opt.cone)
+    for lsp in (True, False):
+      rec.update(run_case(mjwarp, wp, mjm_e, mjd_e, cfg_e, states, {}, lsp, fields, tag="ell"))
     np.savez_compressed(out / f"{name}.npz", **rec)
     print("wrote", out / f"{name}.npz")
     # ---- (2) the rollout states of the parity gate, exported from a GPU run and committed
