@@ -52,6 +52,53 @@ def test_registered_g1_velocity_task_runs_over_the_hip_simulation():
   print(f"reference G1 velocity task over mjlab_amd.Simulation: 100 env steps x 256 envs, {sum(resets)} resets, mean reward {out['mean_reward']:.4f}")
 
 
+_ELLIPTIC_GPU = """
+import json, sys
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import torch
+import reference_env
+from mjlab_amd.graphed_env import GraphedRlEnv
+def edit(cfg):
+  cfg.sim.mujoco.cone = "elliptic"  # reference sim/sim.py:49,52
+env = reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=256, device="cuda:0", cfg_edit=edit)
+st = {{"cone": int(env.sim.mj_model.opt.cone), "fuse": env.sim.fuse}}
+out = reference_env.random_rollout(env, 40, seed=1)
+torch.cuda.synchronize()
+d = env.sim.data
+st["eager_finite"] = all(bool(torch.isfinite(o).all()) for o in out["obs"].values()) and bool(torch.isfinite(d.qpos).all())
+st["elliptic_rows"] = int((d.efc_type == 7).sum())
+g = GraphedRlEnv(env)  # the whole control step as one hipGraph: k_control_step_cone inside
+gen = torch.Generator(device="cuda:0"); gen.manual_seed(3)
+fin, resets = True, 0
+for k in range(60):
+  obs, rew, term, tout, _ = g.step(2.0 * torch.rand((256, 29), device="cuda:0", generator=gen) - 1.0)
+  fin = fin and bool(torch.isfinite(rew).all()) and all(bool(torch.isfinite(o).all()) for o in obs.values())
+  resets += int((term | tout).sum())
+torch.cuda.synchronize()
+st["graphed_finite"], st["graphed_resets"], st["graph"] = fin, resets, g.graph is not None
+z = d.qpos[:, 2]
+st["z_range"] = [float(z.min()), float(z.max())]
+st["overflow"] = env.sim.overflow_report()
+print("RESULT " + json.dumps(st))
+"""
+
+
+def test_velocity_task_with_elliptic_cones_eager_and_as_one_graph():
+  """``MujocoCfg(cone="elliptic")`` on the registered G1 velocity task over the HIP simulation: the reference's eager ``env.step`` (the
+  fused cone kernels under ``sim.step``) and ``GraphedRlEnv`` (``k_control_step_cone`` inside the captured control step)."""
+  import json
+  import subprocess
+
+  code = _ELLIPTIC_GPU.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print("reference G1 velocity task with elliptic cones:", st)
+  assert st["cone"] == 1 and st["fuse"] == "step" and st["eager_finite"] and st["elliptic_rows"] >= 3 * 128
+  assert st["graph"] and st["graphed_finite"] and st["graphed_resets"] > 0
+  assert 0.05 < st["z_range"][0] and st["z_range"][1] < 1.2 and st["overflow"] == {"nconmax": 0, "njmax": 0, "terrain_candidates": 0}, st
+
+
 def test_graphed_env_matches_the_reference_env():
   """the whole control step of the reference's environment as ONE hipGraph (mjlab_amd/graphed_env.py) against the
   reference's own eager ``env.step`` over the same Simulation class, teacher-forced (tests/_graphed_check.py): terminations and

@@ -126,6 +126,40 @@ def test_go1_task_constructs_and_steps():
   assert res["worst"] < 1e-12 and res["finite"]
 
 
+_ELLIPTIC_SCRIPT = """
+import json, sys
+import numpy as np
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env
+from _oracle_simulation import OracleSimulation
+def edit(cfg):
+  cfg.sim.mujoco.cone = "elliptic"  # reference sim/sim.py:49,52: reaches the compiled model through MujocoCfg.edit_spec
+env = reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=8, device="cpu", sim_cls=OracleSimulation, cfg_edit=edit)
+out = reference_env.random_rollout(env, 6)
+d = env.sim.data
+nefc = d.nefc.numpy().ravel()
+types = [int((d.efc_type.numpy()[w, : nefc[w]] == 7).sum()) for w in range(8)]
+print("RESULT " + json.dumps({{"cone": int(env.sim.mj_model.opt.cone), "elliptic_rows": types, "nefc": nefc.tolist(),
+                              "finite": all(bool(np.isfinite(o.numpy()).all()) for o in out["obs"].values()) and bool(np.isfinite(d.qpos.numpy()).all())}}))
+"""
+
+
+def test_velocity_task_with_elliptic_cones_constructs_and_steps():
+  """``MujocoCfg(cone="elliptic")`` on a registered task (no task ships it; the option is the reference's: sim/sim.py:49,52): the
+  reference's own configuration path -- ``edit_spec`` over this repository's ``mujoco`` shim, ``Scene.compile`` -- hands the
+  Simulation a model with elliptic cones, and the environment steps on it (three rows per foot contact).  In its own process, like
+  the other tasks (shared mutable defaults in the reference's configs)."""
+  import json
+  import subprocess
+
+  code = _ELLIPTIC_SCRIPT.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-2000:]
+  res = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  assert res["cone"] == 1 and res["finite"]
+  assert sum(res["elliptic_rows"]) >= 3 * 8 and all(k % 3 == 0 for k in res["elliptic_rows"]), res
+
+
 _TRACKING_SCRIPT = """
 import json, sys
 import numpy as np
