@@ -153,6 +153,55 @@ def test_elliptic_slab_slides_by_coulombs_law_on_the_device():
   assert np.allclose(along, want, rtol=0.06) and (np.abs(across) < 0.02 * want).all()
 
 
+@pytest.mark.parametrize("njmax,lsp", [(300, False), (300, True), (1700, False)], ids=["rows_64_plus", "rows_64_plus_grid", "layout_without_M"])
+def test_elliptic_many_rows_and_the_layout_without_M(njmax, lsp):
+  """The paths the seeded states never reach: worlds with more than 64 rows (the constraint update then runs in 64-row trips with the
+  tiles carried across them) and the layout without M in LDS (the BIG instantiation: here forced for every world by an njmax so large
+  that no row fits next to M).  States: the 32 worlds with the most rows among the parity gate's rollout states (fallen, self-colliding
+  robots; per-world foot friction), against the fp64 restatement."""
+  import torch
+
+  from mjlab_amd import mjcf, robots
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  z = np.load(ROOT / "tests" / "golden" / "rollout_states_g1_velocity_flat.npz")
+  model = copy.deepcopy(robots.load_model("g1_velocity_flat"))
+  model.opt.cone = mjcf.CONE_ELLIPTIC
+  probe = OracleSim(model, z["qpos"].shape[0], njmax=300, precision="f64")
+  for f in ("qpos", "qvel", "ctrl"):
+    getattr(probe, f)[:] = z[f]
+  probe.forward(nthread=8)
+  pick = np.argsort(-probe.nefc.ravel(), kind="stable")[:32]
+  n = pick.size
+  for fuse in ("stage", "step"):
+    sim = Simulation(n, SimulationCfg(njmax=njmax, use_graph=False, ls_parallel=lsp, fuse=fuse), model, "cuda:0")
+    ora = OracleSim(model, n, njmax=njmax, precision="f64", ls_parallel=lsp)
+    sim.expand_model_fields(["geom_friction"])
+    sim.model.geom_friction[:] = torch.from_numpy(z["dr_geom_friction"][pick].astype(np.float32)).cuda()
+    ora.expand_model_field("geom_friction")[:] = z["dr_geom_friction"][pick]
+    for f in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+      getattr(sim.data, f)[:] = torch.from_numpy(z[f][pick].astype(np.float32)).cuda()
+      getattr(ora, f)[:] = z[f][pick].astype(np.float32)
+    sim.forward()
+    ora.forward(nthread=8)
+    nefc = ora.nefc.ravel()
+    assert np.array_equal(_np(sim.data.nefc).ravel(), nefc) and (nefc > 64).sum() >= 3 and nefc.max() >= 80
+    if njmax > 300:  # no row fits next to M: every world runs the layout without it
+      lds = sim.lds_bytes()["solve"]
+      assert lds > 4 * 3 * njmax, lds
+    err = _per_world(_np(sim.data.qacc), ora.qacc)
+    big = nefc > 64
+    print(f"\nelliptic, rollout states, njmax {njmax}, fuse {fuse}, lsp {lsp}: qacc median {np.median(err):.2e} max {err.max():.2e}; worlds with > 64 rows: max {err[big].max():.2e}; "
+          f"iterations device {_np(sim.data.solver_niter).mean():.1f} restatement {ora.solver_niter.mean():.1f}")
+    # (measured: profiles/r05_v33_elliptic_many_rows.txt)
+    assert np.median(err) < 1e-5 and err.max() < (1.5e-4 if lsp else 6e-5), err  # measured 2.4e-6 / 1.4e-5 (grid 3.7e-6 / 2.7e-5)
+    for _ in range(4):
+      sim.step()
+    ora.step(4, nthread=8)
+    perr = _per_world(_np(sim.data.qpos), ora.qpos)
+    assert np.isfinite(_np(sim.data.qpos)).all() and np.median(perr) < (5e-5 if lsp else 5e-6), perr
+
+
 def test_elliptic_launch_structures_are_bit_identical():
   """The cone variants of the fused kernels (kernels.h: k_substep_cone, k_control_step_cone) run the same stage bodies as the one-kernel-
   per-stage pipeline: every output bit-identical over a rollout with task events, resets, forward() folds and a masked forward -- the
