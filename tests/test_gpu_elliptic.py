@@ -202,6 +202,41 @@ def test_elliptic_many_rows_and_the_layout_without_M(njmax, lsp):
     assert np.isfinite(_np(sim.data.qpos)).all() and np.median(perr) < (5e-5 if lsp else 5e-6), perr
 
 
+def test_elliptic_rows_that_do_not_fit_are_dropped_like_the_restatement():
+  """njmax smaller than the rows the state wants: a cone's three rows fit together or not at all, both sides drop the same contacts and
+  say so (data.overflow, MJLAB_OVF_NJMAX); and a state without contacts (nefc = limits only / 0) goes through the cone kernels too."""
+  import torch
+
+  from mjlab_amd import mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = copy.deepcopy(models()["g1_velocity_flat"])
+  model.opt.cone = mjcf.CONE_ELLIPTIC
+  n = 8
+  qpos, qvel, ctrl = golden_inputs(model, n, 11)
+  sim = Simulation(n, SimulationCfg(njmax=20, use_graph=False, ls_parallel=False), model, "cuda:0")
+  ora = OracleSim(model, n, njmax=20, precision="f64")
+  for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+    getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+    getattr(ora, f)[:] = v.astype(np.float32)
+  sim.forward()
+  ora.forward()
+  nefc = ora.nefc.ravel()
+  assert np.array_equal(_np(sim.data.nefc).ravel(), nefc) and nefc.max() <= 20
+  assert np.array_equal(_np(sim.data.overflow).ravel(), ora.overflow.ravel()) and (ora.overflow.ravel() & 2).any()
+  tg = _np(sim.data.efc_type)
+  for w in range(n):
+    assert (tg[w, : nefc[w]] == 7).sum() % 3 == 0 and np.array_equal(tg[w, : nefc[w]], ora.efc_type[w, : nefc[w]])
+  assert _per_world(_np(sim.data.qacc), ora.qacc).max() < 5e-5
+  # in the air: no contact rows
+  sim.data.qpos[:, 2] += 2.0
+  ora.qpos[:, 2] += 2.0
+  sim.step()
+  ora.step()
+  assert int(_np(sim.data.ncon).max()) == 0
+  assert _per_world(_np(sim.data.qvel), ora.qvel).max() < 1e-5
+
+
 def test_elliptic_launch_structures_are_bit_identical():
   """The cone variants of the fused kernels (kernels.h: k_substep_cone, k_control_step_cone) run the same stage bodies as the one-kernel-
   per-stage pipeline: every output bit-identical over a rollout with task events, resets, forward() folds and a masked forward -- the
