@@ -34,7 +34,7 @@ def _per_world(a, b):
 
 
 @pytest.mark.parametrize("lsp", [False, True], ids=["exact_ls", "grid_ls"])
-@pytest.mark.parametrize("name", ["mixed", "go1_velocity_flat", "g1_velocity_flat"])
+@pytest.mark.parametrize("name", ["mixed", "go1_velocity_flat", "g1_velocity_flat", "g1_velocity_rough"])
 def test_elliptic_forward_and_rollout_track_the_restatement(name, lsp):
   import torch
 
@@ -50,6 +50,9 @@ def test_elliptic_forward_and_rollout_track_the_restatement(name, lsp):
     model.dof_frictionloss[6:] = 0.2
     flags = _abi.OPT_FRICTIONLOSS
   nworld, nv = 16, model.nv
+  # (the rough scene: robots on stair edges up to ~100 m from the origin -- fp32 contact geometry there is good to ~1e-5 of a Jacobian
+  # entry and the solve inherits it, as in the pyramid's tests of that scene)
+  rough = name.endswith("rough")
   qpos, qvel, ctrl = golden_inputs(model, nworld, 43)
   sim = Simulation(nworld, SimulationCfg(njmax=300, use_graph=False, ls_parallel=lsp, fuse="stage"), model, "cuda:0")
   ora = OracleSim(model, nworld, njmax=300, precision="f64", flags=flags, ls_parallel=lsp)
@@ -73,10 +76,10 @@ def test_elliptic_forward_and_rollout_track_the_restatement(name, lsp):
     assert np.array_equal(tg[w, :n], ora.efc_type[w, :n]) and np.array_equal(ig[w, :n], ora.efc_id[w, :n])
     with_cones += (tg[w, :n] == 7).sum() >= 3
     Jg = _np(sim.data.efc_J)[w].reshape(-1, nv)[:n]
-    assert np.abs(Jg - ora.efc_J[w].reshape(-1, nv)[:n]).max() < 2e-6 * max(1.0, np.abs(Jg).max())
+    assert np.abs(Jg - ora.efc_J[w].reshape(-1, nv)[:n]).max() < (1e-4 if rough else 2e-6) * max(1.0, np.abs(Jg).max())
     for f, tol in (("efc_D", 1e-3), ("efc_aref", 1e-3), ("efc_pos", 1e-4), ("efc_margin", 1e-6)):
       a, b = _np(getattr(sim.data, f))[w, :n], getattr(ora, f)[w, :n]
-      assert np.abs(a - b).max() <= tol * max(1e-6, np.abs(b).max()), (f, w)
+      assert np.abs(a - b).max() <= (30 if rough else 1) * tol * max(1e-6, np.abs(b).max()), (f, w)
   assert with_cones >= nworld // 2
   # ---- the solve
   qa, fo = _np(sim.data.qacc), _np(sim.data.efc_force)
@@ -106,8 +109,8 @@ def test_elliptic_forward_and_rollout_track_the_restatement(name, lsp):
   print(f"\n{name} lsp={lsp}: elliptic qacc device vs restatement median {np.median(err):.2e} max {err.max():.2e}; stationarity residual max {max(kkt):.2e}; "
         f"iterations device {_np(sim.data.solver_niter).mean():.1f} restatement {ora.solver_niter.mean():.1f}; mu scale {mu_scale:.3f}")
   # measured (profiles/r05_v20_elliptic.txt): exact search median <= 2.3e-6, max <= 2.1e-5; grid search median <= 2.7e-6, max <= 9.8e-5
-  assert np.median(err) < 1e-5 and err.max() < (4e-4 if lsp else 8e-5), err
-  assert max(kkt) < (2e-2 if lsp else 5e-5)  # (the grid search stops where no candidate step improves: stationary to the grid only)
+  assert np.median(err) < 1e-5 and err.max() < (4e-4 if lsp else (1e-4 if rough else 8e-5)), err  # (rough, measured: 2.6e-6 / 2.6e-5)
+  assert max(kkt) < (2e-2 if lsp else (1.5e-4 if rough else 5e-5))  # (the grid search stops where no candidate step improves: stationary to the grid only)
   # ---- a short rollout (stage launches: constraint-cone, solve-cone, integrate)
   for _ in range(10):
     sim.step()
