@@ -205,6 +205,49 @@ def test_elliptic_many_rows_and_the_layout_without_M(njmax, lsp):
     assert np.isfinite(_np(sim.data.qpos)).all() and np.median(perr) < (5e-5 if lsp else 5e-6), perr
 
 
+@pytest.mark.parametrize("lsp", [False, True], ids=["exact_ls", "grid_ls"])
+def test_elliptic_on_the_parity_gates_rollout_states(lsp):
+  """The distribution over all 256 rollout states of the pyramid's parity gate (G1 velocity-flat under its task events: standing,
+  pushed, fallen and self-colliding robots, per-world foot friction, each with its own warm start), elliptic cones, device against the
+  fp64 restatement: forward() and one step."""
+  import torch
+
+  from mjlab_amd import mjcf, robots
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  z = np.load(ROOT / "tests" / "golden" / "rollout_states_g1_velocity_flat.npz")
+  model = copy.deepcopy(robots.load_model("g1_velocity_flat"))
+  model.opt.cone = mjcf.CONE_ELLIPTIC
+  n = z["qpos"].shape[0]
+  sim = Simulation(n, SimulationCfg(njmax=300, use_graph=False, ls_parallel=lsp), model, "cuda:0")
+  ora = OracleSim(model, n, njmax=300, precision="f64", ls_parallel=lsp)
+  sim.expand_model_fields(["geom_friction"])
+  sim.model.geom_friction[:] = torch.from_numpy(z["dr_geom_friction"].astype(np.float32)).cuda()
+  ora.expand_model_field("geom_friction")[:] = z["dr_geom_friction"]
+
+  def load():
+    for f in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+      getattr(sim.data, f)[:] = torch.from_numpy(z[f].astype(np.float32)).cuda()
+      getattr(ora, f)[:] = z[f].astype(np.float32)
+
+  load()
+  sim.forward()
+  ora.forward(nthread=8)
+  assert np.array_equal(_np(sim.data.nefc).ravel(), ora.nefc.ravel())
+  err = _per_world(_np(sim.data.qacc), ora.qacc)
+  load()
+  sim.step()
+  ora.step(1, nthread=8)
+  verr = _per_world(_np(sim.data.qvel), ora.qvel)
+  perr = _per_world(_np(sim.data.qpos), ora.qpos)
+  q = lambda e: (float(np.median(e)), float(np.percentile(e, 99)), float(e.max()))  # noqa: E731
+  print(f"\nelliptic, 256 rollout states, lsp {lsp}: qacc median / p99 / max {q(err)[0]:.2e} / {q(err)[1]:.2e} / {q(err)[2]:.2e}; one step: qvel {q(verr)[0]:.2e} / {q(verr)[1]:.2e} / {q(verr)[2]:.2e}, "
+        f"qpos {q(perr)[0]:.2e} / {q(perr)[1]:.2e} / {q(perr)[2]:.2e}; iterations device {_np(sim.data.solver_niter).mean():.2f} restatement {ora.solver_niter.mean():.2f}")
+  # literals: measured x ~3 (profiles/r05_v35_elliptic_gate.txt)
+  assert q(err)[0] < 8e-6 and q(err)[1] < (1.2e-4 if lsp else 4e-5) and q(err)[2] < (3e-4 if lsp else 5e-5), q(err)
+  assert q(perr)[0] < 3e-7 and q(perr)[2] < (5e-5 if lsp else 1.2e-6), q(perr)
+
+
 def test_elliptic_rows_that_do_not_fit_are_dropped_like_the_restatement():
   """njmax smaller than the rows the state wants: a cone's three rows fit together or not at all, both sides drop the same contacts and
   say so (data.overflow, MJLAB_OVF_NJMAX); and a state without contacts (nefc = limits only / 0) goes through the cone kernels too."""
