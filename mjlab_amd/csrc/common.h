@@ -155,9 +155,6 @@ __device__ __forceinline__ void global_to_lds(float* dst, const float* src, int 
 // sits on the 128-register cap (MJLAB_COPY_BATCH above buys the same overlap with registers and loses it again to spills).  The
 // compiler counts these loads (vmcnt) and waits before the first LDS access that follows; copies only: results are bit-identical.
 // MJLAB_GLDS bit 0: the solve stage's load of M; bit 1: the other stages' prologue copies.
-#ifndef MJLAB_GLDS
-#define MJLAB_GLDS 3
-#endif
 typedef __attribute__((address_space(1))) const void* glds_src_t;
 typedef __attribute__((address_space(3))) void* glds_dst_t;
 __device__ __forceinline__ void glds_to_lds(float* dst, const float* src, int n, int lane) {
@@ -347,13 +344,8 @@ __device__ __forceinline__ bool dof_in_chain(const Model& m, int body, int dof) 
 #ifndef MJLAB_CHOL_ACC
 #define MJLAB_CHOL_ACC 1
 #endif
-// the sweep's scheduling fences (between batches and between columns): experiment switch MJLAB_CHOL_NOBARRIER lets the
-// compiler's scheduler move one column's first multiply-adds under the previous column's pivot chain
-#ifdef MJLAB_CHOL_NOBARRIER
-#define CHOL_SCHED_BARRIER() ((void)0)
-#else
+// the sweep's scheduling fences (between batches and between columns)
 #define CHOL_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#endif
 template <int NVP>
 struct CholCfg {
   static constexpr int LD = (NVP % 8 == 4) ? NVP : NVP + 4;
@@ -430,16 +422,10 @@ struct CholSweep {
 #pragma unroll
     for (int q = 1; q < MJLAB_CHOL_ACC; ++q) if (2 * q < J) accs += acc[q];
     const float t = accs.x + accs.y;
-#ifdef MJLAB_CHOL_REFINE
-    const float djj = fmaxf(lane_bcast(t, J), MINVAL);
-    float invd = __builtin_amdgcn_rcpf(djj);  // v_rcp_f32 (1 ulp) + one Newton step
-    invd = invd * (2.f - djj * invd);
-#else
     // pivot clamped from below by one v_med3 (no canonicalising v_max pair), reciprocal = v_rcp_f32 (1 ulp):
     // 3 of the ~14 scalar-like instructions every column costs on top of its multiply-adds
     const float djj = __builtin_amdgcn_fmed3f(lane_bcast(t, J), MINVAL, 3.0e38f);
     const float invd = __builtin_amdgcn_rcpf(djj);
-#endif
     a[J] = t;
     const float lu = rowid > J ? t * invd : 0.f;
     row[J] = lu;
@@ -475,116 +461,8 @@ struct CholSweep {
 // producers call chol_pad_rows() once per kernel (zero fill; the factor keeps those rows'
 // off-diagonals at zero) and chol_pad_diag() after every (re)write of the matrix.
 // Caller synchronises before and after.
-// MJLAB_CHOL_RL (experiment, MEASURED SLOWER, not the default): RIGHT-LOOKING sweep, register resident, no LDS round trip inside
-// the factorization (round 4).  Result (profiles/r04_v5/ab_chol_rl.txt, phases_rl_*.txt): 13.4 k cycles per factorization on one
-// wave per SIMD against 9.4 k for the left-looking LDS-broadcast sweep -- a v_readlane feeding a multiply-add through an SGPR
-// costs ~21 cycles per pair in a single wave, far more than the ~7 its issue cycles suggest -- and 1.361 vs 1.210 ms per control
-// step.  Kept behind the switch as the record of that measurement.  The idea:
-// Measured on one wave per SIMD (profiles/r04_v3/latency_table.md) the left-looking sweep above takes 9.4 k cycles per 36 x 36
-// factorization: every batch of a column's dot product waits for an LDS broadcast read issued one batch earlier (~2.7 exposed round
-// trips per column), and the kernel's launch time is set by exactly such dependent latency.  Here lane i still owns row i in NVP
-// registers, but column J is eliminated the other way round: once its pivot is known every lane scales its own entry
-// (lu = t / D_J) and applies the rank-1 update a_i[k] -= t_i * Lu[k][J] to the columns k > J of its row, with Lu[k][J] taken
-// from lane k by v_readlane (a scalar operand of the multiply-add).  The only dependent chain is pivot -> reciprocal -> scale ->
-// update of column J+1 -> next pivot (~6 operations per column); the other NVP - J - 2 updates of a column are independent
-// multiply-adds that fill its latency.  Twice the instructions of the LDS-broadcast sweep (a v_readlane per multiply-add instead of
-// a 128-bit broadcast read per four), none of them waiting on memory.  Same LDL^T, same storage (unit-lower Lu with a zero
-// diagonal + 1 / D in LDS, as chol_solve reads it); the sums are formed in a different order, so results differ in the last bits.
-// FWD: the forward substitution of ONE right-hand side rides along (lane i owns b_i): once column J is scaled, b_i -= Lu[i][J] y_J
-// with y_J = b of lane J, which by then has received the updates of all columns < J.  One v_readlane + one multiply-add per
-// column on a chain of its own, next to the pivot chain -- the solve that follows the factorization then only scales by 1 / D and
-// substitutes backwards (chol_solve_back).
 template <int NVP>
-struct CholRL {
-  template <int J, bool FWD>
-  static __device__ __forceinline__ void col(float (&a)[NVP], lds_f32* row, lds_f32* s_invd, int rowid, float& b) {
-    const float t = a[J];
-    const float djj = __builtin_amdgcn_fmed3f(lane_bcast(t, J), MINVAL, 3.0e38f);
-    const float invd = __builtin_amdgcn_rcpf(djj);
-    const float lu = rowid > J ? t * invd : 0.f;
-    row[J] = lu;
-    s_invd[J] = invd;
-    if constexpr (FWD) b = fmaf(-lu, lane_bcast(b, J), b);  // lu = 0 for lanes <= J: their b is final
-    if constexpr (J + 1 < NVP) {
-#pragma unroll
-      for (int k = J + 1; k < NVP; ++k) a[k] = fmaf(-t, lane_bcast(lu, k), a[k]);
-      col<J + 1, FWD>(a, row, s_invd, rowid, b);
-    }
-  }
-};
-
-// MJLAB_CHOL_LOOKAHEAD: the same sweep with the dependence between consecutive columns cut down to its last term.  Column J + 1
-// needs Lu[J+1][0 .. J]; all but the last entry were final a whole column earlier, so their products (the bulk of the column) are
-// accumulated while column J's pivot chain (readlane, clamp, reciprocal, scale) is still in flight, from LDS reads issued before that
-// chain; the last entry, Lu[J+1][J] = t[J+1][J] / d[J], is formed as a wave-uniform value from a v_readlane of lane J+1's t and
-// the reciprocal -- no LDS write -> read round trip sits between two columns any more.  Products and sums are the ones of
-// CholSweep in the same order per partial sum (the last term of a column was the last subtraction of its chain there too), so the
-// factor is bit-identical.
-template <int NVP, int CB>
-struct CholSweepLA {
-  static constexpr int LD = CholCfg<NVP>::LD;
-  template <int R, int K0, int LIM>
-  static __device__ __forceinline__ void load_batch(lds_f32* A, float (&dst)[CB]) {
-#pragma unroll
-    for (int q = 0; q < CB / 4; ++q) {
-      if (K0 + 4 * q < LIM) {
-        const f32x4 v = *(lds_f32x4*)(A + R * LD + K0 + 4 * q);
-        dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
-      }
-    }
-  }
-  // the products k < LIM of column C (row C of Lu against this lane's t), batch BI; `cur` holds batch BI, `nxt` receives batch BI + 1
-  template <int C, int LIM, int BI>
-  static __device__ __forceinline__ void bulk(const float (&a)[NVP], f32x2& acc, float (&cur)[CB], float (&nxt)[CB], lds_f32* A) {
-    constexpr int NBL = (LIM + CB - 1) / CB, K0 = BI * CB;
-    if constexpr (BI < NBL) {
-      if constexpr (BI + 1 < NBL) load_batch<C, K0 + CB, LIM>(A, nxt);
-#pragma unroll
-      for (int k = 0; k < CB; k += 2) {
-        if (K0 + k + 1 < LIM) {
-          const f32x2 av = {a[K0 + k], a[K0 + k + 1]};
-          const f32x2 sv = {cur[k], cur[k + 1]};
-          acc -= av * sv;
-        } else if (K0 + k < LIM) {
-          acc.x -= a[K0 + k] * cur[k];  // (LIM odd: the even-indexed product of the pair whose odd one is the column's last term)
-        }
-      }
-      CHOL_SCHED_BARRIER();
-      bulk<C, LIM, BI + 1>(a, acc, nxt, cur, A);
-    }
-  }
-  // column J: `acc` holds a[J] minus the products k < J - 1, `e` = Lu[J][J-1] (wave-uniform)
-  template <int J>
-  static __device__ __forceinline__ void col(float (&a)[NVP], f32x2 acc, const float e, float (&cur)[CB], float (&oth)[CB], lds_f32* A, lds_f32* row,
-                                             lds_f32* s_invd, int rowid) {
-    if constexpr (J >= 1) {
-      if constexpr ((J - 1) & 1) acc.y -= a[J - 1] * e;
-      else acc.x -= a[J - 1] * e;
-    }
-    const float t = acc.x + acc.y;
-    // next column's row, entries k < J (final since the end of column J - 1), requested ahead of the pivot chain
-    if constexpr (J + 1 < NVP && J >= 1) load_batch<J + 1, 0, J>(A, cur);
-    const float tj = lane_bcast(t, J);
-    float tn = 0.f;
-    if constexpr (J + 1 < NVP) tn = lane_bcast(t, J + 1);
-    const float djj = __builtin_amdgcn_fmed3f(tj, MINVAL, 3.0e38f);
-    const float invd = __builtin_amdgcn_rcpf(djj);
-    a[J] = t;
-    const float lu = rowid > J ? t * invd : 0.f;
-    row[J] = lu;
-    s_invd[J] = invd;
-    if constexpr (J + 1 < NVP) {
-      const float en = tn * invd;  // = lane J+1's lu
-      f32x2 accn = (f32x2){a[J + 1], 0.f};
-      CHOL_SCHED_BARRIER();
-      bulk<J + 1, J, 0>(a, accn, cur, oth, A);
-      col<J + 1>(a, accn, en, cur, oth, A, row, s_invd, rowid);
-    }
-  }
-};
-
-template <int NVP, bool FWD = false>
-__device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int lane, float* fwd = nullptr) {
+__device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int lane) {
   constexpr int LD = CholCfg<NVP>::LD;
   lds_f32* A = (lds_f32*)A_;
   lds_f32* s_invd = (lds_f32*)s_invd_;
@@ -600,12 +478,6 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
     a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
   }
   (void)n;  // rows >= n are identity rows already (chol_pad_rows / chol_pad_diag by the producer)
-#ifdef MJLAB_CHOL_RL
-  float b = FWD ? *fwd : 0.f;
-  CholRL<NVP>::template col<0, FWD>(a, row, s_invd, rowid, b);
-  if (FWD) *fwd = b;
-#else
-  static_assert(!FWD, "the fused forward substitution exists in the right-looking sweep only");
   // Row j of Lu is consumed in batches of CB columns.  The batches are software pipelined
   // through two register buffers: while batch i feeds the FMAs, the reads of batch i+1 --
   // the next batch of the same row, or the first batch of the next row -- are already in
@@ -613,12 +485,7 @@ __device__ CHOL_INLINE void chol_factor(float* A_, float* s_invd_, int n, int la
   // row j+1 is requested before column j is written; its one missing entry Lu[j+1][j] is
   // patched in from lane j+1's register.
   float bufA[MJLAB_CB], bufB[MJLAB_CB];
-#ifdef MJLAB_CHOL_LOOKAHEAD
-  CholSweepLA<NVP, MJLAB_CB>::template col<0>(a, (f32x2){a[0], 0.f}, 0.f, bufA, bufB, A, row, s_invd, rowid);
-#else
   CholSweep<NVP, MJLAB_CB>::template col<0>(a, bufA, bufB, A, row, s_invd, rowid);
-#endif
-#endif
 }
 // Solves Lu D Lu^T x = b with the factor in LDS (as left by chol_factor); lane i owns
 // b_i / x_i (lanes >= n must pass 0).  Forward substitution uses row i of Lu, backward
@@ -649,21 +516,6 @@ __device__ CHOL_INLINE float chol_solve(const float* L_, const float* s_invd_, i
 #pragma unroll
     for (int k = NVP - 1; k >= 0; --k) b = fmaf(-at[k], lane_bcast(b, k), b);
   }
-  return b;
-}
-// The second half of chol_solve for a right-hand side whose forward substitution was done by chol_factor<NVP, true>: y -> x.
-template <int NVP>
-__device__ CHOL_INLINE float chol_solve_back(const float* L_, const float* s_invd_, int lane, float y) {
-  constexpr int LD = CholCfg<NVP>::LD;
-  const lds_f32* L = (const lds_f32*)L_;
-  const lds_f32* s_invd = (const lds_f32*)s_invd_;
-  const int li = lane < NVP ? lane : NVP - 1;
-  float b = y * s_invd[li];
-  float at[NVP];
-#pragma unroll
-  for (int k = 0; k < NVP; ++k) at[k] = L[k * LD + li];  // Lu[k][i]: zero for k <= i
-#pragma unroll
-  for (int k = NVP - 1; k >= 0; --k) b = fmaf(-at[k], lane_bcast(b, k), b);
   return b;
 }
 // ------------------------------------------------------------------------------------
@@ -704,9 +556,6 @@ __device__ CHOL_INLINE float chol_solve_back(const float* L_, const float* s_inv
 __host__ __device__ constexpr bool chol_use_tiles(int nvp) {
   return MJLAB_CHOL_TILES && (MJLAB_CHOL_TILES_MIN ? nvp >= MJLAB_CHOL_TILES_MIN : (nvp == 32 || nvp == 36 || nvp == 48 || nvp == 64));
 }
-#ifndef MJLAB_CHOL_PANEL
-#define MJLAB_CHOL_PANEL 0  // 0: panel x Linv^T as an MFMA (default), 1: substitution after three permlane swaps (experiment)
-#endif
 template <int NVP>
 struct CholT {
   static constexpr int NB = CholCfg<NVP>::NB, NT = NB * (NB + 1) / 2, LD = CholCfg<NVP>::LD;
@@ -766,18 +615,11 @@ __device__ __forceinline__ void tiles_add_M(f32x4 (&T)[CholT<NVP>::NT], const fl
 // Ends the tiles' live range: every register is "written" by an empty asm statement (no instruction), so that the allocator does not
 // keep 6 tiles alive around the solver loop on the paths where they are not refilled (the factor site is one place in a state
 // machine; path-insensitive liveness would carry them from one visit to the next).
-#ifndef MJLAB_TILES_KILL
-#define MJLAB_TILES_KILL 1
-#endif
 template <int NT>
 __device__ __forceinline__ void tiles_kill(f32x4 (&T)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-#if MJLAB_TILES_KILL == 2
-    T[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#elif MJLAB_TILES_KILL == 1
     asm volatile("" : "=v"(T[t]));
-#endif
   }
 }
 // tiles += diag(s[dof]) for dofs < nv (s in LDS: friction-loss curvature, the integrator's h * damping)
@@ -846,25 +688,6 @@ __device__ CHOL_INLINE void chol_factor_tiles(f32x4 (&T)[CholT<NVP>::NT], float*
       const float invl = kk == 0 ? i0 : kk == 1 ? i1 : kk == 2 ? i2 : i3;
       const bool below = jr > r || (jr == r && jq > kk);  // rows of the panel's own block that are eliminated later
       float Wm[NB], Lm[NB];
-#if MJLAB_CHOL_PANEL == 1
-      // ---- 2 (experiment, MEASURED SLOWER: profiles/r05_v5). the panel's rows through the block's unit factor by substitution: every
-      // lane gets the four panel entries of its row -- the values of lane column j in the four 16-lane groups, by one
-      // v_permlane16_swap and two v_permlane32_swap -- forms w_0..w_3 with the uniform factor entries and keeps its own group's
-#pragma unroll
-      for (int i = jb; i < NB; ++i) {
-        const unsigned xv = __float_as_uint(T[K::tix(jb, i)][r]);
-        const auto pq = __builtin_amdgcn_permlane16_swap(xv, xv, false, false);  // [x0 x0 x2 x2], [x1 x1 x3 x3] (rows of 16 lanes)
-        const auto e = __builtin_amdgcn_permlane32_swap(pq[0], pq[0], false, false);  // [x0 x0 x0 x0], [x2 x2 x2 x2]
-        const auto o = __builtin_amdgcn_permlane32_swap(pq[1], pq[1], false, false);  // [x1 x1 x1 x1], [x3 x3 x3 x3]
-        const float b0 = __uint_as_float(e[0]), b1 = __uint_as_float(o[0]), b2 = __uint_as_float(e[1]), b3 = __uint_as_float(o[1]);
-        const float w1 = b1 - b0 * l10;
-        const float w2 = (b2 - b0 * l20) - w1 * l21;
-        const float w3 = ((b3 - b0 * l30) - w1 * l31) - w2 * l32;
-        const float W = kk == 0 ? b0 : kk == 1 ? w1 : kk == 2 ? w2 : w3;
-        Wm[i] = (i > jb || below) ? W : 0.f;
-        Lm[i] = Wm[i] * invl;
-      }
-#else
       // ---- 2. W = panel x Linv^T, Linv = inverse of the block's unit factor (uniform, 6 multiply-adds): ONE MFMA per tile of the block
       // row.  A operand: row 4 q of a 16 x 4 matrix = Linv[q][:] (lanes 0 4 8 12 | 20 24 28 | 40 44 | 60), B operand: the panel's
       // register as it lies; register 0 of the result is W in operand layout (lane (g, j): row 16 i + j, column c(g)).  Masked to the
@@ -880,7 +703,6 @@ __device__ CHOL_INLINE void chol_factor_tiles(f32x4 (&T)[CholT<NVP>::NT], float*
         Wm[i] = (i > jb || below) ? o[0] : 0.f;
         Lm[i] = Wm[i] * invl;
       }
-#endif
       // ---- 3. columns c(kk) = 16 jb + 4 kk + r of the factor, every row (zero in the blocks above)
       const bool colok = 16 * jb + 4 * kk + r < NVP;
 #pragma unroll

@@ -388,7 +388,6 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
   // world coordinates) minus the origin
   float org[3];
   for (int k = 0; k < 3; ++k) org[k] = d.xorigin[(size_t)w * 3 + k];
-#if MJLAB_GLDS & 2
   {  // LDS-DMA (common.h): every lane names its source (static geom: world-frame array, moving geom: local-frame array); the
      // staged static geoms get the origin subtracted on chip after the barrier below -- the same subtraction, the same bits
     const int ng0 = m.size.nstaticgeom, ll = launder(lane);
@@ -398,28 +397,7 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
       if (k0 + ll < 3 * nl) __builtin_amdgcn_global_load_lds((glds_src_t)((e < 3 * ng0 ? gxw : gxr) + e), (glds_dst_t)(s_gx + k0), 4, 0, 0);
     }
   }
-#else
-  {
-    const int ng0 = m.size.nstaticgeom;
-    const float *gxw = d.geom_xpos + (size_t)w * ng * 3, *gxr = d.geom_xrel + (size_t)w * ng * 3;
-    for (int k0 = lane; k0 < 3 * nl; k0 += 64 * CPB) {  // batches of independent loads (common.h, MJLAB_COPY_BATCH)
-      float v[CPB];
-#pragma unroll
-      for (int u = 0; u < CPB; ++u) {
-        const int k = k0 + 64 * u, e = 3 * g0 + k, g = e / 3, c = e - 3 * g;
-        v[u] = 0.f;
-        if (k < 3 * nl) v[u] = g < ng0 ? gxw[e] - (c == 0 ? org[0] : c == 1 ? org[1] : org[2]) : gxr[e];
-      }
-#pragma unroll
-      for (int u = 0; u < CPB; ++u) { const int k = k0 + 64 * u; if (k < 3 * nl) s_gx[k] = v[u]; }
-    }
-  }
-#endif
-#if MJLAB_GLDS & 2
   glds_to_lds(s_gm, d.geom_xmat + ((size_t)w * ng + g0) * 9, 9 * nl, lane);
-#else
-  global_to_lds(s_gm, d.geom_xmat + ((size_t)w * ng + g0) * 9, 9 * nl, lane);
-#endif
   for (int l0 = lane; l0 < nl; l0 += 128) {  // two geoms per lane and trip: their 14 loads in flight together
     int gt[2];
     float gc[2][6];
@@ -440,7 +418,6 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
     }
   }
   __syncthreads();
-#if MJLAB_GLDS & 2
   {
     const int nst = 3 * (m.size.nstaticgeom - g0);  // staged static geoms (the plane of the flat scenes; none on the box terrains)
     if (nst > 0) {
@@ -448,7 +425,6 @@ __device__ __forceinline__ void stage_collision(const Model& m, const Data& d, c
       __syncthreads();
     }
   }
-#endif
   PROF_MARK(0);
   // ---- static pairs, pass 1: the cheap bounding test for every pair, survivors compacted IN PAIR
   // ORDER into an LDS list.  Few of the 502 G1 pairs are ever close, so the divergent narrow

@@ -347,14 +347,7 @@ __device__ __forceinline__ void cone_jac_mul(const ConeCtx& c, float x, float y,
   float x16[NB], y16[NB];
   gather16<NB>(x, x16, c.lane);
   gather16<NB>(TWO ? y : 0.f, y16, c.lane);
-#if MJLAB_JSKIP == 2
-  jac_mul<NVP, true>(sc, x16, y16, out, TWO ? out2 : out, (int*)c.s_vf);  // (masks written, never used: scratch)
-#elif MJLAB_JSKIP == 1
-  int all = (1 << NB) - 1;
-  jac_mul<NVP, true>(sc, x16, y16, out, TWO ? out2 : out, all);
-#else
   jac_mul<NVP, TWO>(sc, x16, y16, out, out2);
-#endif
 }
 
 // BIG: this world has more rows than fit next to M: all njmax rows in LDS instead, M from global memory

@@ -203,49 +203,6 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
       for (int k = 0; k < 4; ++k) s_lquat[4 * b + k] = quat[k];
     }
     __syncthreads();
-#ifndef MJLAB_KIN_DOUBLE
-#define MJLAB_KIN_DOUBLE 0  // experiment: the ancestors composed by pointer doubling, log2(depth) rounds instead of a walk of depth steps; profiles/r05_v23/ab_kin_double.txt
-#endif
-#if MJLAB_KIN_DOUBLE
-    // (2) pointer doubling: every body keeps its pose relative to an ancestor A (first its parent) and A's id; a round composes it with
-    // A's own record and jumps to A's ancestor, so after ceil(log2(depth)) rounds every pose is relative to the world.  Other
-    // association of the same products: not bit-identical to the walk.
-    float ppos[3] = {0.f, 0.f, 0.f}, pquat[4] = {1.f, 0.f, 0.f, 0.f};  // pose of this body's PARENT
-    {
-      int anc = (lane < nb && lane > 0) ? pid : 0;
-      for (int span = 1; span < m.size.nlevel; span <<= 1) {  // wave-uniform
-        float ap[3] = {0.f, 0.f, 0.f}, aq[4] = {1.f, 0.f, 0.f, 0.f};
-        int aa = 0;
-        if (anc > 0) {
-          for (int k = 0; k < 3; ++k) ap[k] = s_lpos[3 * anc + k];
-          for (int k = 0; k < 4; ++k) aq[k] = s_lquat[4 * anc + k];
-          aa = s_pid[anc];
-        }
-        __syncthreads();  // everybody has read this round's records
-        if (anc > 0) {
-          float t[3], q2[4];
-          rot_vec_quat(t, pos, aq);
-          for (int k = 0; k < 3; ++k) pos[k] = ap[k] + t[k];
-          mul_quat(q2, aq, quat);
-          for (int k = 0; k < 4; ++k) quat[k] = q2[k];
-          anc = aa;
-          for (int k = 0; k < 3; ++k) s_lpos[3 * b + k] = pos[k];
-          for (int k = 0; k < 4; ++k) s_lquat[4 * b + k] = quat[k];
-          s_pid[b] = anc;
-        }
-        __syncthreads();
-      }
-      if (lane < nb && lane > 0) {
-        normalize4(quat);
-        for (int k = 0; k < 4; ++k) s_lquat[4 * b + k] = quat[k];
-      }
-      __syncthreads();
-      if (lane < nb && lane > 0 && pid > 0) {  // the parent's world pose, for this body's joints
-        for (int k = 0; k < 3; ++k) ppos[k] = s_lpos[3 * pid + k];
-        for (int k = 0; k < 4; ++k) pquat[k] = s_lquat[4 * pid + k];
-      }
-    }
-#else
     // (2) compose upwards; the world body (0) is the identity
     float ppos[3] = {0.f, 0.f, 0.f}, pquat[4] = {1.f, 0.f, 0.f, 0.f};  // pose of this body's PARENT
     if (lane < nb && lane > 0) {
@@ -273,7 +230,6 @@ __device__ __forceinline__ bool stage_position(const Model& m, const Data& d, co
       for (int k = 0; k < 4; ++k) quat[k] = q2[k];
       normalize4(quat);
     }
-#endif
     __syncthreads();  // every lane has read the relative poses: the xmat area may be overwritten
     if (lane < 9) s_xmat[lane] = (lane % 4 == 0) ? 1.f : 0.f;  // world body (its slot held relative poses)
     if (lane < nb && lane > 0) {

@@ -24,9 +24,6 @@ __host__ __device__ inline int solve_nvp(int nv) {
 #endif
 // everything but the per-row arrays: H / factor, 1 / D, scratch (friction-loss arrays during the solve, 64 floats for the
 // integrator after it), packed M
-#ifndef MJLAB_JSKIP
-#define MJLAB_JSKIP 0  // block-sparse jac_mul (experiment; below)
-#endif
 __host__ __device__ inline int solve_lds_fixed_floats(const mjlab_sizes_t& s) {
   const int nvp = solve_nvp(s.nv), ld = (nvp % 8 == 4) ? nvp : nvp + 4;
   const int scratch = 4 * nvp > 64 ? 4 * nvp : 64;
@@ -51,15 +48,9 @@ __host__ __device__ inline int solve_lds_rows(const mjlab_sizes_t& s) {
 }
 __host__ __device__ inline int solve_lds_floats(const mjlab_sizes_t& s) {
   const int rows = solve_lds_rows(s);
-#if defined(MJLAB_JSKIP) && MJLAB_JSKIP == 2  // experiment: + one word per 4-row group behind the per-row arrays
-  const int all_rows = solve_lds_all_rows_floats(s) + (s.njmax + 3) / 4;
-  if (rows < 0) return all_rows;
-  const int with_m = solve_lds_fixed_floats(s) + 3 * rows + (rows + 3) / 4;
-#else
   const int all_rows = solve_lds_all_rows_floats(s);
   if (rows < 0) return all_rows;
   const int with_m = solve_lds_fixed_floats(s) + 3 * rows;
-#endif
   return with_m > all_rows ? with_m : all_rows;
 }
 
@@ -115,18 +106,8 @@ __device__ __forceinline__ float pick16(const float (&v)[NB], int lane) {
 constexpr int JU = MJLAB_JU;  // 4-row groups per unrolled block
 
 // out[r] = sum_i J[r][i] x_i (+ out2 for a second vector); lanes form 4 row groups x 16 columns
-// MJLAB_JSKIP (experiment, default 0): block-sparse pass.  A row touches the dofs of its bodies' chains only, so
-// most 16-column blocks of a 4-row group are all zero.  The warm start's pass (TWO) notes per group which blocks hold anything (a ballot
-// on the values it loads anyway; lane g of `gmask` keeps group g's three bits: no LDS, one register), the passes of the Newton loop load
-// the other blocks only.  Adds exact zeros otherwise: bit-identical.  Measured: profiles/r05_v23/ab_jskip.txt.
 template <int NVP, bool TWO>
-__device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x16)[CholCfg<NVP>::NB], const float (&y16)[CholCfg<NVP>::NB], float* out, float* out2
-#if MJLAB_JSKIP == 1
-                                        , int& gmask
-#elif MJLAB_JSKIP == 2
-                                        , int* gmask  // LDS, one word per 4-row group
-#endif
-) {
+__device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x16)[CholCfg<NVP>::NB], const float (&y16)[CholCfg<NVP>::NB], float* out, float* out2) {
   constexpr int NB = CholCfg<NVP>::NB;
   const int sub = c.lane >> 4, col = launder(c.lane & 15);
   for (int r0 = 0; r0 < c.nefc; r0 += 4 * JU) {
@@ -134,39 +115,15 @@ __device__ __forceinline__ void jac_mul(const SolveCtx<NVP>& c, const float (&x1
 #pragma unroll
     for (int u = 0; u < JU; ++u) {
       const int r = r0 + 4 * u + sub;
-#if MJLAB_JSKIP == 1
-      const int gi = (r0 >> 2) + u;  // wave-uniform
-      const int mk = (!TWO && gi < 64) ? __builtin_amdgcn_readlane(gmask, gi) : (1 << NB) - 1;
-#elif MJLAB_JSKIP == 2
-      const int mk = TWO ? (1 << NB) - 1 : __builtin_amdgcn_readfirstlane(gmask[(r0 >> 2) + u]);
-#endif
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
         const int cc = 16 * cb + col;
-#if MJLAB_JSKIP
-        jv[u][cb] = 0.f;
-        if ((mk >> cb) & 1) jv[u][cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
-#else
         jv[u][cb] = (r < c.nefc && cc < c.nv) ? c.J[(size_t)r * c.nv + cc] : 0.f;
-#endif
       }
     }
 #pragma unroll
     for (int u = 0; u < JU; ++u) {
       const int r = r0 + 4 * u + sub;
-#if MJLAB_JSKIP
-      if (TWO) {
-        int nzm = 0;
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) nzm |= (__ballot(jv[u][cb] != 0.f) != 0ull) ? (1 << cb) : 0;
-        const int gi = (r0 >> 2) + u;
-#if MJLAB_JSKIP == 1
-        gmask = c.lane == gi ? nzm : gmask;
-#else
-        if (c.lane == 0) gmask[gi] = nzm;
-#endif
-      }
-#endif
       float acc = 0.f, acc2 = 0.f;
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
@@ -199,111 +156,6 @@ __device__ __forceinline__ int build_active_list(const SolveCtx<NVP>& c, int* s_
     nact += __popcll(mask);
   }
   return nact;
-}
-// `am`: the active set of rows 0..63 / 64..127 as bit masks (what the low-rank correction of the factor compares, below).
-template <int NVP>
-__device__ __forceinline__ int build_active_list(const SolveCtx<NVP>& c, int* s_act, unsigned long long (&am)[2]) {
-  int nact = 0;
-  am[0] = am[1] = 0ull;
-  for (int r0 = 0; r0 < c.nefc; r0 += 64) {
-    const int r = r0 + c.lane;
-    const bool act = r < c.nefc && r >= c.nf && c.s_jar[r] < 0.f;  // friction-loss rows: friction_rows() below
-    const unsigned long long mask = __ballot(act);
-    if (act) s_act[nact + __popcll(mask & ((1ull << c.lane) - 1ull))] = r;
-    nact += __popcll(mask);
-    if (r0 == 0) am[0] = mask;
-    if (r0 == 64) am[1] = mask;
-  }
-  return nact;
-}
-
-// ---- LOW-RANK CORRECTION OF THE FACTOR (round 5, MJLAB_SMW).  A Newton iteration that moves 1..3 rows across their zone boundary changes
-// the Hessian by that many rank-1 terms, H_new = H_fact + sum_q s_q u_q u_q^T (u_q = row q of J, s_q = +D_q for a row that became
-// active, -D_q for one that left): 1.7 of the 4.2 refactorizations per world-step are of that kind (profiles/r04_v12).  Instead of a
-// new Hessian pass and a new factorization (~1 600 VALU instructions + 75 MFMAs) the factor in LDS is KEPT and the Newton direction
-// comes from the Sherman-Morrison-Woodbury identity
-//     H_new^-1 g = x0 - Z (S^-1 + U^T Z)^-1 U^T x0,     x0 = H_fact^-1 g,  Z = H_fact^-1 U
-// i.e. one substitution per changed row when the set of changed rows changes (Z goes to LDS: the friction-loss scratch, idle in worlds
-// without such rows), and per iteration <= 3 dot products, a 3 x 3 solve with wave-uniform numbers and <= 3 multiply-adds.  The
-// correction set is the difference between the CURRENT active set and the one the factor was built for (bit masks of rows 0..127), so
-// small changes accumulate until more than 3 rows differ -- then, or when the 3 x 3 system is ill-conditioned, the Hessian is rebuilt
-// and refactored as before.  Exact in exact arithmetic; in fp32 another rounding of the same direction.
-// MEASURED (profiles/r05_v17, r05_v18), NOT THE DEFAULT: 1.4 of the 5.2 counted factorizations per world-step go away (2.2 iterations run
-// on a corrected factor), but the corrected directions are noisier -- a row that becomes ACTIVE is stiff (D ~ 1e3..1e5), the
-// uncorrected x0 is large along it and the correction subtracts it again -- so the solver needs 2.7-3 % more Newton iterations (4.68 ->
-// 4.80 in the bench rollout; the parity gate's bound on the iteration count trips on the tracking scene), the kernel allocates 27
-// spilled VGPRs instead of 16, and against the default build 4096 worlds step at the same rate (3.395 against 3.397 M env-steps/s; the
-// +1.4 % of the first A/B was against a base build that the new code paths had perturbed).  MJLAB_SMW=2 corrects REMOVED rows only
-// (no cancellation: iterations unchanged, 4.69) and is 0.6 % slower.  A factor UPDATE (mju_cholUpdate's recurrence) would not cancel,
-// but on this storage it is a 36-step sweep of ~12 instructions + 2 LDS accesses per column and row: no cheaper than the panels.
-#ifndef MJLAB_SMW
-#define MJLAB_SMW 0
-#endif
-struct SmwState {
-  unsigned long long fact[2];  // active set the factor in LDS belongs to
-  unsigned long long diff[2];  // rows whose activity differs from it (the correction set); 0 = none
-  int n;                       // number of correction rows (0..3)
-  int row[3];
-  float ki[6];                 // inverse of K = S^-1 + U^T Z (symmetric: 00 01 02 11 12 22), padded with identity rows.  (Parked in LDS instead
-                               // -- six fewer values live around the Newton loop -- the kernel allocates WORSE: 47 spilled VGPRs against 27.)
-};
-// Z_q = H_fact^-1 u_q and K^-1 for the rows of `diff`; returns false when K is too ill-conditioned to trust (caller refactors).
-template <int NVP>
-__device__ __forceinline__ bool smw_setup(const SolveCtx<NVP>& c, SmwState& sw, const unsigned long long (&now)[2], const unsigned long long (&diff)[2], int nd,
-                                          float* s_z) {
-  unsigned long long lo = diff[0], hi = diff[1];
-  float u[3], z[3], si[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    u[q] = 0.f; z[q] = 0.f; si[q] = 1.f; sw.row[q] = 0;
-    if (q < nd) {
-      int r;
-      if (lo) { r = (int)__builtin_ctzll(lo); lo &= lo - 1ull; }
-      else { r = 64 + (int)__builtin_ctzll(hi); hi &= hi - 1ull; }
-      const bool added = r < 64 ? ((now[0] >> r) & 1ull) != 0ull : ((now[1] >> (r - 64)) & 1ull) != 0ull;
-      const float Dr = c.s_D[r];
-      si[q] = added ? 1.f / Dr : -1.f / Dr;
-      sw.row[q] = r;
-      u[q] = c.lane < c.nv ? c.J[(size_t)r * c.nv + launder(c.lane)] : 0.f;
-      z[q] = chol_solve_tiles<NVP>(c.s_H, c.s_invd, c.lane, u[q]);
-      if (c.lane < NVP) s_z[q * NVP + c.lane] = z[q];
-    }
-  }
-  // K = S^-1 + U^T Z (symmetric), identity where q >= nd
-  const float k00 = si[0] + wave_sum(u[0] * z[0]);
-  float k01 = 0.f, k11 = 1.f, k02 = 0.f, k12 = 0.f, k22 = 1.f;
-  if (nd > 1) { k01 = wave_sum(u[0] * z[1]); k11 = si[1] + wave_sum(u[1] * z[1]); }
-  if (nd > 2) { k02 = wave_sum(u[0] * z[2]); k12 = wave_sum(u[1] * z[2]); k22 = si[2] + wave_sum(u[2] * z[2]); }
-  // inverse by cofactors; the determinant against the product of the diagonal tells how far K is from singular
-  const float c00 = k11 * k22 - k12 * k12, c01 = k02 * k12 - k01 * k22, c02 = k01 * k12 - k02 * k11;
-  const float det = k00 * c00 + k01 * c01 + k02 * c02;
-  const float scale = fabsf(k00 * k11 * k22);
-  if (!(fabsf(det) > 1e-4f * scale) || !(scale > 0.f)) return false;
-  const float id = 1.f / det;
-  sw.ki[0] = c00 * id; sw.ki[1] = c01 * id; sw.ki[2] = c02 * id;
-  sw.ki[3] = (k00 * k22 - k02 * k02) * id; sw.ki[4] = (k01 * k02 - k00 * k12) * id; sw.ki[5] = (k00 * k11 - k01 * k01) * id;
-  sw.diff[0] = diff[0]; sw.diff[1] = diff[1]; sw.n = nd;
-  return true;
-}
-// x0 = H_fact^-1 g  ->  H_new^-1 g
-template <int NVP>
-__device__ __forceinline__ float smw_apply(const SolveCtx<NVP>& c, const SmwState& sw, const float* s_z, float x0) {
-  float t[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-    if (q < sw.n) {
-      const float uq = c.lane < c.nv ? c.J[(size_t)sw.row[q] * c.nv + launder(c.lane)] : 0.f;
-      t[q] = wave_sum(uq * x0);
-    }
-  const float c0 = sw.ki[0] * t[0] + sw.ki[1] * t[1] + sw.ki[2] * t[2];
-  const float c1 = sw.ki[1] * t[0] + sw.ki[3] * t[1] + sw.ki[4] * t[2];
-  const float c2 = sw.ki[2] * t[0] + sw.ki[4] * t[1] + sw.ki[5] * t[2];
-  const int li = c.lane < NVP ? c.lane : NVP - 1;
-  float x = x0;
-  if (sw.n > 0) x -= c0 * s_z[li];
-  if (sw.n > 1) x -= c1 * s_z[NVP + li];
-  if (sw.n > 2) x -= c2 * s_z[2 * NVP + li];
-  return x;
 }
 
 template <int NVP, bool WITH_H>
@@ -346,19 +198,15 @@ __device__ __forceinline__ float hessian_accum(const SolveCtx<NVP>& c, f32x4 (&a
         // (a left-foot contact of the G1: 12 of 35, all in the first 16-column block), so the tiles of a 16-column block that is all
         // zero in this 4-row group are skipped -- decided by a ballot on the values just loaded, no per-row mask to store or fetch.
         // Adds exact zeros otherwise: results are bit-identical.  1.280 -> 1.260 ms per control step (profiles/r03_v9/ab_hskip.txt)
-#ifndef MJLAB_NO_HSKIP
         bool nz[NB];
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) nz[cb] = __ballot(x[u][cb] != 0.f) != 0ull;
-#endif
         int t = 0;
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
           for (int Jb = 0; Jb <= I; ++Jb) {
-#ifndef MJLAB_NO_HSKIP
             if (nz[I] && nz[Jb])
-#endif
             {
               if constexpr (chol_use_tiles(NVP))  // UPPER tiles U(Jb, I) = H[16 Jb + ..][16 I + ..] (the layout chol_factor_tiles eliminates in, common.h)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[Jb], x[u][I], acc[t], 0, 0, 0);
@@ -682,11 +530,7 @@ __device__ __forceinline__ float grad_noise(float ulps, float scale, bool own, f
 #define MJLAB_INOISE 0.f
 #endif
 #define IMPROVEMENT_FLOOR fmaxf(tol, c.noise_ulps * (MJLAB_INOISE) * 5.9604645e-8f * scale * fabsf(cost))
-#ifndef MJLAB_NO_LSDIFF_COST
 #define LS_BY_DIFFERENCES ((m.opt.flags & (MJLAB_OPT_LS_PARALLEL | MJLAB_OPT_LS_LITERAL_COST)) == MJLAB_OPT_LS_PARALLEL)
-#else  // (round-3 experiment build: the search by differences, the improvement from two totals)
-#define LS_BY_DIFFERENCES false
-#endif
 #define IMPROVEMENT (LS_BY_DIFFERENCES ? -scale * ls_diff : scale * (oldcost - cost))
 // BIG: this world has more rows than fit in LDS next to M: all njmax rows in LDS instead, M from global memory
 // CG: mjSOL_CG -- no Hessian; the direction is M^-1 grad (the factor of M from ST_SMOOTH stays in LDS for the whole solve)
@@ -726,26 +570,12 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
   const int maxiter = m.opt.iterations, lsmax = m.opt.ls_iterations;
   const int nefc = do_solve ? d.nefc[w] : 0;
   c.nefc = nefc;
-#ifdef MJLAB_NO_FRICTIONLOSS  // experiment builds: the cost of the friction-loss branches in a model without such rows
-  c.nf = 0;
-#else
   c.nf = (do_solve && (m.opt.flags & MJLAB_OPT_FRICTIONLOSS)) ? d.nf[w] : 0;
-#endif
   float qacc = 0.f, fc = 0.f, qas = 0.f, Ma = 0.f, cost = 0.f, gauss = 0.f, rhs = 0.f;
   float cg_search = 0.f, cg_grad = 0.f, cg_Mgrad = 0.f;  // CG: the previous direction, gradient and M^-1 gradient
   int iter = 0, state;
   bool need_factor = true;
-#if MJLAB_JSKIP == 1
-  int jskip_mask = (1 << NB) - 1;  // lane g: the non-zero 16-column blocks of row group g (jac_mul)
-#elif MJLAB_JSKIP == 2
-  int* jskip_mask = (int*)(s_vec + (4 * NVP > 64 ? 4 * NVP : 64) + (BIG ? 0 : NVP * (NVP + 1) / 2));  // (the end of the block: solve_lds_floats)
-#endif
   // low-rank correction of the Newton factor (above): tile factorization, worlds whose rows fit the masks, no friction-loss rows
-#if MJLAB_SMW
-  constexpr bool SMW = TILES && !BIG && !CG;
-  SmwState sw;
-  sw.fact[0] = sw.fact[1] = sw.diff[0] = sw.diff[1] = 0ull; sw.n = 0;
-#endif
   PROF_INIT();
 
   if (do_solve) {
@@ -760,17 +590,12 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
     if (BIG) {
       dense_global_to_lds(c.s_H, c.M, nv, ld, lane, true);
     } else {
-#if MJLAB_GLDS & 1
       // every trip of the load in flight at once, straight into the packed copy (common.h: glds_dense_to_packed); the dense
       // lower triangle the factorization reads is laid out from that copy on chip
       glds_dense_to_packed(c.s_M, c.M, nv, lane);
       for (int k = ((nv * (nv + 1)) >> 1) + lane; k < NVP * (NVP + 1) / 2; k += 64) c.s_M[k] = 0.f;
       __syncthreads();
       packed_to_lds(c.s_H, c.s_M, nv, ld, lane);
-#else
-      dense_global_to_lds_packed(c.s_H, c.s_M, c.M, nv, ld, lane);
-      for (int k = ((nv * (nv + 1)) >> 1) + lane; k < NVP * (NVP + 1) / 2; k += 64) c.s_M[k] = 0.f;
-#endif
     }
     chol_pad_rows<NVP>(c.s_H, nv, lane);
     chol_pad_diag<NVP>(c.s_H, nv, lane);
@@ -835,21 +660,6 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
 
     float x = qacc;
     if (!skip_solve) {
-#if defined(MJLAB_CHOL_RL) && defined(MJLAB_CHOL_FWD)
-      if (need_factor) {  // the right-hand side is known when the factorization starts: its forward substitution rides along
-        __syncthreads();
-        float y = rhs;
-        chol_factor<NVP, true>(c.s_H, c.s_invd, nv, lane, &y);
-        __syncthreads();
-        PROF_MARK(12);
-        PROF_COUNT(14);
-        x = chol_solve_back<NVP>(c.s_H, c.s_invd, lane, y);
-      } else {
-        x = chol_solve<NVP>(c.s_H, c.s_invd, lane, rhs);
-      }
-      PROF_MARK(13);
-      PROF_COUNT(15);
-#else
       if constexpr (TILES) {
       if (need_factor) {
         // The two factorizations of M per pass (ST_SMOOTH: M, ST_INTEGRATE: M + h diag): the matrix goes from the packed copy on
@@ -868,11 +678,6 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         PROF_COUNT(14);
       }
       x = chol_solve_tiles<NVP>(c.s_H, c.s_invd, lane, rhs);
-#if MJLAB_SMW
-      if constexpr (SMW) {
-        if (state == ST_NEWTON && sw.n > 0) x = smw_apply<NVP>(c, sw, c.s_fl, x);
-      }
-#endif
       PROF_MARK(13);
       PROF_COUNT(15);
       } else {
@@ -887,7 +692,6 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
       PROF_MARK(13);
       PROF_COUNT(15);
       }
-#endif
     }
 
     if (state == ST_INTEGRATE) {
@@ -943,11 +747,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           float x16[NB], y16[NB];
           gather16<NB>(ws, x16, lane);
           gather16<NB>(qas, y16, lane);
-#if MJLAB_JSKIP
-          jac_mul<NVP, true>(c, x16, y16, c.s_jar, c.s_jv, jskip_mask);
-#else
           jac_mul<NVP, true>(c, x16, y16, c.s_jar, c.s_jv);
-#endif
         }
         __syncthreads();
         for (int r = launder(lane); r < nefc; r += 64) { const float ar = d.efc_aref[wr + r]; c.s_jar[r] -= ar; c.s_jv[r] -= ar; }
@@ -972,13 +772,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         {
           __syncthreads();
           int* s_act = (int*)c.s_jv;
-#if MJLAB_SMW
-          unsigned long long am[2];
-          const int nact = build_active_list<NVP>(c, s_act, am);
-          sw.fact[0] = am[0]; sw.fact[1] = am[1]; sw.n = 0;
-#else
           const int nact = build_active_list<NVP>(c, s_act);
-#endif
           __syncthreads();
           f32x4 htile[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, !CG>(c, htile, s_act, nact);
@@ -1020,11 +814,7 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
           float x16[NB];
           gather16<NB>(search, x16, lane);
           __syncthreads();
-#if MJLAB_JSKIP
-          jac_mul<NVP, false>(c, x16, x16, c.s_jv, c.s_jv, jskip_mask);
-#else
           jac_mul<NVP, false>(c, x16, x16, c.s_jv, c.s_jv);
-#endif
         }
         __syncthreads();
         c.quad_gauss[0] = gauss;
@@ -1076,47 +866,9 @@ __device__ __forceinline__ void stage_solve_impl(const Model& m, const Data& d, 
         // out so that the 24 tile registers are live only inside the branch that needs them.)
         iter++;
         int* s_act = (int*)c.s_jv;  // J search is dead until the next line search
-#if !MJLAB_SMW
         const int nact = build_active_list<NVP>(c, s_act);
         __syncthreads();
         const bool refactor = !CG && any_changed;
-#else
-        unsigned long long am[2];
-        const int nact = build_active_list<NVP>(c, s_act, am);
-        __syncthreads();
-        bool refactor = !CG && any_changed;
-        if constexpr (SMW) {
-          if (c.nf == 0 && nefc <= 128) {
-            // the factor in LDS belongs to the active set sw.fact: 0 rows differ -> it is this Hessian's; 1..3 -> kept and corrected;
-            // more (or an ill-conditioned correction) -> rebuilt
-            const unsigned long long df[2] = {am[0] ^ sw.fact[0], am[1] ^ sw.fact[1]};
-            const int nd = __popcll(df[0]) + __popcll(df[1]);
-            refactor = false;
-            if (nd == 0) {
-              sw.n = 0;
-#if MJLAB_SMW == 2  // removals only: a row that LEFT the active set is corrected without cancellation (x0 is small along it, the correction adds)
-            } else if (nd <= 3 && (df[0] & am[0]) == 0ull && (df[1] & am[1]) == 0ull) {
-#else
-            } else if (nd <= 3) {
-#endif
-              if (!(sw.n == nd && sw.diff[0] == df[0] && sw.diff[1] == df[1])) {
-                __syncthreads();
-                if (!smw_setup<NVP>(c, sw, am, df, nd, c.s_fl)) refactor = true;
-                __syncthreads();
-#ifdef MJLAB_PROFILE  // (slots 1 and 4 carry no phase: corrections set up / iterations that ran on a corrected factor)
-                prof_acc_[4] += 1.f;
-#endif
-              }
-#ifdef MJLAB_PROFILE
-              if (!refactor) prof_acc_[1] += 1.f;
-#endif
-            } else {
-              refactor = true;
-            }
-            if (refactor) { sw.fact[0] = am[0]; sw.fact[1] = am[1]; sw.n = 0; }
-          }
-        }
-#endif
         if (refactor) {
           f32x4 htile[NB * (NB + 1) / 2];
           fc = hessian_accum<NVP, true>(c, htile, s_act, nact);

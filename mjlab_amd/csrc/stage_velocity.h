@@ -78,13 +78,8 @@ __device__ __forceinline__ void stage_velocity(const Model& m, const Data& d, co
   const float* ctrl = d.ctrl + (size_t)w * nu;
   ActuatorConst act;
   if (lane < nu) load_actuator(act, m, ctrl, gain, biasprm, crange, frange, gear, lane);
-#if MJLAB_GLDS & 2
   glds_to_lds(s_qvel, d.qvel + (size_t)w * nv, nv, lane);
   glds_to_lds(s_cdof, d.cdof + (size_t)w * 6 * nv, 6 * nv, lane);
-#else
-  global_to_lds(s_qvel, d.qvel + (size_t)w * nv, nv, lane);
-  global_to_lds(s_cdof, d.cdof + (size_t)w * 6 * nv, 6 * nv, lane);
-#endif
   // second level
   const int v_type = m.jnt_type[v_jnt], v_dofadr = m.jnt_dofadr[v_jnt], v_qadr = m.jnt_qposadr[v_jnt];
   const float v_stiff = MF(jnt_stiffness)[v_jnt];
