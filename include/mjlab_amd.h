@@ -348,6 +348,13 @@ int mjlab_tile_field(void* dst, const void* src, long long nelem, int nworld, in
 /* Device self-test of the wave-level primitives (DPP reductions); synchronises `stream`. */
 int mjlab_selftest(void* stream);
 
+/* Diagnostics: fills the private segment (scratch) of `nblocks` waves on `stream`'s queue with poison words (NaN as a float, a
+ * non-canonical address as the high half of a pointer), 1280 B per lane -- more than any kernel's frame here.  Scratch is not
+ * cleared between kernels, so a kernel that reloads a spill slot it never wrote reads whatever ran before it; launched in front of a
+ * step this makes such a defect visible instead of dependent on process history (tests/test_gpu_scratch.py; DESIGN.md section 7:
+ * the round-5 "memory aperture violation" was such a reload, of a spill store the compiler had placed under EXEC == 0). */
+int mjlab_poison_scratch(int nblocks, void* stream);
+
 /* LDS bytes per workgroup of each stage kernel for this model (occupancy reporting). */
 int mjlab_lds_bytes(const mjlab_model_t* m, int stage);
 

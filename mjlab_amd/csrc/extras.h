@@ -246,6 +246,23 @@ __global__ void k_tile(T* dst, const T* src, long long nelem, long long total) {
 
 // self-test of the DPP reductions against the ds_bpermute versions
 #ifdef MJLAB_MAIN_TU
+// Scratch poisoning (mjlab_poison_scratch; round 6).  The private segment of a wave is not cleared between
+// kernels: a kernel that reloads a spill slot it never wrote sees zeros in a fresh process and the previous kernel's spills
+// afterwards -- exactly how a spill store that hipcc had placed under EXEC == 0 stayed invisible until two instantiations ran back to
+// back.  This kernel makes "the previous kernel" the worst case on purpose: every lane fills a frame larger than any kernel's of this
+// library with words that are a NaN as a float, ~2^31 as an index and a non-canonical address as the high half of a pointer, and
+// stays resident long enough for the launch to occupy every scratch slot it was given.  The run-time rotation of the index keeps the
+// array in scratch (a constant index would be promoted to registers).
+#define MJLAB_POISON_WORDS 320  // 1280 B per lane (tests/test_code_object.py: every kernel's frame <= 1024 B)
+__global__ __launch_bounds__(64) void k_poison_scratch(const unsigned pattern, const int rot, const long long spin, unsigned* sink) {
+  unsigned a[MJLAB_POISON_WORDS];
+  for (int i = 0; i < MJLAB_POISON_WORDS; ++i) a[(i + rot) % MJLAB_POISON_WORDS] = pattern + (unsigned)i;
+  const long long t0 = clock64();
+  while (clock64() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+  unsigned acc = 0;
+  for (int i = 0; i < MJLAB_POISON_WORDS; i += 7) acc ^= a[(i + 2 * rot) % MJLAB_POISON_WORDS];
+  if (acc == 0x9e3779b9u) *sink = acc;  // (never true for the patterns used; keeps the loads, hence the stores, alive)
+}
 __global__ void k_selftest(const float* in, int* nerr) {
   const float v = in[blockIdx.x * 64 + threadIdx.x];
   const float a = wave_sum(v), b = wave_sum_shfl(v);

@@ -223,9 +223,16 @@ __global__ __launch_bounds__(64, MJLAB_WPE) void k_control_step(const Model m_, 
 // constraint stage's ELL instantiation and, for the solve, the cone solver followed by the pyramid path's integrator with its solve
 // switched off (the hand-over of qacc / qfrc_constraint through the public arrays, as between any two stages).  Kernels of their own --
 // the bodies are spelled out a second time rather than shared through a template parameter -- so that the pyramid's kernels, the
-// measured path, are the code they were instruction for instruction.  Built WITHOUT register spills (two waves per SIMD, one for the 64-dof
-// instantiation): with spills -- three or four waves per SIMD -- instantiations of different sizes launched back to back faulted.
+// measured path, are the code they were instruction for instruction.  Built at two waves per SIMD (one for the 64-dof instantiation), without
+// spills.  The round-5 fault of the four-waves build is explained (profiles/r06_fault): hipcc placed ONE spill store of
+// k_substep_cone<32, true> in a divergent loop's exit block ahead of the `s_or_b64 exec` that restores the lanes, so it wrote nothing and the
+// reload returned stale scratch; tools/exec_zero_check.py finds that pattern in the code objects and tests/test_code_object.py forbids it.
 // ====================================================================================
+#ifdef MJLAB_CONE_WPE  // fault-bisect builds (tools/fault_bisect.sh): the cone kernels at MJLAB_CONE_WPE waves per SIMD, i.e. WITH register spills
+#define CONE_WAVES(NVP) MJLAB_CONE_WPE
+#else
+#define CONE_WAVES(NVP) ((NVP) <= 48 ? 2 : 1)
+#endif
 template <int NVP>
 __device__ __forceinline__ void fused_solve_cone(const int wsel_, const bool integrate, const int flags, float* smem) {
   { FUSED_ARGS; stage_solve_cone<NVP>(m, d, w, lane, smem); }
@@ -236,7 +243,7 @@ __device__ __forceinline__ void fused_solve_cone(const int wsel_, const bool int
   }
 }
 template <int NVP, bool INTEGRATE>
-__global__ __launch_bounds__(64, NVP <= 48 ? 2 : 1) void k_substep_cone(const Model m_, const Data d_, const int flags, const int nsub) {
+__global__ __launch_bounds__(64, CONE_WAVES(NVP)) void k_substep_cone(const Model m_, const Data d_, const int flags, const int nsub) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((flags & FLAG_MASK) && !d_.world_mask[blockIdx.x]) return;
   const int wsel_ = blockIdx.x;
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(64, NVP <= 48 ? 2 : 1) void k_substep_cone(const Mo
   if (!INTEGRATE && (flags & FLAG_SNAPSHOT)) { FUSED_ARGS; fold_snapshot(m, d, w, lane); }
 }
 template <int NVP>
-__global__ __launch_bounds__(64, NVP <= 48 ? 2 : 1) void k_control_step_cone(const Model m_, const Data d_, const mjlab_control_t c, const int fold) {
+__global__ __launch_bounds__(64, CONE_WAVES(NVP)) void k_control_step_cone(const Model m_, const Data d_, const mjlab_control_t c, const int fold) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wsel_ = __builtin_amdgcn_readfirstlane(c.world_order ? c.world_order[blockIdx.x] : (int)blockIdx.x);
   if (c.action) {

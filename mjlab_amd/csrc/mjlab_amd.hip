@@ -341,6 +341,17 @@ int mjlab_selftest(void* stream) {
   return 0;
 }
 
+int mjlab_poison_scratch(int nblocks, void* stream) {
+  static unsigned* sink = nullptr;
+  if (!sink && hipMalloc(&sink, sizeof(unsigned)) != hipSuccess) return fail(-13, "poison_scratch: hipMalloc");
+  if (nblocks <= 0) return fail(-14, "poison_scratch: nblocks must be positive");
+  // ~20 us of residency per wave (s_memtime ticks at 100 MHz): the whole launch is on the device at once up to 8192 waves
+  hipLaunchKernelGGL(k_poison_scratch, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, 0x7fc1a000u, 3, 2000LL, sink);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "k_poison_scratch launch failed");
+  return 0;
+}
+
 int mjlab_tile_field(void* dst, const void* src, long long nelem, int nworld, int elem_size, void* stream) {
   if (nelem <= 0 || nworld <= 0) return fail(-9, "tile: empty field");
   const long long total = nelem * nworld;

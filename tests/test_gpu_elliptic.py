@@ -319,7 +319,9 @@ def test_elliptic_launch_structures_are_bit_identical():
 def test_elliptic_kernels_of_different_sizes_back_to_back():
   """Kernels of different padded sizes, launch structures and line searches one after the other in one process (a kernel must not
   depend on what the previous one left in registers, LDS or scratch: a build of the fused cone kernels at four waves per SIMD passed
-  every test alone and faulted on the 32-dof instantiation right after the 36-dof one -- round 5; they run at two waves per SIMD)."""
+  every test alone and faulted on the 32-dof instantiation right after the 36-dof one -- round 5.  Root cause, round 6: a spill store
+  miscompiled to execute under EXEC == 0; the deterministic tests are tests/test_gpu_scratch.py -- scratch poisoned
+  in front of every launch -- and tests/test_code_object.py -- the instruction pattern; this one keeps the original sequence)."""
   import gc
 
   import torch
