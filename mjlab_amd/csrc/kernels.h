@@ -228,9 +228,9 @@ __global__ __launch_bounds__(64, MJLAB_WPE) void k_control_step(const Model m_, 
 // k_substep_cone<32, true> in a divergent loop's exit block ahead of the `s_or_b64 exec` that restores the lanes, so it wrote nothing and the
 // reload returned stale scratch; tools/exec_zero_check.py finds that pattern in the code objects and tests/test_code_object.py forbids it.
 // ====================================================================================
-#ifdef MJLAB_CONE_WPE  // fault-bisect builds (tools/fault_bisect.sh): the cone kernels at MJLAB_CONE_WPE waves per SIMD, i.e. WITH register spills
-#define CONE_WAVES(NVP) MJLAB_CONE_WPE
-#else
+#ifdef MJLAB_CONE_WPE  // waves per SIMD the cone kernels are compiled for: mjlab_amd/native.py tries 4, then 3, and keeps the first build whose
+#define CONE_WAVES(NVP) MJLAB_CONE_WPE  // code object is free of the EXEC == 0 spill-store miscompile (mjlab_amd/code_check.py)
+#else  // ... else this default: two waves per SIMD (one for the 64-dof instantiation), where nothing is spilled
 #define CONE_WAVES(NVP) ((NVP) <= 48 ? 2 : 1)
 #endif
 template <int NVP>

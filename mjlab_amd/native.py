@@ -69,12 +69,32 @@ def _build_locked(out: Path, objdir: Path, hipcc: str, verbose: bool, defines: t
   ]  # largest first: the 64-dof instantiations are the critical path; part 2 = the elliptic-cone kernels, a unit of their own so that
   # the inliner sees the pyramid's kernels (parts 0 and 1: the measured path) among exactly the callers they always had
 
+  cone_choice: dict[str, int] = {}
+
   def compile_one(unit):
     src, obj, extra = unit
-    cmd = [hipcc, *HIPCC_FLAGS, *dflags, *extra, "-c", str(src), "-o", str(obj)]
-    if verbose:
-      print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    # The elliptic-cone kernels (part 2) run 27 % faster at four waves per SIMD than at two (bench.py --cone elliptic: 2.10 against 1.65 M
+    # env-steps/s, profiles/r06_cone) -- but at that register budget hipcc miscompiles a spill store in SOME instantiations (it executes
+    # under EXEC == 0: DESIGN.md section 7, mjlab_amd/code_check.py).  So every cone unit is built for four waves, its code object is
+    # checked, and a unit that carries the pattern is rebuilt for three, then for the spill-free two (kernels.h: CONE_WAVES' default).
+    cone = "-DMJLAB_NVP_PART=2" in extra and not any(x.startswith("-DMJLAB_CONE_WPE") for x in dflags)
+    for wpe in ((4, 3, 0) if cone else (0,)):
+      cmd = [hipcc, *HIPCC_FLAGS, *dflags, *extra, *([f"-DMJLAB_CONE_WPE={wpe}"] if wpe else []), "-c", str(src), "-o", str(obj)]
+      if verbose:
+        print(" ".join(cmd), flush=True)
+      subprocess.run(cmd, check=True)
+      if not wpe:
+        break
+      from . import code_check
+
+      bad = code_check.fatal_hits(obj)
+      if not bad:
+        cone_choice[obj.stem] = wpe
+        break
+      if verbose:
+        print(f"{obj.name}: {sum(map(len, bad.values()))} spill store(s) ahead of their EXEC restore at {wpe} waves per SIMD ({', '.join(bad)}): rebuilding with fewer", flush=True)
+    if cone:
+      cone_choice.setdefault(obj.stem, 2)
 
   with ThreadPoolExecutor(max_workers=jobs or min(len(units), os.cpu_count() or 4)) as pool:
     list(pool.map(compile_one, units))
@@ -84,6 +104,10 @@ def _build_locked(out: Path, objdir: Path, hipcc: str, verbose: bool, defines: t
     print(" ".join(cmd), flush=True)
   subprocess.run(cmd, check=True)
   os.replace(tmp, out)  # (a process that has the old library mapped keeps its inode; nobody ever sees a half-written file)
+  if cone_choice:
+    import json
+
+    (objdir / "cone_waves_per_simd.json").write_text(json.dumps(dict(sorted(cone_choice.items())), indent=1) + "\n")
   return out
 
 

@@ -31,9 +31,11 @@ def test_every_kernel_fits_four_waves_per_simd(kernels):
       assert md["private_segment_fixed_size"] >= 1280, (name, md)
       continue
     if "_cone" in name and "k_constraint_cone" not in name:  # elliptic cones (stage_cone.h, kernels.h): kernels of their own off the measured path
-      # two waves per SIMD (one for the fused 64-dof instantiations), nothing spilled.  (The four-waves build of round 5 faulted because of ONE
-      # miscompiled spill store, not because of spilling: DESIGN.md section 7; test_no_spill_store_executes_ahead_of_its_exec_restore below.)
-      assert md["group_segment_fixed_size"] == 0 and md["vgpr_spill_count"] == 0, (name, md)
+      # The fused ones are built for four waves per SIMD where hipcc compiles that budget correctly, else for three, else for the spill-free
+      # two (native.py picks per translation unit with mjlab_amd/code_check.py; the round-5 fault was ONE miscompiled spill store, not
+      # spilling as such: DESIGN.md section 7; test_no_spill_store_executes_ahead_of_its_exec_restore below); k_solve_cone: two, spill-free.
+      assert md["group_segment_fixed_size"] == 0 and md["private_segment_fixed_size"] <= 1024, (name, md)
+      assert md["vgpr_spill_count"] == 0 or md["vgpr_count"] <= 168, (name, md)
       continue
     assert md["vgpr_count"] <= 128, (name, md)
     assert md["group_segment_fixed_size"] == 0, (name, md)  # LDS is laid out per model at launch (mjlab_lds_bytes)
@@ -95,3 +97,8 @@ def test_no_spill_store_executes_ahead_of_its_exec_restore():
   assert len(res) >= 40
   bad = {name: z.fatal(hits) for name, hits in res.items() if z.fatal(hits)}
   assert not bad, bad
+  # what the build chose for the cone units (written by native.build): the G1's size runs at four waves per SIMD
+  import json
+
+  choice = json.loads((ROOT / "mjlab_amd" / "csrc" / "build" / "libmjlab_amd" / "cone_waves_per_simd.json").read_text())
+  assert set(choice.values()) <= {2, 3, 4} and choice["nvp_36_2"] == 4, choice

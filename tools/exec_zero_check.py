@@ -27,153 +27,11 @@ shipped library.
 """
 from __future__ import annotations
 
-import re
-import subprocess
 import sys
-import tempfile
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parent))
-import code_object  # noqa: E402
-
-LLVM = code_object.LLVM
-MEM = ("scratch_", "global_", "flat_", "buffer_", "ds_")
-
-
-def disassemble(img: bytes) -> str:
-  with tempfile.TemporaryDirectory() as td:
-    f = Path(td) / "dev.co"
-    f.write_bytes(img)
-    return subprocess.run([str(LLVM / "llvm-objdump"), "-d", str(f)], capture_output=True, text=True).stdout
-
-
-def functions(dis: str) -> dict[str, list[tuple[int, str]]]:
-  """name -> [(address, instruction text)] in address order."""
-  out: dict[str, list[tuple[int, str]]] = {}
-  cur = None
-  for line in dis.splitlines():
-    m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)
-    if m:
-      cur = out.setdefault(m.group(2), [])
-      continue
-    if cur is None:
-      continue
-    m = re.match(r"^\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
-    if m and m.group(1):
-      cur.append((int(m.group(2), 16), m.group(1).strip()))
-  return out
-
-
-def writes_exec(ins: str) -> bool:
-  op, _, rest = ins.partition(" ")
-  if "saveexec" in op:
-    return True
-  dst = rest.split(",")[0].strip()
-  return dst in ("exec", "exec_lo", "exec_hi") and op.startswith("s_")
-
-
-def analyse(insts: list[tuple[int, str]]) -> list[tuple[int, str, str]]:
-  """-> [(address, instruction, how EXEC got to zero)] for memory instructions that may execute with EXEC == 0."""
-  index = {a: i for i, (a, _) in enumerate(insts)}
-  n = len(insts)
-  zero_in: list[str | None] = [None] * n  # reason string when EXEC may be zero on entry
-  work: list[int] = []
-
-  def push(i: int, why: str):
-    if 0 <= i < n and zero_in[i] is None:
-      zero_in[i] = why
-      work.append(i)
-
-  def target(a: int, ins: str) -> int | None:
-    m = re.match(r"s_c?branch\S*\s+(\d+)", ins)
-    if not m:
-      return None
-    simm = int(m.group(1))
-    if simm >= 0x8000:
-      simm -= 0x10000
-    return index.get(a + 4 + 4 * simm)
-
-  for i, (a, ins) in enumerate(insts):
-    if ins.startswith("s_cbranch_execnz"):
-      push(i + 1, f"fall-through of s_cbranch_execnz at {a:#x} (divergent loop exit)")
-    elif ins.startswith("s_cbranch_execz"):
-      t = target(a, ins)
-      if t is not None:
-        push(t, f"taken s_cbranch_execz at {a:#x}")
-  # basic-block leaders: branch targets and fall-throughs of branches
-  leader = set()
-  for i, (a, ins) in enumerate(insts):
-    if ins.startswith(("s_branch", "s_cbranch")):
-      t = target(a, ins)
-      if t is not None:
-        leader.add(t)
-      leader.add(i + 1)
-
-  def before_restore(i: int) -> bool:
-    """instruction i is followed, inside its basic block and before any other write of EXEC, by `s_or_b64 exec, exec, sN`: it sits in
-    the prologue of a join / loop-exit block, ahead of the instruction that gives the lanes back."""
-    for j in range(i + 1, n):
-      if j in leader:
-        return False
-      ins = insts[j][1]
-      if ins.startswith("s_or_b64 exec, exec,"):
-        return True
-      if writes_exec(ins) or ins.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")):
-        return False
-    return False
-
-  found = []
-  seen_report = set()
-  while work:
-    i = work.pop()
-    why = zero_in[i]
-    a, ins = insts[i]
-    if ins.startswith(MEM) and i not in seen_report:
-      seen_report.add(i)
-      found.append((a, ins, why + ("; AHEAD OF THE EXEC RESTORE of its block" if before_restore(i) else "")))
-    if writes_exec(ins):
-      continue  # EXEC rewritten: state unknown (not zero for our purpose)
-    if ins.startswith("s_endpgm"):
-      continue
-    if ins.startswith("s_branch"):
-      t = target(a, ins)
-      if t is not None:
-        push(t, why)
-      continue
-    if ins.startswith("s_cbranch_execnz"):  # EXEC == 0 here: not taken
-      push(i + 1, why)
-      continue
-    if ins.startswith("s_cbranch_execz"):  # EXEC == 0 here: taken
-      t = target(a, ins)
-      if t is not None:
-        push(t, why)
-      continue
-    if ins.startswith("s_cbranch"):  # scc / vcc branches: both ways
-      t = target(a, ins)
-      if t is not None:
-        push(t, why)
-    push(i + 1, why)
-  return sorted(found)
-
-
-def fatal(hits):
-  """The hits that are the miscompile: scratch STORES on a path where EXEC may be zero, ahead of their block's `s_or_b64 exec, exec, sN`."""
-  return [h for h in hits if h[1].startswith("scratch_store") and "AHEAD OF THE EXEC RESTORE" in h[2]]
-
-
-def check(path: Path, sub: str = "") -> dict[str, list[tuple[int, str, str]]]:
-  data = path.read_bytes()
-  imgs = [data] if path.suffix == ".co" else code_object.device_objects(path)
-  from concurrent.futures import ThreadPoolExecutor
-
-  res = {}
-  with ThreadPoolExecutor(max_workers=8) as pool:  # (llvm-objdump per code object: subprocesses, the threads only wait)
-    for dis in pool.map(disassemble, imgs):
-      for name, insts in functions(dis).items():
-        if sub in name and insts:
-          res[name] = analyse(insts)
-  return res
-
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from mjlab_amd.code_check import analyse, check, disassemble, fatal, functions, writes_exec  # noqa: E402,F401  (the analysis lives in the package: the build uses it)
 
 if __name__ == "__main__":
   lib = Path(sys.argv[1]) if len(sys.argv) > 1 else Path(__file__).resolve().parents[1] / "mjlab_amd" / "csrc" / "libmjlab_amd.so"
