@@ -107,7 +107,8 @@ def _build_locked(out: Path, objdir: Path, hipcc: str, verbose: bool, defines: t
   if cone_choice:
     import json
 
-    (objdir / "cone_waves_per_simd.json").write_text(json.dumps(dict(sorted(cone_choice.items())), indent=1) + "\n")
+    out.with_name(out.stem + ".cone_waves_per_simd.json").write_text(  # next to the library: travels with it, like the .so git-ignored
+json.dumps(dict(sorted(cone_choice.items())), indent=1) + "\n")
   return out
 
 

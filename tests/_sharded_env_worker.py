@@ -65,7 +65,7 @@ def main():
   from mjlab_amd import dist as mdist
   from mjlab_amd.graphed_env import GraphedRlEnv
 
-  n, steps = 6, 30
+  n, steps = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (6, 30)
   NG = n * WORLD
   info = mdist.init_from_env(envs_per_rank=n, backend="gloo")
   if rank == 0:

@@ -100,5 +100,7 @@ def test_no_spill_store_executes_ahead_of_its_exec_restore():
   # what the build chose for the cone units (written by native.build): the G1's size runs at four waves per SIMD
   import json
 
-  choice = json.loads((ROOT / "mjlab_amd" / "csrc" / "build" / "libmjlab_amd" / "cone_waves_per_simd.json").read_text())
+  choice = json.loads((ROOT / "mjlab_amd" / "csrc" / "libmjlab_amd.cone_waves_per_simd.json").read_text())
   assert set(choice.values()) <= {2, 3, 4} and choice["nvp_36_2"] == 4, choice
+  got = {n: md["vgpr_count"] for n, md in code_object.kernels(ROOT / "mjlab_amd" / "csrc" / "libmjlab_amd.so").items() if "k_control_step_coneILi36E" in n}
+  assert list(got.values()) == [128], got  # (and the library really is that build)

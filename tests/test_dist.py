@@ -1,16 +1,21 @@
-"""Env-sharded multi-process path on CPU (gloo, world_size 2): gather/scatter plumbing and
-rank-sharded physics (on the oracle) equal to the single-process run."""
+"""Env-sharded multi-process path on CPU (gloo, world_size 2, 4 and 8 -- the sizes the driver's scaling run uses): gather/scatter
+plumbing and rank-sharded physics (on the oracle) equal to the single-process run."""
 
 import os
 import sys
 from pathlib import Path
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parents[1]
+
+
+def _per_rank(world_size):
+  return 4 if world_size == 2 else 2
 
 
 def _worker(rank, world_size, port, out_dir):
@@ -20,16 +25,18 @@ def _worker(rank, world_size, port, out_dir):
   from mjlab_amd import robots
   from oracle.oracle import OracleSim
 
-  info = mdist.init_from_env(envs_per_rank=4, backend="gloo")
-  assert info.global_envs == 8 and info.env_slice == slice(rank * 4, rank * 4 + 4)
+  n = _per_rank(world_size)
+  N = n * world_size
+  info = mdist.init_from_env(envs_per_rank=n, backend="gloo")
+  assert info.global_envs == N and info.env_slice == slice(rank * n, rank * n + n)
   model = robots.load_model("go1_velocity_flat")
   rng = np.random.default_rng(123)  # identical global initial state on every rank
-  q = rng.normal(0, 0.05, (8, model.nq - 7))
-  sim = OracleSim(model, 4)
+  q = rng.normal(0, 0.05, (N, model.nq - 7))
+  sim = OracleSim(model, n)
   sim.reset(key=0)
   sim.qpos[:, 7:] += q[info.env_slice]
   # learner on rank 0 decides actions for all envs; ranks receive their slice
-  actions = torch.from_numpy(rng.uniform(-1, 1, (8, model.nu)).astype(np.float32)) if rank == 0 else None
+  actions = torch.from_numpy(rng.uniform(-1, 1, (N, model.nu)).astype(np.float32)) if rank == 0 else None
   mine = mdist.scatter_actions(info, actions, model.nu, "cpu")
   jn = model.actuator_trnid[:, 0]
   sim.ctrl[:] = model.key_qpos[0][model.jnt_qposadr[jn]] + 0.25 * mine.numpy().astype(np.float64)
@@ -38,10 +45,10 @@ def _worker(rank, world_size, port, out_dir):
   gathered = mdist.gather_rollout(info, rows)  # to the learner (rank 0) only
   assert (gathered is None) == (rank != 0)
   everywhere = mdist.gather_rollout(info, rows, to_all=True)
-  assert everywhere.shape == (8, model.nq + model.nv)
+  assert everywhere.shape == (N, model.nq + model.nv)
   if rank == 0:
     assert torch.equal(gathered, everywhere)
-  assert mdist.all_rank_values(float(rank), "cpu") == [0.0, 1.0]
+  assert mdist.all_rank_values(float(rank), "cpu") == [float(r) for r in range(world_size)]
   t = mdist.max_over_ranks(float(rank + 1), "cpu")
   assert t == float(world_size)
   mdist.barrier()
@@ -51,17 +58,20 @@ def _worker(rank, world_size, port, out_dir):
   dist.destroy_process_group()
 
 
-def test_two_rank_shard_equals_single_process(tmp_path):
-  port = 29511 + os.getpid() % 200
-  mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("world_size", [2, 4, 8])
+def test_rank_shards_equal_the_single_process(tmp_path, world_size):
+  """world_size 4 and 8: the first 8-GPU run must not be the first time eight ranks exchange anything."""
+  port = 29511 + os.getpid() % 200 + 7 * world_size
+  mp.spawn(_worker, args=(world_size, port, str(tmp_path)), nprocs=world_size, join=True)
   sys.path.insert(0, str(ROOT))
   from mjlab_amd import robots
   from oracle.oracle import OracleSim
 
+  N = _per_rank(world_size) * world_size
   model = robots.load_model("go1_velocity_flat")
   rng = np.random.default_rng(123)
-  q = rng.normal(0, 0.05, (8, model.nq - 7))
-  sim = OracleSim(model, 8)
+  q = rng.normal(0, 0.05, (N, model.nq - 7))
+  sim = OracleSim(model, N)
   sim.reset(key=0)
   sim.qpos[:, 7:] += q
   actions = np.load(tmp_path / "actions.npy")
@@ -163,25 +173,28 @@ def test_single_rank_passthrough():
   assert mdist.seed_for_rank(42, mdist.ShardInfo(3, 8, 3, 5)) == 45
 
 
-def test_sharded_tracking_environment_equals_the_single_process_batch(tmp_path):
-  """The FULL environment sharded: two gloo ranks, each with its slice of the reference's
+@pytest.mark.parametrize("world_size", [2, 4, 8])
+def test_sharded_tracking_environment_equals_the_single_process_batch(tmp_path, world_size):
+  """The FULL environment sharded: `world_size` gloo ranks, each with its slice of the reference's
   tracking task behind ``GraphedRlEnv(env, shard=...)`` over the oracle, against the single process' batch -- see
-  tests/_sharded_env_worker.py for what is compared after each of the 30 control steps."""
+  tests/_sharded_env_worker.py for what is compared after each control step.  world_size 2: 6 environments per rank, 30 steps;
+  4 and 8: 2 per rank, 40 steps."""
   import json
   import subprocess
 
   if not (ROOT.parent / "reference").exists():
-    import pytest
-
     pytest.skip("needs the reference tree (the environment classes are the reference's own)")
-  port = str(29911 + os.getpid() % 200)
+  port = str(29911 + os.getpid() % 200 + 7 * world_size)
   motion, out = str(tmp_path / "motion.npz"), str(tmp_path / "stats.json")
-  procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "_sharded_env_worker.py"), str(r), "2", port, motion, out], cwd=str(ROOT),
-                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+  n, steps = (6, 30) if world_size == 2 else (2, 40)
+  env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")  # (eight processes on eight cores)
+  procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "_sharded_env_worker.py"), str(r), str(world_size), port, motion, out, str(n), str(steps)],
+                            cwd=str(ROOT), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world_size)]
   outs = [p.communicate(timeout=1500) for p in procs]
   for p, (so, se) in zip(procs, outs):
     assert p.returncode == 0, se[-4000:]
   st = json.loads(Path(out).read_text())
   print(st)
   # the run must have exercised what the exchange is for: failures feeding the sampler, on one rank only in some steps
-  assert st["failed"] >= 4 and st["resets"] >= 4 and st["ended"] >= 4 and st["bin_failed_mass"] > 0 and st["steps_with_global_failures_on_one_rank_only"] >= 1, st
+  few = 4 if world_size == 2 else 2
+  assert st["failed"] >= few and st["resets"] >= few and st["ended"] >= few and st["bin_failed_mass"] > 0 and st["steps_with_global_failures_on_one_rank_only"] >= 1, st

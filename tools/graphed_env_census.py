@@ -68,6 +68,7 @@ class Census(TorchDispatchMode):
     super().__init__()
     self.ops = collections.Counter()
     self.by_owner = collections.defaultdict(collections.Counter)
+    self.who = collections.defaultdict(collections.Counter)  # operator -> (group: function) for the data-movement operators
 
   def __torch_dispatch__(self, func, types, args=(), kwargs=None):
     name = func.overloadpacket.__name__ if hasattr(func, "overloadpacket") else str(func)
@@ -75,6 +76,8 @@ class Census(TorchDispatchMode):
       grp, fn = owner_of_stack()
       self.by_owner[grp][fn] += 1
       self.ops[name] += 1
+      if name in ("copy_", "clone", "index", "index_put_", "cat", "stack", "repeat", "_to_copy", "index_select", "gather", "where", "masked_fill_", "fill_", "zero_"):
+        self.who[name][f"{grp.split(' (')[0]}: {fn}"] += 1
     return func(*args, **(kwargs or {}))
 
 
@@ -121,6 +124,9 @@ def main():
     for fn, k in sorted(fns.items(), key=lambda kv: -kv[1])[:40]:
       print(f"    {fn:66s} {k / steps:9.1f}")
   print(f"{'TOTAL (estimate of graph nodes per step)':70s} {total / steps:9.1f} {dev_total:28.1f}")
+  for opn in ("copy_", "clone", "index", "cat", "repeat", "where"):
+    if c.who[opn]:
+      print(f"{opn} ({sum(c.who[opn].values()) / steps:.0f} per step):", "; ".join(f"{k} {v / steps:.1f}" for k, v in c.who[opn].most_common(14)))
   print("most frequent operators:", ", ".join(f"{k} {v / steps:.0f}" for k, v in c.ops.most_common(14)))
 
 
