@@ -318,6 +318,16 @@ int mjlab_command_motion_write(const mjlab_motion_tables_t* tab, float* qpos, in
 int mjlab_command_motion_relative(const mjlab_motion_tables_t* tab, int nworld, const long long* time_steps, const float* env_origins,
                                   const float* xpos, const float* xquat, int nbody, int anchor_body_id, int anchor_index,
                                   float* body_pos_relative_w, float* body_quat_relative_w, void* stream);
+/* MotionCommand's gathered properties (:128-215) of every world in one launch: joint_pos / joint_vel (nworld, nj), body_pos_w (+ the
+ * world's env origin) / body_quat_w / body_lin_vel_w / body_ang_vel_w (nworld, nb, 3 | 4) of the motion frame time_steps[w], and -- when
+ * body_link_pose_w (nworld, nbody_e, 7) / body_link_vel_w (nworld, nbody_e, 6: linear, angular) are given -- the robot's tracked bodies
+ * `robot.data.body_link_*_w[:, body_indexes]` (track_ids: nb indices on the entity's body axis).  Copies and one addition: the bits
+ * of the reference's index launches (SURVEY 8f row 1 for the tracking task's command term). */
+int mjlab_command_motion_frame(const mjlab_motion_tables_t* tab, int nworld, const long long* time_steps, const float* env_origins,
+                               const float* body_link_pose_w, const float* body_link_vel_w, int nbody_e, const int* track_ids, float* joint_pos,
+                               float* joint_vel, float* body_pos_w, float* body_quat_w, float* body_lin_vel_w, float* body_ang_vel_w,
+                               float* robot_body_pos_w, float* robot_body_quat_w, float* robot_body_lin_vel_w, float* robot_body_ang_vel_w,
+                               void* stream);
 int mjlab_sizeof_motion_tables(void);
 
 /* RewardManager.compute's accumulation loop (managers/reward_manager.py:77-89) as one launch: `values` (k, nworld) holds the raw
@@ -335,6 +345,12 @@ int mjlab_reward_accumulate(const float* values, const float* weights, const int
  *   out[k] = the number of masked worlds.  `entries` are DEVICE arrays. */
 typedef struct mjlab_fill_entry { void* ptr; long long pattern; int row_stride_bytes, row_bytes, elem_bytes, pad_; } mjlab_fill_entry_t;
 typedef struct mjlab_sum_entry { const void* ptr; int is_bool, pad_; } mjlab_sum_entry_t;
+/* n device-to-device copies (dst <- src, nbytes; non-overlapping) in ceil(n / 32) launches: what GraphedRlEnv copies back at the end
+ * of a step body (the tensors the reference rebound).  `entries` is a HOST array; the launches carry it by value (graph safe). */
+#define MJLAB_COPY_BATCH_MAX 32
+typedef struct mjlab_copy_entry { void* dst; const void* src; unsigned long long nbytes; } mjlab_copy_entry_t;
+typedef struct mjlab_copy_batch { mjlab_copy_entry_t e[MJLAB_COPY_BATCH_MAX]; } mjlab_copy_batch_t;
+int mjlab_copy_batch(const mjlab_copy_entry_t* entries, int n, void* stream);
 int mjlab_masked_fill_rows(const mjlab_fill_entry_t* entries, int nentries, const unsigned char* mask, int nworld, void* stream);
 int mjlab_masked_sums(const mjlab_sum_entry_t* entries, int k, const unsigned char* mask, int nworld, float* out, void* stream);
 

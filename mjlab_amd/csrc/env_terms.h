@@ -281,6 +281,61 @@ __global__ __launch_bounds__(256) void k_command_motion_relative(const mjlab_mot
   oP[0] = rp[0] + rot[0], oP[1] = rp[1] + rot[1], oP[2] = apos[2] + rot[2];
 }
 
+// Up to MJLAB_COPY_BATCH_MAX device-to-device copies in ONE launch (mjlab_copy_batch): GraphedRlEnv copies every tensor the reference
+// REBOUND during a step back into the tensor its graph reads (graphed_env.py::_restore_bindings: 14 small copies per step of the
+// tracking task, each a graph node of its own before).  The entries travel by value in the kernel arguments, so a captured graph
+// holds them.  blockIdx.y = entry; words of 4 bytes where size and both addresses allow, bytes otherwise.
+__global__ __launch_bounds__(256) void k_copy_batch(const mjlab_copy_batch_t batch) {
+  const mjlab_copy_entry_t e = batch.e[blockIdx.y];
+  const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (((e.nbytes | (unsigned long long)e.dst | (unsigned long long)e.src) & 3ull) == 0ull) {
+    const unsigned* s = (const unsigned*)e.src;
+    unsigned* d = (unsigned*)e.dst;
+    for (size_t i = i0; i < e.nbytes / 4; i += stride) d[i] = s[i];
+  } else {
+    const unsigned char* s = (const unsigned char*)e.src;
+    unsigned char* d = (unsigned char*)e.dst;
+    for (size_t i = i0; i < e.nbytes; i += stride) d[i] = s[i];
+  }
+}
+
+// MotionCommand's per-step PROPERTIES (commands.py:128-215) for every world at once: the reference gathers each of them from the motion
+// tables / EntityData at every access -- `motion.joint_pos[time_steps]`, `motion.body_pos_w[time_steps] + env_origins[:, None, :]`,
+// `robot.data.body_link_pos_w[:, body_indexes]` ... -- an index launch (plus an add) per property and phase, ~44 per control step of the
+// tracking task (profiles/r06_census).  Copies and ONE addition per element: the same bits.  One thread per (world, tracked body); the
+// joints of a world are dealt out over its threads.
+__global__ __launch_bounds__(256) void k_command_motion_frame(const mjlab_motion_tables_t tab, const int nworld, const long long* time_steps, const float* org,
+                                                              const float* link_pose, const float* link_vel, const int nbody_e, const int* track_ids,
+                                                              float* joint_pos, float* joint_vel, float* body_pos_w, float* body_quat_w,
+                                                              float* body_lin_vel_w, float* body_ang_vel_w, float* robot_pos, float* robot_quat,
+                                                              float* robot_lin_vel, float* robot_ang_vel) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int w = i / tab.nb, b = i - w * tab.nb;
+  if (w >= nworld) return;
+  const long long t = time_steps[w];
+  const size_t fb = (size_t)t * tab.nbody_m + tab.body_indexes[b], o = (size_t)w * tab.nb + b;
+  for (int k = 0; k < 3; ++k) {
+    body_pos_w[3 * o + k] = tab.body_pos_w[3 * fb + k] + org[3 * w + k];
+    body_lin_vel_w[3 * o + k] = tab.body_lin_vel_w[3 * fb + k];
+    body_ang_vel_w[3 * o + k] = tab.body_ang_vel_w[3 * fb + k];
+  }
+  for (int k = 0; k < 4; ++k) body_quat_w[4 * o + k] = tab.body_quat_w[4 * fb + k];
+  for (int j = b; j < tab.nj; j += tab.nb) {
+    joint_pos[(size_t)w * tab.nj + j] = tab.joint_pos[(size_t)t * tab.nj + j];
+    joint_vel[(size_t)w * tab.nj + j] = tab.joint_vel[(size_t)t * tab.nj + j];
+  }
+  if (link_pose) {  // the robot's tracked bodies out of EntityData's body_link_pose_w (.., 7) / body_link_vel_w (.., 6: linear, angular)
+    const size_t rb = (size_t)w * nbody_e + track_ids[b];
+    for (int k = 0; k < 3; ++k) {
+      robot_pos[3 * o + k] = link_pose[7 * rb + k];
+      robot_lin_vel[3 * o + k] = link_vel[6 * rb + k];
+      robot_ang_vel[3 * o + k] = link_vel[6 * rb + 3 + k];
+    }
+    for (int k = 0; k < 4; ++k) robot_quat[4 * o + k] = link_pose[7 * rb + 3 + k];
+  }
+}
+
 // RewardManager.compute's accumulation (managers/reward_manager.py:77-89) for the k active terms whose raw values are the rows of
 // `values` (k, n): value = raw * weight * dt; reward += value (in term order); episode_sum[term] += value; step_reward[:, column] =
 // value / dt (as torch computes it: value * (1 / dt)).  Elementwise IEEE operations in the reference's order: the same bits as its 6 launches per term.

@@ -263,6 +263,45 @@ int mjlab_command_motion_write(const mjlab_motion_tables_t* tab, float* qpos, in
                      joint_v_adr, nworld, mask, time_steps, env_origins, soft_joint_pos_limits, ld_lim, U, ldu, pose_range, velocity_range, joint_lo, joint_hi);
   return launched("k_command_motion_write launch failed");
 }
+int mjlab_copy_batch(const mjlab_copy_entry_t* entries, int n, void* stream) {
+  if (n < 0 || (n > 0 && !entries)) return fail(-24, "copy_batch: bad arguments");
+  for (int k0 = 0; k0 < n; k0 += MJLAB_COPY_BATCH_MAX) {
+    mjlab_copy_batch_t b;
+    memset(&b, 0, sizeof(b));
+    const int m = n - k0 < MJLAB_COPY_BATCH_MAX ? n - k0 : MJLAB_COPY_BATCH_MAX;
+    unsigned long long most = 0;
+    for (int k = 0; k < m; ++k) {
+      if (!entries[k0 + k].dst || !entries[k0 + k].src) return fail(-24, "copy_batch: null pointer in an entry");
+      b.e[k] = entries[k0 + k];
+      most = b.e[k].nbytes > most ? b.e[k].nbytes : most;
+    }
+    unsigned long long gx = (most / 4 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    hipLaunchKernelGGL(k_copy_batch, dim3((unsigned)gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, b);
+    int rc = launched("k_copy_batch launch failed");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int mjlab_command_motion_frame(const mjlab_motion_tables_t* tab, int nworld, const long long* time_steps, const float* env_origins, const float* body_link_pose_w,
+                               const float* body_link_vel_w, int nbody_e, const int* track_ids, float* joint_pos, float* joint_vel, float* body_pos_w,
+                               float* body_quat_w, float* body_lin_vel_w, float* body_ang_vel_w, float* robot_body_pos_w, float* robot_body_quat_w,
+                               float* robot_body_lin_vel_w, float* robot_body_ang_vel_w, void* stream) {
+  int rc = check_tables(tab, "command_motion_frame: bad motion tables");
+  if (rc) return rc;
+  if (!time_steps || !env_origins || !joint_pos || !joint_vel || !body_pos_w || !body_quat_w || !body_lin_vel_w || !body_ang_vel_w)
+    return fail(-23, "command_motion_frame: null argument");
+  if (body_link_pose_w && (!body_link_vel_w || !track_ids || nbody_e < 1 || !robot_body_pos_w || !robot_body_quat_w || !robot_body_lin_vel_w || !robot_body_ang_vel_w))
+    return fail(-23, "command_motion_frame: the robot's part needs pose, velocity, the tracked ids and four outputs");
+  if (nworld < 1) return fail(-23, "command_motion_frame: bad sizes");
+  const long long total = (long long)nworld * tab->nb;
+  hipLaunchKernelGGL(k_command_motion_frame, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *tab, nworld, time_steps, env_origins,
+                     body_link_pose_w, body_link_vel_w, nbody_e, track_ids, joint_pos, joint_vel, body_pos_w, body_quat_w, body_lin_vel_w, body_ang_vel_w,
+                     robot_body_pos_w, robot_body_quat_w, robot_body_lin_vel_w, robot_body_ang_vel_w);
+  return launched("k_command_motion_frame launch failed");
+}
+
 int mjlab_command_motion_relative(const mjlab_motion_tables_t* tab, int nworld, const long long* time_steps, const float* env_origins, const float* xpos,
                                   const float* xquat, int nbody, int anchor_body_id, int anchor_index, float* body_pos_relative_w, float* body_quat_relative_w,
                                   void* stream) {

@@ -158,6 +158,61 @@ def command_motion_relative(tab: MotionTables, time_steps: torch.Tensor, env_ori
     _stream(xpos)), "mjlab_command_motion_relative")  # fmt: skip
 
 
+class CopyEntry(ctypes.Structure):  # mjlab_copy_entry_t
+  _fields_ = [("dst", _vp), ("src", _vp), ("nbytes", ctypes.c_ulonglong)]
+
+
+def copy_batch(pairs: list) -> None:
+  """``dst.copy_(src)`` for every (dst, src) of `pairs` in ONE launch per 32 pairs (``mjlab_copy_batch``); pairs the launch cannot
+  express (another dtype, a strided tensor, a host tensor) keep ``copy_``."""
+  todo = []
+  for dst, src in pairs:
+    if dst.is_cuda and src.is_cuda and dst.dtype == src.dtype and dst.shape == src.shape and dst.is_contiguous() and src.is_contiguous() and dst.numel() > 0:
+      todo.append((dst, src))
+    else:
+      dst.copy_(src)
+  if todo:
+    arr = (CopyEntry * len(todo))()
+    for k, (dst, src) in enumerate(todo):
+      arr[k].dst, arr[k].src, arr[k].nbytes = dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size()
+    native.check(native.lib().mjlab_copy_batch(arr, len(todo), _stream(todo[0][0])), "mjlab_copy_batch")
+
+
+class MotionFrame:
+  """MotionCommand's gathered properties from ONE launch per phase (``mjlab_command_motion_frame``): persistent output buffers (graph
+  safe) under the reference's property names (tasks/tracking/mdp/commands.py:128-215).  ``anchor_*`` are the anchor's rows of the body
+  arrays -- the same table entries (+ the same origin) the reference gathers separately."""
+
+  NAMES = ("joint_pos", "joint_vel", "body_pos_w", "body_quat_w", "body_lin_vel_w", "body_ang_vel_w", "anchor_pos_w", "anchor_quat_w", "anchor_lin_vel_w",
+           "anchor_ang_vel_w", "robot_body_pos_w", "robot_body_quat_w", "robot_body_lin_vel_w", "robot_body_ang_vel_w")
+
+  def __init__(self, term, tab: MotionTables) -> None:
+    dev, n, nb, nj = term.time_steps.device, term.num_envs, int(tab.nb), int(tab.nj)
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    self.term, self.tab = term, tab
+    self.out = {"joint_pos": z(n, nj), "joint_vel": z(n, nj), "body_pos_w": z(n, nb, 3), "body_quat_w": z(n, nb, 4), "body_lin_vel_w": z(n, nb, 3),
+                "body_ang_vel_w": z(n, nb, 3), "robot_body_pos_w": z(n, nb, 3), "robot_body_quat_w": z(n, nb, 4), "robot_body_lin_vel_w": z(n, nb, 3),
+                "robot_body_ang_vel_w": z(n, nb, 3)}
+    self.track = term.body_indexes.to(torch.int32).contiguous()
+    a = int(term.motion_anchor_body_index)
+    self.views = dict(self.out)
+    for k in ("pos_w", "quat_w", "lin_vel_w", "ang_vel_w"):
+      self.views["anchor_" + k] = self.out["body_" + k][:, a]
+
+  def update(self, env_origins: torch.Tensor) -> dict:
+    """Launch for the term's current ``time_steps`` and the robot's current ``EntityData``; returns name -> tensor."""
+    t, o = self.term, self.out
+    pose, vel = _f32(t.robot.data.body_link_pose_w, "body_link_pose_w"), _f32(t.robot.data.body_link_vel_w, "body_link_vel_w")
+    if not (pose.is_contiguous() and vel.is_contiguous()):
+      pose, vel = pose.contiguous(), vel.contiguous()
+    native.check(native.lib().mjlab_command_motion_frame(
+      ctypes.byref(self.tab), pose.shape[0], _dense(t.time_steps, "time_steps", torch.long).data_ptr(), _dense(env_origins, "env_origins", torch.float32).data_ptr(),
+      pose.data_ptr(), vel.data_ptr(), pose.shape[1], self.track.data_ptr(), o["joint_pos"].data_ptr(), o["joint_vel"].data_ptr(), o["body_pos_w"].data_ptr(),
+      o["body_quat_w"].data_ptr(), o["body_lin_vel_w"].data_ptr(), o["body_ang_vel_w"].data_ptr(), o["robot_body_pos_w"].data_ptr(),
+      o["robot_body_quat_w"].data_ptr(), o["robot_body_lin_vel_w"].data_ptr(), o["robot_body_ang_vel_w"].data_ptr(), _stream(pose)), "mjlab_command_motion_frame")  # fmt: skip
+    return self.views
+
+
 def reward_accumulate(values: torch.Tensor, weights: torch.Tensor, columns: torch.Tensor, dt: float, reward_buf: torch.Tensor, sum_ptrs: torch.Tensor,
                       step_reward: torch.Tensor) -> None:
   """The mjlab_reward_accumulate launch on plain tensors: `values` (k, n) raw term outputs, `weights` (k) float32, `columns` (k) int32,

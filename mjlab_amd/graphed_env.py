@@ -207,7 +207,7 @@ class _CachedEntityData:
         del cache[name]
 
 
-def _cache_properties(obj: Any, active: list | None = None) -> Any:
+def _cache_properties(obj: Any, active: list | None = None, prefill: tuple | None = None) -> Any:
   """Gives `obj` a subclass of its own class (same name) whose read-only properties are evaluated once and handed out again until the
   returned ``invalidate()`` is called.  For the tracking task's ``MotionCommand`` (reference tasks/tracking/mdp/commands.py:128-215:
   ``body_pos_w``, ``anchor_quat_w``, ``robot_body_pos_w`` ... are properties that gather from the motion tables / ``EntityData`` at
@@ -223,7 +223,10 @@ def _cache_properties(obj: Any, active: list | None = None) -> Any:
       if not active[0]:
         return fget(self)
       if name not in cache:
-        cache[name] = fget(self)
+        if prefill is not None and name in prefill[0]:
+          cache.update(prefill[1]())  # (names, fill): ONE launch provides all of `names` for this phase (env_terms.MotionFrame)
+        else:
+          cache[name] = fget(self)
       return cache[name]
 
     return property(get)
@@ -281,13 +284,14 @@ class GraphedRlEnv:
     cache_entity_data     property caches for ``EntityData`` / command terms and shared observation terms inside the step body
     fused_terms           None: HIP launches for the event / command / reward-accumulation terms on the GPU, torch restatements elsewhere
     fused_relative_poses  opt-in (tracking): ``MotionCommand``'s relative body poses from one launch -- 1 ulp from the reference's chain
+    fused_motion_frame    (tracking, GPU) ``MotionCommand``'s gathered properties from one ``mjlab_command_motion_frame`` launch per phase (bit for bit)
     forward               "reference": ``sim.forward()`` on all worlds whenever some environment reset; "reset_worlds" (opt-in): only those
     fused_entity_data     None: on the GPU ``EntityData``'s base quantities come from one ``mjlab_entity_readback`` launch per phase (bit for bit
                           the reference's chains); False: the reference's own chains
   """
 
   def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None,
-               fused_relative_poses: bool = False, forward: str = "reference", fused_entity_data: bool | None = None,
+               fused_relative_poses: bool = False, forward: str = "reference", fused_entity_data: bool | None = None, fused_motion_frame: bool = True,
                shard: Any = None, replicate_rng: bool = False) -> None:
     """``shard`` (mjlab_amd.dist.ShardInfo): this environment is rank ``shard.rank``'s slice of a batch of ``shard.global_envs``
     environments (worlds are independent, one process per GPU).  The control step itself needs nothing from the other
@@ -314,6 +318,9 @@ class GraphedRlEnv:
     # with the reference's jit-fused chain to 1 ulp, not bit for bit (tests/test_gpu_reference_env.py), so it is opt-in: the default
     # keeps "rewards and quiet observations bit for bit with the eager reference step"
     self._fused_relative = bool(fused_relative_poses) and self._fused
+    # MotionCommand's gathered properties (joint_pos, body_*_w, anchor_*_w, robot_body_*_w) from one launch per phase instead of an index
+    # launch (+ an add) each: copies, bit for bit (round 6; tools/graphed_env_census.py: ~44 index launches per tracking step)
+    self._fused_frame = bool(fused_motion_frame)
     # forward="reference": sim.forward() on ALL worlds whenever some environment reset, as the reference does (:129-132) -- with 4096
     # envs that is practically every step; "reset_worlds" (SURVEY 8f row 2): only the worlds that reset are recomputed, the others
     # keep the derived quantities of their last physics step, as they do in the reference in a step without resets.  Opt-in: the
@@ -466,7 +473,11 @@ class GraphedRlEnv:
                                         int(rix.body_ids[term.robot_anchor_body_index]))
         if self._cache_entity_data and not getattr(term, "_mjlab_amd_cached", False):
           _cache_properties(term.motion, [True])  # (the tables and body_indexes never change: kept for good, inside and outside the step)
-          self._term_caches.append(_cache_properties(term, self._caching))
+          prefill = None
+          if self._fused and self._fused_frame:
+            frame = env_terms.MotionFrame(term, self._motion_dev[id(term)][0])
+            prefill = (frozenset(frame.NAMES), lambda frame=frame: frame.update(self.env.scene.env_origins))
+          self._term_caches.append(_cache_properties(term, self._caching, prefill))
           term._mjlab_amd_cached = True
     # observation groups assembled in a handful of launches (see _observation_compute): per group the noise bounds of every column
     self._obs_plan: dict = {}
@@ -861,14 +872,20 @@ class GraphedRlEnv:
     return out
 
   def _restore_bindings(self, before: list) -> None:
+    pairs = []
     for owner, key, old, _ in before:
       new = owner[key] if isinstance(owner, (dict, list)) else getattr(owner, key)
       if new is not old and isinstance(new, torch.Tensor) and new.shape == old.shape:
-        old.copy_(new)
+        pairs.append((old, new))
         if isinstance(owner, (dict, list)):
           owner[key] = old
         else:
           setattr(owner, key, old)
+    if self._fused:
+      env_terms.copy_batch(pairs)  # one launch instead of one graph node per rebound tensor (14 in the tracking task)
+    else:
+      for old, new in pairs:
+        old.copy_(new)
 
   # ------------------------------------------------------------------------------------------------------------------ reset
   def _prepare_bookkeeping(self) -> Any:

@@ -15,7 +15,7 @@ def test_struct_mirrors_and_exports():
   assert ctypes.sizeof(env_terms.VelocityCommand) == L.mjlab_sizeof_velocity_command()
   assert ctypes.sizeof(env_terms.MotionTables) == L.mjlab_sizeof_motion_tables()
   for name in ("mjlab_event_reset_root_state_uniform", "mjlab_event_reset_joints_by_scale", "mjlab_event_push_by_setting_velocity", "mjlab_command_uniform_velocity",
-               "mjlab_command_motion_write", "mjlab_command_motion_relative", "mjlab_reward_accumulate"):
+               "mjlab_command_motion_write", "mjlab_command_motion_relative", "mjlab_command_motion_frame", "mjlab_copy_batch", "mjlab_reward_accumulate"):
     assert hasattr(L, name) and name in native.EXPORTED_SYMBOLS, name
 
 
@@ -38,5 +38,7 @@ def test_null_and_size_errors_come_back_as_codes():
   assert L.mjlab_event_reset_root_state_uniform(None, 36, 0, None, 35, 0, 8, None, None, 0, None, None, 12, None, None, None) == -22
   assert b"null argument" in L.mjlab_last_error()
   assert L.mjlab_reward_accumulate(None, None, None, 1, 8, 0.02, None, None, None, 1, None) == -22
+  assert L.mjlab_copy_batch(None, 3, None) == -24 and L.mjlab_copy_batch(None, 0, None) == 0
+  assert L.mjlab_command_motion_frame(None, 8, None, None, None, None, 0, None, None, None, None, None, None, None, None, None, None, None, None) != 0
   assert L.mjlab_command_motion_write(None, None, 36, 0, None, 35, 0, None, None, 8, None, None, None, None, 0, None, 0, None, None, 0.0, 0.0, None) == -22
   assert L.mjlab_command_uniform_velocity(None, None) == -22

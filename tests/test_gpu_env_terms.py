@@ -379,6 +379,68 @@ def test_command_motion_relative():
   del keep
 
 
+def test_command_motion_frame_equals_the_reference_gathers_bit_for_bit():
+  """mjlab_command_motion_frame (env_terms.MotionFrame) against the expressions of MotionCommand's properties (tasks/tracking/mdp/
+  commands.py:128-215) in torch on the same device: copies and one addition -- exact equality."""
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(21)
+  term, idx = _motion_term(g, dev)
+  mo, nb, nbody_e = term.motion, len(idx), 30
+  tab, keep = env_terms.motion_tables(term)
+  ts = torch.randint(0, 40, (N,), generator=g).to(dev)
+  org = (torch.randn((N, 3), generator=g) * 3).to(dev)
+  pose = torch.randn((N, nbody_e, 7), generator=g).to(dev)
+  vel = torch.randn((N, nbody_e, 6), generator=g).to(dev)
+  body_indexes = torch.tensor([0, 5, 11, 17, 29]).to(dev)
+  term.time_steps, term.num_envs, term.body_indexes, term.motion_anchor_body_index = ts, N, body_indexes, 2
+  term.robot = types.SimpleNamespace(data=types.SimpleNamespace(body_link_pose_w=pose, body_link_vel_w=vel))
+  got = env_terms.MotionFrame(term, tab).update(org)
+  torch.cuda.synchronize()
+  body = lambda table: table[:, idx.to(dev)]  # MotionLoader.body_*_w (:52-65)  # noqa: E731
+  want = {
+    "joint_pos": mo.joint_pos[ts], "joint_vel": mo.joint_vel[ts],
+    "body_pos_w": body(mo._body_pos_w)[ts] + org[:, None, :], "body_quat_w": body(mo._body_quat_w)[ts],
+    "body_lin_vel_w": body(mo._body_lin_vel_w)[ts], "body_ang_vel_w": body(mo._body_ang_vel_w)[ts],
+    "anchor_pos_w": body(mo._body_pos_w)[ts, 2] + org, "anchor_quat_w": body(mo._body_quat_w)[ts, 2],
+    "anchor_lin_vel_w": body(mo._body_lin_vel_w)[ts, 2], "anchor_ang_vel_w": body(mo._body_ang_vel_w)[ts, 2],
+    "robot_body_pos_w": pose[..., :3][:, body_indexes], "robot_body_quat_w": pose[..., 3:7][:, body_indexes],
+    "robot_body_lin_vel_w": vel[..., :3][:, body_indexes], "robot_body_ang_vel_w": vel[..., 3:6][:, body_indexes],
+  }
+  assert set(got) == set(want) == set(env_terms.MotionFrame.NAMES)
+  for k, v in want.items():
+    assert got[k].shape == v.shape and torch.equal(got[k], v), k
+  del keep
+
+
+def test_copy_batch_copies_every_pair():
+  """mjlab_copy_batch: 40 pairs (two launches) of float, int64 and bool tensors, odd byte counts included; strided / mixed-dtype pairs
+  keep copy_."""
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(3)
+  pairs = []
+  for k in range(40):
+    shape = (N, 1 + k % 7) if k % 3 else (N,)
+    if k % 5 == 0:
+      src = torch.rand(shape, generator=g) > 0.5
+    elif k % 5 == 1:
+      src = torch.randint(-9, 9, shape, generator=g)
+    else:
+      src = torch.randn(shape, generator=g)
+    pairs.append((torch.zeros_like(src).to(dev), src.to(dev)))
+  odd = (torch.zeros(7, dtype=torch.bool, device=dev), torch.tensor([1, 0, 1, 1, 0, 0, 1], dtype=torch.bool, device=dev))
+  strided = (torch.zeros((N, 2), device=dev), torch.randn((N, 4), generator=g).to(dev)[:, ::2])
+  cast = (torch.zeros(N, device=dev), torch.arange(N, device=dev))
+  env_terms.copy_batch(pairs + [odd, strided, cast])
+  torch.cuda.synchronize()
+  for dst, src in pairs + [odd, strided]:
+    assert torch.equal(dst, src)
+  assert torch.equal(cast[0], cast[1].float())
+
+
 def test_reward_accumulate_equals_the_managers_loop_bit_for_bit():
   """mjlab_reward_accumulate against the reference loop's torch operations (managers/reward_manager.py:77-89) on the same raw term
   values: reward, episode sums and per-step term values, bitwise."""

@@ -83,6 +83,19 @@ ROUGH = {
   "off_frac": 0.12, "unexplained_max": 4e-4,
 }  # fmt: skip
 
+# Worst-world bounds of the REGULAR worlds -- no robot-robot contact deeper than 5 mm, Newton iteration of forward() below its cap
+# (tools/parity_report.py: `regular`; >= 85 % of every sample, asserted) -- for EVERY case, exact and grid search (round 6; VERDICT
+# round 5, item 5): the wide worst-world literals of TRACKING / GRID / the friction-loss case are bounds of a capped or
+# ill-posed solve and now apply to such worlds only.  Measured over the 163 reports on record (profiles/r04_*, r05_*, r06_*:
+# tools/make_parity_literals.py), worst regular world per class: flat qacc 4.1e-5 / qfrc_constraint 7.3e-4 / efc_J 9.7e-6; tracking
+# 3.3e-5 / 4.0e-4 / 1.2e-4; rough 1.3e-4 / 1.5e-4 / 3.8e-4 -- x 3.  The one-step bounds stay the class's all-world ones: step() runs a
+# solve of its own, which can end at its cap in a world whose forward() did not.
+REGULAR = {
+  "flat": {"efc_J": 3e-5, "qacc": 1.2e-4, "qfrc_constraint": 2.2e-3, "step_qpos": FLAT["step_qpos_max"], "step_qvel": FLAT["step_qvel_max"]},
+  "tracking": {"efc_J": 3e-4, "qacc": 1.2e-4, "qfrc_constraint": 2.2e-3, "step_qpos": FLAT["step_qpos_max"], "step_qvel": FLAT["step_qvel_max"]},
+  "rough": {"efc_J": ROUGH["efc_J_max"], "qacc": ROUGH["qacc_max"], "qfrc_constraint": 4.5e-4, "step_qpos": ROUGH["step_qpos_max"], "step_qvel": ROUGH["step_qvel_max"]},
+}
+
 # BASELINE config 4 under its OWN reset distribution (random phases of a motion + pose / velocity / joint noise, anchor
 # terminations: 6 500 resets per 250 steps x 1024 worlds under random actions).  Reset robots regularly start with their feet
 # INSIDE each other (thin foot capsules, noisy leg joints): two capsule axes 0.4 mm apart give a contact normal that fp32
@@ -92,8 +105,7 @@ ROUGH = {
 # Round 5: qacc p99 1.0-2.6e-5 and qfrc_constraint p99 2.5-7.4e-5 over the seeds and both factorizations (the reset distribution
 # puts 150 freshly reset robots with interpenetrating feet into a 25-step sample); the worst "unexplained" world is a maximum over
 # 1024 chaotic worlds (qacc max 4e-5 ... 8e-3 over the seeds, for round 4's arithmetic too: profiles/r05_v9/seeds_tracking.txt)
-TRACKING = dict(FLAT, regular_max={"efc_J": 3e-4, "qacc": FLAT["qacc_max"], "qfrc_constraint": FLAT["qfc_max"],
-                                   "step_qpos": FLAT["step_qpos_max"], "step_qvel": FLAT["step_qvel_max"]}, efc_J_max=0.2, efc_J_p99=1e-4, efc_pos_abs_max=1.5e-5, qacc_p99=3.5e-5, qfc_p99=1.2e-4, qacc_max=5e-2, qfc_max=0.12,
+TRACKING = dict(FLAT, efc_J_max=0.2, efc_J_p99=1e-4, efc_pos_abs_max=1.5e-5, qacc_p99=3.5e-5, qfc_p99=1.2e-4, qacc_max=5e-2, qfc_max=0.12,
                 step_qpos_max=8e-4, step_qvel_max=3e-2, off_frac=0.05, unexplained_max=1e-2)
 
 # ---- element-wise contract.  north_star's "1e-5 rel fp32" holds per world in max-norm at the
@@ -119,6 +131,10 @@ ELEM_FLOOR = {
 }
 
 
+def _scene_class(scene):
+  return "rough" if scene.endswith("rough") else ("tracking" if "tracking" in scene else "flat")
+
+
 def _elem_class(scene, precision):
   robot = "go1" if scene.startswith("go1") else "g1"
   kind = "rough" if scene.endswith("rough") else ("tracking" if "tracking" in scene else "flat")
@@ -137,6 +153,7 @@ def _check_elem(r):
   assert set(el) == set(ELEM_ALL) | set(floors), sorted(set(el) ^ (set(ELEM_ALL) | set(floors)))
 
 
+FRICTIONLOSS = dict(qacc_max=1e-1, qfc_max=1e-1, step_qpos_max=5e-3, step_qvel_max=2.5e-1)  # (capped-solve bounds: see test_rollout_state_parity)
 CASES = [
   # scene, control steps, oracle precision, expanded model fields
   ("go1_velocity_flat", 25, "f64", ("geom_friction",)),
@@ -191,11 +208,10 @@ def _check(r, tol):
   _check_elem(r)
   # the wide worst-world literals (tracking scene; friction-loss case) are for the worlds with a deep self-penetration or a Newton
   # iteration that ended at its cap only: every other world keeps the flat scenes' worst-world bounds
-  if "regular_max" in tol:
-    reg, rm = r["regular"], tol["regular_max"]
-    assert r["deep_self_penetration"] <= 0.10 * n and r["regular_worlds"] >= 0.85 * n, (r["deep_self_penetration"], r["regular_worlds"])  # measured: 15-85 / >= 920 of 1024
-    for k in ("efc_J", "qacc", "qfrc_constraint", "step_qpos", "step_qvel"):
-      assert reg[k] <= rm[k], (k, reg[k], rm[k])
+  reg, rm = r["regular"], REGULAR[_scene_class(r["scene"])]
+  assert r["deep_self_penetration"] <= 0.10 * n and r["regular_worlds"] >= 0.85 * n, (r["deep_self_penetration"], r["regular_worlds"])  # measured: 0-85 / >= 920 of 1024
+  for k in ("efc_J", "qacc", "qfrc_constraint", "step_qpos", "step_qvel"):
+    assert reg[k] <= rm[k], (k, reg[k], rm[k])
 
 
 @pytest.mark.parametrize("scene,steps,precision,expand", CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}" for c in CASES])
@@ -209,8 +225,7 @@ def test_rollout_state_parity(scene, steps, precision, expand):
     # ~15 more rows per world (mean 53, up to 128): one world in 1024 ends its Newton iteration at the cap of 10 on both
     # sides, where the iterate depends on rounding (measured: qacc 3.3e-2 in that world, p99 9.4e-6 as without the rows).
     # Median and p99 keep the literals of the flat scenes; only the worst-world bounds are those of a capped solve.
-    tol = dict(tol, qacc_max=1e-1, qfc_max=1e-1, step_qpos_max=5e-3, step_qvel_max=2.5e-1,
-               regular_max={"efc_J": FLAT["efc_J_max"], "qacc": FLAT["qacc_max"], "qfrc_constraint": FLAT["qfc_max"], "step_qpos": FLAT["step_qpos_max"], "step_qvel": FLAT["step_qvel_max"]})
+    tol = dict(tol, **FRICTIONLOSS)
   _check(r, tol)
   if rough:
     # the compared states really are on the stairs, not on the flat spawn platforms
@@ -247,8 +262,7 @@ def test_rollout_state_parity_with_the_grid_line_search(scene, expand):
   tol = dict(base)
   for k, v in GRID.items():
     tol[k] = max(v, base.get(k, 0.0))
-  if "regular_max" in tol:  # worlds without a deep self-penetration: the grid search's worst-world bounds
-    tol["regular_max"] = {"efc_J": base["regular_max"]["efc_J"], "qacc": GRID["qacc_max"], "qfrc_constraint": GRID["qfc_max"], "step_qpos": GRID["step_qpos_max"], "step_qvel": GRID["step_qvel_max"]}
+  # (the regular worlds keep REGULAR's bounds under the grid search too: GRID's literals are for the capped worlds -- round 6)
   if scene == "g1_tracking_flat":
     # 24 of 1024 worlds above 1e-5, the worst "unexplained" one (no cap, same active set, same iteration count) at 5.2e-4: two
     # sides that picked different grid candidates in a late iteration -- not visible in the counts the classification reads
@@ -274,8 +288,8 @@ def test_literal_termination_switch_matches_the_literal_oracle():
 
 def test_literal_grid_cost_switch_on_the_device():
   """MJLAB_OPT_LS_LITERAL_COST on the device (SimulationCfg.ls_literal_cost): the grid search ranks its candidates by their literal
-  totals.  Against the fp64 restatement on the gate's rollout states the bulk is unchanged and the worst world is not better than
-  under the default (tests/test_oracle_flags.py shows on the CPU what the literal form costs in fp32); the switch exists so that
+  totals.  Against the fp64 restatement on the gate's rollout states the bulk is unchanged and the worst world stays bounded
+  (tests/test_oracle_flags.py shows on the CPU what the literal form costs in fp32); the switch exists so that
   upstream vectors can decide which form upstream takes (tests/test_golden.py)."""
   import numpy as np
   import torch
@@ -302,7 +316,7 @@ def test_literal_grid_cost_switch_on_the_device():
   assert np.median(err[False]) <= 5e-6 and np.median(err[True]) <= 5e-6, (np.median(err[False]), np.median(err[True]))
   assert err[False].max() <= 3e-5, err[False].max()
   assert not np.array_equal(err[False], err[True])  # the switch changes which candidates win somewhere
-  assert err[True].max() >= 0.8 * err[False].max(), (err[True].max(), err[False].max())
+  assert err[True].max() <= 1e-3, err[True].max()  # (bounded; whether the literal form is better or worse is not asserted: ADVICE round 5)
 
 
 def test_warmstart_at_advance_switch():
