@@ -106,7 +106,7 @@ REGULAR = {
 # puts 150 freshly reset robots with interpenetrating feet into a 25-step sample); the worst "unexplained" world is a maximum over
 # 1024 chaotic worlds (qacc max 4e-5 ... 8e-3 over the seeds, for round 4's arithmetic too: profiles/r05_v9/seeds_tracking.txt)
 TRACKING = dict(FLAT, efc_J_max=0.2, efc_J_p99=1e-4, efc_pos_abs_max=1.5e-5, qacc_p99=3.5e-5, qfc_p99=1.2e-4, qacc_max=5e-2, qfc_max=0.12,
-                step_qpos_max=8e-4, step_qvel_max=3e-2, off_frac=0.05, unexplained_max=1e-2)
+                step_qpos_max=8e-4, step_qvel_max=3e-2, off_frac=0.05, unexplained_max=5e-3)  # (unexplained worst over 68 reports on record: 1.7e-3, x 3; was 1e-2)
 
 # ---- element-wise contract.  north_star's "1e-5 rel fp32" holds per world in max-norm at the
 # p99 (the literals above).  ELEMENT by element -- |gpu - oracle| <= atol(field) + 1e-5 |oracle| for every entry,
@@ -267,7 +267,7 @@ def test_rollout_state_parity_with_the_grid_line_search(scene, expand):
     # 24 of 1024 worlds above 1e-5, the worst "unexplained" one (no cap, same active set, same iteration count) at 5.2e-4: two
     # sides that picked different grid candidates in a late iteration -- not visible in the counts the classification reads
     # (measured r04_v1; x 2)
-    tol["unexplained_max"] = 1e-2  # (round 5: the seed spread of this maximum, see TRACKING)
+    tol["unexplained_max"] = TRACKING["unexplained_max"]  # (the seed spread of this maximum, see TRACKING; round 6: 5e-3)
   _check(r, tol)
 
 

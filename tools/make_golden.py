@@ -4,6 +4,8 @@ The reference holds no numeric golden vectors for the step and cannot be run her
 engine, mujoco_warp/mujoco, is not installed) -- SURVEY.md section 8c.  These fixtures are
 therefore REGRESSION vectors produced by this repository's own fp64 oracle; they pin the
 oracle (CPU test) and the HIP path (GPU test) to each other over time, not to upstream.
+That holds doubly for the elliptic-cone fixtures (`*_elliptic.npz`, round 5): the cone model itself is restated from MuJoCo's
+documentation and unpinned -- REGRESSION fixtures, not parity evidence.
 """
 
 import sys
