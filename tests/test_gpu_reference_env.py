@@ -216,6 +216,22 @@ def test_graphed_tracking_env_matches_the_reference_env(tmp_path):
   assert st["graph"] and st["resets"] >= 32 and st["ended"] >= 32 and st["pushes"] >= 64 and st["quiet_env_steps"] >= 2000  # measured: 71 / 108 / 339 / 4618
 
 
+def test_graphed_tracking_env_without_state_estimation(tmp_path):
+  """``Mjlab-Tracking-Flat-Unitree-G1-No-State-Estimation`` (reference tasks/tracking/config/g1/__init__.py:24)
+  as one hipGraph, teacher-forced against the reference's eager step: the policy group without ``motion_anchor_pos_b`` / ``base_lin_vel``."""
+  import json
+  import subprocess
+
+  code = _TRACKING_GRAPHED.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"), motion=str(tmp_path / "motion.npz")).replace(
+    '"Mjlab-Tracking-Flat-Unitree-G1"', '"Mjlab-Tracking-Flat-Unitree-G1-No-State-Estimation"')
+  assert "No-State-Estimation" in code
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print("graphed tracking env (no state estimation) vs reference env:", st)
+  assert st["graph"] and st["resets"] >= 32 and st["ended"] >= 32 and st["pushes"] >= 64 and st["quiet_env_steps"] >= 2000
+
+
 _GO1_GRAPHED = """
 import json, sys
 sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
@@ -293,6 +309,23 @@ def test_graphed_rough_env_with_its_terrain_curriculum(tmp_path):
   st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
   print("graphed rough G1 env vs reference env:", st)
   assert st["graph"] and st["resets"] >= 128 and st["pushes"] >= 128 and st["quiet_env_steps"] >= 2000 and st["level_moves"] >= 64 and st["level_draws"] >= 1
+  assert st["eager_finite"] and st["overflow"] == {"nconmax": 0, "njmax": 0, "terrain_candidates": 0}, st
+
+
+def test_graphed_go1_rough_env_with_both_curricula(tmp_path):
+  """``Mjlab-Velocity-Rough-Unitree-Go1`` (reference tasks/velocity/config/go1/__init__.py:4) as one hipGraph:
+  the Go1's trunk BOX against the generated stairs in the physics, ``terrain_levels_vel`` and ``commands_vel`` inside the graph."""
+  import json
+  import subprocess
+
+  code = _ROUGH_GRAPHED.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests")).replace('"Mjlab-Velocity-Rough-Unitree-G1"', '"Mjlab-Velocity-Rough-Unitree-Go1"').replace(
+    "(256, 29)", "(256, 12)")
+  assert "Rough-Unitree-Go1" in code
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print("graphed rough Go1 env vs reference env:", st)
+  assert st["graph"] and st["resets"] >= 128 and st["pushes"] >= 128 and st["quiet_env_steps"] >= 2000 and st["level_moves"] >= 32
   assert st["eager_finite"] and st["overflow"] == {"nconmax": 0, "njmax": 0, "terrain_candidates": 0}, st
 
 

@@ -17,7 +17,8 @@ import torch
 from mjlab_amd import env_core
 
 GOLD = Path(__file__).resolve().parent / "golden"
-SCENES = ("g1_velocity_flat", "g1_tracking_flat")
+SCENES = ("g1_velocity_flat", "g1_tracking_flat", "g1_tracking_flat_nse", "go1_velocity_rough")
+VELOCITY_SCENES = ("g1_velocity_flat", "go1_velocity_rough")
 
 
 def load(scene):
@@ -112,8 +113,8 @@ def check_obs(scene, dev):
   return len(meta["obs"])
 
 
-def check_velocity(dev):
-  meta, z = load("g1_velocity_flat")
+def check_velocity(scene, dev):
+  meta, z = load(scene)
   changed = 0
   for e in meta["velocity"]:
     v = _t(z, e["pre"], dev).clone()
@@ -131,8 +132,8 @@ def test_core_reproduces_the_reference_on_the_cpu(scene):
   assert check_reset(scene, "cpu", False) >= 20
   assert check_reward(scene, "cpu", False) >= 6
   assert check_obs(scene, "cpu") >= 2
-  if scene == "g1_velocity_flat":
-    assert check_velocity("cpu") >= 4
+  if scene in VELOCITY_SCENES:
+    assert check_velocity(scene, "cpu") >= 4
 
 
 @pytest.mark.gpu
@@ -143,5 +144,5 @@ def test_core_reproduces_the_reference_on_the_device(scene, fused):
   assert check_reward(scene, "cuda:0", fused) >= 6
   if not fused:
     assert check_obs(scene, "cuda:0") >= 2
-    if scene == "g1_velocity_flat":
-      assert check_velocity("cuda:0") >= 4
+    if scene in VELOCITY_SCENES:
+      assert check_velocity(scene, "cuda:0") >= 4

@@ -106,6 +106,23 @@ def test_mask_based_control_step_of_the_tracking_task(tmp_path):
   assert st["resets"] >= 8 and st["ended"] >= 8 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400
 
 
+def test_mask_based_control_step_of_the_tracking_task_without_state_estimation(tmp_path):
+  """``Mjlab-Tracking-Flat-Unitree-G1-No-State-Estimation`` (reference tasks/tracking/config/g1/__init__.py:24):
+  the tracking task whose policy group drops ``motion_anchor_pos_b`` and ``base_lin_vel`` -- the shared observation terms and the
+  group assembly see another layout."""
+  import json
+  import subprocess
+
+  code = _TRACKING.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"), motion=str(tmp_path / "motion.npz")).replace(
+    '"Mjlab-Tracking-Flat-Unitree-G1"', '"Mjlab-Tracking-Flat-Unitree-G1-No-State-Estimation"')
+  assert "No-State-Estimation" in code
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print(st)
+  assert st["resets"] >= 8 and st["ended"] >= 8 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400
+
+
 _GO1 = """
 import json, sys
 sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
@@ -166,6 +183,22 @@ def test_rough_task_with_its_terrain_curriculum():
   assert r.returncode == 0, r.stderr[-3000:]
   st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
   assert st["resets"] >= 16 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400 and st["level_moves"] >= 8 and st["level_draws"] >= 1, st
+
+
+def test_go1_rough_task_with_both_curricula():
+  """``Mjlab-Velocity-Rough-Unitree-Go1`` (reference tasks/velocity/config/go1/__init__.py:4): the Go1 on
+  the generated stairs -- a moving BOX (the trunk) against terrain boxes in the physics, ``terrain_levels_vel`` AND the Go1's
+  ``commands_vel`` curriculum in the managers."""
+  import json
+  import subprocess
+
+  code = _ROUGH.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests")).replace('"Mjlab-Velocity-Rough-Unitree-G1"', '"Mjlab-Velocity-Rough-Unitree-Go1"')
+  assert "Rough-Unitree-Go1" in code
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print(st)
+  assert st["resets"] >= 16 and st["pushes"] >= 16 and st["quiet_env_steps"] >= 400 and st["level_moves"] >= 4, st
 
 
 def test_forward_on_the_reset_worlds_only_is_the_reference_on_those_worlds_and_the_last_step_on_the_others():

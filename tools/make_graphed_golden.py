@@ -36,9 +36,12 @@ ROOT = Path(__file__).resolve().parents[1]
 for p in (ROOT, ROOT / "tools", ROOT / "tests"):
   sys.path.insert(0, str(p))
 
-TASKS = {"g1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-G1", "g1_tracking_flat": "Mjlab-Tracking-Flat-Unitree-G1"}
+TASKS = {"g1_velocity_flat": "Mjlab-Velocity-Flat-Unitree-G1", "g1_tracking_flat": "Mjlab-Tracking-Flat-Unitree-G1",
+         # the two registered tasks no GraphedRlEnv test had run (reference tasks/tracking/config/g1/__init__.py:24,
+         # tasks/velocity/config/go1/__init__.py:4)
+         "g1_tracking_flat_nse": "Mjlab-Tracking-Flat-Unitree-G1-No-State-Estimation", "go1_velocity_rough": "Mjlab-Velocity-Rough-Unitree-Go1"}
 NUM_ENVS, SEED = 16, 21
-NUM_STEPS = {"g1_velocity_flat": 90, "g1_tracking_flat": 24}
+NUM_STEPS = {"g1_velocity_flat": 90, "g1_tracking_flat": 24, "g1_tracking_flat_nse": 24, "go1_velocity_rough": 90}
 MAX_EVENTS = {"reset": 10, "reward": 12, "obs": 6, "velocity": 8}  # recorded calls per kind (the first ones with content)
 
 
@@ -49,7 +52,7 @@ def record(scene: str) -> tuple[dict, dict]:
 
   from mjlab_amd.graphed_env import _as_slice, bookkeeping_plan
 
-  tracking = scene == "g1_tracking_flat"
+  tracking = scene.startswith("g1_tracking_flat")
   motion = None
   if tracking:
     from _motion_fixture import write_full_motion

@@ -38,6 +38,7 @@ TASKS = {
   "Mjlab-Velocity-Flat-Unitree-Go1": ("mjlab.tasks.velocity.config.go1.flat_env_cfg", "UnitreeGo1FlatEnvCfg"),
   "Mjlab-Velocity-Rough-Unitree-Go1": ("mjlab.tasks.velocity.config.go1.rough_env_cfg", "UnitreeGo1RoughEnvCfg"),
   "Mjlab-Tracking-Flat-Unitree-G1": ("mjlab.tasks.tracking.config.g1.flat_env_cfg", "G1FlatEnvCfg"),
+  "Mjlab-Tracking-Flat-Unitree-G1-No-State-Estimation": ("mjlab.tasks.tracking.config.g1.flat_env_cfg", "G1FlatNoStateEstimationEnvCfg"),
 }
 GENERIC_STUBS = ("mujoco_warp", "tyro", "rsl_rl", "tensordict", "trimesh", "viser", "wandb", "moviepy", "glfw", "OpenGL", "imageio", "mediapy",
                  "onnx", "onnxruntime", "PIL", "cv2")
