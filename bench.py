@@ -182,6 +182,7 @@ def main() -> None:
                   help="friction cone of the compiled model (the tasks configure pyramidal: the headline workload; elliptic = the cone variants of the kernels, an experiment line)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-latency-bound", action="store_true", help="skip the one-wave-per-SIMD launch that measures roofline.latency")
+  ap.add_argument("--no-big-batch", action="store_true", help="skip the 16 384-world leg (value_at_16384)")
   ap.add_argument("--no-full-env", action="store_true",
                   help="skip value_full_env (the reference's own ManagerBasedRlEnv of the same task stepped over this Simulation; "
                   "only measured where the reference source is reachable: MJLAB_REFERENCE_SRC / gpurun_ref, tools/stage_reference.sh)")
@@ -379,7 +380,7 @@ def main() -> None:
   # kernel is k_substep<NVP, true>: `substeps_per_call` whole physics steps of every world per launch; it is
   # bracketed here launch by launch on the same rollout (states keep evolving, resets included).  The
   # per-stage figures come from a second pass that runs the stage kernels one by one (informational).
-  solve_ms, stage_ms, dom_ms, dom_name, dom_sub, lat = None, {}, None, None, 1, None
+  solve_ms, stage_ms, dom_ms, dom_name, dom_sub, lat, big = None, {}, None, None, 1, None, None
   if info.rank == 0:
     reps = max(5, min(args.steps, 25))
     if roll.control_kernel:
@@ -452,6 +453,30 @@ def main() -> None:
         del qs, qr
       except Exception as e:  # noqa: BLE001
         lat = {"error": f"{type(e).__name__}: {e}"}
+    # ---- the same rollout on 16 384 worlds: four launches' worth of waves, so that a finished wave's slot goes to
+    # the next world and the launch's tail (a fifth of the 4096-world launch) is paid once per four batches.  `value` stays the 4096 line.
+    if roll.control_kernel and not args.no_big_batch and info.world_size == 1 and args.envs_per_gpu == 4096:
+      try:
+        nbig = 16384
+        bs = Simulation(nbig, SimulationCfg(njmax=int(os.environ.get("MJLAB_BENCH_NJMAX", 300)), fold_forward=not args.no_fold, fuse=args.fuse, ls_parallel=not args.exact_ls), model, dev)
+        br = PhysicsRollout(bs, action_scale=scale, decimation=4, seed=mdist.seed_for_rank(args.seed, info), fused_reset=True,
+                            min_height=-1.0e9 if "motion" in events else (0.3 if robot == "g1" else 0.15), substeps_per_call=args.substeps_per_call,
+                            control_kernel=True, **events)
+        if step_graph:
+          br.capture_graph()
+        for _ in range(min(args.settle, 100) + 5):
+          br.step(br.random_action(out=br.action_buffer))
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        nbs = 20
+        for _ in range(nbs):
+          br.step(br.random_action(out=br.action_buffer))
+        torch.cuda.synchronize()
+        big = {"value": nbig * nbs / (time.perf_counter() - tb), "num_envs": nbig, "steps": nbs, "settle_steps": min(args.settle, 100) + 5}
+        big["ms_per_step"] = nbig / big["value"] * 1e3
+        del bs, br
+      except Exception as e:  # noqa: BLE001
+        big = {"error": f"{type(e).__name__}: {e}"}
     stages = [("position", 1), ("collision", 2), ("velocity", 4), ("constraint", 8), ("solve_integrate", 48)]
     acc = {k: 0.0 for k, _ in stages}
     nlaunch = 0
@@ -642,6 +667,9 @@ def main() -> None:
       },
       "world_physics_steps_per_s": value * roll.decimation,
       "value_with_gather": value if exchange else value_with_rows,
+      # the same task on 16 384 worlds of this one GPU (20 control steps): the contention-free rate per world; `value` above is the 4096 line
+      "value_at_16384": big.get("value") if big else None,
+      "value_at_16384_detail": big,
       "value_full_env": full_env,
       "value_full_env_note": full_env_note,
       "value_full_env_graphed": full_env_graphed,

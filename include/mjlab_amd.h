@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MJLAB_ABI_VERSION 3 /* 2: the round-3 struct layouts (option: ls_parallel_min_step; sizes: nstaticsite; control: motion, read-back); 3: + the environment terms */
+#define MJLAB_ABI_VERSION 4 /* 2: the round-3 struct layouts (option: ls_parallel_min_step; sizes: nstaticsite; control: motion, read-back); 3: + the environment terms; 4: + round 6's entry points (mjlab_command_motion_frame, mjlab_command_motion_metrics, mjlab_copy_batch, mjlab_poison_scratch) */
 
 /* stage bits for mjlab_forward_stages (testing / profiling of single stages) */
 enum {
@@ -329,6 +329,47 @@ int mjlab_command_motion_frame(const mjlab_motion_tables_t* tab, int nworld, con
                                float* robot_body_pos_w, float* robot_body_quat_w, float* robot_body_lin_vel_w, float* robot_body_ang_vel_w,
                                void* stream);
 int mjlab_sizeof_motion_tables(void);
+/* MotionCommand._adaptive_sampling (:256-297) for the worlds of `mask`, the per-world part, in one launch: hist_out (bin_count floats) <-
+ * the number of worlds with mask & terminated per phase bin clamp(time_steps * bin_count // max(time_step_total, 1)) -- written when some
+ * world failed, or always (hist_always; any_failed_out then receives 0 / 1: a sharded caller all-reduces both); time_steps[w] <-
+ * long((searchsorted(cdf, U[w][1]) + U[w][2]) / bin_count * (time_step_total - 1)) where mask[w]; the three sampling metrics (nworld
+ * floats each) <- *entropy / *top1_prob / *top1_bin when some world is masked.  cdf (bin_count floats, the running sum of the sampling
+ * probabilities) and the three scalars are DEVICE values the caller computes once per control step.  bin_count <= MJLAB_MOTION_SAMPLE_MAX_BINS. */
+#define MJLAB_MOTION_SAMPLE_MAX_BINS 4096
+typedef struct mjlab_motion_sample {
+  const unsigned char* mask;       /* (nworld) torch.bool */
+  const unsigned char* terminated; /* (nworld) torch.bool */
+  long long* time_steps;           /* (nworld) torch.long, in / out */
+  const float* U;                  /* (nworld, ldu): column 1 picks the bin, column 2 the place inside it */
+  const float* cdf;                /* (bin_count) */
+  const float *entropy, *top1_prob, *top1_bin; /* device scalars */
+  float* hist_out;                 /* (bin_count) */
+  float* any_failed_out;           /* 1 float or NULL */
+  float *m_entropy, *m_top1_prob, *m_top1_bin; /* (nworld) each */
+  long long time_step_total;
+  int nworld, ldu, bin_count, hist_always;
+} mjlab_motion_sample_t;
+int mjlab_command_motion_sample(const mjlab_motion_sample_t* a, void* stream);
+int mjlab_sizeof_motion_sample(void);
+/* MotionCommand._update_metrics (:221-254): the ten tracking errors of every world in one launch, rows of `out` (10, nworld) in the
+ * order error_anchor_pos, error_anchor_rot, error_anchor_lin_vel, error_anchor_ang_vel, error_body_pos, error_body_rot,
+ * error_body_lin_vel, error_body_ang_vel (means over the nb tracked bodies), error_joint_pos, error_joint_vel.  The body arrays are the
+ * command term's properties, dense (nworld, nb, 3 | 4); the anchor's errors are row `anchor_index` of the body arrays (the term's
+ * anchor_* / robot_anchor_* properties are those rows); the robot's joint arrays may be row views (ld_* floats between rows).
+ * Logging quantities: a few ulp from the reference's torch reductions (summation order), not bit for bit. */
+typedef struct mjlab_motion_metrics {
+  const float *body_pos_w, *body_quat_w, *body_lin_vel_w, *body_ang_vel_w;
+  const float *robot_body_pos_w, *robot_body_quat_w, *robot_body_lin_vel_w, *robot_body_ang_vel_w;
+  const float *body_pos_relative_w, *body_quat_relative_w;
+  const float *joint_pos, *joint_vel;             /* (nworld, nj) dense */
+  const float *robot_joint_pos, *robot_joint_vel; /* (nworld, nj), ld_robot_joint_* floats between rows */
+  float* out;                                     /* (10, nworld) */
+  int ld_robot_joint_pos, ld_robot_joint_vel;
+  int nworld, nb, nj, anchor_index;
+} mjlab_motion_metrics_t;
+int mjlab_command_motion_metrics(const mjlab_motion_metrics_t* a, void* stream);
+int mjlab_sizeof_motion_metrics(void);
+
 
 /* RewardManager.compute's accumulation loop (managers/reward_manager.py:77-89) as one launch: `values` (k, nworld) holds the raw
  * outputs of the k terms with non-zero weight, in term order; per world and term value = raw * weights[i] * dt,

@@ -336,6 +336,111 @@ __global__ __launch_bounds__(256) void k_command_motion_frame(const mjlab_motion
   }
 }
 
+// MotionCommand._update_metrics (tasks/tracking/mdp/commands.py:221-254): the ten tracking errors the command term logs at a reset --
+// four of the anchor body, four averaged over the tracked bodies, two over the joints -- of every world in ONE launch; the reference
+// forms each from a subtraction, a norm (or quat_error_magnitude: math.py:682-693 = quat_box_minus :584-598 = axis_angle_from_quat :472-500
+// of q1 * conj(q2)) and a mean, ~130 small launches per control step.  One wave per world: lane b = tracked body b, lanes = joints for
+// the joint errors.  The values feed extras["log"] only (CommandTerm.reset: the mean over the environments that reset); the sums over
+// bodies / joints are formed in another order than torch's reductions, so they agree with the reference's to a few ulp, not bit for bit.
+__device__ __forceinline__ float wave_sum64(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float norm3_diff(const float* a, const float* b) {
+#pragma clang fp contract(off)
+  const float x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2];
+  return sqrtf(x * x + y * y + z * z);
+}
+__device__ __forceinline__ float quat_error_magnitude(const float* q1, const float* q2) {
+#pragma clang fp contract(off)
+  using namespace env_terms;
+  Quat d = quat_mul(Quat{q1[0], q1[1], q1[2], q1[3]}, Quat{q2[0], -q2[1], -q2[2], -q2[3]});
+  const float sgn = 1.0f - 2.0f * (d.w < 0.0f ? 1.0f : 0.0f);
+  d.w *= sgn; d.x *= sgn; d.y *= sgn; d.z *= sgn;
+  const float mag = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+  const float half = atan2f(mag, d.w), angle = 2.0f * half;
+  const float k = fabsf(angle) > 1.0e-6f ? sinf(half) / angle : 0.5f - angle * angle / 48.0f;
+  const float ax = d.x / k, ay = d.y / k, az = d.z / k;
+  return sqrtf(ax * ax + ay * ay + az * az);
+}
+__global__ __launch_bounds__(64) void k_command_motion_metrics(const mjlab_motion_metrics_t a) {
+#pragma clang fp contract(off)
+  const int w = blockIdx.x, lane = threadIdx.x, nb = a.nb;
+  float e_pos = 0.f, e_rot = 0.f, e_lin = 0.f, e_ang = 0.f, anchor[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = lane; b < nb; b += 64) {
+    const size_t o = (size_t)w * nb + b;
+    e_pos += norm3_diff(a.body_pos_relative_w + 3 * o, a.robot_body_pos_w + 3 * o);
+    e_rot += quat_error_magnitude(a.body_quat_relative_w + 4 * o, a.robot_body_quat_w + 4 * o);
+    e_lin += norm3_diff(a.body_lin_vel_w + 3 * o, a.robot_body_lin_vel_w + 3 * o);
+    e_ang += norm3_diff(a.body_ang_vel_w + 3 * o, a.robot_body_ang_vel_w + 3 * o);
+    if (b == a.anchor_index) {  // anchor_* = the anchor's rows of the body arrays, robot_anchor_* the same rows of the robot's
+      anchor[0] = norm3_diff(a.body_pos_w + 3 * o, a.robot_body_pos_w + 3 * o);
+      anchor[1] = quat_error_magnitude(a.body_quat_w + 4 * o, a.robot_body_quat_w + 4 * o);
+      anchor[2] = norm3_diff(a.body_lin_vel_w + 3 * o, a.robot_body_lin_vel_w + 3 * o);
+      anchor[3] = norm3_diff(a.body_ang_vel_w + 3 * o, a.robot_body_ang_vel_w + 3 * o);
+    }
+  }
+  float jp = 0.f, jv = 0.f;
+  for (int j = lane; j < a.nj; j += 64) {
+    const float dp = a.joint_pos[(size_t)w * a.nj + j] - a.robot_joint_pos[(size_t)w * a.ld_robot_joint_pos + j];
+    const float dv = a.joint_vel[(size_t)w * a.nj + j] - a.robot_joint_vel[(size_t)w * a.ld_robot_joint_vel + j];
+    jp += dp * dp; jv += dv * dv;
+  }
+  const float inv_nb = 1.0f / (float)nb;
+  float out[10] = {wave_sum64(anchor[0]), wave_sum64(anchor[1]), wave_sum64(anchor[2]), wave_sum64(anchor[3]), wave_sum64(e_pos) * inv_nb, wave_sum64(e_rot) * inv_nb,
+                   wave_sum64(e_lin) * inv_nb, wave_sum64(e_ang) * inv_nb, sqrtf(wave_sum64(jp)), sqrtf(wave_sum64(jv))};
+  if (lane < 10) {
+    float v = out[0];
+    for (int k = 1; k < 10; ++k) v = lane == k ? out[k] : v;
+    a.out[(size_t)lane * a.nworld + w] = v;
+  }
+}
+
+// MotionCommand._adaptive_sampling (tasks/tracking/mdp/commands.py:256-297), the per-world part, for the worlds of `mask` in ONE launch of
+// ONE workgroup (the histogram and the two "any" tests are over all worlds; 4096 worlds are four trips of 1024 threads): the failed worlds'
+// phase bins counted (:257-265), a new phase per masked world by inverse CDF (torch.multinomial's distribution without its host round trip:
+// bin = searchsorted(cdf, u1), phase = long((bin + u2) / bin_count * (total - 1)), :283-289), the three sampling metrics filled when some
+// world is masked (:292-297).  The distribution itself (cdf, entropy, top bin: once per control step) stays with the caller.
+// Integer and comparison work plus one float expression evaluated as torch evaluates it (division by a host scalar = multiplication by
+// its float32 reciprocal): the same phases as the torch restatement in mjlab_amd/graphed_env.py, bit for bit.
+__global__ __launch_bounds__(1024) void k_command_motion_sample(const mjlab_motion_sample_t a) {
+#pragma clang fp contract(off)
+  __shared__ float hist[MJLAB_MOTION_SAMPLE_MAX_BINS];
+  __shared__ int any_mask, any_failed;
+  const int tid = threadIdx.x, nbin = a.bin_count;
+  for (int b = tid; b < nbin; b += 1024) hist[b] = 0.f;
+  if (tid == 0) { any_mask = 0; any_failed = 0; }
+  __syncthreads();
+  const long long total = a.time_step_total, den = total > 1 ? total : 1;
+  const float inv_bins = __fdiv_rn(1.f, (float)nbin), span = (float)(total - 1);
+  for (int w = tid; w < a.nworld; w += 1024) {
+    const bool m = a.mask[w] != 0, failed = m && a.terminated[w] != 0;
+    const long long t = a.time_steps[w];
+    if (failed) {
+      long long bin = (t * nbin) / den;  // (both operands non-negative: floor division)
+      bin = bin < 0 ? 0 : bin > nbin - 1 ? nbin - 1 : bin;
+      atomicAdd(&hist[bin], 1.f);
+      any_failed = 1;
+    }
+    if (m) {
+      any_mask = 1;
+      const float u1 = a.U[(size_t)w * a.ldu + 1], u2 = a.U[(size_t)w * a.ldu + 2];
+      int lo = 0, hi = nbin;  // searchsorted(cdf, u1), right = False: the first index with cdf[i] >= u1
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.cdf[mid] < u1) lo = mid + 1; else hi = mid; }
+      const int bin = lo > nbin - 1 ? nbin - 1 : lo;
+      a.time_steps[w] = (long long)((((float)bin + u2) * inv_bins) * span);
+    }
+  }
+  __syncthreads();
+  if (a.hist_always || any_failed)
+    for (int b = tid; b < nbin; b += 1024) a.hist_out[b] = hist[b];
+  if (a.any_failed_out && tid == 0) *a.any_failed_out = any_failed ? 1.f : 0.f;
+  if (any_mask) {
+    const float H = *a.entropy, pm = *a.top1_prob, tb = *a.top1_bin;
+    for (int w = tid; w < a.nworld; w += 1024) { a.m_entropy[w] = H; a.m_top1_prob[w] = pm; a.m_top1_bin[w] = tb; }
+  }
+}
+
 // RewardManager.compute's accumulation (managers/reward_manager.py:77-89) for the k active terms whose raw values are the rows of
 // `values` (k, n): value = raw * weight * dt; reward += value (in term order); episode_sum[term] += value; step_reward[:, column] =
 // value / dt (as torch computes it: value * (1 / dt)).  Elementwise IEEE operations in the reference's order: the same bits as its 6 launches per term.

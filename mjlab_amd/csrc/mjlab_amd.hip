@@ -284,6 +284,29 @@ int mjlab_copy_batch(const mjlab_copy_entry_t* entries, int n, void* stream) {
   return 0;
 }
 
+int mjlab_sizeof_motion_sample(void) { return (int)sizeof(mjlab_motion_sample_t); }
+int mjlab_command_motion_sample(const mjlab_motion_sample_t* a, void* stream) {
+  if (!a) return fail(-25, "command_motion_sample: null argument");
+  const void* ptrs[] = {a->mask, a->terminated, a->time_steps, a->U, a->cdf, a->entropy, a->top1_prob, a->top1_bin, a->hist_out, a->m_entropy, a->m_top1_prob, a->m_top1_bin};
+  for (const void* p : ptrs) if (!p) return fail(-25, "command_motion_sample: null argument");
+  if (a->nworld < 1 || a->ldu < 3 || a->bin_count < 1 || a->bin_count > MJLAB_MOTION_SAMPLE_MAX_BINS || a->time_step_total < 1)
+    return fail(-25, "command_motion_sample: bad sizes (bin_count <= MJLAB_MOTION_SAMPLE_MAX_BINS, U needs three columns)");
+  hipLaunchKernelGGL(k_command_motion_sample, dim3(1), dim3(1024), 0, (hipStream_t)stream, *a);
+  return launched("k_command_motion_sample launch failed");
+}
+
+int mjlab_sizeof_motion_metrics(void) { return (int)sizeof(mjlab_motion_metrics_t); }
+int mjlab_command_motion_metrics(const mjlab_motion_metrics_t* a, void* stream) {
+  if (!a) return fail(-24, "command_motion_metrics: null argument");
+  const void* ptrs[] = {a->body_pos_w, a->body_quat_w, a->body_lin_vel_w, a->body_ang_vel_w, a->robot_body_pos_w, a->robot_body_quat_w, a->robot_body_lin_vel_w,
+                        a->robot_body_ang_vel_w, a->body_pos_relative_w, a->body_quat_relative_w, a->joint_pos, a->joint_vel, a->robot_joint_pos, a->robot_joint_vel, a->out};
+  for (const void* p : ptrs) if (!p) return fail(-24, "command_motion_metrics: null argument");
+  if (a->nworld < 1 || a->nb < 1 || a->nj < 1 || a->anchor_index < 0 || a->anchor_index >= a->nb || (a->nworld > 1 && (a->ld_robot_joint_pos < a->nj || a->ld_robot_joint_vel < a->nj)))
+    return fail(-24, "command_motion_metrics: bad sizes");
+  hipLaunchKernelGGL(k_command_motion_metrics, dim3((unsigned)a->nworld), dim3(64), 0, (hipStream_t)stream, *a);
+  return launched("k_command_motion_metrics launch failed");
+}
+
 int mjlab_command_motion_frame(const mjlab_motion_tables_t* tab, int nworld, const long long* time_steps, const float* env_origins, const float* body_link_pose_w,
                                const float* body_link_vel_w, int nbody_e, const int* track_ids, float* joint_pos, float* joint_vel, float* body_pos_w,
                                float* body_quat_w, float* body_lin_vel_w, float* body_ang_vel_w, float* robot_body_pos_w, float* robot_body_quat_w,

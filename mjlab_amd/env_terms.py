@@ -213,6 +213,76 @@ class MotionFrame:
     return self.views
 
 
+class MotionSampleArgs(ctypes.Structure):  # mjlab_motion_sample_t
+  _fields_ = [(k, _vp) for k in ("mask", "terminated", "time_steps", "U", "cdf", "entropy", "top1_prob", "top1_bin", "hist_out", "any_failed_out", "m_entropy",
+                                 "m_top1_prob", "m_top1_bin")] + [("time_step_total", ctypes.c_longlong)] \
+    + [(k, ctypes.c_int) for k in ("nworld", "ldu", "bin_count", "hist_always")]
+
+
+MOTION_SAMPLE_MAX_BINS = 4096  # include/mjlab_amd.h MJLAB_MOTION_SAMPLE_MAX_BINS
+
+
+def command_motion_sample(term, mask: torch.Tensor, terminated: torch.Tensor, U: torch.Tensor, cdf: torch.Tensor, entropy: torch.Tensor, top1_prob: torch.Tensor,
+                          top1_bin: torch.Tensor, hist_out: torch.Tensor, any_failed_out: torch.Tensor | None) -> None:
+  """MotionCommand._adaptive_sampling's per-world part for the worlds of `mask` (``mjlab_command_motion_sample``): the failed worlds' bins
+  counted into `hist_out` (when some world failed; always, with the 0 / 1 flag in `any_failed_out`, for a sharded caller), new phases by
+  inverse CDF into ``term.time_steps``, the sampling metrics filled from the three device scalars when some world is masked."""
+  a = MotionSampleArgs()
+  a.mask, a.terminated = _dense(mask, "mask", torch.bool).data_ptr(), _dense(terminated, "terminated", torch.bool).data_ptr()
+  a.time_steps = _dense(term.time_steps, "time_steps", torch.long).data_ptr()
+  a.U, a.ldu = _f32(U, "U").data_ptr(), int(U.stride(0))
+  a.cdf = _dense(cdf, "cdf", torch.float32).data_ptr()
+  for key, t in (("entropy", entropy), ("top1_prob", top1_prob), ("top1_bin", top1_bin)):
+    if t.dtype != torch.float32 or not t.is_cuda or t.numel() != 1:
+      raise TypeError(f"{key}: expected a float32 device scalar")
+    setattr(a, key, t.data_ptr())
+  a.hist_out = _dense(hist_out, "hist_out", torch.float32).data_ptr()
+  a.any_failed_out = 0 if any_failed_out is None else any_failed_out.data_ptr()
+  a.m_entropy, a.m_top1_prob, a.m_top1_bin = (_dense(term.metrics[k], k, torch.float32).data_ptr() for k in ("sampling_entropy", "sampling_top1_prob", "sampling_top1_bin"))
+  a.time_step_total, a.nworld, a.bin_count, a.hist_always = int(term.motion.time_step_total), mask.shape[0], int(term.bin_count), int(any_failed_out is not None)
+  if cdf.numel() != a.bin_count or hist_out.numel() != a.bin_count:
+    raise ValueError("cdf / hist_out: bin_count entries expected")
+  native.check(native.lib().mjlab_command_motion_sample(ctypes.byref(a), _stream(mask)), "mjlab_command_motion_sample")
+
+
+class MotionMetricsArgs(ctypes.Structure):  # mjlab_motion_metrics_t
+  _fields_ = [(k, _vp) for k in ("body_pos_w", "body_quat_w", "body_lin_vel_w", "body_ang_vel_w", "robot_body_pos_w", "robot_body_quat_w", "robot_body_lin_vel_w",
+                                 "robot_body_ang_vel_w", "body_pos_relative_w", "body_quat_relative_w", "joint_pos", "joint_vel", "robot_joint_pos", "robot_joint_vel", "out")] \
+    + [(k, ctypes.c_int) for k in ("ld_robot_joint_pos", "ld_robot_joint_vel", "nworld", "nb", "nj", "anchor_index")]
+
+
+class MotionMetrics:
+  """MotionCommand._update_metrics (reference tasks/tracking/mdp/commands.py:221-254) as ONE launch (``mjlab_command_motion_metrics``) into a
+  persistent (10, num_envs) buffer whose rows ARE the entries of ``term.metrics`` (bound once: the reference rebinds ten new tensors per
+  call).  Logging quantities (CommandTerm.reset averages them into ``extras["log"]``): a few ulp from the reference's torch reductions."""
+
+  KEYS = ("error_anchor_pos", "error_anchor_rot", "error_anchor_lin_vel", "error_anchor_ang_vel", "error_body_pos", "error_body_rot", "error_body_lin_vel",
+          "error_body_ang_vel", "error_joint_pos", "error_joint_vel")
+
+  def __init__(self, term) -> None:
+    self.term = term
+    self.buf = torch.zeros((len(self.KEYS), term.num_envs), dtype=torch.float32, device=term.time_steps.device)
+    self.rows = [self.buf[k] for k in range(len(self.KEYS))]
+    for row, key in zip(self.rows, self.KEYS, strict=True):
+      if key in term.metrics:  # what the reference's last update left (an environment that resets before the next update logs it)
+        row.copy_(term.metrics[key])
+      term.metrics[key] = row
+
+  def update(self) -> None:
+    t = self.term
+    a = MotionMetricsArgs()
+    for key in ("body_pos_w", "body_quat_w", "body_lin_vel_w", "body_ang_vel_w", "robot_body_pos_w", "robot_body_quat_w", "robot_body_lin_vel_w", "robot_body_ang_vel_w",
+                "body_pos_relative_w", "body_quat_relative_w", "joint_pos", "joint_vel"):
+      setattr(a, key, _dense(getattr(t, key), key, torch.float32).data_ptr())
+    rjp, rjv = _f32(t.robot_joint_pos, "robot_joint_pos"), _f32(t.robot_joint_vel, "robot_joint_vel")
+    a.robot_joint_pos, a.robot_joint_vel, a.ld_robot_joint_pos, a.ld_robot_joint_vel = rjp.data_ptr(), rjv.data_ptr(), _ld(rjp), _ld(rjv)
+    a.out = self.buf.data_ptr()
+    a.nworld, a.nb, a.nj, a.anchor_index = t.num_envs, len(t.cfg.body_names), rjp.shape[1], int(t.motion_anchor_body_index)
+    for row, key in zip(self.rows, self.KEYS, strict=True):  # (an eager reference step in between rebinds the entries: the rows stay the entries)
+      t.metrics[key] = row
+    native.check(native.lib().mjlab_command_motion_metrics(ctypes.byref(a), _stream(self.buf)), "mjlab_command_motion_metrics")
+
+
 def reward_accumulate(values: torch.Tensor, weights: torch.Tensor, columns: torch.Tensor, dt: float, reward_buf: torch.Tensor, sum_ptrs: torch.Tensor,
                       step_reward: torch.Tensor) -> None:
   """The mjlab_reward_accumulate launch on plain tensors: `values` (k, n) raw term outputs, `weights` (k) float32, `columns` (k) int32,

@@ -285,6 +285,9 @@ class GraphedRlEnv:
     fused_terms           None: HIP launches for the event / command / reward-accumulation terms on the GPU, torch restatements elsewhere
     fused_relative_poses  opt-in (tracking): ``MotionCommand``'s relative body poses from one launch -- 1 ulp from the reference's chain
     fused_motion_frame    (tracking, GPU) ``MotionCommand``'s gathered properties from one ``mjlab_command_motion_frame`` launch per phase (bit for bit)
+    fused_motion_metrics  (tracking, GPU) ``MotionCommand._update_metrics`` -- ten logging quantities, ~130 launches per step -- as one
+                          ``mjlab_command_motion_metrics`` launch into persistent rows of ``term.metrics`` (a few ulp from the reference's reductions;
+                          only ``extras["log"]`` reads them)
     forward               "reference": ``sim.forward()`` on all worlds whenever some environment reset; "reset_worlds" (opt-in): only those
     fused_entity_data     None: on the GPU ``EntityData``'s base quantities come from one ``mjlab_entity_readback`` launch per phase (bit for bit
                           the reference's chains); False: the reference's own chains
@@ -292,7 +295,7 @@ class GraphedRlEnv:
 
   def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None,
                fused_relative_poses: bool = False, forward: str = "reference", fused_entity_data: bool | None = None, fused_motion_frame: bool = True,
-               shard: Any = None, replicate_rng: bool = False) -> None:
+               fused_motion_metrics: bool = True, shard: Any = None, replicate_rng: bool = False) -> None:
     """``shard`` (mjlab_amd.dist.ShardInfo): this environment is rank ``shard.rank``'s slice of a batch of ``shard.global_envs``
     environments (worlds are independent, one process per GPU).  The control step itself needs nothing from the other
     ranks; what the reference computes over the WHOLE batch is exchanged by ``_exchange()`` right after the step -- outside the
@@ -321,6 +324,8 @@ class GraphedRlEnv:
     # MotionCommand's gathered properties (joint_pos, body_*_w, anchor_*_w, robot_body_*_w) from one launch per phase instead of an index
     # launch (+ an add) each: copies, bit for bit (round 6; tools/graphed_env_census.py: ~44 index launches per tracking step)
     self._fused_frame = bool(fused_motion_frame)
+    self._fused_metrics = bool(fused_motion_metrics) and self._fused
+    self._motion_metrics: dict = {}  # MotionCommand: env_terms.MotionMetrics (built at the first update: _update_metrics creates entries on its first call)
     # forward="reference": sim.forward() on ALL worlds whenever some environment reset, as the reference does (:129-132) -- with 4096
     # envs that is practically every step; "reset_worlds" (SURVEY 8f row 2): only the worlds that reset are recomputed, the others
     # keep the derived quantities of their last physics step, as they do in the reference in a step without resets.  Opt-in: the
@@ -471,6 +476,8 @@ class GraphedRlEnv:
           rix = term.robot.indexing
           self._motion_dev[id(term)] = (*env_terms.motion_tables(term), rix.joint_q_adr.to(torch.int32).contiguous(), rix.joint_v_adr.to(torch.int32).contiguous(),
                                         int(rix.body_ids[term.robot_anchor_body_index]))
+          if self._fused_metrics and all(k in term.metrics for k in env_terms.MotionMetrics.KEYS):  # (else at the first update, which creates the missing entries)
+            self._motion_metrics[id(term)] = env_terms.MotionMetrics(term)
         if self._cache_entity_data and not getattr(term, "_mjlab_amd_cached", False):
           _cache_properties(term.motion, [True])  # (the tables and body_indexes never change: kept for good, inside and outside the step)
           prefill = None
@@ -1071,7 +1078,12 @@ class GraphedRlEnv:
     """CommandManager.compute -> CommandTerm.compute (managers/command_manager.py:55-60)."""
     for name in self.env.command_manager.active_terms:
       term = self.env.command_manager.get_term(name)
-      term._update_metrics()  # the reference's own
+      if self._fused_metrics and type(term).__name__ == "MotionCommand":  # the ten tracking errors in one launch (logging quantities)
+        if id(term) not in self._motion_metrics:
+          self._motion_metrics[id(term)] = env_terms.MotionMetrics(term)
+        self._motion_metrics[id(term)].update()
+      else:
+        term._update_metrics()  # the reference's own
       U = self._Uof(("command", name, "compute"))
       if self._fused_command(term):  # time_left -= dt, resampling where it ran out, _update_command: one launch
         env_terms.command_uniform_velocity(term, None, U, self._command_ranges[id(term)]["table"], self.dt)
@@ -1121,36 +1133,33 @@ class GraphedRlEnv:
     """``_adaptive_sampling`` + ``_resample_command`` (:255-363).  The reference runs them only when the id list is non-empty; here
     the sampler's global state and metrics keep their values unless `mask` has an entry (``any`` on the device)."""
     rm, cfg, n, dev = self._m, term.cfg, self.n, self.device
-    anyone = mask.any()
     total = term.motion.time_step_total
     if cfg.disable_adaptive_sampling:
       term.time_steps.masked_fill_(mask, 0)
       self._terms_changed()
+    elif self._fused and term.bin_count <= env_terms.MOTION_SAMPLE_MAX_BINS:
+      # the per-world part of the sampler -- failure histogram, inverse-CDF draw, the three sampling metrics: ~25 launches per call, two
+      # calls per step -- as one launch; the distribution (once per step, below) stays in torch: the launch reads the SAME cdf, so the
+      # phases are the torch path's bit for bit
+      cdf, H, pmax, top = self._sampler_distribution(term)[4:]
+      hist, flag = term._current_bin_failed, None
+      if self._sharded:  # parked for _exchange(): the histogram is the global batch's (all-reduce) before the sampler's update reads it
+        row = self._bin_row(term)
+        hist, flag = row[: term.bin_count], row[term.bin_count:]
+      env_terms.command_motion_sample(term, mask, self.env.termination_manager.terminated, U, cdf, H, pmax, top, hist, flag)
+      self._terms_changed()
     else:
+      anyone = mask.any()
       failed = self.env.termination_manager.terminated & mask
       bins = torch.clamp((term.time_steps * term.bin_count) // max(total, 1), 0, term.bin_count - 1)
       counts = torch.zeros(term.bin_count, device=dev).scatter_add_(0, bins, failed.to(torch.float32))  # (:258-265: bincount of the failed envs' bins)
       if self._sharded:  # parked for _exchange(): the histogram is the global batch's (all-reduce) before the sampler's update reads it
-        buf = self._bin_calls.get(id(term))
-        if buf is None or buf.shape[0] <= self._bin_call:
-          old_buf = buf
-          buf = self._bin_calls[id(term)] = torch.zeros((self._bin_call + 1, term.bin_count + 1), device=dev)
-          if old_buf is not None:
-            buf[: old_buf.shape[0]] = old_buf
-        buf[self._bin_call, : term.bin_count] = counts
-        buf[self._bin_call, term.bin_count] = failed.any().to(torch.float32)
-        self._bin_call += 1
+        row = self._bin_row(term)
+        row[: term.bin_count] = counts
+        row[term.bin_count] = failed.any().to(torch.float32)
       else:
         term._current_bin_failed.copy_(torch.where(failed.any(), counts, term._current_bin_failed))
-      if id(term) not in self._sampler_cache:  # bin_failed_count changes once per step, after the last resample (_update_command's end)
-        p = term.bin_failed_count + cfg.adaptive_uniform_ratio / float(term.bin_count)
-        p = torch.nn.functional.pad(p.unsqueeze(0).unsqueeze(0), (0, cfg.adaptive_kernel_size - 1), mode="replicate")
-        p = torch.nn.functional.conv1d(p, term.kernel.view(1, 1, -1)).view(-1)
-        p = p / p.sum()
-        H = -(p * (p + 1e-12).log()).sum() / math.log(term.bin_count)
-        pmax, imax = p.max(dim=0)
-        self._sampler_cache[id(term)] = (torch.cumsum(p, 0), H.expand(n), pmax.expand(n), (imax.float() / term.bin_count).expand(n))
-      cdf, H, pmax, top = self._sampler_cache[id(term)]
+      cdf, H, pmax, top = self._sampler_distribution(term)[:4]
       # torch.multinomial(p, n, replacement=True) by inverse CDF (the same distribution, no host round trip)
       sampled = torch.searchsorted(cdf, U[:, 1].contiguous()).clamp_(max=term.bin_count - 1)
       t_new = ((sampled + U[:, 2]) / term.bin_count * (total - 1)).long()
@@ -1211,6 +1220,33 @@ class GraphedRlEnv:
     term.body_quat_relative_w = rm.quat_mul(delta_ori, term.body_quat_w)
     term.body_pos_relative_w = delta_pos + rm.quat_apply(delta_ori, term.body_pos_w - anchor_pos)
     self._sampler_update(term)
+
+  def _bin_row(self, term: Any) -> torch.Tensor:
+    """Sharded: the row of this resample call of the step in the term's parked histogram buffer (bin_count counts + an "any failed" flag)."""
+    buf = self._bin_calls.get(id(term))
+    if buf is None or buf.shape[0] <= self._bin_call:
+      old_buf = buf
+      buf = self._bin_calls[id(term)] = torch.zeros((self._bin_call + 1, term.bin_count + 1), device=self.device)
+      if old_buf is not None:
+        buf[: old_buf.shape[0]] = old_buf
+    self._bin_call += 1
+    return buf[self._bin_call - 1]
+
+  def _sampler_distribution(self, term: Any) -> tuple:
+    """The adaptive sampler's distribution (tasks/tracking/mdp/commands.py:267-281, :291-294), once per control step -- ``bin_failed_count``
+    changes after the last resample of a step (``_update_command``'s end): (cdf, H, pmax, top) expanded to the environments for the torch
+    path, then the same four with the last three as device scalars for the one-launch sampler."""
+    if id(term) not in self._sampler_cache:
+      cfg, n = term.cfg, self.n
+      p = term.bin_failed_count + cfg.adaptive_uniform_ratio / float(term.bin_count)
+      p = torch.nn.functional.pad(p.unsqueeze(0).unsqueeze(0), (0, cfg.adaptive_kernel_size - 1), mode="replicate")
+      p = torch.nn.functional.conv1d(p, term.kernel.view(1, 1, -1)).view(-1)
+      p = p / p.sum()
+      H = -(p * (p + 1e-12).log()).sum() / math.log(term.bin_count)
+      pmax, imax = p.max(dim=0)
+      cdf, top = torch.cumsum(p, 0), imax.float() / term.bin_count
+      self._sampler_cache[id(term)] = (cdf, H.expand(n), pmax.expand(n), top.expand(n), cdf, H, pmax, top)
+    return self._sampler_cache[id(term)]
 
   def _sampler_update(self, term: Any) -> None:
     """The end of ``_update_command`` (tasks/tracking/mdp/commands.py:389-392): the failure statistics take this step's histogram in.

@@ -18,7 +18,7 @@ def test_exports_every_declared_symbol():
   assert declared == set(native.EXPORTED_SYMBOLS)
   for sym in declared:
     assert hasattr(L, sym), sym
-  assert L.mjlab_abi_version() == native.ABI_VERSION == 3
+  assert L.mjlab_abi_version() == native.ABI_VERSION == 4
 
 
 def test_layout_matches_struct_sizes():

@@ -414,6 +414,119 @@ def test_command_motion_frame_equals_the_reference_gathers_bit_for_bit():
   del keep
 
 
+def test_command_motion_metrics_equal_the_reference_formulas():
+  """mjlab_command_motion_metrics (env_terms.MotionMetrics) against MotionCommand._update_metrics (reference tasks/tracking/mdp/commands.py:
+  221-254; quat_error_magnitude = math.py:682-693 over quat_box_minus :584-598 and axis_angle_from_quat :472-500) restated in float64 on
+  the same inputs: 1e-6 relative (logging quantities -- a few float32 ulp from the reference's torch reductions), small angles (the Taylor
+  branch), identical quaternions and a robot joint array that is a row view included."""
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(77)
+  nb, nj, a = 14, 29, 3
+  r = lambda *shape: torch.randn(shape, generator=g)  # noqa: E731
+  uq = lambda *shape: torch.nn.functional.normalize(r(*shape, 4), dim=-1)  # noqa: E731
+  t = types.SimpleNamespace(num_envs=N, metrics={"error_anchor_pos": torch.full((N,), 3.0).to(dev), "sampling_entropy": torch.zeros(N).to(dev)},
+                            time_steps=torch.zeros(N, dtype=torch.long, device=dev), cfg=types.SimpleNamespace(body_names=["b"] * nb), motion_anchor_body_index=a)
+  f = {"body_pos_w": r(N, nb, 3), "body_quat_w": uq(N, nb), "body_lin_vel_w": r(N, nb, 3), "body_ang_vel_w": r(N, nb, 3), "robot_body_pos_w": r(N, nb, 3),
+       "robot_body_quat_w": uq(N, nb), "robot_body_lin_vel_w": r(N, nb, 3), "robot_body_ang_vel_w": r(N, nb, 3), "body_pos_relative_w": r(N, nb, 3),
+       "body_quat_relative_w": uq(N, nb), "joint_pos": r(N, nj), "joint_vel": r(N, nj)}
+  f["robot_body_quat_w"][0] = f["body_quat_relative_w"][0]  # zero error: the Taylor branch of axis_angle_from_quat
+  f["robot_body_quat_w"][1] = torch.nn.functional.normalize(f["body_quat_relative_w"][1] + 1e-7 * r(nb, 4), dim=-1)
+  f["robot_body_quat_w"][2] = -f["body_quat_relative_w"][2]  # the same rotation, the other sign
+  state = r(N, 2 * nj + 5)
+  for k, v in f.items():
+    setattr(t, k, v.to(dev))
+  sd = state.to(dev)
+  t.robot_joint_pos, t.robot_joint_vel = sd[:, 2:2 + nj], sd[:, 2 + nj:2 + 2 * nj]  # row views, as EntityData hands them out
+  mm = env_terms.MotionMetrics(t)
+  assert float(t.metrics["error_anchor_pos"][0]) == 3.0 and set(env_terms.MotionMetrics.KEYS) <= set(t.metrics) and "sampling_entropy" in t.metrics
+  rows = [t.metrics[k] for k in env_terms.MotionMetrics.KEYS]
+  mm.update()
+  torch.cuda.synchronize()
+  assert all(t.metrics[k] is row for k, row in zip(env_terms.MotionMetrics.KEYS, rows, strict=True))  # the entries are bound once
+
+  d = {k: v.double() for k, v in f.items()}
+  rjp, rjv = state[:, 2:2 + nj].double(), state[:, 2 + nj:2 + 2 * nj].double()
+
+  def qmul(p, q):
+    w1, x1, y1, z1 = p.unbind(-1)
+    w2, x2, y2, z2 = q.unbind(-1)
+    return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                        w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+
+  def qerr(q1, q2):
+    q = qmul(q1, q2 * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=torch.float64))
+    q = q * (1.0 - 2.0 * (q[..., 0:1] < 0.0))
+    mag = q[..., 1:].norm(dim=-1)
+    half = torch.atan2(mag, q[..., 0])
+    ang = 2.0 * half
+    k = torch.where(ang.abs() > 1e-6, torch.sin(half) / ang, 0.5 - ang * ang / 48)
+    return (q[..., 1:4] / k.unsqueeze(-1)).norm(dim=-1)
+
+  want = {
+    "error_anchor_pos": (d["body_pos_w"][:, a] - d["robot_body_pos_w"][:, a]).norm(dim=-1), "error_anchor_rot": qerr(d["body_quat_w"][:, a], d["robot_body_quat_w"][:, a]),
+    "error_anchor_lin_vel": (d["body_lin_vel_w"][:, a] - d["robot_body_lin_vel_w"][:, a]).norm(dim=-1),
+    "error_anchor_ang_vel": (d["body_ang_vel_w"][:, a] - d["robot_body_ang_vel_w"][:, a]).norm(dim=-1),
+    "error_body_pos": (d["body_pos_relative_w"] - d["robot_body_pos_w"]).norm(dim=-1).mean(dim=-1), "error_body_rot": qerr(d["body_quat_relative_w"], d["robot_body_quat_w"]).mean(dim=-1),
+    "error_body_lin_vel": (d["body_lin_vel_w"] - d["robot_body_lin_vel_w"]).norm(dim=-1).mean(dim=-1),
+    "error_body_ang_vel": (d["body_ang_vel_w"] - d["robot_body_ang_vel_w"]).norm(dim=-1).mean(dim=-1),
+    "error_joint_pos": (d["joint_pos"] - rjp).norm(dim=-1), "error_joint_vel": (d["joint_vel"] - rjv).norm(dim=-1),
+  }
+  for k, v in want.items():
+    got = t.metrics[k].double().cpu()
+    # identical / sign-flipped / 1e-7-perturbed quaternions: the float32 product carries ~1e-7 of rounding, which IS the angle there (the
+    # reference's float32 chain has the same floor) -- absolute 1e-6 rad for those rows, 1e-6 relative elsewhere
+    assert bool(((got - v).abs() <= 1e-6 * v.abs() + 1e-6).all()), (k, float((got - v).abs().max()))
+  assert float(want["error_body_rot"][3:].min()) > 0.5  # (random orientations: the ordinary branch is what the bulk exercises)
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+@pytest.mark.parametrize("case", ["some", "nobody", "masked_but_nobody_failed"])
+def test_command_motion_sample_equals_the_torch_restatement_bit_for_bit(sharded, case):
+  """mjlab_command_motion_sample against the expressions of GraphedRlEnv._resample_MotionCommand's torch path (the mask-based form of
+  MotionCommand._adaptive_sampling, reference tasks/tracking/mdp/commands.py:256-297) on the same device and the same cdf: the failure
+  histogram, the new phases and the sampling metrics -- exact equality; an empty mask leaves everything as it was."""
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(5)
+  n, nbin, total = 4100, 23, 1117
+  p = torch.rand(nbin, generator=g) + 0.05
+  p = (p / p.sum()).to(dev)
+  cdf = torch.cumsum(p, 0)
+  H, pmax, top = (-(p * (p + 1e-12).log()).sum() / math.log(nbin)), p.max(), (p.argmax().float() / nbin)
+  mask = (torch.rand(n, generator=g) < 0.3).to(dev) if case != "nobody" else torch.zeros(n, dtype=torch.bool, device=dev)
+  terminated = (torch.rand(n, generator=g) < 0.5).to(dev) if case == "some" else torch.zeros(n, dtype=torch.bool, device=dev)
+  ts0 = torch.randint(0, total, (n,), generator=g).to(dev)
+  U = torch.rand((n, 40), generator=g).to(dev)[:, 3:30]  # a column slice of the step's block of uniforms
+  U[5, 1] = 0.0
+  U[6, 1] = 0.99999994  # beyond the last cdf entry where the running sum falls short of 1: clamped to the last bin
+  U[7, 1] = float(cdf[3])  # exactly on an edge: searchsorted's "first index with cdf >= u"
+  metrics0 = {k: torch.rand(n, generator=g).to(dev) for k in ("sampling_entropy", "sampling_top1_prob", "sampling_top1_bin")}
+  cur0 = torch.rand(nbin, generator=g).to(dev)
+  term = types.SimpleNamespace(time_steps=ts0.clone(), metrics={k: v.clone() for k, v in metrics0.items()}, bin_count=nbin,
+                               motion=types.SimpleNamespace(time_step_total=total), _current_bin_failed=cur0.clone())
+  row = torch.full((nbin + 1,), -1.0, device=dev)
+  env_terms.command_motion_sample(term, mask, terminated, U, cdf, H, pmax, top, row[:nbin] if sharded else term._current_bin_failed, row[nbin:] if sharded else None)
+  torch.cuda.synchronize()
+  # the torch path (mjlab_amd/graphed_env.py, _resample_MotionCommand)
+  failed = terminated & mask
+  bins = torch.clamp((ts0 * nbin) // max(total, 1), 0, nbin - 1)
+  counts = torch.zeros(nbin, device=dev).scatter_add_(0, bins, failed.to(torch.float32))
+  sampled = torch.searchsorted(cdf, U[:, 1].contiguous()).clamp_(max=nbin - 1)
+  t_new = ((sampled + U[:, 2]) / nbin * (total - 1)).long()
+  assert torch.equal(term.time_steps, torch.where(mask, t_new, ts0))
+  if sharded:
+    assert torch.equal(row[:nbin], counts) and float(row[nbin]) == float(failed.any()) and torch.equal(term._current_bin_failed, cur0)
+  else:
+    assert torch.equal(term._current_bin_failed, counts if bool(failed.any()) else cur0)
+  for k, val in (("sampling_entropy", H), ("sampling_top1_prob", pmax), ("sampling_top1_bin", top)):
+    assert torch.equal(term.metrics[k], val.expand(n) if bool(mask.any()) else metrics0[k]), k
+  if case == "some":
+    assert int(failed.sum()) > 100 and int(counts.sum()) == int(failed.sum()) and int(sampled[6]) == nbin - 1 and int(sampled[7]) == 3
+
+
 def test_copy_batch_copies_every_pair():
   """mjlab_copy_batch: 40 pairs (two launches) of float, int64 and bool tensors, odd byte counts included; strided / mixed-dtype pairs
   keep copy_."""

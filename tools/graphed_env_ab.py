@@ -28,12 +28,12 @@ if "Tracking" in task:
   def edit(cfg):
     cfg.commands.motion.motion_file = path
 
-VARIANTS = {"torch restatements": dict(fused_terms=False), "fused terms (default)": dict(), "fused terms + relative poses": dict(fused_relative_poses=True), "default without the motion-frame launch": dict(fused_motion_frame=False),
+VARIANTS = {"torch restatements": dict(fused_terms=False), "fused terms (default)": dict(), "fused terms + relative poses": dict(fused_relative_poses=True), "default without the motion-frame launch": dict(fused_motion_frame=False), "default without the metrics launch": dict(fused_motion_metrics=False),
             "no EntityData / term caches": dict(cache_entity_data=False), "forward() on the reset worlds only": dict(forward="reset_worlds"),
             "EntityData by the reference's own chains": dict(fused_entity_data=False)}
 envs = {}
 for name, kw in VARIANTS.items():
-  if ("relative" in name or "motion-frame" in name) and "Tracking" not in task:
+  if ("relative" in name or "motion-frame" in name or "metrics" in name) and "Tracking" not in task:
     continue
   env = reference_env.make_env(task, num_envs=n, device="cuda:0", cfg_edit=edit)
   env.reset()

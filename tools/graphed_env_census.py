@@ -12,6 +12,10 @@ fills / sums, the entity read-back) run as torch twins here: their operators are
 per call in the "on the device" column.
 
   python tools/graphed_env_census.py [task] [num_envs]
+  python tools/graphed_env_census.py [task] [num_envs] cuda:0     (GPU box, reference staged: the step body uncaptured over the HIP simulation
+                                                                  with the fused terms ON -- every HIP launch of this package is counted
+                                                                  where mjlab_amd.native.check reports it, every other launch is a torch
+                                                                  operator; scripted math helpers fuse further under the graph's profile)
 """
 from __future__ import annotations
 
@@ -84,8 +88,8 @@ class Census(TorchDispatchMode):
 def main():
   task = sys.argv[1] if len(sys.argv) > 1 else "Mjlab-Tracking-Flat-Unitree-G1"
   n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+  device = sys.argv[3] if len(sys.argv) > 3 else "cpu"
   import reference_env
-  from _oracle_simulation import OracleSimulation
 
   from mjlab_amd.graphed_env import GraphedRlEnv
 
@@ -99,19 +103,35 @@ def main():
     def edit(cfg):
       cfg.commands.motion.motion_file = path
 
-  env = reference_env.make_env(task, num_envs=n, device="cpu", sim_cls=OracleSimulation, seed=7, cfg_edit=edit)
+  hip = collections.Counter()
+  if device == "cpu":
+    from _oracle_simulation import OracleSimulation
+
+    env = reference_env.make_env(task, num_envs=n, device="cpu", sim_cls=OracleSimulation, seed=7, cfg_edit=edit)
+  else:
+    from mjlab_amd import native
+
+    env = reference_env.make_env(task, num_envs=n, device=device, seed=7, cfg_edit=edit)
+    orig_check = native.check
+
+    def counting_check(rc, what):  # every HIP launch of this package reports through native.check(rc, name)
+      hip[what] += 1
+      return orig_check(rc, what)
+
+    native.check = counting_check
   env.reset()
   g = GraphedRlEnv(env, capture=False)
   na = sum(env.action_manager.action_term_dim)
   for _ in range(3):
-    g.step(torch.rand(n, na) * 2 - 1)
+    g.step(torch.rand(n, na, device=device) * 2 - 1)
+  hip.clear()
   c = Census()
   steps = 4
   with c:
     for _ in range(steps):
-      g.step(torch.rand(n, na) * 2 - 1)
+      g.step(torch.rand(n, na, device=device) * 2 - 1)
   total = sum(sum(v.values()) for v in c.by_owner.values())
-  print(f"{task}: {total / steps:.0f} non-view operators per control step on the CPU (uncaptured body, {n} envs, mean of {steps} steps)")
+  print(f"{task}: {total / steps:.0f} non-view operators per control step on {device} (uncaptured body, {n} envs, mean of {steps} steps)")
   print(f"{'owner':70s} {'ops/step':>9s} {'launches/step on the device':>28s}")
   dev_total = 0.0
   for grp, fns in sorted(c.by_owner.items(), key=lambda kv: -sum(kv[1].values())):
@@ -124,6 +144,8 @@ def main():
     for fn, k in sorted(fns.items(), key=lambda kv: -kv[1])[:40]:
       print(f"    {fn:66s} {k / steps:9.1f}")
   print(f"{'TOTAL (estimate of graph nodes per step)':70s} {total / steps:9.1f} {dev_total:28.1f}")
+  if hip:
+    print(f"HIP launches of this package per step ({sum(hip.values()) / steps:.1f}):", ", ".join(f"{k} {v / steps:.1f}" for k, v in hip.most_common()))
   for opn in ("copy_", "clone", "index", "cat", "repeat", "where"):
     if c.who[opn]:
       print(f"{opn} ({sum(c.who[opn].values()) / steps:.0f} per step):", "; ".join(f"{k} {v / steps:.1f}" for k, v in c.who[opn].most_common(14)))
