@@ -116,9 +116,18 @@ def sharded_full_env(args, info, dev, model, tracking):
     def cfg_edit(cfg, _p=motion_path):
       cfg.commands.motion.motion_file = _p
 
-  env = reference_env.make_env(task, num_envs=args.envs_per_gpu, device=dev, seed=mdist.seed_for_rank(args.seed, info), cfg_edit=cfg_edit)
-  env.reset()
-  genv = GraphedRlEnv(env, shard=info)
+  # the set-up that can fail on ONE rank (construction, capture, memory) is agreed on before anybody enters the timed collectives: a rank that
+  # raised here used to skip ahead while the others waited for it in the next barrier -- now every rank reports "failed"
+  err = None
+  try:
+    env = reference_env.make_env(task, num_envs=args.envs_per_gpu, device=dev, seed=mdist.seed_for_rank(args.seed, info), cfg_edit=cfg_edit)
+    env.reset()
+    genv = GraphedRlEnv(env, shard=info, capture=False)
+  except Exception as e:  # noqa: BLE001
+    err = f"{type(e).__name__}: {e}"
+  if mdist.max_over_ranks(0.0 if err is None else 1.0, dev) > 0.0:
+    return None, f"failed during set-up on {'this' if err else 'another'} rank" + (f": {err}" if err else "")
+  genv.capture()  # (its warm-up steps hold the step's collectives: every rank is here)
   na = sum(env.action_manager.action_term_dim)
   gen = torch.Generator(device=dev)
   gen.manual_seed(args.seed)

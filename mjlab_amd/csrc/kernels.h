@@ -72,6 +72,7 @@ typedef float __attribute__((ext_vector_type(2))) f32x2;
 #define MJLAB_CB 8
 #endif
 #define MINVAL 1e-15f
+#define MINMU 1e-5f  // mjMINMU: the smallest contact friction coefficient (mj_contactParam's clamp)
 #define MINIMP 0.0001f
 #define MAXIMP 0.9999f
 #define MF(name) (m.name + (size_t)w * (size_t)m.name##_ws)

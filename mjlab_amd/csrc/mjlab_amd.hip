@@ -58,6 +58,7 @@ static int check_model(const mjlab_model_t* m) {
   if (m->opt.cone != MJLAB_CONE_PYRAMIDAL && m->opt.cone != MJLAB_CONE_ELLIPTIC) return fail(-5, "opt.cone must be MJLAB_CONE_PYRAMIDAL or MJLAB_CONE_ELLIPTIC");
   if (m->opt.cone == MJLAB_CONE_ELLIPTIC && (m->opt.solver != MJLAB_SOL_NEWTON || (m->opt.flags & MJLAB_OPT_FUSE_PRESOLVE)))
     return fail(-5, "MJLAB_CONE_ELLIPTIC runs with MJLAB_SOL_NEWTON, one kernel per stage or MJLAB_OPT_FUSE_STEP (no MJLAB_OPT_FUSE_PRESOLVE)");
+  if (m->opt.cone == MJLAB_CONE_ELLIPTIC && !(m->opt.impratio > 0)) return fail(-5, "opt.impratio must be positive (the elliptic cone's friction rows are scaled by 1 / impratio)");
   if (m->opt.integrator != MJLAB_INT_EULER && m->opt.integrator != MJLAB_INT_IMPLICITFAST)
     return fail(-6, "integrator must be Euler or implicitfast");
   if (m->opt.solver != MJLAB_SOL_CG && m->opt.solver != MJLAB_SOL_NEWTON && m->opt.solver != MJLAB_SOL_PGS)

@@ -330,12 +330,12 @@ __device__ __forceinline__ void emit_contacts(const Model& m, const Data& d, int
   if (pr1 != pr2) {
     const int gi = pr1 > pr2 ? g1 : g2;
     condim = m.geom_condim[gi];
-    for (int k = 0; k < 3; ++k) fri[k] = gfri[3 * gi + k];
+    for (int k = 0; k < 3; ++k) fri[k] = fmaxf(gfri[3 * gi + k], MINMU);  // (mj_contactParam: friction never below mjMINMU; the cone rows divide by it)
     for (int k = 0; k < 2; ++k) solref[k] = gsolref[2 * gi + k];
     for (int k = 0; k < 5; ++k) solimp[k] = gsolimp[5 * gi + k];
   } else {
     condim = max(m.geom_condim[g1], m.geom_condim[g2]);
-    for (int k = 0; k < 3; ++k) fri[k] = fmaxf(gfri[3 * g1 + k], gfri[3 * g2 + k]);
+    for (int k = 0; k < 3; ++k) fri[k] = fmaxf(fmaxf(gfri[3 * g1 + k], gfri[3 * g2 + k]), MINMU);  // (one v_max3_f32)
     const float sm1 = gsolmix[g1], sm2 = gsolmix[g2];
     float mix;
     if (sm1 >= MINVAL && sm2 >= MINVAL) mix = sm1 / (sm1 + sm2);

@@ -122,6 +122,13 @@ class LogBook:
         self.pub[k] = v
     return self.pub
 
+  def clear(self) -> None:
+    """Zero what has been published so far, keeping the vectors (and the tensors handed out) in place."""
+    if self.vec is not None:
+      self.vec.zero_()
+      self.raw.zero_()
+    self.first = False
+
   def finish(self, raw: torch.Tensor, first: bool) -> None:
     cnt = raw[-1]
     new = torch.where(self.div, raw[:-1] / cnt.clamp(min=1.0), raw[:-1]) * self.scale

@@ -608,7 +608,11 @@ class GraphedRlEnv:
 
   # ---------------------------------------------------------------------------------------------------------------- capture
   def capture(self, warmup: int = 2) -> None:
-    """Warm-up passes on a side stream (allocator, lazy initialisation inside the reference's properties), then the capture."""
+    """Warm-up passes on a side stream (allocator, lazy initialisation inside the reference's properties), then the capture.  At least ONE
+    warm-up pass runs whatever `warmup` says: the log book's vectors, the sharded histogram rows and the metric rows are
+    allocated at their first use, and a first use inside the capture would record ``vec.copy_(new)`` -- the "first publication" form --
+    into the graph, so that every replay overwrote ``extras["log"]`` instead of keeping the last reset step's numbers."""
+    warmup = max(1, int(warmup))
     saved = self._save_state()  # the warm-up passes are real steps (with a zero action): the environment gets its state back
     s = torch.cuda.Stream(device=self.device)
     s.wait_stream(torch.cuda.current_stream(self.device))
@@ -618,6 +622,7 @@ class GraphedRlEnv:
     torch.cuda.current_stream(self.device).wait_stream(s)
     for t, c in saved:
       t.copy_(c)
+    self._logbook.clear()  # (the warm-up's numbers are nobody's: until the first reset the published entries read 0, the reference's dict is empty)
     torch.cuda.synchronize(self.device)
     g = torch.cuda.CUDAGraph()
     self.graph_b = None
@@ -977,6 +982,12 @@ class GraphedRlEnv:
     """EntityData.clear_state (entity/data.py:171-181) for the environments of `mask`."""
     d = robot.data.data
     fv, bi, ci, _ = self._index_slices(robot)
+    if self._fused and all(isinstance(x, slice) for x in (fv, bi, ci)):  # the three fills (= 0.0, as the reference writes them) in one launch
+      fills = self.__dict__.setdefault("_clear_fills", {})
+      if id(robot) not in fills:
+        fills[id(robot)] = env_terms.MaskedFill([(d.qfrc_applied[:, fv], 0.0), (d.xfrc_applied[:, bi], 0.0), (d.ctrl[:, ci], 0.0)])
+      fills[id(robot)](mask)
+      return
     keep = (~mask).to(torch.float32)
     for arr, idx, k in ((d.qfrc_applied, fv, keep[:, None]), (d.xfrc_applied, bi, keep[:, None, None]), (d.ctrl, ci, keep[:, None])):
       if isinstance(idx, slice):

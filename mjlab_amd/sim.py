@@ -123,9 +123,10 @@ def check_supported(model: Model) -> None:
     raise NotImplementedError("opt.cone must be pyramidal or elliptic")
   if model.opt.cone == CONE_ELLIPTIC and model.opt.solver != SOL_NEWTON:
     raise NotImplementedError("the elliptic cone is implemented for the Newton solver only (pyramidal: Newton, CG, PGS)")
-  if model.opt.cone == CONE_ELLIPTIC and ((np.asarray(model.geom_condim) == 3) & (np.asarray(model.geom_friction)[:, 0] < 1e-5)).any():
-    # (MuJoCo clamps contact friction at mjMINMU = 1e-5; the cone's scaling divides by it, and neither the kernels nor the restatement clamp)
-    raise NotImplementedError("elliptic cones need a sliding friction >= 1e-5 on every condim-3 geom")
+  if model.opt.cone == CONE_ELLIPTIC and not float(model.opt.impratio) > 0.0:
+    raise ValueError("opt.impratio must be positive")
+  # (contact friction is clamped at mjMINMU = 1e-5 where the collision stage mixes it, like mj_contactParam: a per-world geom_friction that
+  # domain randomisation writes later cannot drive the cone rows' 1 / mu to infinity)
   if model.opt.integrator not in (INT_EULER, INT_IMPLICITFAST):
     raise NotImplementedError("integrator must be 'euler' or 'implicitfast'")
   if model.nv > 64:

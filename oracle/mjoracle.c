@@ -662,6 +662,7 @@ static void emit_contacts(const mjo_model_t* m, mjo_data_t* d, int w, int g1, in
     memcpy(D(contact_frame, 9 * ncm) + 9 * ncon, rc[i].frame, 9 * sizeof(real));
     D(contact_includemargin, ncm)[ncon] = margin - gap;
     real* f5 = D(contact_friction, 5 * ncm) + 5 * ncon;
+    for (int k = 0; k < 3; k++) if (fri[k] < (real)1e-5) fri[k] = (real)1e-5;  /* mj_contactParam: fri[i] = max(mjMINMU, fri[i]) */
     f5[0] = f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = f5[4] = fri[2];
     memcpy(D(contact_solref, 2 * ncm) + 2 * ncon, solref, sizeof(solref));
     memcpy(D(contact_solimp, 5 * ncm) + 5 * ncon, solimp, sizeof(solimp));

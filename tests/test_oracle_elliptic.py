@@ -98,6 +98,20 @@ def test_coulomb_friction_on_an_incline(phi):
   assert abs(across) < 0.01 * want and abs(a[2]) < 0.03 * G
 
 
+@pytest.mark.parametrize("cone", [CONE_ELLIPTIC, CONE_PYRAMIDAL])
+def test_contact_friction_is_clamped_at_mjMINMU(cone):
+  """mj_contactParam's ``fri[i] = max(mjMINMU, fri[i])``: a frictionless slab on a tilted frictionless plane keeps finite
+  rows (the cone rows divide by the friction), carries contact friction 1e-5 and slides at g sin(theta)."""
+  theta = 0.2
+  model = _box(0.0, _tilt(theta), cone=cone)
+  model.geom_friction[:] = 0.0
+  a, s, _ = _slide_acceleration(model, settle=50, measure=200)
+  ncon = int(s.ncon[0, 0])
+  assert ncon >= 1 and np.allclose(s.contact_friction[0, : 5 * ncon], 1e-5)
+  assert np.isfinite(s.qacc).all() and np.isfinite(s.efc_D[0, : int(s.nefc[0, 0])]).all()
+  assert abs(a[0] - G * np.sin(theta)) < 0.02 * G * np.sin(theta)
+
+
 def test_the_pyramid_is_anisotropic_where_the_ellipse_is_not():
   """MuJoCo's pyramid spans |f_1| + |f_2| <= mu f_n in the contact frame: full friction along a frame axis, mu / sqrt(2) on the diagonal
   (the slab accelerates faster there), and a force that is not antiparallel to the sliding velocity in between (it drifts across the slope)."""

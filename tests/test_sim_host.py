@@ -29,7 +29,6 @@ def test_supported_models_pass():
     (lambda m: setattr(m.opt, "solver", 3), "solver"),
     (lambda m: setattr(m.opt, "cone", 2), "cone"),
     (lambda m: (setattr(m.opt, "cone", 1), setattr(m.opt, "solver", 1)), "elliptic"),
-    (lambda m: (setattr(m.opt, "cone", 1), m.geom_friction.__setitem__((slice(None), 0), 0.0)), "sliding friction"),
     (lambda m: m.jnt_type.__setitem__(2, 1), "ball"),
     (lambda m: m.geom_condim.__setitem__(slice(None), 4), "condim"),
     (lambda m: m.sensor_intprm.__setitem__((0, 0), 3), "found"),
@@ -39,6 +38,18 @@ def test_unsupported_features_are_rejected(mutate, match):
   m = copy.deepcopy(robots.load_model("g1_velocity_flat"))
   mutate(m)
   with pytest.raises(NotImplementedError, match=match):
+    check_supported(m)
+
+
+def test_elliptic_cones_need_a_positive_impratio_and_accept_frictionless_geoms():
+  """impratio <= 0 is refused (it used to be clamped silently); a zero sliding friction is no longer refused -- the
+  collision stage and the restatement clamp contact friction at mjMINMU = 1e-5 like mj_contactParam (tests/test_oracle_elliptic.py)."""
+  m = copy.deepcopy(robots.load_model("g1_velocity_flat"))
+  m.opt.cone = 1
+  m.geom_friction[:, 0] = 0.0
+  check_supported(m)
+  m.opt.impratio = 0.0
+  with pytest.raises(ValueError, match="impratio"):
     check_supported(m)
 
 
