@@ -304,7 +304,7 @@ def main() -> None:
     torch.cuda.synchronize()
     value_with_rows = args.envs_per_gpu * args.steps / (time.perf_counter() - t1)
   # the exchange alone (N > 1), so that a scaling curve can be read: scatter of actions + gather of rows
-  comm_ms = None
+  comm_ms, allreduce_us = None, None
   if exchange:
     rows = roll.observation_rows()
     mdist.barrier()
@@ -316,6 +316,18 @@ def main() -> None:
       mdist.gather_rollout(info, rows)
     torch.cuda.synchronize()
     comm_ms = mdist.max_over_ranks((time.perf_counter() - t2) / 20 * 1e3, dev)
+    # the sharded full environment's mid-step collective (GraphedRlEnv._exchange_any: "did ANY environment of the global batch reset?", one
+    # float all-reduced between the step's two graphs): 200 back-to-back calls on the launch stream, one synchronisation -- its cost per step
+    flag = torch.zeros((), device=dev)
+    for _ in range(10):
+      torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+    mdist.barrier()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for _ in range(200):
+      torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    allreduce_us = mdist.max_over_ranks((time.perf_counter() - t3) / 200 * 1e6, dev)
 
   # ---- N > 1, second view: the rank's worlds as TWO HALF BATCHES whose learner round trips are interleaved -- while the rows of
   # one half travel to the learner and its next actions travel back (side stream, ordered by events), the other half steps
@@ -689,6 +701,7 @@ def main() -> None:
       "chunk_values": chunk_rates,
       "per_rank_ms_per_step": rank_ms,
       "exchange_ms_per_step": comm_ms,
+      "allreduce_4_bytes_us": allreduce_us,  # N > 1 (or MJLAB_DIST_FORCE): the sharded full environment's mid-step flag all-reduce, per call
       "pipelined": pipelined,
       "roofline": roof,
       "cpu_baseline": cpu,
