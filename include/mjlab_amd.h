@@ -314,10 +314,13 @@ int mjlab_command_motion_write(const mjlab_motion_tables_t* tab, float* qpos, in
                                const float* U, int ldu, const float* pose_range, const float* velocity_range, float joint_lo,
                                float joint_hi, void* stream);
 /* _update_command's body_pos_relative_w / body_quat_relative_w (:371-392) for every world and tracked body; xpos / xquat are mjData's
- * (nworld, nbody, 3 / 4), anchor_body_id the anchor's body id there, anchor_index its place among the tracked bodies. */
+ * (nworld, nbody, 3 / 4), anchor_body_id the anchor's body id there, anchor_index its place among the tracked bodies.  `exact` selects where
+ * the kernel rounds as the reference's jit-scripted helpers do on this stack (csrc/env_terms.h): 8 = their unfused form (pairwise sum of
+ * squares, cross products as fma), + 2 / 4 = yaw_quat / quat_apply as their NNC-fused kernels, + 16 s1 + 64 s2 = the two quat_mul calls (0 unfused, 1 / 2 = the fused kernel for 2-D / 3-D operands); 0: every operation rounded
+ * separately (1 ulp from any of them).  Which helpers run fused depends on the process's jit history: the caller calibrates. */
 int mjlab_command_motion_relative(const mjlab_motion_tables_t* tab, int nworld, const long long* time_steps, const float* env_origins,
                                   const float* xpos, const float* xquat, int nbody, int anchor_body_id, int anchor_index,
-                                  float* body_pos_relative_w, float* body_quat_relative_w, void* stream);
+                                  float* body_pos_relative_w, float* body_quat_relative_w, int exact, void* stream);
 /* MotionCommand's gathered properties (:128-215) of every world in one launch: joint_pos / joint_vel (nworld, nj), body_pos_w (+ the
  * world's env origin) / body_quat_w / body_lin_vel_w / body_ang_vel_w (nworld, nb, 3 | 4) of the motion frame time_steps[w], and -- when
  * body_link_pose_w (nworld, nbody_e, 7) / body_link_vel_w (nworld, nbody_e, 6: linear, angular) are given -- the robot's tracked bodies

@@ -243,9 +243,55 @@ __global__ __launch_bounds__(256) void k_command_motion_write(const mjlab_motion
 
 // MotionCommand._update_command's relative body poses (commands.py:371-392): the motion's bodies moved to the robot's anchor in x, y and
 // yaw.  One thread per (world, tracked body).
+// The reference's math helpers are torch.jit.script functions: after the profiling executor's first calls they run as NNC-fused kernels that
+// hiprtc compiles with its default -ffp-contract=fast, and THOSE are the reference's values in any run longer than two steps.  Which
+// products the compiler contracts into fma is fixed by the expressions; tools/experiments/rel_probe2.py found the sites by enumeration
+// against the reference's own functions on the MI355X (PyTorch 2.10 / ROCm 7.2: 0 of 229 376 elements differ per helper):
+//   quat_inv   sum of squares pairwise (a^2 + b^2) + (c^2 + d^2) (the reduction kernel's order), division unfused
+//   quat_mul   xx = fma(z1 + x1, x2 + y2, yy) + zz;  w, x: the last product contracted into the sum;  qq, y, z: no contraction (2-D operands;
+//              with the 3-D operands of _update_command also xx's last product and z's: tools/experiments/rel_probe_env.py)
+//   yaw_quat   atan2(2 fma(qw, qz, qx qy), 1 - 2 fma(qz, qz, qy qy))
+//   quat_apply cross products as fma(a, b, -(c d)) (at::cross, in either mode), vec + w t contracted, the second cross added plainly
+namespace env_terms {
+// style 1: the kernel NNC builds for 2-D (N, 4) operands; style 2: for 3-D (n, nb, 4) operands (what _update_command passes): the generated
+// source differs, and with it which products the compiler contracts -- xx's last product and z's
+__device__ __forceinline__ Quat quat_mul_nnc(const Quat a, const Quat b, const int style) {
+#pragma clang fp contract(off)
+  const float ww = (a.z + a.x) * (b.x + b.y), yy = (a.w - a.y) * (b.w + b.z), zz = (a.w + a.y) * (b.w - b.z);
+  const float in = __builtin_fmaf(a.z + a.x, b.x + b.y, yy);
+  const float xx = style == 2 ? __builtin_fmaf(a.w + a.y, b.w - b.z, in) : in + zz;
+  const float qq = 0.5f * (xx + (a.z - a.x) * (b.x - b.y));
+  Quat q;
+  q.w = __builtin_fmaf(a.z - a.y, b.y - b.z, qq - ww);
+  q.x = __builtin_fmaf(a.x + a.w, b.x + b.w, qq - xx);
+  q.y = (qq - yy) + (a.w - a.x) * (b.y + b.z);
+  q.z = style == 2 ? __builtin_fmaf(a.z + a.y, b.w - b.x, qq - zz) : (qq - zz) + (a.z + a.y) * (b.w - b.x);
+  return q;
+}
+__device__ __forceinline__ void cross3_nnc(float* o, const float* a, const float* b) {
+#pragma clang fp contract(off)
+  o[0] = __builtin_fmaf(a[1], b[2], -(a[2] * b[1]));
+  o[1] = __builtin_fmaf(a[2], b[0], -(a[0] * b[2]));
+  o[2] = __builtin_fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+__device__ __forceinline__ void quat_apply_nnc(float* o, const Quat q, const float* v, const bool fused) {
+#pragma clang fp contract(off)
+  const float xyz[3] = {q.x, q.y, q.z};
+  float t[3], c[3];
+  cross3_nnc(t, xyz, v);
+  for (int k = 0; k < 3; ++k) t[k] = t[k] * 2.f;
+  cross3_nnc(c, xyz, t);
+  for (int k = 0; k < 3; ++k) o[k] = (fused ? __builtin_fmaf(q.w, t[k], v[k]) : v[k] + q.w * t[k]) + c[k];
+}
+}  // namespace env_terms
+// _update_command's relative body poses (tasks/tracking/mdp/commands.py:370-392).  Whether a helper runs fused at a call site depends on the
+// jit's profiling history in the process (a call whose input types miss the profiled specialisations falls back to the unfused graph), so the
+// sites are switchable per helper and the caller calibrates against the reference's own functions (GraphedRlEnv._calibrate_relative).
+// `exact`: 8 = the reference-faithful base (quat_inv's pairwise sum, at::cross's fma form), + 2 yaw_quat fused, + 4 quat_apply's sum fused,
+// + 16 * s1 + 64 * s2 with s1 / s2 = the first / second quat_mul's form (0 unfused, 1 / 2 = the fused kernel for 2-D / 3-D operands); 0 = every operation rounded separately and a sequential sum of squares (round 5's kernel: 1 ulp from any of them).
 __global__ __launch_bounds__(256) void k_command_motion_relative(const mjlab_motion_tables_t tab, const int nworld, const long long* time_steps,
                                                                  const float* org, const float* xpos, const float* xquat, const int nbody,
-                                                                 const int anchor_body_id, const int anchor_index, float* out_pos, float* out_quat) {
+                                                                 const int anchor_body_id, const int anchor_index, float* out_pos, float* out_quat, const int exact) {
 #pragma clang fp contract(off)
   using namespace env_terms;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -262,21 +308,29 @@ __global__ __launch_bounds__(256) void k_command_motion_relative(const mjlab_mot
   const float* rp = xpos + ((size_t)w * nbody + anchor_body_id) * 3;
   const float* rq = xquat + ((size_t)w * nbody + anchor_body_id) * 4;
   // quat_inv (math.py:255-266): conjugate / clamp(sum of squares, 1e-9)
-  const float n2 = fmaxf(((aq[0] * aq[0] + aq[1] * aq[1]) + aq[2] * aq[2]) + aq[3] * aq[3], 1e-9f);
+  const bool f_yaw = exact & 2, f_app = exact & 4, base = exact & 8;
+  const int s_mul1 = (exact >> 4) & 3, s_mul2 = (exact >> 6) & 3;
+  const float ss = base ? (aq[0] * aq[0] + aq[1] * aq[1]) + (aq[2] * aq[2] + aq[3] * aq[3]) : ((aq[0] * aq[0] + aq[1] * aq[1]) + aq[2] * aq[2]) + aq[3] * aq[3];
+  const float n2 = fmaxf(ss, 1e-9f);
   const Quat inv{aq[0] / n2, -aq[1] / n2, -aq[2] / n2, -aq[3] / n2};
-  const Quat d = quat_mul(Quat{rq[0], rq[1], rq[2], rq[3]}, inv);
+  const Quat rqq{rq[0], rq[1], rq[2], rq[3]};
+  const Quat d = s_mul1 ? quat_mul_nnc(rqq, inv, s_mul1) : quat_mul(rqq, inv);
   // yaw_quat (math.py:560-582)
-  const float yaw = atan2f(2.f * (d.w * d.z + d.x * d.y), 1.f - 2.f * (d.y * d.y + d.z * d.z));
+  const float y1 = f_yaw ? 2.f * __builtin_fmaf(d.w, d.z, d.x * d.y) : 2.f * (d.w * d.z + d.x * d.y);
+  const float y2 = f_yaw ? 1.f - 2.f * __builtin_fmaf(d.z, d.z, d.y * d.y) : 1.f - 2.f * (d.y * d.y + d.z * d.z);
+  const float yaw = atan2f(y1, y2);
   float cw = cosf(yaw / 2.f), sz = sinf(yaw / 2.f);
   const float nrm = fmaxf(sqrtf(((cw * cw + 0.f) + 0.f) + sz * sz), 1e-9f);
   const Quat dq{cw / nrm, 0.f / nrm, 0.f / nrm, sz / nrm};
   const float* bq = tab.body_quat_w + 4 * fb;
-  const Quat oq = quat_mul(dq, Quat{bq[0], bq[1], bq[2], bq[3]});
+  const Quat bqq{bq[0], bq[1], bq[2], bq[3]};
+  const Quat oq = s_mul2 ? quat_mul_nnc(dq, bqq, s_mul2) : quat_mul(dq, bqq);
   float* oQ = out_quat + ((size_t)w * tab.nb + b) * 4;
   oQ[0] = oq.w, oQ[1] = oq.x, oQ[2] = oq.y, oQ[3] = oq.z;
   float rel[3], rot[3];
   for (int k = 0; k < 3; ++k) rel[k] = bpos[k] - apos[k];
-  quat_apply(rot, dq, rel);
+  if (base) quat_apply_nnc(rot, dq, rel, f_app);
+  else quat_apply(rot, dq, rel);
   float* oP = out_pos + ((size_t)w * tab.nb + b) * 3;
   oP[0] = rp[0] + rot[0], oP[1] = rp[1] + rot[1], oP[2] = apos[2] + rot[2];
 }

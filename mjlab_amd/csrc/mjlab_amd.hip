@@ -328,14 +328,14 @@ int mjlab_command_motion_frame(const mjlab_motion_tables_t* tab, int nworld, con
 
 int mjlab_command_motion_relative(const mjlab_motion_tables_t* tab, int nworld, const long long* time_steps, const float* env_origins, const float* xpos,
                                   const float* xquat, int nbody, int anchor_body_id, int anchor_index, float* body_pos_relative_w, float* body_quat_relative_w,
-                                  void* stream) {
+                                  int exact, void* stream) {
   int rc = check_tables(tab, "command_motion_relative: bad motion tables");
   if (rc) return rc;
   if (!time_steps || !env_origins || !xpos || !xquat || !body_pos_relative_w || !body_quat_relative_w) return fail(-22, "command_motion_relative: null argument");
   if (nworld < 1 || anchor_body_id < 0 || anchor_body_id >= nbody || anchor_index < 0 || anchor_index >= tab->nb) return fail(-22, "command_motion_relative: bad sizes");
   const long long total = (long long)nworld * tab->nb;
   hipLaunchKernelGGL(k_command_motion_relative, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *tab, nworld, time_steps, env_origins, xpos,
-                     xquat, nbody, anchor_body_id, anchor_index, body_pos_relative_w, body_quat_relative_w);
+                     xquat, nbody, anchor_body_id, anchor_index, body_pos_relative_w, body_quat_relative_w, exact);
   return launched("k_command_motion_relative launch failed");
 }
 int mjlab_sizeof_motion_tables(void) { return (int)sizeof(mjlab_motion_tables_t); }

@@ -150,12 +150,14 @@ def command_motion_write(tab: MotionTables, qpos: torch.Tensor, qvel: torch.Tens
 
 
 def command_motion_relative(tab: MotionTables, time_steps: torch.Tensor, env_origins: torch.Tensor, xpos: torch.Tensor, xquat: torch.Tensor, anchor_body_id: int,
-                            anchor_index: int, body_pos_relative_w: torch.Tensor, body_quat_relative_w: torch.Tensor) -> None:
+                            anchor_index: int, body_pos_relative_w: torch.Tensor, body_quat_relative_w: torch.Tensor, exact: int = 8 + 2 + 4 + 16 * 2 + 64 * 2) -> None:
+  """``exact`` (include/mjlab_amd.h): 8 = the reference helpers' unfused rounding, + 2 / 4 = yaw_quat / quat_apply as NNC-fused, + 16 s1 + 64 s2 = the two
+  quat_mul calls (0 unfused, 1 / 2 = fused for 2-D / 3-D operands); 0 = plain."""
   native.check(native.lib().mjlab_command_motion_relative(
     ctypes.byref(tab), xpos.shape[0], _dense(time_steps, "time_steps", torch.long).data_ptr(), _dense(env_origins, "env_origins", torch.float32).data_ptr(),
     _dense(xpos, "xpos", torch.float32).data_ptr(), _dense(xquat, "xquat", torch.float32).data_ptr(), xpos.shape[1], anchor_body_id, anchor_index,
     _dense(body_pos_relative_w, "body_pos_relative_w", torch.float32).data_ptr(), _dense(body_quat_relative_w, "body_quat_relative_w", torch.float32).data_ptr(),
-    _stream(xpos)), "mjlab_command_motion_relative")  # fmt: skip
+    int(exact), _stream(xpos)), "mjlab_command_motion_relative")  # fmt: skip
 
 
 class CopyEntry(ctypes.Structure):  # mjlab_copy_entry_t

@@ -283,7 +283,8 @@ class GraphedRlEnv:
     capture               False: the same step body runs eagerly (CPU runs over the oracle; debugging)
     cache_entity_data     property caches for ``EntityData`` / command terms and shared observation terms inside the step body
     fused_terms           None: HIP launches for the event / command / reward-accumulation terms on the GPU, torch restatements elsewhere
-    fused_relative_poses  opt-in (tracking): ``MotionCommand``'s relative body poses from one launch -- 1 ulp from the reference's chain
+    fused_relative_poses  (tracking, GPU; None = on) ``MotionCommand``'s relative body poses from one launch with the fma sites of the reference's
+                          jit-fused helpers: its steady-state values bit for bit (csrc/env_terms.h; tools/experiments/rel_probe2.py)
     fused_motion_frame    (tracking, GPU) ``MotionCommand``'s gathered properties from one ``mjlab_command_motion_frame`` launch per phase (bit for bit)
     fused_motion_metrics  (tracking, GPU) ``MotionCommand._update_metrics`` -- ten logging quantities, ~130 launches per step -- as one
                           ``mjlab_command_motion_metrics`` launch into persistent rows of ``term.metrics`` (a few ulp from the reference's reductions;
@@ -294,7 +295,7 @@ class GraphedRlEnv:
   """
 
   def __init__(self, env: Any, capture: bool = True, warmup: int = 2, cache_entity_data: bool = True, fused_terms: bool | None = None,
-               fused_relative_poses: bool = False, forward: str = "reference", fused_entity_data: bool | None = None, fused_motion_frame: bool = True,
+               fused_relative_poses: bool | None = None, forward: str = "reference", fused_entity_data: bool | None = None, fused_motion_frame: bool = True,
                fused_motion_metrics: bool = True, shard: Any = None, replicate_rng: bool = False) -> None:
     """``shard`` (mjlab_amd.dist.ShardInfo): this environment is rank ``shard.rank``'s slice of a batch of ``shard.global_envs``
     environments (worlds are independent, one process per GPU).  The control step itself needs nothing from the other
@@ -317,13 +318,15 @@ class GraphedRlEnv:
     # the event / command terms as one HIP launch each (mjlab_amd/env_terms.py) wherever the environment lives on the GPU; the
     # torch restatements below compute the same from the same uniforms (CPU runs over the oracle; fused_terms=False: A/B on the GPU)
     self._fused = torch.device(self.device).type == "cuda" if fused_terms is None else bool(fused_terms)
-    # MotionCommand's relative body poses feed the rewards and observations of EVERY environment in every step; the HIP launch agrees
-    # with the reference's jit-fused chain to 1 ulp, not bit for bit (tests/test_gpu_reference_env.py), so it is opt-in: the default
-    # keeps "rewards and quiet observations bit for bit with the eager reference step"
-    self._fused_relative = bool(fused_relative_poses) and self._fused
+    # MotionCommand's relative body poses feed the rewards and observations of EVERY environment in every step.  The reference's helpers
+    # are jit-scripted: from their third call on they run as NNC-fused kernels compiled with fp contraction, and the HIP launch places its
+    # fma instructions where those kernels have them (round 6): the same bits as the eager reference step (tests/test_gpu_reference_env.py:
+    # rewards and quiet observations bit for bit with it, the launch against the torch chain with 0 differing elements)
+    self._fused_relative = (True if fused_relative_poses is None else bool(fused_relative_poses)) and self._fused
     # MotionCommand's gathered properties (joint_pos, body_*_w, anchor_*_w, robot_body_*_w) from one launch per phase instead of an index
     # launch (+ an add) each: copies, bit for bit (round 6; tools/graphed_env_census.py: ~44 index launches per tracking step)
     self._fused_frame = bool(fused_motion_frame)
+    self._rel_mask: dict = {}  # MotionCommand: the calibrated rounding of the relative-poses launch (_calibrate_relative), -1 = torch chain
     self._fused_metrics = bool(fused_motion_metrics) and self._fused
     self._motion_metrics: dict = {}  # MotionCommand: env_terms.MotionMetrics (built at the first update: _update_metrics creates entries on its first call)
     # forward="reference": sim.forward() on ALL worlds whenever some environment reset, as the reference does (:129-132) -- with 4096
@@ -1214,13 +1217,21 @@ class GraphedRlEnv:
     term.time_steps += 1
     self._terms_changed()
     self._resample_MotionCommand(term, term.time_steps >= term.motion.time_step_total, U)
-    if self._fused_relative:
+    if self._fused_relative and self._rel_mask.get(id(term)) is None:
+      self._calibrate_relative(term)
+    if self._fused_relative and self._rel_mask[id(term)] >= 0:
       tab, _, _, _, anchor_gid = self._motion_dev[id(term)]
       d = term.robot.data.data
       env_terms.command_motion_relative(tab, term.time_steps, self.env.scene.env_origins, d.xpos, d.xquat, anchor_gid, term.motion_anchor_body_index,
-                                        term.body_pos_relative_w, term.body_quat_relative_w)
+                                        term.body_pos_relative_w, term.body_quat_relative_w, self._rel_mask[id(term)])
       self._sampler_update(term)
       return
+    self._relative_chain(term)
+    self._sampler_update(term)
+
+  def _relative_chain(self, term: Any) -> None:
+    """The reference's own chain for the relative body poses (tasks/tracking/mdp/commands.py:370-392), rebinding the two attributes."""
+    rm = self._m
     nb = len(term.cfg.body_names)
     anchor_pos = term.anchor_pos_w[:, None, :].repeat(1, nb, 1)
     anchor_quat = term.anchor_quat_w[:, None, :].repeat(1, nb, 1)
@@ -1230,7 +1241,33 @@ class GraphedRlEnv:
     delta_ori = rm.yaw_quat(rm.quat_mul(robot_quat, rm.quat_inv(anchor_quat)))
     term.body_quat_relative_w = rm.quat_mul(delta_ori, term.body_quat_w)
     term.body_pos_relative_w = delta_pos + rm.quat_apply(delta_ori, term.body_pos_w - anchor_pos)
-    self._sampler_update(term)
+
+  def _calibrate_relative(self, term: Any) -> None:
+    """Which rounding of the relative-poses launch IS the reference's chain in this process?  The reference's helpers are jit-scripted:
+    a call site runs them as NNC-fused kernels (fp contraction) or as their unfused graphs, depending on what the profiling executor has
+    specialised for so far.  The chain is run a few times on the current state (so that its mode has settled), then the launch under
+    each of its 36 roundings (csrc/env_terms.h); the one without a single differing element is used from here on.  None: the torch chain
+    stays (a PyTorch whose fuser contracts differently) -- the launch never runs with a rounding that was not verified."""
+    if torch.cuda.is_current_stream_capturing():
+      raise RuntimeError("the relative-poses launch is calibrated in the warm-up pass, not under capture")
+    tab, _, _, _, anchor_gid = self._motion_dev[id(term)]
+    d = term.robot.data.data
+    keep = (term.body_pos_relative_w, term.body_quat_relative_w)
+    for _ in range(4):
+      self._relative_chain(term)
+    want_p, want_q = term.body_pos_relative_w, term.body_quat_relative_w
+    term.body_pos_relative_w, term.body_quat_relative_w = keep
+    out_p, out_q = torch.empty_like(want_p), torch.empty_like(want_q)
+    found = -1
+    full, none = 8 + 2 + 4 + 16 * 2 + 64 * 2, 8
+    masks = [full, none] + [8 + y + a + 16 * s1 + 64 * s2 for s1 in (2, 1, 0) for s2 in (2, 1, 0) for y in (2, 0) for a in (4, 0)]
+    for mask in dict.fromkeys(masks):  # every helper fused (in the form _update_command's operands get), none, then the mixed cases
+      env_terms.command_motion_relative(tab, term.time_steps, self.env.scene.env_origins, d.xpos, d.xquat, anchor_gid, term.motion_anchor_body_index, out_p, out_q, mask)
+      if torch.equal(out_p, want_p) and torch.equal(out_q, want_q):
+        found = mask
+        break
+    self._rel_mask[id(term)] = found
+    self.relative_rounding = found  # (diagnostic: 174 = every helper fused, 8 = none; -1 = the torch chain is used)
 
   def _bin_row(self, term: Any) -> torch.Tensor:
     """Sharded: the row of this resample call of the step in the term's parked histogram buffer (bin_count counts + an "any failed" flag)."""

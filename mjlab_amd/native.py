@@ -163,7 +163,7 @@ def lib() -> ctypes.CDLL:
   L.mjlab_copy_batch.argtypes = [vp, ci, vp]
   L.mjlab_command_motion_metrics.argtypes = [vp, vp]
   L.mjlab_command_motion_sample.argtypes = [vp, vp]
-  L.mjlab_command_motion_relative.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
+  L.mjlab_command_motion_relative.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, ci, vp]
   L.mjlab_control_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
   L.mjlab_forward_stages.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
   L.mjlab_tile_field.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]

@@ -329,6 +329,7 @@ def run_fused_vs_torch_tracking(make_env, device: str, num_envs: int = 128, step
       worst[f] = max(worst[f], float((getattr(ca, f) - getattr(cb, f)).abs().max()))
     stats["resets"] += int((term_a | to_a).sum())
   stats["worst"] = worst
+  stats["relative_rounding"] = getattr(ga, "relative_rounding", None)  # which rounding of the relative-poses launch reproduced the reference's chain (-1: none, torch chain in use)
   return stats
 
 
@@ -405,4 +406,5 @@ def run_tracking(make_env, device: str, num_envs: int = 32, steps: int = 40, cap
         assert bool((env.episode_length_buf[reset] == 0).all())
     stats["resets"] += int(reset.sum()); stats["ended"] += int((ended & ~reset).sum()); stats["pushes"] += int(push.sum()); stats["quiet_env_steps"] += int(quiet.sum())
   stats["graph"] = g.graph is not None
+  stats["relative_rounding"] = getattr(g, "relative_rounding", None)
   return stats

@@ -214,6 +214,7 @@ def test_graphed_tracking_env_matches_the_reference_env(tmp_path):
   st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
   print("graphed tracking env vs reference env:", st)
   assert st["graph"] and st["resets"] >= 32 and st["ended"] >= 32 and st["pushes"] >= 64 and st["quiet_env_steps"] >= 2000  # measured: 71 / 108 / 339 / 4618
+  assert st["relative_rounding"] >= 8, st  # the relative body poses came from the one launch, in a rounding calibrated against the reference's chain
 
 
 def test_graphed_tracking_env_without_state_estimation(tmp_path):
@@ -357,4 +358,7 @@ def test_fused_motion_command_equals_its_torch_restatement(tmp_path):
   print("fused MotionCommand vs torch restatement:", st)
   w = st["worst"]
   assert st["resets"] >= 32 and st["ended"] >= 32
+  # (the two sides' states differ by an ulp after a resample -- the state write is 1 ulp from its torch restatement -- so the relative poses
+  # are compared to a tolerance here; bit for bit against the eager reference on identical inputs: test_graphed_tracking_env_matches_the_reference_env)
   assert w["qpos"] <= 2e-6 and w["qvel"] <= 1e-5 and w["body_pos_relative_w"] <= 2e-6 and w["body_quat_relative_w"] <= 2e-6 and w["obs"] <= 1e-4 and w["reward"] <= 1e-5, w
+  assert st["relative_rounding"] >= 8, st  # the launch was calibrated (a rounding that reproduces the reference's chain was found), not replaced by the torch chain

@@ -28,7 +28,7 @@ if "Tracking" in task:
   def edit(cfg):
     cfg.commands.motion.motion_file = path
 
-VARIANTS = {"torch restatements": dict(fused_terms=False), "fused terms (default)": dict(), "fused terms + relative poses": dict(fused_relative_poses=True), "default without the motion-frame launch": dict(fused_motion_frame=False), "default without the metrics launch": dict(fused_motion_metrics=False),
+VARIANTS = {"torch restatements": dict(fused_terms=False), "fused terms (default)": dict(), "default without the relative-poses launch": dict(fused_relative_poses=False), "default without the motion-frame launch": dict(fused_motion_frame=False), "default without the metrics launch": dict(fused_motion_metrics=False),
             "no EntityData / term caches": dict(cache_entity_data=False), "forward() on the reset worlds only": dict(forward="reset_worlds"),
             "EntityData by the reference's own chains": dict(fused_entity_data=False)}
 envs = {}
