@@ -10,7 +10,7 @@ gap in ONE command on a machine that has them:
 
 ``--dry-run`` runs the SAME code path here -- the reference's task registry, Scene and MujocoCfg over this repository's
 ``mujoco`` shim, and tools/fake_mjwarp.py (``mujoco_warp`` + ``warp`` backed by the fp32 oracle) in place of the engine -- and
-writes tests/golden_upstream_dryrun/ (git-ignored).  tests/test_upstream_dryrun.py does that in CI and feeds the output through
+writes tests/golden_upstream_dryrun/ (committed: the GPU box has no reference tree, and the HIP-side consumers read it there).  tests/test_upstream_dryrun.py does that in CI and feeds the output through
 the very comparison code the upstream tests use, so every line of this tool and of its consumers has executed before the real run.
 
 Per scene it writes two files, each with ``ls_parallel`` on (the reference's setting, sim/sim.py:89,111) AND off (the seeded-state file also
