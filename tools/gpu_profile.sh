@@ -6,7 +6,7 @@ TAG=${1:-profile}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 R=$(pwd)
 timeout 90 python -c "import torch; x = torch.ones(1024, device='cuda'); print('gpu ok', float((x * 2).sum()))" || { echo "GPU SANITY FAILED" | tee -a $OUT/status.txt; exit 9; }
-BCMD="python $R/bench.py --scene ${SCENE:-g1_velocity_flat} --steps 40 --warmup 10 --no-cpu-baseline --no-full-env --no-latency-bound"  # (the quarter-size launches of roofline.latency would mix into the kernel's average)
+BCMD="python $R/bench.py --scene ${SCENE:-g1_velocity_flat} --steps 40 --warmup 10 --no-cpu-baseline --no-full-env --no-latency-bound --no-big-batch"  # (the quarter-size launches of roofline.latency would mix into the kernel's average)
 (cd /tmp && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- $BCMD > $R/$OUT/prof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/status.txt
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 120 rocprofv3 --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o pmc -- $BCMD > $R/$OUT/pmc_$C.log 2>&1); echo "pmc $C rc=$?" | tee -a $OUT/status.txt
