@@ -19,6 +19,7 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
     const float omx = 1.f - x, omm = 1.f - mid;
     y = 1.f - ((power == 2.f) ? omx * omx / omm : powf(omx, power) / powf(omm, power - 1.f));
   }
+  if (solimp[2] <= MINVAL) y = 0.5f;  // mj getimpedance's flat case (width <= mjMINVAL): the mean of dmin and dmax (the one divergence read in the restatement)
   return dmin + y * (dmax - dmin);
 }
 // reference acceleration and regulariser of one row

@@ -788,6 +788,7 @@ static real impedance(const real* solimp, real pos, real margin) {
   else if (x == 0) y = 0;
   else if (x <= mid) y = (1 / pow(mid, power - 1)) * pow(x, power);
   else y = 1 - (1 / pow(1 - mid, power - 1)) * pow(1 - x, power);
+  if (solimp[2] <= MINVAL) y = (real)0.5; /* mj getimpedance: "flat function" when the width is <= mjMINVAL -- imp = 0.5 (dmin + dmax) */
   return dmin + y * (dmax - dmin);
 }
 

@@ -427,7 +427,7 @@ def test_capacity_paths_with_hundreds_of_contacts(njmax):
     assert float(cost_gpu[w]) <= cost_o * 1.05 + 1e-6, (w, float(cost_gpu[w]), cost_o)
 
 
-@pytest.mark.parametrize("variant", ["impratio", "direct_solref", "margin_gap", "solimp_power", "euler_damped", "springs", "frictionloss"])
+@pytest.mark.parametrize("variant", ["impratio", "direct_solref", "margin_gap", "solimp_power", "solimp_flat", "euler_damped", "springs", "frictionloss"])
 def test_parameter_branches_match_oracle(variant):
   """Less-travelled branches of the constraint parameter code (impratio scaling of the pyramid
   regulariser, negative solref = direct stiffness/damping, geom margin/gap, solimp power != 2,
@@ -450,6 +450,8 @@ def test_parameter_branches_match_oracle(variant):
     model.geom_gap = np.full_like(model.geom_gap, 0.005)
   elif variant == "solimp_power":
     model.geom_solimp = np.tile(np.array([0.8, 0.97, 0.01, 0.3, 3.0]), (model.ngeom, 1))
+  elif variant == "solimp_flat":  # width 0: mj getimpedance's flat case, imp = 0.5 (dmin + dmax) (round 6)
+    model.geom_solimp = np.tile(np.array([0.8, 0.95, 0.0, 0.5, 2.0]), (model.ngeom, 1))
   elif variant == "euler_damped":
     model.opt.integrator = mjcf.INT_EULER
     model.dof_damping = np.where(np.arange(model.nv) >= model.nv - 2, 0.8, 0.0)
