@@ -38,6 +38,9 @@ def test_every_kernel_fits_four_waves_per_simd(kernels):
       assert md["vgpr_spill_count"] == 0 or md["vgpr_count"] <= 168, (name, md)
       continue
     assert md["vgpr_count"] <= 128, (name, md)
+    if "k_command_motion_sample" in name:  # an environment term, ONE workgroup per launch: its histogram (MJLAB_MOTION_SAMPLE_MAX_BINS floats + two flags) is static LDS
+      assert md["group_segment_fixed_size"] <= 4 * 4096 + 16, (name, md)
+      continue
     assert md["group_segment_fixed_size"] == 0, (name, md)  # LDS is laid out per model at launch (mjlab_lds_bytes)
     # scratch per lane: the 64-dof instantiations (beyond every model of the reference) spill the most
     assert md["private_segment_fixed_size"] <= (1024 if "ILi64E" in name else 512), (name, md)
