@@ -336,7 +336,7 @@ int mjlab_sizeof_motion_tables(void);
  * the number of worlds with mask & terminated per phase bin clamp(time_steps * bin_count // max(time_step_total, 1)) -- written when some
  * world failed, or always (hist_always; any_failed_out then receives 0 / 1: a sharded caller all-reduces both); time_steps[w] <-
  * long((searchsorted(cdf, U[w][1]) + U[w][2]) / bin_count * (time_step_total - 1)) where mask[w]; the three sampling metrics (nworld
- * floats each) <- *entropy / *top1_prob / *top1_bin when some world is masked.  cdf (bin_count floats, the running sum of the sampling
+ * floats each) <- *entropy / *top1_prob / *top1_bin when some world is masked; optionally the command term's timer and counter.  cdf (bin_count floats, the running sum of the sampling
  * probabilities) and the three scalars are DEVICE values the caller computes once per control step.  bin_count <= MJLAB_MOTION_SAMPLE_MAX_BINS. */
 #define MJLAB_MOTION_SAMPLE_MAX_BINS 4096
 typedef struct mjlab_motion_sample {
@@ -351,6 +351,12 @@ typedef struct mjlab_motion_sample {
   float *m_entropy, *m_top1_prob, *m_top1_bin; /* (nworld) each */
   long long time_step_total;
   int nworld, ldu, bin_count, hist_always;
+  /* optional (NULL: skipped): CommandTerm._resample's own two lines for the masked worlds (managers/command_manager.py:62-66) --
+   * time_left[w] = U[w][0] * resampling_width + resampling_lo (width = hi - lo rounded to float, as torch multiplies by the scalar),
+   * command_counter[w] += 1 */
+  float* time_left;
+  long long* command_counter;
+  float resampling_width, resampling_lo;
 } mjlab_motion_sample_t;
 int mjlab_command_motion_sample(const mjlab_motion_sample_t* a, void* stream);
 int mjlab_sizeof_motion_sample(void);

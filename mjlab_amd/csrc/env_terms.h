@@ -478,6 +478,10 @@ __global__ __launch_bounds__(1024) void k_command_motion_sample(const mjlab_moti
     }
     if (m) {
       any_mask = 1;
+      if (a.time_left) {  // CommandTerm._resample (managers/command_manager.py:62-66): a new timer and one more resample on the counter
+        a.time_left[w] = a.U[(size_t)w * a.ldu] * a.resampling_width + a.resampling_lo;
+        a.command_counter[w] += 1;
+      }
       const float u1 = a.U[(size_t)w * a.ldu + 1], u2 = a.U[(size_t)w * a.ldu + 2];
       int lo = 0, hi = nbin;  // searchsorted(cdf, u1), right = False: the first index with cdf[i] >= u1
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.cdf[mid] < u1) lo = mid + 1; else hi = mid; }

@@ -290,6 +290,7 @@ int mjlab_command_motion_sample(const mjlab_motion_sample_t* a, void* stream) {
   if (!a) return fail(-25, "command_motion_sample: null argument");
   const void* ptrs[] = {a->mask, a->terminated, a->time_steps, a->U, a->cdf, a->entropy, a->top1_prob, a->top1_bin, a->hist_out, a->m_entropy, a->m_top1_prob, a->m_top1_bin};
   for (const void* p : ptrs) if (!p) return fail(-25, "command_motion_sample: null argument");
+  if ((a->time_left != nullptr) != (a->command_counter != nullptr)) return fail(-25, "command_motion_sample: time_left and command_counter come together");
   if (a->nworld < 1 || a->ldu < 3 || a->bin_count < 1 || a->bin_count > MJLAB_MOTION_SAMPLE_MAX_BINS || a->time_step_total < 1)
     return fail(-25, "command_motion_sample: bad sizes (bin_count <= MJLAB_MOTION_SAMPLE_MAX_BINS, U needs three columns)");
   hipLaunchKernelGGL(k_command_motion_sample, dim3(1), dim3(1024), 0, (hipStream_t)stream, *a);

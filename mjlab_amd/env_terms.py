@@ -218,17 +218,20 @@ class MotionFrame:
 class MotionSampleArgs(ctypes.Structure):  # mjlab_motion_sample_t
   _fields_ = [(k, _vp) for k in ("mask", "terminated", "time_steps", "U", "cdf", "entropy", "top1_prob", "top1_bin", "hist_out", "any_failed_out", "m_entropy",
                                  "m_top1_prob", "m_top1_bin")] + [("time_step_total", ctypes.c_longlong)] \
-    + [(k, ctypes.c_int) for k in ("nworld", "ldu", "bin_count", "hist_always")]
+    + [(k, ctypes.c_int) for k in ("nworld", "ldu", "bin_count", "hist_always")] + [("time_left", _vp), ("command_counter", _vp)] \
+    + [("resampling_width", ctypes.c_float), ("resampling_lo", ctypes.c_float)]
 
 
 MOTION_SAMPLE_MAX_BINS = 4096  # include/mjlab_amd.h MJLAB_MOTION_SAMPLE_MAX_BINS
 
 
 def command_motion_sample(term, mask: torch.Tensor, terminated: torch.Tensor, U: torch.Tensor, cdf: torch.Tensor, entropy: torch.Tensor, top1_prob: torch.Tensor,
-                          top1_bin: torch.Tensor, hist_out: torch.Tensor, any_failed_out: torch.Tensor | None) -> None:
+                          top1_bin: torch.Tensor, hist_out: torch.Tensor, any_failed_out: torch.Tensor | None, resampling_time_range: tuple | None = None) -> None:
   """MotionCommand._adaptive_sampling's per-world part for the worlds of `mask` (``mjlab_command_motion_sample``): the failed worlds' bins
   counted into `hist_out` (when some world failed; always, with the 0 / 1 flag in `any_failed_out`, for a sharded caller), new phases by
-  inverse CDF into ``term.time_steps``, the sampling metrics filled from the three device scalars when some world is masked."""
+  inverse CDF into ``term.time_steps``, the sampling metrics filled from the three device scalars when some world is masked.
+  ``resampling_time_range`` (lo, hi): also CommandTerm._resample's timer ``time_left = U[:, 0] * (hi - lo) + lo`` and ``command_counter += 1``
+  for the masked worlds (managers/command_manager.py:62-66)."""
   a = MotionSampleArgs()
   a.mask, a.terminated = _dense(mask, "mask", torch.bool).data_ptr(), _dense(terminated, "terminated", torch.bool).data_ptr()
   a.time_steps = _dense(term.time_steps, "time_steps", torch.long).data_ptr()
@@ -244,6 +247,10 @@ def command_motion_sample(term, mask: torch.Tensor, terminated: torch.Tensor, U:
   a.time_step_total, a.nworld, a.bin_count, a.hist_always = int(term.motion.time_step_total), mask.shape[0], int(term.bin_count), int(any_failed_out is not None)
   if cdf.numel() != a.bin_count or hist_out.numel() != a.bin_count:
     raise ValueError("cdf / hist_out: bin_count entries expected")
+  if resampling_time_range is not None:
+    lo, hi = resampling_time_range
+    a.time_left, a.command_counter = _dense(term.time_left, "time_left", torch.float32).data_ptr(), _dense(term.command_counter, "command_counter", torch.long).data_ptr()
+    a.resampling_width, a.resampling_lo = float(hi - lo), float(lo)
   native.check(native.lib().mjlab_command_motion_sample(ctypes.byref(a), _stream(mask)), "mjlab_command_motion_sample")
 
 

@@ -909,6 +909,26 @@ class GraphedRlEnv:
     are rebound at every update (the tracking task's MotionCommand, tasks/tracking/mdp/commands.py:216-253) keep the torch path for their metrics."""
     fills, vectors, rkeys, mkeys, tkeys, whole_clear = bookkeeping_plan(self.env, self._robot, self._index_slices(self._robot), len(self._reset_terms),
                                                                         self._ep_len if hasattr(self, "_ep_len") else self.env.episode_length_buf)
+    # MotionCommand with its metrics in persistent rows (env_terms.MotionMetrics; the sampling metrics are updated in place by the reference
+    # too): their masked sums and fills ride in the two launches like UniformVelocityCommand's (CommandTerm.reset, managers/command_manager.py:
+    # 40-53: the mean over the reset environments is logged, then the entries are zeroed) instead of a stack / mul / sum / foreach_mul chain
+    self._book_metric_terms = set()
+    if self._fused_metrics:
+      for name in self.env.command_manager.active_terms:
+        term = self.env.command_manager.get_term(name)
+        if type(term).__name__ != "MotionCommand":
+          continue
+        if id(term) not in self._motion_metrics:  # (entries _update_metrics would create at its first call exist from here on, as zeros)
+          self._motion_metrics[id(term)] = env_terms.MotionMetrics(term)
+        at = len(rkeys) + len(mkeys)
+        keys = [k for k, v in term.metrics.items() if v.dtype == torch.float32 and v.dim() == 1 and v.is_contiguous()]
+        if len(keys) != len(term.metrics):
+          continue
+        for k in keys:
+          fills.append((f"command.{name}.metrics.{k}", term.metrics[k], 0.0))
+        vectors[at:at] = [(f"command.{name}.metrics.{k}", term.metrics[k]) for k in keys]
+        mkeys += [(name, k) for k in keys]
+        self._book_metric_terms.add(id(term))
     return env_core.ResetBookkeeping([(t, v) for _, t, v in fills], [t for _, t in vectors], rkeys, mkeys, tkeys, fused=self._fused), whole_clear
 
   def _masked_reset(self, mask: torch.Tensor) -> None:
@@ -929,7 +949,7 @@ class GraphedRlEnv:
       self._masked_class_reset(cfg.func, mask)
     for name in env.command_manager.active_terms:
       term = env.command_manager.get_term(name)
-      if type(term).__name__ != "UniformVelocityCommand":
+      if type(term).__name__ != "UniformVelocityCommand" and id(term) not in self._book_metric_terms:
         mk, mvals = list(term.metrics), list(term.metrics.values())
         if mvals:
           vals = (torch.stack(mvals, dim=1) * mask[:, None]).sum(dim=0)
@@ -1084,9 +1104,16 @@ class GraphedRlEnv:
       env_terms.command_uniform_velocity(term, mask, U, self._command_ranges[id(term)]["table"], self.dt)
       return
     lo, hi = term.cfg.resampling_time_range
+    if self._fused_motion_sampler(term):  # MotionCommand on the GPU: the timer and the counter ride in the sampler's launch
+      self._resample_MotionCommand(term, mask, U, timer=(lo, hi))
+      return
     term.time_left.copy_(torch.where(mask, U[:, 0] * (hi - lo) + lo, term.time_left))
     getattr(self, "_resample_" + type(term).__name__)(term, mask, U)
     term.command_counter += mask.to(term.command_counter.dtype)
+
+  def _fused_motion_sampler(self, term: Any) -> bool:
+    return (self._fused and type(term).__name__ == "MotionCommand" and not term.cfg.disable_adaptive_sampling and term.bin_count <= env_terms.MOTION_SAMPLE_MAX_BINS
+            and term.command_counter.dtype == torch.long and term.time_left.dtype == torch.float32)
 
   def _command_compute(self) -> None:
     """CommandManager.compute -> CommandTerm.compute (managers/command_manager.py:55-60)."""
@@ -1143,7 +1170,7 @@ class GraphedRlEnv:
                                      self._command_ranges[id(term)]["ang_vel_z"], self._m.wrap_to_pi)
 
   # -- MotionCommand (tasks/tracking/mdp/commands.py:255-392)
-  def _resample_MotionCommand(self, term: Any, mask: torch.Tensor, U: torch.Tensor) -> None:
+  def _resample_MotionCommand(self, term: Any, mask: torch.Tensor, U: torch.Tensor, timer: tuple | None = None) -> None:
     """``_adaptive_sampling`` + ``_resample_command`` (:255-363).  The reference runs them only when the id list is non-empty; here
     the sampler's global state and metrics keep their values unless `mask` has an entry (``any`` on the device)."""
     rm, cfg, n, dev = self._m, term.cfg, self.n, self.device
@@ -1151,7 +1178,7 @@ class GraphedRlEnv:
     if cfg.disable_adaptive_sampling:
       term.time_steps.masked_fill_(mask, 0)
       self._terms_changed()
-    elif self._fused and term.bin_count <= env_terms.MOTION_SAMPLE_MAX_BINS:
+    elif self._fused_motion_sampler(term):
       # the per-world part of the sampler -- failure histogram, inverse-CDF draw, the three sampling metrics: ~25 launches per call, two
       # calls per step -- as one launch; the distribution (once per step, below) stays in torch: the launch reads the SAME cdf, so the
       # phases are the torch path's bit for bit
@@ -1160,7 +1187,7 @@ class GraphedRlEnv:
       if self._sharded:  # parked for _exchange(): the histogram is the global batch's (all-reduce) before the sampler's update reads it
         row = self._bin_row(term)
         hist, flag = row[: term.bin_count], row[term.bin_count:]
-      env_terms.command_motion_sample(term, mask, self.env.termination_manager.terminated, U, cdf, H, pmax, top, hist, flag)
+      env_terms.command_motion_sample(term, mask, self.env.termination_manager.terminated, U, cdf, H, pmax, top, hist, flag, timer)
       self._terms_changed()
     else:
       anyone = mask.any()

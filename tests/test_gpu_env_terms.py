@@ -505,11 +505,18 @@ def test_command_motion_sample_equals_the_torch_restatement_bit_for_bit(sharded,
   U[7, 1] = float(cdf[3])  # exactly on an edge: searchsorted's "first index with cdf >= u"
   metrics0 = {k: torch.rand(n, generator=g).to(dev) for k in ("sampling_entropy", "sampling_top1_prob", "sampling_top1_bin")}
   cur0 = torch.rand(nbin, generator=g).to(dev)
+  tl0, cc0 = (torch.rand(n, generator=g) * 3).to(dev), torch.randint(0, 9, (n,), generator=g).to(dev)
   term = types.SimpleNamespace(time_steps=ts0.clone(), metrics={k: v.clone() for k, v in metrics0.items()}, bin_count=nbin,
-                               motion=types.SimpleNamespace(time_step_total=total), _current_bin_failed=cur0.clone())
+                               motion=types.SimpleNamespace(time_step_total=total), _current_bin_failed=cur0.clone(), time_left=tl0.clone(), command_counter=cc0.clone())
   row = torch.full((nbin + 1,), -1.0, device=dev)
-  env_terms.command_motion_sample(term, mask, terminated, U, cdf, H, pmax, top, row[:nbin] if sharded else term._current_bin_failed, row[nbin:] if sharded else None)
+  timer = (0.37, 4.1) if sharded else None  # CommandTerm._resample's timer and counter ride along (the reset-phase call) or not (the update-phase call)
+  env_terms.command_motion_sample(term, mask, terminated, U, cdf, H, pmax, top, row[:nbin] if sharded else term._current_bin_failed, row[nbin:] if sharded else None, timer)
   torch.cuda.synchronize()
+  if timer is None:
+    assert torch.equal(term.time_left, tl0) and torch.equal(term.command_counter, cc0)
+  else:  # managers/command_manager.py:62-66 as GraphedRlEnv._command_resample writes it
+    assert torch.equal(term.time_left, torch.where(mask, U[:, 0] * (timer[1] - timer[0]) + timer[0], tl0))
+    assert torch.equal(term.command_counter, cc0 + mask.to(cc0.dtype))
   # the torch path (mjlab_amd/graphed_env.py, _resample_MotionCommand)
   failed = terminated & mask
   bins = torch.clamp((ts0 * nbin) // max(total, 1), 0, nbin - 1)
