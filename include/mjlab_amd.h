@@ -359,6 +359,22 @@ typedef struct mjlab_motion_sample {
   float resampling_width, resampling_lo;
 } mjlab_motion_sample_t;
 int mjlab_command_motion_sample(const mjlab_motion_sample_t* a, void* stream);
+/* The sampler's global part in one single-workgroup launch: do_update -- bin_failed_count <- alpha current_bin_failed + one_minus_alpha
+ * bin_failed_count, current_bin_failed <- 0 (commands.py:394-398; elementwise, the reference's bits); do_dist -- the sampling distribution
+ * from bin_failed_count (:267-281, :291-294: + uniform_term = adaptive_uniform_ratio / bin_count, smoothing kernel of kernel_size taps over
+ * the right-padded probabilities, normalisation) as its running sum `cdf` (bin_count floats) and the three logged scalars: normalised
+ * entropy, top-1 probability, top-1 bin / bin_count.  Float rounding from the reference's torch expressions (other summation order). */
+typedef struct mjlab_motion_sampler {
+  float* bin_failed_count;     /* (bin_count) */
+  float* current_bin_failed;   /* (bin_count) */
+  const float* kernel;         /* (kernel_size) device */
+  float* cdf;                  /* (bin_count) out */
+  float *entropy, *top1_prob, *top1_bin; /* device scalars, out */
+  float alpha, one_minus_alpha, uniform_term;
+  int bin_count, kernel_size, do_update, do_dist;
+} mjlab_motion_sampler_t;
+int mjlab_command_motion_sampler(const mjlab_motion_sampler_t* a, void* stream);
+int mjlab_sizeof_motion_sampler(void);
 int mjlab_sizeof_motion_sample(void);
 /* MotionCommand._update_metrics (:221-254): the ten tracking errors of every world in one launch, rows of `out` (10, nworld) in the
  * order error_anchor_pos, error_anchor_rot, error_anchor_lin_vel, error_anchor_ang_vel, error_body_pos, error_body_rot,

@@ -499,6 +499,70 @@ __global__ __launch_bounds__(1024) void k_command_motion_sample(const mjlab_moti
   }
 }
 
+// The adaptive sampler's GLOBAL part (tasks/tracking/mdp/commands.py): `update` = the end of _update_command (:394-398), bin_failed_count <-
+// alpha current + (1 - alpha) bin_failed_count and current <- 0 (elementwise float32 operations in the reference's order: the same bits);
+// `dist` = the sampling distribution of _adaptive_sampling (:267-281, :291-294) from bin_failed_count -- p = bfc + ratio / bins, the non-causal
+// smoothing kernel over p padded with its last value, normalisation, entropy, top bin, running sum -- into a cdf and three scalars that
+// k_command_motion_sample reads.  ONE workgroup (bins are tens to hundreds); sums are formed in a fixed order of this kernel's own, so the
+// distribution agrees with the torch expressions to float rounding, not bit for bit (it decides random draws and three logged numbers).
+__global__ __launch_bounds__(256) void k_command_motion_sampler(const mjlab_motion_sampler_t a) {
+#pragma clang fp contract(off)
+  __shared__ float q[MJLAB_MOTION_SAMPLE_MAX_BINS];
+  __shared__ float red[256];
+  __shared__ int redi[256];
+  const int tid = threadIdx.x, nbin = a.bin_count;
+  if (a.do_update) {
+    for (int b = tid; b < nbin; b += 256) {
+      a.bin_failed_count[b] = a.alpha * a.current_bin_failed[b] + a.one_minus_alpha * a.bin_failed_count[b];
+      a.current_bin_failed[b] = 0.f;
+    }
+    __syncthreads();
+  }
+  if (!a.do_dist) return;
+  for (int b = tid; b < nbin; b += 256) {
+    float acc = 0.f;
+    for (int k = 0; k < a.kernel_size; ++k) {
+      const int j = b + k < nbin ? b + k : nbin - 1;  // replicate padding on the right (a non-causal kernel)
+      acc += a.kernel[k] * (a.bin_failed_count[j] + a.uniform_term);
+    }
+    q[b] = acc;
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int b = tid; b < nbin; b += 256) part += q[b];
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  const float total = red[0];
+  __syncthreads();
+  float h = 0.f, pm = -1.f;
+  int im = 0;
+  for (int b = tid; b < nbin; b += 256) {
+    const float p = q[b] / total;
+    q[b] = p;
+    h += p * logf(p + 1e-12f);
+    if (p > pm) { pm = p; im = b; }
+  }
+  red[tid] = h;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  const float H = -red[0] / logf((float)nbin);
+  __syncthreads();
+  red[tid] = pm; redi[tid] = im;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {  // the largest probability, the FIRST bin that has it (torch.max(dim=0))
+    if (tid < s && (red[tid + s] > red[tid] || (red[tid + s] == red[tid] && redi[tid + s] < redi[tid]))) { red[tid] = red[tid + s]; redi[tid] = redi[tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *a.entropy = H;
+    *a.top1_prob = red[0];
+    *a.top1_bin = (float)redi[0] * __fdiv_rn(1.f, (float)nbin);
+    float run = 0.f;
+    for (int b = 0; b < nbin; ++b) { run += q[b]; a.cdf[b] = run; }
+  }
+}
+
 // RewardManager.compute's accumulation (managers/reward_manager.py:77-89) for the k active terms whose raw values are the rows of
 // `values` (k, n): value = raw * weight * dt; reward += value (in term order); episode_sum[term] += value; step_reward[:, column] =
 // value / dt (as torch computes it: value * (1 / dt)).  Elementwise IEEE operations in the reference's order: the same bits as its 6 launches per term.

@@ -297,6 +297,16 @@ int mjlab_command_motion_sample(const mjlab_motion_sample_t* a, void* stream) {
   return launched("k_command_motion_sample launch failed");
 }
 
+int mjlab_sizeof_motion_sampler(void) { return (int)sizeof(mjlab_motion_sampler_t); }
+int mjlab_command_motion_sampler(const mjlab_motion_sampler_t* a, void* stream) {
+  if (!a || !a->bin_failed_count) return fail(-26, "command_motion_sampler: null argument");
+  if (a->do_update && !a->current_bin_failed) return fail(-26, "command_motion_sampler: the update needs current_bin_failed");
+  if (a->do_dist && (!a->kernel || !a->cdf || !a->entropy || !a->top1_prob || !a->top1_bin || a->kernel_size < 1)) return fail(-26, "command_motion_sampler: the distribution needs kernel, cdf and the three scalars");
+  if (a->bin_count < 1 || a->bin_count > MJLAB_MOTION_SAMPLE_MAX_BINS) return fail(-26, "command_motion_sampler: bin_count must be in [1, MJLAB_MOTION_SAMPLE_MAX_BINS]");
+  hipLaunchKernelGGL(k_command_motion_sampler, dim3(1), dim3(256), 0, (hipStream_t)stream, *a);
+  return launched("k_command_motion_sampler launch failed");
+}
+
 int mjlab_sizeof_motion_metrics(void) { return (int)sizeof(mjlab_motion_metrics_t); }
 int mjlab_command_motion_metrics(const mjlab_motion_metrics_t* a, void* stream) {
   if (!a) return fail(-24, "command_motion_metrics: null argument");

@@ -254,6 +254,43 @@ def command_motion_sample(term, mask: torch.Tensor, terminated: torch.Tensor, U:
   native.check(native.lib().mjlab_command_motion_sample(ctypes.byref(a), _stream(mask)), "mjlab_command_motion_sample")
 
 
+class MotionSamplerArgs(ctypes.Structure):  # mjlab_motion_sampler_t
+  _fields_ = [(k, _vp) for k in ("bin_failed_count", "current_bin_failed", "kernel", "cdf", "entropy", "top1_prob", "top1_bin")] \
+    + [(k, ctypes.c_float) for k in ("alpha", "one_minus_alpha", "uniform_term")] + [(k, ctypes.c_int) for k in ("bin_count", "kernel_size", "do_update", "do_dist")]
+
+
+class MotionSampler:
+  """The adaptive sampler's global part for one MotionCommand (``mjlab_command_motion_sampler``): ``update()`` = the end of
+  ``_update_command`` (bin_failed_count takes the step's histogram in: the reference's bits), ``distribution()`` = the sampling distribution
+  of ``_adaptive_sampling`` into persistent buffers -- ``cdf`` and the three logged scalars that ``command_motion_sample`` reads."""
+
+  def __init__(self, term) -> None:
+    dev, nb = term.bin_failed_count.device, int(term.bin_count)
+    self.term = term
+    self.cdf = torch.zeros(nb, dtype=torch.float32, device=dev)
+    self.scalars = torch.zeros(3, dtype=torch.float32, device=dev)
+    self.entropy, self.top1_prob, self.top1_bin = self.scalars[0], self.scalars[1], self.scalars[2]
+    self.kernel = _dense(term.kernel.to(torch.float32).contiguous(), "kernel", torch.float32)
+
+  def _launch(self, update: bool, dist: bool) -> None:
+    t, a = self.term, MotionSamplerArgs()
+    a.bin_failed_count = _dense(t.bin_failed_count, "bin_failed_count", torch.float32).data_ptr()
+    a.current_bin_failed = _dense(t._current_bin_failed, "_current_bin_failed", torch.float32).data_ptr()
+    a.kernel, a.cdf = self.kernel.data_ptr(), self.cdf.data_ptr()
+    a.entropy, a.top1_prob, a.top1_bin = self.entropy.data_ptr(), self.top1_prob.data_ptr(), self.top1_bin.data_ptr()
+    alpha = float(t.cfg.adaptive_alpha)
+    a.alpha, a.one_minus_alpha, a.uniform_term = alpha, 1 - alpha, float(t.cfg.adaptive_uniform_ratio) / float(t.bin_count)
+    a.bin_count, a.kernel_size, a.do_update, a.do_dist = int(t.bin_count), int(self.kernel.numel()), int(update), int(dist)
+    native.check(native.lib().mjlab_command_motion_sampler(ctypes.byref(a), _stream(self.cdf)), "mjlab_command_motion_sampler")
+
+  def update(self) -> None:
+    self._launch(True, False)
+
+  def distribution(self) -> tuple:
+    self._launch(False, True)
+    return self.cdf, self.entropy, self.top1_prob, self.top1_bin
+
+
 class MotionMetricsArgs(ctypes.Structure):  # mjlab_motion_metrics_t
   _fields_ = [(k, _vp) for k in ("body_pos_w", "body_quat_w", "body_lin_vel_w", "body_ang_vel_w", "robot_body_pos_w", "robot_body_quat_w", "robot_body_lin_vel_w",
                                  "robot_body_ang_vel_w", "body_pos_relative_w", "body_quat_relative_w", "joint_pos", "joint_vel", "robot_joint_pos", "robot_joint_vel", "out")] \

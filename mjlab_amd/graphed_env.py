@@ -326,6 +326,7 @@ class GraphedRlEnv:
     # MotionCommand's gathered properties (joint_pos, body_*_w, anchor_*_w, robot_body_*_w) from one launch per phase instead of an index
     # launch (+ an add) each: copies, bit for bit (round 6; tools/graphed_env_census.py: ~44 index launches per tracking step)
     self._fused_frame = bool(fused_motion_frame)
+    self._motion_sampler: dict = {}  # MotionCommand: env_terms.MotionSampler (the sampler's global part as one launch each)
     self._rel_mask: dict = {}  # MotionCommand: the calibrated rounding of the relative-poses launch (_calibrate_relative), -1 = torch chain
     self._fused_metrics = bool(fused_motion_metrics) and self._fused
     self._motion_metrics: dict = {}  # MotionCommand: env_terms.MotionMetrics (built at the first update: _update_metrics creates entries on its first call)
@@ -1311,6 +1312,10 @@ class GraphedRlEnv:
     """The adaptive sampler's distribution (tasks/tracking/mdp/commands.py:267-281, :291-294), once per control step -- ``bin_failed_count``
     changes after the last resample of a step (``_update_command``'s end): (cdf, H, pmax, top) expanded to the environments for the torch
     path, then the same four with the last three as device scalars for the one-launch sampler."""
+    if id(term) not in self._sampler_cache and self._fused_motion_sampler(term):  # one launch into persistent buffers (float rounding from the torch lines below)
+      if id(term) not in self._motion_sampler:
+        self._motion_sampler[id(term)] = env_terms.MotionSampler(term)
+      self._sampler_cache[id(term)] = (None, None, None, None, *self._motion_sampler[id(term)].distribution())
     if id(term) not in self._sampler_cache:
       cfg, n = term.cfg, self.n
       p = term.bin_failed_count + cfg.adaptive_uniform_ratio / float(term.bin_count)
@@ -1328,6 +1333,9 @@ class GraphedRlEnv:
     Sharded: deferred to ``_exchange()`` -- nothing between here and the end of the step reads ``bin_failed_count``, and the
     histogram has to be the global batch's first."""
     if self._sharded and not term.cfg.disable_adaptive_sampling:
+      return
+    if id(term) in self._motion_sampler:  # the same two lines in one launch, in place (elementwise float32: the reference's bits)
+      self._motion_sampler[id(term)].update()
       return
     term.bin_failed_count = term.cfg.adaptive_alpha * term._current_bin_failed + (1 - term.cfg.adaptive_alpha) * term.bin_failed_count
     term._current_bin_failed.zero_()

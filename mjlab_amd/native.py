@@ -163,6 +163,7 @@ def lib() -> ctypes.CDLL:
   L.mjlab_copy_batch.argtypes = [vp, ci, vp]
   L.mjlab_command_motion_metrics.argtypes = [vp, vp]
   L.mjlab_command_motion_sample.argtypes = [vp, vp]
+  L.mjlab_command_motion_sampler.argtypes = [vp, vp]
   L.mjlab_command_motion_relative.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, ci, vp]
   L.mjlab_control_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
   L.mjlab_forward_stages.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -174,7 +175,7 @@ def lib() -> ctypes.CDLL:
     raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.mjlab_abi_version()}, this package speaks {ABI_VERSION}; rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
   # the two host structs and the control-step structs are mirrored by hand in ctypes (_abi.Option / _abi.Sizes, rollout._Control /
   # _MotionReset): a library built from other headers would be driven with shifted fields -- refuse it here instead
-  from .env_terms import MotionMetricsArgs, MotionSampleArgs, MotionTables, VelocityCommand
+  from .env_terms import MotionMetricsArgs, MotionSampleArgs, MotionSamplerArgs, MotionTables, VelocityCommand
   from .rollout import _Control as Control, _MotionReset as MotionReset  # (imported here: rollout imports this module)
 
   for what, mine, theirs in (("mjlab_option_t", ctypes.sizeof(_abi.Option), L.mjlab_sizeof_option()), ("mjlab_sizes_t", ctypes.sizeof(_abi.Sizes), L.mjlab_sizeof_sizes()),
@@ -182,7 +183,8 @@ def lib() -> ctypes.CDLL:
                              ("mjlab_velocity_command_t", ctypes.sizeof(VelocityCommand), L.mjlab_sizeof_velocity_command()),
                              ("mjlab_motion_tables_t", ctypes.sizeof(MotionTables), L.mjlab_sizeof_motion_tables()),
                              ("mjlab_motion_metrics_t", ctypes.sizeof(MotionMetricsArgs), L.mjlab_sizeof_motion_metrics()),
-                             ("mjlab_motion_sample_t", ctypes.sizeof(MotionSampleArgs), L.mjlab_sizeof_motion_sample())):
+                             ("mjlab_motion_sample_t", ctypes.sizeof(MotionSampleArgs), L.mjlab_sizeof_motion_sample()),
+                             ("mjlab_motion_sampler_t", ctypes.sizeof(MotionSamplerArgs), L.mjlab_sizeof_motion_sampler())):
     if mine != theirs:
       raise NativeLibraryError(f"{LIB_PATH}: sizeof({what}) is {theirs} in the library, {mine} in the Python mirror; rebuild the library")
   _LIB = L
@@ -191,7 +193,7 @@ def lib() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = (
   "mjlab_abi_version", "mjlab_last_error", "mjlab_model_layout", "mjlab_data_layout", "mjlab_sizeof_model",
-  "mjlab_sizeof_data", "mjlab_sizeof_option", "mjlab_sizeof_sizes", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_sizeof_motion_reset", "mjlab_event_reset_root_state_uniform", "mjlab_event_reset_joints_by_scale", "mjlab_event_push_by_setting_velocity", "mjlab_command_uniform_velocity", "mjlab_sizeof_velocity_command", "mjlab_command_motion_write", "mjlab_command_motion_relative", "mjlab_command_motion_frame", "mjlab_copy_batch", "mjlab_command_motion_metrics", "mjlab_sizeof_motion_metrics", "mjlab_command_motion_sample", "mjlab_sizeof_motion_sample", "mjlab_sizeof_motion_tables", "mjlab_reward_accumulate", "mjlab_masked_fill_rows", "mjlab_masked_sums", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest", "mjlab_poison_scratch",
+  "mjlab_sizeof_data", "mjlab_sizeof_option", "mjlab_sizeof_sizes", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_sizeof_motion_reset", "mjlab_event_reset_root_state_uniform", "mjlab_event_reset_joints_by_scale", "mjlab_event_push_by_setting_velocity", "mjlab_command_uniform_velocity", "mjlab_sizeof_velocity_command", "mjlab_command_motion_write", "mjlab_command_motion_relative", "mjlab_command_motion_frame", "mjlab_copy_batch", "mjlab_command_motion_metrics", "mjlab_sizeof_motion_metrics", "mjlab_command_motion_sample", "mjlab_sizeof_motion_sample", "mjlab_command_motion_sampler", "mjlab_sizeof_motion_sampler", "mjlab_sizeof_motion_tables", "mjlab_reward_accumulate", "mjlab_masked_fill_rows", "mjlab_masked_sums", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest", "mjlab_poison_scratch",
 )  # fmt: skip
 
 

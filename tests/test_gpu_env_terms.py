@@ -534,6 +534,37 @@ def test_command_motion_sample_equals_the_torch_restatement_bit_for_bit(sharded,
     assert int(failed.sum()) > 100 and int(counts.sum()) == int(failed.sum()) and int(sampled[6]) == nbin - 1 and int(sampled[7]) == 3
 
 
+@pytest.mark.parametrize("ksize", [1, 3])
+def test_command_motion_sampler_update_and_distribution(ksize):
+  """mjlab_command_motion_sampler (env_terms.MotionSampler) against the reference's lines (tasks/tracking/mdp/commands.py:267-281, 291-294,
+  394-398) in torch on the same device: the statistics' update bit for bit (elementwise), the distribution -- cdf, entropy, top bin -- to
+  float rounding (another summation order)."""
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(31)
+  nbin, alpha, ratio, lam = 37, 0.001, 0.1, 0.8
+  kernel = torch.tensor([lam**i for i in range(ksize)])
+  kernel = (kernel / kernel.sum()).to(dev)
+  bfc0, cur0 = (torch.rand(nbin, generator=g) * 0.05).to(dev), torch.randint(0, 5, (nbin,), generator=g).float().to(dev)
+  term = types.SimpleNamespace(bin_failed_count=bfc0.clone(), _current_bin_failed=cur0.clone(), bin_count=nbin, kernel=kernel,
+                               cfg=types.SimpleNamespace(adaptive_alpha=alpha, adaptive_uniform_ratio=ratio, adaptive_kernel_size=ksize))
+  ms = env_terms.MotionSampler(term)
+  ms.update()
+  torch.cuda.synchronize()
+  assert torch.equal(term.bin_failed_count, alpha * cur0 + (1 - alpha) * bfc0) and not bool(term._current_bin_failed.any())
+  cdf, H, pmax, top = ms.distribution()
+  torch.cuda.synchronize()
+  p = term.bin_failed_count + ratio / float(nbin)
+  p = torch.nn.functional.pad(p.unsqueeze(0).unsqueeze(0), (0, ksize - 1), mode="replicate")
+  p = torch.nn.functional.conv1d(p, kernel.view(1, 1, -1)).view(-1)
+  p = p / p.sum()
+  Hw = -(p * (p + 1e-12).log()).sum() / math.log(nbin)
+  pm, im = p.max(dim=0)
+  assert float((cdf - torch.cumsum(p, 0)).abs().max()) <= 5e-7 and abs(float(cdf[-1]) - 1.0) <= 1e-6
+  assert abs(float(H) - float(Hw)) <= 2e-6 and abs(float(pmax) - float(pm)) <= 1e-7 * float(pm) + 1e-9 and float(top) == float(im.float() / nbin)
+
+
 def test_copy_batch_copies_every_pair():
   """mjlab_copy_batch: 40 pairs (two launches) of float, int64 and bool tensors, odd byte counts included; strided / mixed-dtype pairs
   keep copy_."""
