@@ -429,6 +429,10 @@ int mjlab_tile_field(void* dst, const void* src, long long nelem, int nworld, in
 
 /* Device self-test of the wave-level primitives (DPP reductions); synchronises `stream`. */
 int mjlab_selftest(void* stream);
+/* Diagnostic: x[i] = A[i]^-1 b[i] for `nbatch` symmetric positive definite n x n matrices (dense row-major, lower triangle read) through the
+ * solve stage's own factor + substitution code of the padded size n maps to (the MFMA-tile LDL^T for 32 / 36 / 48 / 64, the LDS-broadcast
+ * column sweep otherwise): one wave per matrix.  What tests/test_gpu_chol.py holds against an fp64 factorization. */
+int mjlab_chol_selftest(int n, int nbatch, const float* A, const float* b, float* x, void* stream);
 
 /* Diagnostics: fills the private segment (scratch) of `nblocks` waves on `stream`'s queue with poison words (NaN as a float, a
  * non-canonical address as the high half of a pointer), 1280 B per lane -- more than any kernel's frame here.  Scratch is not

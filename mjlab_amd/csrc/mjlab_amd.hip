@@ -393,6 +393,15 @@ int mjlab_control_step(const mjlab_model_t* m, const mjlab_data_t* d, const mjla
   return 0;
 }
 
+int mjlab_chol_selftest(int n, int nbatch, const float* A, const float* b, float* x, void* stream) {
+  if (!A || !b || !x || nbatch < 1) return fail(-27, "chol_selftest: null argument or empty batch");
+  const NvpLaunch* L = nvp_launch(solve_nvp(n));
+  if (n < 1 || !L) return fail(-3, "nv must be in [1, 64]");
+  hipError_t e = L->chol_test(A, b, x, n, nbatch, (hipStream_t)stream);
+  if (e != hipSuccess) return fail((int)e, "k_chol_selftest launch failed");
+  return 0;
+}
+
 int mjlab_selftest(void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int nblk = 16, n = nblk * 64;

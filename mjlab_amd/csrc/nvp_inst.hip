@@ -46,6 +46,39 @@ hipError_t NVP_CAT_(mjlab_nvp_step_cone_, MJLAB_NVP)(const mjlab_model_t* m, con
   hipLaunchKernelGGL((k_substep_cone<MJLAB_NVP, true>), dim3(m->size.nworld), dim3(64), (size_t)lds_bytes, st, *m, *d, flags, nsub);
   return hipGetLastError();
 }
+// Diagnostic (mjlab_chol_selftest): the solve stage's factor + substitution pair of THIS padded size on caller-supplied symmetric
+// positive definite matrices, one wave per matrix -- chol_factor_tiles + chol_solve_tiles where the solve stage uses the MFMA tiles, the
+// LDS-broadcast column sweep elsewhere (chol_use_tiles).  In the cone unit so that the measured path's translation units stay as they are.
+template <int NVP>
+__global__ __launch_bounds__(64) void k_chol_selftest(const float* A, const float* b, float* x, const int n) {
+  constexpr int LD = CholCfg<NVP>::LD, NB = CholCfg<NVP>::NB;
+  __shared__ __attribute__((aligned(16))) float s_H[NVP * LD + NVP];
+  float* s_invd = s_H + NVP * LD;
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const float* Aw = A + (size_t)w * n * n;
+  const float rhs = lane < n ? b[(size_t)w * n + lane] : 0.f;
+  float sol;
+  if constexpr (chol_use_tiles(NVP)) {
+    f32x4 t[NB * (NB + 1) / 2];
+    tiles_add_M<NVP, true, false>(t, nullptr, Aw, n, lane);
+    chol_factor_tiles<NVP>(t, s_H, s_invd, lane);
+    __syncthreads();
+    sol = chol_solve_tiles<NVP>(s_H, s_invd, lane, rhs);
+  } else {
+    dense_global_to_lds(s_H, Aw, n, LD, lane, true);
+    chol_pad_rows<NVP>(s_H, n, lane);
+    chol_pad_diag<NVP>(s_H, n, lane);
+    __syncthreads();
+    chol_factor<NVP>(s_H, s_invd, n, lane);
+    __syncthreads();
+    sol = chol_solve<NVP>(s_H, s_invd, lane, rhs);
+  }
+  if (lane < n) x[(size_t)w * n + lane] = sol;
+}
+hipError_t NVP_CAT_(mjlab_nvp_chol_test_, MJLAB_NVP)(const float* A, const float* b, float* x, int n, int nbatch, hipStream_t st) {
+  hipLaunchKernelGGL(k_chol_selftest<MJLAB_NVP>, dim3(nbatch), dim3(64), 0, st, A, b, x, n);
+  return hipGetLastError();
+}
 hipError_t NVP_CAT_(mjlab_nvp_control_cone_, MJLAB_NVP)(const mjlab_model_t* m, const mjlab_data_t* d, const mjlab_control_t* c, int fold, int lds_bytes,
                                                         hipStream_t st) {
   hipLaunchKernelGGL(k_control_step_cone<MJLAB_NVP>, dim3(m->size.nworld), dim3(64), (size_t)lds_bytes, st, *m, *d, *c, fold);
