@@ -287,6 +287,16 @@ typedef struct mjlab_velocity_command {
   unsigned char* is_standing_env; /* (nworld) torch.bool */
   long long* command_counter;     /* (nworld) torch.long */
   float dt, resampling_lo, resampling_hi, rel_heading_envs, rel_standing_envs, heading_control_stiffness;
+  /* compute() only, optional (round 6; all NULL = skipped): _update_metrics (:50-62), which CommandTerm.compute runs FIRST, on the command as
+   * it stands -- error_vel_xy[w] += |vel_command_b[w][:2] - root_link_lin_vel_b[w][:2]| * inv_max_command_step, error_vel_yaw[w] +=
+   * |vel_command_b[w][2] - root_link_ang_vel_b[w][2]| * inv_max_command_step (the reference divides by the host scalar max_command_step =
+   * resampling_hi / step_dt: torch multiplies by its float32 reciprocal).  Logging quantities; the norm may round 1 ulp from torch's reduction. */
+  float* error_vel_xy;               /* (nworld) */
+  float* error_vel_yaw;              /* (nworld) */
+  const float* root_link_lin_vel_b;  /* (nworld, >= 2), ld_lin_vel floats between rows */
+  const float* root_link_ang_vel_b;  /* (nworld, 3), ld_ang_vel floats between rows */
+  int ld_lin_vel, ld_ang_vel;
+  float inv_max_command_step;
 } mjlab_velocity_command_t;
 int mjlab_command_uniform_velocity(const mjlab_velocity_command_t* c, void* stream);
 int mjlab_sizeof_velocity_command(void);

@@ -162,6 +162,12 @@ __global__ __launch_bounds__(256) void k_command_uniform_velocity(const mjlab_ve
     m = t <= 0.f;
   }
   float* v = c.vel_command_b + 3 * (size_t)w;
+  if (!c.mask && c.error_vel_xy) {  // _update_metrics (:50-62) comes first in CommandTerm.compute: on the command as it stands
+    const float* lv = c.root_link_lin_vel_b + (size_t)w * c.ld_lin_vel;
+    const float dx = v[0] - lv[0], dy = v[1] - lv[1];
+    c.error_vel_xy[w] = c.error_vel_xy[w] + sqrtf(dx * dx + dy * dy) * c.inv_max_command_step;
+    c.error_vel_yaw[w] = c.error_vel_yaw[w] + fabsf(v[2] - c.root_link_ang_vel_b[(size_t)w * c.ld_ang_vel + 2]) * c.inv_max_command_step;
+  }
   if (m) {
     const float* u = c.U + (size_t)w * c.ldu;
     const float* rg = c.ranges;  // rows lin_vel_x, lin_vel_y, ang_vel_z, heading: [lo, hi]

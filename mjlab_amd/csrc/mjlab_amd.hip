@@ -242,6 +242,8 @@ int mjlab_command_uniform_velocity(const mjlab_velocity_command_t* c, void* stre
   if (!c || !c->U || !c->ranges || !c->time_left || !c->vel_command_b || !c->is_standing_env || !c->command_counter) return fail(-22, "command_uniform_velocity: null argument");
   if (c->heading_command && (!c->heading_target || !c->is_heading_env || (!c->mask && !c->heading_w))) return fail(-22, "command_uniform_velocity: heading arguments missing");
   if (c->nworld < 1 || c->ldu < 7) return fail(-22, "command_uniform_velocity: bad sizes");
+  if (c->error_vel_xy && (c->mask || !c->error_vel_yaw || !c->root_link_lin_vel_b || !c->root_link_ang_vel_b))
+    return fail(-22, "command_uniform_velocity: the metrics belong to compute() and need both error arrays and both velocities");
   hipLaunchKernelGGL(k_command_uniform_velocity, dim3((c->nworld + 255) / 256), dim3(256), 0, (hipStream_t)stream, *c);
   return launched("k_command_uniform_velocity launch failed");
 }

@@ -21,7 +21,9 @@ class VelocityCommand(ctypes.Structure):  # mjlab_velocity_command_t
               ("mask", _vp), ("U", _vp), ("ranges", _vp), ("heading_w", _vp), ("time_left", _vp), ("vel_command_b", _vp),
               ("heading_target", _vp), ("is_heading_env", _vp), ("is_standing_env", _vp), ("command_counter", _vp),
               ("dt", ctypes.c_float), ("resampling_lo", ctypes.c_float), ("resampling_hi", ctypes.c_float),
-              ("rel_heading_envs", ctypes.c_float), ("rel_standing_envs", ctypes.c_float), ("heading_control_stiffness", ctypes.c_float)]  # fmt: skip
+              ("rel_heading_envs", ctypes.c_float), ("rel_standing_envs", ctypes.c_float), ("heading_control_stiffness", ctypes.c_float),
+              ("error_vel_xy", _vp), ("error_vel_yaw", _vp), ("root_link_lin_vel_b", _vp), ("root_link_ang_vel_b", _vp),
+              ("ld_lin_vel", ctypes.c_int), ("ld_ang_vel", ctypes.c_int), ("inv_max_command_step", ctypes.c_float)]  # fmt: skip
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -89,9 +91,10 @@ def push_by_setting_velocity(qvel: torch.Tensor, v_adr: int, time_left: torch.Te
     "mjlab_event_push_by_setting_velocity")  # fmt: skip
 
 
-def command_uniform_velocity(term, mask: torch.Tensor | None, U: torch.Tensor, ranges: torch.Tensor, dt: float) -> None:
+def command_uniform_velocity(term, mask: torch.Tensor | None, U: torch.Tensor, ranges: torch.Tensor, dt: float, metrics: bool = False) -> None:
   """`term`: the reference's UniformVelocityCommand (its buffers are updated in place); mask None = compute(dt), else reset()
-  for the worlds of the mask; ranges: device (4, 2) rows lin_vel_x, lin_vel_y, ang_vel_z, heading."""
+  for the worlds of the mask; ranges: device (4, 2) rows lin_vel_x, lin_vel_y, ang_vel_z, heading.  ``metrics`` (compute() only): the launch
+  also runs ``_update_metrics`` (tasks/velocity/mdp/velocity_command.py:50-62) first, in place on ``term.metrics`` -- the caller then skips it."""
   cfg = term.cfg
   if cfg.init_velocity_prob > 0.0:
     raise NotImplementedError("command_uniform_velocity: the init-velocity branch is not covered by the fused term")
@@ -112,6 +115,17 @@ def command_uniform_velocity(term, mask: torch.Tensor | None, U: torch.Tensor, r
   c.resampling_lo, c.resampling_hi = cfg.resampling_time_range
   c.rel_heading_envs, c.rel_standing_envs = cfg.rel_heading_envs, cfg.rel_standing_envs
   c.heading_control_stiffness = cfg.heading_control_stiffness
+  if metrics:
+    if mask is not None:
+      raise ValueError("command_uniform_velocity: the metrics belong to compute()")
+    lv, av = _f32(term.robot.data.root_link_lin_vel_b, "root_link_lin_vel_b"), _f32(term.robot.data.root_link_ang_vel_b, "root_link_ang_vel_b")
+    c.error_vel_xy = _dense(term.metrics["error_vel_xy"], "error_vel_xy", torch.float32).data_ptr()
+    c.error_vel_yaw = _dense(term.metrics["error_vel_yaw"], "error_vel_yaw", torch.float32).data_ptr()
+    c.root_link_lin_vel_b, c.root_link_ang_vel_b, c.ld_lin_vel, c.ld_ang_vel = lv.data_ptr(), av.data_ptr(), _ld(lv), _ld(av)
+    # the reference divides by the Python float max_command_step; torch turns a division by a host scalar into a multiplication by 1 / scalar in float32
+    import numpy as np
+
+    c.inv_max_command_step = float(np.float32(1.0) / np.float32(cfg.resampling_time_range[1] / term._env.step_dt))
   native.check(native.lib().mjlab_command_uniform_velocity(ctypes.byref(c), _stream(U)), "mjlab_command_uniform_velocity")
 
 

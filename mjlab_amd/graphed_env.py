@@ -286,7 +286,8 @@ class GraphedRlEnv:
     fused_relative_poses  (tracking, GPU; None = on) ``MotionCommand``'s relative body poses from one launch with the fma sites of the reference's
                           jit-fused helpers: its steady-state values bit for bit (csrc/env_terms.h; tools/experiments/rel_probe2.py)
     fused_motion_frame    (tracking, GPU) ``MotionCommand``'s gathered properties from one ``mjlab_command_motion_frame`` launch per phase (bit for bit)
-    fused_motion_metrics  (tracking, GPU) ``MotionCommand._update_metrics`` -- ten logging quantities, ~130 launches per step -- as one
+    fused_motion_metrics  (GPU) the command terms' ``_update_metrics``: ``UniformVelocityCommand``'s two accumulated errors at the head of its
+                          compute launch; ``MotionCommand._update_metrics`` -- ten logging quantities, ~130 launches per step -- as one
                           ``mjlab_command_motion_metrics`` launch into persistent rows of ``term.metrics`` (a few ulp from the reference's reductions;
                           only ``extras["log"]`` reads them)
     forward               "reference": ``sim.forward()`` on all worlds whenever some environment reset; "reset_worlds" (opt-in): only those
@@ -1120,6 +1121,9 @@ class GraphedRlEnv:
     """CommandManager.compute -> CommandTerm.compute (managers/command_manager.py:55-60)."""
     for name in self.env.command_manager.active_terms:
       term = self.env.command_manager.get_term(name)
+      if self._fused_command(term) and self._fused_metrics:  # UniformVelocityCommand: _update_metrics rides at the head of the compute launch
+        env_terms.command_uniform_velocity(term, None, self._Uof(("command", name, "compute")), self._command_ranges[id(term)]["table"], self.dt, metrics=True)
+        continue
       if self._fused_metrics and type(term).__name__ == "MotionCommand":  # the ten tracking errors in one launch (logging quantities)
         if id(term) not in self._motion_metrics:
           self._motion_metrics[id(term)] = env_terms.MotionMetrics(term)

@@ -248,6 +248,39 @@ def test_command_uniform_velocity_compute(heading_command):
   assert torch.equal(got["time_left"][~m], t32[~m])
 
 
+def test_command_uniform_velocity_compute_with_its_metrics():
+  """``metrics=True``: ``_update_metrics`` (reference tasks/velocity/mdp/velocity_command.py:50-62) at the head of the compute launch, on the
+  command as it stood BEFORE the resample / update -- against the reference's lines in torch on the same device (1 ulp: the norm's reduction),
+  the velocities given as row views of a wider buffer; everything else as without the metrics."""
+  from mjlab_amd import env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(6)
+  ta, tb = _command_term(g, dev), None
+  g = torch.Generator().manual_seed(6)
+  tb = _command_term(g, dev)
+  vel = torch.randn((N, 9), generator=g).to(dev)
+  m0 = {"error_vel_xy": torch.rand(N, generator=g).to(dev), "error_vel_yaw": torch.rand(N, generator=g).to(dev)}
+  for t in (ta, tb):
+    t.metrics = {k: v.clone() for k, v in m0.items()}
+    t.robot.data.root_link_lin_vel_b, t.robot.data.root_link_ang_vel_b = vel[:, 1:4], vel[:, 5:8]
+    t._env = types.SimpleNamespace(step_dt=0.02)
+  U = torch.rand((N, 8), generator=g).to(dev)
+  ranges = torch.tensor([[-1.0, 1.0], [-0.5, 0.5], [-0.7, 0.7], [-3.14, 3.14]]).to(dev)
+  cmd0 = ta.vel_command_b.clone()
+  env_terms.command_uniform_velocity(ta, None, U, ranges, 0.02, metrics=True)
+  env_terms.command_uniform_velocity(tb, None, U, ranges, 0.02)
+  torch.cuda.synchronize()
+  for k, v in _snapshot(ta).items():
+    assert torch.equal(v, _snapshot(tb)[k]), k
+  assert torch.equal(tb.metrics["error_vel_xy"], m0["error_vel_xy"])  # (without the switch the launch leaves them alone)
+  max_command_step = ta.cfg.resampling_time_range[1] / 0.02
+  want_xy = m0["error_vel_xy"] + torch.norm(cmd0[:, :2] - vel[:, 1:3], dim=-1) / max_command_step
+  want_yaw = m0["error_vel_yaw"] + torch.abs(cmd0[:, 2] - vel[:, 7]) / max_command_step
+  assert float((ta.metrics["error_vel_xy"] - want_xy).abs().max()) <= 1.2e-7 * float(want_xy.abs().max())
+  assert torch.equal(ta.metrics["error_vel_yaw"], want_yaw)
+
+
 def test_terms_refuse_what_they_cannot_address():
   from mjlab_amd import env_terms
 
