@@ -328,6 +328,17 @@ class MotionMetrics:
         row.copy_(term.metrics[key])
       term.metrics[key] = row
 
+  def adopt(self) -> None:
+    """Host side, before a replay: an entry somebody rebound since the last update (the reference's own ``_update_metrics`` in an eager
+    step) hands its values to the row and is bound back -- the captured launches and the reset bookkeeping address the rows."""
+    m = self.term.metrics
+    for row, key in zip(self.rows, self.KEYS, strict=True):
+      cur = m.get(key)
+      if cur is not row:
+        if cur is not None and cur.shape == row.shape:
+          row.copy_(cur)
+        m[key] = row
+
   def update(self) -> None:
     t = self.term
     a = MotionMetricsArgs()

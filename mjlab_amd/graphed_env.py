@@ -688,6 +688,8 @@ class GraphedRlEnv:
       self._ep_len.copy_(env.episode_length_buf)
       env.episode_length_buf = self._ep_len
     self._action_in.copy_(action)
+    for mm in self._motion_metrics.values():
+      mm.adopt()  # (an eager reference step / reset in between REBINDS term.metrics entries: their values move into the rows the graph addresses)
     if self._reward is not None:
       self._reward.refresh_weights()  # (host side: the reference reads cfg.weight at every compute())
     if self.graph is not None:
