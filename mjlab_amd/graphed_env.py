@@ -531,7 +531,10 @@ class GraphedRlEnv:
     def cached(command, body_names):
       key = (id(command), None if body_names is None else tuple(body_names))
       if key not in cache:
-        cache[key] = torch.tensor(orig(command, body_names), dtype=torch.long, device=command.device)
+        ids = orig(command, body_names)
+        # every tracked body, in order (body_names=None: the four body-error rewards): `x[:, ids]` would copy the whole tensor -- the
+        # full slice is the same values as a view of the same shape and layout (so the jit helpers see the operand types they saw)
+        cache[key] = slice(None) if ids == list(range(len(command.cfg.body_names))) else torch.tensor(ids, dtype=torch.long, device=command.device)
       return cache[key]
 
     cached._mjlab_amd_orig = orig
