@@ -371,6 +371,8 @@ class GraphedRlEnv:
     self._book = self._prepare_bookkeeping()
     self._obs_memo: dict = {}
     self._obs_memo_on = False
+    self._pure_calls: dict = {}  # helper name -> [(args, result)] of the current observation window (_memoize_helper)
+    self._pure_alias: dict = {}  # (helper name, call index in the window) -> index of an earlier call with equal arguments, learnt in eager passes
     self._share_observation_terms()
     self.graph: torch.cuda.CUDAGraph | None = None
     self.graph_b: torch.cuda.CUDAGraph | None = None  # sharded: the second half of the step (after the mid-step exchange)
@@ -477,6 +479,9 @@ class GraphedRlEnv:
       if type(term).__name__ == "MotionCommand":
         self._command_ranges[id(term)] = (torch.stack(_range_tensors(term.cfg.pose_range, dev)), torch.stack(_range_tensors(term.cfg.velocity_range, dev)))
         self._patch_body_index_lists(term)
+        import mjlab.tasks.tracking.mdp.observations as tracking_obs
+
+        self._memoize_helper(tracking_obs, "subtract_frame_transforms")
         if self._fused:
           rix = term.robot.indexing
           self._motion_dev[id(term)] = (*env_terms.motion_tables(term), rix.joint_q_adr.to(torch.int32).contiguous(), rix.joint_v_adr.to(torch.int32).contiguous(),
@@ -539,6 +544,42 @@ class GraphedRlEnv:
 
     cached._mjlab_amd_orig = orig
     rw._get_body_indexes = tm._get_body_indexes = cached
+
+  def _memoize_helper(self, module: Any, name: str) -> None:
+    """A PURE helper a task module calls with the same arguments from several term functions -- the tracking task's observation terms call
+    ``subtract_frame_transforms`` four times per computation, pairwise with identical arguments, and each caller keeps one half of the
+    result (tasks/tracking/mdp/observations.py:18-72) -- returns, inside one observation computation, the result of its earlier call.
+    "The same arguments" = the same tensor objects, or (the callers build ``x[:, None, :].repeat(...)`` afresh) tensors of equal shape
+    whose VALUES are equal: that comparison runs in every eager pass (a synchronising ``torch.equal``), and a captured pass -- which cannot
+    synchronise -- repeats the aliases of the last eager pass by call index (the structure of a captured step is the warm-up's by
+    construction).  The function, its inputs and therefore its outputs are the reference's: the same bits, half the launches."""
+    orig = getattr(module, name)
+    orig = getattr(orig, "_mjlab_amd_orig", orig)
+
+    def memoized(*args: Any) -> Any:
+      if not self._obs_memo_on or not all(isinstance(a, torch.Tensor) for a in args):
+        return orig(*args)
+      calls = self._pure_calls.setdefault(name, [])
+      k, hit = len(calls), None
+      for i, (prev, _) in enumerate(calls):
+        if len(prev) == len(args) and all(x is y for x, y in zip(args, prev, strict=True)):
+          hit = i
+          break
+      if hit is None:
+        if args[0].is_cuda and torch.cuda.is_current_stream_capturing():
+          hit = self._pure_alias.get((name, k))
+        else:
+          for i, (prev, _) in enumerate(calls):
+            if len(prev) == len(args) and all(x is y or (x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y)) for x, y in zip(args, prev, strict=True)):
+              hit = i
+              break
+          self._pure_alias[(name, k)] = hit
+      out = calls[hit][1] if hit is not None else orig(*args)
+      calls.append((args, out))
+      return out
+
+    memoized._mjlab_amd_orig = orig
+    setattr(module, name, memoized)
 
   def _upload_index_lists(self) -> None:
     """Index lists in the terms' ``SceneEntityCfg`` parameters (``joint_ids = [0, 1, ...]``, resolved by the managers at
@@ -875,12 +916,14 @@ class GraphedRlEnv:
     self._invalidate(_LATE_WRITES)  # (no forward() follows: xpos / xquat / cvel and what the terms derived from them still stand)
     self._sampler_cache.clear()
     self._obs_memo.clear()
+    self._pure_calls.clear()
     self._obs_memo_on = True
     try:
       env.obs_buf = self._observation_compute()
     finally:
       self._obs_memo_on = False
       self._obs_memo.clear()  # (nothing outlives the step)
+      self._pure_calls.clear()
     self._restore_bindings(self._before)
 
   # State the reference carries by REBINDING an attribute to a new tensor (``self.x = torch.where(...)``) would be lost between
