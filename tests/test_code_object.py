@@ -38,8 +38,11 @@ def test_every_kernel_fits_four_waves_per_simd(kernels):
       assert md["vgpr_spill_count"] == 0 or md["vgpr_count"] <= 168, (name, md)
       continue
     assert md["vgpr_count"] <= 128, (name, md)
-    if "k_command_motion_sample" in name:  # an environment term, ONE workgroup per launch: its histogram (MJLAB_MOTION_SAMPLE_MAX_BINS floats + two flags) is static LDS
-      assert md["group_segment_fixed_size"] <= 4 * 4096 + 16, (name, md)
+    if "k_command_motion_sample" in name:  # k_command_motion_sample / _sampler: environment terms, ONE workgroup per launch -- the histogram /
+      assert md["group_segment_fixed_size"] <= 4 * 4096 + 2 * 4 * 256 + 16, (name, md)  # distribution (MJLAB_MOTION_SAMPLE_MAX_BINS floats) and two reduction arrays are static LDS
+      continue
+    if "k_chol_selftest" in name:  # the factorization's diagnostic (nvp_inst.hip, part 2): its factor block is static LDS
+      assert md["group_segment_fixed_size"] <= 4 * 64 * 69 and md["vgpr_spill_count"] == 0, (name, md)
       continue
     assert md["group_segment_fixed_size"] == 0, (name, md)  # LDS is laid out per model at launch (mjlab_lds_bytes)
     # scratch per lane: the 64-dof instantiations (beyond every model of the reference) spill the most
@@ -47,7 +50,9 @@ def test_every_kernel_fits_four_waves_per_simd(kernels):
 
 
 def test_g1_kernels_are_cdna4_code(kernels):
-  g1 = {n: md for n, md in kernels.items() if "ILi36E" in n and "_cone" not in n}  # (the elliptic-cone kernels have their own allocation and limits: above)
+  selftest = [md for n, md in kernels.items() if "k_chol_selftestILi36E" in n]
+  assert len(selftest) == 1 and selftest[0]["insts"].get("mfma", 0) == 51  # the diagnostic runs the tile factorization itself: 51 MFMAs per factor site
+  g1 = {n: md for n, md in kernels.items() if "ILi36E" in n and "_cone" not in n and "k_chol_selftest" not in n}  # (the elliptic-cone kernels have their own allocation and limits: above)
   names = " ".join(g1)
   assert all(k in names for k in ("k_solve_integrate", "k_substep", "k_control_step"))
   for name, md in g1.items():
