@@ -962,6 +962,15 @@ class GraphedRlEnv:
     # MotionCommand with its metrics in persistent rows (env_terms.MotionMetrics; the sampling metrics are updated in place by the reference
     # too): their masked sums and fills ride in the two launches like UniformVelocityCommand's (CommandTerm.reset, managers/command_manager.py:
     # 40-53: the mean over the reset environments is logged, then the entries are zeroed) instead of a stack / mul / sum / foreach_mul chain
+    # Class-based reward terms whose reset(env_ids) is nothing but constant row fills (the velocity task's feet_air_time zeroes three timers:
+    # tasks/velocity/mdp/rewards.py:148-153) -- found by probing, not by name: their fills ride in the bookkeeping's launch; any other
+    # term keeps _masked_class_reset (reset() on all environments, kept where the mask is set: 12 launches per step for that term)
+    self._book_class_terms = set()
+    for cfg in self.env.reward_manager._class_term_cfgs:
+      found = self._probe_class_reset(cfg.func)
+      if found is not None:
+        fills += [(f"reward.class.{type(cfg.func).__name__}.{i}", t, v) for i, (t, v) in enumerate(found)]
+        self._book_class_terms.add(id(cfg.func))
     self._book_metric_terms = set()
     if self._fused_metrics:
       for name in self.env.command_manager.active_terms:
@@ -981,6 +990,54 @@ class GraphedRlEnv:
         self._book_metric_terms.add(id(term))
     return env_core.ResetBookkeeping([(t, v) for _, t, v in fills], [t for _, t in vectors], rkeys, mkeys, tkeys, fused=self._fused), whole_clear
 
+  def _probe_class_reset(self, func: Any) -> list | None:
+    """``[(tensor, constant)]`` if ``func.reset(env_ids)`` does nothing to the term's per-environment tensors but fill rows with constants,
+    else None.  Probed, at construction, on the term object itself: every per-environment tensor is filled with a sentinel, ``reset(None)``
+    runs, and each tensor must come back either untouched or uniformly equal to ONE value -- the same value for two different sentinels;
+    a rebound attribute, a non-uniform result or a value that depends on what was there disqualify the term.  The state is restored."""
+    state: list = []
+    _state_tensors(func, self.n, set(), state)
+    if not state or not hasattr(func, "reset"):
+      return None
+    tensors = [t for _, _, t, _ in state]
+    backups = [t.clone() for t in tensors]
+
+    def cast(t: torch.Tensor, s: float) -> Any:
+      return (s > 0) if t.dtype == torch.bool else (s if t.dtype.is_floating_point else int(s))
+
+    seen: list = []
+    try:
+      for sentinel in (7.25, -3.5):
+        for t in tensors:
+          t.fill_(cast(t, sentinel))
+        func.reset(env_ids=None)
+        vals = []
+        for owner, key, t, _ in state:
+          if (owner[key] if isinstance(owner, (dict, list, tuple)) else getattr(owner, key)) is not t:
+            return None
+          flat = t.reshape(-1)
+          if not bool((flat == flat[0]).all()):
+            return None
+          vals.append(flat[0].item())
+        seen.append(vals)
+    except Exception:  # noqa: BLE001  (a reset() that cannot take env_ids=None, or that reads other state: the generic path)
+      return None
+    finally:
+      for owner, key, t, _ in state:
+        if isinstance(owner, (dict, list)):
+          owner[key] = t
+        elif not isinstance(owner, tuple):
+          setattr(owner, key, t)
+      for t, b in zip(tensors, backups, strict=True):
+        t.copy_(b)
+    out = []
+    for t, a, b in zip(tensors, seen[0], seen[1], strict=True):
+      if a == b:
+        out.append((t, a))  # whatever was there, the rows read `a` afterwards
+      elif not (a == cast(t, 7.25) and b == cast(t, -3.5)):
+        return None  # (neither untouched nor a constant fill)
+    return out
+
   def _masked_reset(self, mask: torch.Tensor) -> None:
     """``_reset_idx`` (:214-249) for the environments of `mask`: the managers' bookkeeping first -- every masked sum the reset logs
     (nothing below changes the summed buffers), then every masked fill (env_core.ResetBookkeeping: two HIP launches on the GPU, the
@@ -996,7 +1053,8 @@ class GraphedRlEnv:
     for index, (fn, prm) in enumerate(self._reset_terms):
       getattr(self, "_" + fn)(mask, self._Uof(("reset", index)), **prm)
     for cfg in env.reward_manager._class_term_cfgs:
-      self._masked_class_reset(cfg.func, mask)
+      if id(cfg.func) not in self._book_class_terms:
+        self._masked_class_reset(cfg.func, mask)
     for name in env.command_manager.active_terms:
       term = env.command_manager.get_term(name)
       if type(term).__name__ != "UniformVelocityCommand" and id(term) not in self._book_metric_terms:
