@@ -342,6 +342,10 @@ int mjlab_command_motion_frame(const mjlab_motion_tables_t* tab, int nworld, con
                                float* robot_body_pos_w, float* robot_body_quat_w, float* robot_body_lin_vel_w, float* robot_body_ang_vel_w,
                                void* stream);
 int mjlab_sizeof_motion_tables(void);
+/* world_mask[w] = (*flag > 0) for every world (flag: one device float, e.g. mjlab_masked_sums' count of masked worlds): what
+ * mjlab_forward_masked then reads for the reference's "forward() on all worlds iff some environment reset" -- one launch instead of a
+ * comparison, a cast and a copy */
+int mjlab_flag_to_mask(const float* flag, int nworld, int* world_mask, void* stream);
 /* MotionCommand._adaptive_sampling (:256-297) for the worlds of `mask`, the per-world part, in one launch: hist_out (bin_count floats) <-
  * the number of worlds with mask & terminated per phase bin clamp(time_steps * bin_count // max(time_step_total, 1)) -- written when some
  * world failed, or always (hist_always; any_failed_out then receives 0 / 1: a sharded caller all-reduces both); time_steps[w] <-

@@ -620,4 +620,11 @@ __global__ __launch_bounds__(64) void k_masked_sums(const mjlab_sum_entry_t* e, 
   if (threadIdx.x == 0) out[i] = acc;
 }
 
+// world_mask[w] = (*flag > 0) for every world: "forward() on ALL worlds iff SOME environment reset" (envs/manager_based_rl_env.py:129-132) with
+// the count of reset environments as the flag (k_masked_sums' last output; summed over the ranks when the environment is sharded)
+__global__ __launch_bounds__(256) void k_flag_to_mask(const float* flag, const int nworld, int* world_mask) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w < nworld) world_mask[w] = *flag > 0.f ? 1 : 0;
+}
+
 #endif  // MJLAB_MAIN_TU

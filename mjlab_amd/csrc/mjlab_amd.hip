@@ -309,6 +309,12 @@ int mjlab_command_motion_sampler(const mjlab_motion_sampler_t* a, void* stream) 
   return launched("k_command_motion_sampler launch failed");
 }
 
+int mjlab_flag_to_mask(const float* flag, int nworld, int* world_mask, void* stream) {
+  if (!flag || !world_mask || nworld < 1) return fail(-28, "flag_to_mask: null argument or no worlds");
+  hipLaunchKernelGGL(k_flag_to_mask, dim3((nworld + 255) / 256), dim3(256), 0, (hipStream_t)stream, flag, nworld, world_mask);
+  return launched("k_flag_to_mask launch failed");
+}
+
 int mjlab_sizeof_motion_metrics(void) { return (int)sizeof(mjlab_motion_metrics_t); }
 int mjlab_command_motion_metrics(const mjlab_motion_metrics_t* a, void* stream) {
   if (!a) return fail(-24, "command_motion_metrics: null argument");

@@ -901,7 +901,6 @@ class GraphedRlEnv:
     self._masked_reset(mask)
     self._invalidate()
     env.scene.write_data_to_sim()
-    self._any_reset.copy_(mask.any().to(torch.float32))
 
   def _step_body_b(self) -> None:
     """The second half: forward(), commands, interval events, observations.  Sharded with the reference's rule "forward() on ALL
@@ -909,7 +908,10 @@ class GraphedRlEnv:
     between the two halves (two captured graphs, then) -- makes the flag global first."""
     env = self.env
     mask = env.reset_buf
-    env.sim.forward(env_mask=(self._any_reset > 0).expand(self.n) if self._forward_all else mask)  # all worlds iff some environment reset (:129-132), or the reset worlds only
+    if self._forward_all and self._fused and hasattr(env.sim, "forward_if"):
+      env.sim.forward_if(self._any_reset)  # all worlds iff some environment reset (:129-132): the flag becomes the world mask in one launch
+    else:
+      env.sim.forward(env_mask=(self._any_reset > 0).expand(self.n) if self._forward_all else mask)  # ... or the reset worlds only
     self._invalidate()
     self._command_compute()
     self._interval_events()
@@ -1046,6 +1048,7 @@ class GraphedRlEnv:
     book, whole_clear = self._book
     self._curricula(mask)  # curriculum_manager.compute(env_ids) comes first (:215), and only when some environment resets
     out = book.sums(mask)  # (the masked sums and, last, the number of environments that reset: the log book divides)
+    self._any_reset.copy_(out[-1])  # "some environment reset" = that count (sharded: summed over the ranks by _exchange_any)
     log = book.log_entries(out)
     if not whole_clear:
       self._clear_state(self._robot, mask)

@@ -397,6 +397,16 @@ class Simulation:
       else:
         self._launch_forward()
 
+  def forward_if(self, flag: torch.Tensor) -> None:
+    """``forward()`` on ALL worlds if the device scalar ``flag`` is positive, on none otherwise -- the reference's "forward() iff some
+    environment reset" (envs/manager_based_rl_env.py:129-132) decided on the device, no host sync: one launch fills ``world_mask``, then
+    ``mjlab_forward_masked``."""
+    if flag.dtype != torch.float32 or flag.numel() != 1 or flag.device != self._data["world_mask"].device:
+      raise TypeError("forward_if: a float32 device scalar is expected")
+    with torch.cuda.device(self._dev):
+      native.check(self._lib.mjlab_flag_to_mask(flag.data_ptr(), self.num_envs, self._data["world_mask"].data_ptr(), self._stream()), "mjlab_flag_to_mask")
+      native.check(self._lib.mjlab_forward_masked(ctypes.byref(self._m), ctypes.byref(self._d), self._stream()), "mjlab_forward_masked")
+
   def step(self, nsubstep: int = 1) -> None:
     """``step()`` is the reference call (one physics step, sim/sim.py:189-195).  ``nsubstep`` > 1 is an
     extension: that many steps with the inputs held fixed -- the reference's decimation loop
