@@ -346,6 +346,10 @@ int mjlab_sizeof_motion_tables(void);
  * mjlab_forward_masked then reads for the reference's "forward() on all worlds iff some environment reset" -- one launch instead of a
  * comparison, a cast and a copy */
 int mjlab_flag_to_mask(const float* flag, int nworld, int* world_mask, void* stream);
+/* extras["log"] of one step from the RAW masked sums (the managers' reset() logging, envs/manager_based_rl_env.py:214-249): vec[i] <-
+ * (div[i] ? *src[i] / max(*count, 1) : *src[i]) * scale[i] if *count > 0 or `first`, else vec[i] stays (a step without resets keeps the
+ * last reset step's numbers).  src: DEVICE array of k device pointers to float scalars; div (k bytes), scale (k floats): device. */
+int mjlab_log_finish(const float* const* src, const unsigned char* div, const float* scale, int k, const float* count, int first, float* vec, void* stream);
 /* MotionCommand._adaptive_sampling (:256-297) for the worlds of `mask`, the per-world part, in one launch: hist_out (bin_count floats) <-
  * the number of worlds with mask & terminated per phase bin clamp(time_steps * bin_count // max(time_step_total, 1)) -- written when some
  * world failed, or always (hist_always; any_failed_out then receives 0 / 1: a sharded caller all-reduces both); time_steps[w] <-

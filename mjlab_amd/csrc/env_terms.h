@@ -620,6 +620,20 @@ __global__ __launch_bounds__(64) void k_masked_sums(const mjlab_sum_entry_t* e, 
   if (threadIdx.x == 0) out[i] = acc;
 }
 
+// extras["log"] of a step (mjlab_amd/env_core.py LogBook.finish; reference: the managers' reset() logging under _reset_idx, which runs
+// only when some environment reset): entry i <- (div[i] ? *src[i] / max(*count, 1) : *src[i]) * scale[i] where *count > 0 (or `first`),
+// else the entry keeps the last reset step's number.  Elementwise IEEE operations in the torch twin's order: the same bits.
+__global__ __launch_bounds__(64) void k_log_finish(const float* const* src, const unsigned char* div, const float* scale, const int k, const float* count,
+                                                   const int first, float* vec) {
+#pragma clang fp contract(off)
+  const float cnt = *count;
+  for (int i = threadIdx.x; i < k; i += 64) {
+    const float raw = *src[i];
+    const float v = (div[i] ? __fdiv_rn(raw, fmaxf(cnt, 1.f)) : raw) * scale[i];
+    if (first || cnt > 0.f) vec[i] = v;
+  }
+}
+
 // world_mask[w] = (*flag > 0) for every world: "forward() on ALL worlds iff SOME environment reset" (envs/manager_based_rl_env.py:129-132) with
 // the count of reset environments as the flag (k_masked_sums' last output; summed over the ranks when the environment is sharded)
 __global__ __launch_bounds__(256) void k_flag_to_mask(const float* flag, const int nworld, int* world_mask) {

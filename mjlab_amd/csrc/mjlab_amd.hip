@@ -309,6 +309,11 @@ int mjlab_command_motion_sampler(const mjlab_motion_sampler_t* a, void* stream) 
   return launched("k_command_motion_sampler launch failed");
 }
 
+int mjlab_log_finish(const float* const* src, const unsigned char* div, const float* scale, int k, const float* count, int first, float* vec, void* stream) {
+  if (!src || !div || !scale || !count || !vec || k < 1) return fail(-29, "log_finish: null argument or no entries");
+  hipLaunchKernelGGL(k_log_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, src, div, scale, k, count, first, vec);
+  return launched("k_log_finish launch failed");
+}
 int mjlab_flag_to_mask(const float* flag, int nworld, int* world_mask, void* stream) {
   if (!flag || !world_mask || nworld < 1) return fail(-28, "flag_to_mask: null argument or no worlds");
   hipLaunchKernelGGL(k_flag_to_mask, dim3((nworld + 255) / 256), dim3(256), 0, (hipStream_t)stream, flag, nworld, world_mask);

@@ -99,9 +99,15 @@ class LogBook:
     self.pub: dict = {}
     self.first = False
 
-  def publish(self, log: dict, mask: torch.Tensor) -> dict:
+  def publish(self, log: dict, mask: torch.Tensor, count: torch.Tensor | None = None) -> dict:
+    """``count``: the number of environments in `mask` as a device float scalar, where the caller has it (the masked sums' last output)."""
     keys = [k for k, (v, _) in log.items() if v.dim() == 0]
-    raw = torch.stack([log[k][0].to(torch.float32) for k in keys] + [mask.sum().to(torch.float32)])
+    if self._publish_fused(log, keys, count):
+      for k, (v, _) in log.items():
+        if v.dim() != 0:
+          self.pub[k] = v
+      return self.pub
+    raw = torch.stack([log[k][0].to(torch.float32) for k in keys] + [(mask.sum() if count is None else count).to(torch.float32)])
     first = False
     if self.vec is None or self.keys != keys:
       kinds = [log[k][1] for k in keys]
@@ -121,6 +127,29 @@ class LogBook:
       if v.dim() != 0:
         self.pub[k] = v
     return self.pub
+
+  def _publish_fused(self, log: dict, keys: list, count: torch.Tensor | None) -> bool:
+    """One HIP launch (``mjlab_log_finish``) straight from the scalars the log names -- no stack, no division / where chain -- when this
+    is a single-process log on the GPU whose values are float32 device scalars at fixed addresses (views into the masked sums' output
+    and persistent state) and the count is at hand; the vectors exist already (the first publication goes through the torch lines)."""
+    if self.world > 1 or count is None or self.vec is None or self.keys != keys or not self.vec.is_cuda:
+      return False
+    vals = [log[k][0] for k in keys]
+    if not all(v.is_cuda and v.dtype == torch.float32 for v in vals) or count.dtype != torch.float32 or not count.is_cuda:
+      return False
+    ptrs = [v.data_ptr() for v in vals]
+    if getattr(self, "_ptrs", None) != ptrs:  # (addresses are part of what a captured launch records: a new table for new addresses)
+      if torch.cuda.is_current_stream_capturing():
+        return False
+      self._ptrs = ptrs
+      self._ptr_table = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+      self._div_u8 = self.div.to(torch.uint8).contiguous()
+    from . import native
+
+    native.check(native.lib().mjlab_log_finish(self._ptr_table.data_ptr(), self._div_u8.data_ptr(), self.scale.data_ptr(), len(keys), count.data_ptr(), 0,
+                                               self.vec.data_ptr(), torch.cuda.current_stream(self.vec.device).cuda_stream), "mjlab_log_finish")
+    self.first = False
+    return True
 
   def clear(self) -> None:
     """Zero what has been published so far, keeping the vectors (and the tensors handed out) in place."""

@@ -1049,6 +1049,7 @@ class GraphedRlEnv:
     self._curricula(mask)  # curriculum_manager.compute(env_ids) comes first (:215), and only when some environment resets
     out = book.sums(mask)  # (the masked sums and, last, the number of environments that reset: the log book divides)
     self._any_reset.copy_(out[-1])  # "some environment reset" = that count (sharded: summed over the ranks by _exchange_any)
+    self._reset_count = out[-1]
     log = book.log_entries(out)
     if not whole_clear:
       self._clear_state(self._robot, mask)
@@ -1075,7 +1076,7 @@ class GraphedRlEnv:
 
   def _publish_log(self, log: dict, mask: torch.Tensor) -> None:
     """``extras["log"]`` through the log book (env_core.LogBook: kept between steps with resets; sharded: finished by _exchange())."""
-    self.env.extras["log"] = self._logbook.publish(log, mask)
+    self.env.extras["log"] = self._logbook.publish(log, mask, self._reset_count)
 
   def _curricula(self, mask: torch.Tensor) -> None:
     """CurriculumManager.compute (managers/curriculum_manager.py:97-102) for ``commands_vel`` (tasks/velocity/mdp/curriculums.py:60-74)

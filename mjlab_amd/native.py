@@ -165,6 +165,7 @@ def lib() -> ctypes.CDLL:
   L.mjlab_command_motion_sample.argtypes = [vp, vp]
   L.mjlab_command_motion_sampler.argtypes = [vp, vp]
   L.mjlab_flag_to_mask.argtypes = [vp, ci, vp, vp]
+  L.mjlab_log_finish.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp]
   L.mjlab_command_motion_relative.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, ci, vp]
   L.mjlab_control_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
   L.mjlab_forward_stages.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -195,7 +196,7 @@ def lib() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = (
   "mjlab_abi_version", "mjlab_last_error", "mjlab_model_layout", "mjlab_data_layout", "mjlab_sizeof_model",
-  "mjlab_sizeof_data", "mjlab_sizeof_option", "mjlab_sizeof_sizes", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_sizeof_motion_reset", "mjlab_event_reset_root_state_uniform", "mjlab_event_reset_joints_by_scale", "mjlab_event_push_by_setting_velocity", "mjlab_command_uniform_velocity", "mjlab_sizeof_velocity_command", "mjlab_command_motion_write", "mjlab_command_motion_relative", "mjlab_command_motion_frame", "mjlab_copy_batch", "mjlab_command_motion_metrics", "mjlab_sizeof_motion_metrics", "mjlab_command_motion_sample", "mjlab_sizeof_motion_sample", "mjlab_command_motion_sampler", "mjlab_sizeof_motion_sampler", "mjlab_flag_to_mask", "mjlab_sizeof_motion_tables", "mjlab_reward_accumulate", "mjlab_masked_fill_rows", "mjlab_masked_sums", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest", "mjlab_chol_selftest", "mjlab_poison_scratch",
+  "mjlab_sizeof_data", "mjlab_sizeof_option", "mjlab_sizeof_sizes", "mjlab_step", "mjlab_forward", "mjlab_forward_masked", "mjlab_entity_readback", "mjlab_masked_reset", "mjlab_interval_push", "mjlab_control_step", "mjlab_sizeof_control", "mjlab_sizeof_motion_reset", "mjlab_event_reset_root_state_uniform", "mjlab_event_reset_joints_by_scale", "mjlab_event_push_by_setting_velocity", "mjlab_command_uniform_velocity", "mjlab_sizeof_velocity_command", "mjlab_command_motion_write", "mjlab_command_motion_relative", "mjlab_command_motion_frame", "mjlab_copy_batch", "mjlab_command_motion_metrics", "mjlab_sizeof_motion_metrics", "mjlab_command_motion_sample", "mjlab_sizeof_motion_sample", "mjlab_command_motion_sampler", "mjlab_sizeof_motion_sampler", "mjlab_flag_to_mask", "mjlab_log_finish", "mjlab_sizeof_motion_tables", "mjlab_reward_accumulate", "mjlab_masked_fill_rows", "mjlab_masked_sums", "mjlab_forward_stages", "mjlab_tile_field", "mjlab_lds_bytes", "mjlab_selftest", "mjlab_chol_selftest", "mjlab_poison_scratch",
 )  # fmt: skip
 
 

@@ -598,6 +598,36 @@ def test_command_motion_sampler_update_and_distribution(ksize):
   assert abs(float(H) - float(Hw)) <= 2e-6 and abs(float(pmax) - float(pm)) <= 1e-7 * float(pm) + 1e-9 and float(top) == float(im.float() / nbin)
 
 
+def test_log_book_publishes_the_same_numbers_through_the_one_launch():
+  """env_core.LogBook with the count at hand on the GPU (``mjlab_log_finish``) against the same book's torch lines: every kind of entry
+  (episode reward sums / command metrics / termination counts / curriculum state), steps with and without resets -- bit for bit, and the
+  entries handed out stay the same tensors."""
+  from mjlab_amd import env_core
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(12)
+  kinds = ["sum_len"] * 5 + ["sum"] * 4 + ["count"] * 3 + ["state"]
+  books = [env_core.LogBook(20.0, dev), env_core.LogBook(20.0, dev)]
+  src = torch.zeros(len(kinds) + 1, device=dev)  # (persistent: what the masked sums' output is)
+  handed = None
+  for step in range(8):
+    nreset = 0 if step in (2, 3, 6) else int(torch.randint(1, 40, (1,), generator=g))
+    mask = torch.zeros(N, dtype=torch.bool, device=dev)
+    mask[torch.randperm(N, generator=g)[:nreset].to(dev)] = True
+    src.copy_(torch.cat([torch.randn(len(kinds), generator=g) * 30, torch.tensor([float(nreset)])]).to(dev))
+    log = {f"k{i}": (src[i], kd) for i, kd in enumerate(kinds)}
+    a = books[0].publish(dict(log), mask, src[-1])  # the launch (after the first publication, which allocates through the torch lines)
+    b = books[1].publish(dict(log), mask)  # the torch lines
+    torch.cuda.synchronize()
+    assert list(a) == list(b)
+    for k in a:
+      assert torch.equal(a[k], b[k]), (step, k, float(a[k]), float(b[k]))
+    if handed is None:
+      handed = {k: v.data_ptr() for k, v in a.items()}
+    assert {k: v.data_ptr() for k, v in a.items()} == handed
+  assert getattr(books[0], "_ptrs", None) is not None and getattr(books[1], "_ptrs", None) is None  # (the launch was what ran on the first book)
+
+
 def test_copy_batch_copies_every_pair():
   """mjlab_copy_batch: 40 pairs (two launches) of float, int64 and bool tensors, odd byte counts included; strided / mixed-dtype pairs
   keep copy_."""
