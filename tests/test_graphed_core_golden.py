@@ -146,3 +146,100 @@ def test_core_reproduces_the_reference_on_the_device(scene, fused):
     assert check_obs(scene, "cuda:0") >= 2
     if scene in VELOCITY_SCENES:
       assert check_velocity(scene, "cuda:0") >= 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", SCENES)
+def test_core_captured_as_one_hipgraph_replays_the_reference(scene):
+  """The same recorded truth through a CAPTURED graph (reference-free, so the driver's box runs it): the reset bookkeeping's launches
+  (mjlab_masked_sums -> mjlab_log_finish -> mjlab_masked_fill_rows) and RewardManager.compute's accumulation (mjlab_reward_accumulate)
+  are captured ONCE on persistent buffers into one hipGraph, as GraphedRlEnv captures them; every recorded step is then copied into
+  those buffers and answered by a replay -- buffers and log bit for bit / to float rounding as in the eager checks above, and the log
+  entries handed out stay the same tensors."""
+  from mjlab_amd import env_terms
+
+  dev = "cuda:0"
+  meta, z = load(scene)
+  e0, r0 = meta["reset"][0], meta["reward"][0]
+  assert all([f["name"] for f in e["fills"]] == [f["name"] for f in e0["fills"]] and e["rkeys"] == e0["rkeys"] for e in meta["reset"])
+  # persistent buffers (what the environment's managers own)
+  mask = _t(z, e0["mask"], dev).clone()
+  fills = [(_t(z, f["pre"], dev).clone(), f["value"]) for f in e0["fills"]]
+  by_name = {f["name"]: t for f, (t, _) in zip(e0["fills"], fills)}
+  vectors = [by_name[v["name"]] if v["name"] in by_name else _t(z, v["pre"], dev).clone() for v in e0["vectors"]]
+  book = env_core.ResetBookkeeping(fills, vectors, e0["rkeys"], [tuple(k) for k in e0["mkeys"]], e0["tkeys"], fused=True)
+  book_log = env_core.LogBook(meta["max_episode_length_s"], dev)
+  values = _t(z, r0["values"], dev).clone()
+  k, nenv = values.shape
+  sums = [t.clone().contiguous() for t in _t(z, r0["sums_pre"], dev)]
+  ptrs = torch.tensor([s.data_ptr() for s in sums], dtype=torch.int64, device=dev)
+  reward_buf = torch.zeros(nenv, device=dev)
+  step_reward = torch.zeros(nenv, r0["nterms"], device=dev)
+  weights = torch.tensor(r0["weights"], dtype=torch.float32, device=dev)
+  columns = torch.tensor(r0["columns"], dtype=torch.int32, device=dev)
+  handed = {}
+
+  def body():
+    env_terms.reward_accumulate(values, weights, columns, r0["dt"], reward_buf, ptrs, step_reward)
+    out = book.sums(mask)
+    handed["log"] = book_log.publish(book.log_entries(out), mask, out[-1])
+    book.fill(mask)
+
+  stream = torch.cuda.Stream()
+  stream.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(stream):
+    body()  # (allocates the log vectors through the torch lines)
+    body()  # (the launch form, its pointer table built outside the capture)
+  torch.cuda.current_stream().wait_stream(stream)
+  torch.cuda.synchronize()
+  assert getattr(book_log, "_ptrs", None) is not None
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph, stream=stream):
+    body()
+  first_log = {key: t.data_ptr() for key, t in handed["log"].items()}
+  book_log.clear()
+
+  n = 0
+  rewards = meta["reward"]
+  for i, e in enumerate(meta["reset"]):
+    r = rewards[i % len(rewards)]
+    assert r["columns"] == r0["columns"] and r["weights"] == r0["weights"]
+    mask.copy_(_t(z, e["mask"], dev))
+    for f, (t, _) in zip(e["fills"], fills):
+      t.copy_(_t(z, f["pre"], dev))
+    for v, t in zip(e["vectors"], vectors):
+      if v["name"] not in by_name:
+        t.copy_(_t(z, v["pre"], dev))
+    values.copy_(_t(z, r["values"], dev))
+    for s, t in zip(sums, _t(z, r["sums_pre"], dev)):
+      s.copy_(t)
+    reward_buf.fill_(7.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(reward_buf.cpu(), torch.from_numpy(np.array(z[r["reward_buf"]]))), scene
+    assert torch.equal(torch.stack(sums).cpu(), torch.from_numpy(np.array(z[r["sums_post"]]))), scene
+    checked = 0
+    for j, (f, (t, _)) in enumerate(zip(e["fills"], fills)):
+      if f["name"] in ("qfrc_applied", "xfrc_applied"):
+        assert bool((t[mask] == 0).all()), f["name"]
+        continue
+      if f["name"] == "ctrl" or f["value"] != e0["fills"][j]["value"]:
+        continue  # (the event manager's step counter: a fill value that changes from step to step is a constant of the captured launch)
+      if f["name"].endswith(".command_counter"):
+        t = t + mask.to(t.dtype)
+      assert torch.equal(t.cpu(), torch.from_numpy(np.array(z[f["post"]]))), (scene, f["name"])
+      checked += 1
+    assert checked >= len(fills) - 5
+    log = handed["log"]
+    assert {key: t.data_ptr() for key, t in log.items()} == first_log
+    for key, ref in e["log"].items():
+      if key.startswith(("Episode_Reward/", "Episode_Termination/")) or (key.startswith("Metrics/") and key in log):
+        assert abs(float(log[key]) - ref) <= 2e-6 * (1.0 + abs(ref)), (scene, key, float(log[key]), ref)
+        n += 1
+  assert n >= 20, n
+  # a step without resets leaves the log where the last reset step put it (the where(count > 0) of the launch, inside the graph)
+  before = {key: float(t) for key, t in handed["log"].items()}
+  mask.zero_()
+  graph.replay()
+  torch.cuda.synchronize()
+  assert {key: float(t) for key, t in handed["log"].items()} == before
