@@ -427,7 +427,9 @@ int mjlab_reward_accumulate(const float* values, const float* weights, const int
  *   (elements of 1, 4 or 8 bytes) where mask[w] is set;
  * mjlab_masked_sums -- out[i] = sum over the masked worlds of vector i (nworld floats, or nworld bools counted as 0 / 1),
  *   out[k] = the number of masked worlds.  `entries` are DEVICE arrays. */
-typedef struct mjlab_fill_entry { void* ptr; long long pattern; int row_stride_bytes, row_bytes, elem_bytes, pad_; } mjlab_fill_entry_t;
+/* from_device != 0: `pattern` is the device ADDRESS of an integer scalar at least elem_bytes wide whose low bytes are the fill value, read
+ * when the launch runs (a captured launch fills with the step's value, e.g. the event manager's step count) */
+typedef struct mjlab_fill_entry { void* ptr; long long pattern; int row_stride_bytes, row_bytes, elem_bytes, from_device; } mjlab_fill_entry_t;
 typedef struct mjlab_sum_entry { const void* ptr; int is_bool, pad_; } mjlab_sum_entry_t;
 /* n device-to-device copies (dst <- src, nbytes; non-overlapping) in ceil(n / 32) launches: what GraphedRlEnv copies back at the end
  * of a step body (the tensors the reference rebound).  `entries` is a HOST array; the launches carry it by value (graph safe). */

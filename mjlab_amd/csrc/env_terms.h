@@ -598,10 +598,13 @@ __global__ __launch_bounds__(64) void k_masked_fill_rows(const mjlab_fill_entry_
   for (int i = 0; i < ne; ++i) {
     char* row = (char*)e[i].ptr + (size_t)w * e[i].row_stride_bytes;
     const int eb = e[i].elem_bytes, nel = e[i].row_bytes / eb;
+    // from_device: the pattern is the ADDRESS of an integer scalar at least elem_bytes wide (little endian: its low bytes) -- a value that
+    // changes from step to step (the event manager's step count, managers/event_manager.py:139-148) under a captured launch
+    const long long pat = e[i].from_device ? (eb == 8 ? *(const long long*)e[i].pattern : eb == 4 ? (long long)*(const int*)e[i].pattern : (long long)*(const char*)e[i].pattern) : e[i].pattern;
     for (int k = threadIdx.x; k < nel; k += 64) {
-      if (eb == 4) ((int*)row)[k] = (int)e[i].pattern;
-      else if (eb == 8) ((long long*)row)[k] = e[i].pattern;
-      else row[k] = (char)e[i].pattern;
+      if (eb == 4) ((int*)row)[k] = (int)pat;
+      else if (eb == 8) ((long long*)row)[k] = pat;
+      else row[k] = (char)pat;
     }
   }
 }

@@ -32,7 +32,10 @@ class TorchMaskedFill:
   def __call__(self, mask: torch.Tensor) -> None:
     for t, value in self.items:
       m = mask.reshape((-1,) + (1,) * (t.dim() - 1))
-      t.masked_fill_(m, bool(value) if t.dtype == torch.bool else value)
+      if isinstance(value, torch.Tensor):  # (a scalar tensor read at every call: the step's value under a capture)
+        torch.where(m, value.to(t.dtype), t, out=t)
+      else:
+        t.masked_fill_(m, bool(value) if t.dtype == torch.bool else value)
 
 
 class TorchMaskedSums:

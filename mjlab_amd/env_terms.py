@@ -408,7 +408,7 @@ class RewardAccumulator:
 
 
 class _FillEntry(ctypes.Structure):  # mjlab_fill_entry_t
-  _fields_ = [("ptr", _vp), ("pattern", ctypes.c_longlong), ("row_stride_bytes", ctypes.c_int), ("row_bytes", ctypes.c_int), ("elem_bytes", ctypes.c_int), ("pad_", ctypes.c_int)]
+  _fields_ = [("ptr", _vp), ("pattern", ctypes.c_longlong), ("row_stride_bytes", ctypes.c_int), ("row_bytes", ctypes.c_int), ("elem_bytes", ctypes.c_int), ("from_device", ctypes.c_int)]
 
 
 class _SumEntry(ctypes.Structure):  # mjlab_sum_entry_t
@@ -434,12 +434,18 @@ class MaskedFill:
       eb = t.element_size()
       if eb not in (1, 4, 8):
         raise TypeError(f"MaskedFill: element size {eb}")
-      if t.dtype.is_floating_point:
+      from_device = 0
+      if isinstance(value, torch.Tensor):  # a value read when the launch runs: an integer device scalar at least as wide as the elements
+        if t.dtype.is_floating_point or t.dtype == torch.bool or value.dtype.is_floating_point or value.numel() != 1 or value.element_size() < eb or value.device != t.device:
+          raise TypeError(f"MaskedFill: a device-valued fill needs integer elements and an integer scalar at least as wide ({t.dtype} <- {value.dtype})")
+        pattern, from_device = value.data_ptr(), 1
+        self.keep.append(value)
+      elif t.dtype.is_floating_point:
         pattern = struct.unpack("<q", struct.pack("<d", float(value)))[0] if eb == 8 else struct.unpack("<i", struct.pack("<f", float(value)))[0]
       else:
         pattern = int(value)
       row = int(t[0].numel()) if t.dim() > 1 else 1
-      entries.append(_FillEntry(t.data_ptr(), pattern, int(t.stride(0)) * eb, row * eb, eb, 0))
+      entries.append(_FillEntry(t.data_ptr(), pattern, int(t.stride(0)) * eb, row * eb, eb, from_device))
       self.keep.append(t)
     self.n = items[0][0].shape[0]
     self.table = _upload(entries, items[0][0].device)

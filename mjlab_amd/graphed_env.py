@@ -368,6 +368,7 @@ class GraphedRlEnv:
     # RewardManager.compute's accumulation (6 launches per term) as one launch; the term functions are the reference's (GPU only)
     self._reward = env_terms.RewardAccumulator(env.reward_manager) if self._fused else None
     self._ep_len = env.episode_length_buf  # the tensor the captured kernels address (see step())
+    self._step_counter = torch.full((), int(env.common_step_counter), dtype=torch.long, device=self.device)  # env.common_step_counter on the device
     self._book = self._prepare_bookkeeping()
     self._obs_memo: dict = {}
     self._obs_memo_on = False
@@ -457,7 +458,6 @@ class GraphedRlEnv:
     self._never_times_out: dict = {}
     self._sampler_cache: dict = {}  # MotionCommand: the adaptive sampler's distribution, the same for every resample of one step
     self._motion_dev: dict = {}  # MotionCommand: (tables, keep-alive, joint q / v addresses as int32, the anchor's global body id)
-    self._step_counter = torch.full((), int(self.env.common_step_counter), dtype=torch.long, device=dev)  # env.common_step_counter on the device
     for name in self.env.command_manager.active_terms:
       term = self.env.command_manager.get_term(name)
       # UniformVelocityCommand: 8 draws per call; MotionCommand: [time_left, bin, within-bin, 6 pose, 6 velocity, nj joints], and a third
@@ -967,6 +967,10 @@ class GraphedRlEnv:
     # Class-based reward terms whose reset(env_ids) is nothing but constant row fills (the velocity task's feet_air_time zeroes three timers:
     # tasks/velocity/mdp/rewards.py:148-153) -- found by probing, not by name: their fills ride in the bookkeeping's launch; any other
     # term keeps _masked_class_reset (reset() on all environments, kept where the mask is set: 12 launches per step for that term)
+    # the event manager stamps the reset environments with the env-step count of THIS step (managers/event_manager.py:139-148:
+    # _sim_step_counter // decimation = common_step_counter): a device scalar the fill reads when it runs, not a constant of the capture
+    if int(self.env._sim_step_counter) // int(self.env.cfg.decimation) == int(self.env.common_step_counter):
+      fills = [(name, t, self._step_counter if name.startswith("event.last_triggered_step_id.") else v) for name, t, v in fills]
     self._book_class_terms = set()
     for cfg in self.env.reward_manager._class_term_cfgs:
       found = self._probe_class_reset(cfg.func)

@@ -87,6 +87,46 @@ def _same_reward_state(a, b, k) -> None:
     assert torch.equal(ra._episode_sums[name], rb._episode_sums[name]), (k, name)
 
 
+def _same_event_bookkeeping(a, b, k) -> None:
+  """EventManager's per-environment stamps of reset-mode terms (managers/event_manager.py:139-148): the env-step count of the reset and
+  the triggered-once flag -- the step count is a value of the STEP, not of the construction / capture."""
+  ea, eb = a.event_manager, b.event_manager
+  for ta, tb in zip(ea._reset_term_last_triggered_step_id, eb._reset_term_last_triggered_step_id, strict=True):
+    assert torch.equal(ta, tb), (k, ta, tb)
+  for ta, tb in zip(ea._reset_term_last_triggered_once, eb._reset_term_last_triggered_once, strict=True):
+    assert torch.equal(ta, tb), k
+
+
+def _state_sweep(a, b, quiet, k, skip=()) -> int:
+  """EVERY per-environment tensor the managers of the two environments hold (the same enumeration _sync copies from) and every
+  per-world mjData array, in the environments that drew no random number in this step: bit for bit.  Returns the number compared."""
+  n = a.num_envs
+  sa, sb = [], []
+  for ma, mb in zip(_managers(a), _managers(b), strict=True):
+    _state_tensors(ma, n, set(), sa)
+    _state_tensors(mb, n, set(), sb)
+  assert [p for *_, p in sa] == [p for *_, p in sb], k
+  bad = []
+  for (_, _, ta, path), (_, _, tb, _) in zip(sa, sb, strict=True):
+    if any(x in path for x in skip):
+      continue
+    if (".metrics.error_" in path or ".metrics.sampling_" in path) and ta.device.type == "cuda":
+      # MotionCommand's logging metrics come from ONE launch each on the GPU (mjlab_command_motion_metrics; the sampler's entropy and
+      # top-bin probability from mjlab_command_motion_sampler): a few ulp from the reference's mean / norm / log reductions,
+      # documented in GraphedRlEnv's options; nothing but extras["log"] reads them
+      if not torch.allclose(ta[quiet], tb[quiet], rtol=2e-5, atol=1e-6):
+        bad.append(path)
+    elif not torch.equal(ta[quiet], tb[quiet]):
+      bad.append(path)
+  private = ("fold_reuse", "world_mask", "sched_thr", "profile")  # (this library's scheduling scratch: which stages a pass could skip, which worlds a masked pass took)
+  for f, ta in a.sim._data.items():
+    tb = b.sim._data[f]
+    if ta.dim() >= 1 and ta.shape[0] == n and f not in skip and f not in private and not torch.equal(ta[quiet], tb[quiet]):
+      bad.append("mjData." + f)
+  assert not bad, (k, bad)
+  return len(sa)
+
+
 def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: bool = True, post_make=None, g_kwargs: dict | None = None,
         reset_at: int | None = None) -> dict:
   """``reset_at``: before that step both environments are reset through their public ``reset()`` (the reference's eager reset of all
@@ -161,6 +201,8 @@ def run(make_env, device: str, num_envs: int = 64, steps: int = 70, capture: boo
     assert torch.equal(cmd_a.command[quiet], cmd_b.command[quiet]) and torch.equal(cmd_a.time_left[quiet], cmd_b.time_left[quiet])
     assert torch.equal(a.episode_length_buf, b.episode_length_buf)
     assert torch.equal(a.action_manager.action, b.action_manager.action) and torch.equal(a.action_manager.prev_action, b.action_manager.prev_action)
+    _same_event_bookkeeping(a, b, k)
+    stats["state_tensors_swept"] = _state_sweep(a, b, quiet, k)
     # ---- the environments that drew random numbers: same distribution, checked against the configuration
     for env in (a, b):
       d = env.sim.data
@@ -384,6 +426,8 @@ def run_tracking(make_env, device: str, num_envs: int = 32, steps: int = 40, cap
     assert torch.equal(cmd_a.body_pos_relative_w[quiet], cmd_b.body_pos_relative_w[quiet]) and torch.equal(cmd_a.body_quat_relative_w[quiet], cmd_b.body_quat_relative_w[quiet])
     assert torch.equal(cmd_a.bin_failed_count, cmd_b.bin_failed_count), k  # the sampler's global statistics: no randomness in them
     assert torch.equal(a.episode_length_buf, b.episode_length_buf)
+    _same_event_bookkeeping(a, b, k)
+    stats["state_tensors_swept"] = _state_sweep(a, b, quiet, k)
     # ---- resampled environments: a motion frame plus the cfg's noise (MotionCommand._resample_command), on both sides
     rs = reset | ended
     if rs.any():

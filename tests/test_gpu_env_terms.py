@@ -755,3 +755,56 @@ def test_masked_fill_rows_and_masked_sums():
   assert out[-1] == float(mask.sum()) and out[-2] == float((done & mask).sum())  # counts are exact
   none = torch.zeros(N, dtype=torch.bool, device=dev)
   assert float(sums(none).abs().max()) == 0.0
+
+
+def test_masked_fill_with_a_value_read_on_the_device_follows_it_through_a_captured_graph():
+  """A fill whose value is a device scalar (the event manager's env-step count, managers/event_manager.py:139-148): int32 rows from an
+  int64 counter (its low bytes) and int64 rows, eagerly and as a captured launch replayed after the counter moved; the torch twin
+  (env_core.TorchMaskedFill) does the same; floating-point targets are refused."""
+  from mjlab_amd import env_core, env_terms
+
+  dev = _dev()
+  g = torch.Generator().manual_seed(14)
+  counter = torch.full((), 41, dtype=torch.long, device=dev)
+  a = torch.randint(0, 9, (N,), generator=g, dtype=torch.int32).to(dev)
+  b = torch.randint(0, 9, (N, 3), generator=g).to(dev)
+  c = torch.randn(N, generator=g).to(dev)
+  twin = [t.clone() for t in (a, b, c)]
+  fill = env_terms.MaskedFill([(a, counter), (b, counter), (c, 2.5)])
+  tfill = env_core.TorchMaskedFill([(twin[0], counter), (twin[1], counter), (twin[2], 2.5)])
+  mask = torch.zeros(N, dtype=torch.bool, device=dev)
+
+  def step(m):
+    mask.copy_(m)
+    counter.add_(1)
+    fill(mask)
+
+  stream = torch.cuda.Stream()
+  stream.wait_stream(torch.cuda.current_stream())
+  masks = [(torch.rand(N, generator=g) < 0.2).to(dev) for _ in range(5)]
+  want = [t.clone() for t in (a, b, c)]
+  with torch.cuda.stream(stream):
+    step(masks[0])
+  torch.cuda.current_stream().wait_stream(stream)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph, stream=stream):
+    counter.add_(1)
+    fill(mask)
+  # (the capture itself runs nothing: the counter still reads 42)
+  want[0][masks[0]] = 42
+  want[1][masks[0]] = 42
+  want[2][masks[0]] = 2.5
+  tfill(masks[0])
+  for k, m in enumerate(masks[1:]):
+    mask.copy_(m)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(counter) == 43 + k
+    want[0][m] = 43 + k
+    want[1][m] = 43 + k
+    want[2][m] = 2.5
+    tfill(m)
+    for got, w, t in zip((a, b, c), want, twin, strict=True):
+      assert torch.equal(got, w) and torch.equal(t, w), k
+  with pytest.raises(TypeError):
+    env_terms.MaskedFill([(c, counter)])
