@@ -56,8 +56,8 @@ static int check_model(const mjlab_model_t* m) {
   if (s.njmax < 1 || s.nconmax < 1) return fail(-4, "njmax and nconmax must be >= 1");
   if (s.ngeom > 65535) return fail(-19, "ngeom must be < 65536 (geom pairs are packed into one word)");
   if (m->opt.cone != MJLAB_CONE_PYRAMIDAL && m->opt.cone != MJLAB_CONE_ELLIPTIC) return fail(-5, "opt.cone must be MJLAB_CONE_PYRAMIDAL or MJLAB_CONE_ELLIPTIC");
-  if (m->opt.cone == MJLAB_CONE_ELLIPTIC && (m->opt.solver != MJLAB_SOL_NEWTON || (m->opt.flags & MJLAB_OPT_FUSE_PRESOLVE)))
-    return fail(-5, "MJLAB_CONE_ELLIPTIC runs with MJLAB_SOL_NEWTON, one kernel per stage or MJLAB_OPT_FUSE_STEP (no MJLAB_OPT_FUSE_PRESOLVE)");
+  if (m->opt.cone == MJLAB_CONE_ELLIPTIC && ((m->opt.solver != MJLAB_SOL_NEWTON && m->opt.solver != MJLAB_SOL_CG) || (m->opt.flags & MJLAB_OPT_FUSE_PRESOLVE)))
+    return fail(-5, "MJLAB_CONE_ELLIPTIC runs with MJLAB_SOL_NEWTON or MJLAB_SOL_CG, one kernel per stage or MJLAB_OPT_FUSE_STEP (no MJLAB_OPT_FUSE_PRESOLVE)");
   if (m->opt.cone == MJLAB_CONE_ELLIPTIC && !(m->opt.impratio > 0)) return fail(-5, "opt.impratio must be positive (the elliptic cone's friction rows are scaled by 1 / impratio)");
   if (m->opt.integrator != MJLAB_INT_EULER && m->opt.integrator != MJLAB_INT_IMPLICITFAST)
     return fail(-6, "integrator must be Euler or implicitfast");

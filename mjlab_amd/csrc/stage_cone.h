@@ -351,7 +351,10 @@ __device__ __forceinline__ void cone_jac_mul(const ConeCtx& c, float x, float y,
 }
 
 // BIG: this world has more rows than fit next to M: all njmax rows in LDS instead, M from global memory
-template <int NVP, bool BIG>
+// CG: mjSOL_CG with elliptic cones (reference sim/sim.py:49-56 accepts the pair) -- mj_solPrimal's Polak-Ribiere directions preconditioned by
+// M: the same constraint update, cost and line search; the matrix factored at the loop's top is M itself (the Hessian's tiles are dropped),
+// so x = M^-1 grad.  An off-path combination: one instantiation (the layout without M in LDS, any row count).
+template <int NVP, bool BIG, bool CG = false>
 __device__ __forceinline__ void stage_solve_cone_impl(const Model& m, const Data& d, const int w, const int lane, float* smem) {
   constexpr int ld = CholCfg<NVP>::LD, NB = CholCfg<NVP>::NB, NT = NB * (NB + 1) / 2;
   const int nv = m.size.nv, njm = m.size.njmax, ncm = m.size.nconmax;
@@ -491,7 +494,7 @@ __device__ __forceinline__ void stage_solve_cone_impl(const Model& m, const Data
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int row = 16 * I + sub * 4 + k, cc = 16 * Jb + col;
-            if (row < nv && cc <= row) s_H[row * ld + cc] = acc[t][k] + (BIG ? M[row * nv + cc] : s_M[((row * (row + 1)) >> 1) + cc]);
+            if (row < nv && cc <= row) s_H[row * ld + cc] = (CG ? 0.f : acc[t][k]) + (BIG ? M[row * nv + cc] : s_M[((row * (row + 1)) >> 1) + cc]);
           }
           ++t;
         }
@@ -508,12 +511,23 @@ __device__ __forceinline__ void stage_solve_cone_impl(const Model& m, const Data
   update();
   PROF_MARK(2);
   int iter = 0;
+  float cg_search = 0.f, cg_grad = 0.f, cg_Mgrad = 0.f;  // CG: the previous direction, gradient and M^-1 gradient
   while (iter < maxiter) {
-    // ---- search = -H^-1 grad
+    // ---- search = -H^-1 grad (CG: -M^-1 grad + beta x the previous direction)
     const float grad = own ? Ma - qs - fc : 0.f;
     chol_factor<NVP>(s_H, s_invd, nv, lane);
     __syncthreads();
-    const float search = -chol_solve<NVP>(s_H, s_invd, lane, grad);
+    float search = -chol_solve<NVP>(s_H, s_invd, lane, grad);
+    if (CG) {  // Polak-Ribiere (mj_solPrimal): beta = grad . (Mgrad - Mgrad_old) / max(grad_old . Mgrad_old, mjMINVAL), clamped at 0
+      const float Mgrad = own ? -search : 0.f;
+      float beta = 0.f;
+      if (iter > 0) {
+        const float num = wave_sum(grad * (Mgrad - cg_Mgrad)), den = wave_sum(cg_grad * cg_Mgrad);
+        beta = fmaxf(0.f, num / fmaxf(den, MINVAL));
+      }
+      search = beta * cg_search - Mgrad;
+      cg_search = search; cg_grad = grad; cg_Mgrad = Mgrad;
+    }
     PROF_MARK(4);
     // ---- line search
     const float snorm = sqrtf(wave_sum(search * search));
@@ -623,7 +637,8 @@ __device__ __forceinline__ void stage_solve_cone_impl(const Model& m, const Data
 template <int NVP>
 __device__ __forceinline__ void stage_solve_cone(const Model& m, const Data& d, const int w, const int lane, float* smem) {
   const int rows_with_m = cone_lds_rows(m.size);  // wave-uniform; the common instantiation is the one with M in LDS
-  if (rows_with_m < 0 || d.nefc[w] > rows_with_m) stage_solve_cone_impl<NVP, true>(m, d, w, lane, smem);
+  if (m.opt.solver == MJLAB_SOL_CG) stage_solve_cone_impl<NVP, true, true>(m, d, w, lane, smem);
+  else if (rows_with_m < 0 || d.nefc[w] > rows_with_m) stage_solve_cone_impl<NVP, true>(m, d, w, lane, smem);
   else stage_solve_cone_impl<NVP, false>(m, d, w, lane, smem);
 }
 

@@ -121,8 +121,8 @@ def check_supported(model: Model) -> None:
     raise NotImplementedError("opt.solver must be Newton, CG or PGS")
   if model.opt.cone not in (CONE_PYRAMIDAL, CONE_ELLIPTIC):
     raise NotImplementedError("opt.cone must be pyramidal or elliptic")
-  if model.opt.cone == CONE_ELLIPTIC and model.opt.solver != SOL_NEWTON:
-    raise NotImplementedError("the elliptic cone is implemented for the Newton solver only (pyramidal: Newton, CG, PGS)")
+  if model.opt.cone == CONE_ELLIPTIC and model.opt.solver not in (SOL_NEWTON, SOL_CG):
+    raise NotImplementedError("the elliptic cone is implemented for the Newton and CG solvers (pyramidal: Newton, CG, PGS)")
   if model.opt.cone == CONE_ELLIPTIC and not float(model.opt.impratio) > 0.0:
     raise ValueError("opt.impratio must be positive")
   # (contact friction is clamped at mjMINMU = 1e-5 where the collision stage mixes it, like mj_contactParam: a per-world geom_friction that

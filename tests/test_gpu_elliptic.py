@@ -1,7 +1,7 @@
 """Elliptic friction cones on the device (csrc/stage_cone.h + the ELL instantiation of the constraint stage):
 MujocoCfg(cone="elliptic") (reference sim/sim.py:49,52) as stage kernels and their fused variants, against the CPU restatement (oracle/mjoracle.c), which
 tests/test_oracle_elliptic.py holds to Coulomb's law, the optimality conditions and cone membership.  The cone model is restated from
-MuJoCo's documentation and UNPINNED on both sides; Newton only (the dual solver and CG keep the pyramid)."""
+MuJoCo's documentation and UNPINNED on both sides; Newton and (round 6) CG -- the dual solver keeps the pyramid."""
 
 import copy
 import sys
@@ -364,7 +364,86 @@ def test_elliptic_is_refused_where_it_is_not_carried():
     sim.forward()
   sim._m.opt.flags &= ~_abi.OPT_FUSE_PRESOLVE
   sim.forward()
+  pgs = copy.deepcopy(model)
+  pgs.opt.solver = mjcf.SOL_PGS
+  with pytest.raises(NotImplementedError, match="elliptic"):
+    check_supported(pgs)
   cg = copy.deepcopy(model)
   cg.opt.solver = mjcf.SOL_CG
-  with pytest.raises(NotImplementedError, match="elliptic"):
-    check_supported(cg)
+  check_supported(cg)  # (round 6: CG carries the elliptic cone too -- test_elliptic_cg_*)
+
+
+
+@pytest.mark.parametrize("fuse", ["stage", "step"])
+@pytest.mark.parametrize("name,iterations", [("mixed", 200), ("go1_velocity_flat", 200), ("g1_velocity_flat", 10), ("g1_velocity_flat", 200)])
+def test_elliptic_cg_tracks_the_restatement_and_converges_to_newton(name, iterations, fuse):
+  """MujocoCfg(solver="cg", cone="elliptic") (reference sim/sim.py:49-56 accepts the pair): mj_solPrimal's Polak-Ribiere directions,
+  preconditioned by M, over the cone solver's constraint update and line search.  Device vs the restatement's CG on the same states:
+  at the iteration cap the same iterate as its fp32 build; with enough iterations the NEWTON solution of the elliptic problem (fp64
+  restatement), stationary, forces inside their cones; both launch structures."""
+  import torch
+
+  from mjlab_amd import mjcf
+  from mjlab_amd.sim import Simulation, SimulationCfg
+
+  model = copy.deepcopy(models()[name])
+  model.opt.cone = mjcf.CONE_ELLIPTIC
+  model.opt.impratio = 2.0 if name == "mixed" else 1.0
+  model.opt.solver = mjcf.SOL_CG
+  model.opt.iterations = iterations
+  nworld, nv = 16, model.nv
+  qpos, qvel, ctrl = golden_inputs(model, nworld, 43)
+  sim = Simulation(nworld, SimulationCfg(njmax=300, use_graph=False, ls_parallel=False, fuse=fuse), model, "cuda:0")
+  assert sim.fuse == fuse
+  newton = copy.deepcopy(model)
+  newton.opt.solver, newton.opt.iterations = mjcf.SOL_NEWTON, 50
+  oras = {"cg64": OracleSim(model, nworld, njmax=300, precision="f64", ls_parallel=False), "cg32": OracleSim(model, nworld, njmax=300, precision="f32", ls_parallel=False),
+          "newton": OracleSim(newton, nworld, njmax=300, precision="f64", ls_parallel=False)}
+  for f, v in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl)):
+    getattr(sim.data, f)[:] = torch.from_numpy(v.astype(np.float32)).cuda()
+    for o in oras.values():
+      getattr(o, f)[:] = v.astype(np.float32)
+  sim.data.qacc_warmstart.zero_()
+  sim.forward()
+  for o in oras.values():
+    o.forward(nthread=8)
+  nefc = oras["cg64"].nefc.ravel()
+  assert np.array_equal(_np(sim.data.nefc).ravel(), nefc) and nefc.max() >= 12
+  it_g = _np(sim.data.solver_niter).ravel()
+  assert it_g.max() <= iterations and (it_g > 0).any()
+  qa = _np(sim.data.qacc)
+  busy = nefc > 0
+  if iterations >= 50:
+    e_cg, e_nt = _per_world(qa, oras["cg64"].qacc), _per_world(qa, oras["newton"].qacc)
+    print(f"\n{name} {fuse}: elliptic CG device vs restatement CG median {np.median(e_cg):.2e} max {e_cg.max():.2e}; vs restatement NEWTON median {np.median(e_nt):.2e} max {e_nt.max():.2e}; "
+          f"iterations device {it_g[busy].mean():.1f} restatement fp32 {oras['cg32'].solver_niter.ravel()[busy].mean():.1f} fp64 {oras['cg64'].solver_niter.ravel()[busy].mean():.1f}")
+    # linear convergence + the fp32 noise floor of the termination test (the pyramid's CG test: 1e-2 in the same norm)
+    # -- and the worst world no further from the fp64 iterate than twice what the restatement's OWN fp32 build is (mixed, impratio 2: 1.4e-2)
+    e_ref = _per_world(oras["cg32"].qacc, oras["cg64"].qacc)
+    bound = max(1e-2, 2.0 * float(e_ref.max()))
+    print(f"{name} {fuse}: fp32 restatement vs fp64 restatement max {e_ref.max():.2e}")
+    assert e_cg.max() < bound and e_nt.max() < bound and np.median(e_nt) < 2e-3
+    assert (it_g[busy] < iterations).mean() > 0.7  # converged by the tolerance, not by the cap
+    fo, tg, ig = _np(sim.data.efc_force), _np(sim.data.efc_type), _np(sim.data.efc_id)
+    fric = _np(sim.data.contact_friction).reshape(nworld, -1, 5)
+    for w in np.flatnonzero(busy):
+      n = int(nefc[w])
+      Jw = _np(sim.data.efc_J)[w].reshape(-1, nv)[:n].astype(np.float64)
+      assert np.abs(_np(sim.data.qfrc_constraint)[w] - Jw.T @ fo[w, :n]).max() < 1e-4 * max(1.0, np.abs(fo[w, :n]).max())
+      for r in np.flatnonzero(tg[w, :n] == 7)[::3]:
+        f0, f1, f2 = fo[w, r : r + 3]
+        fr = fric[w, ig[w, r]]
+        assert f0 >= -1e-5 and np.hypot(f1 / fr[0], f2 / fr[1]) <= f0 * (1 + 1e-3) + 1e-4 * max(1.0, abs(f0)), (w, r, f0, f1, f2)
+  else:
+    e32 = _per_world(qa, oras["cg32"].qacc)
+    print(f"\n{name} {fuse}: elliptic CG at the cap of {iterations}: device vs fp32 restatement median {np.median(e32):.2e} max {e32.max():.2e}; at the cap {float((it_g == iterations).mean()):.2f}")
+    assert (oras["cg64"].solver_niter.ravel() == iterations).mean() > 0.3
+    assert e32.max() < 5e-3  # (the pyramid's capped CG: 2e-3 in the relative norm; the same growth along the CG path)
+    return
+  for _ in range(5):
+    sim.step()
+  oras["cg64"].step(5, nthread=8)
+  assert np.isfinite(_np(sim.data.qpos)).all()
+  perr = _per_world(_np(sim.data.qpos), oras["cg64"].qpos)
+  print(f"{name} {fuse}: qpos after 5 steps median {np.median(perr):.2e} max {perr.max():.2e}")
+  assert perr.max() < 3e-3

@@ -215,3 +215,30 @@ def test_grid_line_search_and_fp32_build_agree_with_the_exact_fp64_solve():
   sc = np.abs(ref).max(axis=1)
   assert (np.abs(out[("f64", True)] - ref).max(axis=1) / sc).max() < 1e-6
   assert (np.abs(out[("f32", True)] - ref).max(axis=1) / sc).max() < 2e-4
+
+
+
+def test_cg_with_elliptic_cones_descends_to_the_newton_solution():
+  """mjSOL_CG x mjCONE_ELLIPTIC (reference sim/sim.py:49-56 accepts the pair): the same primal problem, Polak-Ribiere directions
+  preconditioned by M.  A capped run is what it says (the cost falls monotonically, the distance to the minimiser need not), and with
+  enough iterations the iterate is the Newton solution."""
+  from mjlab_amd.mjcf import SOL_CG
+
+  def model(solver=None, it=None):
+    m = robots.mixed_model()
+    m.opt.cone, m.opt.impratio = CONE_ELLIPTIC, 2.0
+    if solver is not None:
+      m.opt.solver, m.opt.iterations = solver, it
+    return m
+
+  ref = OracleSim(model())
+  ref.forward()
+  assert int(ref.nefc[0, 0]) >= 12 and (ref.efc_type[0, : int(ref.nefc[0, 0])] == 7).sum() >= 6
+  errs = []
+  for it in (1, 4, 16, 64, 300):
+    s = OracleSim(model(SOL_CG, it))
+    s.forward()
+    assert s.solver_niter[0, 0] <= it
+    errs.append(np.abs(s.qacc[0] - ref.qacc[0]).max() / np.abs(ref.qacc[0]).max())
+  assert errs[0] > 0.1 and errs[-1] < 2e-4 and errs[-1] < 1e-2 * min(errs[:-2])
+  assert 10 < s.solver_niter[0, 0] < 300  # converged by the tolerance; Newton needs a handful
