@@ -28,7 +28,7 @@ def test_supported_models_pass():
   [
     (lambda m: setattr(m.opt, "solver", 3), "solver"),
     (lambda m: setattr(m.opt, "cone", 2), "cone"),
-    (lambda m: (setattr(m.opt, "cone", 1), setattr(m.opt, "solver", 1)), "elliptic"),
+    (lambda m: (setattr(m.opt, "cone", 1), setattr(m.opt, "solver", 0)), "elliptic"),
     (lambda m: m.jnt_type.__setitem__(2, 1), "ball"),
     (lambda m: m.geom_condim.__setitem__(slice(None), 4), "condim"),
     (lambda m: m.sensor_intprm.__setitem__((0, 0), 3), "found"),
