@@ -101,6 +101,7 @@ class LogBook:
     self.vec = self.raw = self.div = self.scale = None
     self.pub: dict = {}
     self.first = False
+    self._ptrs: list | None = None  # source addresses the launch form's pointer table was built for (_publish_fused)
 
   def publish(self, log: dict, mask: torch.Tensor, count: torch.Tensor | None = None) -> dict:
     """``count``: the number of environments in `mask` as a device float scalar, where the caller has it (the masked sums' last output)."""
@@ -120,6 +121,7 @@ class LogBook:
       self.vec = torch.zeros(len(keys), device=self.device)
       self.raw = torch.zeros(len(keys) + 1, device=self.device)
       self.pub = {k: self.vec[i] for i, k in enumerate(keys)}
+      self._ptrs = None  # (the launch form's tables follow the new vectors at its next call)
       first = True
     if self.world > 1:
       self.raw.copy_(raw)  # finished by the caller after the all-reduce: finish(self.raw, self.first)
@@ -141,7 +143,7 @@ class LogBook:
     if not all(v.is_cuda and v.dtype == torch.float32 for v in vals) or count.dtype != torch.float32 or not count.is_cuda:
       return False
     ptrs = [v.data_ptr() for v in vals]
-    if getattr(self, "_ptrs", None) != ptrs:  # (addresses are part of what a captured launch records: a new table for new addresses)
+    if self._ptrs != ptrs:  # (addresses are part of what a captured launch records: a new table for new addresses)
       if torch.cuda.is_current_stream_capturing():
         return False
       self._ptrs = ptrs

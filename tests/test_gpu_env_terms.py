@@ -625,7 +625,7 @@ def test_log_book_publishes_the_same_numbers_through_the_one_launch():
     if handed is None:
       handed = {k: v.data_ptr() for k, v in a.items()}
     assert {k: v.data_ptr() for k, v in a.items()} == handed
-  assert getattr(books[0], "_ptrs", None) is not None and getattr(books[1], "_ptrs", None) is None  # (the launch was what ran on the first book)
+  assert books[0]._ptrs is not None and books[1]._ptrs is None  # (the launch was what ran on the first book)
 
 
 def test_copy_batch_copies_every_pair():

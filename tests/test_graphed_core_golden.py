@@ -192,7 +192,7 @@ def test_core_captured_as_one_hipgraph_replays_the_reference(scene):
     body()  # (the launch form, its pointer table built outside the capture)
   torch.cuda.current_stream().wait_stream(stream)
   torch.cuda.synchronize()
-  assert getattr(book_log, "_ptrs", None) is not None
+  assert book_log._ptrs is not None
   graph = torch.cuda.CUDAGraph()
   with torch.cuda.graph(graph, stream=stream):
     body()
