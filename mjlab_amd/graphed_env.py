@@ -28,6 +28,10 @@ a static buffer and replays the graph.  What the graph holds:
     ``CommandTerm.reset / compute / _resample`` (managers/command_manager.py:44-66) and ``UniformVelocityCommand``'s
     ``_resample_command`` / ``_update_command`` (tasks/velocity/mdp/velocity_command.py:64-102)
     ``EventManager.apply(mode="interval")`` (managers/event_manager.py:116-138)
+    ANY OTHER function-based reset / interval event term (the reference's stock ``reset_scene_to_default`` and
+    ``apply_external_force_torque``, envs/mdp/events.py:27-171, or a task's own): the reference's function, unmodified, on ALL
+    environments, and what it wrote to mjData kept where the mask is set (``_generic_event``; which arrays it writes is probed at
+    construction, writes to derived arrays or per-world model fields are refused by name: ``_probe_event_writes``)
   On the GPU the four terms that write mjData -- the two reset events, the push, ``UniformVelocityCommand`` -- are ONE HIP launch each
   (mjlab_amd/env_terms.py, include/mjlab_amd.h "environment terms"); all uniforms of a step come from one block drawn once, which
   the torch restatements (CPU runs over the oracle; ``fused_terms=False``) consume the same way.  Either way
@@ -388,11 +392,13 @@ class GraphedRlEnv:
     for mode, names in ev.active_terms.items():
       for name, cfg in zip(names, ev._mode_term_cfgs[mode], strict=True):
         fn = getattr(cfg.func, "__name__", type(cfg.func).__name__)
-        ok = mode == "startup" or (mode == "reset" and fn in SUPPORTED_RESET_EVENTS and cfg.min_step_count_between_reset == 0) \
-          or (mode == "interval" and fn in SUPPORTED_INTERVAL_EVENTS and not cfg.is_global_time)
-        if not ok:
-          raise NotImplementedError(f"event '{name}' ({mode}: {fn}) has no mask-based restatement in GraphedRlEnv")
-        asset = cfg.params.get("asset_cfg") if mode in ("reset", "interval") else None
+        # a function-based reset / interval term without a restatement of its own runs as the reference's function on ALL environments,
+        # what it wrote kept where the mask is set (_generic_event; probed at construction: _probe_event_writes)
+        ok = mode == "startup" or (mode == "reset" and cfg.min_step_count_between_reset == 0) or (mode == "interval" and not cfg.is_global_time)
+        if not ok or (mode in ("reset", "interval") and not callable(cfg.func)):
+          raise NotImplementedError(f"event '{name}' ({mode}: {fn}) has no mask-based form in GraphedRlEnv (min_step_count_between_reset > 0 / global-time intervals)")
+        restated = (mode == "reset" and fn in SUPPORTED_RESET_EVENTS) or (mode == "interval" and fn in SUPPORTED_INTERVAL_EVENTS)
+        asset = cfg.params.get("asset_cfg") if restated else None
         if asset is not None and env.scene[asset.name] is not self._robot:
           raise NotImplementedError(f"event '{name}' acts on entity '{asset.name}': the mask-based events address the entity 'robot' only")
     if any(ev._mode_class_term_cfgs.get(m) for m in ("reset", "interval")):
@@ -428,7 +434,10 @@ class GraphedRlEnv:
     rix = self._robot.indexing
     for index, cfg in enumerate(ev._mode_term_cfgs.get("reset", [])):
       p, fn = cfg.params, cfg.func.__name__
-      if fn == "reset_root_state_uniform":
+      if fn not in SUPPORTED_RESET_EVENTS:
+        cols(("reset", index), 0)
+        self._reset_terms.append(("generic_event", {"cfg": cfg, "writes": self._probe_event_writes(cfg, "reset")}))
+      elif fn == "reset_root_state_uniform":
         cols(("reset", index), 12)
         self._reset_terms.append((fn, {"pose": torch.stack(_range_tensors(p["pose_range"], dev)), "vel": torch.stack(_range_tensors(p["velocity_range"], dev))}))
       else:
@@ -440,6 +449,10 @@ class GraphedRlEnv:
                                        "dev": (None if isinstance(ids, slice) else ids.to(torch.int32), qa.to(torch.int32).contiguous(), va.to(torch.int32).contiguous(),
                                                torch.tensor([*p["position_range"], *p["velocity_range"]], dtype=torch.float32, device=dev))}))
     for index, cfg in enumerate(ev._mode_term_cfgs.get("interval", [])):
+      if cfg.func.__name__ not in SUPPORTED_INTERVAL_EVENTS:  # (vel = the term's cfg, interval = the tensors it writes: _interval_events tells by the type)
+        cols(("interval", index), 1)
+        self._interval_terms.append((index, cfg.interval_range_s, cfg, self._probe_event_writes(cfg, "interval")))
+        continue
       cols(("interval", index), 7)
       self._interval_terms.append((index, cfg.interval_range_s, torch.stack(_range_tensors(cfg.params["velocity_range"], dev)),
                                    torch.tensor(cfg.interval_range_s, dtype=torch.float32, device=dev)))
@@ -1044,6 +1057,55 @@ class GraphedRlEnv:
         return None  # (neither untouched nor a constant fill)
     return out
 
+  # the mjData arrays an event term may write (entity/entity.py write_*_to_sim, entity/data.py:69-168): everything else in mjData is derived
+  _EVENT_WRITABLE = ("qpos", "qvel", "ctrl", "qfrc_applied", "xfrc_applied", "qacc_warmstart", "act", "mocap_pos", "mocap_quat")
+
+  def _probe_event_writes(self, cfg: Any, mode: str) -> list:
+    """Which tensors does a function-based event term write?  Probed once, eagerly, on the environment as it stands: the writable
+    mjData arrays are shifted by a sentinel, the reference's function runs on ALL environments, and every per-world array of mjData and
+    of the model is compared with what it was.  Writes outside ``_EVENT_WRITABLE`` (derived arrays, per-world model fields: domain
+    randomisation at reset) have no masked form here and are refused.  State and the random generators are restored."""
+    env, n = self.env, self.n
+    if not hasattr(self, "_all_ids"):
+      self._all_ids = torch.arange(n, device=self.device)
+    data = {k: t for k, t in env.sim._data.items() if isinstance(t, torch.Tensor) and t.dim() >= 1 and t.shape[0] == n and not k.startswith(("efc_", "contact_"))}
+    view = getattr(env.sim, "_model_view", {})  # (per-world model fields: the ones expand_model_fields made; the others are shared constants)
+    model = {k: view[k] for k in getattr(env.sim, "_expanded", ()) if isinstance(view.get(k), torch.Tensor)}
+    backup = {("d", k): t.clone() for k, t in data.items()} | {("m", k): t.clone() for k, t in model.items()}
+    cpu_rng = torch.get_rng_state()
+    dev_rng = torch.cuda.get_rng_state(self.device) if str(self.device).startswith("cuda") else None
+    self._invalidate()
+    try:
+      for k in self._EVENT_WRITABLE:
+        if k in data and data[k].dtype.is_floating_point:
+          data[k].add_(0.123456)
+      before = {key: (data if key[0] == "d" else model)[key[1]].clone() for key in backup}
+      cfg.func(env, self._all_ids, **cfg.params)
+      changed = [key for key, old in before.items() if not torch.equal((data if key[0] == "d" else model)[key[1]], old)]
+    finally:
+      for key, old in backup.items():
+        (data if key[0] == "d" else model)[key[1]].copy_(old)
+      torch.set_rng_state(cpu_rng)
+      if dev_rng is not None:
+        torch.cuda.set_rng_state(dev_rng, self.device)
+      self._invalidate()
+    bad = [("mjData." if kind == "d" else "model.") + k for kind, k in changed if kind == "m" or k not in self._EVENT_WRITABLE]
+    fn = getattr(cfg.func, "__name__", type(cfg.func).__name__)
+    if bad:
+      raise NotImplementedError(f"event '{fn}' ({mode}) writes {bad}: only {list(self._EVENT_WRITABLE)} have a masked form in GraphedRlEnv")
+    return [data[k] for kind, k in changed]
+
+  def _generic_event(self, mask: torch.Tensor, U: Any, cfg: Any, writes: list) -> None:
+    """An event term without a restatement of its own (the reference's stock ``reset_scene_to_default``, ``apply_external_force_torque``,
+    a task's own function): the reference's function, unmodified, on ALL environments -- static shapes, so a capture takes it; its
+    random draws come from torch's generator as in the reference -- and what it wrote is kept where `mask` is set, put back elsewhere."""
+    saved = [t.clone() for t in writes]
+    self._invalidate()  # (the function reads EntityData as the simulation stands now)
+    cfg.func(self.env, self._all_ids, **cfg.params)
+    for t, old in zip(writes, saved, strict=True):
+      t.copy_(torch.where(mask.reshape((-1,) + (1,) * (t.dim() - 1)), t, old))
+    self._invalidate()
+
   def _masked_reset(self, mask: torch.Tensor) -> None:
     """``_reset_idx`` (:214-249) for the environments of `mask`: the managers' bookkeeping first -- every masked sum the reset logs
     (nothing below changes the summed buffers), then every masked fill (env_core.ResetBookkeeping: two HIP launches on the GPU, the
@@ -1467,6 +1529,12 @@ class GraphedRlEnv:
     for index, (lo, hi), vel, interval in self._interval_terms:
       time_left = ev._interval_term_time_left[index]
       U = self._Uof(("interval", index))  # (n, 7): six velocity draws, the next interval
+      if not isinstance(vel, torch.Tensor):  # a term without a restatement: the manager's timer here, the reference's function on all environments
+        time_left -= self.dt
+        trig = time_left < 1e-6
+        time_left.copy_(torch.where(trig, U[:, 0] * (hi - lo) + lo, time_left))
+        self._generic_event(trig, None, cfg=vel, writes=interval)
+        continue
       if self._fused:
         env_terms.push_by_setting_velocity(d.qvel, self._index_slices(robot)[3][1], time_left, self.dt, interval, robot.data.root_link_vel_w,
                                            robot.data.root_link_quat_w, U, vel)

@@ -452,3 +452,89 @@ def run_tracking(make_env, device: str, num_envs: int = 32, steps: int = 40, cap
   stats["graph"] = g.graph is not None
   stats["relative_rounding"] = getattr(g, "relative_rounding", None)
   return stats
+
+
+def generic_events_edit(cfg):
+  """The velocity task with two of the reference's stock event terms GraphedRlEnv has no restatement for, appended to its events:
+  ``reset_scene_to_default`` (reset mode, LAST: whatever the random reset terms drew, a reset environment ends in the default state --
+  deterministic, so comparable bit for bit) and ``apply_external_force_torque`` (interval mode: random wrenches on every body)."""
+  import dataclasses
+
+  from mjlab.envs.mdp import events as ref_events
+  from mjlab.managers.manager_term_config import EventTermCfg
+
+  _edit(cfg)
+  base = cfg.events
+  extra = [("zz_default", EventTermCfg, dataclasses.field(default_factory=lambda: EventTermCfg(func=ref_events.reset_scene_to_default, mode="reset"))),
+           ("zz_wrench", EventTermCfg, dataclasses.field(default_factory=lambda: EventTermCfg(
+             func=ref_events.apply_external_force_torque, mode="interval", interval_range_s=(0.06, 0.3), params={"force_range": (-5.0, 5.0), "torque_range": (-1.0, 1.0)})))]
+  plus = dataclasses.make_dataclass("EventCfgWithStockTerms", extra, bases=(type(base),))
+  cfg.events = plus(**{f.name: getattr(base, f.name) for f in dataclasses.fields(base)})
+
+
+def run_generic_events(make_env, device: str, num_envs: int = 32, steps: int = 60, capture: bool = True) -> dict:
+  """GraphedRlEnv with event terms it runs through ``_generic_event`` (the reference's function on all environments, kept where the mask
+  is set) against the eager reference, teacher-forced."""
+  torch.manual_seed(0)
+  a = make_env(num_envs, device, generic_events_edit)
+  b = make_env(num_envs, device, generic_events_edit)
+  a.reset()
+  b.reset()
+  g = GraphedRlEnv(b, capture=capture)
+  assert [fn for fn, _ in g._reset_terms].count("generic_event") == 1 and sum(not isinstance(t[2], torch.Tensor) for t in g._interval_terms) == 1
+  gen = torch.Generator(device=device)
+  gen.manual_seed(5)
+  ev = a.event_manager
+  names = ev.active_terms["interval"]
+  ipush, iwrench = names.index("push_robot"), names.index("zz_wrench")
+  cmd_a = a.command_manager.get_term("twist")
+  robot = a.scene["robot"]
+  bodies = robot.indexing.body_ids
+  dt = a.step_dt
+  na = sum(a.action_manager.action_term_dim)
+  stats = {"resets": 0, "wrenches": 0, "default_states_compared": 0, "quiet_env_steps": 0}
+  for k in range(steps):
+    _sync(a, b)
+    action = torch.rand((num_envs, na), device=device, generator=gen) * 2 - 1
+    if k > 20:
+      action[: num_envs // 8] *= 6.0
+    resample = (cmd_a.time_left - dt) <= 0
+    push = (ev._interval_term_time_left[ipush] - dt) < 1e-6
+    wrench = (ev._interval_term_time_left[iwrench] - dt) < 1e-6
+    xfrc_before = a.sim.data.xfrc_applied.clone()
+    _, rew_a, term_a, to_a, _ = a.step(action)
+    _, rew_b, term_b, to_b, _ = g.step(action)
+    if device != "cpu":
+      torch.cuda.synchronize()
+    assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b) and torch.equal(rew_a, rew_b), k
+    reset = term_a | to_a
+    # ---- the reset term run generically: a reset environment ends in the default state on both sides (a push may follow)
+    m = reset & ~push
+    if m.any():
+      for f in ("qpos", "qvel"):
+        assert torch.equal(getattr(a.sim.data, f)[m], getattr(b.sim.data, f)[m]), (k, f)
+      d0 = robot.data.default_root_state[m].clone()
+      d0[:, :3] += a.scene.env_origins[m]
+      assert torch.equal(b.sim.data.qpos[m][:, :7], d0[:, :7]) and torch.equal(b.sim.data.qpos[m][:, 7:], robot.data.default_joint_pos[m])
+      stats["default_states_compared"] += int(m.sum())
+    # ---- the interval term run generically: wrenches in range where its timer ran out, untouched elsewhere
+    for env in (a, b):
+      x = env.sim.data.xfrc_applied[:, bodies]
+      if wrench.any():
+        xw = x[wrench]
+        assert bool((xw[..., :3].abs() <= 5.0).all()) and bool((xw[..., 3:].abs() <= 1.0).all()) and float(xw[..., :3].abs().max()) > 1.0
+        tl = env.event_manager._interval_term_time_left[iwrench][wrench]
+        assert bool((tl >= 0.06 - 1e-6).all()) and bool((tl <= 0.3 + 1e-6).all())
+      keep = ~wrench & ~reset
+      assert torch.equal(env.sim.data.xfrc_applied[keep], xfrc_before[keep]), k
+      clr = reset & ~wrench
+      assert bool((env.sim.data.xfrc_applied[clr] == 0).all())  # (EntityData.clear_state of the reset, no new wrench)
+    if wrench.any():
+      assert not torch.equal(a.sim.data.xfrc_applied[wrench], b.sim.data.xfrc_applied[wrench]), "two independent draws came out identical"
+    assert torch.equal(a.event_manager._interval_term_time_left[iwrench][~wrench], b.event_manager._interval_term_time_left[iwrench][~wrench])
+    quiet = ~(reset | resample | push | wrench)
+    _same_event_bookkeeping(a, b, k)
+    _state_sweep(a, b, quiet, k)
+    stats["resets"] += int(reset.sum()); stats["wrenches"] += int(wrench.sum()); stats["quiet_env_steps"] += int(quiet.sum())
+  stats["graph"] = g.graph is not None
+  return stats

@@ -362,3 +362,41 @@ def test_fused_motion_command_equals_its_torch_restatement(tmp_path):
   # are compared to a tolerance here; bit for bit against the eager reference on identical inputs: test_graphed_tracking_env_matches_the_reference_env)
   assert w["qpos"] <= 2e-6 and w["qvel"] <= 1e-5 and w["body_pos_relative_w"] <= 2e-6 and w["body_quat_relative_w"] <= 2e-6 and w["obs"] <= 1e-4 and w["reward"] <= 1e-5, w
   assert st["relative_rounding"] >= 8, st  # the launch was calibrated (a rounding that reproduces the reference's chain was found), not replaced by the torch chain
+
+
+_GENERIC_EVENTS_GRAPHED = """
+import json, sys
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env, _graphed_check
+def make(n, device, edit):
+  return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=n, device=device, seed=13, cfg_edit=edit)
+st = _graphed_check.run_generic_events(make, "cuda:0", num_envs=128, steps=60, capture=True)
+# a term that writes per-world MODEL fields at reset (domain randomisation in reset mode) has no masked form: refused at construction, by name
+from mjlab_amd.graphed_env import GraphedRlEnv
+def dr_at_reset(cfg):
+  cfg.events.foot_friction.mode = "reset"
+env = make(8, "cuda:0", dr_at_reset)
+env.reset()
+try:
+  GraphedRlEnv(env, capture=False)
+  st["refused"] = ""
+except NotImplementedError as e:
+  st["refused"] = str(e)
+print("RESULT " + json.dumps(st))
+"""
+
+
+def test_graphed_env_with_stock_event_terms_run_generically():
+  """The reference's ``reset_scene_to_default`` (reset) and ``apply_external_force_torque`` (interval) -- stock event terms without a
+  restatement -- inside the captured control step: the reference's own functions on all environments, kept where the mask is set;
+  teacher-forced against the eager reference on the MI355X (tests/_graphed_check.py::run_generic_events)."""
+  import json
+  import subprocess
+
+  code = _GENERIC_EVENTS_GRAPHED.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print("graphed env with generically run event terms vs reference env:", st)
+  assert st["graph"] and st["resets"] >= 100 and st["wrenches"] >= 400 and st["default_states_compared"] >= 80 and st["quiet_env_steps"] >= 1000
+  assert "randomize_field" in st["refused"] and "model.geom_friction" in st["refused"], st["refused"]

@@ -248,3 +248,18 @@ def test_forward_on_the_reset_worlds_only_is_the_reference_on_those_worlds_and_t
     elif not reset.any():
       assert torch.equal(a.sim.data.xpos, b.sim.data.xpos) and torch.equal(oa["critic"], ob["critic"])
   assert seen >= 1
+
+
+def test_stock_event_terms_without_a_restatement_run_generically():
+  """``reset_scene_to_default`` (reset) and ``apply_external_force_torque`` (interval), envs/mdp/events.py:27-171: the reference's
+  functions on all environments, kept where the mask is set -- teacher-forced against the eager reference (the deterministic reset term
+  bit for bit, the random wrenches in range, every untouched environment bit for bit)."""
+  import _graphed_check
+  from _oracle_simulation import OracleSimulation
+
+  def make(n, device, edit):
+    return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=n, device=device, sim_cls=OracleSimulation, seed=13, cfg_edit=edit)
+
+  st = _graphed_check.run_generic_events(make, "cpu", num_envs=32, steps=60, capture=False)
+  print(st)
+  assert st["resets"] >= 32 and st["wrenches"] >= 100 and st["default_states_compared"] >= 20 and st["quiet_env_steps"] >= 100
