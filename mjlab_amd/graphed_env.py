@@ -28,6 +28,10 @@ a static buffer and replays the graph.  What the graph holds:
     ``CommandTerm.reset / compute / _resample`` (managers/command_manager.py:44-66) and ``UniformVelocityCommand``'s
     ``_resample_command`` / ``_update_command`` (tasks/velocity/mdp/velocity_command.py:64-102)
     ``EventManager.apply(mode="interval")`` (managers/event_manager.py:116-138)
+    A COMMAND TERM OF ANY OTHER CLASS (the contract is ``CommandTerm``, managers/command_manager.py:19-84): the manager's part
+    (timer, counter, metrics logging) as for the two above, the term's own ``_update_metrics`` / ``_update_command`` as they are, and
+    its ``_resample_command`` on ALL environments with what it wrote -- its per-environment state, mjData -- kept where the mask is
+    set (``_generic_command_resample``; probed at construction, global state that changes is refused: ``_probe_command_writes``)
     ANY OTHER function-based reset / interval event term (the reference's stock ``reset_scene_to_default`` and
     ``apply_external_force_torque``, envs/mdp/events.py:27-171, or a task's own): the reference's function, unmodified, on ALL
     environments, and what it wrote to mjData kept where the mask is set (``_generic_event``; which arrays it writes is probed at
@@ -102,7 +106,8 @@ def _state_tensors(obj: Any, n: int | None, seen: set, out: list, depth: int = 0
     items = [(obj, k, v) for k, v in obj.items()]
   elif isinstance(obj, (list, tuple)):
     items = [(obj, i, v) for i, v in enumerate(obj)]
-  elif hasattr(obj, "__dict__") and type(obj).__module__.split(".")[0] in ("mjlab", "mjlab_amd", "__main__"):
+  elif hasattr(obj, "__dict__") and any(c.__module__.split(".")[0] in ("mjlab", "mjlab_amd", "__main__") for c in type(obj).__mro__[:-1]):
+    # (an object of the reference's packages, or of a class derived from one of theirs: a task's own CommandTerm subclass)
     items = [(obj, k, v) for k, v in vars(obj).items()]
   for owner, key, v in items:
     if isinstance(v, torch.Tensor):
@@ -403,9 +408,8 @@ class GraphedRlEnv:
           raise NotImplementedError(f"event '{name}' acts on entity '{asset.name}': the mask-based events address the entity 'robot' only")
     if any(ev._mode_class_term_cfgs.get(m) for m in ("reset", "interval")):
       raise NotImplementedError("class-based reset / interval event terms are not supported by GraphedRlEnv")
-    for name in env.command_manager.active_terms:
-      if type(env.command_manager.get_term(name)).__name__ not in SUPPORTED_COMMANDS:
-        raise NotImplementedError(f"command term '{name}' ({type(env.command_manager.get_term(name)).__name__}) has no mask-based restatement")
+    # (a command term of another class runs generically: its own _resample_command on all environments, kept where the mask is set --
+    # _generic_command_resample, probed at construction by _prepare_events)
     for name, cfg in zip(getattr(env.curriculum_manager, "active_terms", []), getattr(env.curriculum_manager, "_term_cfgs", []), strict=False):
       if getattr(cfg.func, "__name__", "") not in SUPPORTED_CURRICULA:
         raise NotImplementedError(f"curriculum term '{name}' ({getattr(cfg.func, '__name__', cfg.func)}) is not supported by GraphedRlEnv")
@@ -465,6 +469,7 @@ class GraphedRlEnv:
       for k, stage in enumerate(cfg.params["velocity_stages"]):
         self._stage_ranges[(name, k)] = torch.tensor(stage["range"], dtype=torch.float32, device=dev)
     self._command_ranges = {}
+    self._generic_commands: dict = {}  # command terms of other classes: id(term) -> the tensors its _resample_command writes (_probe_command_writes)
     # a command whose resampling time exceeds the episode length (the tracking task: 1e9 s) never runs out between two resets: the
     # timed resample of CommandTerm.compute is then a no-op for every environment and is not issued (checked on the timers as they
     # stand: an environment that was never reset keeps the full path)
@@ -480,6 +485,8 @@ class GraphedRlEnv:
       width = 8 if type(term).__name__ != "MotionCommand" else 15 + term.motion.joint_pos.shape[1]
       for phase in ("reset", "compute") + (("update",) if type(term).__name__ == "MotionCommand" else ()):
         cols(("command", name, phase), width)
+      if type(term).__name__ not in SUPPORTED_COMMANDS:
+        self._generic_commands[id(term)] = self._probe_command_writes(name, term)
       if type(term).__name__ == "UniformVelocityCommand":  # ranges as device tensors [lo, hi]: a curriculum may change them inside the graph
         rg = term.cfg.ranges
         table = torch.zeros((4, 2), dtype=torch.float32, device=dev)  # rows lin_vel_x, lin_vel_y, ang_vel_z, heading (the fused term reads it whole)
@@ -1095,6 +1102,53 @@ class GraphedRlEnv:
       raise NotImplementedError(f"event '{fn}' ({mode}) writes {bad}: only {list(self._EVENT_WRITABLE)} have a masked form in GraphedRlEnv")
     return [data[k] for kind, k in changed]
 
+  def _probe_command_writes(self, name: str, term: Any) -> list:
+    """Which tensors does ``term._resample_command`` write?  As _probe_event_writes: the term's per-environment state tensors and the
+    writable mjData arrays, on sentinel-shifted state, everything restored.  State of another shape that changes (global statistics, as
+    the tracking task's sampler keeps) has no masked form here and is refused."""
+    env, n = self.env, self.n
+    if not hasattr(self, "_all_ids"):
+      self._all_ids = torch.arange(n, device=self.device)
+    found: list = []
+    _state_tensors(term, None, set(), found)
+    state = {path: t for _, _, t, path in found if not (t.numel() > 1 and 0 in t.stride())}  # (expanded views of constants are nobody's state)
+    data = {k: t for k, t in env.sim._data.items() if isinstance(t, torch.Tensor) and t.dim() >= 1 and t.shape[0] == n and not k.startswith(("efc_", "contact_"))}
+    every = {("s", k): t for k, t in state.items()} | {("d", k): t for k, t in data.items()}
+    backup = {key: t.clone() for key, t in every.items()}
+    cpu_rng = torch.get_rng_state()
+    dev_rng = torch.cuda.get_rng_state(self.device) if str(self.device).startswith("cuda") else None
+    self._invalidate()
+    try:
+      for key, t in every.items():
+        if t.dtype.is_floating_point and (key[0] == "s" or key[1] in self._EVENT_WRITABLE):
+          t.add_(0.123456)
+      before = {key: t.clone() for key, t in every.items()}
+      term._resample_command(self._all_ids)
+      changed = [key for key, old in before.items() if not torch.equal(every[key], old)]
+    finally:
+      for key, old in backup.items():
+        every[key].copy_(old)
+      torch.set_rng_state(cpu_rng)
+      if dev_rng is not None:
+        torch.cuda.set_rng_state(dev_rng, self.device)
+      self._invalidate()
+    bad = [("mjData." if kind == "d" else "state") + k for kind, k in changed
+           if (kind == "d" and k not in self._EVENT_WRITABLE) or (kind == "s" and not (every[(kind, k)].dim() >= 1 and every[(kind, k)].shape[0] == n))]
+    if bad:
+      raise NotImplementedError(f"command term '{name}' ({type(term).__name__}): _resample_command writes {bad}, which has no masked form in GraphedRlEnv")
+    return [every[key] for key in changed]
+
+  def _generic_command_resample(self, term: Any, mask: torch.Tensor) -> None:
+    """``_resample_command`` of a command term without a restatement: the term's own method on ALL environments, what it wrote (its
+    per-environment state, mjData) kept where `mask` is set."""
+    writes = self._generic_commands[id(term)]
+    saved = [t.clone() for t in writes]
+    self._invalidate()
+    term._resample_command(self._all_ids)
+    for t, old in zip(writes, saved, strict=True):
+      t.copy_(torch.where(mask.reshape((-1,) + (1,) * (t.dim() - 1)), t, old))
+    self._invalidate()
+
   def _generic_event(self, mask: torch.Tensor, U: Any, cfg: Any, writes: list) -> None:
     """An event term without a restatement of its own (the reference's stock ``reset_scene_to_default``, ``apply_external_force_torque``,
     a task's own function): the reference's function, unmodified, on ALL environments -- static shapes, so a capture takes it; its
@@ -1286,7 +1340,10 @@ class GraphedRlEnv:
       self._resample_MotionCommand(term, mask, U, timer=(lo, hi))
       return
     term.time_left.copy_(torch.where(mask, U[:, 0] * (hi - lo) + lo, term.time_left))
-    getattr(self, "_resample_" + type(term).__name__)(term, mask, U)
+    if id(term) in self._generic_commands:
+      self._generic_command_resample(term, mask)
+    else:
+      getattr(self, "_resample_" + type(term).__name__)(term, mask, U)
     term.command_counter += mask.to(term.command_counter.dtype)
 
   def _fused_motion_sampler(self, term: Any) -> bool:
@@ -1315,6 +1372,8 @@ class GraphedRlEnv:
         self._command_resample(term, term.time_left <= 0.0, U)
       if type(term).__name__ == "MotionCommand":
         self._update_MotionCommand(term, self._Uof(("command", name, "update")))
+      elif id(term) in self._generic_commands:
+        term._update_command()  # the reference's own (a term whose update indexes with variable-length id lists fails the capture, loudly)
       else:
         getattr(self, "_update_" + type(term).__name__)(term)
 

@@ -538,3 +538,96 @@ def run_generic_events(make_env, device: str, num_envs: int = 32, steps: int = 6
     stats["resets"] += int(reset.sum()); stats["wrenches"] += int(wrench.sum()); stats["quiet_env_steps"] += int(quiet.sum())
   stats["graph"] = g.graph is not None
   return stats
+
+
+def toy_command_edit(cfg):
+  """The velocity task with its command term replaced by a class GraphedRlEnv has no restatement for: a CommandTerm subclass written
+  here (uniform planar velocity + yaw rate, resampled by ``_resample_command`` with plain tensor indexing; ``_update_command`` clips the
+  yaw rate by the speed -- deterministic), no curriculum on it."""
+  import dataclasses
+
+  from mjlab.managers.command_manager import CommandTerm
+  from mjlab.managers.manager_term_config import CommandTermCfg
+
+  class ToyVelocityCommand(CommandTerm):
+    def __init__(self, cfg, env):
+      super().__init__(cfg, env)
+      self.robot = env.scene["robot"]
+      self.vel_command_b = torch.zeros(self.num_envs, 3, device=self.device)
+      self.metrics["error_vel_xy"] = torch.zeros(self.num_envs, device=self.device)
+
+    @property
+    def command(self):
+      return self.vel_command_b
+
+    def _update_metrics(self):
+      horizon = self.cfg.resampling_time_range[1] / self._env.step_dt
+      self.metrics["error_vel_xy"] += torch.norm(self.vel_command_b[:, :2] - self.robot.data.root_link_lin_vel_b[:, :2], dim=-1) / horizon
+
+    def _resample_command(self, env_ids):
+      r = torch.rand((len(env_ids), 3), device=self.device)
+      self.vel_command_b[env_ids] = r * 2.0 - 1.0
+
+    def _update_command(self):
+      speed = torch.norm(self.vel_command_b[:, :2], dim=-1)
+      self.vel_command_b[:, 2] = torch.minimum(self.vel_command_b[:, 2], 1.2 - speed)
+
+  @dataclasses.dataclass(kw_only=True)
+  class ToyVelocityCommandCfg(CommandTermCfg):
+    class_type: type = ToyVelocityCommand
+
+  _edit(cfg)
+  cfg.commands.twist = ToyVelocityCommandCfg(resampling_time_range=(0.2, 0.5))
+  if getattr(cfg, "curriculum", None) is not None and hasattr(cfg.curriculum, "command_vel"):
+    cfg.curriculum.command_vel = None
+
+
+def run_toy_command(make_env, device: str, num_envs: int = 32, steps: int = 60, capture: bool = True) -> dict:
+  """GraphedRlEnv with a command term of a class it has no restatement for (``_generic_command_resample``) against the eager reference,
+  teacher-forced: untouched environments bit for bit over every state tensor, resampled ones in range, the deterministic update bit for bit."""
+  torch.manual_seed(0)
+  a = make_env(num_envs, device, toy_command_edit)
+  b = make_env(num_envs, device, toy_command_edit)
+  a.reset()
+  b.reset()
+  g = GraphedRlEnv(b, capture=capture)
+  cmd_a, cmd_b = a.command_manager.get_term("twist"), b.command_manager.get_term("twist")
+  assert type(cmd_b).__name__ == "ToyVelocityCommand" and id(cmd_b) in g._generic_commands and len(g._generic_commands[id(cmd_b)]) == 1
+  gen = torch.Generator(device=device)
+  gen.manual_seed(6)
+  ev = a.event_manager
+  dt = a.step_dt
+  na = sum(a.action_manager.action_term_dim)
+  stats = {"resets": 0, "resamples": 0, "quiet_env_steps": 0}
+  for k in range(steps):
+    _sync(a, b)
+    action = torch.rand((num_envs, na), device=device, generator=gen) * 2 - 1
+    if k > 20:
+      action[: num_envs // 8] *= 6.0
+    resample = (cmd_a.time_left - dt) <= 0
+    push = (ev._interval_term_time_left[0] - dt) < 1e-6
+    counter_before = cmd_a.command_counter.clone()
+    obs_a, rew_a, term_a, to_a, _ = a.step(action)
+    obs_b, rew_b, term_b, to_b, _ = g.step(action)
+    if device != "cpu":
+      torch.cuda.synchronize()
+    assert torch.equal(term_a, term_b) and torch.equal(to_a, to_b) and torch.equal(rew_a, rew_b), k
+    reset = term_a | to_a
+    _same_logs(a, b, k, reset)
+    drew = reset | resample
+    for c in (cmd_a, cmd_b):
+      v = c.command
+      assert bool((v[:, :2].abs() <= 1.0).all()) and bool((v[:, 2] <= 1.2 - torch.norm(v[:, :2], dim=-1) + 1e-6).all())
+      assert bool((c.time_left[drew] >= 0.2 - dt - 1e-6).all()) and bool((c.time_left[drew] <= 0.5 + 1e-6).all())
+    assert torch.equal(cmd_a.command_counter, cmd_b.command_counter)
+    assert torch.equal(cmd_b.command_counter[~reset], (counter_before + resample.to(counter_before.dtype))[~reset]) and bool((cmd_b.command_counter[reset] == 1).all())
+    if drew.any():
+      assert not torch.equal(cmd_a.command[drew], cmd_b.command[drew]), "two independent draws came out identical"
+    quiet = ~(reset | resample | push)
+    for grp in obs_a:
+      assert torch.equal(obs_a[grp][quiet], obs_b[grp][quiet]), (k, grp)
+    _same_event_bookkeeping(a, b, k)
+    _state_sweep(a, b, quiet, k)
+    stats["resets"] += int(reset.sum()); stats["resamples"] += int((resample & ~reset).sum()); stats["quiet_env_steps"] += int(quiet.sum())
+  stats["graph"] = g.graph is not None
+  return stats

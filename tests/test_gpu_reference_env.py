@@ -400,3 +400,27 @@ def test_graphed_env_with_stock_event_terms_run_generically():
   print("graphed env with generically run event terms vs reference env:", st)
   assert st["graph"] and st["resets"] >= 100 and st["wrenches"] >= 400 and st["default_states_compared"] >= 80 and st["quiet_env_steps"] >= 1000
   assert "randomize_field" in st["refused"] and "model.geom_friction" in st["refused"], st["refused"]
+
+
+_TOY_COMMAND_GRAPHED = """
+import json, sys
+sys.path.insert(0, {tools!r}); sys.path.insert(0, {tests!r})
+import reference_env, _graphed_check
+def make(n, device, edit):
+  return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=n, device=device, seed=17, cfg_edit=edit)
+print("RESULT " + json.dumps(_graphed_check.run_toy_command(make, "cuda:0", num_envs=128, steps=60, capture=True)))
+"""
+
+
+def test_graphed_env_with_a_command_term_of_another_class():
+  """A CommandTerm subclass without a restatement inside the captured control step (``_generic_command_resample``: the term's own
+  ``_resample_command`` on all environments, kept where the mask is set), teacher-forced against the eager reference on the MI355X."""
+  import json
+  import subprocess
+
+  code = _TOY_COMMAND_GRAPHED.format(tools=str(ROOT / "tools"), tests=str(ROOT / "tests"))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+  assert r.returncode == 0, r.stderr[-3000:]
+  st = json.loads(next(line for line in r.stdout.splitlines() if line.startswith("RESULT "))[7:])
+  print("graphed env with a generically run command term vs reference env:", st)
+  assert st["graph"] and st["resets"] >= 100 and st["resamples"] >= 200 and st["quiet_env_steps"] >= 1000

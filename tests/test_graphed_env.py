@@ -263,3 +263,17 @@ def test_stock_event_terms_without_a_restatement_run_generically():
   st = _graphed_check.run_generic_events(make, "cpu", num_envs=32, steps=60, capture=False)
   print(st)
   assert st["resets"] >= 32 and st["wrenches"] >= 100 and st["default_states_compared"] >= 20 and st["quiet_env_steps"] >= 100
+
+
+def test_command_term_of_another_class_runs_generically():
+  """A CommandTerm subclass GraphedRlEnv has no restatement for (managers/command_manager.py:19-84 is its whole contract): its own
+  ``_resample_command`` on all environments, kept where the mask is set; ``_update_metrics`` / ``_update_command`` as they are."""
+  import _graphed_check
+  from _oracle_simulation import OracleSimulation
+
+  def make(n, device, edit):
+    return reference_env.make_env("Mjlab-Velocity-Flat-Unitree-G1", num_envs=n, device=device, sim_cls=OracleSimulation, seed=17, cfg_edit=edit)
+
+  st = _graphed_check.run_toy_command(make, "cpu", num_envs=32, steps=60, capture=False)
+  print(st)
+  assert st["resets"] >= 32 and st["resamples"] >= 60 and st["quiet_env_steps"] >= 300
