@@ -1067,63 +1067,30 @@ class GraphedRlEnv:
   # the mjData arrays an event term may write (entity/entity.py write_*_to_sim, entity/data.py:69-168): everything else in mjData is derived
   _EVENT_WRITABLE = ("qpos", "qvel", "ctrl", "qfrc_applied", "xfrc_applied", "qacc_warmstart", "act", "mocap_pos", "mocap_quat")
 
-  def _probe_event_writes(self, cfg: Any, mode: str) -> list:
-    """Which tensors does a function-based event term write?  Probed once, eagerly, on the environment as it stands: the writable
-    mjData arrays are shifted by a sentinel, the reference's function runs on ALL environments, and every per-world array of mjData and
-    of the model is compared with what it was.  Writes outside ``_EVENT_WRITABLE`` (derived arrays, per-world model fields: domain
-    randomisation at reset) have no masked form here and are refused.  State and the random generators are restored."""
+  def _probe_writes(self, call: Any, state: dict, what: str) -> list:
+    """Which tensors does ``call()`` -- a reference function run on ALL environments -- write?  Probed once, eagerly, on the environment
+    as it stands: the writable mjData arrays and the given `state` tensors are shifted by a sentinel (a write of the value that was
+    there would go unseen), ``call()`` runs, and every per-world array of mjData, every per-world model field and every `state`
+    tensor is compared with what it was.  Only per-environment state and ``_EVENT_WRITABLE`` have a masked form (``torch.where`` over
+    the rows): writes to derived mjData arrays, to per-world MODEL fields (domain randomisation at reset) or to state of another shape
+    (global statistics) are refused by name.  State and the random generators are restored."""
     env, n = self.env, self.n
     if not hasattr(self, "_all_ids"):
       self._all_ids = torch.arange(n, device=self.device)
     data = {k: t for k, t in env.sim._data.items() if isinstance(t, torch.Tensor) and t.dim() >= 1 and t.shape[0] == n and not k.startswith(("efc_", "contact_"))}
     view = getattr(env.sim, "_model_view", {})  # (per-world model fields: the ones expand_model_fields made; the others are shared constants)
     model = {k: view[k] for k in getattr(env.sim, "_expanded", ()) if isinstance(view.get(k), torch.Tensor)}
-    backup = {("d", k): t.clone() for k, t in data.items()} | {("m", k): t.clone() for k, t in model.items()}
-    cpu_rng = torch.get_rng_state()
-    dev_rng = torch.cuda.get_rng_state(self.device) if str(self.device).startswith("cuda") else None
-    self._invalidate()
-    try:
-      for k in self._EVENT_WRITABLE:
-        if k in data and data[k].dtype.is_floating_point:
-          data[k].add_(0.123456)
-      before = {key: (data if key[0] == "d" else model)[key[1]].clone() for key in backup}
-      cfg.func(env, self._all_ids, **cfg.params)
-      changed = [key for key, old in before.items() if not torch.equal((data if key[0] == "d" else model)[key[1]], old)]
-    finally:
-      for key, old in backup.items():
-        (data if key[0] == "d" else model)[key[1]].copy_(old)
-      torch.set_rng_state(cpu_rng)
-      if dev_rng is not None:
-        torch.cuda.set_rng_state(dev_rng, self.device)
-      self._invalidate()
-    bad = [("mjData." if kind == "d" else "model.") + k for kind, k in changed if kind == "m" or k not in self._EVENT_WRITABLE]
-    fn = getattr(cfg.func, "__name__", type(cfg.func).__name__)
-    if bad:
-      raise NotImplementedError(f"event '{fn}' ({mode}) writes {bad}: only {list(self._EVENT_WRITABLE)} have a masked form in GraphedRlEnv")
-    return [data[k] for kind, k in changed]
-
-  def _probe_command_writes(self, name: str, term: Any) -> list:
-    """Which tensors does ``term._resample_command`` write?  As _probe_event_writes: the term's per-environment state tensors and the
-    writable mjData arrays, on sentinel-shifted state, everything restored.  State of another shape that changes (global statistics, as
-    the tracking task's sampler keeps) has no masked form here and is refused."""
-    env, n = self.env, self.n
-    if not hasattr(self, "_all_ids"):
-      self._all_ids = torch.arange(n, device=self.device)
-    found: list = []
-    _state_tensors(term, None, set(), found)
-    state = {path: t for _, _, t, path in found if not (t.numel() > 1 and 0 in t.stride())}  # (expanded views of constants are nobody's state)
-    data = {k: t for k, t in env.sim._data.items() if isinstance(t, torch.Tensor) and t.dim() >= 1 and t.shape[0] == n and not k.startswith(("efc_", "contact_"))}
-    every = {("s", k): t for k, t in state.items()} | {("d", k): t for k, t in data.items()}
+    every = {("mjData.", k): t for k, t in data.items()} | {("model.", k): t for k, t in model.items()} | {("state", k): t for k, t in state.items()}
     backup = {key: t.clone() for key, t in every.items()}
     cpu_rng = torch.get_rng_state()
     dev_rng = torch.cuda.get_rng_state(self.device) if str(self.device).startswith("cuda") else None
     self._invalidate()
     try:
-      for key, t in every.items():
-        if t.dtype.is_floating_point and (key[0] == "s" or key[1] in self._EVENT_WRITABLE):
+      for (kind, k), t in every.items():
+        if t.dtype.is_floating_point and (kind == "state" or (kind == "mjData." and k in self._EVENT_WRITABLE)):
           t.add_(0.123456)
       before = {key: t.clone() for key, t in every.items()}
-      term._resample_command(self._all_ids)
+      call()
       changed = [key for key, old in before.items() if not torch.equal(every[key], old)]
     finally:
       for key, old in backup.items():
@@ -1132,11 +1099,23 @@ class GraphedRlEnv:
       if dev_rng is not None:
         torch.cuda.set_rng_state(dev_rng, self.device)
       self._invalidate()
-    bad = [("mjData." if kind == "d" else "state") + k for kind, k in changed
-           if (kind == "d" and k not in self._EVENT_WRITABLE) or (kind == "s" and not (every[(kind, k)].dim() >= 1 and every[(kind, k)].shape[0] == n))]
+    per_env = lambda t: t.dim() >= 1 and t.shape[0] == n  # noqa: E731
+    bad = [kind + k for kind, k in changed if kind == "model." or (kind == "mjData." and k not in self._EVENT_WRITABLE) or (kind == "state" and not per_env(every[(kind, k)]))]
     if bad:
-      raise NotImplementedError(f"command term '{name}' ({type(term).__name__}): _resample_command writes {bad}, which has no masked form in GraphedRlEnv")
+      raise NotImplementedError(f"{what} writes {bad}: only per-environment state and mjData's {list(self._EVENT_WRITABLE)} have a masked form in GraphedRlEnv")
     return [every[key] for key in changed]
+
+  def _probe_event_writes(self, cfg: Any, mode: str) -> list:
+    """The tensors a function-based event term writes (``_probe_writes`` of the reference's function on all environments)."""
+    fn = getattr(cfg.func, "__name__", type(cfg.func).__name__)
+    return self._probe_writes(lambda: cfg.func(self.env, self._all_ids, **cfg.params), {}, f"event '{fn}' ({mode})")
+
+  def _probe_command_writes(self, name: str, term: Any) -> list:
+    """The tensors ``term._resample_command`` writes: the term's own state (per environment, or refused) and mjData."""
+    found: list = []
+    _state_tensors(term, None, set(), found)
+    state = {path: t for _, _, t, path in found if not (t.numel() > 1 and 0 in t.stride())}  # (expanded views of constants are nobody's state)
+    return self._probe_writes(lambda: term._resample_command(self._all_ids), state, f"command term '{name}' ({type(term).__name__}): _resample_command")
 
   def _generic_command_resample(self, term: Any, mask: torch.Tensor) -> None:
     """``_resample_command`` of a command term without a restatement: the term's own method on ALL environments, what it wrote (its
