@@ -372,7 +372,7 @@ int mjlab_masked_fill_rows(const mjlab_fill_entry_t* entries, int nentries, cons
 int mjlab_masked_sums(const mjlab_sum_entry_t* entries, int k, const unsigned char* mask, int nworld, float* out, void* stream) {
   if (!mask || !out || (k > 0 && !entries)) return fail(-22, "masked_sums: null argument");
   if (k < 0 || nworld < 1) return fail(-22, "masked_sums: bad sizes");
-  hipLaunchKernelGGL(k_masked_sums, dim3(k + 1), dim3(64), 0, (hipStream_t)stream, entries, k, mask, nworld, out);
+  hipLaunchKernelGGL(k_masked_sums, dim3(k + 1), dim3(256), 0, (hipStream_t)stream, entries, k, mask, nworld, out);
   return launched("k_masked_sums launch failed");
 }
 int mjlab_reward_accumulate(const float* values, const float* weights, const int* columns, int k, int nworld, float dt, float* reward,
